@@ -1,0 +1,311 @@
+/*
+ * ovgpu.h — C ABI of the MI355X-native MSCKF / SLAM EKF feature-update path.
+ *
+ * This is the drop-in boundary.  Everything that crosses it is
+ * plain-old-data: flat arrays, sizes and status codes.  The functions declared
+ * here are what a binding inside rpng/open_vins (the C++ shim under
+ * open_vins_amd/shim/) calls in place of the reference's
+ * Eigen code.  Each entry point cites the reference interface it replaces
+ * (paths relative to the open_vins checkout, v2.7).
+ *
+ * Conventions
+ *   - all matrices are row-major, IEEE double unless stated (pixel
+ *     measurements are float, exactly as ov_core::Feature stores them,
+ *     ov_core/src/feat/Feature.h:49-55);
+ *   - quaternions are JPL, stored (x,y,z,w) (ov_core/src/utils/quat_ops.h);
+ *   - every function returns an ovgpu_status (0 = OK); nothing exits the
+ *     process (the reference's std::exit on a negative covariance diagonal,
+ *     ov_msckf/src/state/StateHelper.cpp:172-182, becomes
+ *     OVGPU_ERR_NEGATIVE_DIAGONAL);
+ *   - buffers are owned by the caller; the context owns its device memory;
+ *   - a context is bound to one HIP device and is not re-entrant, matching the
+ *     reference's single-threaded update path (SURVEY.md §8b "Threading").
+ */
+#ifndef OVGPU_H
+#define OVGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------- */
+/* status codes                                                              */
+/* ------------------------------------------------------------------------- */
+typedef enum {
+  OVGPU_OK = 0,
+  OVGPU_ERR_INVALID = 1,           /* bad argument / size                    */
+  OVGPU_ERR_NO_DEVICE = 2,         /* no HIP device / extension unusable     */
+  OVGPU_ERR_HIP = 3,               /* a HIP runtime call failed              */
+  OVGPU_ERR_NEGATIVE_DIAGONAL = 4, /* StateHelper.cpp:172-182                */
+  OVGPU_ERR_NOT_SPD = 5,           /* Cholesky of S broke down               */
+  OVGPU_ERR_CAPACITY = 6,          /* more clones/cams/measurements than ctx */
+  OVGPU_ERR_NO_STATE = 7           /* ovgpu_set_state was never called       */
+} ovgpu_status;
+
+/* per-feature outcome (what the reference expresses by erasing the feature
+ * from feature_vec and setting to_delete, UpdaterMSCKF.cpp:88-90,136-139,
+ * 225-227)                                                                   */
+typedef enum {
+  OVGPU_FEAT_USED = 0,           /* accepted, stacked into the update        */
+  OVGPU_FEAT_TOO_FEW_MEAS = 1,   /* < 2 measurements after cleaning (:87)    */
+  OVGPU_FEAT_TRI_FAILED = 2,     /* single_triangulation returned false      */
+  OVGPU_FEAT_GN_FAILED = 3,      /* single_gaussnewton returned false        */
+  OVGPU_FEAT_CHI2_REJECTED = 4   /* chi2 > chi2_multipler * table (:225)     */
+} ovgpu_feat_status;
+
+/* ov_type::LandmarkRepresentation::Representation
+ * (ov_core/src/types/LandmarkRepresentation.h:38-46), same numeric values    */
+typedef enum {
+  OVGPU_REP_GLOBAL_3D = 0,
+  OVGPU_REP_GLOBAL_FULL_INVERSE_DEPTH = 1,
+  OVGPU_REP_ANCHORED_3D = 2,
+  OVGPU_REP_ANCHORED_FULL_INVERSE_DEPTH = 3,
+  OVGPU_REP_ANCHORED_MSCKF_INVERSE_DEPTH = 4,
+  OVGPU_REP_ANCHORED_INVERSE_DEPTH_SINGLE = 5
+} ovgpu_feat_rep;
+
+/* ------------------------------------------------------------------------- */
+/* options: UpdaterOptions (ov_msckf/src/update/UpdaterOptions.h:32-48),      */
+/* FeatureInitializerOptions (ov_core/src/feat/FeatureInitializerOptions.h:   */
+/* 33-69) and the StateOptions subset the path reads                          */
+/* (ov_msckf/src/state/StateOptions.h:35-92).  Defaults = the reference's.    */
+/* ------------------------------------------------------------------------- */
+typedef struct {
+  /* UpdaterOptions */
+  double chi2_multipler; /* (sic) reference spelling, default 5              */
+  double sigma_pix;      /* default 1                                        */
+  /* FeatureInitializerOptions */
+  int32_t triangulate_1d;  /* default 0 */
+  int32_t refine_features; /* default 1 */
+  int32_t max_runs;        /* default 5 */
+  int32_t _pad0;
+  double init_lamda;      /* 1e-3 */
+  double max_lamda;       /* 1e10 */
+  double min_dx;          /* 1e-6 */
+  double min_dcost;       /* 1e-6 */
+  double lam_mult;        /* 10   */
+  double min_dist;        /* 0.10 */
+  double max_dist;        /* 60   */
+  double max_baseline;    /* 40   */
+  double max_cond_number; /* 10000 */
+  /* StateOptions subset */
+  int32_t do_fej;                     /* use_fej                            */
+  int32_t do_calib_camera_pose;       /* calib_cam_extrinsics               */
+  int32_t do_calib_camera_intrinsics; /* calib_cam_intrinsics               */
+  int32_t feat_rep_msckf;             /* ovgpu_feat_rep                     */
+} ovgpu_options;
+
+/* Fills *o with the reference defaults. */
+void ovgpu_default_options(ovgpu_options *o);
+
+/* ------------------------------------------------------------------------- */
+/* state snapshot: what UpdaterMSCKF::update reads out of ov_msckf::State     */
+/* (ov_msckf/src/state/State.h:137-192).  The clone table is ordered by the   */
+/* caller (normally ascending timestamp = iteration order of _clones_IMU).    */
+/* ------------------------------------------------------------------------- */
+typedef struct {
+  int32_t N;               /* dim of the covariance (State::_Cov)           */
+  int32_t C;               /* number of IMU clones in the window            */
+  int32_t K;               /* number of cameras                             */
+  int32_t _pad0;
+  const double *P;             /* [N*N] row-major covariance                */
+  const double *clone_q_p;     /* [C*7] q_GtoI (JPL xyzw), p_IinG  (value)  */
+  const double *clone_q_p_fej; /* [C*7] first-estimate values (PoseJPL fej) */
+  const int32_t *clone_cov_id; /* [C]   Type::id() of each clone (6 dof)    */
+  const double *calib_q_p;     /* [K*7] q_ItoC, p_IinC                      */
+  const double *intrinsics;    /* [K*8] fx fy cx cy d0 d1 d2 d3             */
+  const uint8_t *cam_is_fisheye; /* [K] 0 = CamRadtan, 1 = CamEqui          */
+  const int32_t *calib_cov_id; /* [K] id of the 6-dof extrinsic, -1 if none */
+  const int32_t *intr_cov_id;  /* [K] id of the 8-dof intrinsics, -1 if none*/
+} ovgpu_state_view;
+
+/* ------------------------------------------------------------------------- */
+/* feature tracks, flattened (ov_core::Feature, Feature.h:39-98).             */
+/* Measurements of feature f are meas_offsets[f] .. meas_offsets[f+1]-1.      */
+/* Inside a feature they MUST be grouped by camera in the iteration order of  */
+/* Feature::timestamps and in time order inside a camera: the anchor rule of  */
+/* FeatureInitializer.cpp:36-46 (first camera group with strictly most        */
+/* measurements, last measurement of that group) is evaluated on this order.  */
+/* clone_idx is the index into the clone table (the result of                 */
+/* Feature::clean_old_measurements, Feature.cpp:26-53, done by the caller).   */
+/* ------------------------------------------------------------------------- */
+typedef struct {
+  int32_t F; /* number of features                                        */
+  int32_t M; /* total number of measurements = meas_offsets[F]            */
+  const int32_t *meas_offsets; /* [F+1]                                   */
+  const float *uv;             /* [2*M] raw pixel (Feature::uvs)          */
+  const float *uvn;            /* [2*M] normalized (Feature::uvs_norm)    */
+  const int32_t *clone_idx;    /* [M]                                     */
+  const int32_t *cam_idx;      /* [M]                                     */
+} ovgpu_features_view;
+
+/* ------------------------------------------------------------------------- */
+/* results of one MSCKF update                                                */
+/* ------------------------------------------------------------------------- */
+typedef struct {
+  int32_t n_used;      /* features stacked into the update                  */
+  int32_t n_rows;      /* rows of Hx_big before compression (ct_meas)       */
+  int32_t D;           /* columns of the stacked Jacobian (canonical order) */
+  int32_t n_rows_comp; /* rows after measurement compression                */
+  int32_t status;      /* ovgpu_status of the EKF step                      */
+  int32_t _pad0;
+  /* device-side stage times in ms (same five stages the reference prints,
+   * UpdaterMSCKF.cpp:289-294), 0 when timing is disabled                   */
+  float ms_triangulate;
+  float ms_system;
+  float ms_compress;
+  float ms_update;
+  float ms_total;
+  float _pad1;
+} ovgpu_update_stats;
+
+typedef struct ovgpu_ctx ovgpu_ctx;
+
+/* ------------------------------------------------------------------------- */
+/* life cycle                                                                */
+/* ------------------------------------------------------------------------- */
+
+/* Creates a context on HIP device `device`.  Replaces the constructors
+ * ov_msckf::UpdaterMSCKF::UpdaterMSCKF (UpdaterMSCKF.cpp:42-56: stores the
+ * options, builds the FeatureInitializer and the chi2 table for dof 1..499)
+ * and ov_core::FeatureInitializer::FeatureInitializer
+ * (FeatureInitializer.h:88).  Fails with OVGPU_ERR_NO_DEVICE when no GPU is
+ * present: there is no CPU fallback.                                         */
+int ovgpu_create(const ovgpu_options *opts, int device, ovgpu_ctx **out);
+void ovgpu_destroy(ovgpu_ctx *ctx);
+
+/* Last HIP / library error text for this thread (never NULL). */
+const char *ovgpu_last_error(void);
+
+/* 0.95 chi-square quantile for `dof` degrees of freedom — the table entry the
+ * reference gets from boost::math::quantile(chi_squared(dof), 0.95)
+ * (UpdaterMSCKF.cpp:52-55, :219-220).  Host-side, no GPU needed.             */
+double ovgpu_chi2_quantile_95(int dof);
+
+/* Uploads the state snapshot (covariance, clone / calibration tables) and
+ * builds the clone-camera pose table of UpdaterMSCKF.cpp:97-115
+ * (R_GtoCi = R_ItoC R_GtoIi, p_CiinG = p_IiinG - R_GtoCi^T p_IinC).
+ * The data stay resident in HBM until the next ovgpu_set_state.              */
+int ovgpu_set_state(ovgpu_ctx *ctx, const ovgpu_state_view *st);
+
+/* Uploads a batch of feature tracks (host pointers) and keeps it resident.   */
+int ovgpu_set_features(ovgpu_ctx *ctx, const ovgpu_features_view *fv);
+
+/* ------------------------------------------------------------------------- */
+/* ov_core::FeatureInitializer                                               */
+/* ------------------------------------------------------------------------- */
+
+/* Runs single_triangulation / single_triangulation_1d
+ * (FeatureInitializer.cpp:30-112 / :114-195) followed, when
+ * refine_features is set, by single_gaussnewton (:197-375) on every resident
+ * feature, exactly the loop of UpdaterMSCKF.cpp:117-142.
+ *   p_FinA, p_FinG   [3*F]  Feature::p_FinA / p_FinG
+ *   anchor_meas      [F]    index (into the flat measurement arrays) of the
+ *                           anchor measurement: its cam_idx / clone_idx are
+ *                           Feature::anchor_cam_id / anchor_clone_timestamp
+ *   status           [F]    OVGPU_FEAT_USED (= success so far),
+ *                           _TOO_FEW_MEAS, _TRI_FAILED or _GN_FAILED
+ * All outputs are host pointers; any may be NULL.                            */
+int ovgpu_triangulate(ovgpu_ctx *ctx, double *p_FinA, double *p_FinG,
+                      int32_t *anchor_meas, int32_t *status);
+
+/* ------------------------------------------------------------------------- */
+/* ov_msckf::UpdaterMSCKF::update  (UpdaterMSCKF.cpp:58-295)                  */
+/* ------------------------------------------------------------------------- */
+
+/* Mode B (whole update on the GPU): triangulate + refine, build and
+ * nullspace-project every feature's Jacobian, chi2-gate against the prior,
+ * compress the stacked system, and apply StateHelper::EKFUpdate
+ * (StateHelper.cpp:116-197).  Operates on the resident state and features.
+ *   feat_status [F]     ovgpu_feat_status per feature (NULL ok)
+ *   chi2        [F]     gate statistic, NaN when the gate was not reached
+ *   chi2_thresh [F]     chi2_multipler * table[rows]
+ *   p_FinG      [3*F]   triangulated positions (Feature::p_FinG)
+ *   dx          [N]     correction vector K*res (the caller applies
+ *                       Type::update to variables the GPU does not hold)
+ *   P_out       [N*N]   updated covariance
+ * The resident covariance, clone and calibration tables are updated in place
+ * (box-plus of JPLQuat.h:114-125 / PoseJPL.h:74-91 / Vec.h:55-58), FEJ values
+ * untouched, so a following call sees the posterior, as VioManager's
+ * successive updater calls do (VioManager.cpp:525-547).                      */
+int ovgpu_msckf_update(ovgpu_ctx *ctx, int32_t *feat_status, double *chi2,
+                       double *chi2_thresh, double *p_FinG, double *dx,
+                       double *P_out, ovgpu_update_stats *stats);
+
+/* Mode A (strict drop-in): same pipeline up to and including
+ * UpdaterHelper::measurement_compress_inplace (UpdaterHelper.cpp:456-487) and
+ * returns the compressed system so that the caller feeds the stock
+ * StateHelper::EKFUpdate.
+ *   D_out          number of columns
+ *   col_cov_id [D] covariance index of every column of H (canonical order)
+ *   H   [rows*D]   compressed Jacobian (upper-triangular when rows == D)
+ *   r   [rows]     compressed residual
+ *   rows_out       min(ct_meas, D)
+ * H, r, col_cov_id must hold Dmax = 6*C + 14*K columns / rows.               */
+int ovgpu_msckf_compress(ovgpu_ctx *ctx, int32_t *feat_status, double *chi2,
+                         double *chi2_thresh, double *p_FinG, int32_t *D_out,
+                         int32_t *rows_out, int32_t *col_cov_id, double *H,
+                         double *r, ovgpu_update_stats *stats);
+
+/* Reads back the resident posterior tables after ovgpu_msckf_update.
+ * Any pointer may be NULL.  Sizes as in ovgpu_state_view.                    */
+int ovgpu_get_state(ovgpu_ctx *ctx, double *P, double *clone_q_p,
+                    double *calib_q_p, double *intrinsics);
+
+/* ------------------------------------------------------------------------- */
+/* feature-sharded multi-GPU update                           */
+/* ------------------------------------------------------------------------- */
+
+/* Number of doubles of one rank's compressed triangle [R | Q^T r]:
+ * Dmax * (Dmax + 1) with Dmax = 6*C + 14*K of the resident state.            */
+int ovgpu_triangle_len(ovgpu_ctx *ctx, int64_t *n_doubles);
+
+/* Stage 1 on every rank: everything of ovgpu_msckf_update up to the local
+ * compression of this rank's feature shard; the local triangle stays in HBM.
+ * `tri_dev` (DEVICE pointer, ovgpu_triangle_len doubles, may be NULL)
+ * receives a copy so that the caller can hand it to RCCL
+ * (torch.distributed.all_gather_into_tensor).                                */
+int ovgpu_msckf_local(ovgpu_ctx *ctx, int32_t *feat_status, double *chi2,
+                      double *chi2_thresh, double *p_FinG, void *tri_dev,
+                      ovgpu_update_stats *stats);
+
+/* Stage 2: `tris_dev` (DEVICE pointer) holds G gathered triangles; they are
+ * re-compressed by one more QR (QR of stacked R factors = R of the full
+ * stack) and the EKF update is applied to the resident state.  Every rank
+ * calls it with identical data and obtains identical dx / P_out.             */
+int ovgpu_msckf_merge_update(ovgpu_ctx *ctx, const void *tris_dev, int G,
+                             double *dx, double *P_out,
+                             ovgpu_update_stats *stats);
+
+/* ------------------------------------------------------------------------- */
+/* benchmarking hooks                                                         */
+/* ------------------------------------------------------------------------- */
+
+/* Re-uploads the prior (covariance + pose tables) saved by the last
+ * ovgpu_set_state from a device-side copy, so that repeated timed updates all
+ * start from the same prior with inputs already resident in HBM.             */
+int ovgpu_reset_state(ovgpu_ctx *ctx);
+
+/* Enqueues one complete update (as ovgpu_msckf_update) on the context's
+ * stream without any host read-back or synchronisation.                      */
+int ovgpu_msckf_update_async(ovgpu_ctx *ctx);
+
+/* Blocks until the context's stream is idle. */
+int ovgpu_synchronize(ovgpu_ctx *ctx);
+
+/* hipStream_t of the context, as an integer (for hipEvent timing). */
+uint64_t ovgpu_stream(ovgpu_ctx *ctx);
+
+/* Time in ms of the dominant kernel (measurement compression) and of the
+ * whole update, averaged over the launches since the last call with
+ * reset != 0; measured with HIP events on the context's stream.              */
+int ovgpu_kernel_times(ovgpu_ctx *ctx, int reset, double *ms_compress_avg,
+                       double *ms_update_avg, int64_t *n_launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OVGPU_H */

@@ -1,0 +1,538 @@
+// k_system.h — per-feature linear system: Jacobian, chi2 gate, nullspace projection, stacking.
+//
+//   UpdaterHelper::get_feature_jacobian_full            UpdaterHelper.cpp:192-424
+//   UpdaterHelper::get_feature_jacobian_representation  UpdaterHelper.cpp:32-190
+//   UpdaterHelper::nullspace_project_inplace            UpdaterHelper.cpp:426-454
+//   chi2 gate                                           UpdaterMSCKF.cpp:209-234, StateHelper.cpp:226-254
+//   stacking into Hx_big / res_big                      UpdaterMSCKF.cpp:237-255
+//
+// One workgroup (256 threads) per feature, persistent over the feature list.
+//
+// Design notes (MI355X-first, not a translation of the Eigen code):
+//  * Before the nullspace projection every Jacobian row is block-sparse: 6 clone columns,
+//    6 extrinsic + 8 intrinsic columns of its camera (+ anchor blocks for anchored
+//    representations).  Rows are kept in that 46-double sparse form in LDS; the dense
+//    2m x d_f matrix of the reference is never materialised on chip.
+//  * chi2 gate: with N an orthonormal basis of the left nullspace of H_f,
+//        r'^T (N^T S0 N)^-1 r'  =  r^T W r - (H_f^T W r)^T (H_f^T W H_f)^-1 (H_f^T W r),
+//    W = S0^-1, S0 = H P H^T + sigma^2 I on the UNPROJECTED rows.  So one Cholesky of the
+//    2m x 2m matrix S0 with four extra right-hand sides [r | H_f] gives the statistic of
+//    UpdaterMSCKF.cpp:212 without forming N^T H.  S0 is built from the sparse rows in
+//    16-row chunks of T = H P (P stays L2-resident) and lives packed-lower in LDS.
+//  * nullspace projection: 3 Householder reflectors of H_f in compact-WY form
+//    Q^T = I - V T^T V^T.  Each thread owns one output column c of the canonical stacked
+//    Jacobian, computes V^T h_c from the few non-zeros of h_c and streams rows 3..2m-1 of
+//    Q^T h_c straight to HBM (consecutive threads -> consecutive addresses).  Any orthonormal
+//    basis of the nullspace gives the same chi2 and the same compressed information as the
+//    reference's Givens sequence.
+#pragma once
+#include "device_math.h"
+#include "ovgpu_types.h"
+
+namespace ovg {
+
+static constexpr int SYS_NT = 256;  // threads per workgroup
+static constexpr int SYS_RCM = 8;   // measurements per T-chunk (16 rows)
+
+// LDS carve sizes in bytes for a batch whose longest track is m_max (host + device agree on this)
+__host__ __device__ inline size_t sys_lds_fixed_bytes(int m_max, int row_stride, int D) {
+  size_t b = 0;
+  b += (size_t)m_max * 8 * sizeof(int);            // minfo
+  b += (size_t)m_max * row_stride * sizeof(double); // rows
+  b += (size_t)2 * m_max * 3 * sizeof(double);      // V
+  b += 64 * sizeof(double);                         // tau, T, representation scratch
+  b += (size_t)2 * SYS_RCM * D * sizeof(double);    // T chunk
+  return (b + 15) & ~(size_t)15;
+}
+__host__ __device__ inline size_t sys_gate_doubles(int m) {
+  const size_t n = 2 * (size_t)m;
+  return n * (n + 1) / 2 + 4 * n;
+}
+
+// packed index of the gate matrix: rows 0..n-1 lower-triangular, rows n..n+3 dense (the 4 RHS)
+__device__ __forceinline__ size_t sidx(int i, int j, int n) {
+  return (i < n) ? ((size_t)i * (i + 1) / 2 + j) : ((size_t)n * (n + 1) / 2 + (size_t)(i - n) * n + j);
+}
+
+// offsets inside one measurement's row store
+enum { RO_HF = 0, RO_CLONE = 6, RO_CPOSE = 18, RO_CINTR = 30, RO_RES = 46, RO_ANC = 48, RO_ACAL = 60 };
+
+__device__ __forceinline__ bool rep_is_relative(int rep) { return rep >= OVGPU_REP_ANCHORED_3D; }
+
+// UpdaterHelper.cpp:44-67 / :130-152 — d p / d (theta, phi, rho)
+__device__ __forceinline__ void inv_depth_jac(const V3 &p, double *J) {
+  const double rho = 1.0 / norm(p);
+  const double phi = acos(rho * p.z);
+  const double theta = atan2(p.y, p.x);
+  const double sin_th = sin(theta), cos_th = cos(theta), sin_phi = sin(phi), cos_phi = cos(phi);
+  J[0] = -(1.0 / rho) * sin_th * sin_phi, J[1] = (1.0 / rho) * cos_th * cos_phi, J[2] = -(1.0 / (rho * rho)) * cos_th * sin_phi;
+  J[3] = (1.0 / rho) * cos_th * sin_phi, J[4] = (1.0 / rho) * sin_th * cos_phi, J[5] = -(1.0 / (rho * rho)) * sin_th * sin_phi;
+  J[6] = 0.0, J[7] = -(1.0 / rho) * sin_phi, J[8] = -(1.0 / (rho * rho)) * cos_phi;
+}
+
+__global__ void __launch_bounds__(SYS_NT) k_system(SysParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x;
+  const int D = p.D, LD = p.LD, N = p.N, RS = p.row_stride;
+  // ---- LDS carve
+  int *minfo = reinterpret_cast<int *>(smem);
+  double *rows = reinterpret_cast<double *>(smem + (((size_t)p.m_max * 8 * sizeof(int) + 15) & ~(size_t)15));
+  double *V = rows + (size_t)p.m_max * RS;
+  double *hq = V + (size_t)2 * p.m_max * 3; // [0..2] tau, [3..11] T, [12..20] dpfg_dlambda, [21..38] H_anc, [39..56] H_calib, [57..] flags
+  double *Tch = hq + 64;
+  double *S_lds = Tch + (size_t)2 * SYS_RCM * D;
+
+  const bool relative = rep_is_relative(p.opt.feat_rep);
+
+  for (int f = blockIdx.x; f < p.F; f += gridDim.x) {
+    const int m0 = p.meas_offsets[f];
+    const int m = p.meas_offsets[f + 1] - m0;
+    const int64_t orow0 = p.row_off[f];
+    const int n_out = (int)(p.row_off[f + 1] - orow0); // 2m - 3 (0 when m < 2)
+    const int status_in = p.status[f];
+    __syncthreads(); // previous feature's LDS fully consumed
+
+    if (status_in != OVGPU_FEAT_USED) {
+      // failed before the gate: its rows of the stacked system are zero
+      for (int64_t e = tid; e < (int64_t)n_out * LD; e += SYS_NT) p.Hbig[orow0 * LD + e] = 0.0;
+      continue;
+    }
+    const int n = 2 * m;
+    double *S = (m <= p.m_lds_max) ? S_lds : (p.ws + (size_t)blockIdx.x * p.ws_stride);
+
+    // ------------------------------------------------------------------
+    // (a0) representation Jacobian — UpdaterHelper.cpp:32-190 (once per feature)
+    // ------------------------------------------------------------------
+    V3 p_FinG = load_v3(p.p_FinG + 3 * f);
+    int anchor_cam = -1, anchor_clone = -1;
+    if (relative) {
+      const int ac = p.meas_cc[p.anchor_meas[f]];
+      anchor_cam = ac >> 10, anchor_clone = ac & 1023;
+      const V3 p_FinA = load_v3(p.p_FinA + 3 * f);
+      const M3 R_ItoC = load_m3(p.tab_cam + 12 * anchor_cam);
+      const V3 p_IinC = load_v3(p.tab_cam + 12 * anchor_cam + 9);
+      const M3 R_GtoI = load_m3(p.tab_clone + 24 * anchor_clone);
+      const V3 p_IinG = load_v3(p.tab_clone + 24 * anchor_clone + 9);
+      p_FinG = mulT(R_GtoI, mulT(R_ItoC, p_FinA - p_IinC)) + p_IinG; // UpdaterHelper.cpp:274
+    }
+    if (tid == 0) {
+      double *dl = hq + 12;
+      if (p.opt.feat_rep == OVGPU_REP_GLOBAL_3D) {
+        dl[0] = 1, dl[1] = 0, dl[2] = 0, dl[3] = 0, dl[4] = 1, dl[5] = 0, dl[6] = 0, dl[7] = 0, dl[8] = 1;
+      } else if (p.opt.feat_rep == OVGPU_REP_GLOBAL_FULL_INVERSE_DEPTH) {
+        inv_depth_jac(p_FinG, dl); // fej value == value for MSCKF features (UpdaterMSCKF.cpp:186-194)
+      } else {
+        // anchored (UpdaterHelper.cpp:84-189)
+        const V3 p_FinA_in = load_v3(p.p_FinA + 3 * f);
+        const M3 R_ItoC = load_m3(p.tab_cam + 12 * anchor_cam);
+        const V3 p_IinC = load_v3(p.tab_cam + 12 * anchor_cam + 9);
+        M3 R_GtoI = load_m3(p.tab_clone + 24 * anchor_clone);
+        V3 p_IinG = load_v3(p.tab_clone + 24 * anchor_clone + 9);
+        V3 p_FinA = p_FinA_in;
+        if (p.opt.do_fej) { // :93-100
+          const V3 best = mulT(R_GtoI, mulT(R_ItoC, p_FinA_in - p_IinC)) + p_IinG;
+          R_GtoI = load_m3(p.tab_clone + 24 * anchor_clone + 12);
+          p_IinG = load_v3(p.tab_clone + 24 * anchor_clone + 21);
+          p_FinA = mul(R_ItoC, mul(R_GtoI, best - p_IinG)) + p_IinC;
+        }
+        const M3 R_CtoG = mul(transpose(R_GtoI), transpose(R_ItoC)); // :101
+        {
+          const M3 blk = mul(transpose(R_GtoI), skew_x(mulT(R_ItoC, p_FinA - p_IinC))); // :105
+          double *Ha = hq + 21;
+          Ha[0] = -blk.a00, Ha[1] = -blk.a01, Ha[2] = -blk.a02, Ha[3] = 1, Ha[4] = 0, Ha[5] = 0;
+          Ha[6] = -blk.a10, Ha[7] = -blk.a11, Ha[8] = -blk.a12, Ha[9] = 0, Ha[10] = 1, Ha[11] = 0;
+          Ha[12] = -blk.a20, Ha[13] = -blk.a21, Ha[14] = -blk.a22, Ha[15] = 0, Ha[16] = 0, Ha[17] = 1;
+        }
+        {
+          const M3 blk = mul(R_CtoG, skew_x(p_FinA - p_IinC)); // :115-116
+          double *Hc = hq + 39;
+          Hc[0] = -blk.a00, Hc[1] = -blk.a01, Hc[2] = -blk.a02, Hc[3] = -R_CtoG.a00, Hc[4] = -R_CtoG.a01, Hc[5] = -R_CtoG.a02;
+          Hc[6] = -blk.a10, Hc[7] = -blk.a11, Hc[8] = -blk.a12, Hc[9] = -R_CtoG.a10, Hc[10] = -R_CtoG.a11, Hc[11] = -R_CtoG.a12;
+          Hc[12] = -blk.a20, Hc[13] = -blk.a21, Hc[14] = -blk.a22, Hc[15] = -R_CtoG.a20, Hc[16] = -R_CtoG.a21, Hc[17] = -R_CtoG.a22;
+        }
+        M3 d{1, 0, 0, 0, 1, 0, 0, 0, 1};
+        if (p.opt.feat_rep == OVGPU_REP_ANCHORED_FULL_INVERSE_DEPTH) {
+          double J[9];
+          inv_depth_jac(p_FinA, J);
+          d = M3{J[0], J[1], J[2], J[3], J[4], J[5], J[6], J[7], J[8]};
+        } else if (p.opt.feat_rep == OVGPU_REP_ANCHORED_MSCKF_INVERSE_DEPTH) { // :157-175
+          const double alpha = p_FinA.x / p_FinA.z, beta = p_FinA.y / p_FinA.z, rho = 1.0 / p_FinA.z;
+          d = M3{1.0 / rho, 0.0, -(1.0 / (rho * rho)) * alpha, 0.0, 1.0 / rho, -(1.0 / (rho * rho)) * beta, 0.0, 0.0, -(1.0 / (rho * rho))};
+        }
+        store_m3(dl, mul(R_CtoG, d));
+      }
+    }
+    __syncthreads();
+
+    // ------------------------------------------------------------------
+    // (a) per-measurement sparse Jacobian rows — UpdaterHelper.cpp:314-421
+    // ------------------------------------------------------------------
+    for (int i = tid; i < m; i += SYS_NT) {
+      const int code = p.meas_cc[m0 + i];
+      const int cam = code >> 10, cl = code & 1023;
+      int *mi = minfo + 8 * i;
+      const int ccol = p.clone_col[cl], pcol = p.calib_col[cam], icol = p.intr_col[cam];
+      mi[0] = cam, mi[1] = cl, mi[2] = ccol, mi[3] = pcol, mi[4] = icol;
+      mi[5] = p.col_cov[ccol];
+      mi[6] = pcol >= 0 ? p.col_cov[pcol] : -1;
+      mi[7] = icol >= 0 ? p.col_cov[icol] : -1;
+      double *rd = rows + (size_t)i * RS;
+
+      const M3 R_ItoC = load_m3(p.tab_cam + 12 * cam);
+      const V3 p_IinC = load_v3(p.tab_cam + 12 * cam + 9);
+      const CamIntr ci = load_cam(p.intr + 8 * cam);
+      const bool fish = p.fisheye[cam] != 0;
+      const double *tc = p.tab_clone + 24 * cl;
+      M3 R_GtoIi = load_m3(tc);
+      V3 p_IiinG = load_v3(tc + 9);
+      V3 p_FinIi = mul(R_GtoIi, p_FinG - p_IiinG);  // :334
+      V3 p_FinCi = mul(R_ItoC, p_FinIi) + p_IinC;   // :337
+      const double un = p_FinCi.x / p_FinCi.z, vn = p_FinCi.y / p_FinCi.z;
+      double ud, vd;
+      if (fish)
+        equi_distort_d(ci, un, vn, ud, vd); // :343 (float round trip, Q2)
+      else
+        radtan_distort_d(ci, un, vn, ud, vd);
+      rd[RO_RES] = (double)p.uv[2 * (m0 + i)] - ud; // :346-348
+      rd[RO_RES + 1] = (double)p.uv[2 * (m0 + i) + 1] - vd;
+      if (p.opt.do_fej) { // :354-363  (uv_norm is deliberately NOT recomputed, Q4)
+        R_GtoIi = load_m3(tc + 12);
+        p_IiinG = load_v3(tc + 21);
+        p_FinIi = mul(R_GtoIi, p_FinG - p_IiinG); // p_FinG_fej == p_FinG for MSCKF features (Q5)
+        p_FinCi = mul(R_ItoC, p_FinIi) + p_IinC;
+      }
+      double dzn[4], dze[16];
+      if (fish)
+        equi_jacobian(ci, un, vn, dzn, dze); // :367
+      else
+        radtan_jacobian(ci, un, vn, dzn, dze);
+      const double iz = 1.0 / p_FinCi.z;
+      const double n02 = -p_FinCi.x * iz * iz, n12 = -p_FinCi.y * iz * iz; // :370-371
+      // dz_dpfc = dz_dzn * dzn_dpfc (2x3)
+      const double a00 = dzn[0] * iz, a01 = dzn[1] * iz, a02 = dzn[0] * n02 + dzn[1] * n12;
+      const double a10 = dzn[2] * iz, a11 = dzn[3] * iz, a12 = dzn[2] * n02 + dzn[3] * n12;
+      const M3 dpfc_dpfg = mul(R_ItoC, R_GtoIi); // :374
+      // dz_dpfg = dz_dpfc * dpfc_dpfg
+      const double g00 = a00 * dpfc_dpfg.a00 + a01 * dpfc_dpfg.a10 + a02 * dpfc_dpfg.a20;
+      const double g01 = a00 * dpfc_dpfg.a01 + a01 * dpfc_dpfg.a11 + a02 * dpfc_dpfg.a21;
+      const double g02 = a00 * dpfc_dpfg.a02 + a01 * dpfc_dpfg.a12 + a02 * dpfc_dpfg.a22;
+      const double g10 = a10 * dpfc_dpfg.a00 + a11 * dpfc_dpfg.a10 + a12 * dpfc_dpfg.a20;
+      const double g11 = a10 * dpfc_dpfg.a01 + a11 * dpfc_dpfg.a11 + a12 * dpfc_dpfg.a21;
+      const double g12 = a10 * dpfc_dpfg.a02 + a11 * dpfc_dpfg.a12 + a12 * dpfc_dpfg.a22;
+      // H_f = dz_dpfg * dpfg_dlambda (:389)
+      const double *dl = hq + 12;
+      rd[RO_HF + 0] = g00 * dl[0] + g01 * dl[3] + g02 * dl[6];
+      rd[RO_HF + 1] = g00 * dl[1] + g01 * dl[4] + g02 * dl[7];
+      rd[RO_HF + 2] = g00 * dl[2] + g01 * dl[5] + g02 * dl[8];
+      rd[RO_HF + 3] = g10 * dl[0] + g11 * dl[3] + g12 * dl[6];
+      rd[RO_HF + 4] = g10 * dl[1] + g11 * dl[4] + g12 * dl[7];
+      rd[RO_HF + 5] = g10 * dl[2] + g11 * dl[5] + g12 * dl[8];
+      // clone block = dz_dpfc * [R_ItoC skew(p_FinIi), -dpfc_dpfg]  (:377-392)
+      const M3 Rsk = mul(R_ItoC, skew_x(p_FinIi));
+      rd[RO_CLONE + 0] = a00 * Rsk.a00 + a01 * Rsk.a10 + a02 * Rsk.a20;
+      rd[RO_CLONE + 1] = a00 * Rsk.a01 + a01 * Rsk.a11 + a02 * Rsk.a21;
+      rd[RO_CLONE + 2] = a00 * Rsk.a02 + a01 * Rsk.a12 + a02 * Rsk.a22;
+      rd[RO_CLONE + 3] = -g00, rd[RO_CLONE + 4] = -g01, rd[RO_CLONE + 5] = -g02;
+      rd[RO_CLONE + 6] = a10 * Rsk.a00 + a11 * Rsk.a10 + a12 * Rsk.a20;
+      rd[RO_CLONE + 7] = a10 * Rsk.a01 + a11 * Rsk.a11 + a12 * Rsk.a21;
+      rd[RO_CLONE + 8] = a10 * Rsk.a02 + a11 * Rsk.a12 + a12 * Rsk.a22;
+      rd[RO_CLONE + 9] = -g10, rd[RO_CLONE + 10] = -g11, rd[RO_CLONE + 11] = -g12;
+      // extrinsics: dz_dpfc * [skew(p_FinCi - p_IinC), I]  (:404-413)
+      {
+        const M3 sk = skew_x(p_FinCi - p_IinC);
+        rd[RO_CPOSE + 0] = a00 * sk.a00 + a01 * sk.a10 + a02 * sk.a20;
+        rd[RO_CPOSE + 1] = a00 * sk.a01 + a01 * sk.a11 + a02 * sk.a21;
+        rd[RO_CPOSE + 2] = a00 * sk.a02 + a01 * sk.a12 + a02 * sk.a22;
+        rd[RO_CPOSE + 3] = a00, rd[RO_CPOSE + 4] = a01, rd[RO_CPOSE + 5] = a02;
+        rd[RO_CPOSE + 6] = a10 * sk.a00 + a11 * sk.a10 + a12 * sk.a20;
+        rd[RO_CPOSE + 7] = a10 * sk.a01 + a11 * sk.a11 + a12 * sk.a21;
+        rd[RO_CPOSE + 8] = a10 * sk.a02 + a11 * sk.a12 + a12 * sk.a22;
+        rd[RO_CPOSE + 9] = a10, rd[RO_CPOSE + 10] = a11, rd[RO_CPOSE + 11] = a12;
+      }
+      // intrinsics (:416-418)
+#pragma unroll
+      for (int s = 0; s < 16; s++) rd[RO_CINTR + s] = dze[s];
+      if (relative) { // representation extras (:396-398): dz_dpfg * H_anc, dz_dpfg * H_calib
+        const double *Ha = hq + 21, *Hc = hq + 39;
+#pragma unroll
+        for (int s = 0; s < 6; s++) {
+          rd[RO_ANC + s] = g00 * Ha[s] + g01 * Ha[6 + s] + g02 * Ha[12 + s];
+          rd[RO_ANC + 6 + s] = g10 * Ha[s] + g11 * Ha[6 + s] + g12 * Ha[12 + s];
+          rd[RO_ACAL + s] = g00 * Hc[s] + g01 * Hc[6 + s] + g02 * Hc[12 + s];
+          rd[RO_ACAL + 6 + s] = g10 * Hc[s] + g11 * Hc[6 + s] + g12 * Hc[12 + s];
+        }
+      }
+    }
+    __syncthreads();
+
+    const int anc_ccol = relative ? p.clone_col[anchor_clone] : -1;
+    const int anc_pcol = (relative && p.opt.do_calib_pose) ? p.calib_col[anchor_cam] : -1;
+    const int anc_ccov = anc_ccol >= 0 ? p.col_cov[anc_ccol] : -1;
+    const int anc_pcov = anc_pcol >= 0 ? p.col_cov[anc_pcol] : -1;
+
+    // ------------------------------------------------------------------
+    // (c) chi2 gate: S0 = H P H^T + sigma^2 I (packed lower) with RHS rows [res ; H_f^T]
+    // ------------------------------------------------------------------
+    for (int i0 = 0; i0 < m; i0 += SYS_RCM) {
+      const int mc = min(SYS_RCM, m - i0);
+      // phase 1: T = H P for the chunk's 2*mc rows, all D columns
+      for (int c = tid; c < D; c += SYS_NT) {
+        const double *Pc = p.P + p.col_cov[c];
+        for (int ii = 0; ii < mc; ii++) {
+          const int *mi = minfo + 8 * (i0 + ii);
+          const double *rd = rows + (size_t)(i0 + ii) * RS;
+          double t0 = 0.0, t1 = 0.0;
+          {
+            const double *Pr = Pc + (size_t)mi[5] * N;
+#pragma unroll
+            for (int s = 0; s < 6; s++) {
+              const double pv = Pr[(size_t)s * N];
+              t0 = fma(rd[RO_CLONE + s], pv, t0), t1 = fma(rd[RO_CLONE + 6 + s], pv, t1);
+            }
+          }
+          if (mi[6] >= 0) {
+            const double *Pr = Pc + (size_t)mi[6] * N;
+#pragma unroll
+            for (int s = 0; s < 6; s++) {
+              const double pv = Pr[(size_t)s * N];
+              t0 = fma(rd[RO_CPOSE + s], pv, t0), t1 = fma(rd[RO_CPOSE + 6 + s], pv, t1);
+            }
+          }
+          if (mi[7] >= 0) {
+            const double *Pr = Pc + (size_t)mi[7] * N;
+#pragma unroll
+            for (int s = 0; s < 8; s++) {
+              const double pv = Pr[(size_t)s * N];
+              t0 = fma(rd[RO_CINTR + s], pv, t0), t1 = fma(rd[RO_CINTR + 8 + s], pv, t1);
+            }
+          }
+          if (anc_ccov >= 0) {
+            const double *Pr = Pc + (size_t)anc_ccov * N;
+#pragma unroll
+            for (int s = 0; s < 6; s++) {
+              const double pv = Pr[(size_t)s * N];
+              t0 = fma(rd[RO_ANC + s], pv, t0), t1 = fma(rd[RO_ANC + 6 + s], pv, t1);
+            }
+          }
+          if (anc_pcov >= 0) {
+            const double *Pr = Pc + (size_t)anc_pcov * N;
+#pragma unroll
+            for (int s = 0; s < 6; s++) {
+              const double pv = Pr[(size_t)s * N];
+              t0 = fma(rd[RO_ACAL + s], pv, t0), t1 = fma(rd[RO_ACAL + 6 + s], pv, t1);
+            }
+          }
+          Tch[(size_t)(2 * ii) * D + c] = t0;
+          Tch[(size_t)(2 * ii + 1) * D + c] = t1;
+        }
+      }
+      __syncthreads();
+      // phase 2: S0[r][q] = T[r] . H[q]  for r in the chunk, q <= r
+      const int r0 = 2 * i0, nr = 2 * mc;
+      for (int idx = tid; idx < nr * n; idx += SYS_NT) {
+        const int rr = idx / n, q = idx - rr * n;
+        const int r = r0 + rr;
+        if (q > r) continue;
+        const int qi = q >> 1, qa = q & 1;
+        const int *mi = minfo + 8 * qi;
+        const double *rd = rows + (size_t)qi * RS;
+        const double *Tr = Tch + (size_t)rr * D;
+        double s = (q == r) ? p.opt.sigma_pix_sq : 0.0;
+        {
+          const double *t = Tr + mi[2];
+          const double *h = rd + RO_CLONE + 6 * qa;
+#pragma unroll
+          for (int k = 0; k < 6; k++) s = fma(t[k], h[k], s);
+        }
+        if (mi[3] >= 0) {
+          const double *t = Tr + mi[3];
+          const double *h = rd + RO_CPOSE + 6 * qa;
+#pragma unroll
+          for (int k = 0; k < 6; k++) s = fma(t[k], h[k], s);
+        }
+        if (mi[4] >= 0) {
+          const double *t = Tr + mi[4];
+          const double *h = rd + RO_CINTR + 8 * qa;
+#pragma unroll
+          for (int k = 0; k < 8; k++) s = fma(t[k], h[k], s);
+        }
+        if (anc_ccol >= 0) {
+          const double *t = Tr + anc_ccol;
+          const double *h = rd + RO_ANC + 6 * qa;
+#pragma unroll
+          for (int k = 0; k < 6; k++) s = fma(t[k], h[k], s);
+        }
+        if (anc_pcol >= 0) {
+          const double *t = Tr + anc_pcol;
+          const double *h = rd + RO_ACAL + 6 * qa;
+#pragma unroll
+          for (int k = 0; k < 6; k++) s = fma(t[k], h[k], s);
+        }
+        S[sidx(r, q, n)] = s;
+      }
+      __syncthreads();
+    }
+    // right-hand sides: row n = res, rows n+1..n+3 = H_f columns
+    for (int q = tid; q < n; q += SYS_NT) {
+      const double *rd = rows + (size_t)(q >> 1) * RS;
+      const int qa = q & 1;
+      S[sidx(n, q, n)] = rd[RO_RES + qa];
+      S[sidx(n + 1, q, n)] = rd[RO_HF + 3 * qa + 0];
+      S[sidx(n + 2, q, n)] = rd[RO_HF + 3 * qa + 1];
+      S[sidx(n + 3, q, n)] = rd[RO_HF + 3 * qa + 2];
+    }
+    __syncthreads();
+    // right-looking Cholesky of the (n + 4) x n lower trapezoid; the 4 extra rows end as (L^-1 b)^T
+    {
+      const int ti = tid >> 4, tj = tid & 15;
+      for (int k = 0; k < n; k++) {
+        const double dkk = sqrt(S[sidx(k, k, n)]);
+        __syncthreads();
+        const double inv = 1.0 / dkk;
+        for (int i = k + 1 + tid; i < n + 4; i += SYS_NT) S[sidx(i, k, n)] *= inv;
+        if (tid == 0) S[sidx(k, k, n)] = dkk;
+        __syncthreads();
+        for (int i = k + 1 + ti; i < n + 4; i += 16) {
+          const double lik = S[sidx(i, k, n)];
+          const int jmax = min(i, n - 1);
+          for (int j = k + 1 + tj; j <= jmax; j += 16) S[sidx(i, j, n)] = fma(-lik, S[sidx(j, k, n)], S[sidx(i, j, n)]);
+        }
+        __syncthreads();
+      }
+    }
+    // chi2 = |y_r|^2 - g^T G^-1 g,  y_r = L^-1 res, Y_f = L^-1 H_f, G = Y_f^T Y_f, g = Y_f^T y_r
+    if (tid < 64) {
+      double a = 0, G00 = 0, G01 = 0, G02 = 0, G11 = 0, G12 = 0, G22 = 0, g0 = 0, g1 = 0, g2 = 0;
+      for (int j = tid; j < n; j += 64) {
+        const double yr = S[sidx(n, j, n)], y0 = S[sidx(n + 1, j, n)], y1 = S[sidx(n + 2, j, n)], y2 = S[sidx(n + 3, j, n)];
+        a = fma(yr, yr, a);
+        G00 = fma(y0, y0, G00), G01 = fma(y0, y1, G01), G02 = fma(y0, y2, G02);
+        G11 = fma(y1, y1, G11), G12 = fma(y1, y2, G12), G22 = fma(y2, y2, G22);
+        g0 = fma(y0, yr, g0), g1 = fma(y1, yr, g1), g2 = fma(y2, yr, g2);
+      }
+      a = wave_sum(a);
+      G00 = wave_sum(G00), G01 = wave_sum(G01), G02 = wave_sum(G02), G11 = wave_sum(G11), G12 = wave_sum(G12), G22 = wave_sum(G22);
+      g0 = wave_sum(g0), g1 = wave_sum(g1), g2 = wave_sum(g2);
+      const M3 G{G00, G01, G02, G01, G11, G12, G02, G12, G22};
+      const V3 g{g0, g1, g2};
+      const V3 x = colpiv_qr_solve3(G, g);
+      const double chi2 = a - dot(g, x);
+      const int dof = n - 3;
+      const double thr = p.opt.chi2_multipler * p.chi2_table[min(dof, p.chi2_table_len - 1)]; // UpdaterMSCKF.cpp:216-222
+      if (tid == 0) {
+        p.chi2[f] = chi2;
+        p.chi2_thresh[f] = thr;
+        const bool reject = chi2 > thr; // :225
+        hq[57] = reject ? 1.0 : 0.0;
+        if (reject) p.status[f] = OVGPU_FEAT_CHI2_REJECTED;
+      }
+    }
+    __syncthreads();
+    if (hq[57] != 0.0) {
+      for (int64_t e = tid; e < (int64_t)n_out * LD; e += SYS_NT) p.Hbig[orow0 * LD + e] = 0.0;
+      continue;
+    }
+
+    // ------------------------------------------------------------------
+    // (b) Householder QR of H_f (2m x 3) -> V, tau, T   (role of UpdaterHelper.cpp:426-454)
+    // ------------------------------------------------------------------
+    if (tid < 64) {
+      const int lane = tid;
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        // column k, rows k..n-1 (H_f element (row, k) lives at rows[(row>>1)*RS + 3*(row&1) + k])
+        double sig = 0.0;
+        for (int r = k + 1 + lane; r < n; r += 64) {
+          const double x = rows[(size_t)(r >> 1) * RS + RO_HF + 3 * (r & 1) + k];
+          sig = fma(x, x, sig);
+        }
+        sig = wave_sum(sig);
+        const double alpha = rows[(size_t)(k >> 1) * RS + RO_HF + 3 * (k & 1) + k];
+        double beta = alpha, tau = 0.0, scale = 0.0;
+        if (sig > 2.2250738585072014e-308) {
+          beta = sqrt(alpha * alpha + sig);
+          if (alpha >= 0.0) beta = -beta;
+          scale = 1.0 / (alpha - beta);
+          tau = (beta - alpha) / beta;
+        }
+        // v_k
+        for (int r = lane; r < n; r += 64) {
+          double v = 0.0;
+          if (r == k) v = 1.0;
+          else if (r > k) v = rows[(size_t)(r >> 1) * RS + RO_HF + 3 * (r & 1) + k] * scale;
+          V[(size_t)r * 3 + k] = v;
+        }
+        if (lane == 0) hq[k] = tau;
+        // apply H_k to the remaining columns of H_f
+        for (int c = k + 1; c < 3; c++) {
+          double w = 0.0;
+          for (int r = k + lane; r < n; r += 64) w = fma(V[(size_t)r * 3 + k], rows[(size_t)(r >> 1) * RS + RO_HF + 3 * (r & 1) + c], w);
+          w = wave_sum(w) * tau;
+          for (int r = k + lane; r < n; r += 64) {
+            double *x = &rows[(size_t)(r >> 1) * RS + RO_HF + 3 * (r & 1) + c];
+            *x = fma(-w, V[(size_t)r * 3 + k], *x);
+          }
+        }
+      }
+      // T of the compact WY form Q = I - V T V^T (forward, column-wise)
+      double v01 = 0, v02 = 0, v12 = 0;
+      for (int r = lane; r < n; r += 64) {
+        const double a = V[(size_t)r * 3], b = V[(size_t)r * 3 + 1], c = V[(size_t)r * 3 + 2];
+        v01 = fma(a, b, v01), v02 = fma(a, c, v02), v12 = fma(b, c, v12);
+      }
+      v01 = wave_sum(v01), v02 = wave_sum(v02), v12 = wave_sum(v12);
+      if (lane == 0) {
+        const double t0 = hq[0], t1 = hq[1], t2 = hq[2];
+        const double T00 = t0, T11 = t1, T22 = t2;
+        const double T01 = -t1 * (T00 * v01);
+        const double T02 = -t2 * (T00 * v02 + T01 * v12);
+        const double T12 = -t2 * (T11 * v12);
+        hq[3] = T00, hq[4] = T01, hq[5] = T02, hq[6] = T11, hq[7] = T12, hq[8] = T22;
+      }
+    }
+    __syncthreads();
+
+    // ------------------------------------------------------------------
+    // (d) stack: thread-per-column, rows 3..n-1 of Q^T [H_x | res] -> Hbig   (UpdaterMSCKF.cpp:237-255)
+    // ------------------------------------------------------------------
+    {
+      const double T00 = hq[3], T01 = hq[4], T02 = hq[5], T11 = hq[6], T12 = hq[7], T22 = hq[8];
+      for (int c = tid; c < LD; c += SYS_NT) {
+        int kind = 3, var = 0, sub = 0; // 3 = residual column
+        if (c < D) kind = p.col_kind[c], var = p.col_var[c], sub = p.col_sub[c];
+        const bool anc_hit_c = (kind == COL_CLONE && var == anchor_clone && relative);
+        const bool anc_hit_p = (kind == COL_CALIB_POSE && var == anchor_cam && relative && p.opt.do_calib_pose);
+        auto hval = [&](int i, int a) -> double {
+          const int *mi = minfo + 8 * i;
+          const double *rd = rows + (size_t)i * RS;
+          double h = 0.0;
+          if (kind == 3) h = rd[RO_RES + a];
+          else if (kind == COL_CLONE) { if (mi[1] == var) h = rd[RO_CLONE + 6 * a + sub]; }
+          else if (kind == COL_CALIB_POSE) { if (mi[0] == var && mi[3] >= 0) h = rd[RO_CPOSE + 6 * a + sub]; }
+          else { if (mi[0] == var && mi[4] >= 0) h = rd[RO_CINTR + 8 * a + sub]; }
+          if (anc_hit_c) h += rd[RO_ANC + 6 * a + sub];
+          if (anc_hit_p) h += rd[RO_ACAL + 6 * a + sub];
+          return h;
+        };
+        // y = V^T h
+        double y0 = 0, y1 = 0, y2 = 0;
+        for (int i = 0; i < m; i++) {
+          const double h0 = hval(i, 0), h1 = hval(i, 1);
+          const double *v = V + (size_t)6 * i;
+          y0 = fma(v[0], h0, y0), y1 = fma(v[1], h0, y1), y2 = fma(v[2], h0, y2);
+          y0 = fma(v[3], h1, y0), y1 = fma(v[4], h1, y1), y2 = fma(v[5], h1, y2);
+        }
+        // z = T^T y
+        const double z0 = T00 * y0, z1 = T01 * y0 + T11 * y1, z2 = T02 * y0 + T12 * y1 + T22 * y2;
+        double *out = p.Hbig + orow0 * LD + c;
+        for (int r = 3; r < n; r++) {
+          const double h = hval(r >> 1, r & 1);
+          const double *v = V + (size_t)3 * r;
+          out[(size_t)(r - 3) * LD] = h - (v[0] * z0 + v[1] * z1 + v[2] * z2);
+        }
+      }
+    }
+  }
+}
+
+} // namespace ovg

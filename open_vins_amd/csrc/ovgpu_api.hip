@@ -1,0 +1,773 @@
+// ovgpu_api.hip — host side of the C ABI declared in include/ovgpu.h.
+//
+// One context = one HIP device + one stream.  All inputs of an update (prior covariance, pose
+// tables, feature tracks) are resident in HBM; a complete UpdaterMSCKF::update
+// (UpdaterMSCKF.cpp:58-295) is a fixed sequence of kernel launches on that stream with no host
+// round trip in between.  There is no CPU fallback: without a GPU ovgpu_create fails.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "chi2.h"
+#include "k_compress.h"
+#include "k_ekf.h"
+#include "k_system.h"
+#include "k_triangulate.h"
+#include "ovgpu_types.h"
+
+using namespace ovg;
+
+static thread_local std::string g_err = "";
+static int set_err(int code, const std::string &msg) {
+  g_err = msg;
+  return code;
+}
+
+#define HIPCHK(expr)                                                                                         \
+  do {                                                                                                       \
+    hipError_t _e = (expr);                                                                                  \
+    if (_e != hipSuccess) {                                                                                  \
+      return set_err(OVGPU_ERR_HIP, std::string(#expr) + " -> " + hipGetErrorString(_e) + " (" __FILE__ ":" + \
+                                        std::to_string(__LINE__) + ")");                                     \
+    }                                                                                                        \
+  } while (0)
+
+namespace {
+
+template <class T>
+struct DevBuf {
+  T *p = nullptr;
+  size_t cap = 0; // elements
+  hipError_t reserve(size_t n) {
+    if (n <= cap) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    hipError_t e = hipMalloc((void **)&p, std::max<size_t>(n, 1) * sizeof(T));
+    if (e == hipSuccess) cap = n;
+    return e;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
+struct EventPair {
+  hipEvent_t a = nullptr, b = nullptr;
+};
+
+} // namespace
+
+struct ovgpu_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  ovgpu_options opts{};
+  DevOptions dopt{};
+  int lds_limit = 160 * 1024;
+  int num_cu = 256;
+
+  // ---- state
+  bool have_state = false;
+  int N = 0, C = 0, K = 0, D = 0, LD = 0;
+  DevBuf<double> P, P0, clone_qp, clone_qp0, clone_fej, calib_qp, calib_qp0, intr, intr0;
+  DevBuf<uint8_t> fisheye;
+  DevBuf<int32_t> clone_cov, calib_cov, intr_cov, clone_col, calib_col, intr_col, col_cov;
+  DevBuf<uint8_t> col_kind, col_sub;
+  DevBuf<uint16_t> col_var;
+  DevBuf<double> tab_clone, tab_cam, tab_cc;
+  std::vector<int32_t> h_col_cov;
+
+  // ---- features
+  bool have_feats = false;
+  int F = 0, M = 0, m_max = 0;
+  int64_t rows_total = 0;
+  DevBuf<int32_t> meas_offsets;
+  DevBuf<uint16_t> meas_cc;
+  DevBuf<float> uv, uvn;
+  DevBuf<int64_t> row_off;
+  DevBuf<double> pA, pG, chi2, chi2_thr;
+  DevBuf<int32_t> anchor, status;
+  DevBuf<double> chi2_table;
+  int chi2_table_len = 0;
+  std::vector<double> h_chi2_table;
+  std::vector<int32_t> h_offsets;
+
+  // ---- workspaces
+  DevBuf<double> Hbig, gate_ws, Rws, Mt, Aaug, dx;
+  DevBuf<int32_t> flags;
+  int W = 1;
+  int sys_grid = 1;
+  int64_t gate_ws_stride = 0;
+  int m_lds_max = 0;
+  size_t sys_lds_bytes = 0;
+  int row_stride = 48;
+
+  // ---- timing
+  std::vector<EventPair> ev_compress, ev_update;
+  size_t ev_used = 0;
+  bool timing = true;
+};
+
+static hipError_t upload(void *dst, const void *src, size_t bytes, hipStream_t s) {
+  if (bytes == 0) return hipSuccess;
+  return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s);
+}
+
+extern "C" {
+
+const char *ovgpu_last_error(void) { return g_err.c_str(); }
+
+void ovgpu_default_options(ovgpu_options *o) {
+  if (!o) return;
+  std::memset(o, 0, sizeof(*o));
+  o->chi2_multipler = 5.0, o->sigma_pix = 1.0; // UpdaterOptions.h:35-41
+  o->triangulate_1d = 0, o->refine_features = 1, o->max_runs = 5; // FeatureInitializerOptions.h:36-42
+  o->init_lamda = 1e-3, o->max_lamda = 1e10, o->min_dx = 1e-6, o->min_dcost = 1e-6, o->lam_mult = 10;
+  o->min_dist = 0.10, o->max_dist = 60, o->max_baseline = 40, o->max_cond_number = 10000;
+  o->do_fej = 1, o->do_calib_camera_pose = 1, o->do_calib_camera_intrinsics = 1; // StateOptions.h:38-47 (true in shipped configs)
+  o->feat_rep_msckf = OVGPU_REP_GLOBAL_3D;
+}
+
+double ovgpu_chi2_quantile_95(int dof) { return chi2_quantile_95(dof); }
+
+int ovgpu_create(const ovgpu_options *opts, int device, ovgpu_ctx **out) {
+  if (!opts || !out) return set_err(OVGPU_ERR_INVALID, "null argument");
+  *out = nullptr;
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0)
+    return set_err(OVGPU_ERR_NO_DEVICE, std::string("no HIP device (") + hipGetErrorString(e) + "): this library has no CPU fallback");
+  if (device < 0 || device >= ndev) return set_err(OVGPU_ERR_INVALID, "device index out of range");
+  if (opts->feat_rep_msckf < 0 || opts->feat_rep_msckf > OVGPU_REP_ANCHORED_INVERSE_DEPTH_SINGLE)
+    return set_err(OVGPU_ERR_INVALID, "unknown feature representation");
+  HIPCHK(hipSetDevice(device));
+  ovgpu_ctx *c = new ovgpu_ctx();
+  c->device = device;
+  c->opts = *opts;
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, device));
+  c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  c->lds_limit = (int)std::min<size_t>(prop.sharedMemPerBlock, 160 * 1024);
+  HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  DevOptions &d = c->dopt;
+  d.chi2_multipler = opts->chi2_multipler;
+  d.sigma_pix_sq = opts->sigma_pix * opts->sigma_pix; // UpdaterMSCKF.cpp:45
+  d.init_lamda = opts->init_lamda, d.max_lamda = opts->max_lamda, d.min_dx = opts->min_dx, d.min_dcost = opts->min_dcost;
+  d.lam_mult = opts->lam_mult, d.min_dist = opts->min_dist, d.max_dist = opts->max_dist, d.max_baseline = opts->max_baseline;
+  d.max_cond_number = opts->max_cond_number;
+  d.triangulate_1d = opts->triangulate_1d, d.refine_features = opts->refine_features, d.max_runs = opts->max_runs;
+  d.do_fej = opts->do_fej, d.do_calib_pose = opts->do_calib_camera_pose, d.do_calib_intr = opts->do_calib_camera_intrinsics;
+  d.feat_rep = opts->feat_rep_msckf;
+  if (d.feat_rep == OVGPU_REP_ANCHORED_INVERSE_DEPTH_SINGLE) d.feat_rep = OVGPU_REP_ANCHORED_MSCKF_INVERSE_DEPTH; // UpdaterMSCKF.cpp:180-183
+  c->row_stride = (d.feat_rep >= OVGPU_REP_ANCHORED_3D) ? 72 : 48;
+  // allow the large dynamic LDS carve of the per-feature kernel
+  (void)hipFuncSetAttribute((const void *)k_system, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_limit);
+  (void)hipFuncSetAttribute((const void *)k_ekf_chol, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_limit);
+  (void)hipFuncSetAttribute((const void *)k_triangulate, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_limit);
+  const char *tenv = std::getenv("OVGPU_TIMING");
+  c->timing = !(tenv && tenv[0] == '0');
+  *out = c;
+  return OVGPU_OK;
+}
+
+void ovgpu_destroy(ovgpu_ctx *c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  for (auto &e : c->ev_compress) {
+    if (e.a) (void)hipEventDestroy(e.a);
+    if (e.b) (void)hipEventDestroy(e.b);
+  }
+  for (auto &e : c->ev_update) {
+    if (e.a) (void)hipEventDestroy(e.a);
+    if (e.b) (void)hipEventDestroy(e.b);
+  }
+  c->P.release(), c->P0.release(), c->clone_qp.release(), c->clone_qp0.release(), c->clone_fej.release();
+  c->calib_qp.release(), c->calib_qp0.release(), c->intr.release(), c->intr0.release(), c->fisheye.release();
+  c->clone_cov.release(), c->calib_cov.release(), c->intr_cov.release(), c->clone_col.release(), c->calib_col.release();
+  c->intr_col.release(), c->col_cov.release(), c->col_kind.release(), c->col_sub.release(), c->col_var.release();
+  c->tab_clone.release(), c->tab_cam.release(), c->tab_cc.release();
+  c->meas_offsets.release(), c->meas_cc.release(), c->uv.release(), c->uvn.release(), c->row_off.release();
+  c->pA.release(), c->pG.release(), c->chi2.release(), c->chi2_thr.release(), c->anchor.release(), c->status.release();
+  c->chi2_table.release(), c->Hbig.release(), c->gate_ws.release(), c->Rws.release(), c->Mt.release(), c->Aaug.release();
+  c->dx.release(), c->flags.release();
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+static int launch_build_tables(ovgpu_ctx *c) {
+  const int n = std::max(c->K * c->C, std::max(c->C, c->K));
+  hipLaunchKernelGGL(k_build_tables, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->C, c->K, c->clone_qp.p, c->clone_fej.p, c->calib_qp.p,
+                     c->tab_clone.p, c->tab_cam.p, c->tab_cc.p);
+  HIPCHK(hipGetLastError());
+  return OVGPU_OK;
+}
+
+int ovgpu_set_state(ovgpu_ctx *c, const ovgpu_state_view *st) {
+  if (!c || !st) return set_err(OVGPU_ERR_INVALID, "null argument");
+  if (st->N <= 0 || st->C <= 0 || st->K <= 0) return set_err(OVGPU_ERR_INVALID, "empty state");
+  if (st->C > OVG_MAX_CLONES || st->K > OVG_MAX_CAMS) return set_err(OVGPU_ERR_CAPACITY, "too many clones / cameras");
+  if (!st->P || !st->clone_q_p || !st->clone_q_p_fej || !st->clone_cov_id || !st->calib_q_p || !st->intrinsics || !st->cam_is_fisheye ||
+      !st->calib_cov_id || !st->intr_cov_id)
+    return set_err(OVGPU_ERR_INVALID, "null state array");
+  HIPCHK(hipSetDevice(c->device));
+  const int N = st->N, C = st->C, K = st->K;
+
+  // ---- canonical column order: calibrated camera variables and clones sorted by covariance id
+  struct Var { int cov, size, kind, index; };
+  std::vector<Var> vars;
+  for (int k = 0; k < K; k++) {
+    if (c->dopt.do_calib_pose && st->calib_cov_id[k] >= 0) vars.push_back({st->calib_cov_id[k], 6, COL_CALIB_POSE, k});
+    if (c->dopt.do_calib_intr && st->intr_cov_id[k] >= 0) vars.push_back({st->intr_cov_id[k], 8, COL_CALIB_INTR, k});
+  }
+  for (int i = 0; i < C; i++) vars.push_back({st->clone_cov_id[i], 6, COL_CLONE, i});
+  std::stable_sort(vars.begin(), vars.end(), [](const Var &a, const Var &b) { return a.cov < b.cov; });
+  std::vector<int32_t> clone_col(C, -1), calib_col(K, -1), intr_col(K, -1), col_cov;
+  std::vector<uint8_t> col_kind, col_sub;
+  std::vector<uint16_t> col_var;
+  int D = 0;
+  for (const Var &v : vars) {
+    if (v.cov < 0 || v.cov + v.size > N) return set_err(OVGPU_ERR_INVALID, "covariance id out of range");
+    if (v.kind == COL_CLONE) clone_col[v.index] = D;
+    if (v.kind == COL_CALIB_POSE) calib_col[v.index] = D;
+    if (v.kind == COL_CALIB_INTR) intr_col[v.index] = D;
+    for (int i = 0; i < v.size; i++) {
+      col_cov.push_back(v.cov + i);
+      col_kind.push_back((uint8_t)v.kind);
+      col_var.push_back((uint16_t)v.index);
+      col_sub.push_back((uint8_t)i);
+    }
+    D += v.size;
+  }
+  if (D + 1 > 512) return set_err(OVGPU_ERR_CAPACITY, "more than 511 Jacobian columns");
+  c->N = N, c->C = C, c->K = K, c->D = D, c->LD = D + 1;
+  c->h_col_cov = col_cov;
+
+  HIPCHK(c->P.reserve((size_t)N * N));
+  HIPCHK(c->P0.reserve((size_t)N * N));
+  HIPCHK(c->clone_qp.reserve(7 * C));
+  HIPCHK(c->clone_qp0.reserve(7 * C));
+  HIPCHK(c->clone_fej.reserve(7 * C));
+  HIPCHK(c->calib_qp.reserve(7 * K));
+  HIPCHK(c->calib_qp0.reserve(7 * K));
+  HIPCHK(c->intr.reserve(8 * K));
+  HIPCHK(c->intr0.reserve(8 * K));
+  HIPCHK(c->fisheye.reserve(K));
+  HIPCHK(c->clone_cov.reserve(C));
+  HIPCHK(c->calib_cov.reserve(K));
+  HIPCHK(c->intr_cov.reserve(K));
+  HIPCHK(c->clone_col.reserve(C));
+  HIPCHK(c->calib_col.reserve(K));
+  HIPCHK(c->intr_col.reserve(K));
+  HIPCHK(c->col_cov.reserve(D));
+  HIPCHK(c->col_kind.reserve(D));
+  HIPCHK(c->col_sub.reserve(D));
+  HIPCHK(c->col_var.reserve(D));
+  HIPCHK(c->tab_clone.reserve(24 * C));
+  HIPCHK(c->tab_cam.reserve(12 * K));
+  HIPCHK(c->tab_cc.reserve((size_t)12 * K * C));
+  HIPCHK(c->Mt.reserve((size_t)D * N));
+  HIPCHK(c->Aaug.reserve((size_t)D * (D + N + 1)));
+  HIPCHK(c->dx.reserve(N));
+  HIPCHK(c->flags.reserve(4));
+
+  hipStream_t s = c->stream;
+  // calibration ids the kernels see: -1 when that calibration is not being estimated
+  std::vector<int32_t> calib_cov(K), intr_cov(K);
+  for (int k = 0; k < K; k++) {
+    calib_cov[k] = (c->dopt.do_calib_pose && st->calib_cov_id[k] >= 0) ? st->calib_cov_id[k] : -1;
+    intr_cov[k] = (c->dopt.do_calib_intr && st->intr_cov_id[k] >= 0) ? st->intr_cov_id[k] : -1;
+  }
+  HIPCHK(upload(c->P.p, st->P, sizeof(double) * N * N, s));
+  HIPCHK(upload(c->clone_qp.p, st->clone_q_p, sizeof(double) * 7 * C, s));
+  HIPCHK(upload(c->clone_fej.p, st->clone_q_p_fej, sizeof(double) * 7 * C, s));
+  HIPCHK(upload(c->calib_qp.p, st->calib_q_p, sizeof(double) * 7 * K, s));
+  HIPCHK(upload(c->intr.p, st->intrinsics, sizeof(double) * 8 * K, s));
+  HIPCHK(upload(c->fisheye.p, st->cam_is_fisheye, K, s));
+  HIPCHK(upload(c->clone_cov.p, st->clone_cov_id, sizeof(int32_t) * C, s));
+  HIPCHK(upload(c->calib_cov.p, calib_cov.data(), sizeof(int32_t) * K, s));
+  HIPCHK(upload(c->intr_cov.p, intr_cov.data(), sizeof(int32_t) * K, s));
+  HIPCHK(upload(c->clone_col.p, clone_col.data(), sizeof(int32_t) * C, s));
+  HIPCHK(upload(c->calib_col.p, calib_col.data(), sizeof(int32_t) * K, s));
+  HIPCHK(upload(c->intr_col.p, intr_col.data(), sizeof(int32_t) * K, s));
+  HIPCHK(upload(c->col_cov.p, col_cov.data(), sizeof(int32_t) * D, s));
+  HIPCHK(upload(c->col_kind.p, col_kind.data(), D, s));
+  HIPCHK(upload(c->col_sub.p, col_sub.data(), D, s));
+  HIPCHK(upload(c->col_var.p, col_var.data(), sizeof(uint16_t) * D, s));
+  // the pageable-host copies above must complete before the caller's buffers may change
+  HIPCHK(hipStreamSynchronize(s));
+  // device-side copy of the prior for ovgpu_reset_state
+  HIPCHK(hipMemcpyAsync(c->P0.p, c->P.p, sizeof(double) * N * N, hipMemcpyDeviceToDevice, s));
+  HIPCHK(hipMemcpyAsync(c->clone_qp0.p, c->clone_qp.p, sizeof(double) * 7 * C, hipMemcpyDeviceToDevice, s));
+  HIPCHK(hipMemcpyAsync(c->calib_qp0.p, c->calib_qp.p, sizeof(double) * 7 * K, hipMemcpyDeviceToDevice, s));
+  HIPCHK(hipMemcpyAsync(c->intr0.p, c->intr.p, sizeof(double) * 8 * K, hipMemcpyDeviceToDevice, s));
+  int rc = launch_build_tables(c);
+  if (rc != OVGPU_OK) return rc;
+  c->have_state = true;
+  c->have_feats = false; // workspaces depend on D
+  return OVGPU_OK;
+}
+
+int ovgpu_reset_state(ovgpu_ctx *c) {
+  if (!c) return set_err(OVGPU_ERR_INVALID, "null ctx");
+  if (!c->have_state) return set_err(OVGPU_ERR_NO_STATE, "ovgpu_set_state was never called");
+  hipStream_t s = c->stream;
+  HIPCHK(hipMemcpyAsync(c->P.p, c->P0.p, sizeof(double) * c->N * c->N, hipMemcpyDeviceToDevice, s));
+  HIPCHK(hipMemcpyAsync(c->clone_qp.p, c->clone_qp0.p, sizeof(double) * 7 * c->C, hipMemcpyDeviceToDevice, s));
+  HIPCHK(hipMemcpyAsync(c->calib_qp.p, c->calib_qp0.p, sizeof(double) * 7 * c->K, hipMemcpyDeviceToDevice, s));
+  HIPCHK(hipMemcpyAsync(c->intr.p, c->intr0.p, sizeof(double) * 8 * c->K, hipMemcpyDeviceToDevice, s));
+  return launch_build_tables(c);
+}
+
+int ovgpu_set_features(ovgpu_ctx *c, const ovgpu_features_view *fv) {
+  if (!c || !fv) return set_err(OVGPU_ERR_INVALID, "null argument");
+  if (!c->have_state) return set_err(OVGPU_ERR_NO_STATE, "ovgpu_set_state must precede ovgpu_set_features");
+  if (fv->F < 0 || fv->M < 0) return set_err(OVGPU_ERR_INVALID, "negative sizes");
+  if (fv->F > 0 && (!fv->meas_offsets)) return set_err(OVGPU_ERR_INVALID, "null feature arrays");
+  if (fv->M > 0 && (!fv->uv || !fv->uvn || !fv->clone_idx || !fv->cam_idx)) return set_err(OVGPU_ERR_INVALID, "null measurement arrays");
+  HIPCHK(hipSetDevice(c->device));
+  const int F = fv->F, M = fv->M;
+  if (F > 0 && (fv->meas_offsets[0] != 0 || fv->meas_offsets[F] != M)) return set_err(OVGPU_ERR_INVALID, "meas_offsets must span [0, M]");
+  std::vector<uint16_t> cc(std::max(M, 1));
+  for (int i = 0; i < M; i++) {
+    const int cl = fv->clone_idx[i], cam = fv->cam_idx[i];
+    if (cl < 0 || cl >= c->C || cam < 0 || cam >= c->K) return set_err(OVGPU_ERR_INVALID, "measurement refers to an unknown clone / camera");
+    cc[i] = (uint16_t)((cam << 10) | cl);
+  }
+  std::vector<int64_t> row_off(F + 1, 0);
+  int m_max = 0;
+  for (int f = 0; f < F; f++) {
+    const int m = fv->meas_offsets[f + 1] - fv->meas_offsets[f];
+    if (m < 0) return set_err(OVGPU_ERR_INVALID, "meas_offsets not monotone");
+    m_max = std::max(m_max, m);
+    row_off[f + 1] = row_off[f] + (m >= 2 ? 2 * m - 3 : 0); // rows after the nullspace projection (UpdaterHelper.cpp:449-450)
+  }
+  c->F = F, c->M = M, c->m_max = m_max, c->rows_total = row_off[F];
+  c->h_offsets.assign(fv->meas_offsets, fv->meas_offsets + (F > 0 ? F + 1 : 0));
+  if (F == 0) c->h_offsets.assign(1, 0);
+
+  // chi2 table for dof 1 .. max(499, 2 m_max)  (UpdaterMSCKF.cpp:52-55; dof >= 500 is computed on the fly there, :216-222)
+  const int need = std::max(500, 2 * m_max + 1);
+  if ((int)c->h_chi2_table.size() < need) {
+    const int old = (int)c->h_chi2_table.size();
+    c->h_chi2_table.resize(need, 0.0);
+    for (int i = std::max(old, 1); i < need; i++) c->h_chi2_table[i] = chi2_quantile_95(i);
+  }
+  c->chi2_table_len = (int)c->h_chi2_table.size();
+  HIPCHK(c->chi2_table.reserve(c->chi2_table_len));
+
+  HIPCHK(c->meas_offsets.reserve(F + 1));
+  HIPCHK(c->meas_cc.reserve(M));
+  HIPCHK(c->uv.reserve((size_t)2 * M));
+  HIPCHK(c->uvn.reserve((size_t)2 * M));
+  HIPCHK(c->row_off.reserve(F + 1));
+  HIPCHK(c->pA.reserve((size_t)3 * F));
+  HIPCHK(c->pG.reserve((size_t)3 * F));
+  HIPCHK(c->chi2.reserve(F));
+  HIPCHK(c->chi2_thr.reserve(F));
+  HIPCHK(c->anchor.reserve(F));
+  HIPCHK(c->status.reserve(F));
+
+  // ---- per-feature kernel: LDS carve and (for long tracks) a global gate workspace
+  const size_t fixed = sys_lds_fixed_bytes(std::max(m_max, 1), c->row_stride, c->D);
+  int m_lds = 0;
+  if (fixed < (size_t)c->lds_limit) {
+    const size_t avail = (size_t)c->lds_limit - fixed;
+    while (m_lds < m_max && sys_gate_doubles(m_lds + 1) * sizeof(double) <= avail) m_lds++;
+  } else {
+    return set_err(OVGPU_ERR_CAPACITY, "track too long for the per-feature kernel's LDS row store");
+  }
+  c->m_lds_max = m_lds;
+  c->sys_lds_bytes = fixed + sys_gate_doubles(m_lds) * sizeof(double);
+  c->sys_grid = std::max(1, std::min(F, c->num_cu * 4));
+  if (m_lds < m_max) {
+    c->gate_ws_stride = (int64_t)sys_gate_doubles(m_max);
+    HIPCHK(c->gate_ws.reserve((size_t)c->gate_ws_stride * c->sys_grid));
+  } else {
+    c->gate_ws_stride = 0;
+  }
+  // ---- stacked system and TSQR accumulators
+  const int D = c->D, LD = c->LD;
+  HIPCHK(c->Hbig.reserve((size_t)std::max<int64_t>(c->rows_total, 1) * LD));
+  int W = 1;
+  {
+    const char *wenv = std::getenv("OVGPU_TSQR_W");
+    int64_t target = wenv ? std::atoll(wenv) : (c->rows_total + D - 1) / std::max(D, 1);
+    target = std::max<int64_t>(1, std::min<int64_t>(target, 512));
+    while (W < target) W <<= 1;
+  }
+  c->W = W;
+  HIPCHK(c->Rws.reserve((size_t)std::max(W, 16) * D * LD));
+
+  hipStream_t s = c->stream;
+  HIPCHK(upload(c->meas_offsets.p, fv->meas_offsets, sizeof(int32_t) * (F + 1), s));
+  HIPCHK(upload(c->meas_cc.p, cc.data(), sizeof(uint16_t) * M, s));
+  HIPCHK(upload(c->uv.p, fv->uv, sizeof(float) * 2 * M, s));
+  HIPCHK(upload(c->uvn.p, fv->uvn, sizeof(float) * 2 * M, s));
+  HIPCHK(upload(c->row_off.p, row_off.data(), sizeof(int64_t) * (F + 1), s));
+  HIPCHK(upload(c->chi2_table.p, c->h_chi2_table.data(), sizeof(double) * c->chi2_table_len, s));
+  HIPCHK(hipStreamSynchronize(s)); // host staging vectors go out of scope
+  c->have_feats = true;
+  return OVGPU_OK;
+}
+
+// ---------------------------------------------------------------------------
+// pipeline stages (all asynchronous on ctx->stream)
+// ---------------------------------------------------------------------------
+static int enqueue_triangulate(ovgpu_ctx *c) {
+  if (c->F == 0) return OVGPU_OK;
+  TriParams p;
+  p.F = c->F, p.C = c->C, p.K = c->K;
+  p.meas_offsets = c->meas_offsets.p, p.meas_cc = c->meas_cc.p, p.uvn = c->uvn.p, p.tab_cc = c->tab_cc.p;
+  p.p_FinA = c->pA.p, p.p_FinG = c->pG.p, p.anchor_meas = c->anchor.p, p.status = c->status.p;
+  p.opt = c->dopt;
+  const size_t lds = (size_t)c->K * c->C * 12 * sizeof(double);
+  hipLaunchKernelGGL(k_triangulate, dim3((c->F + 3) / 4), dim3(256), lds, c->stream, p);
+  HIPCHK(hipGetLastError());
+  return OVGPU_OK;
+}
+
+static int enqueue_system(ovgpu_ctx *c) {
+  if (c->F == 0) return OVGPU_OK;
+  SysParams p;
+  p.F = c->F, p.C = c->C, p.K = c->K, p.D = c->D, p.LD = c->LD, p.N = c->N;
+  p.meas_offsets = c->meas_offsets.p, p.meas_cc = c->meas_cc.p, p.uv = c->uv.p;
+  p.tab_clone = c->tab_clone.p, p.tab_cam = c->tab_cam.p, p.intr = c->intr.p, p.fisheye = c->fisheye.p;
+  p.clone_col = c->clone_col.p, p.calib_col = c->calib_col.p, p.intr_col = c->intr_col.p;
+  p.col_cov = c->col_cov.p, p.col_kind = c->col_kind.p, p.col_var = c->col_var.p, p.col_sub = c->col_sub.p;
+  p.P = c->P.p, p.p_FinG = c->pG.p, p.p_FinA = c->pA.p, p.anchor_meas = c->anchor.p;
+  p.status = c->status.p, p.chi2 = c->chi2.p, p.chi2_thresh = c->chi2_thr.p;
+  p.chi2_table = c->chi2_table.p, p.chi2_table_len = c->chi2_table_len;
+  p.row_off = c->row_off.p, p.Hbig = c->Hbig.p, p.ws = c->gate_ws.p, p.ws_stride = c->gate_ws_stride;
+  p.m_lds_max = c->m_lds_max, p.m_max = std::max(c->m_max, 1), p.row_stride = c->row_stride;
+  p.opt = c->dopt;
+  hipLaunchKernelGGL(k_system, dim3(c->sys_grid), dim3(SYS_NT), c->sys_lds_bytes, c->stream, p);
+  HIPCHK(hipGetLastError());
+  return OVGPU_OK;
+}
+
+static constexpr int QR_B = 32;
+
+// merges triangles Rws[0..G) pairwise until Rws[0] holds the result
+static int enqueue_merge_tree(ovgpu_ctx *c, int G) {
+  const int D = c->D, LD = c->LD;
+  const int nt = ((LD + 63) / 64) * 64;
+  for (int stride = 1; stride < G; stride <<= 1) {
+    const int pairs = (G - stride + 2 * stride - 1) / (2 * stride); // i = 0, 2s, 4s, ... with i + s < G
+    if (pairs <= 0) break;
+    QrAppendParams q;
+    q.D = D, q.LD = LD;
+    q.dst = c->Rws.p, q.dst_wg_stride = 2 * (int64_t)stride;
+    q.src = c->Rws.p + (size_t)stride * D * LD, q.src_wg_stride = 2 * (int64_t)stride * D * LD;
+    q.src_rows_per_wg = D, q.src_rows_total = D, q.triangular = 1, q.zero_dst = 0;
+    hipLaunchKernelGGL(k_qr_append<QR_B>, dim3(pairs), dim3(nt), 0, c->stream, q);
+    HIPCHK(hipGetLastError());
+  }
+  return OVGPU_OK;
+}
+
+static int enqueue_compress(ovgpu_ctx *c) {
+  const int D = c->D, LD = c->LD;
+  const int nt = ((LD + 63) / 64) * 64;
+  const int W = c->W;
+  int64_t rpw = (c->rows_total + W - 1) / W;
+  rpw = ((rpw + QR_B - 1) / QR_B) * QR_B;
+  if (rpw == 0) rpw = QR_B;
+  QrAppendParams q;
+  q.D = D, q.LD = LD;
+  q.dst = c->Rws.p, q.dst_wg_stride = 1;
+  q.src = c->Hbig.p, q.src_wg_stride = rpw * LD;
+  q.src_rows_per_wg = rpw, q.src_rows_total = c->rows_total, q.triangular = 0, q.zero_dst = 1;
+  hipLaunchKernelGGL(k_qr_append<QR_B>, dim3(W), dim3(nt), 0, c->stream, q);
+  HIPCHK(hipGetLastError());
+  return enqueue_merge_tree(c, W);
+}
+
+static int enqueue_ekf(ovgpu_ctx *c) {
+  EkfParams p;
+  p.N = c->N, p.D = c->D, p.LD = c->LD, p.LA = c->D + c->N + 1;
+  p.R = c->Rws.p, p.col_cov = c->col_cov.p, p.P = c->P.p, p.Mt = c->Mt.p, p.A = c->Aaug.p, p.dx = c->dx.p, p.flags = c->flags.p;
+  p.sigma2 = c->dopt.sigma_pix_sq;
+  hipStream_t s = c->stream;
+  HIPCHK(hipMemsetAsync(c->flags.p, 0, 4 * sizeof(int32_t), s));
+  const int tm = (p.D + 15) / 16, tn = (p.N + 15) / 16;
+  hipLaunchKernelGGL(k_ekf_mt, dim3((tm * tn + 3) / 4), dim3(256), 0, s, p);
+  hipLaunchKernelGGL(k_ekf_s, dim3((tm * tm + 3) / 4), dim3(256), 0, s, p);
+  const size_t lds = (size_t)(CH_NB * CH_NB + CH_NB * p.LA) * sizeof(double);
+  if (lds > (size_t)c->lds_limit) return set_err(OVGPU_ERR_CAPACITY, "state too large for the Cholesky panel in LDS");
+  hipLaunchKernelGGL(k_ekf_chol, dim3(1), dim3(1024), lds, s, p);
+  hipLaunchKernelGGL(k_ekf_pupdate, dim3((tn * tn + 3) / 4), dim3(256), 0, s, p);
+  hipLaunchKernelGGL(k_ekf_dx, dim3((p.N + 255) / 256), dim3(256), 0, s, p);
+  const int n = std::max(c->C, c->K);
+  hipLaunchKernelGGL(k_boxplus, dim3((n + 255) / 256), dim3(256), 0, s, c->C, c->K, c->dx.p, c->clone_cov.p, c->calib_cov.p, c->intr_cov.p,
+                     c->clone_qp.p, c->calib_qp.p, c->intr.p);
+  HIPCHK(hipGetLastError());
+  return launch_build_tables(c);
+}
+
+static EventPair *next_events(ovgpu_ctx *c, std::vector<EventPair> &v, size_t idx) {
+  if (idx >= v.size()) {
+    if (v.size() >= 8192) return nullptr;
+    v.resize(idx + 1);
+  }
+  EventPair &e = v[idx];
+  if (!e.a) {
+    if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) return nullptr;
+  }
+  return &e;
+}
+
+enum { STAGE_LOCAL = 1, STAGE_EKF = 2 };
+
+static int enqueue_pipeline(ovgpu_ctx *c, int stages) {
+  if (!c->have_state) return set_err(OVGPU_ERR_NO_STATE, "ovgpu_set_state was never called");
+  if (!c->have_feats) return set_err(OVGPU_ERR_NO_STATE, "ovgpu_set_features was never called (or the state changed since)");
+  HIPCHK(hipSetDevice(c->device));
+  EventPair *eu = nullptr, *ec = nullptr;
+  if (c->timing) {
+    eu = next_events(c, c->ev_update, c->ev_used);
+    ec = next_events(c, c->ev_compress, c->ev_used);
+    if (eu && ec) c->ev_used++;
+    else eu = ec = nullptr;
+  }
+  if (eu) HIPCHK(hipEventRecord(eu->a, c->stream));
+  int rc = OVGPU_OK;
+  if (stages & STAGE_LOCAL) {
+    if ((rc = enqueue_triangulate(c)) != OVGPU_OK) return rc;
+    if ((rc = enqueue_system(c)) != OVGPU_OK) return rc;
+    if (ec) HIPCHK(hipEventRecord(ec->a, c->stream));
+    if ((rc = enqueue_compress(c)) != OVGPU_OK) return rc;
+    if (ec) HIPCHK(hipEventRecord(ec->b, c->stream));
+  }
+  if (stages & STAGE_EKF) {
+    if ((rc = enqueue_ekf(c)) != OVGPU_OK) return rc;
+  }
+  if (eu) HIPCHK(hipEventRecord(eu->b, c->stream));
+  return OVGPU_OK;
+}
+
+static int read_feature_outputs(ovgpu_ctx *c, int32_t *feat_status, double *chi2, double *chi2_thresh, double *p_FinG, ovgpu_update_stats *stats) {
+  const int F = c->F;
+  hipStream_t s = c->stream;
+  std::vector<int32_t> st(F);
+  if (F > 0) HIPCHK(hipMemcpyAsync(st.data(), c->status.p, sizeof(int32_t) * F, hipMemcpyDeviceToHost, s));
+  if (chi2 && F > 0) HIPCHK(hipMemcpyAsync(chi2, c->chi2.p, sizeof(double) * F, hipMemcpyDeviceToHost, s));
+  if (chi2_thresh && F > 0) HIPCHK(hipMemcpyAsync(chi2_thresh, c->chi2_thr.p, sizeof(double) * F, hipMemcpyDeviceToHost, s));
+  if (p_FinG && F > 0) HIPCHK(hipMemcpyAsync(p_FinG, c->pG.p, sizeof(double) * 3 * F, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  const double qnan = std::nan("");
+  int n_used = 0;
+  int64_t rows = 0;
+  const std::vector<int32_t> &offs = c->h_offsets;
+  for (int f = 0; f < F; f++) {
+    if (st[f] == OVGPU_FEAT_USED) {
+      n_used++;
+      rows += 2 * (offs[f + 1] - offs[f]) - 3;
+    }
+    // the gate is only reached by features that triangulated
+    if (st[f] != OVGPU_FEAT_USED && st[f] != OVGPU_FEAT_CHI2_REJECTED) {
+      if (chi2) chi2[f] = qnan;
+      if (chi2_thresh) chi2_thresh[f] = qnan;
+    }
+  }
+  if (feat_status) std::memcpy(feat_status, st.data(), sizeof(int32_t) * F);
+  if (stats) {
+    stats->n_used = n_used;
+    stats->n_rows = (int32_t)rows;
+    stats->D = c->D;
+    stats->n_rows_comp = rows > 0 ? c->D : 0;
+  }
+  return OVGPU_OK;
+}
+
+static void fill_times(ovgpu_ctx *c, ovgpu_update_stats *stats) {
+  if (!stats || !c->timing || c->ev_used == 0) return;
+  float ms = 0.f;
+  EventPair &eu = c->ev_update[c->ev_used - 1];
+  EventPair &ec = c->ev_compress[c->ev_used - 1];
+  if (hipEventElapsedTime(&ms, eu.a, eu.b) == hipSuccess) stats->ms_total = ms;
+  if (hipEventElapsedTime(&ms, ec.a, ec.b) == hipSuccess) stats->ms_compress = ms;
+  if (hipEventElapsedTime(&ms, eu.a, ec.a) == hipSuccess) stats->ms_system = ms; // triangulate + system
+  if (hipEventElapsedTime(&ms, ec.b, eu.b) == hipSuccess) stats->ms_update = ms;
+}
+
+int ovgpu_triangulate(ovgpu_ctx *c, double *p_FinA, double *p_FinG, int32_t *anchor_meas, int32_t *status) {
+  if (!c) return set_err(OVGPU_ERR_INVALID, "null ctx");
+  if (!c->have_state || !c->have_feats) return set_err(OVGPU_ERR_NO_STATE, "state / features not set");
+  HIPCHK(hipSetDevice(c->device));
+  int rc = enqueue_triangulate(c);
+  if (rc != OVGPU_OK) return rc;
+  const int F = c->F;
+  hipStream_t s = c->stream;
+  if (F > 0) {
+    if (p_FinA) HIPCHK(hipMemcpyAsync(p_FinA, c->pA.p, sizeof(double) * 3 * F, hipMemcpyDeviceToHost, s));
+    if (p_FinG) HIPCHK(hipMemcpyAsync(p_FinG, c->pG.p, sizeof(double) * 3 * F, hipMemcpyDeviceToHost, s));
+    if (anchor_meas) HIPCHK(hipMemcpyAsync(anchor_meas, c->anchor.p, sizeof(int32_t) * F, hipMemcpyDeviceToHost, s));
+    if (status) HIPCHK(hipMemcpyAsync(status, c->status.p, sizeof(int32_t) * F, hipMemcpyDeviceToHost, s));
+  }
+  HIPCHK(hipStreamSynchronize(s));
+  return OVGPU_OK;
+}
+
+static int finish_update(ovgpu_ctx *c, double *dx, double *P_out, ovgpu_update_stats *stats) {
+  hipStream_t s = c->stream;
+  int32_t flags[4] = {0, 0, 0, 0};
+  HIPCHK(hipMemcpyAsync(flags, c->flags.p, sizeof(flags), hipMemcpyDeviceToHost, s));
+  if (dx) HIPCHK(hipMemcpyAsync(dx, c->dx.p, sizeof(double) * c->N, hipMemcpyDeviceToHost, s));
+  if (P_out) HIPCHK(hipMemcpyAsync(P_out, c->P.p, sizeof(double) * c->N * c->N, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  int status = OVGPU_OK;
+  if (flags[0]) status = OVGPU_ERR_NOT_SPD;
+  else if (flags[1]) status = OVGPU_ERR_NEGATIVE_DIAGONAL;
+  if (stats) stats->status = status;
+  fill_times(c, stats);
+  if (status != OVGPU_OK) return set_err(status, status == OVGPU_ERR_NOT_SPD ? "innovation covariance not SPD" : "negative covariance diagonal after the update");
+  return OVGPU_OK;
+}
+
+int ovgpu_msckf_update(ovgpu_ctx *c, int32_t *feat_status, double *chi2, double *chi2_thresh, double *p_FinG, double *dx, double *P_out,
+                       ovgpu_update_stats *stats) {
+  if (!c) return set_err(OVGPU_ERR_INVALID, "null ctx");
+  if (stats) std::memset(stats, 0, sizeof(*stats));
+  int rc = enqueue_pipeline(c, STAGE_LOCAL | STAGE_EKF);
+  if (rc != OVGPU_OK) return rc;
+  rc = read_feature_outputs(c, feat_status, chi2, chi2_thresh, p_FinG, stats);
+  if (rc != OVGPU_OK) return rc;
+  return finish_update(c, dx, P_out, stats);
+}
+
+int ovgpu_msckf_update_async(ovgpu_ctx *c) {
+  if (!c) return set_err(OVGPU_ERR_INVALID, "null ctx");
+  return enqueue_pipeline(c, STAGE_LOCAL | STAGE_EKF);
+}
+
+int ovgpu_msckf_compress(ovgpu_ctx *c, int32_t *feat_status, double *chi2, double *chi2_thresh, double *p_FinG, int32_t *D_out, int32_t *rows_out,
+                         int32_t *col_cov_id, double *H, double *r, ovgpu_update_stats *stats) {
+  if (!c) return set_err(OVGPU_ERR_INVALID, "null ctx");
+  if (stats) std::memset(stats, 0, sizeof(*stats));
+  int rc = enqueue_pipeline(c, STAGE_LOCAL);
+  if (rc != OVGPU_OK) return rc;
+  ovgpu_update_stats local;
+  std::memset(&local, 0, sizeof(local));
+  rc = read_feature_outputs(c, feat_status, chi2, chi2_thresh, p_FinG, &local);
+  if (rc != OVGPU_OK) return rc;
+  const int D = c->D, LD = c->LD;
+  std::vector<double> tri((size_t)D * LD);
+  HIPCHK(hipMemcpy(tri.data(), c->Rws.p, sizeof(double) * D * LD, hipMemcpyDeviceToHost));
+  const int rows = local.n_rows > 0 ? D : 0;
+  if (H)
+    for (int i = 0; i < rows; i++) std::memcpy(H + (size_t)i * D, tri.data() + (size_t)i * LD, sizeof(double) * D);
+  if (r)
+    for (int i = 0; i < rows; i++) r[i] = tri[(size_t)i * LD + D];
+  if (col_cov_id) std::memcpy(col_cov_id, c->h_col_cov.data(), sizeof(int32_t) * D);
+  if (D_out) *D_out = D;
+  if (rows_out) *rows_out = rows;
+  fill_times(c, &local);
+  if (stats) *stats = local;
+  return OVGPU_OK;
+}
+
+int ovgpu_get_state(ovgpu_ctx *c, double *P, double *clone_q_p, double *calib_q_p, double *intrinsics) {
+  if (!c) return set_err(OVGPU_ERR_INVALID, "null ctx");
+  if (!c->have_state) return set_err(OVGPU_ERR_NO_STATE, "ovgpu_set_state was never called");
+  HIPCHK(hipSetDevice(c->device));
+  hipStream_t s = c->stream;
+  if (P) HIPCHK(hipMemcpyAsync(P, c->P.p, sizeof(double) * c->N * c->N, hipMemcpyDeviceToHost, s));
+  if (clone_q_p) HIPCHK(hipMemcpyAsync(clone_q_p, c->clone_qp.p, sizeof(double) * 7 * c->C, hipMemcpyDeviceToHost, s));
+  if (calib_q_p) HIPCHK(hipMemcpyAsync(calib_q_p, c->calib_qp.p, sizeof(double) * 7 * c->K, hipMemcpyDeviceToHost, s));
+  if (intrinsics) HIPCHK(hipMemcpyAsync(intrinsics, c->intr.p, sizeof(double) * 8 * c->K, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  return OVGPU_OK;
+}
+
+int ovgpu_triangle_len(ovgpu_ctx *c, int64_t *n_doubles) {
+  if (!c || !n_doubles) return set_err(OVGPU_ERR_INVALID, "null argument");
+  if (!c->have_state) return set_err(OVGPU_ERR_NO_STATE, "ovgpu_set_state was never called");
+  *n_doubles = (int64_t)c->D * c->LD;
+  return OVGPU_OK;
+}
+
+int ovgpu_msckf_local(ovgpu_ctx *c, int32_t *feat_status, double *chi2, double *chi2_thresh, double *p_FinG, void *tri_dev,
+                      ovgpu_update_stats *stats) {
+  if (!c) return set_err(OVGPU_ERR_INVALID, "null ctx");
+  if (stats) std::memset(stats, 0, sizeof(*stats));
+  int rc = enqueue_pipeline(c, STAGE_LOCAL);
+  if (rc != OVGPU_OK) return rc;
+  if (tri_dev) HIPCHK(hipMemcpyAsync(tri_dev, c->Rws.p, sizeof(double) * c->D * c->LD, hipMemcpyDeviceToDevice, c->stream));
+  if (feat_status || chi2 || chi2_thresh || p_FinG || stats) {
+    rc = read_feature_outputs(c, feat_status, chi2, chi2_thresh, p_FinG, stats);
+    if (rc != OVGPU_OK) return rc;
+    fill_times(c, stats);
+  } else {
+    HIPCHK(hipStreamSynchronize(c->stream)); // tri_dev is consumed by another library's stream (RCCL)
+  }
+  return OVGPU_OK;
+}
+
+int ovgpu_msckf_merge_update(ovgpu_ctx *c, const void *tris_dev, int G, double *dx, double *P_out, ovgpu_update_stats *stats) {
+  if (!c || !tris_dev || G < 1) return set_err(OVGPU_ERR_INVALID, "bad argument");
+  if (!c->have_state) return set_err(OVGPU_ERR_NO_STATE, "ovgpu_set_state was never called");
+  HIPCHK(hipSetDevice(c->device));
+  const size_t tri = (size_t)c->D * c->LD;
+  HIPCHK(c->Rws.reserve(std::max<size_t>((size_t)G, 16) * tri));
+  HIPCHK(hipMemcpyAsync(c->Rws.p, tris_dev, sizeof(double) * tri * G, hipMemcpyDeviceToDevice, c->stream));
+  int rc = enqueue_merge_tree(c, G);
+  if (rc != OVGPU_OK) return rc;
+  rc = enqueue_ekf(c);
+  if (rc != OVGPU_OK) return rc;
+  if (stats) {
+    std::memset(stats, 0, sizeof(*stats));
+    stats->D = c->D;
+    stats->n_rows_comp = c->D;
+  }
+  ovgpu_update_stats *no_times = nullptr;
+  (void)no_times;
+  hipStream_t s = c->stream;
+  int32_t flags[4] = {0, 0, 0, 0};
+  HIPCHK(hipMemcpyAsync(flags, c->flags.p, sizeof(flags), hipMemcpyDeviceToHost, s));
+  if (dx) HIPCHK(hipMemcpyAsync(dx, c->dx.p, sizeof(double) * c->N, hipMemcpyDeviceToHost, s));
+  if (P_out) HIPCHK(hipMemcpyAsync(P_out, c->P.p, sizeof(double) * c->N * c->N, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  int status = flags[0] ? OVGPU_ERR_NOT_SPD : (flags[1] ? OVGPU_ERR_NEGATIVE_DIAGONAL : OVGPU_OK);
+  if (stats) stats->status = status;
+  if (status != OVGPU_OK) return set_err(status, "EKF update failed");
+  return OVGPU_OK;
+}
+
+int ovgpu_synchronize(ovgpu_ctx *c) {
+  if (!c) return set_err(OVGPU_ERR_INVALID, "null ctx");
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return OVGPU_OK;
+}
+
+uint64_t ovgpu_stream(ovgpu_ctx *c) { return c ? (uint64_t)(uintptr_t)c->stream : 0; }
+
+int ovgpu_kernel_times(ovgpu_ctx *c, int reset, double *ms_compress_avg, double *ms_update_avg, int64_t *n_launches) {
+  if (!c) return set_err(OVGPU_ERR_INVALID, "null ctx");
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  double sc = 0, su = 0;
+  int64_t n = 0;
+  for (size_t i = 0; i < c->ev_used; i++) {
+    float a = 0.f, b = 0.f;
+    if (hipEventElapsedTime(&a, c->ev_compress[i].a, c->ev_compress[i].b) != hipSuccess) continue;
+    if (hipEventElapsedTime(&b, c->ev_update[i].a, c->ev_update[i].b) != hipSuccess) continue;
+    sc += a, su += b, n++;
+  }
+  if (ms_compress_avg) *ms_compress_avg = n ? sc / n : 0.0;
+  if (ms_update_avg) *ms_update_avg = n ? su / n : 0.0;
+  if (n_launches) *n_launches = n;
+  if (reset) c->ev_used = 0;
+  return OVGPU_OK;
+}
+
+} // extern "C"

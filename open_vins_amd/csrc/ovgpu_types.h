@@ -1,0 +1,77 @@
+// ovgpu_types.h — device-side parameter blocks shared by the kernels and the host API.
+#pragma once
+#include <stdint.h>
+
+#include "../../include/ovgpu.h"
+
+namespace ovg {
+
+// FeatureInitializerOptions + UpdaterOptions subset, passed by value to kernels
+struct DevOptions {
+  double chi2_multipler, sigma_pix_sq;
+  double init_lamda, max_lamda, min_dx, min_dcost, lam_mult;
+  double min_dist, max_dist, max_baseline, max_cond_number;
+  int triangulate_1d, refine_features, max_runs;
+  int do_fej, do_calib_pose, do_calib_intr, feat_rep;
+};
+
+// packed (camera, clone) code of one measurement: cam << 10 | clone
+static constexpr int OVG_MAX_CLONES = 1024;
+static constexpr int OVG_MAX_CAMS = 64;
+
+struct TriParams {
+  int F, C, K;
+  const int32_t *meas_offsets; // [F+1]
+  const uint16_t *meas_cc;     // [M]
+  const float *uvn;            // [2M]
+  const double *tab_cc;        // [K*C*12]
+  double *p_FinA, *p_FinG;     // [3F]
+  int32_t *anchor_meas;        // [F]
+  int32_t *status;             // [F]
+  DevOptions opt;
+};
+
+// column kinds of the canonical stacked-Jacobian column order
+enum { COL_CLONE = 0, COL_CALIB_POSE = 1, COL_CALIB_INTR = 2 };
+
+struct SysParams {
+  int F, C, K, D, LD, N;
+  const int32_t *meas_offsets;
+  const uint16_t *meas_cc;
+  const float *uv;
+  const double *tab_clone; // [C*24]
+  const double *tab_cam;   // [K*12]
+  const double *intr;      // [K*8]
+  const uint8_t *fisheye;  // [K]
+  const int32_t *clone_col, *calib_col, *intr_col; // first column of each variable or -1
+  const int32_t *col_cov;  // [D] covariance index of each column
+  const uint8_t *col_kind; // [D]
+  const uint16_t *col_var; // [D] clone / camera index
+  const uint8_t *col_sub;  // [D] offset inside the variable
+  const double *P;         // [N*N]
+  const double *p_FinG, *p_FinA;
+  const int32_t *anchor_meas;
+  int32_t *status;
+  double *chi2, *chi2_thresh;
+  const double *chi2_table; // [table_len], index = dof
+  int chi2_table_len;
+  const int64_t *row_off;   // [F+1] first output row of each feature
+  double *Hbig;             // [rows_total * LD]
+  double *ws;               // global workspace for the gate matrix when it does not fit LDS
+  int64_t ws_stride;        // doubles per workgroup
+  int m_lds_max;            // largest track length whose gate matrix is LDS-resident
+  int m_max;                // largest track length in the batch
+  int row_stride;           // doubles per measurement in the LDS row store (48, or 72 with anchored reps)
+  DevOptions opt;
+};
+
+struct CompressParams {
+  int D, LD;
+  int64_t rows_total;
+  const double *Hbig;
+  double *Rws;       // [W * D * LD] per-worker triangles
+  int W;             // workers in the leaf phase
+  int64_t rows_per_worker;
+};
+
+} // namespace ovg

@@ -1,0 +1,162 @@
+"""Thin Python binding of the C ABI, named after the reference classes it stands in for.
+
+The host language of the reference is C++; the drop-in C++ shim (same class names and
+signatures as ov_msckf::UpdaterMSCKF / ov_core::FeatureInitializer) lives in
+open_vins_amd/shim/.  This module only exists so that tests and bench.py can drive the very
+same C entry points from Python; it contains no arithmetic.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+
+
+def _dp(a):
+    return a.ctypes.data_as(capi.c_double_p) if a is not None else None
+
+
+def _ip(a):
+    return a.ctypes.data_as(capi.c_int32_p) if a is not None else None
+
+
+class UpdaterMSCKF:
+    """ov_msckf::UpdaterMSCKF (ov_msckf/src/update/UpdaterMSCKF.h:60-78) on one MI355X.
+
+    ``options`` carries UpdaterOptions + FeatureInitializerOptions + the StateOptions subset
+    (capi.default_options).  The constructor builds the chi2 table and the feature initializer
+    exactly like UpdaterMSCKF.cpp:42-56 does — inside ovgpu_create.
+    """
+
+    def __init__(self, options: capi.Options | None = None, device: int = 0):
+        self.lib = capi.load()
+        self.options = options if options is not None else capi.default_options()
+        self._ctx = C.c_void_p()
+        capi.check(self.lib.ovgpu_create(C.byref(self.options), int(device), C.byref(self._ctx)), "ovgpu_create")
+        self._views = None
+
+    def close(self):
+        if getattr(self, "_ctx", None) is not None and self._ctx:
+            self.lib.ovgpu_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- inputs ---------------------------------------------------------
+    def set_problem(self, prob):
+        """Uploads state + features of a synth.Problem-like snapshot (kept resident in HBM)."""
+        self._views = capi.Views(prob)
+        capi.check(self.lib.ovgpu_set_state(self._ctx, C.byref(self._views.state)), "ovgpu_set_state")
+        capi.check(self.lib.ovgpu_set_features(self._ctx, C.byref(self._views.features)), "ovgpu_set_features")
+        self.F, self.N = self._views.features.F, self._views.state.N
+        self.Cn, self.K = self._views.state.C, self._views.state.K
+
+    def set_features(self, prob):
+        v = capi.Views(prob)
+        capi.check(self.lib.ovgpu_set_features(self._ctx, C.byref(v.features)), "ovgpu_set_features")
+        self._views_feat = v
+        self.F = v.features.F
+
+    def reset_state(self):
+        capi.check(self.lib.ovgpu_reset_state(self._ctx), "ovgpu_reset_state")
+
+    # ---- ov_core::FeatureInitializer ------------------------------------
+    def triangulate(self):
+        F = self.F
+        out = dict(p_FinA=np.zeros((F, 3)), p_FinG=np.zeros((F, 3)), anchor_meas=np.zeros(F, np.int32), status=np.zeros(F, np.int32))
+        capi.check(self.lib.ovgpu_triangulate(self._ctx, _dp(out["p_FinA"]), _dp(out["p_FinG"]), _ip(out["anchor_meas"]), _ip(out["status"])),
+                   "ovgpu_triangulate")
+        return out
+
+    # ---- UpdaterMSCKF::update -------------------------------------------
+    def update(self, check=True):
+        F, N = self.F, self.N
+        out = dict(feat_status=np.zeros(F, np.int32), chi2=np.zeros(F), chi2_thresh=np.zeros(F), p_FinG=np.zeros((F, 3)),
+                   dx=np.zeros(N), P=np.zeros((N, N)))
+        stats = capi.UpdateStats()
+        rc = self.lib.ovgpu_msckf_update(self._ctx, _ip(out["feat_status"]), _dp(out["chi2"]), _dp(out["chi2_thresh"]), _dp(out["p_FinG"]),
+                                         _dp(out["dx"]), _dp(out["P"]), C.byref(stats))
+        out["rc"] = rc
+        if check:
+            capi.check(rc, "ovgpu_msckf_update")
+        out["stats"] = stats.as_dict()
+        out.update(self.get_state(P=False))
+        return out
+
+    def compress(self):
+        """Mode A: returns the compressed (H, r) for the stock StateHelper::EKFUpdate."""
+        F = self.F
+        Dmax = 6 * self.Cn + 14 * self.K
+        out = dict(feat_status=np.zeros(F, np.int32), chi2=np.zeros(F), chi2_thresh=np.zeros(F), p_FinG=np.zeros((F, 3)))
+        H = np.zeros((Dmax, Dmax))
+        r = np.zeros(Dmax)
+        cols = np.zeros(Dmax, np.int32)
+        D, rows = C.c_int32(0), C.c_int32(0)
+        stats = capi.UpdateStats()
+        capi.check(self.lib.ovgpu_msckf_compress(self._ctx, _ip(out["feat_status"]), _dp(out["chi2"]), _dp(out["chi2_thresh"]), _dp(out["p_FinG"]),
+                                                 C.byref(D), C.byref(rows), _ip(cols), _dp(H), _dp(r), C.byref(stats)), "ovgpu_msckf_compress")
+        d, n = D.value, rows.value
+        out["D"], out["rows"] = d, n
+        out["H"] = np.ascontiguousarray(H.reshape(-1)[: n * d].reshape(n, d))
+        out["r"] = r[:n].copy()
+        out["col_cov_id"] = cols[:d].copy()
+        out["stats"] = stats.as_dict()
+        return out
+
+    def get_state(self, P=True):
+        out = dict(clone_q_p=np.zeros((self.Cn, 7)), calib_q_p=np.zeros((self.K, 7)), intrinsics=np.zeros((self.K, 8)))
+        Pm = np.zeros((self.N, self.N)) if P else None
+        capi.check(self.lib.ovgpu_get_state(self._ctx, _dp(Pm), _dp(out["clone_q_p"]), _dp(out["calib_q_p"]), _dp(out["intrinsics"])),
+                   "ovgpu_get_state")
+        if P:
+            out["P"] = Pm
+        return out
+
+    # ---- feature-sharded multi-GPU update ----------------
+    def triangle_len(self):
+        n = C.c_int64(0)
+        capi.check(self.lib.ovgpu_triangle_len(self._ctx, C.byref(n)), "ovgpu_triangle_len")
+        return n.value
+
+    def local(self, tri_dev_ptr=None, want_outputs=True):
+        F = self.F
+        out = dict(feat_status=np.zeros(F, np.int32), chi2=np.zeros(F), chi2_thresh=np.zeros(F), p_FinG=np.zeros((F, 3)))
+        stats = capi.UpdateStats()
+        if want_outputs:
+            rc = self.lib.ovgpu_msckf_local(self._ctx, _ip(out["feat_status"]), _dp(out["chi2"]), _dp(out["chi2_thresh"]), _dp(out["p_FinG"]),
+                                            C.c_void_p(tri_dev_ptr) if tri_dev_ptr else None, C.byref(stats))
+        else:
+            rc = self.lib.ovgpu_msckf_local(self._ctx, None, None, None, None, C.c_void_p(tri_dev_ptr) if tri_dev_ptr else None, None)
+        capi.check(rc, "ovgpu_msckf_local")
+        out["stats"] = stats.as_dict()
+        return out
+
+    def merge_update(self, tris_dev_ptr, G, want_outputs=True):
+        N = self.N
+        out = dict(dx=np.zeros(N), P=np.zeros((N, N)))
+        stats = capi.UpdateStats()
+        if want_outputs:
+            rc = self.lib.ovgpu_msckf_merge_update(self._ctx, C.c_void_p(tris_dev_ptr), int(G), _dp(out["dx"]), _dp(out["P"]), C.byref(stats))
+        else:
+            rc = self.lib.ovgpu_msckf_merge_update(self._ctx, C.c_void_p(tris_dev_ptr), int(G), None, None, None)
+        capi.check(rc, "ovgpu_msckf_merge_update")
+        out["stats"] = stats.as_dict()
+        return out
+
+    # ---- benchmarking hooks ---------------------------------------------
+    def update_async(self):
+        capi.check(self.lib.ovgpu_msckf_update_async(self._ctx), "ovgpu_msckf_update_async")
+
+    def synchronize(self):
+        capi.check(self.lib.ovgpu_synchronize(self._ctx), "ovgpu_synchronize")
+
+    def kernel_times(self, reset=True):
+        a, b, n = C.c_double(0), C.c_double(0), C.c_int64(0)
+        capi.check(self.lib.ovgpu_kernel_times(self._ctx, 1 if reset else 0, C.byref(a), C.byref(b), C.byref(n)), "ovgpu_kernel_times")
+        return dict(ms_compress=a.value, ms_update=b.value, launches=n.value)

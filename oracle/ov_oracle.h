@@ -1,0 +1,100 @@
+/*
+ * ov_oracle.h — C ABI of the CPU oracle.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This is a float64 CPU restatement of the
+ * reference algorithm (rpng/open_vins v2.7) for the MSCKF / SLAM feature
+ * update path.  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may load it; the product (open_vins_amd/, libovgpu.so)
+ * never links, imports or calls anything in oracle/.
+ *
+ * PARITY UNPINNED: the reference ships no golden vectors / known-answer tests
+ * for this path and cannot be compiled here (Eigen, Boost, OpenCV absent), so
+ * the oracle is pinned only by (i) line-by-line restatement (each function
+ * cites the reference file:line), (ii) independent numpy/scipy invariants in
+ * tests/test_oracle_*.py.  See DESIGN.md §3.
+ *
+ * It shares the POD views of include/ovgpu.h so that tests feed identical
+ * inputs to both sides.
+ */
+#ifndef OV_ORACLE_H
+#define OV_ORACLE_H
+#include "../include/ovgpu.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* boost::math::quantile(chi_squared(dof), 0.95) — UpdaterMSCKF.cpp:52-55 */
+double oracle_chi2_quantile_95(int dof);
+
+/* CamRadtan / CamEqui distort_d (CamBase.h:130-135 with the float casts) and
+ * compute_distort_jacobian.  cam_d[8], uv_norm[2] -> uv_dist[2],
+ * dz_dzn[4] (2x2), dz_dzeta[16] (2x8).                                      */
+void oracle_cam_distort(const double *cam_d, int is_fisheye, const double *uv_norm,
+                        double *uv_dist, double *dz_dzn, double *dz_dzeta);
+
+/* Eigen::JacobiRotation::makeGivens(p, q) -> c, s (real case). */
+void oracle_make_givens(double p, double q, double *c, double *s);
+
+/* UpdaterHelper::nullspace_project_inplace (UpdaterHelper.cpp:426-454).
+ * H_f [rows x nf], H_x [rows x cols], res [rows] row-major, in place; the
+ * projected system is rows nf..rows-1.                                      */
+void oracle_nullspace_project(double *H_f, double *H_x, double *res, int rows,
+                              int nf, int cols);
+
+/* UpdaterHelper::measurement_compress_inplace (UpdaterHelper.cpp:456-487).
+ * Returns the new number of rows (rows if rows <= cols).                    */
+int oracle_measurement_compress(double *H_x, double *res, int rows, int cols);
+
+/* StateHelper::EKFUpdate (StateHelper.cpp:116-197) on a covariance P[N*N]
+ * with H [rows x D] whose column j maps to covariance index col_cov_id[j],
+ * R = sigma2 * I.  P is updated in place, dx[N] is returned.
+ * Returns OVGPU_OK / OVGPU_ERR_NEGATIVE_DIAGONAL / OVGPU_ERR_NOT_SPD.       */
+int oracle_ekf_update(double *P, int N, const double *H, const double *res,
+                      int rows, int D, const int32_t *col_cov_id, double sigma2,
+                      double *dx);
+
+/* Box-plus of the clone / calibration tables with dx
+ * (JPLQuat.h:114-125, PoseJPL.h:74-91, Vec.h:55-58).                        */
+void oracle_apply_dx(const ovgpu_state_view *st, const double *dx,
+                     double *clone_q_p_out, double *calib_q_p_out,
+                     double *intrinsics_out);
+
+/* FeatureInitializer::single_triangulation(_1d) + single_gaussnewton over all
+ * features (UpdaterMSCKF.cpp:117-142).                                      */
+int oracle_triangulate(const ovgpu_options *opts, const ovgpu_state_view *st,
+                       const ovgpu_features_view *fv, double *p_FinA,
+                       double *p_FinG, int32_t *anchor_meas, int32_t *status);
+
+/* UpdaterHelper::get_feature_jacobian_full for ONE feature f with given
+ * p_FinG / p_FinA (UpdaterHelper.cpp:192-424) in the canonical column order
+ * (see oracle_column_map).  H_f [2m x 3], H_x [2m x D], res [2m].           */
+int oracle_feature_jacobian(const ovgpu_options *opts, const ovgpu_state_view *st,
+                            const ovgpu_features_view *fv, int f,
+                            const double *p_FinG, const double *p_FinA,
+                            int anchor_meas, double *H_f, double *H_x,
+                            double *res, int *nf_out);
+
+/* Canonical column order shared by oracle and GPU: calibrated camera
+ * variables and clones sorted by covariance id.  Returns D; col_cov_id may be
+ * NULL.                                                                      */
+int oracle_column_map(const ovgpu_options *opts, const ovgpu_state_view *st,
+                      int32_t *col_cov_id);
+
+/* The complete UpdaterMSCKF::update (UpdaterMSCKF.cpp:58-295).
+ * Outputs as in ovgpu_msckf_update, plus the compressed system
+ * (H_comp [rows_comp x D], r_comp) before the EKF step, and the five stage
+ * wall times in seconds (clean is folded into marshalling, so four here:
+ * triangulate, create system, compress, update).  Any output may be NULL.   */
+int oracle_msckf_update(const ovgpu_options *opts, const ovgpu_state_view *st,
+                        const ovgpu_features_view *fv, int32_t *feat_status,
+                        double *chi2, double *chi2_thresh, double *p_FinG,
+                        double *dx, double *P_out, double *clone_q_p_out,
+                        double *calib_q_p_out, double *intrinsics_out,
+                        double *H_comp, double *r_comp, int32_t *rows_comp,
+                        ovgpu_update_stats *stats, double *stage_seconds);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

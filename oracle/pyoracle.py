@@ -1,0 +1,168 @@
+"""ctypes loader of oracle/libov_oracle.so.
+
+TEST INFRASTRUCTURE ONLY: may be imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg,
+never by the product package.  PARITY UNPINNED (see ov_oracle.h).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from open_vins_amd import capi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libov_oracle.so")
+_lib = None
+
+dp, ip = capi.c_double_p, capi.c_int32_p
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        build()
+    lib = C.CDLL(LIB_PATH)
+    O, SV, FV, US = C.POINTER(capi.Options), C.POINTER(capi.StateView), C.POINTER(capi.FeaturesView), C.POINTER(capi.UpdateStats)
+    lib.oracle_chi2_quantile_95.restype = C.c_double
+    lib.oracle_chi2_quantile_95.argtypes = [C.c_int]
+    lib.oracle_cam_distort.restype = None
+    lib.oracle_cam_distort.argtypes = [dp, C.c_int, dp, dp, dp, dp]
+    lib.oracle_make_givens.restype = None
+    lib.oracle_make_givens.argtypes = [C.c_double, C.c_double, dp, dp]
+    lib.oracle_nullspace_project.restype = None
+    lib.oracle_nullspace_project.argtypes = [dp, dp, dp, C.c_int, C.c_int, C.c_int]
+    lib.oracle_measurement_compress.restype = C.c_int
+    lib.oracle_measurement_compress.argtypes = [dp, dp, C.c_int, C.c_int]
+    lib.oracle_ekf_update.restype = C.c_int
+    lib.oracle_ekf_update.argtypes = [dp, C.c_int, dp, dp, C.c_int, C.c_int, ip, C.c_double, dp]
+    lib.oracle_apply_dx.restype = None
+    lib.oracle_apply_dx.argtypes = [SV, dp, dp, dp, dp]
+    lib.oracle_triangulate.restype = C.c_int
+    lib.oracle_triangulate.argtypes = [O, SV, FV, dp, dp, ip, ip]
+    lib.oracle_feature_jacobian.restype = C.c_int
+    lib.oracle_feature_jacobian.argtypes = [O, SV, FV, C.c_int, dp, dp, C.c_int, dp, dp, dp, C.POINTER(C.c_int)]
+    lib.oracle_column_map.restype = C.c_int
+    lib.oracle_column_map.argtypes = [O, SV, ip]
+    lib.oracle_msckf_update.restype = C.c_int
+    lib.oracle_msckf_update.argtypes = [O, SV, FV, ip, dp, dp, dp, dp, dp, dp, dp, dp, dp, dp, ip, US, dp]
+    _lib = lib
+    return lib
+
+
+def _p(a):
+    return a.ctypes.data_as(dp)
+
+
+def _pi(a):
+    return a.ctypes.data_as(ip)
+
+
+def chi2_quantile_95(dof):
+    return load().oracle_chi2_quantile_95(int(dof))
+
+
+def column_map(opts, views):
+    lib = load()
+    D = lib.oracle_column_map(C.byref(opts), C.byref(views.state), None)
+    cols = np.zeros(D, dtype=np.int32)
+    lib.oracle_column_map(C.byref(opts), C.byref(views.state), _pi(cols))
+    return cols
+
+
+def triangulate(opts, views):
+    lib = load()
+    F = views.features.F
+    pA = np.zeros((F, 3))
+    pG = np.zeros((F, 3))
+    anchor = np.zeros(F, dtype=np.int32)
+    status = np.zeros(F, dtype=np.int32)
+    lib.oracle_triangulate(C.byref(opts), C.byref(views.state), C.byref(views.features), _p(pA), _p(pG), _pi(anchor), _pi(status))
+    return dict(p_FinA=pA, p_FinG=pG, anchor_meas=anchor, status=status)
+
+
+def feature_jacobian(opts, views, f, p_FinG, p_FinA=None, anchor_meas=-1):
+    lib = load()
+    m = int(views.meas_offsets[f + 1] - views.meas_offsets[f])
+    D = lib.oracle_column_map(C.byref(opts), C.byref(views.state), None)
+    H_f = np.zeros((2 * m, 3))
+    H_x = np.zeros((2 * m, D))
+    res = np.zeros(2 * m)
+    nf = C.c_int(3)
+    pG = np.ascontiguousarray(p_FinG, dtype=np.float64)
+    pA = np.ascontiguousarray(p_FinA if p_FinA is not None else np.zeros(3), dtype=np.float64)
+    lib.oracle_feature_jacobian(C.byref(opts), C.byref(views.state), C.byref(views.features), int(f), _p(pG), _p(pA),
+                                int(anchor_meas), _p(H_f), _p(H_x), _p(res), C.byref(nf))
+    n = nf.value
+    if n != 3:
+        H_f = np.ascontiguousarray(H_f.reshape(-1)[: 2 * m * n].reshape(2 * m, n))
+    return H_f, H_x, res
+
+
+def nullspace_project(H_f, H_x, res):
+    lib = load()
+    H_f = np.ascontiguousarray(H_f, dtype=np.float64).copy()
+    H_x = np.ascontiguousarray(H_x, dtype=np.float64).copy()
+    res = np.ascontiguousarray(res, dtype=np.float64).copy()
+    rows, nf = H_f.shape
+    lib.oracle_nullspace_project(_p(H_f), _p(H_x), _p(res), rows, nf, H_x.shape[1])
+    return H_f, H_x[nf:].copy(), res[nf:].copy()
+
+
+def measurement_compress(H_x, res):
+    lib = load()
+    H_x = np.ascontiguousarray(H_x, dtype=np.float64).copy()
+    res = np.ascontiguousarray(res, dtype=np.float64).copy()
+    r = lib.oracle_measurement_compress(_p(H_x), _p(res), H_x.shape[0], H_x.shape[1])
+    return H_x[:r].copy(), res[:r].copy()
+
+
+def ekf_update(P, H, res, col_cov_id, sigma2):
+    lib = load()
+    P = np.ascontiguousarray(P, dtype=np.float64).copy()
+    H = np.ascontiguousarray(H, dtype=np.float64)
+    res = np.ascontiguousarray(res, dtype=np.float64)
+    cols = np.ascontiguousarray(col_cov_id, dtype=np.int32)
+    dx = np.zeros(P.shape[0])
+    st = lib.oracle_ekf_update(_p(P), P.shape[0], _p(H), _p(res), H.shape[0], H.shape[1], _pi(cols), float(sigma2), _p(dx))
+    return st, P, dx
+
+
+def msckf_update(opts, views, want_compressed=False):
+    """Runs the complete reference-order update on the CPU; returns a dict of outputs."""
+    lib = load()
+    F, N, Cn, K = views.features.F, views.state.N, views.state.C, views.state.K
+    D = lib.oracle_column_map(C.byref(opts), C.byref(views.state), None)
+    out = dict(
+        feat_status=np.zeros(F, dtype=np.int32), chi2=np.zeros(F), chi2_thresh=np.zeros(F), p_FinG=np.zeros((F, 3)),
+        dx=np.zeros(N), P=np.zeros((N, N)), clone_q_p=np.zeros((Cn, 7)), calib_q_p=np.zeros((K, 7)), intrinsics=np.zeros((K, 8)),
+    )
+    Hc = np.zeros((D, D)) if want_compressed else None
+    rc = np.zeros(D) if want_compressed else None
+    if want_compressed:
+        # rows_comp <= D only when the stack has more rows than columns; otherwise rows = ct_meas <= D too
+        pass
+    rows = C.c_int32(0)
+    stats = capi.UpdateStats()
+    secs = np.zeros(4)
+    rcode = lib.oracle_msckf_update(
+        C.byref(opts), C.byref(views.state), C.byref(views.features), _pi(out["feat_status"]), _p(out["chi2"]), _p(out["chi2_thresh"]),
+        _p(out["p_FinG"]), _p(out["dx"]), _p(out["P"]), _p(out["clone_q_p"]), _p(out["calib_q_p"]), _p(out["intrinsics"]),
+        _p(Hc) if want_compressed else None, _p(rc) if want_compressed else None, C.byref(rows), C.byref(stats), _p(secs))
+    assert rcode == 0
+    out["stats"] = stats.as_dict()
+    out["stage_seconds"] = dict(zip(["triangulate", "system", "compress", "update"], secs.tolist()))
+    out["rows_comp"] = rows.value
+    out["D"] = D
+    if want_compressed:
+        out["H_comp"] = Hc[: rows.value]
+        out["r_comp"] = rc[: rows.value]
+    return out
