@@ -212,6 +212,16 @@ int ovgpu_set_features(ovgpu_ctx *ctx, const ovgpu_features_view *fv);
 int ovgpu_triangulate(ovgpu_ctx *ctx, double *p_FinA, double *p_FinG,
                       int32_t *anchor_meas, int32_t *status);
 
+/* Supplies the feature positions instead of triangulating them: the updates that
+ * follow (until the next ovgpu_set_features) skip the triangulation stage and use
+ * these values.  This is the situation of UpdaterSLAM::update, where the landmark
+ * estimate comes out of the state (UpdaterSLAM.cpp:326-353), and what the stage-wise
+ * parity tests use.  p_FinG [3*F] is required; p_FinA [3*F] and anchor_meas [F] are
+ * needed for anchored representations; status [F] (NULL = all OVGPU_FEAT_USED).
+ * Host pointers.                                                                  */
+int ovgpu_set_triangulation(ovgpu_ctx *ctx, const double *p_FinA, const double *p_FinG,
+                            const int32_t *anchor_meas, const int32_t *status);
+
 /* ------------------------------------------------------------------------- */
 /* ov_msckf::UpdaterMSCKF::update  (UpdaterMSCKF.cpp:58-295)                  */
 /* ------------------------------------------------------------------------- */
@@ -279,6 +289,20 @@ int ovgpu_msckf_local(ovgpu_ctx *ctx, int32_t *feat_status, double *chi2,
 int ovgpu_msckf_merge_update(ovgpu_ctx *ctx, const void *tris_dev, int G,
                              double *dx, double *P_out,
                              ovgpu_update_stats *stats);
+
+/* ------------------------------------------------------------------------- */
+/* camera models                                                              */
+/* ------------------------------------------------------------------------- */
+
+/* Evaluates the device camera model on n normalized points (host arrays):
+ * CamBase::distort_d (CamBase.h:130-135 -> CamRadtan::distort_f, CamRadtan.h:127-146,
+ * or CamEqui::distort_f, CamEqui.h:136-158, including the float round trip) and
+ * compute_distort_jacobian (CamRadtan.h:154-198 / CamEqui.h:166-230).
+ *   cam8 [8] fx fy cx cy d0..d3 ; uv_norm [2n] ; uv_dist [2n] ; dz_dzn [4n] ; dz_dzeta [16n]
+ * Used by the parity tests of the camera row; outputs may be NULL. */
+int ovgpu_cam_distort(ovgpu_ctx *ctx, int is_fisheye, const double *cam8, int n,
+                      const double *uv_norm, double *uv_dist, double *dz_dzn,
+                      double *dz_dzeta);
 
 /* ------------------------------------------------------------------------- */
 /* benchmarking hooks                                                         */

@@ -151,6 +151,7 @@ def declare(lib):
         "ovgpu_set_state": (C.c_int, [ctxp, C.POINTER(StateView)]),
         "ovgpu_set_features": (C.c_int, [ctxp, C.POINTER(FeaturesView)]),
         "ovgpu_triangulate": (C.c_int, [ctxp, c_double_p, c_double_p, c_int32_p, c_int32_p]),
+        "ovgpu_set_triangulation": (C.c_int, [ctxp, c_double_p, c_double_p, c_int32_p, c_int32_p]),
         "ovgpu_msckf_update": (C.c_int, [ctxp, c_int32_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p,
                                          C.POINTER(UpdateStats)]),
         "ovgpu_msckf_compress": (C.c_int, [ctxp, c_int32_p, c_double_p, c_double_p, c_double_p, c_int32_p, c_int32_p,
@@ -159,6 +160,7 @@ def declare(lib):
         "ovgpu_triangle_len": (C.c_int, [ctxp, C.POINTER(C.c_int64)]),
         "ovgpu_msckf_local": (C.c_int, [ctxp, c_int32_p, c_double_p, c_double_p, c_double_p, vp, C.POINTER(UpdateStats)]),
         "ovgpu_msckf_merge_update": (C.c_int, [ctxp, vp, C.c_int, c_double_p, c_double_p, C.POINTER(UpdateStats)]),
+        "ovgpu_cam_distort": (C.c_int, [ctxp, C.c_int, c_double_p, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p]),
         "ovgpu_reset_state": (C.c_int, [ctxp]),
         "ovgpu_msckf_update_async": (C.c_int, [ctxp]),
         "ovgpu_synchronize": (C.c_int, [ctxp]),

@@ -240,6 +240,35 @@ __device__ __forceinline__ double cond_sym3(const M3 &A) {
   return mx / mn;
 }
 
+// Float arithmetic that must round after every operation, as the reference's x86-64 build does.
+// HIP's __fmul_rn / __fadd_rn are plain operators to the optimiser and get contracted into
+// v_fma_f32 under the default -ffp-contract=fast, which rounds once instead of twice; measured on
+// MI355X: 1 % of the distorted pixels came out one float ulp off.  The pragma removes the
+// `contract` flag from these instructions, so they cannot be fused even after inlining.
+__device__ __forceinline__ float mul_f32(float a, float b) {
+#pragma clang fp contract(off)
+  return a * b;
+}
+__device__ __forceinline__ float add_f32(float a, float b) {
+#pragma clang fp contract(off)
+  return a + b;
+}
+__device__ __forceinline__ float sub_f32(float a, float b) {
+#pragma clang fp contract(off)
+  return a - b;
+}
+
+// Correctly rounded float square root.  __fsqrt_rn / sqrtf lower to a bare v_sqrt_f32 (1 ulp) on
+// gfx950; the reference's x86 sqrtss is IEEE-exact and its result feeds float-rounded pixels and
+// GN costs, so a 1-ulp difference becomes visible.  sqrt in double (correctly rounded, 53 >= 2*24+2
+// bits) followed by one rounding to float is the correctly rounded float result.
+// The empty asm keeps LLVM from shrinking (float)sqrt((double)x) back to sqrtf(x).
+__device__ __forceinline__ float sqrtf_rn(float x) {
+  double d = (double)x;
+  asm volatile("" : "+v"(d));
+  return (float)sqrt(d);
+}
+
 // ---------------------------------------------------------------------------
 // camera models
 // ---------------------------------------------------------------------------
@@ -255,13 +284,13 @@ __device__ __forceinline__ CamIntr load_cam(const double *p) { return CamIntr{p[
 // contracting the float products into FMAs (which would round differently).
 __device__ __forceinline__ void radtan_distort_d(const CamIntr &c, double xn, double yn, double &u, double &v) {
   const float x = (float)xn, y = (float)yn;
-  const float rf = __fsqrt_rn(__fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y)));
+  const float rf = sqrtf_rn(add_f32(mul_f32(x, x), mul_f32(y, y)));
   const double r = (double)rf;
   const double r_2 = r * r;
   const double r_4 = r_2 * r_2;
   const double xd = (double)x, yd = (double)y;
-  const double twoxx = (double)__fmul_rn(__fmul_rn(2.0f, x), x); // 2 * x * x in float
-  const double twoyy = (double)__fmul_rn(__fmul_rn(2.0f, y), y);
+  const double twoxx = (double)mul_f32(mul_f32(2.0f, x), x); // 2 * x * x in float
+  const double twoyy = (double)mul_f32(mul_f32(2.0f, y), y);
   const double rad = 1.0 + c.d0 * r_2 + c.d1 * r_4;
   const double x1 = xd * rad + 2.0 * c.d2 * xd * yd + c.d3 * (r_2 + twoxx);
   const double y1 = yd * rad + c.d2 * (r_2 + twoyy) + 2.0 * c.d3 * xd * yd;
@@ -272,7 +301,7 @@ __device__ __forceinline__ void radtan_distort_d(const CamIntr &c, double xn, do
 // CamEqui::distort_f through distort_d (CamEqui.h:136-158)
 __device__ __forceinline__ void equi_distort_d(const CamIntr &c, double xn, double yn, double &u, double &v) {
   const float x = (float)xn, y = (float)yn;
-  const float rf = __fsqrt_rn(__fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y)));
+  const float rf = sqrtf_rn(add_f32(mul_f32(x, x), mul_f32(y, y)));
   const double r = (double)rf;
   const double th = atan(r);
   const double th2 = th * th;

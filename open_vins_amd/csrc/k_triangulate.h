@@ -79,8 +79,8 @@ __device__ __forceinline__ double gn_cost(const double *lds_cc, const uint16_t *
     const double hi2 = R.a10 * alpha + R.a11 * beta + R.a12 + rho * pA.y;
     const double hi3 = R.a20 * alpha + R.a21 * beta + R.a22 + rho * pA.z;
     const float2 z = uvn[i];
-    const float r0 = __fsub_rn(z.x, (float)(hi1 / hi3)), r1 = __fsub_rn(z.y, (float)(hi2 / hi3));
-    const float n = __fsqrt_rn(__fadd_rn(__fmul_rn(r0, r0), __fmul_rn(r1, r1)));
+    const float r0 = sub_f32(z.x, (float)(hi1 / hi3)), r1 = sub_f32(z.y, (float)(hi2 / hi3));
+    const float n = sqrtf_rn(add_f32(mul_f32(r0, r0), mul_f32(r1, r1)));
     err += (double)n * (double)n;
   }
   return wave_sum(err);
@@ -221,7 +221,7 @@ __global__ void __launch_bounds__(256) k_triangulate(TriParams p) {
           const double j0 = (R.a00 * hi3 - hi1 * R.a20) / h3sq, j1 = (R.a01 * hi3 - hi1 * R.a21) / h3sq, j2 = (pA.x * hi3 - hi1 * pA.z) / h3sq;
           const double j3 = (R.a10 * hi3 - hi2 * R.a20) / h3sq, j4 = (R.a11 * hi3 - hi2 * R.a21) / h3sq, j5 = (pA.y * hi3 - hi2 * pA.z) / h3sq;
           const float2 z = uvn[i];
-          const double r0 = (double)__fsub_rn(z.x, (float)(hi1 / hi3)), r1 = (double)__fsub_rn(z.y, (float)(hi2 / hi3)); // :273-275
+          const double r0 = (double)sub_f32(z.x, (float)(hi1 / hi3)), r1 = (double)sub_f32(z.y, (float)(hi2 / hi3)); // :273-275
           g0 += j0 * r0 + j3 * r1, g1 += j1 * r0 + j4 * r1, g2 += j2 * r0 + j5 * r1; // :282
           H00 += j0 * j0 + j3 * j3, H01 += j0 * j1 + j3 * j4, H02 += j0 * j2 + j3 * j5; // :283
           H11 += j1 * j1 + j4 * j4, H12 += j1 * j2 + j4 * j5, H22 += j2 * j2 + j5 * j5;

@@ -87,6 +87,9 @@ struct ovgpu_ctx {
 
   // ---- features
   bool have_feats = false;
+  bool given_tri = false; // positions supplied by ovgpu_set_triangulation
+  std::vector<int32_t> h_given_status;
+  DevBuf<int32_t> given_status;
   int F = 0, M = 0, m_max = 0;
   int64_t rows_total = 0;
   DevBuf<int32_t> meas_offsets;
@@ -198,7 +201,7 @@ void ovgpu_destroy(ovgpu_ctx *c) {
   c->meas_offsets.release(), c->meas_cc.release(), c->uv.release(), c->uvn.release(), c->row_off.release();
   c->pA.release(), c->pG.release(), c->chi2.release(), c->chi2_thr.release(), c->anchor.release(), c->status.release();
   c->chi2_table.release(), c->Hbig.release(), c->gate_ws.release(), c->Rws.release(), c->Mt.release(), c->Aaug.release();
-  c->dx.release(), c->flags.release();
+  c->dx.release(), c->flags.release(), c->given_status.release();
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -416,6 +419,7 @@ int ovgpu_set_features(ovgpu_ctx *c, const ovgpu_features_view *fv) {
   HIPCHK(upload(c->chi2_table.p, c->h_chi2_table.data(), sizeof(double) * c->chi2_table_len, s));
   HIPCHK(hipStreamSynchronize(s)); // host staging vectors go out of scope
   c->have_feats = true;
+  c->given_tri = false;
   return OVGPU_OK;
 }
 
@@ -541,7 +545,10 @@ static int enqueue_pipeline(ovgpu_ctx *c, int stages) {
   if (eu) HIPCHK(hipEventRecord(eu->a, c->stream));
   int rc = OVGPU_OK;
   if (stages & STAGE_LOCAL) {
-    if ((rc = enqueue_triangulate(c)) != OVGPU_OK) return rc;
+    if (c->given_tri) {
+      // the gate overwrites status; restore the caller's per-feature status for this run
+      if (c->F > 0) HIPCHK(hipMemcpyAsync(c->status.p, c->given_status.p, sizeof(int32_t) * c->F, hipMemcpyDeviceToDevice, c->stream));
+    } else if ((rc = enqueue_triangulate(c)) != OVGPU_OK) return rc;
     if ((rc = enqueue_system(c)) != OVGPU_OK) return rc;
     if (ec) HIPCHK(hipEventRecord(ec->a, c->stream));
     if ((rc = enqueue_compress(c)) != OVGPU_OK) return rc;
@@ -614,6 +621,33 @@ int ovgpu_triangulate(ovgpu_ctx *c, double *p_FinA, double *p_FinG, int32_t *anc
     if (status) HIPCHK(hipMemcpyAsync(status, c->status.p, sizeof(int32_t) * F, hipMemcpyDeviceToHost, s));
   }
   HIPCHK(hipStreamSynchronize(s));
+  return OVGPU_OK;
+}
+
+int ovgpu_set_triangulation(ovgpu_ctx *c, const double *p_FinA, const double *p_FinG, const int32_t *anchor_meas, const int32_t *status) {
+  if (!c || !p_FinG) return set_err(OVGPU_ERR_INVALID, "null argument");
+  if (!c->have_state || !c->have_feats) return set_err(OVGPU_ERR_NO_STATE, "state / features not set");
+  if (c->dopt.feat_rep >= OVGPU_REP_ANCHORED_3D && (!p_FinA || !anchor_meas))
+    return set_err(OVGPU_ERR_INVALID, "anchored representations need p_FinA and anchor_meas");
+  HIPCHK(hipSetDevice(c->device));
+  const int F = c->F;
+  hipStream_t s = c->stream;
+  std::vector<int32_t> st(F, OVGPU_FEAT_USED);
+  for (int f = 0; f < F; f++) {
+    if (status) st[f] = status[f];
+    if (c->h_offsets[f + 1] - c->h_offsets[f] < 2) st[f] = OVGPU_FEAT_TOO_FEW_MEAS;
+    if (anchor_meas && st[f] == OVGPU_FEAT_USED && (anchor_meas[f] < c->h_offsets[f] || anchor_meas[f] >= c->h_offsets[f + 1]))
+      return set_err(OVGPU_ERR_INVALID, "anchor_meas outside the feature's measurements");
+  }
+  HIPCHK(c->given_status.reserve(F));
+  if (F > 0) {
+    HIPCHK(upload(c->pG.p, p_FinG, sizeof(double) * 3 * F, s));
+    if (p_FinA) HIPCHK(upload(c->pA.p, p_FinA, sizeof(double) * 3 * F, s));
+    if (anchor_meas) HIPCHK(upload(c->anchor.p, anchor_meas, sizeof(int32_t) * F, s));
+    HIPCHK(upload(c->given_status.p, st.data(), sizeof(int32_t) * F, s));
+  }
+  HIPCHK(hipStreamSynchronize(s));
+  c->given_tri = true;
   return OVGPU_OK;
 }
 
@@ -739,6 +773,46 @@ int ovgpu_msckf_merge_update(ovgpu_ctx *c, const void *tris_dev, int G, double *
   int status = flags[0] ? OVGPU_ERR_NOT_SPD : (flags[1] ? OVGPU_ERR_NEGATIVE_DIAGONAL : OVGPU_OK);
   if (stats) stats->status = status;
   if (status != OVGPU_OK) return set_err(status, "EKF update failed");
+  return OVGPU_OK;
+}
+
+// diagnostic kernel: evaluates the device camera model on a batch of normalized points
+__global__ void k_cam_distort(int n, int fisheye, const double *__restrict__ cam8, const double *__restrict__ uvn, double *uv, double *dzn, double *dze) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const CamIntr ci = load_cam(cam8);
+  double u, v, a[4], b[16];
+  if (fisheye) {
+    equi_distort_d(ci, uvn[2 * i], uvn[2 * i + 1], u, v);
+    equi_jacobian(ci, uvn[2 * i], uvn[2 * i + 1], a, b);
+  } else {
+    radtan_distort_d(ci, uvn[2 * i], uvn[2 * i + 1], u, v);
+    radtan_jacobian(ci, uvn[2 * i], uvn[2 * i + 1], a, b);
+  }
+  uv[2 * i] = u, uv[2 * i + 1] = v;
+  for (int k = 0; k < 4; k++) dzn[4 * i + k] = a[k];
+  for (int k = 0; k < 16; k++) dze[16 * i + k] = b[k];
+}
+
+int ovgpu_cam_distort(ovgpu_ctx *c, int is_fisheye, const double *cam8, int n, const double *uv_norm, double *uv_dist, double *dz_dzn, double *dz_dzeta) {
+  if (!c || !cam8 || !uv_norm || n < 0) return set_err(OVGPU_ERR_INVALID, "bad argument");
+  HIPCHK(hipSetDevice(c->device));
+  DevBuf<double> d_cam, d_in, d_uv, d_a, d_b;
+  HIPCHK(d_cam.reserve(8));
+  HIPCHK(d_in.reserve((size_t)2 * n));
+  HIPCHK(d_uv.reserve((size_t)2 * n));
+  HIPCHK(d_a.reserve((size_t)4 * n));
+  HIPCHK(d_b.reserve((size_t)16 * n));
+  hipStream_t s = c->stream;
+  HIPCHK(upload(d_cam.p, cam8, 8 * sizeof(double), s));
+  HIPCHK(upload(d_in.p, uv_norm, sizeof(double) * 2 * n, s));
+  if (n > 0) hipLaunchKernelGGL(k_cam_distort, dim3((n + 255) / 256), dim3(256), 0, s, n, is_fisheye, d_cam.p, d_in.p, d_uv.p, d_a.p, d_b.p);
+  HIPCHK(hipGetLastError());
+  if (uv_dist) HIPCHK(hipMemcpyAsync(uv_dist, d_uv.p, sizeof(double) * 2 * n, hipMemcpyDeviceToHost, s));
+  if (dz_dzn) HIPCHK(hipMemcpyAsync(dz_dzn, d_a.p, sizeof(double) * 4 * n, hipMemcpyDeviceToHost, s));
+  if (dz_dzeta) HIPCHK(hipMemcpyAsync(dz_dzeta, d_b.p, sizeof(double) * 16 * n, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  d_cam.release(), d_in.release(), d_uv.release(), d_a.release(), d_b.release();
   return OVGPU_OK;
 }
 

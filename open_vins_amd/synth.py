@@ -263,17 +263,21 @@ def state_sigmas(C, K):
 
 
 def make_problem(cfg=2, rep=0, *, C=None, K=None, F=None, track="full", fisheye=False,
-                 min_obs=5, pose_noise=1.0, seed=None) -> Problem:
+                 min_obs=5, pose_noise=1.0, seed=None, shard=0, outlier_frac=0.0) -> Problem:
     """Builds the snapshot of BASELINE.json config `cfg`; C/K/F override its sizes.
 
     track = "full": every visible observation is kept; "ragged": a contiguous sub-window of clones of
-    length ~U[5, C] per feature."""
+    length ~U[5, C] per feature.  The state (clones, calibration, prior P) depends only on (cfg, rep / seed,
+    C, K); `shard` selects an independent feature stream on the same state (feature-sharded multi-GPU runs).
+    outlier_frac: fraction of features whose pixels get a gross 15 px offset (exercises the chi2 gate)."""
     base = CONFIGS[cfg]
     C = C or base["C"]
     K = K or base["K"]
     F = F if F is not None else base["F"]
     seed = (1000 * cfg + rep) if seed is None else seed
-    rng = np.random.default_rng(seed)
+    rng = np.random.default_rng([seed, 1])        # state stream
+    rng_P = np.random.default_rng([seed, 2])      # prior covariance stream
+    rng_f = np.random.default_rng([seed, 3, shard])  # feature stream
 
     traj = load_traj_window()
     assert C <= traj.shape[0]
@@ -329,14 +333,14 @@ def make_problem(cfg=2, rep=0, *, C=None, K=None, F=None, track="full", fisheye=
     batch = max(256, int(F * 1.25) + 16)
     cams_desc = np.arange(K - 1, -1, -1)  # camera groups in descending id (libstdc++ unordered_map order)
     while nfeat < F:
-        j = rng.integers(0, C, batch)
-        k = rng.integers(0, K, batch)
-        u = rng.uniform(0, IMG_W, batch).astype(np.float32).astype(np.float64)
-        v = rng.uniform(0, IMG_H, batch).astype(np.float32).astype(np.float64)
-        depth = rng.uniform(5.0, 7.0, batch)
-        lo = rng.integers(0, C, batch)
-        ln = rng.integers(5, C + 1, batch)
-        noise = rng.normal(0, 1.0, (batch, K, C, 2))
+        j = rng_f.integers(0, C, batch)
+        k = rng_f.integers(0, K, batch)
+        u = rng_f.uniform(0, IMG_W, batch).astype(np.float32).astype(np.float64)
+        v = rng_f.uniform(0, IMG_H, batch).astype(np.float32).astype(np.float64)
+        depth = rng_f.uniform(5.0, 7.0, batch)
+        lo = rng_f.integers(0, C, batch)
+        ln = rng_f.integers(5, C + 1, batch)
+        noise = rng_f.normal(0, 1.0, (batch, K, C, 2))
         camk = intr_true[k].T  # [8,batch]
         xn, yn = undistort(camk, u, v)
         xn = xn.astype(np.float32).astype(np.float64)  # undistort_cv returns float
@@ -368,6 +372,9 @@ def make_problem(cfg=2, rep=0, *, C=None, K=None, F=None, track="full", fisheye=
             win = (cc >= c0[:, None]) & (cc < (c0 + ln)[:, None])
             valid &= win[:, None, :]
         # noisy raw pixel (float32) and its undistorted normalised coordinate (float32)
+        if outlier_frac > 0:
+            bad = rng_f.uniform(0, 1, batch) < outlier_frac
+            noise = noise + np.where(bad, 15.0, 0.0)[:, None, None, None] * np.sign(noise)
         un = (ud + noise[..., 0]).astype(np.float32)
         vn = (vd + noise[..., 1]).astype(np.float32)
         xu = np.zeros_like(ud)
@@ -403,7 +410,7 @@ def make_problem(cfg=2, rep=0, *, C=None, K=None, F=None, track="full", fisheye=
     N = 16 + 14 * K + 6 * C
     sig = state_sigmas(C, K)
     assert sig.shape[0] == N
-    G = np.tril(rng.normal(0, 1.0 / np.sqrt(N), (N, N)), -1)
+    G = np.tril(rng_P.normal(0, 1.0 / np.sqrt(N), (N, N)), -1)
     L = sig[:, None] * (np.eye(N) + 0.1 * G)
     P = L @ L.T
     P = 0.5 * (P + P.T)

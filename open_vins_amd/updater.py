@@ -74,6 +74,15 @@ class UpdaterMSCKF:
                    "ovgpu_triangulate")
         return out
 
+    def set_triangulation(self, p_FinG, p_FinA=None, anchor_meas=None, status=None):
+        """Positions supplied by the caller (UpdaterSLAM::update path, stage-wise parity tests)."""
+        self._given = [np.ascontiguousarray(p_FinG, dtype=np.float64),
+                       np.ascontiguousarray(p_FinA, dtype=np.float64) if p_FinA is not None else None,
+                       np.ascontiguousarray(anchor_meas, dtype=np.int32) if anchor_meas is not None else None,
+                       np.ascontiguousarray(status, dtype=np.int32) if status is not None else None]
+        g = self._given
+        capi.check(self.lib.ovgpu_set_triangulation(self._ctx, _dp(g[1]), _dp(g[0]), _ip(g[2]), _ip(g[3])), "ovgpu_set_triangulation")
+
     # ---- UpdaterMSCKF::update -------------------------------------------
     def update(self, check=True):
         F, N = self.F, self.N

@@ -22,6 +22,16 @@
 
 namespace {
 
+// double -> float rounding that the optimiser cannot fold away.  g++ 11 -O3 was observed to
+// drop a plain (double)(float)x round trip when it SLP-vectorises the surrounding code; the
+// reference rounds through Eigen::Vector2f objects across a virtual call (CamBase.h:130-135),
+// so the rounding really happens there.  The empty asm makes the float value opaque.
+inline float f32(double x) {
+  float f = (float)x;
+  asm volatile("" : "+x"(f));
+  return f;
+}
+
 // ---------------------------------------------------------------------------
 // tiny fixed-size helpers (row-major 3x3)
 // ---------------------------------------------------------------------------
@@ -416,21 +426,21 @@ double chi2_quantile(int dof, double p) {
 // (CamBase.h:130-135).  uv_norm is an Eigen::Vector2f, so products of two of
 // its coefficients (and the sqrt argument) are evaluated in float.
 inline void radtan_distort_d(const double *cam_d, const double *uvn_d, double *out) {
-  float x = (float)uvn_d[0], y = (float)uvn_d[1];
+  float x = f32(uvn_d[0]), y = f32(uvn_d[1]);
   double r = (double)std::sqrt(x * x + y * y); // float sqrt of a float expression
   double r_2 = r * r;
   double r_4 = r_2 * r_2;
   double x1 = x * (1 + cam_d[4] * r_2 + cam_d[5] * r_4) + 2 * cam_d[6] * x * y + cam_d[7] * (r_2 + 2 * x * x);
   double y1 = y * (1 + cam_d[4] * r_2 + cam_d[5] * r_4) + cam_d[6] * (r_2 + 2 * y * y) + 2 * cam_d[7] * x * y;
-  float u = (float)(cam_d[0] * x1 + cam_d[2]);
-  float v = (float)(cam_d[1] * y1 + cam_d[3]);
+  float u = f32(cam_d[0] * x1 + cam_d[2]);
+  float v = f32(cam_d[1] * y1 + cam_d[3]);
   out[0] = (double)u;
   out[1] = (double)v;
 }
 
 // CamEqui::distort_f (CamEqui.h:136-158) through distort_d.
 inline void equi_distort_d(const double *cam_d, const double *uvn_d, double *out) {
-  float x = (float)uvn_d[0], y = (float)uvn_d[1];
+  float x = f32(uvn_d[0]), y = f32(uvn_d[1]);
   double r = (double)std::sqrt(x * x + y * y);
   double theta = std::atan(r);
   double theta_d = theta + cam_d[4] * std::pow(theta, 3) + cam_d[5] * std::pow(theta, 5) + cam_d[6] * std::pow(theta, 7) +
@@ -439,8 +449,8 @@ inline void equi_distort_d(const double *cam_d, const double *uvn_d, double *out
   double cdist = (r > 1e-8) ? theta_d * inv_r : 1.0;
   double x1 = x * cdist;
   double y1 = y * cdist;
-  float u = (float)(cam_d[0] * x1 + cam_d[2]);
-  float v = (float)(cam_d[1] * y1 + cam_d[3]);
+  float u = f32(cam_d[0] * x1 + cam_d[2]);
+  float v = f32(cam_d[1] * y1 + cam_d[3]);
   out[0] = (double)u;
   out[1] = (double)v;
 }
@@ -673,7 +683,7 @@ double compute_error(const std::vector<RelPose> &rel, const FeatMeas &fm, double
     double hi1 = R(0, 0) * alpha + R(0, 1) * beta + R(0, 2) + rho * rp.p_AinCi[0];
     double hi2 = R(1, 0) * alpha + R(1, 1) * beta + R(1, 2) + rho * rp.p_AinCi[1];
     double hi3 = R(2, 0) * alpha + R(2, 1) * beta + R(2, 2) + rho * rp.p_AinCi[2];
-    float z0 = (float)(hi1 / hi3), z1 = (float)(hi2 / hi3); // Eigen::Matrix<float,2,1> z  (:414-415)
+    float z0 = f32(hi1 / hi3), z1 = f32(hi2 / hi3); // Eigen::Matrix<float,2,1> z  (:414-415)
     float r0 = fm.uvn[2 * i] - z0, r1 = fm.uvn[2 * i + 1] - z1;
     float n = std::sqrt(r0 * r0 + r1 * r1); // res.norm() in float
     err += std::pow((double)n, 2);          // pow(float, int) promotes to double (:418)
@@ -731,7 +741,7 @@ bool single_gaussnewton(const ovgpu_options &o, const StateTables &T, const Feat
         H[3] = (R(1, 0) * hi3 - hi2 * R(2, 0)) / h3sq;
         H[4] = (R(1, 1) * hi3 - hi2 * R(2, 1)) / h3sq;
         H[5] = (p[1] * hi3 - hi2 * p[2]) / h3sq;
-        float z0 = (float)(hi1 / hi3), z1 = (float)(hi2 / hi3);
+        float z0 = f32(hi1 / hi3), z1 = f32(hi2 / hi3);
         float r0 = fm.uvn[2 * i] - z0, r1 = fm.uvn[2 * i + 1] - z1; // :273-275
         double rd0 = (double)r0, rd1 = (double)r1;
         for (int a = 0; a < 3; a++) {
@@ -1225,12 +1235,15 @@ int oracle_ekf_update(double *P, int N, const double *H, const double *res, int 
   return ekf_update(P, N, H, res, rows, D, col_cov_id, sigma2, dx);
 }
 
-void oracle_apply_dx(const ovgpu_state_view *st, const double *dx, double *clone_q_p_out, double *calib_q_p_out, double *intrinsics_out) {
+void oracle_apply_dx(const ovgpu_options *opts, const ovgpu_state_view *st, const double *dx, double *clone_q_p_out, double *calib_q_p_out,
+                     double *intrinsics_out) {
+  // calibration that is not being estimated is not a state variable (State.cpp:120-131): it gets no update
+  const bool upd_pose = opts->do_calib_camera_pose != 0, upd_intr = opts->do_calib_camera_intrinsics != 0;
   if (clone_q_p_out)
     for (int c = 0; c < st->C; c++) pose_update(st->clone_q_p + 7 * c, dx + st->clone_cov_id[c], clone_q_p_out + 7 * c);
   if (calib_q_p_out)
     for (int k = 0; k < st->K; k++) {
-      if (st->calib_cov_id[k] >= 0)
+      if (upd_pose && st->calib_cov_id[k] >= 0)
         pose_update(st->calib_q_p + 7 * k, dx + st->calib_cov_id[k], calib_q_p_out + 7 * k);
       else
         std::memcpy(calib_q_p_out + 7 * k, st->calib_q_p + 7 * k, 7 * sizeof(double));
@@ -1238,7 +1251,7 @@ void oracle_apply_dx(const ovgpu_state_view *st, const double *dx, double *clone
   if (intrinsics_out)
     for (int k = 0; k < st->K; k++)
       for (int i = 0; i < 8; i++)
-        intrinsics_out[8 * k + i] = st->intrinsics[8 * k + i] + (st->intr_cov_id[k] >= 0 ? dx[st->intr_cov_id[k] + i] : 0.0); // Vec.h:55-58
+        intrinsics_out[8 * k + i] = st->intrinsics[8 * k + i] + ((upd_intr && st->intr_cov_id[k] >= 0) ? dx[st->intr_cov_id[k] + i] : 0.0); // Vec.h:55-58
 }
 
 int oracle_column_map(const ovgpu_options *opts, const ovgpu_state_view *st, int32_t *col_cov_id) {
@@ -1292,10 +1305,12 @@ int oracle_feature_jacobian(const ovgpu_options *opts, const ovgpu_state_view *s
   return OVGPU_OK;
 }
 
-int oracle_msckf_update(const ovgpu_options *opts, const ovgpu_state_view *st, const ovgpu_features_view *fv, int32_t *feat_status,
-                        double *chi2_out, double *chi2_thresh_out, double *p_FinG_out, double *dx_out, double *P_out,
-                        double *clone_q_p_out, double *calib_q_p_out, double *intrinsics_out, double *H_comp, double *r_comp,
-                        int32_t *rows_comp, ovgpu_update_stats *stats, double *stage_seconds) {
+int oracle_msckf_update_given(const ovgpu_options *opts, const ovgpu_state_view *st, const ovgpu_features_view *fv,
+                              const double *given_p_FinA, const double *given_p_FinG, const int32_t *given_anchor,
+                              const int32_t *given_status, int32_t *feat_status, double *chi2_out, double *chi2_thresh_out,
+                              double *p_FinG_out, double *dx_out, double *P_out, double *clone_q_p_out, double *calib_q_p_out,
+                              double *intrinsics_out, double *H_comp, double *r_comp, int32_t *rows_comp, ovgpu_update_stats *stats,
+                              double *stage_seconds) {
   const ovgpu_options &o = *opts;
   const int F = fv->F, N = st->N;
   double t0 = now_s();
@@ -1316,6 +1331,16 @@ int oracle_msckf_update(const ovgpu_options *opts, const ovgpu_state_view *st, c
   std::vector<V3> pA(F, V3{{NAN, NAN, NAN}}), pG(F, V3{{NAN, NAN, NAN}});
   for (int f = 0; f < F; f++) {
     FeatMeas fm{fv->meas_offsets[f], fv->meas_offsets[f + 1], fv->uvn, fv->uv, fv->clone_idx, fv->cam_idx};
+    if (given_p_FinG) { // triangulation supplied by the caller (landmarks already in the state / stage-wise parity tests)
+      status[f] = given_status ? given_status[f] : OVGPU_FEAT_USED;
+      anchor[f] = given_anchor ? given_anchor[f] : (fm.m1 - fm.m0 >= 1 ? pick_anchor(fm) : -1);
+      for (int i = 0; i < 3; i++) {
+        pG[f][i] = given_p_FinG[3 * f + i];
+        pA[f][i] = given_p_FinA ? given_p_FinA[3 * f + i] : NAN;
+      }
+      if (fm.m1 - fm.m0 < 2) status[f] = OVGPU_FEAT_TOO_FEW_MEAS;
+      continue;
+    }
     if (fm.m1 - fm.m0 < 2) { // :87-93
       status[f] = OVGPU_FEAT_TOO_FEW_MEAS;
       continue;
@@ -1470,7 +1495,7 @@ int oracle_msckf_update(const ovgpu_options *opts, const ovgpu_state_view *st, c
   if (rows_comp) *rows_comp = rows;
   if (dx_out) std::memcpy(dx_out, dx.data(), N * sizeof(double));
   if (P_out) std::memcpy(P_out, P.data(), (size_t)N * N * sizeof(double));
-  oracle_apply_dx(st, dx.data(), clone_q_p_out, calib_q_p_out, intrinsics_out);
+  oracle_apply_dx(opts, st, dx.data(), clone_q_p_out, calib_q_p_out, intrinsics_out);
   if (stats) *stats = stl;
   if (stage_seconds) {
     stage_seconds[0] = t1 - t0;
@@ -1479,6 +1504,15 @@ int oracle_msckf_update(const ovgpu_options *opts, const ovgpu_state_view *st, c
     stage_seconds[3] = t4 - t3;
   }
   return OVGPU_OK;
+}
+
+int oracle_msckf_update(const ovgpu_options *opts, const ovgpu_state_view *st, const ovgpu_features_view *fv, int32_t *feat_status,
+                        double *chi2_out, double *chi2_thresh_out, double *p_FinG_out, double *dx_out, double *P_out,
+                        double *clone_q_p_out, double *calib_q_p_out, double *intrinsics_out, double *H_comp, double *r_comp,
+                        int32_t *rows_comp, ovgpu_update_stats *stats, double *stage_seconds) {
+  return oracle_msckf_update_given(opts, st, fv, nullptr, nullptr, nullptr, nullptr, feat_status, chi2_out, chi2_thresh_out, p_FinG_out,
+                                   dx_out, P_out, clone_q_p_out, calib_q_p_out, intrinsics_out, H_comp, r_comp, rows_comp, stats,
+                                   stage_seconds);
 }
 
 } // extern "C"

@@ -56,7 +56,7 @@ int oracle_ekf_update(double *P, int N, const double *H, const double *res,
 
 /* Box-plus of the clone / calibration tables with dx
  * (JPLQuat.h:114-125, PoseJPL.h:74-91, Vec.h:55-58).                        */
-void oracle_apply_dx(const ovgpu_state_view *st, const double *dx,
+void oracle_apply_dx(const ovgpu_options *opts, const ovgpu_state_view *st, const double *dx,
                      double *clone_q_p_out, double *calib_q_p_out,
                      double *intrinsics_out);
 
@@ -93,6 +93,19 @@ int oracle_msckf_update(const ovgpu_options *opts, const ovgpu_state_view *st,
                         double *calib_q_p_out, double *intrinsics_out,
                         double *H_comp, double *r_comp, int32_t *rows_comp,
                         ovgpu_update_stats *stats, double *stage_seconds);
+
+/* Same, with the triangulation supplied by the caller (given_p_FinG != NULL): the path
+ * UpdaterSLAM::update takes for landmarks that already live in the state, and what the
+ * stage-wise parity tests use to compare everything after loop A on identical positions.
+ * given_p_FinA / given_anchor / given_status may be NULL (GLOBAL_3D, anchor rule, all USED). */
+int oracle_msckf_update_given(const ovgpu_options *opts, const ovgpu_state_view *st,
+                              const ovgpu_features_view *fv, const double *given_p_FinA,
+                              const double *given_p_FinG, const int32_t *given_anchor,
+                              const int32_t *given_status, int32_t *feat_status, double *chi2,
+                              double *chi2_thresh, double *p_FinG, double *dx, double *P_out,
+                              double *clone_q_p_out, double *calib_q_p_out, double *intrinsics_out,
+                              double *H_comp, double *r_comp, int32_t *rows_comp,
+                              ovgpu_update_stats *stats, double *stage_seconds);
 
 #ifdef __cplusplus
 }

@@ -45,7 +45,7 @@ def load():
     lib.oracle_ekf_update.restype = C.c_int
     lib.oracle_ekf_update.argtypes = [dp, C.c_int, dp, dp, C.c_int, C.c_int, ip, C.c_double, dp]
     lib.oracle_apply_dx.restype = None
-    lib.oracle_apply_dx.argtypes = [SV, dp, dp, dp, dp]
+    lib.oracle_apply_dx.argtypes = [O, SV, dp, dp, dp, dp]
     lib.oracle_triangulate.restype = C.c_int
     lib.oracle_triangulate.argtypes = [O, SV, FV, dp, dp, ip, ip]
     lib.oracle_feature_jacobian.restype = C.c_int
@@ -54,6 +54,8 @@ def load():
     lib.oracle_column_map.argtypes = [O, SV, ip]
     lib.oracle_msckf_update.restype = C.c_int
     lib.oracle_msckf_update.argtypes = [O, SV, FV, ip, dp, dp, dp, dp, dp, dp, dp, dp, dp, dp, ip, US, dp]
+    lib.oracle_msckf_update_given.restype = C.c_int
+    lib.oracle_msckf_update_given.argtypes = [O, SV, FV, dp, dp, ip, ip, ip, dp, dp, dp, dp, dp, dp, dp, dp, dp, dp, ip, US, dp]
     _lib = lib
     return lib
 
@@ -136,8 +138,10 @@ def ekf_update(P, H, res, col_cov_id, sigma2):
     return st, P, dx
 
 
-def msckf_update(opts, views, want_compressed=False):
-    """Runs the complete reference-order update on the CPU; returns a dict of outputs."""
+def msckf_update(opts, views, want_compressed=False, given=None):
+    """Runs the complete reference-order update on the CPU; returns a dict of outputs.
+
+    given = dict(p_FinG=..., p_FinA=..., anchor_meas=..., status=...) injects a triangulation (see ov_oracle.h)."""
     lib = load()
     F, N, Cn, K = views.features.F, views.state.N, views.state.C, views.state.K
     D = lib.oracle_column_map(C.byref(opts), C.byref(views.state), None)
@@ -153,8 +157,17 @@ def msckf_update(opts, views, want_compressed=False):
     rows = C.c_int32(0)
     stats = capi.UpdateStats()
     secs = np.zeros(4)
-    rcode = lib.oracle_msckf_update(
-        C.byref(opts), C.byref(views.state), C.byref(views.features), _pi(out["feat_status"]), _p(out["chi2"]), _p(out["chi2_thresh"]),
+    g_pA = g_pG = g_an = g_st = None
+    if given is not None:
+        g_pG = np.ascontiguousarray(given["p_FinG"], dtype=np.float64)
+        g_pA = np.ascontiguousarray(given["p_FinA"], dtype=np.float64) if given.get("p_FinA") is not None else None
+        g_an = np.ascontiguousarray(given["anchor_meas"], dtype=np.int32) if given.get("anchor_meas") is not None else None
+        g_st = np.ascontiguousarray(given["status"], dtype=np.int32) if given.get("status") is not None else None
+    rcode = lib.oracle_msckf_update_given(
+        C.byref(opts), C.byref(views.state), C.byref(views.features),
+        _p(g_pA) if g_pA is not None else None, _p(g_pG) if g_pG is not None else None,
+        _pi(g_an) if g_an is not None else None, _pi(g_st) if g_st is not None else None,
+        _pi(out["feat_status"]), _p(out["chi2"]), _p(out["chi2_thresh"]),
         _p(out["p_FinG"]), _p(out["dx"]), _p(out["P"]), _p(out["clone_q_p"]), _p(out["calib_q_p"]), _p(out["intrinsics"]),
         _p(Hc) if want_compressed else None, _p(rc) if want_compressed else None, C.byref(rows), C.byref(stats), _p(secs))
     assert rcode == 0

@@ -1,0 +1,365 @@
+"""GPU parity tests (run with `-m gpu` on an MI355X): the HIP path, called through the C ABI, against the CPU
+oracle on identical seeded inputs.
+
+Tolerances (floating point path; stated per SURVEY.md §8c and confirmed by measurement):
+  * triangulation + Gauss-Newton: |p_FinG - oracle| <= 1e-9 m for every feature (measured max 5e-11 m over
+    776 features).  The LM loop of the reference accepts / rejects steps on float32-rounded costs (Q3); the
+    kernels reproduce every float rounding of that path (no FMA contraction of float products, correctly
+    rounded float sqrt), so the same branches are taken and only double round-off from the summation order
+    (serial in the oracle, wavefront butterfly on the GPU) remains.
+  * everything after loop A, with the SAME positions injected on both sides: chi2 rel 1e-8, dx rel 1e-8,
+    P rel-Frobenius 1e-9, identical accept / reject sets (features within 1e-6 of the gate are excused).
+  * end to end (positions triangulated on each side): same bounds as with injected positions, relaxed by 10x.
+"""
+import numpy as np
+import pytest
+
+from open_vins_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+
+TOL_TRI = 1e-9
+TOL_CHI2 = 1e-8
+TOL_DX = 1e-8
+TOL_P = 1e-9
+
+
+@pytest.fixture(scope="module")
+def Updater():
+    import torch
+    assert torch.cuda.is_available(), "these tests need a GPU"
+    from open_vins_amd.updater import UpdaterMSCKF
+    return UpdaterMSCKF
+
+
+def _check_tri(out, ref, ok):
+    assert np.abs(out["p_FinG"][ok] - ref["p_FinG"][ok]).max() < TOL_TRI
+    assert np.abs(out["p_FinA"][ok] - ref["p_FinA"][ok]).max() < TOL_TRI
+
+
+def _rel(a, b):
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+def _check_given(Updater, oracle, prob, opts, tol_dx=TOL_DX, tol_p=TOL_P):
+    """Injects the oracle's triangulation on both sides and compares everything downstream."""
+    v = capi.Views(prob)
+    tri = oracle.triangulate(opts, v)
+    ref = oracle.msckf_update(opts, v, want_compressed=True, given=tri)
+    up = Updater(opts)
+    up.set_problem(prob)
+    up.set_triangulation(tri["p_FinG"], tri["p_FinA"], tri["anchor_meas"], tri["status"])
+    out = up.update()
+    # accept / reject sets
+    diff = np.nonzero(out["feat_status"] != ref["feat_status"])[0]
+    for f in diff:
+        margin = abs(ref["chi2"][f] / ref["chi2_thresh"][f] - 1.0)
+        assert margin < 1e-6, f"feature {f}: status {out['feat_status'][f]} vs {ref['feat_status'][f]} (gate margin {margin})"
+    gate = np.isfinite(ref["chi2"])
+    assert gate.sum() > 0
+    np.testing.assert_allclose(out["chi2"][gate], ref["chi2"][gate], rtol=TOL_CHI2)
+    np.testing.assert_allclose(out["chi2_thresh"][gate], ref["chi2_thresh"][gate], rtol=1e-12)
+    if len(diff) == 0:
+        assert out["stats"]["n_used"] == ref["stats"]["n_used"]
+        assert out["stats"]["n_rows"] == ref["stats"]["n_rows"]
+        assert _rel(out["dx"], ref["dx"]) < tol_dx
+        assert _rel(out["P"], ref["P"]) < tol_p
+        assert np.abs(out["clone_q_p"] - ref["clone_q_p"]).max() < 1e-9
+        assert np.abs(out["calib_q_p"] - ref["calib_q_p"]).max() < 1e-9
+        assert np.abs(out["intrinsics"] - ref["intrinsics"]).max() < 1e-8
+        assert np.array_equal(out["P"], out["P"].T)
+    up.close()
+    return out, ref
+
+
+# --------------------------------------------------------------------------- loop A
+@pytest.mark.parametrize("kw", [dict(), dict(track="ragged"), dict(fisheye=True), dict(K=1, C=12), dict(cfg=4, F=150)])
+def test_triangulation_parity(Updater, oracle, kw):
+    kw = dict(kw)
+    prob = synth.make_problem(kw.pop("cfg", 2), F=kw.pop("F", 300), **kw)
+    opts = capi.default_options()
+    ref = oracle.triangulate(opts, capi.Views(prob))
+    up = Updater(opts)
+    up.set_problem(prob)
+    out = up.triangulate()
+    assert np.array_equal(out["anchor_meas"], ref["anchor_meas"])
+    same = out["status"] == ref["status"]
+    assert same.all()
+    ok = same & (ref["status"] == capi.FEAT_USED)
+    assert ok.sum() > 0.5 * prob.F
+    _check_tri(out, ref, ok)
+    up.close()
+
+
+def test_triangulation_1d_parity(Updater, oracle):
+    prob = synth.make_problem(2, F=200)
+    opts = capi.default_options(triangulate_1d=1)
+    ref = oracle.triangulate(opts, capi.Views(prob))
+    up = Updater(opts)
+    up.set_problem(prob)
+    out = up.triangulate()
+    ok = (out["status"] == ref["status"]) & (ref["status"] == capi.FEAT_USED)
+    assert ok.sum() > 0.5 * prob.F
+    _check_tri(out, ref, ok)
+    up.close()
+
+
+def test_triangulation_without_refinement_is_tight(Updater, oracle):
+    """Without the LM loop there is no float-cost branch: the linear triangulation agrees to round-off."""
+    prob = synth.make_problem(2, F=200)
+    opts = capi.default_options(refine_features=0)
+    ref = oracle.triangulate(opts, capi.Views(prob))
+    up = Updater(opts)
+    up.set_problem(prob)
+    out = up.triangulate()
+    assert np.array_equal(out["status"], ref["status"])
+    ok = ref["status"] == capi.FEAT_USED
+    assert np.abs(out["p_FinG"][ok] - ref["p_FinG"][ok]).max() < 1e-9
+    up.close()
+
+
+# --------------------------------------------------------------------------- loops B, C and the EKF update (positions injected)
+@pytest.mark.parametrize("kw", [
+    dict(F=120),
+    dict(F=120, track="ragged"),
+    dict(F=100, fisheye=True),
+    dict(F=100, outlier_frac=0.25),
+    dict(F=60, K=1, C=12),
+    dict(F=7),
+    dict(F=1),
+    dict(cfg=4, F=40),
+])
+def test_update_parity_given_positions(Updater, oracle, kw):
+    kw = dict(kw)
+    prob = synth.make_problem(kw.pop("cfg", 2), **kw)
+    opts = capi.default_options(chi2_multipler=1.0)
+    out, ref = _check_given(Updater, oracle, prob, opts)
+    if kw.get("outlier_frac"):
+        assert np.sum(ref["feat_status"] == capi.FEAT_CHI2_REJECTED) >= 5  # the gate was exercised
+
+
+@pytest.mark.parametrize("rep", [capi.REP_GLOBAL_FULL_INVERSE_DEPTH, capi.REP_ANCHORED_3D, capi.REP_ANCHORED_FULL_INVERSE_DEPTH,
+                                 capi.REP_ANCHORED_MSCKF_INVERSE_DEPTH, capi.REP_ANCHORED_INVERSE_DEPTH_SINGLE])
+def test_update_parity_feature_representations(Updater, oracle, rep):
+    prob = synth.make_problem(2, F=60, C=14)
+    _check_given(Updater, oracle, prob, capi.default_options(chi2_multipler=1.0, feat_rep_msckf=rep))
+
+
+@pytest.mark.parametrize("flags", [dict(do_fej=0), dict(do_calib_camera_pose=0), dict(do_calib_camera_intrinsics=0),
+                                   dict(do_calib_camera_pose=0, do_calib_camera_intrinsics=0), dict(sigma_pix=2.0, chi2_multipler=3.0)])
+def test_update_parity_state_options(Updater, oracle, flags):
+    prob = synth.make_problem(2, F=60, C=14)
+    _check_given(Updater, oracle, prob, capi.default_options(**{"chi2_multipler": 1.0, **flags}))
+
+
+def test_update_parity_long_tracks_use_global_gate_workspace(Updater, oracle):
+    """cfg-5 geometry (50 clones x 4 cameras, up to 200 measurements per feature): the gate matrix no longer
+    fits LDS and goes through the HBM workspace."""
+    prob = synth.make_problem(5, F=12)
+    assert np.diff(prob.meas_offsets).max() > 120
+    _check_given(Updater, oracle, prob, capi.default_options(chi2_multipler=1.0))
+
+
+def test_short_and_empty_tracks(Updater, oracle):
+    prob = synth.make_problem(2, F=12)
+    keep, offs = [], [0]
+    for f in range(prob.F):
+        a, b = int(prob.meas_offsets[f]), int(prob.meas_offsets[f + 1])
+        if f == 2:
+            b = a + 1
+        if f == 4:
+            b = a
+        if f == 6:
+            b = a + 2
+        keep += list(range(a, b))
+        offs.append(offs[-1] + (b - a))
+    keep = np.asarray(keep)
+    prob.meas_offsets = np.asarray(offs, dtype=np.int32)
+    prob.uv = prob.uv.reshape(-1, 2)[keep].reshape(-1)
+    prob.uvn = prob.uvn.reshape(-1, 2)[keep].reshape(-1)
+    prob.clone_idx, prob.cam_idx = prob.clone_idx[keep], prob.cam_idx[keep]
+    opts = capi.default_options(chi2_multipler=1.0)
+    out, ref = _check_given(Updater, oracle, prob, opts)
+    assert out["feat_status"][2] == capi.FEAT_TOO_FEW_MEAS and out["feat_status"][4] == capi.FEAT_TOO_FEW_MEAS
+    # end to end as well (statuses come from the GPU triangulation here)
+    up = Updater(opts)
+    up.set_problem(prob)
+    o2 = up.update()
+    assert o2["feat_status"][2] == capi.FEAT_TOO_FEW_MEAS and o2["feat_status"][4] == capi.FEAT_TOO_FEW_MEAS
+    up.close()
+
+
+def test_no_features_is_a_no_op(Updater):
+    prob = synth.make_problem(2, F=5)
+    empty = prob.subset([])
+    up = Updater(capi.default_options())
+    up.set_problem(empty)
+    out = up.update()
+    assert out["stats"]["n_used"] == 0 and out["stats"]["n_rows"] == 0
+    np.testing.assert_array_equal(out["P"], prob.P)  # UpdaterMSCKF.cpp:61-62 returns early
+    assert np.all(out["dx"] == 0)
+    up.close()
+
+
+def test_all_features_rejected_leaves_state_untouched(Updater):
+    prob = synth.make_problem(2, F=20)
+    up = Updater(capi.default_options(chi2_multipler=1e-9))
+    up.set_problem(prob)
+    out = up.update()
+    assert out["stats"]["n_used"] == 0
+    np.testing.assert_allclose(out["P"], prob.P, rtol=0, atol=0)
+    assert np.all(out["dx"] == 0)
+    up.close()
+
+
+# --------------------------------------------------------------------------- end to end + mode A
+def test_end_to_end_update(Updater, oracle):
+    prob = synth.make_problem(2, F=200)
+    opts = capi.default_options(chi2_multipler=1.0)
+    ref = oracle.msckf_update(opts, capi.Views(prob))
+    up = Updater(opts)
+    up.set_problem(prob)
+    out = up.update()
+    assert np.array_equal(out["feat_status"], ref["feat_status"])
+    ok = ref["feat_status"] == 0
+    assert np.abs(out["p_FinG"][ok] - ref["p_FinG"][ok]).max() < TOL_TRI
+    assert _rel(out["dx"], ref["dx"]) < 10 * TOL_DX
+    assert _rel(out["P"], ref["P"]) < 10 * TOL_P
+    up.close()
+
+
+def test_mode_a_compressed_system(Updater, oracle):
+    """ovgpu_msckf_compress hands back (H, r) for the stock StateHelper::EKFUpdate: R^T R and R^T c equal the
+    reference's compressed system's (R itself is only unique up to row signs), and feeding it to the
+    oracle's EKFUpdate reproduces the oracle's posterior."""
+    prob = synth.make_problem(2, F=100)
+    opts = capi.default_options(chi2_multipler=1.0)
+    v = capi.Views(prob)
+    tri = oracle.triangulate(opts, v)
+    ref = oracle.msckf_update(opts, v, want_compressed=True, given=tri)
+    up = Updater(opts)
+    up.set_problem(prob)
+    up.set_triangulation(tri["p_FinG"], tri["p_FinA"], tri["anchor_meas"], tri["status"])
+    cmp = up.compress()
+    assert cmp["D"] == ref["D"] and cmp["rows"] == cmp["D"]
+    assert np.array_equal(cmp["col_cov_id"], oracle.column_map(opts, v))
+    H, r = cmp["H"], cmp["r"]
+    assert np.abs(np.tril(H, -1)).max() == 0.0
+    G = ref["H_comp"].T @ ref["H_comp"]
+    assert np.linalg.norm(H.T @ H - G) / np.linalg.norm(G) < 1e-11
+    g = ref["H_comp"].T @ ref["r_comp"]
+    assert np.linalg.norm(H.T @ r - g) / np.linalg.norm(g) < 1e-10
+    st, P1, dx1 = oracle.ekf_update(prob.P, H, r, cmp["col_cov_id"], 1.0)
+    assert st == 0
+    assert _rel(P1, ref["P"]) < TOL_P and _rel(dx1, ref["dx"]) < TOL_DX
+    # the resident state was not touched by mode A
+    np.testing.assert_array_equal(up.get_state()["P"], prob.P)
+    up.close()
+
+
+def test_consecutive_updates_see_the_posterior(Updater, oracle):
+    """VioManager calls the updaters back to back on the evolving state (VioManager.cpp:525-547)."""
+    prob = synth.make_problem(2, F=60)
+    second = synth.make_problem(2, F=40, shard=1)
+    opts = capi.default_options(chi2_multipler=1.0)
+    v1 = capi.Views(prob)
+    t1 = oracle.triangulate(opts, v1)
+    r1 = oracle.msckf_update(opts, v1, given=t1)
+    import copy
+    p2 = copy.copy(second)
+    p2.P, p2.clone_q_p, p2.calib_q_p, p2.intrinsics = r1["P"], r1["clone_q_p"], r1["calib_q_p"], r1["intrinsics"]
+    v2 = capi.Views(p2)
+    t2 = oracle.triangulate(opts, v2)
+    r2 = oracle.msckf_update(opts, v2, given=t2)
+    up = Updater(opts)
+    up.set_problem(prob)
+    up.set_triangulation(t1["p_FinG"], t1["p_FinA"], t1["anchor_meas"], t1["status"])
+    up.update()
+    up.set_features(second)
+    up.set_triangulation(t2["p_FinG"], t2["p_FinA"], t2["anchor_meas"], t2["status"])
+    o2 = up.update()
+    assert np.array_equal(o2["feat_status"], r2["feat_status"])
+    assert _rel(o2["P"], r2["P"]) < 1e-8 and _rel(o2["dx"], r2["dx"]) < 1e-6
+    up.close()
+
+
+def test_reset_state_is_idempotent(Updater):
+    prob = synth.make_problem(2, F=80)
+    up = Updater(capi.default_options(chi2_multipler=1.0))
+    up.set_problem(prob)
+    a = up.update()
+    up.reset_state()
+    b = up.update()
+    np.testing.assert_array_equal(a["P"], b["P"])  # same kernels, same inputs, no atomics: bitwise repeatable
+    np.testing.assert_array_equal(a["dx"], b["dx"])
+    up.close()
+
+
+# --------------------------------------------------------------------------- feature sharding on one GPU
+def test_sharded_update_equals_unsharded(Updater, oracle):
+    """Two contexts each compress half of the features; QR of the two stacked triangles + one EKF update must
+    equal the single-context update (QR([R1; R2]) has the same R^T R as QR of the full stack)."""
+    import torch
+    from open_vins_amd import parallel
+    prob = synth.make_problem(2, F=120)
+    opts = capi.default_options(chi2_multipler=1.0)
+    v = capi.Views(prob)
+    tri = oracle.triangulate(opts, v)
+    full = Updater(opts)
+    full.set_problem(prob)
+    full.set_triangulation(tri["p_FinG"], tri["p_FinA"], tri["anchor_meas"], tri["status"])
+    ref = full.update()
+    G = 2
+    tris = []
+    ups = []
+    for rank in range(G):
+        ids = parallel.shard_features(prob.meas_offsets, rank, G)
+        sub = prob.subset(ids)
+        u = Updater(opts)
+        u.set_problem(sub)
+        off = prob.meas_offsets
+        anchor_local = tri["anchor_meas"][ids] - off[ids] + sub.meas_offsets[:-1]
+        u.set_triangulation(tri["p_FinG"][ids], tri["p_FinA"][ids], anchor_local, tri["status"][ids])
+        t = torch.empty(u.triangle_len(), dtype=torch.float64, device="cuda")
+        u.local(t.data_ptr(), want_outputs=False)
+        tris.append(t)
+        ups.append(u)
+    gathered = torch.cat(tris)
+    torch.cuda.synchronize()
+    out = ups[0].merge_update(gathered.data_ptr(), G)
+    assert _rel(out["P"], ref["P"]) < 1e-10
+    assert _rel(out["dx"], ref["dx"]) < 1e-9
+    for u in ups:
+        u.close()
+    full.close()
+
+
+# --------------------------------------------------------------------------- BASELINE.json full sizes: properties
+def test_cfg2_full_size_against_oracle(Updater, oracle):
+    """configs[1]: 30 clones, stereo, 800 features — the bench workload, compared with the oracle directly."""
+    prob = synth.make_problem(2)
+    assert prob.F == 800 and prob.N == 224
+    _check_given(Updater, oracle, prob, capi.default_options(chi2_multipler=1.0), tol_dx=1e-7, tol_p=1e-8)
+
+
+def test_cfg3_full_size_properties(Updater):
+    """configs[2] (2000 features): size-independent properties — symmetric PSD posterior, shrinking marginals,
+    information-form identity dx = P' H^T r / sigma^2 evaluated through the compressed system."""
+    prob = synth.make_problem(3)
+    assert prob.F == 2000
+    opts = capi.default_options(chi2_multipler=1.0)
+    up = Updater(opts)
+    up.set_problem(prob)
+    cmp = up.compress()
+    up.reset_state()
+    out = up.update()
+    P1 = out["P"]
+    assert np.array_equal(P1, P1.T)
+    assert np.linalg.eigvalsh(P1).min() > -1e-12
+    assert np.all(np.diag(P1) <= np.diag(prob.P) + 1e-15)
+    H = np.zeros((cmp["rows"], prob.N))
+    H[:, cmp["col_cov_id"]] = cmp["H"]
+    Pinf = np.linalg.inv(np.linalg.inv(prob.P) + H.T @ H)
+    assert _rel(P1, Pinf) < 1e-7
+    assert _rel(out["dx"], Pinf @ H.T @ cmp["r"]) < 1e-6
+    up.close()
