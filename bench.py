@@ -1,0 +1,173 @@
+#!/usr/bin/env python3
+"""MSCKF-update benchmark (BASELINE.json metric: MSCKF features/sec per EKF update at a 30-clone state).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one complete UpdaterMSCKF::update (triangulate + refine -> Jacobians -> nullspace -> chi2 gate ->
+measurement compression -> EKF update) of the BASELINE.json configs[1] snapshot (rpng_sim stereo, 30 clones,
+800 MSCKF features, N = 224, D = 208) with every input already resident in HBM.  At N > 1 (one process per GPU,
+launched by torch.distributed.run) the features are sharded: every rank holds its own 800-feature shard on the
+same prior (weak scaling), compresses it locally, the D x (D+1) triangles are all-gathered over RCCL and every
+rank applies the identical merge + EKF update.  value = features of all ranks / max-over-ranks time.
+
+Rank 0 prints ONE JSON line with the contract fields plus
+  roofline     : the dominant kernel (measurement compression, a tall-skinny Householder QR in f64), algorithmic
+                 FLOPs of SURVEY.md §8(d) (2 r D^2 per feature) over its HIP-event time on the kernel's stream
+  cpu_baseline : the oracle (float64 restatement of the reference's serial Eigen path) on the host cores, 1 thread.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP64_TFLOPS = 78.6  # MI355X FP64 vector = matrix peak (spec), 256 CU x 128 flop/clk x 2.4 GHz
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--cfg", type=int, default=2, help="BASELINE.json config index + 1 (2 = configs[1])")
+    ap.add_argument("--features", type=int, default=None, help="override features per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from open_vins_amd import capi, parallel, synth
+    from open_vins_amd.updater import UpdaterMSCKF
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the update path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)  # RCCL over xGMI
+
+    # ---- workload: configs[1] on every rank, rank-specific feature stream on the shared prior
+    prob = synth.make_problem(args.cfg, F=args.features, shard=rank)
+    opts = capi.default_options(chi2_multipler=1.0)  # config/rpng_sim/estimator_config.yaml:100-101
+    up = UpdaterMSCKF(opts, device=local_rank)
+    up.set_problem(prob)  # H2D once; everything below runs on resident data
+    backend = parallel.GpuShardBackend(up)
+
+    def step():
+        up.reset_state()  # device-side copy of the prior: every step updates the same prior
+        if world == 1:
+            up.update_async()
+        else:
+            parallel.distributed_update(backend, dist, device, want_outputs=False)
+
+    def fence():
+        up.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    up.kernel_times(reset=True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    kt = up.kernel_times(reset=True)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    ms_per_step = 1e3 * dt / args.steps
+    feats_total = prob.F * world
+    value = feats_total / (dt / args.steps)
+
+    out = None
+    if rank == 0:
+        flops_total, flops_compress = synth.algorithmic_flops(prob)
+        ms_c = kt["ms_compress"]
+        achieved = flops_compress / (ms_c * 1e-3) / 1e12 if ms_c > 0 else 0.0
+        out = {
+            "metric": "MSCKF features/sec per EKF update (30-clone state)",
+            "value": value,
+            "unit": "features/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"BASELINE.json configs[{args.cfg - 1}]: rpng_sim stereo radtan rig, {prob.C}-clone window, "
+                            f"{prob.F} MSCKF features/update per GPU, N={prob.N}, D={prob.Dmax}, online cam extrinsic+intrinsic calib, FEJ",
+                "features_per_gpu": prob.F, "clones": prob.C, "cameras": prob.K, "state_dim": prob.N,
+                "measurements_per_gpu": prob.M, "parallelism": f"feature-shard x{world}" if world > 1 else "single GPU",
+            },
+            "roofline": {
+                "kernel": "measurement compression (TSQR, k_qr_append leaf + merge tree)",
+                "bound": "mfma",
+                "achieved": achieved,
+                "peak": PEAK_FP64_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": achieved / PEAK_FP64_TFLOPS,
+                "traffic": None,
+                "algorithmic_flops_per_launch": flops_compress,
+                "avg_ms_per_launch": ms_c,
+                "update_ms_device": kt["ms_update"],
+                "update_algorithmic_tflops": flops_total / (kt["ms_update"] * 1e-3) / 1e12 if kt["ms_update"] > 0 else 0.0,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(prob, opts)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    up.close()
+    return out
+
+
+def cpu_baseline(prob, opts):
+    """The oracle (kind "port": float64 restatement of the reference's serial path, 1 thread) timed on this
+    host on the same snapshot: 1 warm-up + 3 updates of the full 800-feature workload (~10-15 s of CPU work)."""
+    from open_vins_amd import capi
+    from oracle import pyoracle
+    v = capi.Views(prob)
+    pyoracle.msckf_update(opts, v)
+    ts = []
+    stages = None
+    for _ in range(3):
+        t = time.perf_counter()
+        o = pyoracle.msckf_update(opts, v)
+        ts.append(time.perf_counter() - t)
+        stages = o["stage_seconds"]
+    med = sorted(ts)[len(ts) // 2]
+    return {
+        "value": prob.F / med,
+        "unit": "features/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"3 full updates of the same {prob.F}-feature snapshot after 1 warm-up, median {med:.3f} s/update; "
+                  f"host has {os.cpu_count()} cores; stages (s) {json.dumps({k: round(x, 4) for k, x in stages.items()})}",
+        "seconds_per_update": med,
+    }
+
+
+if __name__ == "__main__":
+    main()
