@@ -16,6 +16,7 @@
 
 #include "chi2.h"
 #include "k_compress.h"
+#include "k_tsqr.h"
 #include "k_ekf.h"
 #include "k_system.h"
 #include "k_triangulate.h"
@@ -107,6 +108,7 @@ struct ovgpu_ctx {
   DevBuf<double> Hbig, gate_ws, Rws, Mt, Aaug, dx;
   DevBuf<int32_t> flags;
   int W = 1;
+  int64_t rows_per_node = 128;
   int sys_grid = 1;
   int64_t gate_ws_stride = 0;
   int m_lds_max = 0;
@@ -122,6 +124,37 @@ struct ovgpu_ctx {
 static hipError_t upload(void *dst, const void *src, size_t bytes, hipStream_t s) {
   if (bytes == 0) return hipSuccess;
   return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s);
+}
+
+// profiling builds (-DQR_PROFILE): 128 cycle counters written by node 0 of the last leaf / merge launch
+static long long *qr_dbg_buffer() {
+#ifdef QR_PROFILE
+  static long long *buf = nullptr;
+  if (!buf) {
+    (void)hipMalloc((void **)&buf, 128 * sizeof(long long));
+    (void)hipMemset(buf, 0, 128 * sizeof(long long));
+  }
+  return buf;
+#else
+  return nullptr;
+#endif
+}
+
+static constexpr int QR_B = 32;  // row block of the generic fallback kernel (D + 1 > 256 columns)
+static constexpr int QR_LEAF_Q = 32; // leaf nodes fold 4 * 32 = 128 dense rows per append
+
+template <int QH, bool TRI>
+static int launch_qr_node(ovgpu_ctx *c, int nodes, const QrNodeParams &q) {
+  const size_t lds = qr_node_lds_bytes(q.NT, QH);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void *)k_qr_node<QH, TRI>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  const int NW = (q.NT + 1) / 2;
+  hipLaunchKernelGGL((k_qr_node<QH, TRI>), dim3(nodes), dim3(64 * NW), lds, c->stream, q);
+  HIPCHK(hipGetLastError());
+  return OVGPU_OK;
 }
 
 extern "C" {
@@ -400,12 +433,17 @@ int ovgpu_set_features(ovgpu_ctx *c, const ovgpu_features_view *fv) {
   // ---- stacked system and TSQR accumulators
   const int D = c->D, LD = c->LD;
   HIPCHK(c->Hbig.reserve((size_t)std::max<int64_t>(c->rows_total, 1) * LD));
+  // leaf nodes of the TSQR: one per CU when there are enough rows, every node a whole number of 128-row appends
   int W = 1;
   {
+    const int64_t blk = 4 * QR_LEAF_Q;
     const char *wenv = std::getenv("OVGPU_TSQR_W");
-    int64_t target = wenv ? std::atoll(wenv) : (c->rows_total + D - 1) / std::max(D, 1);
-    target = std::max<int64_t>(1, std::min<int64_t>(target, 512));
-    while (W < target) W <<= 1;
+    const int64_t target = std::max<int64_t>(1, wenv ? std::atoll(wenv) : c->num_cu);
+    int64_t rpn = (c->rows_total + target - 1) / target;
+    rpn = std::max<int64_t>(blk, ((rpn + blk - 1) / blk) * blk);
+    if (rpn < 2 * blk && c->rows_total > 2 * blk) rpn = 2 * blk; // a leaf shorter than D rows compresses nothing
+    c->rows_per_node = rpn;
+    W = (int)std::max<int64_t>(1, (c->rows_total + rpn - 1) / rpn);
   }
   c->W = W;
   HIPCHK(c->Rws.reserve((size_t)std::max(W, 16) * D * LD));
@@ -458,40 +496,61 @@ static int enqueue_system(ovgpu_ctx *c) {
   return OVGPU_OK;
 }
 
-static constexpr int QR_B = 32;
-
 // merges triangles Rws[0..G) pairwise until Rws[0] holds the result
 static int enqueue_merge_tree(ovgpu_ctx *c, int G) {
   const int D = c->D, LD = c->LD;
-  const int nt = ((LD + 63) / 64) * 64;
+  const int NT = (LD + 15) / 16;
   for (int stride = 1; stride < G; stride <<= 1) {
     const int pairs = (G - stride + 2 * stride - 1) / (2 * stride); // i = 0, 2s, 4s, ... with i + s < G
     if (pairs <= 0) break;
-    QrAppendParams q;
-    q.D = D, q.LD = LD;
-    q.dst = c->Rws.p, q.dst_wg_stride = 2 * (int64_t)stride;
-    q.src = c->Rws.p + (size_t)stride * D * LD, q.src_wg_stride = 2 * (int64_t)stride * D * LD;
-    q.src_rows_per_wg = D, q.src_rows_total = D, q.triangular = 1, q.zero_dst = 0;
-    hipLaunchKernelGGL(k_qr_append<QR_B>, dim3(pairs), dim3(nt), 0, c->stream, q);
-    HIPCHK(hipGetLastError());
+    if (NT <= 16) {
+      QrNodeParams q;
+      q.D = D, q.LD = LD, q.NT = NT;
+      q.acc = c->Rws.p, q.acc_stride = 2 * (int64_t)stride;
+      q.src = c->Rws.p + (size_t)stride * D * LD, q.src_stride = 2 * (int64_t)stride * D * LD;
+      q.rows_per_node = D, q.rows_total = D, q.zero_init = 0, q.dbg = qr_dbg_buffer();
+      int rc;
+      // a merge node needs QH >= 4 NW quads per register array (NW = ceil(NT / 2) waves)
+      if (NT <= 8) rc = launch_qr_node<16, true>(c, pairs, q);
+      else if (NT <= 14) rc = launch_qr_node<28, true>(c, pairs, q);
+      else rc = launch_qr_node<32, true>(c, pairs, q);
+      if (rc != OVGPU_OK) return rc;
+    } else {
+      const int nt = ((LD + 63) / 64) * 64;
+      QrAppendParams q;
+      q.D = D, q.LD = LD;
+      q.dst = c->Rws.p, q.dst_wg_stride = 2 * (int64_t)stride;
+      q.src = c->Rws.p + (size_t)stride * D * LD, q.src_wg_stride = 2 * (int64_t)stride * D * LD;
+      q.src_rows_per_wg = D, q.src_rows_total = D, q.triangular = 1, q.zero_dst = 0;
+      hipLaunchKernelGGL(k_qr_append<QR_B>, dim3(pairs), dim3(nt), 0, c->stream, q);
+      HIPCHK(hipGetLastError());
+    }
   }
   return OVGPU_OK;
 }
 
 static int enqueue_compress(ovgpu_ctx *c) {
   const int D = c->D, LD = c->LD;
-  const int nt = ((LD + 63) / 64) * 64;
+  const int NT = (LD + 15) / 16;
   const int W = c->W;
-  int64_t rpw = (c->rows_total + W - 1) / W;
-  rpw = ((rpw + QR_B - 1) / QR_B) * QR_B;
-  if (rpw == 0) rpw = QR_B;
-  QrAppendParams q;
-  q.D = D, q.LD = LD;
-  q.dst = c->Rws.p, q.dst_wg_stride = 1;
-  q.src = c->Hbig.p, q.src_wg_stride = rpw * LD;
-  q.src_rows_per_wg = rpw, q.src_rows_total = c->rows_total, q.triangular = 0, q.zero_dst = 1;
-  hipLaunchKernelGGL(k_qr_append<QR_B>, dim3(W), dim3(nt), 0, c->stream, q);
-  HIPCHK(hipGetLastError());
+  if (NT <= 16) {
+    QrNodeParams q;
+    q.D = D, q.LD = LD, q.NT = NT;
+    q.acc = c->Rws.p, q.acc_stride = 1;
+    q.src = c->Hbig.p, q.src_stride = 0;
+    q.rows_per_node = c->rows_per_node, q.rows_total = c->rows_total, q.zero_init = 1, q.dbg = qr_dbg_buffer();
+    const int rc = launch_qr_node<QR_LEAF_Q, false>(c, W, q);
+    if (rc != OVGPU_OK) return rc;
+  } else {
+    const int nt = ((LD + 63) / 64) * 64;
+    QrAppendParams q;
+    q.D = D, q.LD = LD;
+    q.dst = c->Rws.p, q.dst_wg_stride = 1;
+    q.src = c->Hbig.p, q.src_wg_stride = c->rows_per_node * LD;
+    q.src_rows_per_wg = c->rows_per_node, q.src_rows_total = c->rows_total, q.triangular = 0, q.zero_dst = 1;
+    hipLaunchKernelGGL(k_qr_append<QR_B>, dim3(W), dim3(nt), 0, c->stream, q);
+    HIPCHK(hipGetLastError());
+  }
   return enqueue_merge_tree(c, W);
 }
 
@@ -824,6 +883,12 @@ int ovgpu_synchronize(ovgpu_ctx *c) {
 }
 
 uint64_t ovgpu_stream(ovgpu_ctx *c) { return c ? (uint64_t)(uintptr_t)c->stream : 0; }
+
+#ifdef QR_PROFILE
+int ovgpu_debug_qr_cycles(long long *out128) {
+  return hipMemcpy(out128, qr_dbg_buffer(), 128 * sizeof(long long), hipMemcpyDeviceToHost) == hipSuccess ? OVGPU_OK : OVGPU_ERR_HIP;
+}
+#endif
 
 int ovgpu_kernel_times(ovgpu_ctx *c, int reset, double *ms_compress_avg, double *ms_update_avg, int64_t *n_launches) {
   if (!c) return set_err(OVGPU_ERR_INVALID, "null ctx");

@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""Developer script: per-phase cycle counts of the TSQR node kernel (needs tools/_prof/libovgpu_prof.so, built with -DQR_PROFILE)."""
+import ctypes, os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+from open_vins_amd import capi
+capi.LIB_PATH = os.path.join(os.path.dirname(__file__), "_prof", "libovgpu_prof.so")
+import numpy as np
+from open_vins_amd import synth
+from open_vins_amd.updater import UpdaterMSCKF
+
+prob = synth.make_problem(2, F=int(sys.argv[1]) if len(sys.argv) > 1 else 800)
+up = UpdaterMSCKF(capi.default_options(chi2_multipler=1.0))
+up.set_problem(prob)
+for _ in range(3):
+    up.reset_state(); up.update_async()
+up.synchronize()
+print(up.kernel_times(reset=True))
+lib = capi.load()
+buf = (ctypes.c_longlong * 128)()
+lib.ovgpu_debug_qr_cycles.argtypes = [ctypes.POINTER(ctypes.c_longlong)]
+lib.ovgpu_debug_qr_cycles(buf)
+a = np.array(buf[:]).reshape(2, 16, 4)
+for name, blk in (("leaf (dense, node 0)", a[0]), ("last merge (node 0)", a[1])):
+    print(name, "cycles per wave: [other+loop-top, owner pre-step, barrier wait, apply]")
+    for w in range(8):
+        print("  wave", w, blk[w], "sum", blk[w].sum())
