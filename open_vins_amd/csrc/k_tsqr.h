@@ -462,4 +462,145 @@ __global__ void __launch_bounds__(512) k_qr_node(QrNodeParams p) {
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------
+// The whole merge tree in ONE launch, software-pipelined across its levels.
+//
+// A merge node only needs panel p of its two inputs to run its own panel p: the accumulator rows 16 p .. 16 p + 15 of
+// child A (final once A finished ITS panel p) and rows < 16 (p + 1) of child B's triangle.  So all nodes of all levels
+// run concurrently, each one panel behind its children: the tree costs about one merge plus one panel per level
+// instead of one merge per level.  Every node is a workgroup; all of them must be co-resident (the host launches at
+// most one node per CU; a node occupies a whole CU's register file), and every wait is bounded.
+//
+// Hand-off (MI355X_MICROARCH.md, "inter-workgroup visibility"): producer = plain stores, __syncthreads, lane 0:
+// agent-scope release fence, s_waitcnt vmcnt(0), relaxed agent-scope store of the panel counter; consumer = lane 0
+// polls the counter with relaxed agent-scope loads (+ s_sleep), agent-scope acquire fence, __syncthreads, plain loads.
+// ---------------------------------------------------------------------------------------------------
+struct QrTreeNode {
+  int32_t a_slot, b_slot; // triangles: accumulator (in place) and the one folded into it
+  int32_t dep_a, dep_b;   // node whose output the slot is (-1: a leaf result, complete before the launch)
+};
+
+struct QrTreeParams {
+  int D, LD, NT;
+  double *tri;             // triangle slot s at tri + s * D * LD
+  const QrTreeNode *nodes; // one per workgroup
+  int32_t *progress;       // [nodes] panels finished, zeroed before the launch
+  int32_t *error;          // set to 1 when a wait ran into its bound
+  int64_t spin_limit;
+};
+
+__device__ __forceinline__ void qr_wait_panels(const int32_t *flag, int need, int64_t limit, int32_t *error) {
+  int64_t it = 0;
+  while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+    __builtin_amdgcn_s_sleep(8);
+    if (++it > limit) {
+      *error = 1;
+      break;
+    }
+  }
+}
+
+// rows 16 j .. 16 j + 15 of one tile column -> quads 4 j .. 4 j + 3 of a register array (j is wave-uniform)
+template <int QS>
+__device__ __forceinline__ void qr_load_chunk(double (&y)[QS], int j, const double *src, int64_t row0, int g, int64_t lim, int col, int LD, bool valid) {
+  const bool ok = valid && col < LD;
+  double v[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int64_t r = row0 + 4 * i + g;
+    v[i] = (ok && r < lim) ? src[(size_t)r * LD + col] : 0.0;
+  }
+#pragma unroll
+  for (int q = 0; q < QS; q++) y[q] = ((q >> 2) == j) ? v[q & 3] : y[q];
+}
+
+template <int QH>
+__global__ void __launch_bounds__(512) k_qr_tree(QrTreeParams p) {
+  static_assert(QH % 4 == 0, "quads come in chunks of 4");
+  constexpr int QB = 2 * QH + 2;
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int NT = p.NT, LDP = NT * 16 + 2, D = p.D, LD = p.LD;
+  double *Rp = lds;               // [16][LDP] accumulator rows of the current panel (second buffer unused here)
+  double *xb = Rp + 2 * 16 * LDP; // [2][4][QB]
+  double *sc = xb + 2 * 4 * QB;   // [2][4]
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int w = tid >> 6, l = tid & 63, c = l & 15, g = l >> 4;
+  const int NW = nthr >> 6;
+  const int t0 = w, t1 = NT - 1 - w;
+  const bool has1 = t1 > t0;
+  const int NP = (D + 15) >> 4;
+  const QrTreeNode nd = p.nodes[blockIdx.x];
+  double *acc = p.tri + (size_t)nd.a_slot * D * LD;
+  const double *src = p.tri + (size_t)nd.b_slot * D * LD;
+  const bool cp_ok = tid < 32 * NT;
+  const int cp_r = tid >= 16 * NT ? 1 : 0, cp_c = tid - cp_r * 16 * NT;
+
+  double ya[QH], yb[QH];
+#pragma unroll
+  for (int q = 0; q < QH; q++) ya[q] = 0.0, yb[q] = 0.0;
+  QrGeom G;
+  G.LDP = LDP, G.w = w, G.l = l, G.c = c, G.g = g;
+  G.cola = 16 * t0 + c, G.colb = has1 ? 16 * t1 + c : NT * 16;
+  for (int e = tid; e < 16 * LDP; e += nthr) Rp[e] = 0.0; // pad columns stay zero
+  int par = 0;
+
+  for (int pnl = 0; pnl < NP; pnl++) {
+    // ---- wait until both inputs have finished this panel
+    if (tid == 0) {
+      if (nd.dep_a >= 0) qr_wait_panels(p.progress + nd.dep_a, pnl + 1, p.spin_limit, p.error);
+      if (nd.dep_b >= 0) qr_wait_panels(p.progress + nd.dep_b, pnl + 1, p.spin_limit, p.error);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+    // ---- accumulator rows of the panel -> LDS; rows 16 pnl .. of the source triangle -> registers
+    if (cp_ok) {
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        const int row = 2 * i + cp_r, j = 16 * pnl + row;
+        Rp[row * LDP + cp_c] = (j < D && cp_c < LD) ? acc[(size_t)j * LD + cp_c] : 0.0;
+      }
+    }
+    const bool split = pnl >= NW;
+    if (pnl == NW) { // every early tile is finished: ya now takes the rows 4 QH .. of the late tile
+#pragma unroll
+      for (int q = 0; q < QH; q++) ya[q] = 0.0;
+    }
+    if (!split) {
+      if (pnl <= t0) qr_load_chunk<QH>(ya, pnl, src, 16 * pnl, g, D, G.cola, LD, true);
+      if (has1 && pnl <= t1) qr_load_chunk<QH>(yb, pnl, src, 16 * pnl, g, D, G.colb, LD, true);
+    } else if (has1 && pnl <= t1) {
+      if (4 * pnl < QH) qr_load_chunk<QH>(yb, pnl, src, 16 * pnl, g, D, G.colb, LD, true);
+      else qr_load_chunk<QH>(ya, pnl - QH / 4, src, 16 * pnl, g, D, G.colb, LD, true);
+    }
+    __syncthreads();
+
+    G.owner_is_b = !(pnl < NW);
+    G.owner_w = G.owner_is_b ? NT - 1 - pnl : pnl;
+    G.pnl = pnl, G.kmax = min(16, D - 16 * pnl);
+    const bool actb = has1 && t1 >= pnl;
+    if (!split) {
+      if (pnl < 4) qr_panel_pair<QH, (QH < 16 ? QH : 16), true, true>(ya, yb, G, Rp, xb, sc, par, true);
+      else qr_panel_pair<QH, QH, true, true>(ya, yb, G, Rp, xb, sc, par, true);
+    } else {
+      if (4 * (pnl + 1) - QH <= 16) qr_panel_split<QH, (QH < 16 ? QH : 16)>(ya, yb, G, Rp, xb, sc, par, actb);
+      else qr_panel_split<QH, QH>(ya, yb, G, Rp, xb, sc, par, actb);
+    }
+    __syncthreads();
+    // ---- the panel's rows are final: write them out and publish
+    if (cp_ok) {
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        const int row = 2 * i + cp_r, j = 16 * pnl + row;
+        if (j < D && cp_c < LD) acc[(size_t)j * LD + cp_c] = Rp[row * LDP + cp_c];
+      }
+    }
+    __syncthreads();
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(p.progress + blockIdx.x, pnl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
 } // namespace ovg

@@ -17,6 +17,7 @@
 #include "chi2.h"
 #include "k_compress.h"
 #include "k_tsqr.h"
+#include "k_tsqr_pw.h"
 #include "k_ekf.h"
 #include "k_system.h"
 #include "k_triangulate.h"
@@ -109,6 +110,10 @@ struct ovgpu_ctx {
   DevBuf<int32_t> flags;
   int W = 1;
   int64_t rows_per_node = 128;
+  DevBuf<QrTreeNode> tree_nodes; // merge tree of the pipelined launch, cached per leaf count
+  DevBuf<int32_t> tree_flags;    // [nodes] progress counters + [1] error flag
+  int tree_G = 0;
+  bool tree_pipelined = true;
   int sys_grid = 1;
   int64_t gate_ws_stride = 0;
   int m_lds_max = 0;
@@ -153,6 +158,36 @@ static int launch_qr_node(ovgpu_ctx *c, int nodes, const QrNodeParams &q) {
   }
   const int NW = (q.NT + 1) / 2;
   hipLaunchKernelGGL((k_qr_node<QH, TRI>), dim3(nodes), dim3(64 * NW), lds, c->stream, q);
+  HIPCHK(hipGetLastError());
+  return OVGPU_OK;
+}
+
+// leaf nodes: the "panel wave" variant (k_tsqr_pw.h), NT <= 15
+template <int QH>
+static int launch_qr_leaf_pw(ovgpu_ctx *c, int nodes, const QrNodeParams &q) {
+  const size_t lds = pw::qr_node_lds_bytes(q.NT, QH);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void *)pw::k_qr_node<QH, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  const int NW = pw::qr_node_bulk_waves(q.NT) + 1;
+  hipLaunchKernelGGL((pw::k_qr_node<QH, false>), dim3(nodes), dim3(64 * NW), lds, c->stream, q);
+  HIPCHK(hipGetLastError());
+  return OVGPU_OK;
+}
+
+// the whole merge tree in one pipelined launch (k_qr_tree); G - 1 nodes, all co-resident
+template <int QH>
+static int launch_qr_tree(ovgpu_ctx *c, int nodes, const QrTreeParams &q) {
+  const size_t lds = qr_node_lds_bytes(q.NT, QH);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void *)k_qr_tree<QH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  const int NW = (q.NT + 1) / 2;
+  hipLaunchKernelGGL((k_qr_tree<QH>), dim3(nodes), dim3(64 * NW), lds, c->stream, q);
   HIPCHK(hipGetLastError());
   return OVGPU_OK;
 }
@@ -205,6 +240,7 @@ int ovgpu_create(const ovgpu_options *opts, int device, ovgpu_ctx **out) {
   if (d.feat_rep == OVGPU_REP_ANCHORED_INVERSE_DEPTH_SINGLE) d.feat_rep = OVGPU_REP_ANCHORED_MSCKF_INVERSE_DEPTH; // UpdaterMSCKF.cpp:180-183
   c->row_stride = (d.feat_rep >= OVGPU_REP_ANCHORED_3D) ? 72 : 48;
   // allow the large dynamic LDS carve of the per-feature kernel
+  if (const char *e = std::getenv("OVGPU_TSQR_PIPELINE")) c->tree_pipelined = std::atoi(e) != 0;
   (void)hipFuncSetAttribute((const void *)k_system, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_limit);
   (void)hipFuncSetAttribute((const void *)k_ekf_chol, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_limit);
   (void)hipFuncSetAttribute((const void *)k_triangulate, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_limit);
@@ -233,7 +269,7 @@ void ovgpu_destroy(ovgpu_ctx *c) {
   c->tab_clone.release(), c->tab_cam.release(), c->tab_cc.release();
   c->meas_offsets.release(), c->meas_cc.release(), c->uv.release(), c->uvn.release(), c->row_off.release();
   c->pA.release(), c->pG.release(), c->chi2.release(), c->chi2_thr.release(), c->anchor.release(), c->status.release();
-  c->chi2_table.release(), c->Hbig.release(), c->gate_ws.release(), c->Rws.release(), c->Mt.release(), c->Aaug.release();
+  c->chi2_table.release(), c->Hbig.release(), c->gate_ws.release(), c->Rws.release(), c->tree_nodes.release(), c->tree_flags.release(), c->Mt.release(), c->Aaug.release();
   c->dx.release(), c->flags.release(), c->given_status.release();
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -500,6 +536,34 @@ static int enqueue_system(ovgpu_ctx *c) {
 static int enqueue_merge_tree(ovgpu_ctx *c, int G) {
   const int D = c->D, LD = c->LD;
   const int NT = (LD + 15) / 16;
+  if (G <= 1) return OVGPU_OK;
+  if (c->tree_pipelined && NT <= 16 && G - 1 <= c->num_cu) {
+    // ---- one launch for the whole tree, software-pipelined across the levels (k_qr_tree)
+    if (c->tree_G != G) {
+      std::vector<QrTreeNode> nodes;
+      std::vector<int32_t> writer(G, -1); // node that produces the current content of a slot
+      for (int stride = 1; stride < G; stride <<= 1)
+        for (int i = 0; i + stride < G; i += 2 * stride) {
+          QrTreeNode n;
+          n.a_slot = i, n.b_slot = i + stride, n.dep_a = writer[i], n.dep_b = writer[i + stride];
+          writer[i] = (int32_t)nodes.size();
+          nodes.push_back(n);
+        }
+      HIPCHK(c->tree_nodes.reserve(nodes.size()));
+      HIPCHK(c->tree_flags.reserve(nodes.size() + 1));
+      HIPCHK(hipMemcpyAsync(c->tree_nodes.p, nodes.data(), nodes.size() * sizeof(QrTreeNode), hipMemcpyHostToDevice, c->stream));
+      HIPCHK(hipStreamSynchronize(c->stream)); // the host vector goes out of scope
+      c->tree_G = G;
+    }
+    const int n_nodes = G - 1;
+    HIPCHK(hipMemsetAsync(c->tree_flags.p, 0, sizeof(int32_t) * (n_nodes + 1), c->stream));
+    QrTreeParams q;
+    q.D = D, q.LD = LD, q.NT = NT, q.tri = c->Rws.p, q.nodes = c->tree_nodes.p;
+    q.progress = c->tree_flags.p, q.error = c->tree_flags.p + n_nodes, q.spin_limit = 4000000; // ~ seconds: only a lost node gets there
+    if (NT <= 8) return launch_qr_tree<16>(c, n_nodes, q);
+    if (NT <= 14) return launch_qr_tree<28>(c, n_nodes, q);
+    return launch_qr_tree<32>(c, n_nodes, q);
+  }
   for (int stride = 1; stride < G; stride <<= 1) {
     const int pairs = (G - stride + 2 * stride - 1) / (2 * stride); // i = 0, 2s, 4s, ... with i + s < G
     if (pairs <= 0) break;
@@ -539,7 +603,7 @@ static int enqueue_compress(ovgpu_ctx *c) {
     q.acc = c->Rws.p, q.acc_stride = 1;
     q.src = c->Hbig.p, q.src_stride = 0;
     q.rows_per_node = c->rows_per_node, q.rows_total = c->rows_total, q.zero_init = 1, q.dbg = qr_dbg_buffer();
-    const int rc = launch_qr_node<QR_LEAF_Q, false>(c, W, q);
+    const int rc = NT <= 15 ? launch_qr_leaf_pw<QR_LEAF_Q>(c, W, q) : launch_qr_node<QR_LEAF_Q, false>(c, W, q);
     if (rc != OVGPU_OK) return rc;
   } else {
     const int nt = ((LD + 63) / 64) * 64;

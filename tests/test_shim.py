@@ -1,0 +1,20 @@
+"""CPU test of the C++ marshalling layer of the drop-in shim (open_vins_amd/shim): builds and runs its self-test."""
+import os
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shim_selftest_builds_and_passes():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "open_vins_amd", "csrc")])
+    out = subprocess.check_output(["make", "-s", "-C", os.path.join(ROOT, "open_vins_amd", "shim")], text=True)
+    assert "shim selftest ok" in out
+
+
+def test_dropin_translation_unit_keeps_the_reference_signatures():
+    src = open(os.path.join(ROOT, "open_vins_amd", "shim", "UpdaterMSCKF.cpp")).read()
+    # ov_msckf/src/update/UpdaterMSCKF.h:60,68
+    assert "UpdaterMSCKF::UpdaterMSCKF(UpdaterOptions &options, FeatureInitializerOptions &feat_init_options)" in src
+    assert "void UpdaterMSCKF::update(std::shared_ptr<State> state, std::vector<std::shared_ptr<Feature>> &feature_vec)" in src
+    assert "StateHelper::EKFUpdate(state, Hx_order_big, Hx_big, res_big, R_big)" in src
+    assert "oracle" not in src

@@ -21,6 +21,6 @@ lib.ovgpu_debug_qr_cycles.argtypes = [ctypes.POINTER(ctypes.c_longlong)]
 lib.ovgpu_debug_qr_cycles(buf)
 a = np.array(buf[:]).reshape(2, 16, 4)
 for name, blk in (("leaf (dense, node 0)", a[0]), ("last merge (node 0)", a[1])):
-    print(name, "cycles per wave: [other+loop-top, owner pre-step, barrier wait, apply]")
+    print(name, "cycles per wave (last wave = panel wave): [loop top, barrier wait, apply, publish]")
     for w in range(8):
         print("  wave", w, blk[w], "sum", blk[w].sum())
