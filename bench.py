@@ -120,13 +120,13 @@ def main():
                 "measurements_per_gpu": prob.M, "parallelism": f"feature-shard x{world}" if world > 1 else "single GPU",
             },
             "roofline": {
-                "kernel": "measurement compression (TSQR, k_qr_append leaf + merge tree)",
+                "kernel": "measurement compression = TSQR leaf (pw::k_qr_node<32,false>) + pipelined merge tree (k_qr_tree), timed together with HIP events",
                 "bound": "mfma",
                 "achieved": achieved,
                 "peak": PEAK_FP64_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": achieved / PEAK_FP64_TFLOPS,
-                "traffic": None,
+                "traffic": pmc_traffic_bytes(),
                 "algorithmic_flops_per_launch": flops_compress,
                 "avg_ms_per_launch": ms_c,
                 "update_ms_device": kt["ms_update"],
@@ -141,6 +141,20 @@ def main():
         dist.destroy_process_group()
     up.close()
     return out
+
+
+def pmc_traffic_bytes():
+    """HBM bytes per compression launch (leaf + tree) from the committed rocprofv3 PMC passes (profiles/r01_pmc.json:
+    FETCH_SIZE and WRITE_SIZE in separate passes, read side doubled as MI355X_MICROARCH.md prescribes for gfx950).
+    The counters cannot be collected inside this process; None when the file is absent."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc.json")
+    if not os.path.exists(path):
+        return None
+    k = json.load(open(path))["kernels"]
+    tot = 0.0
+    for name in ("leaf k_qr_node<32,false>", "tree k_qr_tree<28>"):
+        tot += 1024.0 * (2.0 * k[name]["FETCH_SIZE_KiB"] + k[name]["WRITE_SIZE_KiB"])
+    return tot
 
 
 def cpu_baseline(prob, opts):
