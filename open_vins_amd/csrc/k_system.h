@@ -70,6 +70,11 @@ __device__ __forceinline__ void inv_depth_jac(const V3 &p, double *J) {
   J[6] = 0.0, J[7] = -(1.0 / rho) * sin_phi, J[8] = -(1.0 / (rho * rho)) * cos_phi;
 }
 
+__device__ __forceinline__ double lane_bcast_d(double v, int lane) { // lane is wave-uniform
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+
 __global__ void __launch_bounds__(SYS_NT) k_system(SysParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
@@ -84,6 +89,12 @@ __global__ void __launch_bounds__(SYS_NT) k_system(SysParams p) {
 
   const bool relative = rep_is_relative(p.opt.feat_rep);
 
+#ifdef SYS_PROFILE
+  long long sys_tacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, sys_tlast = clock64();
+#define SYS_T(i) { __syncthreads(); const long long tn = clock64(); sys_tacc[i] += tn - sys_tlast; sys_tlast = tn; }
+#else
+#define SYS_T(i)
+#endif
   for (int f = blockIdx.x; f < p.F; f += gridDim.x) {
     const int m0 = p.meas_offsets[f];
     const int m = p.meas_offsets[f + 1] - m0;
@@ -101,6 +112,7 @@ __global__ void __launch_bounds__(SYS_NT) k_system(SysParams p) {
     double *S = (m <= p.m_lds_max) ? S_lds : (p.ws + (size_t)blockIdx.x * p.ws_stride);
 
     // ------------------------------------------------------------------
+    SYS_T(0)
     // (a0) representation Jacobian — UpdaterHelper.cpp:32-190 (once per feature)
     // ------------------------------------------------------------------
     V3 p_FinG = load_v3(p.p_FinG + 3 * f);
@@ -165,6 +177,7 @@ __global__ void __launch_bounds__(SYS_NT) k_system(SysParams p) {
     __syncthreads();
 
     // ------------------------------------------------------------------
+    SYS_T(1)
     // (a) per-measurement sparse Jacobian rows — UpdaterHelper.cpp:314-421
     // ------------------------------------------------------------------
     for (int i = tid; i < m; i += SYS_NT) {
@@ -271,106 +284,130 @@ __global__ void __launch_bounds__(SYS_NT) k_system(SysParams p) {
     const int anc_pcov = anc_pcol >= 0 ? p.col_cov[anc_pcol] : -1;
 
     // ------------------------------------------------------------------
+    SYS_T(2)
     // (c) chi2 gate: S0 = H P H^T + sigma^2 I (packed lower) with RHS rows [res ; H_f^T]
     // ------------------------------------------------------------------
+    // P entries this thread (= column c of T) keeps across measurements: the 14 calibration rows of a camera are
+    // shared by all of that camera's measurements, the anchor rows by the whole feature — loaded once, not per row
+    int cache_c = -1, cache_cam = -1;
+    double pcp[6] = {0, 0, 0, 0, 0, 0}, pci[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pac[6] = {0, 0, 0, 0, 0, 0}, pap[6] = {0, 0, 0, 0, 0, 0};
     for (int i0 = 0; i0 < m; i0 += SYS_RCM) {
       const int mc = min(SYS_RCM, m - i0);
       // phase 1: T = H P for the chunk's 2*mc rows, all D columns
       for (int c = tid; c < D; c += SYS_NT) {
         const double *Pc = p.P + p.col_cov[c];
-        for (int ii = 0; ii < mc; ii++) {
-          const int *mi = minfo + 8 * (i0 + ii);
-          const double *rd = rows + (size_t)(i0 + ii) * RS;
-          double t0 = 0.0, t1 = 0.0;
-          {
-            const double *Pr = Pc + (size_t)mi[5] * N;
+        // the clone rows of every measurement of the chunk: all loads in flight before the first FMA
+        double pcl[SYS_RCM][6];
 #pragma unroll
-            for (int s = 0; s < 6; s++) {
-              const double pv = Pr[(size_t)s * N];
-              t0 = fma(rd[RO_CLONE + s], pv, t0), t1 = fma(rd[RO_CLONE + 6 + s], pv, t1);
-            }
-          }
-          if (mi[6] >= 0) {
-            const double *Pr = Pc + (size_t)mi[6] * N;
+        for (int ii = 0; ii < SYS_RCM; ii++) {
+          const double *Pr = Pc + (size_t)minfo[8 * (i0 + min(ii, mc - 1)) + 5] * N;
 #pragma unroll
-            for (int s = 0; s < 6; s++) {
-              const double pv = Pr[(size_t)s * N];
-              t0 = fma(rd[RO_CPOSE + s], pv, t0), t1 = fma(rd[RO_CPOSE + 6 + s], pv, t1);
-            }
-          }
-          if (mi[7] >= 0) {
-            const double *Pr = Pc + (size_t)mi[7] * N;
-#pragma unroll
-            for (int s = 0; s < 8; s++) {
-              const double pv = Pr[(size_t)s * N];
-              t0 = fma(rd[RO_CINTR + s], pv, t0), t1 = fma(rd[RO_CINTR + 8 + s], pv, t1);
-            }
-          }
+          for (int s = 0; s < 6; s++) pcl[ii][s] = Pr[(size_t)s * N];
+        }
+        if (c != cache_c) {
+          cache_c = c, cache_cam = -1;
           if (anc_ccov >= 0) {
-            const double *Pr = Pc + (size_t)anc_ccov * N;
 #pragma unroll
-            for (int s = 0; s < 6; s++) {
-              const double pv = Pr[(size_t)s * N];
-              t0 = fma(rd[RO_ANC + s], pv, t0), t1 = fma(rd[RO_ANC + 6 + s], pv, t1);
-            }
+            for (int s = 0; s < 6; s++) pac[s] = Pc[(size_t)(anc_ccov + s) * N];
           }
           if (anc_pcov >= 0) {
-            const double *Pr = Pc + (size_t)anc_pcov * N;
 #pragma unroll
-            for (int s = 0; s < 6; s++) {
-              const double pv = Pr[(size_t)s * N];
-              t0 = fma(rd[RO_ACAL + s], pv, t0), t1 = fma(rd[RO_ACAL + 6 + s], pv, t1);
-            }
+            for (int s = 0; s < 6; s++) pap[s] = Pc[(size_t)(anc_pcov + s) * N];
           }
-          Tch[(size_t)(2 * ii) * D + c] = t0;
-          Tch[(size_t)(2 * ii + 1) * D + c] = t1;
+        }
+#pragma unroll
+        for (int ii = 0; ii < SYS_RCM; ii++) {
+          if (ii < mc) {
+            const int *mi = minfo + 8 * (i0 + ii);
+            const double *rd = rows + (size_t)(i0 + ii) * RS;
+            if (mi[0] != cache_cam) {
+              cache_cam = mi[0];
+              if (mi[6] >= 0) {
+#pragma unroll
+                for (int s = 0; s < 6; s++) pcp[s] = Pc[(size_t)(mi[6] + s) * N];
+              }
+              if (mi[7] >= 0) {
+#pragma unroll
+                for (int s = 0; s < 8; s++) pci[s] = Pc[(size_t)(mi[7] + s) * N];
+              }
+            }
+            double t0 = 0.0, t1 = 0.0;
+#pragma unroll
+            for (int s = 0; s < 6; s++) t0 = fma(rd[RO_CLONE + s], pcl[ii][s], t0), t1 = fma(rd[RO_CLONE + 6 + s], pcl[ii][s], t1);
+            if (mi[6] >= 0) {
+#pragma unroll
+              for (int s = 0; s < 6; s++) t0 = fma(rd[RO_CPOSE + s], pcp[s], t0), t1 = fma(rd[RO_CPOSE + 6 + s], pcp[s], t1);
+            }
+            if (mi[7] >= 0) {
+#pragma unroll
+              for (int s = 0; s < 8; s++) t0 = fma(rd[RO_CINTR + s], pci[s], t0), t1 = fma(rd[RO_CINTR + 8 + s], pci[s], t1);
+            }
+            if (anc_ccov >= 0) {
+#pragma unroll
+              for (int s = 0; s < 6; s++) t0 = fma(rd[RO_ANC + s], pac[s], t0), t1 = fma(rd[RO_ANC + 6 + s], pac[s], t1);
+            }
+            if (anc_pcov >= 0) {
+#pragma unroll
+              for (int s = 0; s < 6; s++) t0 = fma(rd[RO_ACAL + s], pap[s], t0), t1 = fma(rd[RO_ACAL + 6 + s], pap[s], t1);
+            }
+            Tch[(size_t)(2 * ii) * D + c] = t0;
+            Tch[(size_t)(2 * ii + 1) * D + c] = t1;
+          }
         }
       }
       __syncthreads();
-      // phase 2: S0[r][q] = T[r] . H[q]  for r in the chunk, q <= r
+      SYS_T(9)
+      // phase 2: S0[r][q] = T[r] . H[q]  for r in the chunk, q <= r.  Thread = (column q of S0, row parity): the sparse
+      // row H[q] and its column offsets sit in registers for all rows of the chunk, so the only LDS traffic of the inner
+      // loop is T[r] at addresses known up front (no index load -> address -> value chains).
       const int r0 = 2 * i0, nr = 2 * mc;
-      for (int idx = tid; idx < nr * n; idx += SYS_NT) {
-        const int rr = idx / n, q = idx - rr * n;
-        const int r = r0 + rr;
-        if (q > r) continue;
-        const int qi = q >> 1, qa = q & 1;
-        const int *mi = minfo + 8 * qi;
-        const double *rd = rows + (size_t)qi * RS;
-        const double *Tr = Tch + (size_t)rr * D;
-        double s = (q == r) ? p.opt.sigma_pix_sq : 0.0;
-        {
-          const double *t = Tr + mi[2];
-          const double *h = rd + RO_CLONE + 6 * qa;
+      {
+        const int tq = tid & (SYS_NT / 2 - 1), tp = tid / (SYS_NT / 2);
+        for (int q = tq; q < n && q <= r0 + nr - 1; q += SYS_NT / 2) {
+          const int qi = q >> 1, qa = q & 1;
+          const int *mi = minfo + 8 * qi;
+          const double *rd = rows + (size_t)qi * RS;
+          const int c_cl = mi[2], c_po = mi[3], c_in = mi[4];
+          double hcl[6], hpo[6], hin[8], han[6], hac[6];
 #pragma unroll
-          for (int k = 0; k < 6; k++) s = fma(t[k], h[k], s);
-        }
-        if (mi[3] >= 0) {
-          const double *t = Tr + mi[3];
-          const double *h = rd + RO_CPOSE + 6 * qa;
+          for (int k = 0; k < 6; k++) hcl[k] = rd[RO_CLONE + 6 * qa + k];
 #pragma unroll
-          for (int k = 0; k < 6; k++) s = fma(t[k], h[k], s);
-        }
-        if (mi[4] >= 0) {
-          const double *t = Tr + mi[4];
-          const double *h = rd + RO_CINTR + 8 * qa;
+          for (int k = 0; k < 6; k++) hpo[k] = c_po >= 0 ? rd[RO_CPOSE + 6 * qa + k] : 0.0;
 #pragma unroll
-          for (int k = 0; k < 8; k++) s = fma(t[k], h[k], s);
-        }
-        if (anc_ccol >= 0) {
-          const double *t = Tr + anc_ccol;
-          const double *h = rd + RO_ANC + 6 * qa;
+          for (int k = 0; k < 8; k++) hin[k] = c_in >= 0 ? rd[RO_CINTR + 8 * qa + k] : 0.0;
 #pragma unroll
-          for (int k = 0; k < 6; k++) s = fma(t[k], h[k], s);
-        }
-        if (anc_pcol >= 0) {
-          const double *t = Tr + anc_pcol;
-          const double *h = rd + RO_ACAL + 6 * qa;
+          for (int k = 0; k < 6; k++) han[k] = anc_ccol >= 0 ? rd[RO_ANC + 6 * qa + k] : 0.0;
 #pragma unroll
-          for (int k = 0; k < 6; k++) s = fma(t[k], h[k], s);
+          for (int k = 0; k < 6; k++) hac[k] = anc_pcol >= 0 ? rd[RO_ACAL + 6 * qa + k] : 0.0;
+          for (int rr = tp; rr < nr; rr += 2) {
+            const int r = r0 + rr;
+            if (q > r) continue;
+            const double *Tr = Tch + (size_t)rr * D;
+            double sv = (q == r) ? p.opt.sigma_pix_sq : 0.0;
+#pragma unroll
+            for (int k = 0; k < 6; k++) sv = fma(Tr[c_cl + k], hcl[k], sv);
+            if (c_po >= 0) {
+#pragma unroll
+              for (int k = 0; k < 6; k++) sv = fma(Tr[c_po + k], hpo[k], sv);
+            }
+            if (c_in >= 0) {
+#pragma unroll
+              for (int k = 0; k < 8; k++) sv = fma(Tr[c_in + k], hin[k], sv);
+            }
+            if (anc_ccol >= 0) {
+#pragma unroll
+              for (int k = 0; k < 6; k++) sv = fma(Tr[anc_ccol + k], han[k], sv);
+            }
+            if (anc_pcol >= 0) {
+#pragma unroll
+              for (int k = 0; k < 6; k++) sv = fma(Tr[anc_pcol + k], hac[k], sv);
+            }
+            S[sidx(r, q, n)] = sv;
+          }
         }
-        S[sidx(r, q, n)] = s;
       }
       __syncthreads();
+      SYS_T(3)
     }
     // right-hand sides: row n = res, rows n+1..n+3 = H_f columns
     for (int q = tid; q < n; q += SYS_NT) {
@@ -382,24 +419,88 @@ __global__ void __launch_bounds__(SYS_NT) k_system(SysParams p) {
       S[sidx(n + 3, q, n)] = rd[RO_HF + 3 * qa + 2];
     }
     __syncthreads();
-    // right-looking Cholesky of the (n + 4) x n lower trapezoid; the 4 extra rows end as (L^-1 b)^T
+    SYS_T(4)
+    // Blocked right-looking Cholesky of the (n + 4) x n lower trapezoid; the 4 extra rows end as (L^-1 b)^T.
+    // Per block of 8 columns: wave 0 factors the (rows x 8) panel in registers (row r of the panel in lane
+    // r & 63, pivots and multipliers broadcast with v_readlane: no LDS round trip, no workgroup barrier inside the
+    // panel), then all waves apply the rank-8 update to the trailing trapezoid.  2 barriers per 8 columns.
     {
-      const int ti = tid >> 4, tj = tid & 15;
-      for (int k = 0; k < n; k++) {
-        const double dkk = sqrt(S[sidx(k, k, n)]);
+      constexpr int CB = 8, CS = 8; // block width, row slots per lane (n + 4 <= 64 * CS)
+      const int lane = tid & 63, wv = tid >> 6;
+      for (int kb = 0; kb < n; kb += CB) {
+        const int nb = min(CB, n - kb);
+        if (wv == 0) {
+          const int rs = (n + 4 - kb + 63) >> 6;
+          double a[CS][CB];
+#pragma unroll
+          for (int sl = 0; sl < CS; sl++)
+            if (sl < rs) {
+              const int row = kb + lane + 64 * sl;
+#pragma unroll
+              for (int jj = 0; jj < CB; jj++) {
+                const int col = kb + jj;
+                a[sl][jj] = (jj < nb && row < n + 4 && (row >= n || col <= row)) ? S[sidx(row, col, n)] : 0.0;
+              }
+            }
+#pragma unroll
+          for (int k = 0; k < CB; k++) {
+            if (k < nb) {
+              const double dkk = lane_bcast_d(a[0][k], k); // row kb + k lives in lane k, slot 0
+              // pivot: d = sqrt(dkk), inv = 1 / d from one v_rsq_f64 seed + Newton steps (a few ulp; the chain of a column step)
+              double inv = __builtin_amdgcn_rsq(dkk);
+#pragma unroll
+              for (int it = 0; it < 2; it++) inv = fma(0.5 * inv, fma(-dkk * inv, inv, 1.0), inv);
+              double d = dkk * inv;
+              d = fma(0.5 * inv, fma(-d, d, dkk), d);
+              if (!(dkk > 0.0)) d = sqrt(dkk), inv = 1.0 / d; // keep the NaN / inf behaviour of a broken-down factorisation
+#pragma unroll
+              for (int sl = 0; sl < CS; sl++)
+                if (sl < rs) a[sl][k] = (lane + 64 * sl == k) ? d : a[sl][k] * inv;
+#pragma unroll
+              for (int jj = k + 1; jj < CB; jj++) {
+                if (jj < nb) {
+                  const double ljk = lane_bcast_d(a[0][k], jj); // L[kb + jj][kb + k]
+#pragma unroll
+                  for (int sl = 0; sl < CS; sl++)
+                    if (sl < rs) a[sl][jj] = fma(-a[sl][k], ljk, a[sl][jj]);
+                }
+              }
+            }
+          }
+#pragma unroll
+          for (int sl = 0; sl < CS; sl++)
+            if (sl < rs) {
+              const int row = kb + lane + 64 * sl;
+#pragma unroll
+              for (int jj = 0; jj < CB; jj++) {
+                const int col = kb + jj;
+                if (jj < nb && row < n + 4 && (row >= n || col <= row)) S[sidx(row, col, n)] = a[sl][jj];
+              }
+            }
+        }
         __syncthreads();
-        const double inv = 1.0 / dkk;
-        for (int i = k + 1 + tid; i < n + 4; i += SYS_NT) S[sidx(i, k, n)] *= inv;
-        if (tid == 0) S[sidx(k, k, n)] = dkk;
-        __syncthreads();
-        for (int i = k + 1 + ti; i < n + 4; i += 16) {
-          const double lik = S[sidx(i, k, n)];
-          const int jmax = min(i, n - 1);
-          for (int j = k + 1 + tj; j <= jmax; j += 16) S[sidx(i, j, n)] = fma(-lik, S[sidx(j, k, n)], S[sidx(i, j, n)]);
+        // trailing update: S[i][j] -= sum_l L[i][kb + l] L[j][kb + l]   for kb + nb <= j <= min(i, n - 1), i < n + 4
+        {
+          const int ti = tid >> 4, tj = tid & 15;
+          for (int i = kb + nb + ti; i < n + 4; i += SYS_NT / 16) {
+            double li[CB];
+#pragma unroll
+            for (int l2 = 0; l2 < CB; l2++) li[l2] = (l2 < nb) ? S[sidx(i, kb + l2, n)] : 0.0;
+            const int jmax = min(i, n - 1);
+#pragma unroll 2
+            for (int j = kb + nb + tj; j <= jmax; j += 16) {
+              double acc = S[sidx(i, j, n)];
+#pragma unroll
+              for (int l2 = 0; l2 < CB; l2++)
+                if (l2 < nb) acc = fma(-li[l2], S[sidx(j, kb + l2, n)], acc);
+              S[sidx(i, j, n)] = acc;
+            }
+          }
         }
         __syncthreads();
       }
     }
+    SYS_T(5)
     // chi2 = |y_r|^2 - g^T G^-1 g,  y_r = L^-1 res, Y_f = L^-1 H_f, G = Y_f^T Y_f, g = Y_f^T y_r
     if (tid < 64) {
       double a = 0, G00 = 0, G01 = 0, G02 = 0, G11 = 0, G12 = 0, G22 = 0, g0 = 0, g1 = 0, g2 = 0;
@@ -434,6 +535,7 @@ __global__ void __launch_bounds__(SYS_NT) k_system(SysParams p) {
     }
 
     // ------------------------------------------------------------------
+    SYS_T(6)
     // (b) Householder QR of H_f (2m x 3) -> V, tau, T   (role of UpdaterHelper.cpp:426-454)
     // ------------------------------------------------------------------
     if (tid < 64) {
@@ -493,6 +595,7 @@ __global__ void __launch_bounds__(SYS_NT) k_system(SysParams p) {
     __syncthreads();
 
     // ------------------------------------------------------------------
+    SYS_T(7)
     // (d) stack: thread-per-column, rows 3..n-1 of Q^T [H_x | res] -> Hbig   (UpdaterMSCKF.cpp:237-255)
     // ------------------------------------------------------------------
     {
@@ -502,20 +605,24 @@ __global__ void __launch_bounds__(SYS_NT) k_system(SysParams p) {
         if (c < D) kind = p.col_kind[c], var = p.col_var[c], sub = p.col_sub[c];
         const bool anc_hit_c = (kind == COL_CLONE && var == anchor_clone && relative);
         const bool anc_hit_p = (kind == COL_CALIB_POSE && var == anchor_cam && relative && p.opt.do_calib_pose);
+        // branch-free element of the sparse Jacobian: every load address is known up front, so the compiler can keep
+        // several rows in flight (the branchy form was LDS-latency bound: 2 dependent reads per element)
+        const int kclone = (kind == COL_CLONE) ? var : -1000;
+        const int kcam = (kind == COL_CALIB_POSE || kind == COL_CALIB_INTR) ? var : -1000; // such a column exists only for a calibrated camera
+        const int off0 = kind == 3 ? RO_RES : (kind == COL_CLONE ? RO_CLONE + sub : (kind == COL_CALIB_POSE ? RO_CPOSE + sub : RO_CINTR + sub));
+        const int astr = kind == 3 ? 1 : (kind == COL_CALIB_INTR ? 8 : 6);
         auto hval = [&](int i, int a) -> double {
-          const int *mi = minfo + 8 * i;
+          const int2 key = *reinterpret_cast<const int2 *>(minfo + 8 * i); // (camera, clone)
           const double *rd = rows + (size_t)i * RS;
-          double h = 0.0;
-          if (kind == 3) h = rd[RO_RES + a];
-          else if (kind == COL_CLONE) { if (mi[1] == var) h = rd[RO_CLONE + 6 * a + sub]; }
-          else if (kind == COL_CALIB_POSE) { if (mi[0] == var && mi[3] >= 0) h = rd[RO_CPOSE + 6 * a + sub]; }
-          else { if (mi[0] == var && mi[4] >= 0) h = rd[RO_CINTR + 8 * a + sub]; }
+          const double hv = rd[off0 + astr * a];
+          double h = (kind == 3 || key.y == kclone || key.x == kcam) ? hv : 0.0;
           if (anc_hit_c) h += rd[RO_ANC + 6 * a + sub];
           if (anc_hit_p) h += rd[RO_ACAL + 6 * a + sub];
           return h;
         };
         // y = V^T h
         double y0 = 0, y1 = 0, y2 = 0;
+#pragma unroll 4
         for (int i = 0; i < m; i++) {
           const double h0 = hval(i, 0), h1 = hval(i, 1);
           const double *v = V + (size_t)6 * i;
@@ -525,6 +632,7 @@ __global__ void __launch_bounds__(SYS_NT) k_system(SysParams p) {
         // z = T^T y
         const double z0 = T00 * y0, z1 = T01 * y0 + T11 * y1, z2 = T02 * y0 + T12 * y1 + T22 * y2;
         double *out = p.Hbig + orow0 * LD + c;
+#pragma unroll 4
         for (int r = 3; r < n; r++) {
           const double h = hval(r >> 1, r & 1);
           const double *v = V + (size_t)3 * r;
@@ -532,7 +640,12 @@ __global__ void __launch_bounds__(SYS_NT) k_system(SysParams p) {
         }
       }
     }
+    SYS_T(8)
   }
+#ifdef SYS_PROFILE
+  if (p.dbg && tid == 0 && blockIdx.x == 0)
+    for (int i = 0; i < 10; i++) p.dbg[100 + i] = sys_tacc[i];
+#endif
 }
 
 } // namespace ovg

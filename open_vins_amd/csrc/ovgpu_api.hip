@@ -527,6 +527,7 @@ static int enqueue_system(ovgpu_ctx *c) {
   p.row_off = c->row_off.p, p.Hbig = c->Hbig.p, p.ws = c->gate_ws.p, p.ws_stride = c->gate_ws_stride;
   p.m_lds_max = c->m_lds_max, p.m_max = std::max(c->m_max, 1), p.row_stride = c->row_stride;
   p.opt = c->dopt;
+  p.dbg = qr_dbg_buffer();
   hipLaunchKernelGGL(k_system, dim3(c->sys_grid), dim3(SYS_NT), c->sys_lds_bytes, c->stream, p);
   HIPCHK(hipGetLastError());
   return OVGPU_OK;

@@ -62,6 +62,7 @@ struct SysParams {
   int m_lds_max;            // largest track length whose gate matrix is LDS-resident
   int m_max;                // largest track length in the batch
   int row_stride;           // doubles per measurement in the LDS row store (48, or 72 with anchored reps)
+  long long *dbg;           // profiling builds only (-DSYS_PROFILE)
   DevOptions opt;
 };
 

@@ -24,3 +24,8 @@ for name, blk in (("leaf (dense, node 0)", a[0]), ("last merge (node 0)", a[1]))
     print(name, "cycles per wave (last wave = panel wave): [loop top, barrier wait, apply, publish]")
     for w in range(8):
         print("  wave", w, blk[w], "sum", blk[w].sum())
+s = np.array(buf[100:110])
+names = ["loop top/wait", "(a0) representation", "(a) rows", "(c) T=HP + S0 chunks", "RHS", "Cholesky", "chi2 reduce", "(b) Householder H_f", "(d) stack/output", "(c) phase 1 only (T = H P)"]
+print("k_system block 0 cycles by phase (sum over its features):")
+for nme, v in zip(names, s):
+    print("  %-24s %10d  %5.1f%%" % (nme, v, 100.0 * v / max(s.sum(), 1)))
