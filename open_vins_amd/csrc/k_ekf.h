@@ -4,7 +4,7 @@
 // With the compressed system [R | c] (D x D upper triangular, R_noise = sigma^2 I):
 //   Mt = R P(cols,:)                       (D x N)   = (P H^T)^T            StateHelper.cpp:137-146
 //   S  = R P(cols,cols) R^T + sigma^2 I    (D x D)                          :151-156
-//   S  = U^T U ;  Y = U^-T Mt ; y = U^-T c           (replaces Sinv, K)     :160-162
+//   S  = U^T U ;  Y = U^-T Mt ; y = U^-T c           (replaces Sinv, K)     :160-162   (k_ekf_chol_step, one launch per 16 rows)
 //   P' = P - Y^T Y                                   (= P - K M^T)          :166-167
 //   dx = Y^T y                                       (= K res)              :185
 // The reference forms S^-1 explicitly; Y^T Y = M S^-1 M^T is the same matrix and is symmetric by
@@ -42,7 +42,8 @@ struct EkfParams {
   const int32_t *col_cov;
   double *P;        // [N x N] in/out
   double *Mt;       // [D x N]
-  double *A;        // [D x LA] augmented [S | Mt | c]
+  double *A;        // [D x LA] augmented [S | Mt | c] (work matrix of the factorisation)
+  double *Y;        // [D x LA] result rows [U | U^-T Mt | U^-T c]
   double *dx;       // [N]
   int32_t *flags;   // [0] = 1 if S not SPD, [1] = 1 if a diagonal of P' is negative
   double sigma2;
@@ -89,92 +90,126 @@ __global__ void __launch_bounds__(256) k_ekf_s(EkfParams p) {
     for (int r = lane; r < p.D; r += 64) p.A[(size_t)r * p.LA + p.D + p.N] = p.R[(size_t)r * p.LD + p.D];
 }
 
-// Blocked right-looking Cholesky S = U^T U of the leading D x D block of A, carried through the
-// augmented columns: on exit A[:, D:] = U^-T [Mt | c].  Single workgroup, 1024 threads; the
-// matrix (D x LA doubles, < 1.5 MB) stays in L2.
-static constexpr int CH_NB = 16;
-__global__ void __launch_bounds__(1024) k_ekf_chol(EkfParams p) {
-  extern __shared__ __attribute__((aligned(16))) double lds[];
-  double *Ukk = lds;                // [16 x 16]
-  double *Wp = lds + CH_NB * CH_NB; // [16 x LA]
-  const int tid = threadIdx.x, NT = blockDim.x;
+// ---------------------------------------------------------------------------------------------------
+// Blocked right-looking Cholesky S = U^T U carried through the augmented columns, one launch per block of 16
+// rows, one WAVEFRONT per 16x16 tile of the trailing matrix (a single-workgroup version needed 0.6 ms for
+// D = 208: 13 block steps of a D x LA update by one CU).
+//
+// Step kb:  U_kk = chol(A[kb:kb+16, kb:kb+16]);  W = U_kk^-T A[kb:kb+16, kb+16:LA];  A[i][j] -= sum_l W[l][i] W[l][j].
+// Every wave factors the 16x16 diagonal block itself (120 multiply-adds, in registers, pivots and multipliers
+// moved with v_readlane) and solves for the two 16-column slices of W its tile needs, so a step has no
+// intra-launch dependency: tiles only READ rows kb..kb+15 of A and only WRITE rows >= kb+16.  The finished rows
+// [U_kk | W] go to a second matrix Y, which the covariance update reads (rows of A are never read again).
+// The tile update itself is 4 v_mfma_f64_16x16x4_f64.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double ekf_bcast(double v, int lane) { // lane is wave-uniform
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+
+__global__ void __launch_bounds__(256) k_ekf_chol_step(EkfParams p, int kb) {
+  __shared__ double stage[4][2][16 * 16];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int D = p.D, LA = p.LA;
-  for (int kb = 0; kb < D; kb += CH_NB) {
-    const int nb = min(CH_NB, D - kb);
-    // 1. diagonal block (upper part) to LDS, unblocked factorisation by the first 256 threads
-    if (tid < CH_NB * CH_NB) {
-      const int i = tid / CH_NB, j = tid % CH_NB;
-      Ukk[tid] = (i < nb && j < nb && j >= i) ? p.A[(size_t)(kb + i) * LA + kb + j] : (i == j ? 1.0 : 0.0);
+  const int tb = kb >> 4, TM = (D + 15) >> 4, TL = (LA + 15) >> 4;
+  const int nb = min(16, D - kb);
+  // wave -> job: first the TL - tb "writer" jobs (finished rows of column tile jt -> Y), then the trailing tiles (it, jt >= it)
+  int job = blockIdx.x * 4 + wv;
+  const int n_writer = TL - tb;
+  int it = -1, jt = 0;
+  if (job < n_writer) {
+    jt = tb + job;
+  } else {
+    job -= n_writer;
+    it = tb + 1;
+    while (it < TM && job >= TL - it) job -= TL - it, it++;
+    if (it >= TM) return;
+    jt = it + job;
+  }
+  // ---- 1. U_kk: lane j < 16 holds column j of the diagonal block (upper part), identity beyond nb
+  double u[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    const int j = lane & 15;
+    u[i] = (i < nb && j < nb && j >= i) ? p.A[(size_t)(kb + i) * LA + kb + j] : (i == j ? 1.0 : 0.0);
+  }
+  double dinv[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    const double dk = ekf_bcast(u[k], k);
+    if (!(dk > 0.0) && it < 0 && jt == tb && lane == 0) p.flags[0] = 1;
+    const double d = sqrt(dk), inv = 1.0 / d;
+    dinv[k] = inv;
+    u[k] = ((lane & 15) == k) ? d : u[k] * inv; // row k of U (lanes j > k); lanes j < k hold zeros there
+#pragma unroll
+    for (int i = k + 1; i < 16; i++) {
+      const double uki = ekf_bcast(u[k], i); // U[k][i]
+      u[i] = fma(-uki, u[k], u[i]);          // only lanes j >= i matter
     }
-    __syncthreads();
-    for (int k = 0; k < nb; k++) {
-      if (tid == 0) {
-        const double d = Ukk[k * CH_NB + k];
-        if (!(d > 0.0)) p.flags[0] = 1;
-        Ukk[k * CH_NB + k] = sqrt(d);
+  }
+  // ---- 2. W = U_kk^-T B: lanes 0-15 solve the columns of tile `it` (or nothing), lanes 16-31 those of tile jt
+  const int half = lane >> 4, cc = lane & 15;
+  const int tcol = (half == 0 ? it : jt) * 16 + cc;
+  const bool wvalid = half < 2 && (half == 1 || it >= 0) && tcol < LA;
+  double w[16];
+#pragma unroll
+  for (int l = 0; l < 16; l++) w[l] = (wvalid && l < nb) ? p.A[(size_t)(kb + l) * LA + tcol] : 0.0;
+#pragma unroll
+  for (int l = 0; l < 16; l++) {
+    double sacc = w[l];
+#pragma unroll
+    for (int q = 0; q < l; q++) sacc = fma(-ekf_bcast(u[q], l), w[q], sacc); // U[q][l] lives in lane l
+    w[l] = sacc * dinv[l];
+  }
+  if (it < 0) {
+    // writer: rows kb .. kb+nb-1 of Y, columns of tile jt (the diagonal tile stores U_kk itself: lane j holds column j)
+    if (jt == tb) {
+      if (lane < nb) {
+#pragma unroll
+        for (int l = 0; l < 16; l++)
+          if (l < nb) p.Y[(size_t)(kb + l) * LA + kb + lane] = (lane >= l) ? u[l] : 0.0;
       }
-      __syncthreads();
-      if (tid > k && tid < nb) Ukk[k * CH_NB + tid] /= Ukk[k * CH_NB + k];
-      __syncthreads();
-      if (tid < CH_NB * CH_NB) {
-        const int i = tid / CH_NB, j = tid % CH_NB;
-        if (i > k && j >= i && j < nb) Ukk[i * CH_NB + j] -= Ukk[k * CH_NB + i] * Ukk[k * CH_NB + j];
+      if (half == 1 && cc >= nb && tcol < LA) { // a partial last block: the rest of its tile are right-hand-side columns
+#pragma unroll
+        for (int l = 0; l < 16; l++)
+          if (l < nb) p.Y[(size_t)(kb + l) * LA + tcol] = w[l];
       }
-      __syncthreads();
+    } else if (half == 1 && tcol < LA) {
+#pragma unroll
+      for (int l = 0; l < 16; l++)
+        if (l < nb) p.Y[(size_t)(kb + l) * LA + tcol] = w[l];
     }
-    // 2. row panel: W = U_kk^-T A[kb:kb+nb, kb+nb:LA]  (thread per column), kept in LDS and written back
-    for (int j = kb + nb + tid; j < LA; j += NT) {
-      double w[CH_NB];
+    return;
+  }
+  // ---- 3. tile update A[i0.., j0..] -= W_i^T W_j on the matrix cores (operands staged through LDS)
+  double *wi = stage[wv][0], *wj = stage[wv][1];
+  if (half < 2) {
+    double *dst = half == 0 ? wi : wj;
 #pragma unroll
-      for (int l = 0; l < CH_NB; l++) w[l] = (l < nb) ? p.A[(size_t)(kb + l) * LA + j] : 0.0;
+    for (int l = 0; l < 16; l++) dst[l * 16 + cc] = w[l];
+  }
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  double4_t acc = {0.0, 0.0, 0.0, 0.0};
+  const int m = lane & 15, kk = lane >> 4;
 #pragma unroll
-      for (int l = 0; l < CH_NB; l++) {
-        double s = w[l];
+  for (int q = 0; q < 4; q++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wi[(4 * q + kk) * 16 + m], wj[(4 * q + kk) * 16 + m], acc, 0, 0, 0);
+  const int col = jt * 16 + m;
 #pragma unroll
-        for (int q = 0; q < CH_NB; q++)
-          if (q < l) s = fma(-Ukk[q * CH_NB + l], w[q], s);
-        w[l] = s / Ukk[l * CH_NB + l];
-      }
-#pragma unroll
-      for (int l = 0; l < CH_NB; l++) {
-        Wp[(size_t)l * LA + j] = w[l];
-        if (l < nb) p.A[(size_t)(kb + l) * LA + j] = w[l];
-      }
-    }
-    // write the factored diagonal block back
-    if (tid < CH_NB * CH_NB) {
-      const int i = tid / CH_NB, j = tid % CH_NB;
-      if (i < nb && j < nb && j >= i) p.A[(size_t)(kb + i) * LA + kb + j] = Ukk[tid];
-    }
-    __syncthreads();
-    // 3. trailing update: A[i][j] -= sum_l W[l][i] W[l][j]   for kb+nb <= i < D, j >= i
-    {
-      const int tj = tid & 511, ti = tid >> 9; // 512 column lanes x 2 row phases
-      for (int j = kb + nb + tj; j < LA; j += 512) {
-        double wj[CH_NB];
-#pragma unroll
-        for (int l = 0; l < CH_NB; l++) wj[l] = Wp[(size_t)l * LA + j];
-        const int imax = min(j, D - 1);
-        for (int i = kb + nb + ti; i <= imax; i += 2) {
-          double s = 0.0;
-#pragma unroll
-          for (int l = 0; l < CH_NB; l++) s = fma(Wp[(size_t)l * LA + i], wj[l], s);
-          p.A[(size_t)i * LA + j] -= s;
-        }
-      }
-    }
-    __syncthreads();
+  for (int q = 0; q < 4; q++) {
+    const int row = it * 16 + kk + 4 * q;
+    if (row < D && col < LA && col >= row) p.A[(size_t)row * LA + col] -= acc[q];
   }
 }
 
-// P' = P - Y^T Y,  Y = A[:, D : D+N]     one wavefront per 16x16 tile of P
+// P' = P - Y^T Y,  Y = [:, D : D+N] of the factorised augmented matrix     one wavefront per 16x16 tile of P
 __global__ void __launch_bounds__(256) k_ekf_pupdate(EkfParams p) {
   const int lane = threadIdx.x & 63;
   const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int tn = (p.N + 15) / 16;
   if (tile >= tn * tn) return;
   const int r0 = (tile / tn) * 16, c0 = (tile % tn) * 16;
-  const double *Y = p.A + p.D;
+  const double *Y = p.Y + p.D;
   auto fa = [&](int i, int k) { const int r = r0 + i; return (r < p.N) ? Y[(size_t)k * p.LA + r] : 0.0; };
   auto fb = [&](int k, int j) { const int c = c0 + j; return (c < p.N) ? Y[(size_t)k * p.LA + c] : 0.0; };
   const double4_t acc = mfma_tile(fa, fb, p.D, lane);
@@ -194,8 +229,8 @@ __global__ void __launch_bounds__(256) k_ekf_pupdate(EkfParams p) {
 __global__ void k_ekf_dx(EkfParams p) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= p.N) return;
-  const double *Y = p.A + p.D;
-  const double *y = p.A + p.D + p.N;
+  const double *Y = p.Y + p.D;
+  const double *y = p.Y + p.D + p.N;
   double s = 0.0;
   for (int r = 0; r < p.D; r++) s = fma(Y[(size_t)r * p.LA + i], y[(size_t)r * p.LA], s);
   p.dx[i] = s;

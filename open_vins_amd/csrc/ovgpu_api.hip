@@ -106,7 +106,7 @@ struct ovgpu_ctx {
   std::vector<int32_t> h_offsets;
 
   // ---- workspaces
-  DevBuf<double> Hbig, gate_ws, Rws, Mt, Aaug, dx;
+  DevBuf<double> Hbig, gate_ws, Rws, Mt, Aaug, Yaug, dx;
   DevBuf<int32_t> flags;
   int W = 1;
   int64_t rows_per_node = 128;
@@ -242,7 +242,6 @@ int ovgpu_create(const ovgpu_options *opts, int device, ovgpu_ctx **out) {
   // allow the large dynamic LDS carve of the per-feature kernel
   if (const char *e = std::getenv("OVGPU_TSQR_PIPELINE")) c->tree_pipelined = std::atoi(e) != 0;
   (void)hipFuncSetAttribute((const void *)k_system, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_limit);
-  (void)hipFuncSetAttribute((const void *)k_ekf_chol, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_limit);
   (void)hipFuncSetAttribute((const void *)k_triangulate, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_limit);
   const char *tenv = std::getenv("OVGPU_TIMING");
   c->timing = !(tenv && tenv[0] == '0');
@@ -269,7 +268,7 @@ void ovgpu_destroy(ovgpu_ctx *c) {
   c->tab_clone.release(), c->tab_cam.release(), c->tab_cc.release();
   c->meas_offsets.release(), c->meas_cc.release(), c->uv.release(), c->uvn.release(), c->row_off.release();
   c->pA.release(), c->pG.release(), c->chi2.release(), c->chi2_thr.release(), c->anchor.release(), c->status.release();
-  c->chi2_table.release(), c->Hbig.release(), c->gate_ws.release(), c->Rws.release(), c->tree_nodes.release(), c->tree_flags.release(), c->Mt.release(), c->Aaug.release();
+  c->chi2_table.release(), c->Hbig.release(), c->gate_ws.release(), c->Rws.release(), c->tree_nodes.release(), c->tree_flags.release(), c->Mt.release(), c->Aaug.release(), c->Yaug.release();
   c->dx.release(), c->flags.release(), c->given_status.release();
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -348,6 +347,7 @@ int ovgpu_set_state(ovgpu_ctx *c, const ovgpu_state_view *st) {
   HIPCHK(c->tab_cc.reserve((size_t)12 * K * C));
   HIPCHK(c->Mt.reserve((size_t)D * N));
   HIPCHK(c->Aaug.reserve((size_t)D * (D + N + 1)));
+  HIPCHK(c->Yaug.reserve((size_t)D * (D + N + 1)));
   HIPCHK(c->dx.reserve(N));
   HIPCHK(c->flags.reserve(4));
 
@@ -622,16 +622,23 @@ static int enqueue_compress(ovgpu_ctx *c) {
 static int enqueue_ekf(ovgpu_ctx *c) {
   EkfParams p;
   p.N = c->N, p.D = c->D, p.LD = c->LD, p.LA = c->D + c->N + 1;
-  p.R = c->Rws.p, p.col_cov = c->col_cov.p, p.P = c->P.p, p.Mt = c->Mt.p, p.A = c->Aaug.p, p.dx = c->dx.p, p.flags = c->flags.p;
+  p.R = c->Rws.p, p.col_cov = c->col_cov.p, p.P = c->P.p, p.Mt = c->Mt.p, p.A = c->Aaug.p, p.Y = c->Yaug.p, p.dx = c->dx.p, p.flags = c->flags.p;
   p.sigma2 = c->dopt.sigma_pix_sq;
   hipStream_t s = c->stream;
   HIPCHK(hipMemsetAsync(c->flags.p, 0, 4 * sizeof(int32_t), s));
   const int tm = (p.D + 15) / 16, tn = (p.N + 15) / 16;
   hipLaunchKernelGGL(k_ekf_mt, dim3((tm * tn + 3) / 4), dim3(256), 0, s, p);
   hipLaunchKernelGGL(k_ekf_s, dim3((tm * tm + 3) / 4), dim3(256), 0, s, p);
-  const size_t lds = (size_t)(CH_NB * CH_NB + CH_NB * p.LA) * sizeof(double);
-  if (lds > (size_t)c->lds_limit) return set_err(OVGPU_ERR_CAPACITY, "state too large for the Cholesky panel in LDS");
-  hipLaunchKernelGGL(k_ekf_chol, dim3(1), dim3(1024), lds, s, p);
+  // Cholesky of S carried through [Mt | c]: one launch per block of 16 rows, one wavefront per trailing 16x16 tile
+  {
+    const int TM = (p.D + 15) / 16, TL = (p.LA + 15) / 16;
+    for (int kb = 0; kb < p.D; kb += 16) {
+      const int tb = kb / 16;
+      int jobs = TL - tb; // writers of the finished rows
+      for (int it = tb + 1; it < TM; it++) jobs += TL - it;
+      hipLaunchKernelGGL(k_ekf_chol_step, dim3((jobs + 3) / 4), dim3(256), 0, s, p, kb);
+    }
+  }
   hipLaunchKernelGGL(k_ekf_pupdate, dim3((tn * tn + 3) / 4), dim3(256), 0, s, p);
   hipLaunchKernelGGL(k_ekf_dx, dim3((p.N + 255) / 256), dim3(256), 0, s, p);
   const int n = std::max(c->C, c->K);
