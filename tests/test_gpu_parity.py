@@ -363,3 +363,66 @@ def test_cfg3_full_size_properties(Updater):
     assert _rel(P1, Pinf) < 1e-7
     assert _rel(out["dx"], Pinf @ H.T @ cmp["r"]) < 1e-6
     up.close()
+
+
+# --------------------------------------------------------------------------- measurement compression variants
+def _compress_with_env(Updater, prob, opts, tri, **env):
+    """The TSQR shape is read from the environment when a context is created / the features are uploaded."""
+    import os
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update({k: str(v) for k, v in env.items()})
+    try:
+        up = Updater(opts)
+        up.set_problem(prob)
+        up.set_triangulation(tri["p_FinG"], tri["p_FinA"], tri["anchor_meas"], tri["status"])
+        cmp = up.compress()
+        up.close()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    return cmp
+
+
+@pytest.mark.parametrize("kw", [dict(F=300), dict(cfg=4, F=120), dict(F=200, K=1, C=12)])
+def test_compression_is_independent_of_the_tree_shape(Updater, oracle, kw):
+    """QR([R_1; R_2; ...]) = QR of the full stack: any number of leaves, and the pipelined single-launch merge
+    tree vs one launch per level, give the same R^T R / R^T c (upper triangular, D x D)."""
+    kw = dict(kw)
+    prob = synth.make_problem(kw.pop("cfg", 2), **kw)
+    opts = capi.default_options(chi2_multipler=1.0)
+    tri = oracle.triangulate(opts, capi.Views(prob))
+    base = _compress_with_env(Updater, prob, opts, tri, OVGPU_TSQR_W=1)
+    G0, g0 = base["H"].T @ base["H"], base["H"].T @ base["r"]
+    for env in (dict(OVGPU_TSQR_W=2), dict(OVGPU_TSQR_W=5), dict(OVGPU_TSQR_W=64), dict(OVGPU_TSQR_W=64, OVGPU_TSQR_PIPELINE=0),
+                dict(OVGPU_TSQR_W=256)):
+        c = _compress_with_env(Updater, prob, opts, tri, **env)
+        assert c["rows"] == base["rows"] and c["D"] == base["D"]
+        assert np.abs(np.tril(c["H"], -1)).max() == 0.0
+        assert np.linalg.norm(c["H"].T @ c["H"] - G0) / np.linalg.norm(G0) < 1e-12, env
+        assert np.linalg.norm(c["H"].T @ c["r"] - g0) / np.linalg.norm(g0) < 1e-11, env
+
+
+def test_cfg4_full_size_properties(Updater):
+    """configs[3] shape on one GPU (30 clones, 4 cameras, D = 236: the 15-tile path of the TSQR, N = 252): a 1250-feature
+    shard — what one of 8 ranks holds — through size-independent properties of the posterior."""
+    prob = synth.make_problem(4, F=1250)
+    assert prob.K == 4 and prob.N == 252
+    opts = capi.default_options(chi2_multipler=1.0)
+    up = Updater(opts)
+    up.set_problem(prob)
+    cmp = up.compress()
+    assert cmp["D"] == 236 and np.abs(np.tril(cmp["H"], -1)).max() == 0.0
+    up.reset_state()
+    out = up.update()
+    P1 = out["P"]
+    assert np.array_equal(P1, P1.T)
+    assert np.linalg.eigvalsh(P1).min() > -1e-12
+    H = np.zeros((cmp["rows"], prob.N))
+    H[:, cmp["col_cov_id"]] = cmp["H"]
+    Pinf = np.linalg.inv(np.linalg.inv(prob.P) + H.T @ H)
+    assert _rel(P1, Pinf) < 1e-7
+    assert _rel(out["dx"], Pinf @ H.T @ cmp["r"]) < 1e-6
+    up.close()
