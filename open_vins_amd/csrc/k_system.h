@@ -75,6 +75,55 @@ __device__ __forceinline__ double lane_bcast_d(double v, int lane) { // lane is 
   return __hiloint2double(hi, lo);
 }
 
+// One 8-column panel of the gate Cholesky, factored by a single wavefront in registers: row r of the panel
+// (rows kb .. n+3) lives in lane r & 63, slot r >> 6; pivots and multipliers are broadcast with v_readlane, so
+// there is no LDS round trip and no workgroup barrier inside the panel.  CS = row slots per lane.
+template <int CS>
+__device__ __forceinline__ void gate_chol_panel(double *S, int n, int kb, int nb, int lane) {
+  constexpr int CB = 8;
+  double a[CS][CB];
+  size_t base[CS];
+  bool okr[CS];
+#pragma unroll
+  for (int sl = 0; sl < CS; sl++) {
+    const int row = kb + lane + 64 * sl;
+    okr[sl] = row < n + 4;
+    base[sl] = (row < n ? (size_t)row * (row + 1) / 2 : (size_t)n * (n + 1) / 2 + (size_t)(row - n) * n) + kb; // &S[row][kb]
+#pragma unroll
+    for (int jj = 0; jj < CB; jj++) a[sl][jj] = (okr[sl] && jj < nb && (row >= n || kb + jj <= row)) ? S[base[sl] + jj] : 0.0;
+  }
+#pragma unroll
+  for (int k = 0; k < CB; k++) {
+    if (k < nb) {
+      const double dkk = lane_bcast_d(a[0][k], k); // row kb + k lives in lane k, slot 0
+      // pivot: d = sqrt(dkk), inv = 1 / d from one v_rsq_f64 seed + Newton steps (a few ulp; the chain of a column step)
+      double inv = __builtin_amdgcn_rsq(dkk);
+#pragma unroll
+      for (int it = 0; it < 2; it++) inv = fma(0.5 * inv, fma(-dkk * inv, inv, 1.0), inv);
+      double d = dkk * inv;
+      d = fma(0.5 * inv, fma(-d, d, dkk), d);
+      if (!(dkk > 0.0)) d = sqrt(dkk), inv = 1.0 / d; // keep the NaN / inf behaviour of a broken-down factorisation
+#pragma unroll
+      for (int sl = 0; sl < CS; sl++) a[sl][k] = (lane + 64 * sl == k) ? d : a[sl][k] * inv;
+#pragma unroll
+      for (int jj = k + 1; jj < CB; jj++) {
+        if (jj < nb) {
+          const double ljk = lane_bcast_d(a[0][k], jj); // L[kb + jj][kb + k]
+#pragma unroll
+          for (int sl = 0; sl < CS; sl++) a[sl][jj] = fma(-a[sl][k], ljk, a[sl][jj]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int sl = 0; sl < CS; sl++) {
+    const int row = kb + lane + 64 * sl;
+#pragma unroll
+    for (int jj = 0; jj < CB; jj++)
+      if (okr[sl] && jj < nb && (row >= n || kb + jj <= row)) S[base[sl] + jj] = a[sl][jj];
+  }
+}
+
 __global__ void __launch_bounds__(SYS_NT) k_system(SysParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
@@ -425,60 +474,16 @@ __global__ void __launch_bounds__(SYS_NT) k_system(SysParams p) {
     // r & 63, pivots and multipliers broadcast with v_readlane: no LDS round trip, no workgroup barrier inside the
     // panel), then all waves apply the rank-8 update to the trailing trapezoid.  2 barriers per 8 columns.
     {
-      constexpr int CB = 8, CS = 8; // block width, row slots per lane (n + 4 <= 64 * CS)
+      constexpr int CB = 8; // block width; the panel routine handles n + 4 <= 512 rows
       const int lane = tid & 63, wv = tid >> 6;
       for (int kb = 0; kb < n; kb += CB) {
         const int nb = min(CB, n - kb);
         if (wv == 0) {
-          const int rs = (n + 4 - kb + 63) >> 6;
-          double a[CS][CB];
-#pragma unroll
-          for (int sl = 0; sl < CS; sl++)
-            if (sl < rs) {
-              const int row = kb + lane + 64 * sl;
-#pragma unroll
-              for (int jj = 0; jj < CB; jj++) {
-                const int col = kb + jj;
-                a[sl][jj] = (jj < nb && row < n + 4 && (row >= n || col <= row)) ? S[sidx(row, col, n)] : 0.0;
-              }
-            }
-#pragma unroll
-          for (int k = 0; k < CB; k++) {
-            if (k < nb) {
-              const double dkk = lane_bcast_d(a[0][k], k); // row kb + k lives in lane k, slot 0
-              // pivot: d = sqrt(dkk), inv = 1 / d from one v_rsq_f64 seed + Newton steps (a few ulp; the chain of a column step)
-              double inv = __builtin_amdgcn_rsq(dkk);
-#pragma unroll
-              for (int it = 0; it < 2; it++) inv = fma(0.5 * inv, fma(-dkk * inv, inv, 1.0), inv);
-              double d = dkk * inv;
-              d = fma(0.5 * inv, fma(-d, d, dkk), d);
-              if (!(dkk > 0.0)) d = sqrt(dkk), inv = 1.0 / d; // keep the NaN / inf behaviour of a broken-down factorisation
-#pragma unroll
-              for (int sl = 0; sl < CS; sl++)
-                if (sl < rs) a[sl][k] = (lane + 64 * sl == k) ? d : a[sl][k] * inv;
-#pragma unroll
-              for (int jj = k + 1; jj < CB; jj++) {
-                if (jj < nb) {
-                  const double ljk = lane_bcast_d(a[0][k], jj); // L[kb + jj][kb + k]
-#pragma unroll
-                  for (int sl = 0; sl < CS; sl++)
-                    if (sl < rs) a[sl][jj] = fma(-a[sl][k], ljk, a[sl][jj]);
-                }
-              }
-            }
-          }
-#pragma unroll
-          for (int sl = 0; sl < CS; sl++)
-            if (sl < rs) {
-              const int row = kb + lane + 64 * sl;
-#pragma unroll
-              for (int jj = 0; jj < CB; jj++) {
-                const int col = kb + jj;
-                if (jj < nb && row < n + 4 && (row >= n || col <= row)) S[sidx(row, col, n)] = a[sl][jj];
-              }
-            }
+          if (n + 4 - kb <= 128) gate_chol_panel<2>(S, n, kb, nb, lane);
+          else gate_chol_panel<8>(S, n, kb, nb, lane);
         }
         __syncthreads();
+        SYS_T(0)
         // trailing update: S[i][j] -= sum_l L[i][kb + l] L[j][kb + l]   for kb + nb <= j <= min(i, n - 1), i < n + 4
         {
           const int ti = tid >> 4, tj = tid & 15;
@@ -498,6 +503,7 @@ __global__ void __launch_bounds__(SYS_NT) k_system(SysParams p) {
           }
         }
         __syncthreads();
+        SYS_T(4)
       }
     }
     SYS_T(5)
