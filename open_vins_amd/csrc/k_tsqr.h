@@ -471,9 +471,10 @@ __global__ void __launch_bounds__(512) k_qr_node(QrNodeParams p) {
 // instead of one merge per level.  Every node is a workgroup; all of them must be co-resident (the host launches at
 // most one node per CU; a node occupies a whole CU's register file), and every wait is bounded.
 //
-// Hand-off (MI355X_MICROARCH.md, "inter-workgroup visibility"): producer = plain stores, __syncthreads, lane 0:
-// agent-scope release fence, s_waitcnt vmcnt(0), relaxed agent-scope store of the panel counter; consumer = lane 0
-// polls the counter with relaxed agent-scope loads (+ s_sleep), agent-scope acquire fence, __syncthreads, plain loads.
+// Hand-off (MI355X_MICROARCH.md, "inter-workgroup visibility", the sc1-both-sides form): producer = agent-scope
+// (write-through) stores of the panel rows, every wave drains its stores (s_waitcnt vmcnt(0)) before the workgroup
+// barrier, lane 0 then stores the panel counter (relaxed, agent scope); consumer = lane 0 polls the counter with
+// relaxed agent-scope loads (+ s_sleep), __syncthreads, agent-scope loads of the rows (they bypass the CU's L1).
 // ---------------------------------------------------------------------------------------------------
 struct QrTreeNode {
   int32_t a_slot, b_slot; // triangles: accumulator (in place) and the one folded into it
@@ -488,6 +489,11 @@ struct QrTreeParams {
   int32_t *error;          // set to 1 when a wait ran into its bound
   int64_t spin_limit;
 };
+
+// agent-scope (sc1) accesses: stores write through the XCD's L2, loads bypass the CU's L1 — with both sides using them
+// the hand-off needs no release / acquire fence (a buffer_wbl2 per panel costs more than the panel's stores)
+__device__ __forceinline__ double ld_agent(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 __device__ __forceinline__ void qr_wait_panels(const int32_t *flag, int need, int64_t limit, int32_t *error) {
   int64_t it = 0;
@@ -508,7 +514,7 @@ __device__ __forceinline__ void qr_load_chunk(double (&y)[QS], int j, const doub
 #pragma unroll
   for (int i = 0; i < 4; i++) {
     const int64_t r = row0 + 4 * i + g;
-    v[i] = (ok && r < lim) ? src[(size_t)r * LD + col] : 0.0;
+    v[i] = (ok && r < lim) ? ld_agent(src + (size_t)r * LD + col) : 0.0;
   }
 #pragma unroll
   for (int q = 0; q < QS; q++) y[q] = ((q >> 2) == j) ? v[q & 3] : y[q];
@@ -549,7 +555,6 @@ __global__ void __launch_bounds__(512) k_qr_tree(QrTreeParams p) {
     if (tid == 0) {
       if (nd.dep_a >= 0) qr_wait_panels(p.progress + nd.dep_a, pnl + 1, p.spin_limit, p.error);
       if (nd.dep_b >= 0) qr_wait_panels(p.progress + nd.dep_b, pnl + 1, p.spin_limit, p.error);
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     __syncthreads();
     // ---- accumulator rows of the panel -> LDS; rows 16 pnl .. of the source triangle -> registers
@@ -557,7 +562,7 @@ __global__ void __launch_bounds__(512) k_qr_tree(QrTreeParams p) {
 #pragma unroll
       for (int i = 0; i < 8; i++) {
         const int row = 2 * i + cp_r, j = 16 * pnl + row;
-        Rp[row * LDP + cp_c] = (j < D && cp_c < LD) ? acc[(size_t)j * LD + cp_c] : 0.0;
+        Rp[row * LDP + cp_c] = (j < D && cp_c < LD) ? ld_agent(acc + (size_t)j * LD + cp_c) : 0.0;
       }
     }
     const bool split = pnl >= NW;
@@ -591,13 +596,12 @@ __global__ void __launch_bounds__(512) k_qr_tree(QrTreeParams p) {
 #pragma unroll
       for (int i = 0; i < 8; i++) {
         const int row = 2 * i + cp_r, j = 16 * pnl + row;
-        if (j < D && cp_c < LD) acc[(size_t)j * LD + cp_c] = Rp[row * LDP + cp_c];
+        if (j < D && cp_c < LD) st_agent(acc + (size_t)j * LD + cp_c, Rp[row * LDP + cp_c]);
       }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every wave drains its write-through stores before the barrier
     __syncthreads();
     if (tid == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __hip_atomic_store(p.progress + blockIdx.x, pnl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }

@@ -52,6 +52,7 @@ int main(int argc, char **argv) {
   QrNodeParams q{};
   q.D = D, q.LD = LD, q.NT = NT, q.acc = dR, q.acc_stride = 1, q.src = dA, q.src_stride = 0;
   q.rows_per_node = (rows + G - 1) / G, q.rows_total = rows, q.zero_init = 1, q.dbg = nullptr;
+  if (argc > 4) q.rows_per_node = atoi(argv[4]); // e.g. all rows in node 0: the other leaves are zero triangles (steps with tau' = 0)
   // merge tree description
   std::vector<QrTreeNode> nodes;
   std::vector<int32_t> writer(G, -1);
