@@ -265,6 +265,44 @@ int ovgpu_msckf_compress(ovgpu_ctx *ctx, int32_t *feat_status, double *chi2,
 int ovgpu_get_state(ovgpu_ctx *ctx, double *P, double *clone_q_p,
                     double *calib_q_p, double *intrinsics);
 
+
+/* ------------------------------------------------------------------------- */
+/* ov_msckf::UpdaterSLAM::update  (UpdaterSLAM.cpp:253-479)                   */
+/* ------------------------------------------------------------------------- */
+
+/* SLAM landmarks that live in the state (State::_features_SLAM, ov_type::Landmark,
+ * ov_core/src/types/Landmark.h).  This round supports the reference default
+ * feat_rep_slam = GLOBAL_3D (StateOptions.h:89): a landmark is a 3-dof global position.
+ *   p_value [3*L]  Landmark::get_xyz(false)   (UpdaterSLAM.cpp:349-352)
+ *   p_fej   [3*L]  Landmark::get_xyz(true)
+ *   cov_id  [L]    Type::id() of the 3-dof landmark in the covariance                   */
+typedef struct {
+  int32_t L;
+  int32_t _pad0;
+  const double *p_value;
+  const double *p_fej;
+  const int32_t *cov_id;
+} ovgpu_landmarks_view;
+
+/* Uploads the landmarks the next ovgpu_slam_update works on; their 3 columns each join the
+ * canonical column order (sorted by covariance id).  Call after ovgpu_set_state.             */
+int ovgpu_set_landmarks(ovgpu_ctx *ctx, const ovgpu_landmarks_view *lm);
+
+/* UpdaterSLAM::update on the resident state, landmarks and feature tracks: feature f observes
+ * landmark lm_index[f].  Per feature the Jacobian of UpdaterHelper::get_feature_jacobian_full
+ * with the landmark's own columns appended (UpdaterSLAM.cpp:369-384, no nullspace projection
+ * for a full 3-dof landmark), the chi2 gate on all 2m rows against the prior with the
+ * landmark's covariance (:390-420, dof = 2m), stacking (:427-447) and one EKF update (:470).
+ * The context's options are the UpdaterSLAM's (sigma_pix, chi2_multipler of `slam`).
+ * The reference stacks without compressing; here the stack goes through the same TSQR as the
+ * MSCKF update first — the EKF result is the same matrix (QR is an orthogonal transform of
+ * the rows).  Features with no measurement are flagged OVGPU_FEAT_TOO_FEW_MEAS (:289-291).
+ *   feat_status, chi2, chi2_thresh [F];  dx [N];  P_out [N*N];  lm_out [3*L] updated
+ *   landmark positions (Landmark::update, Landmark.h:80-89: additive for GLOBAL_3D).     */
+int ovgpu_slam_update(ovgpu_ctx *ctx, const int32_t *lm_index, int32_t *feat_status,
+                      double *chi2, double *chi2_thresh, double *dx, double *P_out,
+                      double *lm_out, ovgpu_update_stats *stats);
+
 /* ------------------------------------------------------------------------- */
 /* feature-sharded multi-GPU update                           */
 /* ------------------------------------------------------------------------- */

@@ -73,6 +73,11 @@ class FeaturesView(C.Structure):
     ]
 
 
+class LandmarksView(C.Structure):
+    """ovgpu_landmarks_view"""
+    _fields_ = [("L", C.c_int32), ("_pad0", C.c_int32), ("p_value", c_double_p), ("p_fej", c_double_p), ("cov_id", c_int32_p)]
+
+
 class UpdateStats(C.Structure):
     """ovgpu_update_stats"""
     _fields_ = [
@@ -133,6 +138,19 @@ class Views:
         fv.clone_idx = _ptr(self.clone_idx, C.c_int32)
         fv.cam_idx = _ptr(self.cam_idx, C.c_int32)
         self.features = fv
+        # SLAM landmarks (synth.make_slam_problem); absent for MSCKF snapshots
+        self.landmarks = None
+        if getattr(prob, "lm_value", None) is not None:
+            self.lm_value = f64(prob.lm_value)
+            self.lm_fej = f64(prob.lm_fej)
+            self.lm_cov_id = i32(prob.lm_cov_id)
+            self.lm_index = i32(prob.lm_index)
+            lv = LandmarksView()
+            lv.L = int(self.lm_cov_id.shape[0])
+            lv.p_value = _ptr(self.lm_value, C.c_double)
+            lv.p_fej = _ptr(self.lm_fej, C.c_double)
+            lv.cov_id = _ptr(self.lm_cov_id, C.c_int32)
+            self.landmarks = lv
 
 
 _lib = None
@@ -157,6 +175,9 @@ def declare(lib):
         "ovgpu_msckf_compress": (C.c_int, [ctxp, c_int32_p, c_double_p, c_double_p, c_double_p, c_int32_p, c_int32_p,
                                            c_int32_p, c_double_p, c_double_p, C.POINTER(UpdateStats)]),
         "ovgpu_get_state": (C.c_int, [ctxp, c_double_p, c_double_p, c_double_p, c_double_p]),
+        "ovgpu_set_landmarks": (C.c_int, [ctxp, C.POINTER(LandmarksView)]),
+        "ovgpu_slam_update": (C.c_int, [ctxp, c_int32_p, c_int32_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p,
+                                        C.POINTER(UpdateStats)]),
         "ovgpu_triangle_len": (C.c_int, [ctxp, C.POINTER(C.c_int64)]),
         "ovgpu_msckf_local": (C.c_int, [ctxp, c_int32_p, c_double_p, c_double_p, c_double_p, vp, C.POINTER(UpdateStats)]),
         "ovgpu_msckf_merge_update": (C.c_int, [ctxp, vp, C.c_int, c_double_p, c_double_p, C.POINTER(UpdateStats)]),

@@ -165,6 +165,9 @@ __global__ void __launch_bounds__(SYS_NT) k_system(SysParams p) {
     // (a0) representation Jacobian — UpdaterHelper.cpp:32-190 (once per feature)
     // ------------------------------------------------------------------
     V3 p_FinG = load_v3(p.p_FinG + 3 * f);
+    const bool slam = p.slam != 0; // UpdaterSLAM::update: the feature is a landmark of the state (GLOBAL_3D)
+    const int lm_id = slam ? p.feat_lm[f] : -1, lm_col = slam ? p.feat_lmcol[f] : -1, lm_cov = slam ? p.feat_lmcov[f] : -1;
+    const V3 p_FinG_fej = slam ? load_v3(p.p_fej + 3 * f) : p_FinG; // fej == value for MSCKF features (UpdaterMSCKF.cpp:186-194)
     int anchor_cam = -1, anchor_clone = -1;
     if (relative) {
       const int ac = p.meas_cc[p.anchor_meas[f]];
@@ -260,7 +263,7 @@ __global__ void __launch_bounds__(SYS_NT) k_system(SysParams p) {
       if (p.opt.do_fej) { // :354-363  (uv_norm is deliberately NOT recomputed, Q4)
         R_GtoIi = load_m3(tc + 12);
         p_IiinG = load_v3(tc + 21);
-        p_FinIi = mul(R_GtoIi, p_FinG - p_IiinG); // p_FinG_fej == p_FinG for MSCKF features (Q5)
+        p_FinIi = mul(R_GtoIi, p_FinG_fej - p_IiinG); // p_FinG_fej == p_FinG for MSCKF features (Q5), the landmark's fej for SLAM
         p_FinCi = mul(R_ItoC, p_FinIi) + p_IinC;
       }
       double dzn[4], dze[16];
@@ -340,6 +343,7 @@ __global__ void __launch_bounds__(SYS_NT) k_system(SysParams p) {
     // shared by all of that camera's measurements, the anchor rows by the whole feature — loaded once, not per row
     int cache_c = -1, cache_cam = -1;
     double pcp[6] = {0, 0, 0, 0, 0, 0}, pci[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pac[6] = {0, 0, 0, 0, 0, 0}, pap[6] = {0, 0, 0, 0, 0, 0};
+    double plm[3] = {0, 0, 0}; // SLAM: the landmark's 3 rows of P
     for (int i0 = 0; i0 < m; i0 += SYS_RCM) {
       const int mc = min(SYS_RCM, m - i0);
       // phase 1: T = H P for the chunk's 2*mc rows, all D columns
@@ -362,6 +366,10 @@ __global__ void __launch_bounds__(SYS_NT) k_system(SysParams p) {
           if (anc_pcov >= 0) {
 #pragma unroll
             for (int s = 0; s < 6; s++) pap[s] = Pc[(size_t)(anc_pcov + s) * N];
+          }
+          if (lm_cov >= 0) {
+#pragma unroll
+            for (int s = 0; s < 3; s++) plm[s] = Pc[(size_t)(lm_cov + s) * N];
           }
         }
 #pragma unroll
@@ -399,6 +407,10 @@ __global__ void __launch_bounds__(SYS_NT) k_system(SysParams p) {
 #pragma unroll
               for (int s = 0; s < 6; s++) t0 = fma(rd[RO_ACAL + s], pap[s], t0), t1 = fma(rd[RO_ACAL + 6 + s], pap[s], t1);
             }
+            if (lm_cov >= 0) {
+#pragma unroll
+              for (int s = 0; s < 3; s++) t0 = fma(rd[RO_HF + s], plm[s], t0), t1 = fma(rd[RO_HF + 3 + s], plm[s], t1);
+            }
             Tch[(size_t)(2 * ii) * D + c] = t0;
             Tch[(size_t)(2 * ii + 1) * D + c] = t1;
           }
@@ -417,7 +429,9 @@ __global__ void __launch_bounds__(SYS_NT) k_system(SysParams p) {
           const int *mi = minfo + 8 * qi;
           const double *rd = rows + (size_t)qi * RS;
           const int c_cl = mi[2], c_po = mi[3], c_in = mi[4];
-          double hcl[6], hpo[6], hin[8], han[6], hac[6];
+          double hcl[6], hpo[6], hin[8], han[6], hac[6], hlm[3];
+#pragma unroll
+          for (int k = 0; k < 3; k++) hlm[k] = lm_col >= 0 ? rd[RO_HF + 3 * qa + k] : 0.0;
 #pragma unroll
           for (int k = 0; k < 6; k++) hcl[k] = rd[RO_CLONE + 6 * qa + k];
 #pragma unroll
@@ -450,6 +464,10 @@ __global__ void __launch_bounds__(SYS_NT) k_system(SysParams p) {
             if (anc_pcol >= 0) {
 #pragma unroll
               for (int k = 0; k < 6; k++) sv = fma(Tr[anc_pcol + k], hac[k], sv);
+            }
+            if (lm_col >= 0) {
+#pragma unroll
+              for (int k = 0; k < 3; k++) sv = fma(Tr[lm_col + k], hlm[k], sv);
             }
             S[sidx(r, q, n)] = sv;
           }
@@ -523,8 +541,9 @@ __global__ void __launch_bounds__(SYS_NT) k_system(SysParams p) {
       const M3 G{G00, G01, G02, G01, G11, G12, G02, G12, G22};
       const V3 g{g0, g1, g2};
       const V3 x = colpiv_qr_solve3(G, g);
-      const double chi2 = a - dot(g, x);
-      const int dof = n - 3;
+      // SLAM: the landmark is a state variable, the gate is on all n rows (UpdaterSLAM.cpp:390-405)
+      const double chi2 = slam ? a : a - dot(g, x);
+      const int dof = slam ? n : n - 3;
       const double thr = p.opt.chi2_multipler * p.chi2_table[min(dof, p.chi2_table_len - 1)]; // UpdaterMSCKF.cpp:216-222
       if (tid == 0) {
         p.chi2[f] = chi2;
@@ -544,7 +563,7 @@ __global__ void __launch_bounds__(SYS_NT) k_system(SysParams p) {
     SYS_T(6)
     // (b) Householder QR of H_f (2m x 3) -> V, tau, T   (role of UpdaterHelper.cpp:426-454)
     // ------------------------------------------------------------------
-    if (tid < 64) {
+    if (!slam && tid < 64) {
       const int lane = tid;
 #pragma unroll
       for (int k = 0; k < 3; k++) {
@@ -607,7 +626,7 @@ __global__ void __launch_bounds__(SYS_NT) k_system(SysParams p) {
     {
       const double T00 = hq[3], T01 = hq[4], T02 = hq[5], T11 = hq[6], T12 = hq[7], T22 = hq[8];
       for (int c = tid; c < LD; c += SYS_NT) {
-        int kind = 3, var = 0, sub = 0; // 3 = residual column
+        int kind = COL_RESIDUAL, var = 0, sub = 0;
         if (c < D) kind = p.col_kind[c], var = p.col_var[c], sub = p.col_sub[c];
         const bool anc_hit_c = (kind == COL_CLONE && var == anchor_clone && relative);
         const bool anc_hit_p = (kind == COL_CALIB_POSE && var == anchor_cam && relative && p.opt.do_calib_pose);
@@ -615,17 +634,26 @@ __global__ void __launch_bounds__(SYS_NT) k_system(SysParams p) {
         // several rows in flight (the branchy form was LDS-latency bound: 2 dependent reads per element)
         const int kclone = (kind == COL_CLONE) ? var : -1000;
         const int kcam = (kind == COL_CALIB_POSE || kind == COL_CALIB_INTR) ? var : -1000; // such a column exists only for a calibrated camera
-        const int off0 = kind == 3 ? RO_RES : (kind == COL_CLONE ? RO_CLONE + sub : (kind == COL_CALIB_POSE ? RO_CPOSE + sub : RO_CINTR + sub));
-        const int astr = kind == 3 ? 1 : (kind == COL_CALIB_INTR ? 8 : 6);
+        const bool whole = kind == COL_RESIDUAL || (kind == COL_LANDMARK && var == lm_id); // columns every row of the feature touches
+        const int off0 = kind == COL_RESIDUAL ? RO_RES
+                                              : (kind == COL_CLONE ? RO_CLONE + sub
+                                                                   : (kind == COL_CALIB_POSE ? RO_CPOSE + sub : (kind == COL_CALIB_INTR ? RO_CINTR + sub : RO_HF + sub)));
+        const int astr = kind == COL_RESIDUAL ? 1 : (kind == COL_CALIB_INTR ? 8 : (kind == COL_LANDMARK ? 3 : 6));
         auto hval = [&](int i, int a) -> double {
           const int2 key = *reinterpret_cast<const int2 *>(minfo + 8 * i); // (camera, clone)
           const double *rd = rows + (size_t)i * RS;
           const double hv = rd[off0 + astr * a];
-          double h = (kind == 3 || key.y == kclone || key.x == kcam) ? hv : 0.0;
+          double h = (whole || key.y == kclone || key.x == kcam) ? hv : 0.0;
           if (anc_hit_c) h += rd[RO_ANC + 6 * a + sub];
           if (anc_hit_p) h += rd[RO_ACAL + 6 * a + sub];
           return h;
         };
+        if (slam) { // UpdaterSLAM.cpp:381-383, :427-447: the rows go into the stack as they are, landmark columns included
+          double *out = p.Hbig + orow0 * LD + c;
+#pragma unroll 4
+          for (int r = 0; r < n; r++) out[(size_t)r * LD] = hval(r >> 1, r & 1);
+          continue;
+        }
         // y = V^T h
         double y0 = 0, y1 = 0, y2 = 0;
 #pragma unroll 4

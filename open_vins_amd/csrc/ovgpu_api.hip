@@ -86,6 +86,14 @@ struct ovgpu_ctx {
   DevBuf<uint16_t> col_var;
   DevBuf<double> tab_clone, tab_cam, tab_cc;
   std::vector<int32_t> h_col_cov;
+  struct HVar { int cov, size, kind, index; };
+  std::vector<HVar> h_vars; // clones + calibrated camera variables of the resident state (landmarks are merged in by build_columns)
+  // SLAM landmarks (ovgpu_set_landmarks); L > 0 switches the per-feature kernel to the UpdaterSLAM rules
+  int L = 0;
+  std::vector<int32_t> h_lm_cov, h_lm_col;
+  std::vector<double> h_lm_value, h_lm_fej;
+  DevBuf<double> pFej, lm_pos;
+  DevBuf<int32_t> feat_lm, feat_lmcol, feat_lmcov, lm_cov;
 
   // ---- features
   bool have_feats = false;
@@ -269,6 +277,7 @@ void ovgpu_destroy(ovgpu_ctx *c) {
   c->meas_offsets.release(), c->meas_cc.release(), c->uv.release(), c->uvn.release(), c->row_off.release();
   c->pA.release(), c->pG.release(), c->chi2.release(), c->chi2_thr.release(), c->anchor.release(), c->status.release();
   c->chi2_table.release(), c->Hbig.release(), c->gate_ws.release(), c->Rws.release(), c->tree_nodes.release(), c->tree_flags.release(), c->Mt.release(), c->Aaug.release(), c->Yaug.release();
+  c->pFej.release(), c->lm_pos.release(), c->feat_lm.release(), c->feat_lmcol.release(), c->feat_lmcov.release(), c->lm_cov.release();
   c->dx.release(), c->flags.release(), c->given_status.release();
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -279,6 +288,55 @@ static int launch_build_tables(ovgpu_ctx *c) {
   hipLaunchKernelGGL(k_build_tables, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->C, c->K, c->clone_qp.p, c->clone_fej.p, c->calib_qp.p,
                      c->tab_clone.p, c->tab_cam.p, c->tab_cc.p);
   HIPCHK(hipGetLastError());
+  return OVGPU_OK;
+}
+
+// Canonical column order of the stacked Jacobian: calibrated camera variables, clones and (SLAM) landmarks sorted by
+// covariance id.  Called by ovgpu_set_state and ovgpu_set_landmarks.
+static int build_columns(ovgpu_ctx *c) {
+  std::vector<ovgpu_ctx::HVar> vars = c->h_vars;
+  for (int l = 0; l < c->L; l++) vars.push_back({c->h_lm_cov[l], 3, COL_LANDMARK, l});
+  std::stable_sort(vars.begin(), vars.end(), [](const ovgpu_ctx::HVar &a, const ovgpu_ctx::HVar &b) { return a.cov < b.cov; });
+  const int C = c->C, K = c->K, N = c->N;
+  std::vector<int32_t> clone_col(C, -1), calib_col(K, -1), intr_col(K, -1), col_cov;
+  std::vector<uint8_t> col_kind, col_sub;
+  std::vector<uint16_t> col_var;
+  c->h_lm_col.assign(c->L, -1);
+  int D = 0;
+  for (const auto &v : vars) {
+    if (v.cov < 0 || v.cov + v.size > N) return set_err(OVGPU_ERR_INVALID, "covariance id out of range");
+    if (v.kind == COL_CLONE) clone_col[v.index] = D;
+    if (v.kind == COL_CALIB_POSE) calib_col[v.index] = D;
+    if (v.kind == COL_CALIB_INTR) intr_col[v.index] = D;
+    if (v.kind == COL_LANDMARK) c->h_lm_col[v.index] = D;
+    for (int i = 0; i < v.size; i++) {
+      col_cov.push_back(v.cov + i);
+      col_kind.push_back((uint8_t)v.kind);
+      col_var.push_back((uint16_t)v.index);
+      col_sub.push_back((uint8_t)i);
+    }
+    D += v.size;
+  }
+  if (D + 1 > 512) return set_err(OVGPU_ERR_CAPACITY, "more than 511 Jacobian columns");
+  c->D = D, c->LD = D + 1;
+  c->h_col_cov = col_cov;
+  HIPCHK(c->col_cov.reserve(D));
+  HIPCHK(c->col_kind.reserve(D));
+  HIPCHK(c->col_sub.reserve(D));
+  HIPCHK(c->col_var.reserve(D));
+  HIPCHK(c->Mt.reserve((size_t)D * N));
+  HIPCHK(c->Aaug.reserve((size_t)D * (D + N + 1)));
+  HIPCHK(c->Yaug.reserve((size_t)D * (D + N + 1)));
+  hipStream_t s = c->stream;
+  HIPCHK(upload(c->clone_col.p, clone_col.data(), sizeof(int32_t) * C, s));
+  HIPCHK(upload(c->calib_col.p, calib_col.data(), sizeof(int32_t) * K, s));
+  HIPCHK(upload(c->intr_col.p, intr_col.data(), sizeof(int32_t) * K, s));
+  HIPCHK(upload(c->col_cov.p, col_cov.data(), sizeof(int32_t) * D, s));
+  HIPCHK(upload(c->col_kind.p, col_kind.data(), D, s));
+  HIPCHK(upload(c->col_sub.p, col_sub.data(), D, s));
+  HIPCHK(upload(c->col_var.p, col_var.data(), sizeof(uint16_t) * D, s));
+  HIPCHK(hipStreamSynchronize(s)); // host staging vectors go out of scope
+  c->have_feats = false;           // workspaces depend on D
   return OVGPU_OK;
 }
 
@@ -293,34 +351,22 @@ int ovgpu_set_state(ovgpu_ctx *c, const ovgpu_state_view *st) {
   const int N = st->N, C = st->C, K = st->K;
 
   // ---- canonical column order: calibrated camera variables and clones sorted by covariance id
-  struct Var { int cov, size, kind, index; };
-  std::vector<Var> vars;
+  c->h_vars.clear();
   for (int k = 0; k < K; k++) {
-    if (c->dopt.do_calib_pose && st->calib_cov_id[k] >= 0) vars.push_back({st->calib_cov_id[k], 6, COL_CALIB_POSE, k});
-    if (c->dopt.do_calib_intr && st->intr_cov_id[k] >= 0) vars.push_back({st->intr_cov_id[k], 8, COL_CALIB_INTR, k});
+    if (c->dopt.do_calib_pose && st->calib_cov_id[k] >= 0) c->h_vars.push_back({st->calib_cov_id[k], 6, COL_CALIB_POSE, k});
+    if (c->dopt.do_calib_intr && st->intr_cov_id[k] >= 0) c->h_vars.push_back({st->intr_cov_id[k], 8, COL_CALIB_INTR, k});
   }
-  for (int i = 0; i < C; i++) vars.push_back({st->clone_cov_id[i], 6, COL_CLONE, i});
-  std::stable_sort(vars.begin(), vars.end(), [](const Var &a, const Var &b) { return a.cov < b.cov; });
-  std::vector<int32_t> clone_col(C, -1), calib_col(K, -1), intr_col(K, -1), col_cov;
-  std::vector<uint8_t> col_kind, col_sub;
-  std::vector<uint16_t> col_var;
-  int D = 0;
-  for (const Var &v : vars) {
-    if (v.cov < 0 || v.cov + v.size > N) return set_err(OVGPU_ERR_INVALID, "covariance id out of range");
-    if (v.kind == COL_CLONE) clone_col[v.index] = D;
-    if (v.kind == COL_CALIB_POSE) calib_col[v.index] = D;
-    if (v.kind == COL_CALIB_INTR) intr_col[v.index] = D;
-    for (int i = 0; i < v.size; i++) {
-      col_cov.push_back(v.cov + i);
-      col_kind.push_back((uint8_t)v.kind);
-      col_var.push_back((uint16_t)v.index);
-      col_sub.push_back((uint8_t)i);
-    }
-    D += v.size;
+  for (int i = 0; i < C; i++) c->h_vars.push_back({st->clone_cov_id[i], 6, COL_CLONE, i});
+  c->N = N, c->C = C, c->K = K;
+  c->L = 0, c->h_lm_cov.clear(), c->h_lm_col.clear();
+  HIPCHK(c->clone_col.reserve(C));
+  HIPCHK(c->calib_col.reserve(K));
+  HIPCHK(c->intr_col.reserve(K));
+  {
+    const int rcb = build_columns(c);
+    if (rcb != OVGPU_OK) return rcb;
   }
-  if (D + 1 > 512) return set_err(OVGPU_ERR_CAPACITY, "more than 511 Jacobian columns");
-  c->N = N, c->C = C, c->K = K, c->D = D, c->LD = D + 1;
-  c->h_col_cov = col_cov;
+  const int D = c->D;
 
   HIPCHK(c->P.reserve((size_t)N * N));
   HIPCHK(c->P0.reserve((size_t)N * N));
@@ -335,13 +381,6 @@ int ovgpu_set_state(ovgpu_ctx *c, const ovgpu_state_view *st) {
   HIPCHK(c->clone_cov.reserve(C));
   HIPCHK(c->calib_cov.reserve(K));
   HIPCHK(c->intr_cov.reserve(K));
-  HIPCHK(c->clone_col.reserve(C));
-  HIPCHK(c->calib_col.reserve(K));
-  HIPCHK(c->intr_col.reserve(K));
-  HIPCHK(c->col_cov.reserve(D));
-  HIPCHK(c->col_kind.reserve(D));
-  HIPCHK(c->col_sub.reserve(D));
-  HIPCHK(c->col_var.reserve(D));
   HIPCHK(c->tab_clone.reserve(24 * C));
   HIPCHK(c->tab_cam.reserve(12 * K));
   HIPCHK(c->tab_cc.reserve((size_t)12 * K * C));
@@ -367,13 +406,6 @@ int ovgpu_set_state(ovgpu_ctx *c, const ovgpu_state_view *st) {
   HIPCHK(upload(c->clone_cov.p, st->clone_cov_id, sizeof(int32_t) * C, s));
   HIPCHK(upload(c->calib_cov.p, calib_cov.data(), sizeof(int32_t) * K, s));
   HIPCHK(upload(c->intr_cov.p, intr_cov.data(), sizeof(int32_t) * K, s));
-  HIPCHK(upload(c->clone_col.p, clone_col.data(), sizeof(int32_t) * C, s));
-  HIPCHK(upload(c->calib_col.p, calib_col.data(), sizeof(int32_t) * K, s));
-  HIPCHK(upload(c->intr_col.p, intr_col.data(), sizeof(int32_t) * K, s));
-  HIPCHK(upload(c->col_cov.p, col_cov.data(), sizeof(int32_t) * D, s));
-  HIPCHK(upload(c->col_kind.p, col_kind.data(), D, s));
-  HIPCHK(upload(c->col_sub.p, col_sub.data(), D, s));
-  HIPCHK(upload(c->col_var.p, col_var.data(), sizeof(uint16_t) * D, s));
   // the pageable-host copies above must complete before the caller's buffers may change
   HIPCHK(hipStreamSynchronize(s));
   // device-side copy of the prior for ovgpu_reset_state
@@ -420,7 +452,8 @@ int ovgpu_set_features(ovgpu_ctx *c, const ovgpu_features_view *fv) {
     const int m = fv->meas_offsets[f + 1] - fv->meas_offsets[f];
     if (m < 0) return set_err(OVGPU_ERR_INVALID, "meas_offsets not monotone");
     m_max = std::max(m_max, m);
-    row_off[f + 1] = row_off[f] + (m >= 2 ? 2 * m - 3 : 0); // rows after the nullspace projection (UpdaterHelper.cpp:449-450)
+    // MSCKF: rows after the nullspace projection (UpdaterHelper.cpp:449-450); SLAM (landmarks resident): all 2m rows (UpdaterSLAM.cpp:381-383)
+    row_off[f + 1] = row_off[f] + (c->L > 0 ? (m >= 1 ? 2 * m : 0) : (m >= 2 ? 2 * m - 3 : 0));
   }
   c->F = F, c->M = M, c->m_max = m_max, c->rows_total = row_off[F];
   c->h_offsets.assign(fv->meas_offsets, fv->meas_offsets + (F > 0 ? F + 1 : 0));
@@ -528,6 +561,8 @@ static int enqueue_system(ovgpu_ctx *c) {
   p.m_lds_max = c->m_lds_max, p.m_max = std::max(c->m_max, 1), p.row_stride = c->row_stride;
   p.opt = c->dopt;
   p.dbg = qr_dbg_buffer();
+  p.slam = c->L > 0 ? 1 : 0;
+  p.p_fej = c->pFej.p, p.feat_lm = c->feat_lm.p, p.feat_lmcol = c->feat_lmcol.p, p.feat_lmcov = c->feat_lmcov.p;
   hipLaunchKernelGGL(k_system, dim3(c->sys_grid), dim3(SYS_NT), c->sys_lds_bytes, c->stream, p);
   HIPCHK(hipGetLastError());
   return OVGPU_OK;
@@ -851,6 +886,87 @@ int ovgpu_get_state(ovgpu_ctx *c, double *P, double *clone_q_p, double *calib_q_
   if (intrinsics) HIPCHK(hipMemcpyAsync(intrinsics, c->intr.p, sizeof(double) * 8 * c->K, hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
   return OVGPU_OK;
+}
+
+
+// ---------------------------------------------------------------------------
+// UpdaterSLAM::update (UpdaterSLAM.cpp:253-479), GLOBAL_3D landmarks
+// ---------------------------------------------------------------------------
+int ovgpu_set_landmarks(ovgpu_ctx *c, const ovgpu_landmarks_view *lm) {
+  if (!c || !lm) return set_err(OVGPU_ERR_INVALID, "null argument");
+  if (!c->have_state) return set_err(OVGPU_ERR_NO_STATE, "ovgpu_set_state must precede ovgpu_set_landmarks");
+  if (lm->L < 0 || lm->L > 4096) return set_err(OVGPU_ERR_INVALID, "bad landmark count");
+  if (lm->L > 0 && (!lm->p_value || !lm->p_fej || !lm->cov_id)) return set_err(OVGPU_ERR_INVALID, "null landmark arrays");
+  if (c->dopt.feat_rep != OVGPU_REP_GLOBAL_3D) return set_err(OVGPU_ERR_INVALID, "SLAM landmarks are supported in the GLOBAL_3D representation only");
+  HIPCHK(hipSetDevice(c->device));
+  c->L = lm->L;
+  c->h_lm_cov.assign(lm->cov_id, lm->cov_id + lm->L);
+  c->h_lm_value.assign(lm->p_value, lm->p_value + 3 * (size_t)lm->L);
+  c->h_lm_fej.assign(lm->p_fej, lm->p_fej + 3 * (size_t)lm->L);
+  HIPCHK(c->lm_pos.reserve(3 * (size_t)std::max(lm->L, 1)));
+  HIPCHK(c->lm_cov.reserve(std::max(lm->L, 1)));
+  if (lm->L > 0) {
+    HIPCHK(upload(c->lm_pos.p, c->h_lm_value.data(), sizeof(double) * 3 * lm->L, c->stream));
+    HIPCHK(upload(c->lm_cov.p, c->h_lm_cov.data(), sizeof(int32_t) * lm->L, c->stream));
+  }
+  return build_columns(c); // synchronises; the feature batch has to be uploaded again (row counts and D changed)
+}
+
+__global__ void k_landmark_update(int L, const double *__restrict__ dx, const int32_t *__restrict__ lm_cov, double *lm_pos) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x; // Landmark::update for a 3-dof global position: additive (Landmark.h:80-89)
+  if (t < 3 * L) lm_pos[t] += dx[lm_cov[t / 3] + t % 3];
+}
+
+int ovgpu_slam_update(ovgpu_ctx *c, const int32_t *lm_index, int32_t *feat_status, double *chi2, double *chi2_thresh, double *dx, double *P_out,
+                      double *lm_out, ovgpu_update_stats *stats) {
+  if (!c) return set_err(OVGPU_ERR_INVALID, "null ctx");
+  if (c->L <= 0) return set_err(OVGPU_ERR_NO_STATE, "ovgpu_set_landmarks was never called");
+  if (!c->have_feats) return set_err(OVGPU_ERR_NO_STATE, "ovgpu_set_features must follow ovgpu_set_landmarks");
+  if (c->F > 0 && !lm_index) return set_err(OVGPU_ERR_INVALID, "null lm_index");
+  HIPCHK(hipSetDevice(c->device));
+  if (stats) std::memset(stats, 0, sizeof(*stats));
+  const int F = c->F;
+  hipStream_t s = c->stream;
+  // per-feature landmark data; a feature without measurements is dropped (UpdaterSLAM.cpp:289-291)
+  std::vector<double> pg(3 * (size_t)std::max(F, 1)), pf(3 * (size_t)std::max(F, 1));
+  std::vector<int32_t> flm(std::max(F, 1)), fcol(std::max(F, 1)), fcov(std::max(F, 1)), st(std::max(F, 1));
+  for (int f = 0; f < F; f++) {
+    const int l = lm_index[f];
+    if (l < 0 || l >= c->L) return set_err(OVGPU_ERR_INVALID, "lm_index out of range");
+    for (int i = 0; i < 3; i++) pg[3 * f + i] = c->h_lm_value[3 * l + i], pf[3 * f + i] = c->h_lm_fej[3 * l + i];
+    flm[f] = l, fcol[f] = c->h_lm_col[l], fcov[f] = c->h_lm_cov[l];
+    st[f] = (c->h_offsets[f + 1] - c->h_offsets[f] >= 1) ? OVGPU_FEAT_USED : OVGPU_FEAT_TOO_FEW_MEAS;
+  }
+  HIPCHK(c->pFej.reserve(3 * (size_t)std::max(F, 1)));
+  HIPCHK(c->feat_lm.reserve(std::max(F, 1)));
+  HIPCHK(c->feat_lmcol.reserve(std::max(F, 1)));
+  HIPCHK(c->feat_lmcov.reserve(std::max(F, 1)));
+  HIPCHK(c->given_status.reserve(std::max(F, 1)));
+  if (F > 0) {
+    HIPCHK(upload(c->pG.p, pg.data(), sizeof(double) * 3 * F, s));
+    HIPCHK(upload(c->pFej.p, pf.data(), sizeof(double) * 3 * F, s));
+    HIPCHK(upload(c->feat_lm.p, flm.data(), sizeof(int32_t) * F, s));
+    HIPCHK(upload(c->feat_lmcol.p, fcol.data(), sizeof(int32_t) * F, s));
+    HIPCHK(upload(c->feat_lmcov.p, fcov.data(), sizeof(int32_t) * F, s));
+    HIPCHK(upload(c->given_status.p, st.data(), sizeof(int32_t) * F, s));
+    HIPCHK(hipStreamSynchronize(s));
+  }
+  c->given_tri = true; // positions come from the state: no triangulation stage
+  int rc = enqueue_pipeline(c, STAGE_LOCAL | STAGE_EKF);
+  if (rc != OVGPU_OK) return rc;
+  hipLaunchKernelGGL(k_landmark_update, dim3((3 * c->L + 255) / 256), dim3(256), 0, s, c->L, c->dx.p, c->lm_cov.p, c->lm_pos.p);
+  HIPCHK(hipGetLastError());
+  rc = read_feature_outputs(c, feat_status, chi2, chi2_thresh, nullptr, stats);
+  if (rc != OVGPU_OK) return rc;
+  if (stats) { // SLAM rows: 2m per accepted feature
+    int64_t rows = 0;
+    if (feat_status)
+      for (int f = 0; f < F; f++)
+        if (feat_status[f] == OVGPU_FEAT_USED) rows += 2 * (c->h_offsets[f + 1] - c->h_offsets[f]);
+    stats->n_rows = (int32_t)rows;
+  }
+  if (lm_out) HIPCHK(hipMemcpyAsync(lm_out, c->lm_pos.p, sizeof(double) * 3 * c->L, hipMemcpyDeviceToHost, s));
+  return finish_update(c, dx, P_out, stats);
 }
 
 int ovgpu_triangle_len(ovgpu_ctx *c, int64_t *n_doubles) {

@@ -32,7 +32,7 @@ struct TriParams {
 };
 
 // column kinds of the canonical stacked-Jacobian column order
-enum { COL_CLONE = 0, COL_CALIB_POSE = 1, COL_CALIB_INTR = 2 };
+enum { COL_CLONE = 0, COL_CALIB_POSE = 1, COL_CALIB_INTR = 2, COL_LANDMARK = 3, COL_RESIDUAL = 4 };
 
 struct SysParams {
   int F, C, K, D, LD, N;
@@ -63,6 +63,12 @@ struct SysParams {
   int m_max;                // largest track length in the batch
   int row_stride;           // doubles per measurement in the LDS row store (48, or 72 with anchored reps)
   long long *dbg;           // profiling builds only (-DSYS_PROFILE)
+  // UpdaterSLAM::update mode (landmarks live in the state): no nullspace projection, gate on all 2m rows
+  int slam;
+  const double *p_fej;      // [3F] first-estimate position of the feature's landmark
+  const int32_t *feat_lm;   // [F] landmark index, first Jacobian column and covariance id of its 3 dof
+  const int32_t *feat_lmcol;
+  const int32_t *feat_lmcov;
   DevOptions opt;
 };
 

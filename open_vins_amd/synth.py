@@ -210,6 +210,11 @@ class Problem:
     cam_idx: np.ndarray
     p_FinG_true: np.ndarray
     meta: dict = field(default_factory=dict)
+    # SLAM snapshots (make_slam_problem): landmarks that live in the state, feature f observes landmark lm_index[f]
+    lm_value: np.ndarray | None = None
+    lm_fej: np.ndarray | None = None
+    lm_cov_id: np.ndarray | None = None
+    lm_index: np.ndarray | None = None
 
     @property
     def F(self):
@@ -433,6 +438,27 @@ def make_problem(cfg=2, rep=0, *, C=None, K=None, F=None, track="full", fisheye=
         p_FinG_true=np.asarray(pf_l, dtype=np.float64).reshape(-1, 3),
         meta=dict(track=track, fisheye=bool(fisheye), min_obs=min_obs),
     )
+
+
+def make_slam_problem(cfg=2, L=20, *, lm_noise=0.05, seed=None, **kw) -> Problem:
+    """A snapshot for UpdaterSLAM::update: L landmarks (GLOBAL_3D) live in the state behind the clones, each observed by
+    one track.  Estimate = truth + N(0, lm_noise), fej = estimate + N(0, lm_noise / 5); the prior covariance is rebuilt
+    for the larger state the same way make_problem does (landmark sigma = 2 lm_noise)."""
+    prob = make_problem(cfg, F=L, seed=seed, **kw)
+    rng = np.random.default_rng([prob.seed, 7])
+    N0 = prob.N
+    N = N0 + 3 * L
+    prob.lm_value = np.ascontiguousarray(prob.p_FinG_true + rng.normal(0, lm_noise, (L, 3)))
+    prob.lm_fej = np.ascontiguousarray(prob.lm_value + rng.normal(0, lm_noise / 5, (L, 3)))
+    prob.lm_cov_id = (N0 + 3 * np.arange(L)).astype(np.int32)
+    prob.lm_index = np.arange(L, dtype=np.int32)
+    sig = np.concatenate([state_sigmas(prob.C, prob.K), np.full(3 * L, 2 * lm_noise)])
+    G = np.tril(rng.normal(0, 1.0 / np.sqrt(N), (N, N)), -1)
+    Lc = sig[:, None] * (np.eye(N) + 0.1 * G)
+    P = Lc @ Lc.T
+    prob.P = np.ascontiguousarray(0.5 * (P + P.T))
+    prob.N = N
+    return prob
 
 
 def algorithmic_flops(prob: Problem):

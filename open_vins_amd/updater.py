@@ -127,6 +127,30 @@ class UpdaterMSCKF:
             out["P"] = Pm
         return out
 
+    # ---- UpdaterSLAM::update (UpdaterSLAM.cpp:253-479) ------------------
+    def set_slam_problem(self, prob):
+        """State, landmarks and tracks of a synth.make_slam_problem snapshot (order matters: the landmarks define the
+        Jacobian columns and the row count of every feature)."""
+        v = capi.Views(prob)
+        self._views = v
+        self.F, self.N, self.Cn, self.K = v.features.F, v.state.N, v.state.C, v.state.K
+        capi.check(self.lib.ovgpu_set_state(self._ctx, C.byref(v.state)), "ovgpu_set_state")
+        capi.check(self.lib.ovgpu_set_landmarks(self._ctx, C.byref(v.landmarks)), "ovgpu_set_landmarks")
+        capi.check(self.lib.ovgpu_set_features(self._ctx, C.byref(v.features)), "ovgpu_set_features")
+
+    def slam_update(self):
+        v = self._views
+        F, N, L = self.F, self.N, v.landmarks.L
+        out = dict(feat_status=np.zeros(F, np.int32), chi2=np.zeros(F), chi2_thresh=np.zeros(F), dx=np.zeros(N), P=np.zeros((N, N)),
+                   landmarks=np.zeros((L, 3)))
+        stats = capi.UpdateStats()
+        rc = self.lib.ovgpu_slam_update(self._ctx, _ip(v.lm_index), _ip(out["feat_status"]), _dp(out["chi2"]), _dp(out["chi2_thresh"]),
+                                        _dp(out["dx"]), _dp(out["P"]), _dp(out["landmarks"]), C.byref(stats))
+        out["rc"] = rc
+        capi.check(rc, "ovgpu_slam_update")
+        out["stats"] = stats.as_dict()
+        return out
+
     # ---- feature-sharded multi-GPU update (SURVEY.md §8e) ----------------
     def triangle_len(self):
         n = C.c_int64(0)

@@ -963,7 +963,7 @@ struct LocalCols {
 
 void feature_jacobian_full(const ovgpu_options &o, const ovgpu_state_view *st, const StateTables &T, const FeatMeas &fm, int rep,
                            const V3 &p_FinG_in, const V3 &p_FinA, int anchor_meas, const LocalCols &lc, double *H_f, int &nf,
-                           double *H_x, double *res) {
+                           double *H_x, double *res, const V3 *p_FinG_fej_in = nullptr) {
   const int m = fm.m1 - fm.m0;
   const int ncols = lc.ncols;
   int anchor_cam = -1, anchor_clone = -1;
@@ -973,7 +973,8 @@ void feature_jacobian_full(const ovgpu_options &o, const ovgpu_state_view *st, c
     anchor_clone = fm.clone_idx[anchor_meas];
     p_FinG = add(mulT(T.R_GtoI[anchor_clone], mulT(T.R_ItoC[anchor_cam], sub(p_FinA, T.p_IinC[anchor_cam]))), T.p_IinG[anchor_clone]);
   }
-  V3 p_FinG_fej = p_FinG; // :279-283 and UpdaterMSCKF.cpp:186-194 (fej == value for MSCKF features)
+  // :279-283 and UpdaterMSCKF.cpp:186-194 (fej == value for MSCKF features); SLAM landmarks carry their own (UpdaterSLAM.cpp:345-353)
+  V3 p_FinG_fej = p_FinG_fej_in ? *p_FinG_fej_in : p_FinG;
 
   RepJac rj = feature_jacobian_representation(o, T, rep, p_FinG, p_FinG_fej, p_FinA, anchor_cam, anchor_clone);
   nf = rj.nf;
@@ -1503,6 +1504,138 @@ int oracle_msckf_update_given(const ovgpu_options *opts, const ovgpu_state_view 
     stage_seconds[2] = t3 - t2;
     stage_seconds[3] = t4 - t3;
   }
+  return OVGPU_OK;
+}
+
+// ---------------------------------------------------------------------------
+// UpdaterSLAM::update — UpdaterSLAM.cpp:253-479, landmarks in GLOBAL_3D.
+// Column order: the canonical map of the MSCKF path with the landmarks merged in
+// by covariance id (the reference's is "first seen"; any order gives the same
+// update).  Unused variables keep zero columns.
+// ---------------------------------------------------------------------------
+int oracle_slam_update(const ovgpu_options *opts, const ovgpu_state_view *st, const ovgpu_landmarks_view *lm, const ovgpu_features_view *fv,
+                       const int32_t *lm_index, int32_t *feat_status, double *chi2_out, double *chi2_thresh_out, double *dx_out, double *P_out,
+                       double *lm_out, int32_t *D_out, int32_t *col_cov_out, double *H_out, double *res_out, int32_t *rows_out,
+                       ovgpu_update_stats *stats) {
+  const ovgpu_options &o = *opts;
+  const int F = fv->F, N = st->N, L = lm->L;
+  StateTables T = build_tables(st);
+  ColumnMap cm = build_column_map(o, st);
+  const double sigma2 = std::pow(o.sigma_pix, 2);
+  // merged column map: base variables + landmarks, sorted by covariance id
+  struct Ent { int cov, size, base_var, lmk; };
+  std::vector<Ent> ents;
+  {
+    int col = 0;
+    for (const VarRef &v : cm.vars) ents.push_back({v.cov_id, v.size, (int)(&v - &cm.vars[0]), -1}), col += v.size;
+    for (int l = 0; l < L; l++) ents.push_back({lm->cov_id[l], 3, -1, l});
+    std::stable_sort(ents.begin(), ents.end(), [](const Ent &a, const Ent &b) { return a.cov < b.cov; });
+  }
+  std::vector<int> base_col(cm.vars.size(), -1), lm_col(L, -1);
+  std::vector<int32_t> col_cov;
+  int Dt = 0;
+  for (const Ent &e : ents) {
+    if (e.base_var >= 0) base_col[e.base_var] = Dt;
+    else lm_col[e.lmk] = Dt;
+    for (int i = 0; i < e.size; i++) col_cov.push_back(e.cov + i);
+    Dt += e.size;
+  }
+  std::vector<int> l_calib(st->K, -1), l_intr(st->K, -1), l_clone(st->C, -1);
+  for (size_t vi = 0; vi < cm.vars.size(); vi++) {
+    const VarRef &v = cm.vars[vi];
+    if (v.kind == 0) l_calib[v.index] = base_col[vi];
+    if (v.kind == 1) l_intr[v.index] = base_col[vi];
+    if (v.kind == 2) l_clone[v.index] = base_col[vi];
+  }
+  LocalCols lc{Dt, l_calib.data(), l_intr.data(), l_clone.data()};
+
+  static std::vector<double> chi2_table;
+  if (chi2_table.empty()) {
+    chi2_table.resize(500, 0.0);
+    for (int i = 1; i < 500; i++) chi2_table[i] = chi2_quantile(i, 0.95);
+  }
+  size_t max_meas = 0;
+  for (int f = 0; f < F; f++) max_meas += 2 * (size_t)(fv->meas_offsets[f + 1] - fv->meas_offsets[f]);
+  std::vector<double> Hx_big(max_meas * (size_t)Dt, 0.0), res_big(max_meas, 0.0);
+  std::vector<double> H_f, H_x, res, HP, S;
+  std::vector<int> status(F, OVGPU_FEAT_USED);
+  std::vector<double> chi2v(F, NAN), thrv(F, NAN);
+  size_t ct_meas = 0;
+  int n_used = 0;
+  for (int f = 0; f < F; f++) {
+    FeatMeas fm{fv->meas_offsets[f], fv->meas_offsets[f + 1], fv->uvn, fv->uv, fv->clone_idx, fv->cam_idx};
+    const int m = fm.m1 - fm.m0;
+    if (m < 1) { // UpdaterSLAM.cpp:289-291
+      status[f] = OVGPU_FEAT_TOO_FEW_MEAS;
+      continue;
+    }
+    const int l = lm_index[f];
+    V3 pG{{lm->p_value[3 * l], lm->p_value[3 * l + 1], lm->p_value[3 * l + 2]}};
+    V3 pF{{lm->p_fej[3 * l], lm->p_fej[3 * l + 1], lm->p_fej[3 * l + 2]}};
+    V3 pA{{NAN, NAN, NAN}};
+    H_f.assign((size_t)2 * m * 3, 0.0);
+    H_x.assign((size_t)2 * m * Dt, 0.0);
+    res.assign(2 * m, 0.0);
+    int nf = 3;
+    feature_jacobian_full(o, st, T, fm, OVGPU_REP_GLOBAL_3D, pG, pA, -1, lc, H_f.data(), nf, H_x.data(), res.data(), &pF); // :369
+    for (int a = 0; a < 2 * m; a++) // :381-383  H_xf = [H_x | H_f], here the landmark columns of the big map
+      for (int b = 0; b < 3; b++) H_x[(size_t)a * Dt + lm_col[l] + b] = H_f[(size_t)a * 3 + b];
+    const int r = 2 * m;
+    // chi2 :390-396
+    HP.assign((size_t)r * Dt, 0.0);
+    for (int a = 0; a < r; a++)
+      for (int k = 0; k < Dt; k++) {
+        const double h = H_x[(size_t)a * Dt + k];
+        if (h == 0.0) continue;
+        const double *pk = st->P + (size_t)col_cov[k] * N;
+        for (int b = 0; b < Dt; b++) HP[(size_t)a * Dt + b] += h * pk[col_cov[b]];
+      }
+    S.assign((size_t)r * r, 0.0);
+    for (int a = 0; a < r; a++)
+      for (int b = 0; b <= a; b++) {
+        double sv = 0;
+        for (int k = 0; k < Dt; k++) sv += HP[(size_t)a * Dt + k] * H_x[(size_t)b * Dt + k];
+        S[(size_t)a * r + b] = sv, S[(size_t)b * r + a] = sv;
+      }
+    for (int a = 0; a < r; a++) S[(size_t)a * r + a] += sigma2;
+    double chi2 = NAN;
+    if (cholesky_lower(S.data(), r)) {
+      std::vector<double> y(res.begin(), res.end());
+      cholesky_solve(S.data(), r, y.data());
+      chi2 = 0;
+      for (int a = 0; a < r; a++) chi2 += res[a] * y[a];
+    }
+    const double chi2_check = (r < 500) ? chi2_table[r] : chi2_quantile(r, 0.95); // :399-405
+    chi2v[f] = chi2, thrv[f] = o.chi2_multipler * chi2_check;
+    if (chi2 > o.chi2_multipler * chi2_check) { // :410
+      status[f] = OVGPU_FEAT_CHI2_REJECTED;
+      continue;
+    }
+    std::memcpy(Hx_big.data() + ct_meas * (size_t)Dt, H_x.data(), (size_t)r * Dt * sizeof(double)); // :427-447
+    std::memcpy(res_big.data() + ct_meas, res.data(), r * sizeof(double));
+    ct_meas += r;
+    n_used++;
+  }
+  std::vector<double> P(st->P, st->P + (size_t)N * N), dx(N, 0.0);
+  ovgpu_update_stats stl;
+  std::memset(&stl, 0, sizeof(stl));
+  stl.n_used = n_used, stl.n_rows = (int)ct_meas, stl.D = Dt, stl.n_rows_comp = (int)ct_meas;
+  if (ct_meas >= 1) stl.status = ekf_update(P.data(), N, Hx_big.data(), res_big.data(), (int)ct_meas, Dt, col_cov.data(), sigma2, dx.data()); // :470
+  if (feat_status)
+    for (int f = 0; f < F; f++) feat_status[f] = status[f];
+  if (chi2_out) std::memcpy(chi2_out, chi2v.data(), F * sizeof(double));
+  if (chi2_thresh_out) std::memcpy(chi2_thresh_out, thrv.data(), F * sizeof(double));
+  if (dx_out) std::memcpy(dx_out, dx.data(), N * sizeof(double));
+  if (P_out) std::memcpy(P_out, P.data(), (size_t)N * N * sizeof(double));
+  if (lm_out)
+    for (int l = 0; l < L; l++)
+      for (int i = 0; i < 3; i++) lm_out[3 * l + i] = lm->p_value[3 * l + i] + dx[lm->cov_id[l] + i]; // Landmark::update, Landmark.h:80-89
+  if (D_out) *D_out = Dt;
+  if (col_cov_out) std::memcpy(col_cov_out, col_cov.data(), Dt * sizeof(int32_t));
+  if (H_out) std::memcpy(H_out, Hx_big.data(), ct_meas * (size_t)Dt * sizeof(double));
+  if (res_out) std::memcpy(res_out, res_big.data(), ct_meas * sizeof(double));
+  if (rows_out) *rows_out = (int32_t)ct_meas;
+  if (stats) *stats = stl;
   return OVGPU_OK;
 }
 

@@ -107,6 +107,16 @@ int oracle_msckf_update_given(const ovgpu_options *opts, const ovgpu_state_view 
                               double *H_comp, double *r_comp, int32_t *rows_comp,
                               ovgpu_update_stats *stats, double *stage_seconds);
 
+/* UpdaterSLAM::update (UpdaterSLAM.cpp:253-479) for GLOBAL_3D landmarks that live in the state: per feature the
+ * full Jacobian with the landmark's columns, the chi2 gate on all 2m rows (dof 2m), stacking and ONE EKFUpdate on
+ * the uncompressed stack (the reference does not compress here).  H_out / res_out (rows_max x D, rows_max = 2 M)
+ * return the stacked system for invariant checks; any output may be NULL.                                        */
+int oracle_slam_update(const ovgpu_options *opts, const ovgpu_state_view *st, const ovgpu_landmarks_view *lm,
+                       const ovgpu_features_view *fv, const int32_t *lm_index, int32_t *feat_status, double *chi2,
+                       double *chi2_thresh, double *dx, double *P_out, double *lm_out, int32_t *D_out,
+                       int32_t *col_cov_id, double *H_out, double *res_out, int32_t *rows_out,
+                       ovgpu_update_stats *stats);
+
 #ifdef __cplusplus
 }
 #endif

@@ -179,3 +179,30 @@ def msckf_update(opts, views, want_compressed=False, given=None):
         out["H_comp"] = Hc[: rows.value]
         out["r_comp"] = rc[: rows.value]
     return out
+
+
+def slam_update(opts, views, want_stack=False):
+    """UpdaterSLAM::update for GLOBAL_3D landmarks (oracle_slam_update); views must carry landmarks."""
+    lib = load()
+    F, N, M = views.features.F, views.state.N, views.features.M
+    L = views.landmarks.L
+    Dmax = 6 * views.state.C + 14 * views.state.K + 3 * L
+    out = dict(feat_status=np.zeros(F, dtype=np.int32), chi2=np.zeros(F), chi2_thresh=np.zeros(F), dx=np.zeros(N), P=np.zeros((N, N)),
+               landmarks=np.zeros((L, 3)))
+    D, rows = C.c_int32(0), C.c_int32(0)
+    cols = np.zeros(Dmax, dtype=np.int32)
+    H = np.zeros((2 * max(M, 1), Dmax)) if want_stack else None
+    r = np.zeros(2 * max(M, 1)) if want_stack else None
+    stats = capi.UpdateStats()
+    lib.oracle_slam_update.restype = C.c_int
+    rc = lib.oracle_slam_update(C.byref(opts), C.byref(views.state), C.byref(views.landmarks), C.byref(views.features), _pi(views.lm_index),
+                                _pi(out["feat_status"]), _p(out["chi2"]), _p(out["chi2_thresh"]), _p(out["dx"]), _p(out["P"]), _p(out["landmarks"]),
+                                C.byref(D), _pi(cols), _p(H) if want_stack else None, _p(r) if want_stack else None, C.byref(rows), C.byref(stats))
+    assert rc == 0
+    d, n = D.value, rows.value
+    out["D"], out["rows"], out["col_cov_id"] = d, n, cols[:d].copy()
+    out["stats"] = stats.as_dict()
+    if want_stack:
+        out["H"] = np.ascontiguousarray(H.reshape(-1)[: n * d].reshape(n, d))
+        out["r"] = r[:n].copy()
+    return out

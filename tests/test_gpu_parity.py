@@ -426,3 +426,42 @@ def test_cfg4_full_size_properties(Updater):
     assert _rel(P1, Pinf) < 1e-7
     assert _rel(out["dx"], Pinf @ H.T @ cmp["r"]) < 1e-6
     up.close()
+
+
+# --------------------------------------------------------------------------- UpdaterSLAM::update
+@pytest.mark.parametrize("kw", [dict(L=12), dict(L=3, K=1, C=12), dict(L=40), dict(L=12, track="ragged")])
+def test_slam_update_parity(Updater, oracle, kw):
+    """landmarks that live in the state (GLOBAL_3D) — Jacobian with the landmark's columns, gate on all
+    2m rows, stacking, EKF update.  The GPU compresses the stack before the update, the reference does not: same
+    posterior.  L = 12 gives D = 244 (16 column tiles), L = 40 gives D = 328 (generic TSQR path)."""
+    kw = dict(kw)
+    prob = synth.make_slam_problem(2, **kw)
+    opts = capi.default_options(chi2_multipler=1.0)
+    ref = oracle.slam_update(opts, capi.Views(prob))
+    up = Updater(opts)
+    up.set_slam_problem(prob)
+    out = up.slam_update()
+    assert np.array_equal(out["feat_status"], ref["feat_status"])
+    gate = np.isfinite(ref["chi2"])
+    np.testing.assert_allclose(out["chi2"][gate], ref["chi2"][gate], rtol=TOL_CHI2)
+    np.testing.assert_allclose(out["chi2_thresh"][gate], ref["chi2_thresh"][gate], rtol=1e-12)
+    assert out["stats"]["n_used"] == ref["stats"]["n_used"] and out["stats"]["n_rows"] == ref["stats"]["n_rows"]
+    assert _rel(out["dx"], ref["dx"]) < 1e-7
+    assert _rel(out["P"], ref["P"]) < 1e-8 and np.array_equal(out["P"], out["P"].T)
+    assert np.abs(out["landmarks"] - ref["landmarks"]).max() < 1e-9
+    up.close()
+
+
+def test_slam_then_msckf_on_one_context(Updater, oracle):
+    """ovgpu_set_state clears the landmarks: the same context goes back to the MSCKF rules afterwards."""
+    opts = capi.default_options(chi2_multipler=1.0)
+    up = Updater(opts)
+    up.set_slam_problem(synth.make_slam_problem(2, L=6))
+    up.slam_update()
+    prob = synth.make_problem(2, F=60)
+    ref = oracle.msckf_update(opts, capi.Views(prob))
+    up.set_problem(prob)
+    out = up.update()
+    assert np.array_equal(out["feat_status"], ref["feat_status"])
+    assert _rel(out["dx"], ref["dx"]) < 1e-7
+    up.close()
