@@ -429,11 +429,12 @@ def test_cfg4_full_size_properties(Updater):
 
 
 # --------------------------------------------------------------------------- UpdaterSLAM::update
-@pytest.mark.parametrize("kw", [dict(L=12), dict(L=3, K=1, C=12), dict(L=40), dict(L=12, track="ragged")])
+@pytest.mark.parametrize("kw", [dict(L=12), dict(L=3, K=1, C=12), dict(L=24), dict(L=12, track="ragged")])
 def test_slam_update_parity(Updater, oracle, kw):
     """landmarks that live in the state (GLOBAL_3D) — Jacobian with the landmark's columns, gate on all
     2m rows, stacking, EKF update.  The GPU compresses the stack before the update, the reference does not: same
-    posterior.  L = 12 gives D = 244 (16 column tiles), L = 40 gives D = 328 (generic TSQR path)."""
+    posterior.  L = 12 gives D = 244 (16 column tiles), L = 24 gives D = 280 (generic TSQR path; the oracle, like the reference, does not
+    compress the SLAM stack: its S is rows x rows, which is what makes this case slow on the CPU)."""
     kw = dict(kw)
     prob = synth.make_slam_problem(2, **kw)
     opts = capi.default_options(chi2_multipler=1.0)
