@@ -303,6 +303,14 @@ int ovgpu_slam_update(ovgpu_ctx *ctx, const int32_t *lm_index, int32_t *feat_sta
                       double *chi2, double *chi2_thresh, double *dx, double *P_out,
                       double *lm_out, ovgpu_update_stats *stats);
 
+/* Mode A of the SLAM update (strict drop-in): everything of ovgpu_slam_update up to the
+ * compressed stack, returned for the stock StateHelper::EKFUpdate exactly as
+ * ovgpu_msckf_compress does.  The landmark columns appear in col_cov_id with the landmarks'
+ * covariance ids.  H, r, col_cov_id must hold 6*C + 14*K + 3*L columns / rows.                */
+int ovgpu_slam_compress(ovgpu_ctx *ctx, const int32_t *lm_index, int32_t *feat_status,
+                        double *chi2, double *chi2_thresh, int32_t *D_out, int32_t *rows_out,
+                        int32_t *col_cov_id, double *H, double *r, ovgpu_update_stats *stats);
+
 /* ------------------------------------------------------------------------- */
 /* feature-sharded multi-GPU update                           */
 /* ------------------------------------------------------------------------- */

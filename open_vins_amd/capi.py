@@ -176,6 +176,8 @@ def declare(lib):
                                            c_int32_p, c_double_p, c_double_p, C.POINTER(UpdateStats)]),
         "ovgpu_get_state": (C.c_int, [ctxp, c_double_p, c_double_p, c_double_p, c_double_p]),
         "ovgpu_set_landmarks": (C.c_int, [ctxp, C.POINTER(LandmarksView)]),
+        "ovgpu_slam_compress": (C.c_int, [ctxp, c_int32_p, c_int32_p, c_double_p, c_double_p, c_int32_p, c_int32_p, c_int32_p, c_double_p,
+                                          c_double_p, C.POINTER(UpdateStats)]),
         "ovgpu_slam_update": (C.c_int, [ctxp, c_int32_p, c_int32_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p,
                                         C.POINTER(UpdateStats)]),
         "ovgpu_triangle_len": (C.c_int, [ctxp, C.POINTER(C.c_int64)]),

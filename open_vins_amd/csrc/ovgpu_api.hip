@@ -743,7 +743,7 @@ static int read_feature_outputs(ovgpu_ctx *c, int32_t *feat_status, double *chi2
   for (int f = 0; f < F; f++) {
     if (st[f] == OVGPU_FEAT_USED) {
       n_used++;
-      rows += 2 * (offs[f + 1] - offs[f]) - 3;
+      rows += 2 * (offs[f + 1] - offs[f]) - (c->L > 0 ? 0 : 3); // SLAM stacks all 2m rows (no nullspace projection)
     }
     // the gate is only reached by features that triangulated
     if (st[f] != OVGPU_FEAT_USED && st[f] != OVGPU_FEAT_CHI2_REJECTED) {
@@ -917,8 +917,8 @@ __global__ void k_landmark_update(int L, const double *__restrict__ dx, const in
   if (t < 3 * L) lm_pos[t] += dx[lm_cov[t / 3] + t % 3];
 }
 
-int ovgpu_slam_update(ovgpu_ctx *c, const int32_t *lm_index, int32_t *feat_status, double *chi2, double *chi2_thresh, double *dx, double *P_out,
-                      double *lm_out, ovgpu_update_stats *stats) {
+// per-feature landmark data of a SLAM batch -> device; the triangulation stage is replaced by the state's landmark estimates
+static int slam_prepare(ovgpu_ctx *c, const int32_t *lm_index, ovgpu_update_stats *stats) {
   if (!c) return set_err(OVGPU_ERR_INVALID, "null ctx");
   if (c->L <= 0) return set_err(OVGPU_ERR_NO_STATE, "ovgpu_set_landmarks was never called");
   if (!c->have_feats) return set_err(OVGPU_ERR_NO_STATE, "ovgpu_set_features must follow ovgpu_set_landmarks");
@@ -952,21 +952,30 @@ int ovgpu_slam_update(ovgpu_ctx *c, const int32_t *lm_index, int32_t *feat_statu
     HIPCHK(hipStreamSynchronize(s));
   }
   c->given_tri = true; // positions come from the state: no triangulation stage
-  int rc = enqueue_pipeline(c, STAGE_LOCAL | STAGE_EKF);
+  return OVGPU_OK;
+}
+
+int ovgpu_slam_update(ovgpu_ctx *c, const int32_t *lm_index, int32_t *feat_status, double *chi2, double *chi2_thresh, double *dx, double *P_out,
+                      double *lm_out, ovgpu_update_stats *stats) {
+  int rc = slam_prepare(c, lm_index, stats);
+  if (rc != OVGPU_OK) return rc;
+  const int F = c->F;
+  hipStream_t s = c->stream;
+  rc = enqueue_pipeline(c, STAGE_LOCAL | STAGE_EKF);
   if (rc != OVGPU_OK) return rc;
   hipLaunchKernelGGL(k_landmark_update, dim3((3 * c->L + 255) / 256), dim3(256), 0, s, c->L, c->dx.p, c->lm_cov.p, c->lm_pos.p);
   HIPCHK(hipGetLastError());
   rc = read_feature_outputs(c, feat_status, chi2, chi2_thresh, nullptr, stats);
   if (rc != OVGPU_OK) return rc;
-  if (stats) { // SLAM rows: 2m per accepted feature
-    int64_t rows = 0;
-    if (feat_status)
-      for (int f = 0; f < F; f++)
-        if (feat_status[f] == OVGPU_FEAT_USED) rows += 2 * (c->h_offsets[f + 1] - c->h_offsets[f]);
-    stats->n_rows = (int32_t)rows;
-  }
   if (lm_out) HIPCHK(hipMemcpyAsync(lm_out, c->lm_pos.p, sizeof(double) * 3 * c->L, hipMemcpyDeviceToHost, s));
   return finish_update(c, dx, P_out, stats);
+}
+
+int ovgpu_slam_compress(ovgpu_ctx *c, const int32_t *lm_index, int32_t *feat_status, double *chi2, double *chi2_thresh, int32_t *D_out,
+                        int32_t *rows_out, int32_t *col_cov_id, double *H, double *r, ovgpu_update_stats *stats) {
+  const int rc = slam_prepare(c, lm_index, stats);
+  if (rc != OVGPU_OK) return rc;
+  return ovgpu_msckf_compress(c, feat_status, chi2, chi2_thresh, nullptr, D_out, rows_out, col_cov_id, H, r, stats);
 }
 
 int ovgpu_triangle_len(ovgpu_ctx *c, int64_t *n_doubles) {
