@@ -151,6 +151,22 @@ class UpdaterMSCKF:
         out["stats"] = stats.as_dict()
         return out
 
+    def slam_compress(self):
+        """Mode A of the SLAM update: the compressed (H, r) incl. the landmark columns."""
+        v = self._views
+        F, L = self.F, v.landmarks.L
+        Dmax = 6 * self.Cn + 14 * self.K + 3 * L
+        out = dict(feat_status=np.zeros(F, np.int32), chi2=np.zeros(F), chi2_thresh=np.zeros(F))
+        H, r, cols = np.zeros((Dmax, Dmax)), np.zeros(Dmax), np.zeros(Dmax, np.int32)
+        D, rows = C.c_int32(0), C.c_int32(0)
+        stats = capi.UpdateStats()
+        capi.check(self.lib.ovgpu_slam_compress(self._ctx, _ip(v.lm_index), _ip(out["feat_status"]), _dp(out["chi2"]), _dp(out["chi2_thresh"]),
+                                                C.byref(D), C.byref(rows), _ip(cols), _dp(H), _dp(r), C.byref(stats)), "ovgpu_slam_compress")
+        d, n = D.value, rows.value
+        out.update(D=d, rows=n, H=np.ascontiguousarray(H.reshape(-1)[: n * d].reshape(n, d)), r=r[:n].copy(), col_cov_id=cols[:d].copy(),
+                   stats=stats.as_dict())
+        return out
+
     # ---- feature-sharded multi-GPU update (SURVEY.md §8e) ----------------
     def triangle_len(self):
         n = C.c_int64(0)

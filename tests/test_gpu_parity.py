@@ -466,3 +466,24 @@ def test_slam_then_msckf_on_one_context(Updater, oracle):
     assert np.array_equal(out["feat_status"], ref["feat_status"])
     assert _rel(out["dx"], ref["dx"]) < 1e-7
     up.close()
+
+
+def test_slam_mode_a_compressed_system(Updater, oracle):
+    """ovgpu_slam_compress: R^T R / R^T c of the compressed stack equal those of the reference's uncompressed SLAM stack,
+    landmark columns included, and feeding it to the oracle's EKFUpdate reproduces the oracle's posterior."""
+    prob = synth.make_slam_problem(2, L=10)
+    opts = capi.default_options(chi2_multipler=1.0)
+    ref = oracle.slam_update(opts, capi.Views(prob), want_stack=True)
+    up = Updater(opts)
+    up.set_slam_problem(prob)
+    cmp = up.slam_compress()
+    assert cmp["D"] == ref["D"] and np.array_equal(cmp["col_cov_id"], ref["col_cov_id"])
+    assert np.array_equal(cmp["feat_status"], ref["feat_status"])
+    H, r = cmp["H"], cmp["r"]
+    assert np.abs(np.tril(H, -1)).max() == 0.0
+    G, g = ref["H"].T @ ref["H"], ref["H"].T @ ref["r"]
+    assert np.linalg.norm(H.T @ H - G) / np.linalg.norm(G) < 1e-11
+    assert np.linalg.norm(H.T @ r - g) / np.linalg.norm(g) < 1e-10
+    st, P1, dx1 = oracle.ekf_update(prob.P, H, r, cmp["col_cov_id"], 1.0)
+    assert st == 0 and _rel(P1, ref["P"]) < 1e-8 and _rel(dx1, ref["dx"]) < 1e-7
+    up.close()
