@@ -1,0 +1,154 @@
+"""Closed-loop harness for BASELINE.json configs[0] (rpng_sim mono, 11-clone window, ~50 MSCKF features per update).
+
+NOT part of the product path: a small host-side sliding-window filter around the update under test, so that the same
+measurement stream can be run once with the CPU oracle as updater and once with the GPU library, and the two
+trajectories / ATE values compared ("ATE parity").  What is restated minimally:
+
+  * cloning: the newest clone is predicted from the previous one by the true relative motion plus noise
+    (R_new = dR R_last, p_new = p_last + dp): error-state Jacobian blockdiag(dR, I), noise Q — the role of
+    Propagator::propagate_and_clone + StateHelper::augment_clone (Propagator.cpp:76-137, StateHelper.cpp:579-616);
+  * first-estimate Jacobians: a clone's fej value is its estimate at cloning time and never changes;
+  * MSCKF feature selection: a track is used at the frame after its last observation (VioManager.cpp:366-429),
+    every observation lies inside the window;
+  * marginalisation of the oldest clone after the update (StateHelper.cpp:271-339): row / column deletion.
+
+The trajectory is the committed fixture tests/golden/sim_traj_window.txt (64 poses at 10 Hz of the rpng_sim B-spline).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import synth
+
+
+def _rot(q):
+    return synth.quat_2_rot(q)
+
+
+class Stream:
+    """Truth, tracks and noise of one closed-loop run; identical for every updater under test."""
+
+    def __init__(self, C=12, feats_per_frame=50, seed=7, sigma_px=1.0, q_theta=np.deg2rad(0.15), q_p=0.01):
+        rng = np.random.default_rng(seed)
+        traj = synth.load_traj_window()
+        self.T = traj.shape[0]
+        q = traj[:, 4:8].copy()
+        q[q[:, 3] < 0] *= -1
+        q /= np.linalg.norm(q, axis=1, keepdims=True)
+        self.truth = np.hstack([q, traj[:, 1:4]])
+        self.C = C
+        Tm = np.asarray(synth._T_IMU_CAM[0])
+        R_CtoI, p_CinI = Tm[:, :3], Tm[:, 3]
+        self.calib_true = np.concatenate([synth.rot_2_quat(R_CtoI.T), -R_CtoI.T @ p_CinI])
+        self.intr_true = np.asarray(synth._INTRINSICS[0], dtype=np.float64)
+        self.q_theta, self.q_p = q_theta, q_p
+        self.clone_noise = rng.normal(0, 1, (self.T, 6)) * np.array([q_theta] * 3 + [q_p] * 3)
+        self.init_noise = rng.normal(0, 1, (C, 6)) * np.array([0.01] * 3 + [0.03] * 3)
+        self.calib_noise = np.concatenate([rng.normal(0, 0.3 * 0.005, 3), rng.normal(0, 0.3 * 0.015, 3)])
+        self.intr_noise = np.concatenate([rng.normal(0, 0.3, 4), rng.normal(0, 0.3 * 0.0005, 4)])
+        # tracks: (frames a..b, pixel / normalised observations); used in the update of frame b + 1
+        R_ItoC, p_IinC = _rot(self.calib_true[:4]), self.calib_true[4:]
+        Rg = [_rot(self.truth[i, :4]) for i in range(self.T)]
+        self.tracks = {t: [] for t in range(self.T)}
+        for t_use in range(C - 1, self.T):
+            b = t_use - 1
+            made = 0
+            while made < feats_per_frame:
+                a = int(rng.integers(max(t_use - (C - 1), 0), b - 3))
+                j = int(rng.integers(a, b + 1))
+                u, v = rng.uniform(0, synth.IMG_W), rng.uniform(0, synth.IMG_H)
+                xn, yn = synth.radtan_undistort(self.intr_true, np.array([u]), np.array([v]))
+                depth = rng.uniform(5.0, 7.0)
+                p_C = depth * np.array([xn[0], yn[0], 1.0])
+                p_G = Rg[j].T @ (R_ItoC.T @ (p_C - p_IinC)) + self.truth[j, 4:]
+                obs = []
+                for i in range(a, b + 1):
+                    pc = R_ItoC @ (Rg[i] @ (p_G - self.truth[i, 4:])) + p_IinC
+                    if not (0.1 <= pc[2] <= 7.0):
+                        continue
+                    ud, vd = synth.radtan_distort(self.intr_true, np.float32(pc[0] / pc[2]).astype(np.float64), np.float32(pc[1] / pc[2]).astype(np.float64))
+                    if not (0 <= ud <= synth.IMG_W and 0 <= vd <= synth.IMG_H):
+                        continue
+                    un, vn = np.float32(ud + rng.normal(0, sigma_px)), np.float32(vd + rng.normal(0, sigma_px))
+                    xu, yu = synth.radtan_undistort(self.intr_true, np.array([float(un)]), np.array([float(vn)]))
+                    obs.append((i, un, vn, np.float32(xu[0]), np.float32(yu[0])))
+                if len(obs) >= 5:
+                    self.tracks[t_use].append(obs)
+                    made += 1
+
+
+def _compose(last_est, truth_last, truth_new):
+    """Newest clone predicted from the previous estimate by the TRUE relative motion."""
+    dR = _rot(truth_new[:4]) @ _rot(truth_last[:4]).T
+    q = synth.rot_2_quat(dR @ _rot(last_est[:4]))
+    if q[3] < 0:
+        q = -q
+    return np.concatenate([q, last_est[4:] + truth_new[4:] - truth_last[4:]]), dR
+
+
+def run(stream: Stream, update_fn=None):
+    """Runs the sliding-window filter over the stream.  update_fn(prob) -> dict(P, clone_q_p, calib_q_p, intrinsics,
+    feat_status); None = no updates (dead reckoning).  Returns per-frame estimates of the newest clone and the truth."""
+    C, K = stream.C, 1
+    base = 16 + 14 * K
+    sig = synth.state_sigmas(C, K)
+    sig[base:] = np.tile([0.01] * 3 + [0.03] * 3, C)
+    N = base + 6 * C
+    P = np.diag(sig ** 2)
+    frames = list(range(C))
+    clones = np.stack([synth.boxplus_pose(stream.truth[i], stream.init_noise[i]) for i in range(C)])
+    fej = clones.copy()
+    calib = synth.boxplus_pose(stream.calib_true, stream.calib_noise)[None, :]
+    intr = (stream.intr_true + stream.intr_noise)[None, :]
+    est, used = {frames[-1]: clones[-1].copy()}, {}
+    for t in range(C, stream.T):
+        # ---- clone the new pose (window grows to C + 1) ... then drop the oldest so that the update sees C clones
+        new, dR = _compose(clones[-1], stream.truth[t - 1], stream.truth[t])
+        new = synth.boxplus_pose(new, stream.clone_noise[t])
+        J = np.zeros((6, N))
+        J[:3, N - 6:N - 3] = dR
+        J[3:, N - 3:N] = np.eye(3)
+        Q = np.diag([stream.q_theta ** 2] * 3 + [stream.q_p ** 2] * 3)
+        P = np.block([[P, P @ J.T], [J @ P, J @ P @ J.T + Q]])
+        keep = np.r_[0:base, base + 6:N + 6]  # marginalise the oldest clone (StateHelper.cpp:271-339)
+        P = P[np.ix_(keep, keep)]
+        clones = np.vstack([clones[1:], new[None, :]])
+        fej = np.vstack([fej[1:], new[None, :]])
+        frames = frames[1:] + [t]
+        # ---- MSCKF update with the tracks that ended at t - 1
+        tracks = stream.tracks[t]
+        if update_fn is not None and tracks:
+            idx = {f: i for i, f in enumerate(frames)}
+            offs, uv, uvn, ci = [0], [], [], []
+            for obs in tracks:
+                obs = [o for o in obs if o[0] in idx]
+                for (f, un, vn, xu, yu) in obs:
+                    uv += [un, vn]
+                    uvn += [xu, yu]
+                    ci.append(idx[f])
+                offs.append(len(ci))
+            prob = synth.Problem(
+                cfg=1, seed=0, N=N, C=C, K=K, P=np.ascontiguousarray(P), clone_q_p=np.ascontiguousarray(clones),
+                clone_q_p_fej=np.ascontiguousarray(fej), clone_q_p_true=stream.truth[frames], clone_cov_id=(base + 6 * np.arange(C)).astype(np.int32),
+                calib_q_p=np.ascontiguousarray(calib), calib_q_p_true=stream.calib_true[None, :], intrinsics=np.ascontiguousarray(intr),
+                cam_is_fisheye=np.zeros(K, np.uint8), calib_cov_id=np.array([16], np.int32), intr_cov_id=np.array([22], np.int32),
+                meas_offsets=np.asarray(offs, np.int32), uv=np.asarray(uv, np.float32), uvn=np.asarray(uvn, np.float32),
+                clone_idx=np.asarray(ci, np.int32), cam_idx=np.zeros(len(ci), np.int32), p_FinG_true=np.zeros((len(tracks), 3)))
+            out = update_fn(prob)
+            P = 0.5 * (out["P"] + out["P"].T)
+            clones, calib, intr = out["clone_q_p"].copy(), out["calib_q_p"].copy(), out["intrinsics"].copy()
+            used[t] = int(np.sum(out["feat_status"] == 0))
+        est[t] = clones[-1].copy()
+    ts = sorted(est)
+    return dict(frames=np.array(ts), est=np.stack([est[t] for t in ts]), truth=stream.truth[ts], used=used)
+
+
+def ate(res):
+    """Absolute trajectory error of the newest-clone estimates, no alignment (estimate and truth share the frame in
+    simulation, ov_eval/src/calc/ResultTrajectory.cpp:82-110): (mean orientation error in deg, mean position error in m)."""
+    e_p = np.linalg.norm(res["est"][:, 4:] - res["truth"][:, 4:], axis=1)
+    e_o = []
+    for qe, qt in zip(res["est"][:, :4], res["truth"][:, :4]):
+        R = _rot(qe).T @ _rot(qt)
+        e_o.append(np.degrees(np.arccos(np.clip((np.trace(R) - 1) / 2, -1, 1))))
+    return float(np.mean(e_o)), float(np.mean(e_p))

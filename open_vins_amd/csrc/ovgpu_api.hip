@@ -119,7 +119,8 @@ struct ovgpu_ctx {
   int W = 1;
   int64_t rows_per_node = 128;
   DevBuf<QrTreeNode> tree_nodes; // merge tree of the pipelined launch, cached per leaf count
-  DevBuf<int32_t> tree_flags;    // [nodes] progress counters + [1] error flag
+  DevBuf<int32_t> tree_flags;    // [nodes] progress counters
+  DevBuf<int32_t> tree_err;      // [1] sticky: a node of the pipelined tree ran into its wait bound
   int tree_G = 0;
   bool tree_pipelined = true;
   int sys_grid = 1;
@@ -276,7 +277,7 @@ void ovgpu_destroy(ovgpu_ctx *c) {
   c->tab_clone.release(), c->tab_cam.release(), c->tab_cc.release();
   c->meas_offsets.release(), c->meas_cc.release(), c->uv.release(), c->uvn.release(), c->row_off.release();
   c->pA.release(), c->pG.release(), c->chi2.release(), c->chi2_thr.release(), c->anchor.release(), c->status.release();
-  c->chi2_table.release(), c->Hbig.release(), c->gate_ws.release(), c->Rws.release(), c->tree_nodes.release(), c->tree_flags.release(), c->Mt.release(), c->Aaug.release(), c->Yaug.release();
+  c->chi2_table.release(), c->Hbig.release(), c->gate_ws.release(), c->Rws.release(), c->tree_nodes.release(), c->tree_flags.release(), c->tree_err.release(), c->Mt.release(), c->Aaug.release(), c->Yaug.release();
   c->pFej.release(), c->lm_pos.release(), c->feat_lm.release(), c->feat_lmcol.release(), c->feat_lmcov.release(), c->lm_cov.release();
   c->dx.release(), c->flags.release(), c->given_status.release();
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -587,6 +588,10 @@ static int enqueue_merge_tree(ovgpu_ctx *c, int G) {
         }
       HIPCHK(c->tree_nodes.reserve(nodes.size()));
       HIPCHK(c->tree_flags.reserve(nodes.size() + 1));
+      if (!c->tree_err.p) {
+        HIPCHK(c->tree_err.reserve(1));
+        HIPCHK(hipMemsetAsync(c->tree_err.p, 0, sizeof(int32_t), c->stream));
+      }
       HIPCHK(hipMemcpyAsync(c->tree_nodes.p, nodes.data(), nodes.size() * sizeof(QrTreeNode), hipMemcpyHostToDevice, c->stream));
       HIPCHK(hipStreamSynchronize(c->stream)); // the host vector goes out of scope
       c->tree_G = G;
@@ -595,7 +600,7 @@ static int enqueue_merge_tree(ovgpu_ctx *c, int G) {
     HIPCHK(hipMemsetAsync(c->tree_flags.p, 0, sizeof(int32_t) * (n_nodes + 1), c->stream));
     QrTreeParams q;
     q.D = D, q.LD = LD, q.NT = NT, q.tri = c->Rws.p, q.nodes = c->tree_nodes.p;
-    q.progress = c->tree_flags.p, q.error = c->tree_flags.p + n_nodes, q.spin_limit = 4000000; // ~ seconds: only a lost node gets there
+    q.progress = c->tree_flags.p, q.error = c->tree_err.p, q.spin_limit = 4000000; // ~ seconds: only a lost node gets there
     if (NT <= 8) return launch_qr_tree<16>(c, n_nodes, q);
     if (NT <= 14) return launch_qr_tree<28>(c, n_nodes, q);
     return launch_qr_tree<32>(c, n_nodes, q);
@@ -817,6 +822,16 @@ int ovgpu_set_triangulation(ovgpu_ctx *c, const double *p_FinA, const double *p_
   return OVGPU_OK;
 }
 
+// The pipelined merge tree bounds every wait; a node that ran into the bound (it can only happen when the nodes were not
+// all resident) leaves a sticky flag behind.  Called after a stream synchronisation.
+static int check_tree_error(ovgpu_ctx *c) {
+  if (!c->tree_err.p) return OVGPU_OK;
+  int32_t e = 0;
+  HIPCHK(hipMemcpy(&e, c->tree_err.p, sizeof(e), hipMemcpyDeviceToHost));
+  if (e) return set_err(OVGPU_ERR_HIP, "TSQR merge tree: a node timed out waiting for its inputs (set OVGPU_TSQR_PIPELINE=0)");
+  return OVGPU_OK;
+}
+
 static int finish_update(ovgpu_ctx *c, double *dx, double *P_out, ovgpu_update_stats *stats) {
   hipStream_t s = c->stream;
   int32_t flags[4] = {0, 0, 0, 0};
@@ -830,7 +845,7 @@ static int finish_update(ovgpu_ctx *c, double *dx, double *P_out, ovgpu_update_s
   if (stats) stats->status = status;
   fill_times(c, stats);
   if (status != OVGPU_OK) return set_err(status, status == OVGPU_ERR_NOT_SPD ? "innovation covariance not SPD" : "negative covariance diagonal after the update");
-  return OVGPU_OK;
+  return check_tree_error(c);
 }
 
 int ovgpu_msckf_update(ovgpu_ctx *c, int32_t *feat_status, double *chi2, double *chi2_thresh, double *p_FinG, double *dx, double *P_out,
@@ -872,7 +887,7 @@ int ovgpu_msckf_compress(ovgpu_ctx *c, int32_t *feat_status, double *chi2, doubl
   if (rows_out) *rows_out = rows;
   fill_times(c, &local);
   if (stats) *stats = local;
-  return OVGPU_OK;
+  return check_tree_error(c);
 }
 
 int ovgpu_get_state(ovgpu_ctx *c, double *P, double *clone_q_p, double *calib_q_p, double *intrinsics) {
@@ -1076,7 +1091,7 @@ int ovgpu_synchronize(ovgpu_ctx *c) {
   if (!c) return set_err(OVGPU_ERR_INVALID, "null ctx");
   HIPCHK(hipSetDevice(c->device));
   HIPCHK(hipStreamSynchronize(c->stream));
-  return OVGPU_OK;
+  return check_tree_error(c);
 }
 
 uint64_t ovgpu_stream(ovgpu_ctx *c) { return c ? (uint64_t)(uintptr_t)c->stream : 0; }
