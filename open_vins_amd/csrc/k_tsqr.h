@@ -181,59 +181,44 @@ __device__ __forceinline__ void qr_apply_pair(double (&ya)[QH], double (&yb)[QH]
   }
 }
 
+// Streaming a pivot column from LDS: groups of 8 values, two groups of lookahead (16 values in flight cover the LDS
+// latency; the compiler barrier keeps the scheduler from hoisting every read to the top, which Y's VGPR footprint
+// cannot afford).  BODY(q, x) is expanded for q = 0 .. NX-1.
+#define QRT_STREAM(NX, XG, BODY)                                                            \
+  {                                                                                         \
+    double x0_[8], x1_[8], x2_[8];                                                          \
+    _Pragma("unroll") for (int i_ = 0; i_ < 8; i_++) x0_[i_] = (i_ < (NX)) ? (XG)[i_] : 0.0;  \
+    _Pragma("unroll") for (int i_ = 0; i_ < 8; i_++) x1_[i_] = (8 + i_ < (NX)) ? (XG)[8 + i_] : 0.0; \
+    _Pragma("unroll") for (int q_ = 0; q_ < (NX); q_ += 8) {                                \
+      _Pragma("unroll") for (int i_ = 0; i_ < 8; i_++) x2_[i_] = (q_ + 16 + i_ < (NX)) ? (XG)[q_ + 16 + i_] : 0.0; \
+      asm volatile("" ::: "memory");                                                        \
+      _Pragma("unroll") for (int i_ = 0; i_ < 8; i_++) {                                    \
+        if (q_ + i_ < (NX)) { BODY((q_ + i_), x0_[i_]) }                                    \
+      }                                                                                     \
+      _Pragma("unroll") for (int i_ = 0; i_ < 8; i_++) x0_[i_] = x1_[i_], x1_[i_] = x2_[i_]; \
+    }                                                                                       \
+  }
+
 // "split tile" flavour (triangle, panels >= NW): yb = rows {4 q + g}, q < QH, and ya = the QH quads after them of
 // ONE tile; NQ quads of the upper part can be non-zero.  The pivot column has QH + NQ values per lane: streamed
 // from LDS in groups of 8 with one group of lookahead, once per pass.
 template <int QH, int NQ>
 __device__ __forceinline__ void qr_apply_split(double (&ya)[QH], double (&yb)[QH], const double *xg, double u0, double taup, double beta, double *Rk,
                                                int col, bool own, int c, int k, int g) {
-  static_assert(QH % 8 == 0 || QH % 4 == 0, "");
   constexpr int NX = QH + NQ;
   double d = 0.0, e = 0.0;
-  {
-    double xa[8], xn[8];
-#pragma unroll
-    for (int i = 0; i < 8; i++) xa[i] = xg[i];
-#pragma unroll
-    for (int q = 0; q < NX; q += 8) {
-      if (q + 8 < NX) {
-#pragma unroll
-        for (int i = 0; i < 8; i++) xn[i] = (q + 8 + i < NX) ? xg[q + 8 + i] : 0.0;
-      }
-      asm volatile("" ::: "memory"); // the next group's reads are in flight while this one is consumed; no deeper hoisting
-#pragma unroll
-      for (int i = 0; i < 8; i += 2) {
-        const int q0 = q + i, q1 = q + i + 1;
-        if (q0 < NX) d = fma(xa[i], q0 < QH ? yb[q0 < QH ? q0 : 0] : ya[q0 >= QH ? q0 - QH : 0], d);
-        if (q1 < NX) e = fma(xa[i + 1], q1 < QH ? yb[q1 < QH ? q1 : 0] : ya[q1 >= QH ? q1 - QH : 0], e);
-      }
-#pragma unroll
-      for (int i = 0; i < 8; i++) xa[i] = xn[i];
-    }
-  }
+#define QRT_B1(q, x)                                                                           \
+  if ((q) < QH) { if ((q) & 1) e = fma(x, yb[(q) < QH ? (q) : 0], e); else d = fma(x, yb[(q) < QH ? (q) : 0], d); } \
+  else { if ((q) & 1) e = fma(x, ya[(q) >= QH ? (q) - QH : 0], e); else d = fma(x, ya[(q) >= QH ? (q) - QH : 0], d); }
+  QRT_STREAM(NX, xg, QRT_B1)
+#undef QRT_B1
   const double cf = qr_coef(gsum4(d + e), u0, taup, beta, Rk, col, own, c, k, g);
   asm volatile("" ::: "memory");
-  {
-    double xa[8], xn[8];
-#pragma unroll
-    for (int i = 0; i < 8; i++) xa[i] = xg[i];
-#pragma unroll
-    for (int q = 0; q < NX; q += 8) {
-      if (q + 8 < NX) {
-#pragma unroll
-        for (int i = 0; i < 8; i++) xn[i] = (q + 8 + i < NX) ? xg[q + 8 + i] : 0.0;
-      }
-      asm volatile("" ::: "memory");
-#pragma unroll
-      for (int i = 0; i < 8; i++) {
-        const int q0 = q + i;
-        if (q0 < QH) yb[q0 < QH ? q0 : 0] = fma(-cf, xa[i], yb[q0 < QH ? q0 : 0]);
-        else if (q0 < NX) ya[q0 >= QH && q0 < NX ? q0 - QH : 0] = fma(-cf, xa[i], ya[q0 >= QH && q0 < NX ? q0 - QH : 0]);
-      }
-#pragma unroll
-      for (int i = 0; i < 8; i++) xa[i] = xn[i];
-    }
-  }
+#define QRT_B2(q, x)                                                              \
+  if ((q) < QH) yb[(q) < QH ? (q) : 0] = fma(-cf, x, yb[(q) < QH ? (q) : 0]);     \
+  else ya[(q) >= QH ? (q) - QH : 0] = fma(-cf, x, ya[(q) >= QH ? (q) - QH : 0]);
+  QRT_STREAM(NX, xg, QRT_B2)
+#undef QRT_B2
 }
 
 // One column step, first half (owner wave only): |y_k|^2 -> reflector scalars, raw pivot column -> LDS.
