@@ -312,6 +312,26 @@ int ovgpu_slam_compress(ovgpu_ctx *ctx, const int32_t *lm_index, int32_t *feat_s
                         int32_t *col_cov_id, double *H, double *r, ovgpu_update_stats *stats);
 
 /* ------------------------------------------------------------------------- */
+/* the two helpers of the path as standalone calls (UpdaterZeroVelocity.cpp:183-321 */
+/* and any other updater stack a dense system and call them this way)         */
+/* ------------------------------------------------------------------------- */
+
+/* UpdaterHelper::measurement_compress_inplace (UpdaterHelper.cpp:456-487): (rows x cols) H and
+ * res (host, row-major) -> the upper-triangular (cols x cols) system with the same H^T H and
+ * H^T res; rows <= cols is returned unchanged (:459-460).  H_out holds min(rows, cols) x cols.     */
+int ovgpu_measurement_compress(ovgpu_ctx *ctx, int rows, int cols, const double *H,
+                               const double *res, double *H_out, double *res_out,
+                               int32_t *rows_out);
+
+/* StateHelper::EKFUpdate (StateHelper.cpp:116-197) with R = sigma2 * I on the RESIDENT
+ * covariance and pose tables: column j of H (rows x cols, host) is the covariance index
+ * col_cov_id[j].  dx [N] and P_out [N*N] as in ovgpu_msckf_update.  Re-upload the feature batch
+ * (ovgpu_set_features) before the next feature update: the compression buffers are shared.   */
+int ovgpu_ekf_update(ovgpu_ctx *ctx, int rows, int cols, const int32_t *col_cov_id,
+                     const double *H, const double *res, double sigma2, double *dx,
+                     double *P_out);
+
+/* ------------------------------------------------------------------------- */
 /* feature-sharded multi-GPU update                           */
 /* ------------------------------------------------------------------------- */
 

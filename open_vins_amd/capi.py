@@ -175,6 +175,8 @@ def declare(lib):
         "ovgpu_msckf_compress": (C.c_int, [ctxp, c_int32_p, c_double_p, c_double_p, c_double_p, c_int32_p, c_int32_p,
                                            c_int32_p, c_double_p, c_double_p, C.POINTER(UpdateStats)]),
         "ovgpu_get_state": (C.c_int, [ctxp, c_double_p, c_double_p, c_double_p, c_double_p]),
+        "ovgpu_measurement_compress": (C.c_int, [ctxp, C.c_int, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p, c_int32_p]),
+        "ovgpu_ekf_update": (C.c_int, [ctxp, C.c_int, C.c_int, c_int32_p, c_double_p, c_double_p, C.c_double, c_double_p, c_double_p]),
         "ovgpu_set_landmarks": (C.c_int, [ctxp, C.POINTER(LandmarksView)]),
         "ovgpu_slam_compress": (C.c_int, [ctxp, c_int32_p, c_int32_p, c_double_p, c_double_p, c_int32_p, c_int32_p, c_int32_p, c_double_p,
                                           c_double_p, C.POINTER(UpdateStats)]),

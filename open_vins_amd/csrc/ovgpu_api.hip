@@ -432,6 +432,23 @@ int ovgpu_reset_state(ovgpu_ctx *c) {
   return launch_build_tables(c);
 }
 
+// Sizes the stacked-system buffer and the TSQR leaf layout for c->rows_total rows of c->LD columns:
+// one leaf node per CU when there are enough rows, every node a whole number of 128-row appends.
+static int configure_tsqr(ovgpu_ctx *c) {
+  const int D = c->D, LD = c->LD;
+  HIPCHK(c->Hbig.reserve((size_t)std::max<int64_t>(c->rows_total, 1) * LD));
+  const int64_t blk = 4 * QR_LEAF_Q;
+  const char *wenv = std::getenv("OVGPU_TSQR_W");
+  const int64_t target = std::max<int64_t>(1, wenv ? std::atoll(wenv) : c->num_cu);
+  int64_t rpn = (c->rows_total + target - 1) / target;
+  rpn = std::max<int64_t>(blk, ((rpn + blk - 1) / blk) * blk);
+  if (rpn < 2 * blk && c->rows_total > 2 * blk) rpn = 2 * blk; // a leaf shorter than D rows compresses nothing
+  c->rows_per_node = rpn;
+  c->W = (int)std::max<int64_t>(1, (c->rows_total + rpn - 1) / rpn);
+  HIPCHK(c->Rws.reserve((size_t)std::max(c->W, 16) * D * LD));
+  return OVGPU_OK;
+}
+
 int ovgpu_set_features(ovgpu_ctx *c, const ovgpu_features_view *fv) {
   if (!c || !fv) return set_err(OVGPU_ERR_INVALID, "null argument");
   if (!c->have_state) return set_err(OVGPU_ERR_NO_STATE, "ovgpu_set_state must precede ovgpu_set_features");
@@ -501,22 +518,10 @@ int ovgpu_set_features(ovgpu_ctx *c, const ovgpu_features_view *fv) {
     c->gate_ws_stride = 0;
   }
   // ---- stacked system and TSQR accumulators
-  const int D = c->D, LD = c->LD;
-  HIPCHK(c->Hbig.reserve((size_t)std::max<int64_t>(c->rows_total, 1) * LD));
-  // leaf nodes of the TSQR: one per CU when there are enough rows, every node a whole number of 128-row appends
-  int W = 1;
   {
-    const int64_t blk = 4 * QR_LEAF_Q;
-    const char *wenv = std::getenv("OVGPU_TSQR_W");
-    const int64_t target = std::max<int64_t>(1, wenv ? std::atoll(wenv) : c->num_cu);
-    int64_t rpn = (c->rows_total + target - 1) / target;
-    rpn = std::max<int64_t>(blk, ((rpn + blk - 1) / blk) * blk);
-    if (rpn < 2 * blk && c->rows_total > 2 * blk) rpn = 2 * blk; // a leaf shorter than D rows compresses nothing
-    c->rows_per_node = rpn;
-    W = (int)std::max<int64_t>(1, (c->rows_total + rpn - 1) / rpn);
+    const int rct = configure_tsqr(c);
+    if (rct != OVGPU_OK) return rct;
   }
-  c->W = W;
-  HIPCHK(c->Rws.reserve((size_t)std::max(W, 16) * D * LD));
 
   hipStream_t s = c->stream;
   HIPCHK(upload(c->meas_offsets.p, fv->meas_offsets, sizeof(int32_t) * (F + 1), s));
@@ -659,11 +664,11 @@ static int enqueue_compress(ovgpu_ctx *c) {
   return enqueue_merge_tree(c, W);
 }
 
-static int enqueue_ekf(ovgpu_ctx *c) {
+static int enqueue_ekf(ovgpu_ctx *c, const int32_t *col_cov_dev = nullptr, double sigma2 = -1.0) {
   EkfParams p;
   p.N = c->N, p.D = c->D, p.LD = c->LD, p.LA = c->D + c->N + 1;
-  p.R = c->Rws.p, p.col_cov = c->col_cov.p, p.P = c->P.p, p.Mt = c->Mt.p, p.A = c->Aaug.p, p.Y = c->Yaug.p, p.dx = c->dx.p, p.flags = c->flags.p;
-  p.sigma2 = c->dopt.sigma_pix_sq;
+  p.R = c->Rws.p, p.col_cov = col_cov_dev ? col_cov_dev : c->col_cov.p, p.P = c->P.p, p.Mt = c->Mt.p, p.A = c->Aaug.p, p.Y = c->Yaug.p, p.dx = c->dx.p, p.flags = c->flags.p;
+  p.sigma2 = sigma2 >= 0.0 ? sigma2 : c->dopt.sigma_pix_sq;
   hipStream_t s = c->stream;
   HIPCHK(hipMemsetAsync(c->flags.p, 0, 4 * sizeof(int32_t), s));
   const int tm = (p.D + 15) / 16, tn = (p.N + 15) / 16;
@@ -991,6 +996,96 @@ int ovgpu_slam_compress(ovgpu_ctx *c, const int32_t *lm_index, int32_t *feat_sta
   const int rc = slam_prepare(c, lm_index, stats);
   if (rc != OVGPU_OK) return rc;
   return ovgpu_msckf_compress(c, feat_status, chi2, chi2_thresh, nullptr, D_out, rows_out, col_cov_id, H, r, stats);
+}
+
+
+// ---------------------------------------------------------------------------
+// UpdaterHelper::measurement_compress_inplace and StateHelper::EKFUpdate as standalone calls on a
+// caller-supplied dense system (UpdaterZeroVelocity.cpp:183-321 uses them this way)
+// ---------------------------------------------------------------------------
+struct DenseJob { // temporarily re-targets the context's compression buffers at a (rows x cols) system
+  ovgpu_ctx *c;
+  int D, LD, W;
+  int64_t rows_total, rows_per_node;
+  explicit DenseJob(ovgpu_ctx *ctx) : c(ctx), D(ctx->D), LD(ctx->LD), W(ctx->W), rows_total(ctx->rows_total), rows_per_node(ctx->rows_per_node) {}
+  ~DenseJob() { c->D = D, c->LD = LD, c->W = W, c->rows_total = rows_total, c->rows_per_node = rows_per_node; }
+};
+
+// uploads [H | res] and runs the TSQR; the triangle ends in c->Rws (cols x (cols + 1))
+static int dense_compress(ovgpu_ctx *c, int rows, int cols, const double *H, const double *res) {
+  if (rows < 0 || cols <= 0 || cols + 1 > 512) return set_err(OVGPU_ERR_INVALID, "bad system size");
+  if (rows > 0 && (!H || !res)) return set_err(OVGPU_ERR_INVALID, "null system");
+  HIPCHK(hipSetDevice(c->device));
+  c->D = cols, c->LD = cols + 1, c->rows_total = rows;
+  int rc = configure_tsqr(c);
+  if (rc != OVGPU_OK) return rc;
+  std::vector<double> st((size_t)std::max(rows, 1) * c->LD);
+  for (int i = 0; i < rows; i++) {
+    std::memcpy(&st[(size_t)i * c->LD], H + (size_t)i * cols, sizeof(double) * cols);
+    st[(size_t)i * c->LD + cols] = res[i];
+  }
+  if (rows > 0) HIPCHK(upload(c->Hbig.p, st.data(), sizeof(double) * (size_t)rows * c->LD, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (rows == 0) {
+    HIPCHK(hipMemsetAsync(c->Rws.p, 0, sizeof(double) * (size_t)cols * c->LD, c->stream));
+    return OVGPU_OK;
+  }
+  return enqueue_compress(c);
+}
+
+int ovgpu_measurement_compress(ovgpu_ctx *c, int rows, int cols, const double *H, const double *res, double *H_out, double *res_out, int32_t *rows_out) {
+  if (!c) return set_err(OVGPU_ERR_INVALID, "null ctx");
+  if (rows <= cols) { // UpdaterHelper.cpp:459-460: nothing to compress
+    if (H_out && H && H_out != H) std::memcpy(H_out, H, sizeof(double) * (size_t)rows * cols);
+    if (res_out && res && res_out != res) std::memcpy(res_out, res, sizeof(double) * rows);
+    if (rows_out) *rows_out = rows;
+    return OVGPU_OK;
+  }
+  DenseJob job(c);
+  int rc = dense_compress(c, rows, cols, H, res);
+  if (rc != OVGPU_OK) return rc;
+  const int LD = cols + 1;
+  std::vector<double> tri((size_t)cols * LD);
+  HIPCHK(hipMemcpyAsync(tri.data(), c->Rws.p, sizeof(double) * tri.size(), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  for (int i = 0; i < cols; i++) {
+    if (H_out) std::memcpy(H_out + (size_t)i * cols, &tri[(size_t)i * LD], sizeof(double) * cols);
+    if (res_out) res_out[i] = tri[(size_t)i * LD + cols];
+  }
+  if (rows_out) *rows_out = cols; // :481-486
+  return check_tree_error(c);
+}
+
+int ovgpu_ekf_update(ovgpu_ctx *c, int rows, int cols, const int32_t *col_cov_id, const double *H, const double *res, double sigma2, double *dx,
+                     double *P_out) {
+  if (!c) return set_err(OVGPU_ERR_INVALID, "null ctx");
+  if (!c->have_state) return set_err(OVGPU_ERR_NO_STATE, "ovgpu_set_state was never called");
+  if (!col_cov_id || sigma2 < 0.0) return set_err(OVGPU_ERR_INVALID, "bad argument");
+  for (int i = 0; i < cols; i++)
+    if (col_cov_id[i] < 0 || col_cov_id[i] >= c->N) return set_err(OVGPU_ERR_INVALID, "column id outside the covariance");
+  int rc;
+  {
+    DenseJob job(c);
+    // the EKF kernels take an upper-triangular system: any (rows x cols) stack goes through the QR first (an orthogonal
+    // transform of the rows changes neither K res nor K H P; the reference's EKFUpdate uses H as given)
+    rc = dense_compress(c, rows, cols, H, res);
+    if (rc != OVGPU_OK) return rc;
+    DevBuf<int32_t> cols_dev;
+    HIPCHK(cols_dev.reserve(cols));
+    HIPCHK(upload(cols_dev.p, col_cov_id, sizeof(int32_t) * cols, c->stream));
+    HIPCHK(c->Mt.reserve((size_t)cols * c->N));
+    HIPCHK(c->Aaug.reserve((size_t)cols * (cols + c->N + 1)));
+    HIPCHK(c->Yaug.reserve((size_t)cols * (cols + c->N + 1)));
+    rc = enqueue_ekf(c, cols_dev.p, sigma2);
+    if (rc == OVGPU_OK) rc = finish_update(c, dx, P_out, nullptr);
+    cols_dev.release();
+  }
+  // the context's own workspaces are sized by its column map again
+  HIPCHK(c->Mt.reserve((size_t)c->D * c->N));
+  HIPCHK(c->Aaug.reserve((size_t)c->D * (c->D + c->N + 1)));
+  HIPCHK(c->Yaug.reserve((size_t)c->D * (c->D + c->N + 1)));
+  c->have_feats = false; // Hbig / Rws were re-targeted: upload the feature batch again before the next feature update
+  return rc;
 }
 
 int ovgpu_triangle_len(ovgpu_ctx *c, int64_t *n_doubles) {

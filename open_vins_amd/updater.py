@@ -167,6 +167,27 @@ class UpdaterMSCKF:
                    stats=stats.as_dict())
         return out
 
+    # ---- standalone helpers (UpdaterHelper::measurement_compress_inplace, StateHelper::EKFUpdate) ----
+    def measurement_compress(self, H, res):
+        H = np.ascontiguousarray(H, dtype=np.float64)
+        res = np.ascontiguousarray(res, dtype=np.float64)
+        rows, cols = H.shape
+        n = min(rows, cols)
+        Ho, ro = np.zeros((max(n, 1), cols)), np.zeros(max(n, 1))
+        rows_out = C.c_int32(0)
+        capi.check(self.lib.ovgpu_measurement_compress(self._ctx, rows, cols, _dp(H), _dp(res), _dp(Ho), _dp(ro), C.byref(rows_out)),
+                   "ovgpu_measurement_compress")
+        return Ho[: rows_out.value], ro[: rows_out.value]
+
+    def ekf_update(self, H, res, col_cov_id, sigma2):
+        H = np.ascontiguousarray(H, dtype=np.float64)
+        res = np.ascontiguousarray(res, dtype=np.float64)
+        cols = np.ascontiguousarray(col_cov_id, dtype=np.int32)
+        dx, P = np.zeros(self.N), np.zeros((self.N, self.N))
+        capi.check(self.lib.ovgpu_ekf_update(self._ctx, H.shape[0], H.shape[1], _ip(cols), _dp(H), _dp(res), float(sigma2), _dp(dx), _dp(P)),
+                   "ovgpu_ekf_update")
+        return dx, P
+
     # ---- feature-sharded multi-GPU update ----------------
     def triangle_len(self):
         n = C.c_int64(0)

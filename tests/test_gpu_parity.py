@@ -487,3 +487,47 @@ def test_slam_mode_a_compressed_system(Updater, oracle):
     st, P1, dx1 = oracle.ekf_update(prob.P, H, r, cmp["col_cov_id"], 1.0)
     assert st == 0 and _rel(P1, ref["P"]) < 1e-8 and _rel(dx1, ref["dx"]) < 1e-7
     up.close()
+
+
+# --------------------------------------------------------------------------- the helpers as standalone calls
+@pytest.mark.parametrize("shape", [(500, 60), (3000, 208), (40, 90), (700, 300)])
+def test_standalone_measurement_compress(Updater, oracle, shape):
+    """UpdaterHelper::measurement_compress_inplace on a caller-supplied dense system (the ZUPT updater's use): upper
+    triangular, same H^T H / H^T r as the oracle's Givens sweep; rows <= cols comes back unchanged (UpdaterHelper.cpp:459)."""
+    rows, cols = shape
+    rng = np.random.default_rng(rows + cols)
+    H = rng.normal(size=(rows, cols)) * rng.uniform(0.1, 30.0, cols)
+    r = rng.normal(size=rows)
+    up = Updater(capi.default_options())
+    Hc, rc = up.measurement_compress(H, r)
+    up.close()
+    Ho, ro = oracle.measurement_compress(H.copy(), r.copy())
+    assert Hc.shape == Ho.shape
+    if rows <= cols:
+        np.testing.assert_array_equal(Hc, H)
+        np.testing.assert_array_equal(rc, r)
+        return
+    assert np.abs(np.tril(Hc, -1)).max() == 0.0
+    G = Ho.T @ Ho
+    assert np.linalg.norm(Hc.T @ Hc - G) / np.linalg.norm(G) < 1e-12
+    assert np.linalg.norm(Hc.T @ rc - Ho.T @ ro) / np.linalg.norm(Ho.T @ ro) < 1e-11
+
+
+def test_standalone_ekf_update(Updater, oracle):
+    """StateHelper::EKFUpdate on the resident state with an arbitrary dense system — here one that touches the IMU block
+    and the time offset, which the feature Jacobians never do — against the oracle's EKFUpdate."""
+    prob = synth.make_problem(2, F=5)
+    rng = np.random.default_rng(3)
+    cols = np.concatenate([np.arange(0, 16), prob.clone_cov_id[-1] + np.arange(6)]).astype(np.int32)  # IMU 15, dt, newest clone
+    H = rng.normal(size=(9, cols.size))
+    r = rng.normal(size=9) * 0.01
+    st, P1, dx1 = oracle.ekf_update(prob.P, H, r, cols, 1e-4)
+    assert st == 0
+    up = Updater(capi.default_options())
+    up.set_problem(prob)
+    dx, P = up.ekf_update(H, r, cols, 1e-4)
+    assert _rel(dx, dx1) < 1e-9 and _rel(P, P1) < 1e-10 and np.array_equal(P, P.T)
+    # the resident tables took the correction: the newest clone moved by its part of dx
+    got = up.get_state(P=False)["clone_q_p"][-1, 4:]
+    np.testing.assert_allclose(got, prob.clone_q_p[-1, 4:] + dx1[prob.clone_cov_id[-1] + 3: prob.clone_cov_id[-1] + 6], atol=1e-12)
+    up.close()
