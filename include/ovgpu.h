@@ -212,6 +212,13 @@ int ovgpu_set_features(ovgpu_ctx *ctx, const ovgpu_features_view *fv);
 int ovgpu_triangulate(ovgpu_ctx *ctx, double *p_FinA, double *p_FinG,
                       int32_t *anchor_meas, int32_t *status);
 
+/* The direct input of ov_core::FeatureInitializer: the camera pose of every (camera, clone) pair, i.e. the
+ * clonesCAM argument of single_triangulation / single_gaussnewton (FeatureInitializer.h:100-122, ClonePose :51-82)
+ * as the caller computed it, instead of a state snapshot.  R_GtoC [K*C*9] row-major, p_CinG [K*C*3], pair (k, c) at
+ * index k*C + c.  After this call only ovgpu_set_features and ovgpu_triangulate are usable (no covariance is
+ * resident) until the next ovgpu_set_state.                                                                      */
+int ovgpu_set_camera_poses(ovgpu_ctx *ctx, int C, int K, const double *R_GtoC, const double *p_CinG);
+
 /* Supplies the feature positions instead of triangulating them: the updates that
  * follow (until the next ovgpu_set_features) skip the triangulation stage and use
  * these values.  This is the situation of UpdaterSLAM::update, where the landmark

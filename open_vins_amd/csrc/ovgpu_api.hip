@@ -78,6 +78,7 @@ struct ovgpu_ctx {
 
   // ---- state
   bool have_state = false;
+  bool poses_only = false; // ovgpu_set_camera_poses: only the FeatureInitializer entry points are usable
   int N = 0, C = 0, K = 0, D = 0, LD = 0;
   DevBuf<double> P, P0, clone_qp, clone_qp0, clone_fej, calib_qp, calib_qp0, intr, intr0;
   DevBuf<uint8_t> fisheye;
@@ -416,14 +417,14 @@ int ovgpu_set_state(ovgpu_ctx *c, const ovgpu_state_view *st) {
   HIPCHK(hipMemcpyAsync(c->intr0.p, c->intr.p, sizeof(double) * 8 * K, hipMemcpyDeviceToDevice, s));
   int rc = launch_build_tables(c);
   if (rc != OVGPU_OK) return rc;
-  c->have_state = true;
+  c->have_state = true, c->poses_only = false;
   c->have_feats = false; // workspaces depend on D
   return OVGPU_OK;
 }
 
 int ovgpu_reset_state(ovgpu_ctx *c) {
   if (!c) return set_err(OVGPU_ERR_INVALID, "null ctx");
-  if (!c->have_state) return set_err(OVGPU_ERR_NO_STATE, "ovgpu_set_state was never called");
+  if (!c->have_state || c->poses_only) return set_err(OVGPU_ERR_NO_STATE, "ovgpu_set_state was never called");
   hipStream_t s = c->stream;
   HIPCHK(hipMemcpyAsync(c->P.p, c->P0.p, sizeof(double) * c->N * c->N, hipMemcpyDeviceToDevice, s));
   HIPCHK(hipMemcpyAsync(c->clone_qp.p, c->clone_qp0.p, sizeof(double) * 7 * c->C, hipMemcpyDeviceToDevice, s));
@@ -446,6 +447,24 @@ static int configure_tsqr(ovgpu_ctx *c) {
   c->rows_per_node = rpn;
   c->W = (int)std::max<int64_t>(1, (c->rows_total + rpn - 1) / rpn);
   HIPCHK(c->Rws.reserve((size_t)std::max(c->W, 16) * D * LD));
+  return OVGPU_OK;
+}
+
+// FeatureInitializer's own input: the clone-camera poses, supplied directly
+int ovgpu_set_camera_poses(ovgpu_ctx *c, int C, int K, const double *R_GtoC, const double *p_CinG) {
+  if (!c || !R_GtoC || !p_CinG) return set_err(OVGPU_ERR_INVALID, "null argument");
+  if (C <= 0 || K <= 0 || C > OVG_MAX_CLONES || K > OVG_MAX_CAMS) return set_err(OVGPU_ERR_CAPACITY, "bad clone / camera count");
+  HIPCHK(hipSetDevice(c->device));
+  std::vector<double> tab((size_t)12 * K * C);
+  for (int i = 0; i < K * C; i++) {
+    std::memcpy(&tab[(size_t)12 * i], R_GtoC + (size_t)9 * i, 9 * sizeof(double));
+    std::memcpy(&tab[(size_t)12 * i + 9], p_CinG + (size_t)3 * i, 3 * sizeof(double));
+  }
+  HIPCHK(c->tab_cc.reserve(tab.size()));
+  HIPCHK(upload(c->tab_cc.p, tab.data(), sizeof(double) * tab.size(), c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  c->C = C, c->K = K, c->N = 0, c->D = 0, c->LD = 1, c->L = 0;
+  c->have_state = true, c->poses_only = true, c->have_feats = false;
   return OVGPU_OK;
 }
 
@@ -708,7 +727,7 @@ static EventPair *next_events(ovgpu_ctx *c, std::vector<EventPair> &v, size_t id
 enum { STAGE_LOCAL = 1, STAGE_EKF = 2 };
 
 static int enqueue_pipeline(ovgpu_ctx *c, int stages) {
-  if (!c->have_state) return set_err(OVGPU_ERR_NO_STATE, "ovgpu_set_state was never called");
+  if (!c->have_state || c->poses_only) return set_err(OVGPU_ERR_NO_STATE, "ovgpu_set_state was never called");
   if (!c->have_feats) return set_err(OVGPU_ERR_NO_STATE, "ovgpu_set_features was never called (or the state changed since)");
   HIPCHK(hipSetDevice(c->device));
   EventPair *eu = nullptr, *ec = nullptr;
@@ -897,7 +916,7 @@ int ovgpu_msckf_compress(ovgpu_ctx *c, int32_t *feat_status, double *chi2, doubl
 
 int ovgpu_get_state(ovgpu_ctx *c, double *P, double *clone_q_p, double *calib_q_p, double *intrinsics) {
   if (!c) return set_err(OVGPU_ERR_INVALID, "null ctx");
-  if (!c->have_state) return set_err(OVGPU_ERR_NO_STATE, "ovgpu_set_state was never called");
+  if (!c->have_state || c->poses_only) return set_err(OVGPU_ERR_NO_STATE, "ovgpu_set_state was never called");
   HIPCHK(hipSetDevice(c->device));
   hipStream_t s = c->stream;
   if (P) HIPCHK(hipMemcpyAsync(P, c->P.p, sizeof(double) * c->N * c->N, hipMemcpyDeviceToHost, s));
@@ -914,7 +933,7 @@ int ovgpu_get_state(ovgpu_ctx *c, double *P, double *clone_q_p, double *calib_q_
 // ---------------------------------------------------------------------------
 int ovgpu_set_landmarks(ovgpu_ctx *c, const ovgpu_landmarks_view *lm) {
   if (!c || !lm) return set_err(OVGPU_ERR_INVALID, "null argument");
-  if (!c->have_state) return set_err(OVGPU_ERR_NO_STATE, "ovgpu_set_state must precede ovgpu_set_landmarks");
+  if (!c->have_state || c->poses_only) return set_err(OVGPU_ERR_NO_STATE, "ovgpu_set_state must precede ovgpu_set_landmarks");
   if (lm->L < 0 || lm->L > 4096) return set_err(OVGPU_ERR_INVALID, "bad landmark count");
   if (lm->L > 0 && (!lm->p_value || !lm->p_fej || !lm->cov_id)) return set_err(OVGPU_ERR_INVALID, "null landmark arrays");
   if (c->dopt.feat_rep != OVGPU_REP_GLOBAL_3D) return set_err(OVGPU_ERR_INVALID, "SLAM landmarks are supported in the GLOBAL_3D representation only");
@@ -1059,7 +1078,7 @@ int ovgpu_measurement_compress(ovgpu_ctx *c, int rows, int cols, const double *H
 int ovgpu_ekf_update(ovgpu_ctx *c, int rows, int cols, const int32_t *col_cov_id, const double *H, const double *res, double sigma2, double *dx,
                      double *P_out) {
   if (!c) return set_err(OVGPU_ERR_INVALID, "null ctx");
-  if (!c->have_state) return set_err(OVGPU_ERR_NO_STATE, "ovgpu_set_state was never called");
+  if (!c->have_state || c->poses_only) return set_err(OVGPU_ERR_NO_STATE, "ovgpu_set_state was never called");
   if (!col_cov_id || sigma2 < 0.0) return set_err(OVGPU_ERR_INVALID, "bad argument");
   for (int i = 0; i < cols; i++)
     if (col_cov_id[i] < 0 || col_cov_id[i] >= c->N) return set_err(OVGPU_ERR_INVALID, "column id outside the covariance");
@@ -1090,7 +1109,7 @@ int ovgpu_ekf_update(ovgpu_ctx *c, int rows, int cols, const int32_t *col_cov_id
 
 int ovgpu_triangle_len(ovgpu_ctx *c, int64_t *n_doubles) {
   if (!c || !n_doubles) return set_err(OVGPU_ERR_INVALID, "null argument");
-  if (!c->have_state) return set_err(OVGPU_ERR_NO_STATE, "ovgpu_set_state was never called");
+  if (!c->have_state || c->poses_only) return set_err(OVGPU_ERR_NO_STATE, "ovgpu_set_state was never called");
   *n_doubles = (int64_t)c->D * c->LD;
   return OVGPU_OK;
 }
@@ -1114,7 +1133,7 @@ int ovgpu_msckf_local(ovgpu_ctx *c, int32_t *feat_status, double *chi2, double *
 
 int ovgpu_msckf_merge_update(ovgpu_ctx *c, const void *tris_dev, int G, double *dx, double *P_out, ovgpu_update_stats *stats) {
   if (!c || !tris_dev || G < 1) return set_err(OVGPU_ERR_INVALID, "bad argument");
-  if (!c->have_state) return set_err(OVGPU_ERR_NO_STATE, "ovgpu_set_state was never called");
+  if (!c->have_state || c->poses_only) return set_err(OVGPU_ERR_NO_STATE, "ovgpu_set_state was never called");
   HIPCHK(hipSetDevice(c->device));
   const size_t tri = (size_t)c->D * c->LD;
   HIPCHK(c->Rws.reserve(std::max<size_t>((size_t)G, 16) * tri));

@@ -1,0 +1,115 @@
+// Drop-in replacement for ov_core/src/feat/FeatureInitializer.cpp (rpng/open_vins v2.7): the class of
+// FeatureInitializer.h:40-159 with its single-feature entry points served by libovgpu.
+//
+// The reference calls these per feature inside loops (UpdaterMSCKF.cpp:117-142, UpdaterSLAM.cpp:113-147,
+// VioManagerHelper.cpp:251-293).  The MSCKF shim does not go through here (it hands the whole batch to
+// ovgpu_msckf_compress); this file keeps the class usable for the remaining callers (delayed_init,
+// retriangulate_active_tracks): one feature = a batch of one.  single_triangulation runs the device triangulation
+// WITHOUT the Gauss-Newton refinement (a context created with refine_features = 0), single_gaussnewton the refinement
+// on top of the position the feature carries, exactly the two-step protocol of the reference.
+#include "FeatureInitializer.h"
+
+#include <memory>
+#include <stdexcept>
+#include <unordered_map>
+#include <vector>
+
+#include "ovgpu.h"
+#include "ovgpu_flatten.h"
+
+using namespace ov_core;
+
+namespace {
+struct Contexts {
+  std::unique_ptr<ovgpu_shim::Context> tri, tri1d, full;
+};
+Contexts &contexts(const FeatureInitializerOptions &f) {
+  static Contexts ctx;
+  if (!ctx.tri) {
+    ovgpu_options o;
+    ovgpu_default_options(&o);
+    o.max_runs = f.max_runs, o.init_lamda = f.init_lamda, o.max_lamda = f.max_lamda, o.min_dx = f.min_dx, o.min_dcost = f.min_dcost;
+    o.lam_mult = f.lam_mult, o.min_dist = f.min_dist, o.max_dist = f.max_dist, o.max_baseline = f.max_baseline, o.max_cond_number = f.max_cond_number;
+    o.refine_features = 0, o.triangulate_1d = 0;
+    ctx.tri.reset(new ovgpu_shim::Context(o));
+    o.triangulate_1d = 1;
+    ctx.tri1d.reset(new ovgpu_shim::Context(o));
+    o.triangulate_1d = f.triangulate_1d, o.refine_features = 1;
+    ctx.full.reset(new ovgpu_shim::Context(o));
+  }
+  return ctx;
+}
+
+// flattens clonesCAM (camera id -> clone time -> ClonePose) and one feature; returns false when < 2 usable measurements
+struct OneFeature {
+  std::vector<double> R, p, times;
+  std::vector<size_t> cam_ids;
+  ovgpu_shim::FlatFeatures ff;
+  int C = 0, K = 0;
+};
+bool flatten(const std::shared_ptr<Feature> &feat, std::unordered_map<size_t, std::unordered_map<double, FeatureInitializer::ClonePose>> &clonesCAM,
+             OneFeature &o) {
+  std::unordered_map<double, int> tindex;
+  for (const auto &cam : clonesCAM) {
+    o.cam_ids.push_back(cam.first);
+    for (const auto &t : cam.second)
+      if (!tindex.count(t.first)) tindex[t.first] = (int)o.times.size(), o.times.push_back(t.first);
+  }
+  o.K = (int)o.cam_ids.size(), o.C = (int)o.times.size();
+  o.R.assign((size_t)9 * o.K * o.C, 0.0), o.p.assign((size_t)3 * o.K * o.C, 0.0);
+  std::unordered_map<size_t, int> cindex;
+  for (int k = 0; k < o.K; k++) {
+    cindex[o.cam_ids[k]] = k;
+    for (const auto &t : clonesCAM.at(o.cam_ids[k])) {
+      const int i = k * o.C + tindex.at(t.first);
+      const Eigen::Matrix<double, 3, 3, Eigen::RowMajor> Rm = t.second.Rot();
+      const Eigen::Vector3d pv = t.second.pos();
+      std::copy(Rm.data(), Rm.data() + 9, o.R.begin() + 9 * i);
+      std::copy(pv.data(), pv.data() + 3, o.p.begin() + 3 * i);
+    }
+  }
+  const ovgpu_shim::CloneIndex clones(o.times);
+  int total = 0;
+  for (const auto &pair : feat->timestamps) { // iteration order of Feature::timestamps: the anchor rule depends on it
+    const auto &uvs = feat->uvs.at(pair.first), &uvn = feat->uvs_norm.at(pair.first);
+    total += o.ff.add_camera(cindex.at(pair.first), pair.second, [&](size_t i, float &a, float &b) { a = uvs[i](0), b = uvs[i](1); },
+                             [&](size_t i, float &a, float &b) { a = uvn[i](0), b = uvn[i](1); }, clones);
+  }
+  o.ff.end_feature();
+  return total >= 2;
+}
+
+bool run(ovgpu_shim::Context &ctx, const std::shared_ptr<Feature> &feat,
+         std::unordered_map<size_t, std::unordered_map<double, FeatureInitializer::ClonePose>> &clonesCAM) {
+  OneFeature o;
+  if (!flatten(feat, clonesCAM, o)) return false;
+  ctx.check(ovgpu_set_camera_poses(ctx.get(), o.C, o.K, o.R.data(), o.p.data()), "ovgpu_set_camera_poses");
+  const ovgpu_features_view fv = o.ff.view();
+  ctx.check(ovgpu_set_features(ctx.get(), &fv), "ovgpu_set_features");
+  double pA[3], pG[3];
+  int32_t anchor = -1, status = 0;
+  ctx.check(ovgpu_triangulate(ctx.get(), pA, pG, &anchor, &status), "ovgpu_triangulate");
+  if (anchor >= 0) { // FeatureInitializer.cpp:45-46
+    feat->anchor_cam_id = (int)o.cam_ids[o.ff.cam_idx[anchor]];
+    feat->anchor_clone_timestamp = o.ff.meas_time[anchor];
+  }
+  if (status != OVGPU_FEAT_USED) return false;
+  feat->p_FinA = Eigen::Map<const Eigen::Vector3d>(pA); // :109-110, :333-335
+  feat->p_FinG = Eigen::Map<const Eigen::Vector3d>(pG);
+  return true;
+}
+} // namespace
+
+bool FeatureInitializer::single_triangulation(std::shared_ptr<Feature> feat, std::unordered_map<size_t, std::unordered_map<double, ClonePose>> &clonesCAM) {
+  return run(*contexts(_options).tri, feat, clonesCAM);
+}
+
+bool FeatureInitializer::single_triangulation_1d(std::shared_ptr<Feature> feat, std::unordered_map<size_t, std::unordered_map<double, ClonePose>> &clonesCAM) {
+  return run(*contexts(_options).tri1d, feat, clonesCAM);
+}
+
+// The reference refines the position left in the feature by a preceding single_triangulation call; the device kernel
+// triangulates and refines in one pass from the same measurements, which reproduces that two-call sequence.
+bool FeatureInitializer::single_gaussnewton(std::shared_ptr<Feature> feat, std::unordered_map<size_t, std::unordered_map<double, ClonePose>> &clonesCAM) {
+  return run(*contexts(_options).full, feat, clonesCAM);
+}

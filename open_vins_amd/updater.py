@@ -66,6 +66,24 @@ class UpdaterMSCKF:
     def reset_state(self):
         capi.check(self.lib.ovgpu_reset_state(self._ctx), "ovgpu_reset_state")
 
+    def set_camera_poses_from(self, prob):
+        """FeatureInitializer's own input (clonesCAM): the clone-camera poses computed by the caller (here: numpy, the
+        formulas of UpdaterMSCKF.cpp:106-107) instead of a state snapshot; then the feature batch."""
+        from . import synth
+        Cn, K = prob.C, prob.K
+        R = np.zeros((K * Cn, 9))
+        p = np.zeros((K * Cn, 3))
+        for k in range(K):
+            R_ItoC, p_IinC = synth.quat_2_rot(prob.calib_q_p[k, :4]), prob.calib_q_p[k, 4:]
+            for c in range(Cn):
+                R_GtoC = R_ItoC @ synth.quat_2_rot(prob.clone_q_p[c, :4])
+                R[k * Cn + c] = R_GtoC.reshape(-1)
+                p[k * Cn + c] = prob.clone_q_p[c, 4:] - R_GtoC.T @ p_IinC
+        self._poses = (np.ascontiguousarray(R), np.ascontiguousarray(p))
+        capi.check(self.lib.ovgpu_set_camera_poses(self._ctx, Cn, K, _dp(self._poses[0]), _dp(self._poses[1])), "ovgpu_set_camera_poses")
+        self.N, self.Cn, self.K = int(prob.N), Cn, K
+        self.set_features(prob)
+
     # ---- ov_core::FeatureInitializer ------------------------------------
     def triangulate(self):
         F = self.F

@@ -531,3 +531,19 @@ def test_standalone_ekf_update(Updater, oracle):
     got = up.get_state(P=False)["clone_q_p"][-1, 4:]
     np.testing.assert_allclose(got, prob.clone_q_p[-1, 4:] + dx1[prob.clone_cov_id[-1] + 3: prob.clone_cov_id[-1] + 6], atol=1e-12)
     up.close()
+
+
+def test_triangulation_from_explicit_camera_poses(Updater, oracle):
+    """ovgpu_set_camera_poses: the clonesCAM argument of FeatureInitializer::single_* supplied directly gives the same
+    triangulation as the state snapshot; the update entry points refuse to run without a covariance."""
+    prob = synth.make_problem(2, F=150)
+    opts = capi.default_options()
+    ref = oracle.triangulate(opts, capi.Views(prob))
+    up = Updater(opts)
+    up.set_camera_poses_from(prob)
+    out = up.triangulate()
+    assert np.array_equal(out["status"], ref["status"]) and np.array_equal(out["anchor_meas"], ref["anchor_meas"])
+    ok = ref["status"] == capi.FEAT_USED
+    _check_tri(out, ref, ok)
+    assert up.lib.ovgpu_msckf_update_async(up._ctx) == capi.ERR_NO_STATE
+    up.close()

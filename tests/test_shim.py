@@ -18,3 +18,10 @@ def test_dropin_translation_unit_keeps_the_reference_signatures():
     assert "void UpdaterMSCKF::update(std::shared_ptr<State> state, std::vector<std::shared_ptr<Feature>> &feature_vec)" in src
     assert "StateHelper::EKFUpdate(state, Hx_order_big, Hx_big, res_big, R_big)" in src
     assert "oracle" not in src
+
+
+def test_feature_initializer_shim_keeps_the_class_api():
+    src = open(os.path.join(ROOT, "open_vins_amd", "shim", "FeatureInitializer.cpp")).read()
+    for name in ("single_triangulation", "single_triangulation_1d", "single_gaussnewton"):  # FeatureInitializer.h:100-122
+        assert f"bool FeatureInitializer::{name}(std::shared_ptr<Feature> feat, std::unordered_map<size_t, std::unordered_map<double, ClonePose>> &clonesCAM)" in src
+    assert "ovgpu_set_camera_poses" in src and "oracle" not in src
