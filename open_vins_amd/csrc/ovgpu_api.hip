@@ -119,7 +119,9 @@ struct ovgpu_ctx {
   DevBuf<int32_t> flags;
   int W = 1;
   int64_t rows_per_node = 128;
-  DevBuf<QrTreeNode> tree_nodes; // merge tree of the pipelined launch, cached per leaf count
+  DevBuf<QrTreeNode> tree_nodes, tree_nodes2; // merge trees of the pipelined launch, cached per leaf count (two: the local
+                                              // compression and the cross-GPU merge alternate in the sharded update)
+  int tree_G2 = 0;
   DevBuf<int32_t> tree_flags;    // [nodes] progress counters
   DevBuf<int32_t> tree_err;      // [1] sticky: a node of the pipelined tree ran into its wait bound
   int tree_G = 0;
@@ -278,7 +280,7 @@ void ovgpu_destroy(ovgpu_ctx *c) {
   c->tab_clone.release(), c->tab_cam.release(), c->tab_cc.release();
   c->meas_offsets.release(), c->meas_cc.release(), c->uv.release(), c->uvn.release(), c->row_off.release();
   c->pA.release(), c->pG.release(), c->chi2.release(), c->chi2_thr.release(), c->anchor.release(), c->status.release();
-  c->chi2_table.release(), c->Hbig.release(), c->gate_ws.release(), c->Rws.release(), c->tree_nodes.release(), c->tree_flags.release(), c->tree_err.release(), c->Mt.release(), c->Aaug.release(), c->Yaug.release();
+  c->chi2_table.release(), c->Hbig.release(), c->gate_ws.release(), c->Rws.release(), c->tree_nodes.release(), c->tree_nodes2.release(), c->tree_flags.release(), c->tree_err.release(), c->Mt.release(), c->Aaug.release(), c->Yaug.release();
   c->pFej.release(), c->lm_pos.release(), c->feat_lm.release(), c->feat_lmcol.release(), c->feat_lmcov.release(), c->lm_cov.release();
   c->dx.release(), c->flags.release(), c->given_status.release();
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -600,7 +602,11 @@ static int enqueue_merge_tree(ovgpu_ctx *c, int G) {
   if (G <= 1) return OVGPU_OK;
   if (c->tree_pipelined && NT <= 16 && G - 1 <= c->num_cu) {
     // ---- one launch for the whole tree, software-pipelined across the levels (k_qr_tree)
-    if (c->tree_G != G) {
+    DevBuf<QrTreeNode> *slot = nullptr;
+    if (c->tree_G == G) slot = &c->tree_nodes;
+    else if (c->tree_G2 == G) slot = &c->tree_nodes2;
+    if (!slot) {
+      slot = (c->tree_G == 0) ? &c->tree_nodes : &c->tree_nodes2; // the first tree built stays, the second slot is replaced
       std::vector<QrTreeNode> nodes;
       std::vector<int32_t> writer(G, -1); // node that produces the current content of a slot
       for (int stride = 1; stride < G; stride <<= 1)
@@ -610,20 +616,21 @@ static int enqueue_merge_tree(ovgpu_ctx *c, int G) {
           writer[i] = (int32_t)nodes.size();
           nodes.push_back(n);
         }
-      HIPCHK(c->tree_nodes.reserve(nodes.size()));
-      HIPCHK(c->tree_flags.reserve(nodes.size() + 1));
+      HIPCHK(slot->reserve(nodes.size()));
       if (!c->tree_err.p) {
         HIPCHK(c->tree_err.reserve(1));
         HIPCHK(hipMemsetAsync(c->tree_err.p, 0, sizeof(int32_t), c->stream));
       }
-      HIPCHK(hipMemcpyAsync(c->tree_nodes.p, nodes.data(), nodes.size() * sizeof(QrTreeNode), hipMemcpyHostToDevice, c->stream));
+      HIPCHK(hipMemcpyAsync(slot->p, nodes.data(), nodes.size() * sizeof(QrTreeNode), hipMemcpyHostToDevice, c->stream));
       HIPCHK(hipStreamSynchronize(c->stream)); // the host vector goes out of scope
-      c->tree_G = G;
+      if (slot == &c->tree_nodes) c->tree_G = G;
+      else c->tree_G2 = G;
     }
+    HIPCHK(c->tree_flags.reserve((size_t)G));
     const int n_nodes = G - 1;
     HIPCHK(hipMemsetAsync(c->tree_flags.p, 0, sizeof(int32_t) * (n_nodes + 1), c->stream));
     QrTreeParams q;
-    q.D = D, q.LD = LD, q.NT = NT, q.tri = c->Rws.p, q.nodes = c->tree_nodes.p;
+    q.D = D, q.LD = LD, q.NT = NT, q.tri = c->Rws.p, q.nodes = slot->p;
     q.progress = c->tree_flags.p, q.error = c->tree_err.p, q.spin_limit = 4000000; // ~ seconds: only a lost node gets there
     if (NT <= 8) return launch_qr_tree<16>(c, n_nodes, q);
     if (NT <= 14) return launch_qr_tree<28>(c, n_nodes, q);
@@ -1158,7 +1165,7 @@ int ovgpu_msckf_merge_update(ovgpu_ctx *c, const void *tris_dev, int G, double *
   int status = flags[0] ? OVGPU_ERR_NOT_SPD : (flags[1] ? OVGPU_ERR_NEGATIVE_DIAGONAL : OVGPU_OK);
   if (stats) stats->status = status;
   if (status != OVGPU_OK) return set_err(status, "EKF update failed");
-  return OVGPU_OK;
+  return check_tree_error(c);
 }
 
 // diagnostic kernel: evaluates the device camera model on a batch of normalized points
