@@ -49,6 +49,8 @@ struct QrNodeParams {
   int64_t rows_total;     // dense: rows of the stack
   int zero_init;          // dense: the accumulator starts as zero (it is not read)
   long long *dbg;         // profiling builds only (-DQR_PROFILE): per-wave cycle counts of the step phases
+  int32_t *progress;      // leaf nodes, optional: [nodes] panels of the LAST append that are final (agent-scope hand-off to
+                          // the merge tree running concurrently on another stream); nullptr = plain stores, no flags
 };
 
 // sum over the 4 lanes {c, c + 16, c + 32, c + 48} that share a column: two gfx950 row swaps, no LDS traffic
@@ -463,7 +465,8 @@ __global__ void __launch_bounds__(512) k_qr_node(QrNodeParams p) {
 // ---------------------------------------------------------------------------------------------------
 struct QrTreeNode {
   int32_t a_slot, b_slot; // triangles: accumulator (in place) and the one folded into it
-  int32_t dep_a, dep_b;   // node whose output the slot is (-1: a leaf result, complete before the launch)
+  int32_t dep_a, dep_b;   // >= 0: merge node whose output the slot is; -1: complete before the launch; <= -2: leaf node
+                          // -(dep + 2) of a leaf kernel running concurrently (its per-panel counters in leaf_progress)
 };
 
 struct QrTreeParams {
@@ -471,8 +474,10 @@ struct QrTreeParams {
   double *tri;             // triangle slot s at tri + s * D * LD
   const QrTreeNode *nodes; // one per workgroup
   int32_t *progress;       // [nodes] panels finished, zeroed before the launch
+  const int32_t *leaf_progress; // [leaves] panels finished by the leaf kernel (dep <= -2), or nullptr
   int32_t *error;          // set to 1 when a wait ran into its bound
   int64_t spin_limit;
+  long long *dbg; // optional: [2 * nodes] wall-clock (100 MHz) at node start and when its first panel's inputs were there
 };
 
 // agent-scope (sc1) accesses: stores write through the XCD's L2, loads bypass the CU's L1 — with both sides using them
@@ -534,12 +539,16 @@ __global__ void __launch_bounds__(512) k_qr_tree(QrTreeParams p) {
   G.cola = 16 * t0 + c, G.colb = has1 ? 16 * t1 + c : NT * 16;
   for (int e = tid; e < 16 * LDP; e += nthr) Rp[e] = 0.0; // pad columns stay zero
   int par = 0;
+  if (p.dbg && tid == 0) p.dbg[2 * blockIdx.x] = wall_clock64();
 
   for (int pnl = 0; pnl < NP; pnl++) {
     // ---- wait until both inputs have finished this panel
     if (tid == 0) {
       if (nd.dep_a >= 0) qr_wait_panels(p.progress + nd.dep_a, pnl + 1, p.spin_limit, p.error);
+      else if (nd.dep_a <= -2) qr_wait_panels(p.leaf_progress - (nd.dep_a + 2), pnl + 1, p.spin_limit, p.error);
       if (nd.dep_b >= 0) qr_wait_panels(p.progress + nd.dep_b, pnl + 1, p.spin_limit, p.error);
+      else if (nd.dep_b <= -2) qr_wait_panels(p.leaf_progress - (nd.dep_b + 2), pnl + 1, p.spin_limit, p.error);
+      if (p.dbg && pnl == 0) p.dbg[2 * blockIdx.x + 1] = wall_clock64();
     }
     __syncthreads();
     // ---- accumulator rows of the panel -> LDS; rows 16 pnl .. of the source triangle -> registers

@@ -369,7 +369,15 @@ __global__ void __launch_bounds__(512) k_qr_node(QrNodeParams p) {
     n_app = (int)((row_end - row_begin + 4 * QH - 1) / (4 * QH));
     if (n_app == 0) {
       if (p.zero_init)
-        for (int e = tid; e < D * LD; e += nthr) acc[e] = 0.0;
+        for (int e = tid; e < D * LD; e += nthr) {
+          if (p.progress) st_agent(acc + e, 0.0);
+          else acc[e] = 0.0;
+        }
+      if (p.progress) { // an empty node still hands its (zero) triangle to the merge tree
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(p.progress + blockIdx.x, (D + 15) >> 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
       return;
     }
   }
@@ -390,6 +398,7 @@ __global__ void __launch_bounds__(512) k_qr_node(QrNodeParams p) {
 
   for (int a = 0; a < n_app; a++) {
     const bool acc_zero = !TRI && p.zero_init && a == 0;
+    const bool publish = p.progress != nullptr && a == n_app - 1; // the merge tree consumes this append's panels as they finish
     const int64_t rb = TRI ? 0 : row_begin + (int64_t)a * 4 * QH;
     const int64_t rlim = TRI ? (int64_t)D : row_end;
     // ---- the block of rows to fold in.  A triangle's rows past 16 (tile + 1) are zero in that tile; only rows < 4 QH are loaded now.
@@ -474,11 +483,16 @@ __global__ void __launch_bounds__(512) k_qr_node(QrNodeParams p) {
 #pragma unroll
         for (int i = 0; i < 8; i++) {
           const int row = 2 * i + cp_r, j = 16 * pnl + row;
-          if (j < D && cp_c < LD) acc[(size_t)j * LD + cp_c] = Rc[row * LDP + cp_c];
+          if (j < D && cp_c < LD) {
+            if (publish) st_agent(acc + (size_t)j * LD + cp_c, Rc[row * LDP + cp_c]); // write-through: read by another CU right away
+            else acc[(size_t)j * LD + cp_c] = Rc[row * LDP + cp_c];
+          }
           if (have_next) Rn[row * LDP + cp_c] = pre[i];
         }
       }
+      if (publish) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every wave drains its stores before the barrier
       __syncthreads();
+      if (publish && tid == 0) __hip_atomic_store(p.progress + blockIdx.x, pnl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (have_next && is_pw) {
 #pragma unroll
         for (int q = 0; q < QH; q++) ya[q] = hb[q * 64 + l], yb[q] = hb[(QH + q) * 64 + l];

@@ -122,6 +122,12 @@ struct ovgpu_ctx {
   DevBuf<QrTreeNode> tree_nodes, tree_nodes2; // merge trees of the pipelined launch, cached per leaf count (two: the local
                                               // compression and the cross-GPU merge alternate in the sharded update)
   int tree_G2 = 0;
+  // leaf / tree overlap: the merge tree runs on a second stream next to the leaf kernel's last append
+  hipStream_t stream2 = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  DevBuf<int32_t> leaf_flags; // [W] panels of the last append finished by each leaf node
+  int tree_overlap = -1; // -1: only when leaves and merge nodes all get a CU of their own; 0 / 1 force it (OVGPU_TSQR_OVERLAP)
+  bool tree_nodes_overlap = false, tree_nodes2_overlap = false; // dependency flavour the cached trees were built with
   DevBuf<int32_t> tree_flags;    // [nodes] progress counters
   DevBuf<int32_t> tree_err;      // [1] sticky: a node of the pipelined tree ran into its wait bound
   int tree_G = 0;
@@ -150,6 +156,19 @@ static long long *qr_dbg_buffer() {
   if (!buf) {
     (void)hipMalloc((void **)&buf, 128 * sizeof(long long));
     (void)hipMemset(buf, 0, 128 * sizeof(long long));
+  }
+  return buf;
+#else
+  return nullptr;
+#endif
+}
+
+static long long *tree_dbg_buffer() {
+#ifdef QR_PROFILE
+  static long long *buf = nullptr;
+  if (!buf) {
+    (void)hipMalloc((void **)&buf, 1024 * sizeof(long long));
+    (void)hipMemset(buf, 0, 1024 * sizeof(long long));
   }
   return buf;
 #else
@@ -191,7 +210,7 @@ static int launch_qr_leaf_pw(ovgpu_ctx *c, int nodes, const QrNodeParams &q) {
 
 // the whole merge tree in one pipelined launch (k_qr_tree); G - 1 nodes, all co-resident
 template <int QH>
-static int launch_qr_tree(ovgpu_ctx *c, int nodes, const QrTreeParams &q) {
+static int launch_qr_tree(ovgpu_ctx *c, int nodes, const QrTreeParams &q, hipStream_t ts) {
   const size_t lds = qr_node_lds_bytes(q.NT, QH);
   static bool attr_done = false;
   if (!attr_done) {
@@ -199,7 +218,7 @@ static int launch_qr_tree(ovgpu_ctx *c, int nodes, const QrTreeParams &q) {
     attr_done = true;
   }
   const int NW = (q.NT + 1) / 2;
-  hipLaunchKernelGGL((k_qr_tree<QH>), dim3(nodes), dim3(64 * NW), lds, c->stream, q);
+  hipLaunchKernelGGL((k_qr_tree<QH>), dim3(nodes), dim3(64 * NW), lds, ts, q);
   HIPCHK(hipGetLastError());
   return OVGPU_OK;
 }
@@ -253,6 +272,10 @@ int ovgpu_create(const ovgpu_options *opts, int device, ovgpu_ctx **out) {
   c->row_stride = (d.feat_rep >= OVGPU_REP_ANCHORED_3D) ? 72 : 48;
   // allow the large dynamic LDS carve of the per-feature kernel
   if (const char *e = std::getenv("OVGPU_TSQR_PIPELINE")) c->tree_pipelined = std::atoi(e) != 0;
+  if (const char *e = std::getenv("OVGPU_TSQR_OVERLAP")) c->tree_overlap = std::atoi(e) != 0 ? 1 : 0;
+  if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess)
+    c->tree_overlap = 0;
   (void)hipFuncSetAttribute((const void *)k_system, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_limit);
   (void)hipFuncSetAttribute((const void *)k_triangulate, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_limit);
   const char *tenv = std::getenv("OVGPU_TIMING");
@@ -283,6 +306,10 @@ void ovgpu_destroy(ovgpu_ctx *c) {
   c->chi2_table.release(), c->Hbig.release(), c->gate_ws.release(), c->Rws.release(), c->tree_nodes.release(), c->tree_nodes2.release(), c->tree_flags.release(), c->tree_err.release(), c->Mt.release(), c->Aaug.release(), c->Yaug.release();
   c->pFej.release(), c->lm_pos.release(), c->feat_lm.release(), c->feat_lmcol.release(), c->feat_lmcov.release(), c->lm_cov.release();
   c->dx.release(), c->flags.release(), c->given_status.release();
+  if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+  if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+  if (c->stream2) (void)hipStreamDestroy(c->stream2);
+  c->leaf_flags.release();
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -596,19 +623,28 @@ static int enqueue_system(ovgpu_ctx *c) {
 }
 
 // merges triangles Rws[0..G) pairwise until Rws[0] holds the result
-static int enqueue_merge_tree(ovgpu_ctx *c, int G) {
+static bool tree_can_pipeline(const ovgpu_ctx *c, int G) {
+  const int NT = (c->LD + 15) / 16;
+  return c->tree_pipelined && NT <= 16 && G - 1 <= c->num_cu;
+}
+
+// leaves_live: the leaf kernel is running concurrently (other stream) and publishes its last append panel by panel
+static int enqueue_merge_tree(ovgpu_ctx *c, int G, bool leaves_live = false, hipStream_t on = nullptr) {
   const int D = c->D, LD = c->LD;
   const int NT = (LD + 15) / 16;
   if (G <= 1) return OVGPU_OK;
+  hipStream_t ts = on ? on : c->stream;
   if (c->tree_pipelined && NT <= 16 && G - 1 <= c->num_cu) {
     // ---- one launch for the whole tree, software-pipelined across the levels (k_qr_tree)
     DevBuf<QrTreeNode> *slot = nullptr;
-    if (c->tree_G == G) slot = &c->tree_nodes;
-    else if (c->tree_G2 == G) slot = &c->tree_nodes2;
+    if (c->tree_G == G && c->tree_nodes_overlap == leaves_live) slot = &c->tree_nodes;
+    else if (c->tree_G2 == G && c->tree_nodes2_overlap == leaves_live) slot = &c->tree_nodes2;
     if (!slot) {
       slot = (c->tree_G == 0) ? &c->tree_nodes : &c->tree_nodes2; // the first tree built stays, the second slot is replaced
       std::vector<QrTreeNode> nodes;
       std::vector<int32_t> writer(G, -1); // node that produces the current content of a slot
+      if (leaves_live)
+        for (int i = 0; i < G; i++) writer[i] = -(i + 2); // leaf i, still running
       for (int stride = 1; stride < G; stride <<= 1)
         for (int i = 0; i + stride < G; i += 2 * stride) {
           QrTreeNode n;
@@ -623,18 +659,20 @@ static int enqueue_merge_tree(ovgpu_ctx *c, int G) {
       }
       HIPCHK(hipMemcpyAsync(slot->p, nodes.data(), nodes.size() * sizeof(QrTreeNode), hipMemcpyHostToDevice, c->stream));
       HIPCHK(hipStreamSynchronize(c->stream)); // the host vector goes out of scope
-      if (slot == &c->tree_nodes) c->tree_G = G;
-      else c->tree_G2 = G;
+      if (slot == &c->tree_nodes) c->tree_G = G, c->tree_nodes_overlap = leaves_live;
+      else c->tree_G2 = G, c->tree_nodes2_overlap = leaves_live;
     }
     HIPCHK(c->tree_flags.reserve((size_t)G));
     const int n_nodes = G - 1;
-    HIPCHK(hipMemsetAsync(c->tree_flags.p, 0, sizeof(int32_t) * (n_nodes + 1), c->stream));
+    if (!leaves_live) HIPCHK(hipMemsetAsync(c->tree_flags.p, 0, sizeof(int32_t) * (n_nodes + 1), ts)); // (overlap: zeroed before the fork)
     QrTreeParams q;
     q.D = D, q.LD = LD, q.NT = NT, q.tri = c->Rws.p, q.nodes = slot->p;
-    q.progress = c->tree_flags.p, q.error = c->tree_err.p, q.spin_limit = 4000000; // ~ seconds: only a lost node gets there
-    if (NT <= 8) return launch_qr_tree<16>(c, n_nodes, q);
-    if (NT <= 14) return launch_qr_tree<28>(c, n_nodes, q);
-    return launch_qr_tree<32>(c, n_nodes, q);
+    q.progress = c->tree_flags.p, q.leaf_progress = leaves_live ? c->leaf_flags.p : nullptr, q.error = c->tree_err.p;
+    q.spin_limit = 4000000; // ~ seconds: only a lost node gets there
+    q.dbg = tree_dbg_buffer();
+    if (NT <= 8) return launch_qr_tree<16>(c, n_nodes, q, ts);
+    if (NT <= 14) return launch_qr_tree<28>(c, n_nodes, q, ts);
+    return launch_qr_tree<32>(c, n_nodes, q, ts);
   }
   for (int stride = 1; stride < G; stride <<= 1) {
     const int pairs = (G - stride + 2 * stride - 1) / (2 * stride); // i = 0, 2s, 4s, ... with i + s < G
@@ -644,7 +682,7 @@ static int enqueue_merge_tree(ovgpu_ctx *c, int G) {
       q.D = D, q.LD = LD, q.NT = NT;
       q.acc = c->Rws.p, q.acc_stride = 2 * (int64_t)stride;
       q.src = c->Rws.p + (size_t)stride * D * LD, q.src_stride = 2 * (int64_t)stride * D * LD;
-      q.rows_per_node = D, q.rows_total = D, q.zero_init = 0, q.dbg = qr_dbg_buffer();
+      q.rows_per_node = D, q.rows_total = D, q.zero_init = 0, q.dbg = qr_dbg_buffer(), q.progress = nullptr;
       int rc;
       // a merge node needs QH >= 4 NW quads per register array (NW = ceil(NT / 2) waves)
       if (NT <= 8) rc = launch_qr_node<16, true>(c, pairs, q);
@@ -674,9 +712,32 @@ static int enqueue_compress(ovgpu_ctx *c) {
     q.D = D, q.LD = LD, q.NT = NT;
     q.acc = c->Rws.p, q.acc_stride = 1;
     q.src = c->Hbig.p, q.src_stride = 0;
-    q.rows_per_node = c->rows_per_node, q.rows_total = c->rows_total, q.zero_init = 1, q.dbg = qr_dbg_buffer();
+    q.rows_per_node = c->rows_per_node, q.rows_total = c->rows_total, q.zero_init = 1, q.dbg = qr_dbg_buffer(), q.progress = nullptr;
+    // The merge tree can run NEXT TO the leaf kernel (second stream): leaf nodes publish the panels of their last append
+    // as they finish, level-1 merge nodes pick them up.  Both kernels run 256-VGPR waves, two per SIMD, so a leaf and a
+    // merge workgroup do NOT share a CU: the overlap pays only while leaves + merge nodes (2W-1) fit the chip one per CU
+    // (measured with W=203: 53 merge nodes start with the leaves, the other 149 when the leaves retire -> no gain).
+    // Leaves never wait, so a merge node that got its CU first only spins until they come.
+    const bool want_overlap = c->tree_overlap < 0 ? (2 * W - 1 <= c->num_cu) : c->tree_overlap != 0;
+    const bool overlap = want_overlap && NT <= 15 && W > 1 && tree_can_pipeline(c, W);
+    if (overlap) {
+      HIPCHK(c->leaf_flags.reserve(W));
+      HIPCHK(c->tree_flags.reserve((size_t)W));
+      HIPCHK(hipMemsetAsync(c->leaf_flags.p, 0, sizeof(int32_t) * W, c->stream));
+      HIPCHK(hipMemsetAsync(c->tree_flags.p, 0, sizeof(int32_t) * W, c->stream));
+      q.progress = c->leaf_flags.p;
+      HIPCHK(hipEventRecord(c->ev_fork, c->stream));
+      HIPCHK(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+    }
     const int rc = NT <= 15 ? launch_qr_leaf_pw<QR_LEAF_Q>(c, W, q) : launch_qr_node<QR_LEAF_Q, false>(c, W, q);
     if (rc != OVGPU_OK) return rc;
+    if (overlap) {
+      const int rt = enqueue_merge_tree(c, W, true, c->stream2);
+      if (rt != OVGPU_OK) return rt;
+      HIPCHK(hipEventRecord(c->ev_join, c->stream2));
+      HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join, 0));
+      return OVGPU_OK;
+    }
   } else {
     const int nt = ((LD + 63) / 64) * 64;
     QrAppendParams q;
@@ -1218,6 +1279,9 @@ int ovgpu_synchronize(ovgpu_ctx *c) {
 uint64_t ovgpu_stream(ovgpu_ctx *c) { return c ? (uint64_t)(uintptr_t)c->stream : 0; }
 
 #ifdef QR_PROFILE
+int ovgpu_debug_tree_times(long long *out1024) {
+  return hipMemcpy(out1024, tree_dbg_buffer(), 1024 * sizeof(long long), hipMemcpyDeviceToHost) == hipSuccess ? OVGPU_OK : OVGPU_ERR_HIP;
+}
 int ovgpu_debug_qr_cycles(long long *out128) {
   return hipMemcpy(out128, qr_dbg_buffer(), 128 * sizeof(long long), hipMemcpyDeviceToHost) == hipSuccess ? OVGPU_OK : OVGPU_ERR_HIP;
 }

@@ -389,7 +389,7 @@ def _compress_with_env(Updater, prob, opts, tri, **env):
 @pytest.mark.parametrize("kw", [dict(F=300), dict(cfg=4, F=120), dict(F=200, K=1, C=12)])
 def test_compression_is_independent_of_the_tree_shape(Updater, oracle, kw):
     """QR([R_1; R_2; ...]) = QR of the full stack: any number of leaves, and the pipelined single-launch merge
-    tree vs one launch per level, give the same R^T R / R^T c (upper triangular, D x D)."""
+    tree vs one launch per level, with the tree started next to the leaves (second stream) or after them, give the same R^T R / R^T c (upper triangular, D x D)."""
     kw = dict(kw)
     prob = synth.make_problem(kw.pop("cfg", 2), **kw)
     opts = capi.default_options(chi2_multipler=1.0)
@@ -397,7 +397,7 @@ def test_compression_is_independent_of_the_tree_shape(Updater, oracle, kw):
     base = _compress_with_env(Updater, prob, opts, tri, OVGPU_TSQR_W=1)
     G0, g0 = base["H"].T @ base["H"], base["H"].T @ base["r"]
     for env in (dict(OVGPU_TSQR_W=2), dict(OVGPU_TSQR_W=5), dict(OVGPU_TSQR_W=64), dict(OVGPU_TSQR_W=64, OVGPU_TSQR_PIPELINE=0),
-                dict(OVGPU_TSQR_W=256)):
+                dict(OVGPU_TSQR_W=64, OVGPU_TSQR_OVERLAP=0), dict(OVGPU_TSQR_W=256), dict(OVGPU_TSQR_W=256, OVGPU_TSQR_OVERLAP=1)):
         c = _compress_with_env(Updater, prob, opts, tri, **env)
         assert c["rows"] == base["rows"] and c["D"] == base["D"]
         assert np.abs(np.tril(c["H"], -1)).max() == 0.0

@@ -51,7 +51,7 @@ int main(int argc, char **argv) {
   hipMemcpy(dA, A.data(), A.size() * 8, hipMemcpyHostToDevice);
   QrNodeParams q{};
   q.D = D, q.LD = LD, q.NT = NT, q.acc = dR, q.acc_stride = 1, q.src = dA, q.src_stride = 0;
-  q.rows_per_node = (rows + G - 1) / G, q.rows_total = rows, q.zero_init = 1, q.dbg = nullptr;
+  q.rows_per_node = (rows + G - 1) / G, q.rows_total = rows, q.zero_init = 1, q.dbg = nullptr, q.progress = nullptr;
   if (argc > 4) q.rows_per_node = atoi(argv[4]); // e.g. all rows in node 0: the other leaves are zero triangles (steps with tau' = 0)
   // merge tree description
   std::vector<QrTreeNode> nodes;
@@ -68,7 +68,7 @@ int main(int argc, char **argv) {
   hipMalloc((void **)&dF, (nodes.size() + 1) * 4);
   hipMemcpy(dN, nodes.data(), nodes.size() * sizeof(QrTreeNode), hipMemcpyHostToDevice);
   QrTreeParams t{};
-  t.D = D, t.LD = LD, t.NT = NT, t.tri = dR, t.nodes = dN, t.progress = dF, t.error = dF + nodes.size(), t.spin_limit = 2000000;
+  t.D = D, t.LD = LD, t.NT = NT, t.tri = dR, t.nodes = dN, t.progress = dF, t.leaf_progress = nullptr, t.dbg = nullptr, t.error = dF + nodes.size(), t.spin_limit = 2000000;
   hipEvent_t e0, e1, e2;
   hipEventCreate(&e0), hipEventCreate(&e1), hipEventCreate(&e2);
   float tl = 1e9f, tt = 1e9f;
