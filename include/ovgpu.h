@@ -278,17 +278,26 @@ int ovgpu_get_state(ovgpu_ctx *ctx, double *P, double *clone_q_p,
 /* ------------------------------------------------------------------------- */
 
 /* SLAM landmarks that live in the state (State::_features_SLAM, ov_type::Landmark,
- * ov_core/src/types/Landmark.h).  This round supports the reference default
- * feat_rep_slam = GLOBAL_3D (StateOptions.h:89): a landmark is a 3-dof global position.
- *   p_value [3*L]  Landmark::get_xyz(false)   (UpdaterSLAM.cpp:349-352)
- *   p_fej   [3*L]  Landmark::get_xyz(true)
- *   cov_id  [L]    Type::id() of the 3-dof landmark in the covariance                   */
+ * ov_core/src/types/Landmark.h), all in one 3-dof representation `feat_rep` (StateOptions
+ * feat_rep_slam; 0 = GLOBAL_3D, the reference default, StateOptions.h:89).  The 1-dof
+ * ANCHORED_INVERSE_DEPTH_SINGLE is not supported (OVGPU_ERR_INVALID).
+ *   p_value [3*L]  Landmark::value()  — REPRESENTATION coordinates (xyz, (theta, phi, rho) or
+ *                  (alpha, beta, rho), Landmark.cpp:66-141); the library applies
+ *                  Landmark::get_xyz (Landmark.cpp:25-62) where the reference does
+ *                  (UpdaterSLAM.cpp:345-353)
+ *   p_fej   [3*L]  Landmark::fej()
+ *   cov_id  [L]    Type::id() of the 3-dof landmark in the covariance
+ *   anchor_cam, anchor_clone [L]  Landmark::_anchor_cam_id and the clone index (into the
+ *                  state view's clone arrays) of _anchor_clone_timestamp; read for the anchored
+ *                  representations only (may be NULL otherwise)                          */
 typedef struct {
   int32_t L;
-  int32_t _pad0;
+  int32_t feat_rep; /* ovgpu_feat_rep of every landmark of the view */
   const double *p_value;
   const double *p_fej;
   const int32_t *cov_id;
+  const int32_t *anchor_cam;
+  const int32_t *anchor_clone;
 } ovgpu_landmarks_view;
 
 /* Uploads the landmarks the next ovgpu_slam_update works on; their 3 columns each join the
@@ -305,7 +314,9 @@ int ovgpu_set_landmarks(ovgpu_ctx *ctx, const ovgpu_landmarks_view *lm);
  * MSCKF update first — the EKF result is the same matrix (QR is an orthogonal transform of
  * the rows).  Features with no measurement are flagged OVGPU_FEAT_TOO_FEW_MEAS (:289-291).
  *   feat_status, chi2, chi2_thresh [F];  dx [N];  P_out [N*N];  lm_out [3*L] updated
- *   landmark positions (Landmark::update, Landmark.h:80-89: additive for GLOBAL_3D).     */
+ *   landmark values in representation coordinates (Landmark::update, Landmark.h:80-89:
+ *   additive).  The landmarks stay resident: a following ovgpu_slam_update /
+ *   ovgpu_slam_delayed_init continues from the updated values.                          */
 int ovgpu_slam_update(ovgpu_ctx *ctx, const int32_t *lm_index, int32_t *feat_status,
                       double *chi2, double *chi2_thresh, double *dx, double *P_out,
                       double *lm_out, ovgpu_update_stats *stats);
@@ -317,6 +328,47 @@ int ovgpu_slam_update(ovgpu_ctx *ctx, const int32_t *lm_index, int32_t *feat_sta
 int ovgpu_slam_compress(ovgpu_ctx *ctx, const int32_t *lm_index, int32_t *feat_status,
                         double *chi2, double *chi2_thresh, int32_t *D_out, int32_t *rows_out,
                         int32_t *col_cov_id, double *H, double *r, ovgpu_update_stats *stats);
+
+/* UpdaterSLAM::delayed_init (UpdaterSLAM.cpp:61-251) with StateHelper::initialize /
+ * initialize_invertible (StateHelper.cpp:393-577) on the resident state and the uploaded feature
+ * tracks: every feature is triangulated against the clone poses at entry (:121-144), then ONE
+ * AFTER THE OTHER (each accepted feature changes the state the next one is linearised at):
+ * Jacobians (:165), separation of the 2m rows into the 3 rows that determine the landmark and
+ * the 2m-3 rows that do not (StateHelper.cpp:429-455; any orthonormal basis gives the same
+ * result, here 3 Householder reflectors instead of the Givens sweep), chi2 gate of the latter
+ * against chi2_multipler * chi2_0.95(2m) (:459-470), and for an accepted feature the covariance
+ * augmentation (:541-565), the landmark's first correction (:569) and StateHelper::EKFUpdate
+ * with the 2m-3 rows (:476-478).  The context's options are the UpdaterSLAM's (sigma_pix,
+ * chi2_multipler of `slam`).  `feat_rep` = StateOptions::feat_rep_slam (3-dof representations;
+ * must equal the representation of the resident landmarks when there are any).
+ *
+ * The covariance grows by 3 per accepted feature, in feature order (new ids N, N+3, ...).
+ * Outputs (any may be NULL):
+ *   feat_status, chi2, chi2_thresh [F]   as ovgpu_msckf_update (chi2 rejected ->
+ *                                        OVGPU_FEAT_CHI2_REJECTED)
+ *   lm_cov_id [F]     covariance id given to the feature's landmark, -1 if not initialised
+ *   lm_value, lm_fej [3*F]  Landmark::value() / fej() in representation coordinates AFTER the
+ *                     whole call (later features' updates included)
+ *   anchor_cam, anchor_clone [F]   anchor of the triangulation (Feature::anchor_cam_id and the
+ *                     clone index of anchor_clone_timestamp)
+ *   dx_seq [F * (N + 3*F)]  row f = the state correction of feature f's EKFUpdate (zero when it
+ *                     was rejected), for the variables the library does not hold (IMU, time
+ *                     offset ...): apply the rows in order
+ *   N_out             new covariance dimension N + 3 * n_accepted
+ *   P_out [(N + 3*F)^2 capacity]   the N_out x N_out covariance, row-major with stride N_out
+ * Afterwards the resident state has dimension N_out and the accepted landmarks are resident
+ * (appended to those of ovgpu_set_landmarks); upload the next feature batch with
+ * ovgpu_set_features before another feature update.                                       */
+int ovgpu_slam_delayed_init(ovgpu_ctx *ctx, int32_t feat_rep, int32_t *feat_status, double *chi2,
+                            double *chi2_thresh, int32_t *lm_cov_id, double *lm_value,
+                            double *lm_fej, int32_t *anchor_cam, int32_t *anchor_clone,
+                            double *dx_seq, int32_t *N_out, double *P_out,
+                            ovgpu_update_stats *stats);
+
+/* Landmarks resident after ovgpu_slam_update / ovgpu_slam_delayed_init: L_out = count,
+ * value / fej [3*L] (representation coordinates), cov_id / anchor_cam / anchor_clone [L]. */
+int ovgpu_get_landmarks(ovgpu_ctx *ctx, int32_t *L_out, double *value, double *fej,
+                        int32_t *cov_id, int32_t *anchor_cam, int32_t *anchor_clone);
 
 /* ------------------------------------------------------------------------- */
 /* the two helpers of the path as standalone calls (UpdaterZeroVelocity.cpp:183-321 */

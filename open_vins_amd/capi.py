@@ -75,7 +75,8 @@ class FeaturesView(C.Structure):
 
 class LandmarksView(C.Structure):
     """ovgpu_landmarks_view"""
-    _fields_ = [("L", C.c_int32), ("_pad0", C.c_int32), ("p_value", c_double_p), ("p_fej", c_double_p), ("cov_id", c_int32_p)]
+    _fields_ = [("L", C.c_int32), ("feat_rep", C.c_int32), ("p_value", c_double_p), ("p_fej", c_double_p), ("cov_id", c_int32_p),
+                ("anchor_cam", c_int32_p), ("anchor_clone", c_int32_p)]
 
 
 class UpdateStats(C.Structure):
@@ -150,6 +151,11 @@ class Views:
             lv.p_value = _ptr(self.lm_value, C.c_double)
             lv.p_fej = _ptr(self.lm_fej, C.c_double)
             lv.cov_id = _ptr(self.lm_cov_id, C.c_int32)
+            lv.feat_rep = int(getattr(prob, "lm_rep", 0) or 0)
+            self.lm_anchor_cam = i32(prob.lm_anchor_cam) if getattr(prob, "lm_anchor_cam", None) is not None else None
+            self.lm_anchor_clone = i32(prob.lm_anchor_clone) if getattr(prob, "lm_anchor_clone", None) is not None else None
+            lv.anchor_cam = _ptr(self.lm_anchor_cam, C.c_int32)
+            lv.anchor_clone = _ptr(self.lm_anchor_clone, C.c_int32)
             self.landmarks = lv
 
 
@@ -179,6 +185,9 @@ def declare(lib):
         "ovgpu_measurement_compress": (C.c_int, [ctxp, C.c_int, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p, c_int32_p]),
         "ovgpu_ekf_update": (C.c_int, [ctxp, C.c_int, C.c_int, c_int32_p, c_double_p, c_double_p, C.c_double, c_double_p, c_double_p]),
         "ovgpu_set_landmarks": (C.c_int, [ctxp, C.POINTER(LandmarksView)]),
+        "ovgpu_get_landmarks": (C.c_int, [ctxp, c_int32_p, c_double_p, c_double_p, c_int32_p, c_int32_p, c_int32_p]),
+        "ovgpu_slam_delayed_init": (C.c_int, [ctxp, C.c_int32, c_int32_p, c_double_p, c_double_p, c_int32_p, c_double_p, c_double_p, c_int32_p,
+                                              c_int32_p, c_double_p, c_int32_p, c_double_p, C.POINTER(UpdateStats)]),
         "ovgpu_slam_compress": (C.c_int, [ctxp, c_int32_p, c_int32_p, c_double_p, c_double_p, c_int32_p, c_int32_p, c_int32_p, c_double_p,
                                           c_double_p, C.POINTER(UpdateStats)]),
         "ovgpu_slam_update": (C.c_int, [ctxp, c_int32_p, c_int32_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p,

@@ -43,8 +43,11 @@ __device__ __forceinline__ double4_t mfma_tile(FA fa, FB fb, int K, int lane) {
 }
 
 struct EkfParams {
-  int N, D, LD, LA; // LA = D + N + 1 columns of the augmented matrix
-  const double *R;  // [D x LD] compressed system (last column = residual)
+  int N, D, LD, LA; // D = rows of the system, LA = D + N + 1 columns of the augmented matrix
+  int DC;           // Jacobian columns (= D for a compressed, upper-triangular system; the residual is column DC)
+  int tri;          // 1: R is upper triangular (entries left of the diagonal are not read)
+  const int32_t *pred; // optional: the whole update is skipped when *pred == 0 (delayed initialisation: feature rejected)
+  const double *R;  // [D x LD] system rows (last column = residual)
   const int32_t *col_cov;
   double *P;        // [N x N] in/out
   double *Mt;       // [D x N]
@@ -60,11 +63,11 @@ __global__ void __launch_bounds__(256) k_ekf_mt(EkfParams p) {
   const int lane = threadIdx.x & 63;
   const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int tn = (p.N + 15) / 16, tm = (p.D + 15) / 16;
-  if (tile >= tn * tm) return;
+  if (tile >= tn * tm || (p.pred && *p.pred == 0)) return;
   const int r0 = (tile / tn) * 16, c0 = (tile % tn) * 16;
-  auto fa = [&](int i, int k) { const int r = r0 + i; return (r < p.D && k >= r) ? p.R[(size_t)r * p.LD + k] : 0.0; }; // R upper triangular
+  auto fa = [&](int i, int k) { const int r = r0 + i; return (r < p.D && (k >= r || !p.tri)) ? p.R[(size_t)r * p.LD + k] : 0.0; };
   auto fb = [&](int k, int j) { const int c = c0 + j; return (c < p.N) ? p.P[(size_t)p.col_cov[k] * p.N + c] : 0.0; };
-  const double4_t acc = mfma_tile(fa, fb, p.D, lane);
+  const double4_t acc = mfma_tile(fa, fb, p.DC, lane);
   const int col = c0 + (lane & 15);
 #pragma unroll
   for (int q = 0; q < 4; q++) {
@@ -81,11 +84,11 @@ __global__ void __launch_bounds__(256) k_ekf_s(EkfParams p) {
   const int lane = threadIdx.x & 63;
   const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int tm = (p.D + 15) / 16;
-  if (tile >= tm * tm) return;
+  if (tile >= tm * tm || (p.pred && *p.pred == 0)) return;
   const int r0 = (tile / tm) * 16, c0 = (tile % tm) * 16;
   auto fa = [&](int i, int k) { const int r = r0 + i; return (r < p.D) ? p.Mt[(size_t)r * p.N + p.col_cov[k]] : 0.0; };
-  auto fb = [&](int k, int j) { const int c = c0 + j; return (c < p.D && k >= c) ? p.R[(size_t)c * p.LD + k] : 0.0; };
-  const double4_t acc = mfma_tile(fa, fb, p.D, lane);
+  auto fb = [&](int k, int j) { const int c = c0 + j; return (c < p.D && (k >= c || !p.tri)) ? p.R[(size_t)c * p.LD + k] : 0.0; };
+  const double4_t acc = mfma_tile(fa, fb, p.DC, lane);
   const int col = c0 + (lane & 15);
 #pragma unroll
   for (int q = 0; q < 4; q++) {
@@ -93,7 +96,7 @@ __global__ void __launch_bounds__(256) k_ekf_s(EkfParams p) {
     if (row < p.D && col < p.D) p.A[(size_t)row * p.LA + col] = acc[q] + (row == col ? p.sigma2 : 0.0);
   }
   if (tile == 0)
-    for (int r = lane; r < p.D; r += 64) p.A[(size_t)r * p.LA + p.D + p.N] = p.R[(size_t)r * p.LD + p.D];
+    for (int r = lane; r < p.D; r += 64) p.A[(size_t)r * p.LA + p.D + p.N] = p.R[(size_t)r * p.LD + p.DC];
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -119,6 +122,7 @@ __global__ void __launch_bounds__(256) k_ekf_chol_step(EkfParams p, int kb) {
   const int D = p.D, LA = p.LA;
   const int tb = kb >> 4, TM = (D + 15) >> 4, TL = (LA + 15) >> 4;
   const int nb = min(16, D - kb);
+  if (p.pred && *p.pred == 0) return;
   // wave -> job: first the TL - tb "writer" jobs (finished rows of column tile jt -> Y), then the trailing tiles (it, jt >= it)
   int job = blockIdx.x * 4 + wv;
   const int n_writer = TL - tb;
@@ -213,7 +217,7 @@ __global__ void __launch_bounds__(256) k_ekf_pupdate(EkfParams p) {
   const int lane = threadIdx.x & 63;
   const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int tn = (p.N + 15) / 16;
-  if (tile >= tn * tn) return;
+  if (tile >= tn * tn || (p.pred && *p.pred == 0)) return;
   const int r0 = (tile / tn) * 16, c0 = (tile % tn) * 16;
   const double *Y = p.Y + p.D;
   auto fa = [&](int i, int k) { const int r = r0 + i; return (r < p.N) ? Y[(size_t)k * p.LA + r] : 0.0; };
@@ -235,6 +239,10 @@ __global__ void __launch_bounds__(256) k_ekf_pupdate(EkfParams p) {
 __global__ void k_ekf_dx(EkfParams p) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= p.N) return;
+  if (p.pred && *p.pred == 0) { // no update: the correction is zero
+    p.dx[i] = 0.0;
+    return;
+  }
   const double *Y = p.Y + p.D;
   const double *y = p.Y + p.D + p.N;
   double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
@@ -270,7 +278,8 @@ __device__ __forceinline__ void pose_boxplus(double *qp, const double *dx6) {
 }
 
 __global__ void k_boxplus(int C, int K, const double *__restrict__ dx, const int32_t *__restrict__ clone_cov, const int32_t *__restrict__ calib_cov,
-                          const int32_t *__restrict__ intr_cov, double *clone_qp, double *calib_qp, double *intr) {
+                          const int32_t *__restrict__ intr_cov, double *clone_qp, double *calib_qp, double *intr, const int32_t *pred) {
+  if (pred && *pred == 0) return; // a zero correction would still renormalise the quaternions
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t < C) pose_boxplus(clone_qp + 7 * t, dx + clone_cov[t]);
   if (t < K) {

@@ -1,0 +1,170 @@
+// k_slam.h — the small kernels around the SLAM landmarks that live in the state.
+//
+//   Landmark::get_xyz / set_from_xyz                   ov_core/src/types/Landmark.cpp:25-141
+//   Landmark::update                                    ov_core/src/types/Landmark.h:80-89
+//   UpdaterSLAM::update, landmark -> feature            UpdaterSLAM.cpp:333-353
+//   StateHelper::initialize_invertible                  StateHelper.cpp:484-577
+//
+// The landmarks are resident in REPRESENTATION coordinates (what ov_type::Landmark stores): the additive
+// correction of the EKF applies to those, the Jacobians need xyz.
+#pragma once
+#include "device_math.h"
+#include "ovgpu_types.h"
+
+namespace ovg {
+
+// Landmark::get_xyz — Landmark.cpp:25-62 (3-dof representations)
+__device__ __forceinline__ V3 lm_to_xyz(int rep, const double *v) {
+  if (rep == OVGPU_REP_GLOBAL_FULL_INVERSE_DEPTH || rep == OVGPU_REP_ANCHORED_FULL_INVERSE_DEPTH) {
+    const double ir = 1.0 / v[2];
+    return V3{ir * cos(v[0]) * sin(v[1]), ir * sin(v[0]) * sin(v[1]), ir * cos(v[1])};
+  }
+  if (rep == OVGPU_REP_ANCHORED_MSCKF_INVERSE_DEPTH) {
+    const double ir = 1.0 / v[2];
+    return V3{ir * v[0], ir * v[1], ir};
+  }
+  return V3{v[0], v[1], v[2]};
+}
+
+// Landmark::set_from_xyz — Landmark.cpp:66-141
+__device__ __forceinline__ void lm_from_xyz(int rep, const V3 &p, double *v) {
+  if (rep == OVGPU_REP_GLOBAL_FULL_INVERSE_DEPTH || rep == OVGPU_REP_ANCHORED_FULL_INVERSE_DEPTH) {
+    const double rho = 1.0 / norm(p);
+    v[0] = atan2(p.y, p.x), v[1] = acos(rho * p.z), v[2] = rho;
+    return;
+  }
+  if (rep == OVGPU_REP_ANCHORED_MSCKF_INVERSE_DEPTH) {
+    v[0] = p.x / p.z, v[1] = p.y / p.z, v[2] = 1.0 / p.z;
+    return;
+  }
+  v[0] = p.x, v[1] = p.y, v[2] = p.z;
+}
+
+struct LandmarkStore {
+  double *value, *fej;    // [3 * cap] representation coordinates
+  int32_t *cov, *col;     // [cap] covariance id, first Jacobian column (-1: not in the column map yet)
+  int32_t *anchor;        // [cap] packed (camera << 10 | clone) or -1
+};
+
+// per-feature inputs of the SLAM update from the landmark each feature observes (UpdaterSLAM.cpp:333-353)
+__global__ void k_slam_gather(int F, int rep, const int32_t *__restrict__ lm_index, const int32_t *__restrict__ meas_offsets, LandmarkStore lm,
+                              double *p_FinG, double *p_FinA, double *p_fej, int32_t *feat_lm, int32_t *feat_lmcol, int32_t *feat_lmcov,
+                              int32_t *feat_anchor, int32_t *status) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= F) return;
+  const int l = lm_index[f];
+  const V3 x = lm_to_xyz(rep, lm.value + 3 * l), xf = lm_to_xyz(rep, lm.fej + 3 * l);
+  double *dst = rep >= OVGPU_REP_ANCHORED_3D ? p_FinA : p_FinG; // position in the anchor camera / in the global frame
+  dst[3 * f] = x.x, dst[3 * f + 1] = x.y, dst[3 * f + 2] = x.z;
+  p_fej[3 * f] = xf.x, p_fej[3 * f + 1] = xf.y, p_fej[3 * f + 2] = xf.z;
+  feat_lm[f] = l, feat_lmcol[f] = lm.col[l], feat_lmcov[f] = lm.cov[l], feat_anchor[f] = lm.anchor[l];
+  status[f] = (meas_offsets[f + 1] - meas_offsets[f] >= 1) ? OVGPU_FEAT_USED : OVGPU_FEAT_TOO_FEW_MEAS; // UpdaterSLAM.cpp:289-291
+}
+
+// Landmark::update: value += dx[id .. id+2]     (L from a device counter when the count changes inside a stream of launches)
+__global__ void k_landmark_update(int L, const int32_t *__restrict__ L_dev, const double *__restrict__ dx, const int32_t *__restrict__ lm_cov,
+                                  double *lm_value, const int32_t *pred) {
+  if (pred && *pred == 0) return;
+  const int n = L_dev ? *L_dev : L;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < 3 * n) lm_value[t] += dx[lm_cov[t / 3] + t % 3];
+}
+
+// dst (n x n, leading dimension ldd) <- src (leading dimension lds); the rest of dst's rows / columns up to nd is zeroed
+__global__ void k_cov_copy(int n, int nd, const double *__restrict__ src, int lds, double *__restrict__ dst, int ldd) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+  if (i < nd && j < nd) dst[(size_t)i * ldd + j] = (i < n && j < n) ? src[(size_t)i * lds + j] : 0.0;
+}
+
+struct InitParams {
+  int N, D, LD;             // N = leading dimension of P (the padded capacity)
+  int rep, f;
+  const int32_t *col_cov;   // [D]
+  const double *init_out;   // [3 * LD + 9]: Q1^T [H_x | res], R1
+  double *P;
+  double sigma2;
+  int32_t *ctr;             // [0] current covariance dimension, [1] current landmark count, [2] this feature passed the gate
+  const double *p_FinG, *p_FinA;
+  const uint16_t *meas_cc;
+  const int32_t *anchor_meas;
+  LandmarkStore lm;
+  int32_t *feat_slot;       // [F] landmark slot given to feature f, -1 if not initialised
+};
+
+// StateHelper::initialize_invertible (StateHelper.cpp:484-577) for one 3-dof landmark.  One workgroup.
+//   G = H_L^-1 H_R (3 x D),  new columns of P = -P(:, cols) G^T,  P_LL = G P_small G^T + sigma^2 H_L^-1 H_L^-T,
+//   landmark value += H_L^-1 res.
+__global__ void __launch_bounds__(256) k_init_invertible(InitParams p) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const int tid = threadIdx.x, N = p.N, D = p.D, LD = p.LD;
+  if (p.ctr[2] == 0) {
+    if (tid == 0) p.feat_slot[p.f] = -1;
+    return;
+  }
+  double *G = sm;          // [3][LD]
+  double *t = G + 3 * LD;  // [3][N]
+  double *PLL = t + 3 * N; // [9]
+  const double *top = p.init_out, *R1 = p.init_out + (size_t)3 * LD;
+  // H_L^-1 of the upper-triangular 3 x 3 (StateHelper.cpp:548)
+  const double u00 = R1[0], u01 = R1[1], u02 = R1[2], u11 = R1[4], u12 = R1[5], u22 = R1[8];
+  const double i00 = 1.0 / u00, i11 = 1.0 / u11, i22 = 1.0 / u22;
+  const double i01 = -u01 * i00 * i11, i12 = -u12 * i11 * i22, i02 = (u01 * u12 - u02 * u11) * i00 * i11 * i22;
+  for (int c = tid; c < LD; c += 256) {
+    const double a = top[c], b = top[LD + c], d = top[2 * LD + c];
+    G[c] = i00 * a + i01 * b + i02 * d;
+    G[LD + c] = i11 * b + i12 * d;
+    G[2 * LD + c] = i22 * d;
+  }
+  __syncthreads();
+  for (int i = tid; i < N; i += 256) { // t = G P(cols, :)
+    double t0 = 0.0, t1 = 0.0, t2 = 0.0;
+    for (int c = 0; c < D; c++) {
+      const double pv = p.P[(size_t)p.col_cov[c] * N + i];
+      t0 = fma(G[c], pv, t0), t1 = fma(G[LD + c], pv, t1), t2 = fma(G[2 * LD + c], pv, t2);
+    }
+    t[i] = t0, t[N + i] = t1, t[2 * N + i] = t2;
+  }
+  __syncthreads();
+  if (tid < 9) {
+    const int j = tid / 3, k = tid % 3;
+    double s = 0.0;
+    for (int c = 0; c < D; c++) s = fma(t[(size_t)j * N + p.col_cov[c]], G[(size_t)k * LD + c], s);
+    // sigma^2 H_L^-1 H_L^-T (:549, R = sigma^2 I)
+    const double inv[3][3] = {{i00, i01, i02}, {0.0, i11, i12}, {0.0, 0.0, i22}};
+    double w = 0.0;
+    for (int q = 0; q < 3; q++) w = fma(inv[j][q], inv[k][q], w);
+    PLL[tid] = fma(p.sigma2, w, s);
+  }
+  __syncthreads();
+  const int id = p.ctr[0], slot = p.ctr[1];
+  for (int i = tid; i < N; i += 256) {
+    if (i >= id && i < id + 3) continue;
+#pragma unroll
+    for (int j = 0; j < 3; j++) { // :556-557
+      const double v = -t[(size_t)j * N + i];
+      p.P[(size_t)i * N + id + j] = v;
+      p.P[(size_t)(id + j) * N + i] = v;
+    }
+  }
+  if (tid < 9) {
+    const int j = tid / 3, k = tid % 3;
+    p.P[(size_t)(id + j) * N + id + k] = 0.5 * (PLL[3 * j + k] + PLL[3 * k + j]); // :558, symmetric by construction up to rounding
+  }
+  if (tid == 0) {
+    const bool relative = p.rep >= OVGPU_REP_ANCHORED_3D;
+    const double *x = (relative ? p.p_FinA : p.p_FinG) + 3 * p.f;
+    double v[3];
+    lm_from_xyz(p.rep, V3{x[0], x[1], x[2]}, v); // UpdaterSLAM.cpp:213-221
+    for (int j = 0; j < 3; j++) {
+      p.lm.fej[3 * slot + j] = v[j];
+      p.lm.value[3 * slot + j] = v[j] + G[(size_t)j * LD + D]; // new_variable->update(H_Linv * res), :569
+    }
+    p.lm.cov[slot] = id, p.lm.col[slot] = -1;
+    p.lm.anchor[slot] = relative ? (int32_t)p.meas_cc[p.anchor_meas[p.f]] : -1;
+    p.feat_slot[p.f] = slot;
+  }
+  __syncthreads();
+  if (tid == 0) p.ctr[0] = id + 3, p.ctr[1] = slot + 1;
+}
+
+} // namespace ovg

@@ -144,7 +144,7 @@ __global__ void __launch_bounds__(SYS_NT) k_system(SysParams p) {
 #else
 #define SYS_T(i)
 #endif
-  for (int f = blockIdx.x; f < p.F; f += gridDim.x) {
+  for (int f = p.f_begin + blockIdx.x; f < p.f_end; f += gridDim.x) {
     const int m0 = p.meas_offsets[f];
     const int m = p.meas_offsets[f + 1] - m0;
     const int64_t orow0 = p.row_off[f];
@@ -155,6 +155,7 @@ __global__ void __launch_bounds__(SYS_NT) k_system(SysParams p) {
     if (status_in != OVGPU_FEAT_USED) {
       // failed before the gate: its rows of the stacked system are zero
       for (int64_t e = tid; e < (int64_t)n_out * LD; e += SYS_NT) p.Hbig[orow0 * LD + e] = 0.0;
+      if (p.init && tid == 0) p.init_flag[0] = 0;
       continue;
     }
     const int n = 2 * m;
@@ -167,10 +168,11 @@ __global__ void __launch_bounds__(SYS_NT) k_system(SysParams p) {
     V3 p_FinG = load_v3(p.p_FinG + 3 * f);
     const bool slam = p.slam != 0; // UpdaterSLAM::update: the feature is a landmark of the state (GLOBAL_3D)
     const int lm_id = slam ? p.feat_lm[f] : -1, lm_col = slam ? p.feat_lmcol[f] : -1, lm_cov = slam ? p.feat_lmcov[f] : -1;
-    const V3 p_FinG_fej = slam ? load_v3(p.p_fej + 3 * f) : p_FinG; // fej == value for MSCKF features (UpdaterMSCKF.cpp:186-194)
+    V3 p_FinG_fej = slam ? load_v3(p.p_fej + 3 * f) : p_FinG; // fej == value for MSCKF features (UpdaterMSCKF.cpp:186-194)
     int anchor_cam = -1, anchor_clone = -1;
     if (relative) {
-      const int ac = p.meas_cc[p.anchor_meas[f]];
+      // MSCKF / delayed init: the anchor of the triangulation; SLAM: the landmark's (UpdaterSLAM.cpp:345-348)
+      const int ac = slam ? p.feat_anchor[f] : p.meas_cc[p.anchor_meas[f]];
       anchor_cam = ac >> 10, anchor_clone = ac & 1023;
       const V3 p_FinA = load_v3(p.p_FinA + 3 * f);
       const M3 R_ItoC = load_m3(p.tab_cam + 12 * anchor_cam);
@@ -178,13 +180,14 @@ __global__ void __launch_bounds__(SYS_NT) k_system(SysParams p) {
       const M3 R_GtoI = load_m3(p.tab_clone + 24 * anchor_clone);
       const V3 p_IinG = load_v3(p.tab_clone + 24 * anchor_clone + 9);
       p_FinG = mulT(R_GtoI, mulT(R_ItoC, p_FinA - p_IinC)) + p_IinG; // UpdaterHelper.cpp:274
+      p_FinG_fej = p_FinG;                                           // :279-283: the "best" estimate, p_FinA_fej is not used
     }
     if (tid == 0) {
       double *dl = hq + 12;
       if (p.opt.feat_rep == OVGPU_REP_GLOBAL_3D) {
         dl[0] = 1, dl[1] = 0, dl[2] = 0, dl[3] = 0, dl[4] = 1, dl[5] = 0, dl[6] = 0, dl[7] = 0, dl[8] = 1;
       } else if (p.opt.feat_rep == OVGPU_REP_GLOBAL_FULL_INVERSE_DEPTH) {
-        inv_depth_jac(p_FinG, dl); // fej value == value for MSCKF features (UpdaterMSCKF.cpp:186-194)
+        inv_depth_jac(p.opt.do_fej ? p_FinG_fej : p_FinG, dl); // UpdaterHelper.cpp:46 (fej == value for MSCKF features)
       } else {
         // anchored (UpdaterHelper.cpp:84-189)
         const V3 p_FinA_in = load_v3(p.p_FinA + 3 * f);
@@ -543,7 +546,8 @@ __global__ void __launch_bounds__(SYS_NT) k_system(SysParams p) {
       const V3 x = colpiv_qr_solve3(G, g);
       // SLAM: the landmark is a state variable, the gate is on all n rows (UpdaterSLAM.cpp:390-405)
       const double chi2 = slam ? a : a - dot(g, x);
-      const int dof = slam ? n : n - 3;
+      // StateHelper::initialize gates the 2m-3 projected rows against the quantile of ALL res.rows() = 2m (StateHelper.cpp:466)
+      const int dof = (slam || p.init) ? n : n - 3;
       const double thr = p.opt.chi2_multipler * p.chi2_table[min(dof, p.chi2_table_len - 1)]; // UpdaterMSCKF.cpp:216-222
       if (tid == 0) {
         p.chi2[f] = chi2;
@@ -551,6 +555,7 @@ __global__ void __launch_bounds__(SYS_NT) k_system(SysParams p) {
         const bool reject = chi2 > thr; // :225
         hq[57] = reject ? 1.0 : 0.0;
         if (reject) p.status[f] = OVGPU_FEAT_CHI2_REJECTED;
+        if (p.init) p.init_flag[0] = reject ? 0 : 1;
       }
     }
     __syncthreads();
@@ -589,7 +594,7 @@ __global__ void __launch_bounds__(SYS_NT) k_system(SysParams p) {
           else if (r > k) v = rows[(size_t)(r >> 1) * RS + RO_HF + 3 * (r & 1) + k] * scale;
           V[(size_t)r * 3 + k] = v;
         }
-        if (lane == 0) hq[k] = tau;
+        if (lane == 0) hq[k] = tau, hq[58 + k] = beta; // beta_k = R1[k][k]
         // apply H_k to the remaining columns of H_f
         for (int c = k + 1; c < 3; c++) {
           double w = 0.0;
@@ -665,6 +670,13 @@ __global__ void __launch_bounds__(SYS_NT) k_system(SysParams p) {
         }
         // z = T^T y
         const double z0 = T00 * y0, z1 = T01 * y0 + T11 * y1, z2 = T02 * y0 + T12 * y1 + T22 * y2;
+        if (p.init) { // StateHelper.cpp:445-448: the 3 rows that determine the new variable, [Hxinit | resinit]
+#pragma unroll
+          for (int r = 0; r < 3; r++) {
+            const double *v = V + (size_t)3 * r;
+            p.init_out[(size_t)r * LD + c] = hval(r >> 1, r & 1) - (v[0] * z0 + v[1] * z1 + v[2] * z2);
+          }
+        }
         double *out = p.Hbig + orow0 * LD + c;
 #pragma unroll 4
         for (int r = 3; r < n; r++) {
@@ -673,6 +685,10 @@ __global__ void __launch_bounds__(SYS_NT) k_system(SysParams p) {
           out[(size_t)(r - 3) * LD] = h - (v[0] * z0 + v[1] * z1 + v[2] * z2);
         }
       }
+    }
+    if (p.init && tid < 9) { // H_finit = R1 (3 x 3 upper triangular): Q^T H_f, diagonal = beta
+      const int i = tid / 3, j = tid % 3;
+      p.init_out[(size_t)3 * LD + tid] = j < i ? 0.0 : (j == i ? hq[58 + i] : rows[(size_t)(i >> 1) * RS + RO_HF + 3 * (i & 1) + j]);
     }
     SYS_T(8)
   }

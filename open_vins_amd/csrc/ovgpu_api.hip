@@ -19,6 +19,7 @@
 #include "k_tsqr.h"
 #include "k_tsqr_pw.h"
 #include "k_ekf.h"
+#include "k_slam.h"
 #include "k_system.h"
 #include "k_triangulate.h"
 #include "ovgpu_types.h"
@@ -53,6 +54,17 @@ struct DevBuf {
     cap = 0;
     hipError_t e = hipMalloc((void **)&p, std::max<size_t>(n, 1) * sizeof(T));
     if (e == hipSuccess) cap = n;
+    return e;
+  }
+  // like reserve, but the first `keep` elements survive a reallocation
+  hipError_t grow(size_t n, size_t keep) {
+    if (n <= cap) return hipSuccess;
+    T *q = nullptr;
+    hipError_t e = hipMalloc((void **)&q, n * sizeof(T));
+    if (e != hipSuccess) return e;
+    if (p && keep > 0) e = hipMemcpy(q, p, std::min(keep, cap) * sizeof(T), hipMemcpyDeviceToDevice);
+    if (p) (void)hipFree(p);
+    p = q, cap = n;
     return e;
   }
   void release() {
@@ -91,10 +103,14 @@ struct ovgpu_ctx {
   std::vector<HVar> h_vars; // clones + calibrated camera variables of the resident state (landmarks are merged in by build_columns)
   // SLAM landmarks (ovgpu_set_landmarks); L > 0 switches the per-feature kernel to the UpdaterSLAM rules
   int L = 0;
+  int lm_rep = OVGPU_REP_GLOBAL_3D; // representation of the resident landmarks (StateOptions::feat_rep_slam)
   std::vector<int32_t> h_lm_cov, h_lm_col;
-  std::vector<double> h_lm_value, h_lm_fej;
-  DevBuf<double> pFej, lm_pos;
-  DevBuf<int32_t> feat_lm, feat_lmcol, feat_lmcov, lm_cov;
+  DevBuf<double> pFej, lm_val, lm_fej; // landmark values in representation coordinates (ov_type::Landmark::value / fej)
+  DevBuf<int32_t> feat_lm, feat_lmcol, feat_lmcov, feat_anchor, lm_cov, lm_col, lm_anchor, lm_index;
+  bool slam_rows = false; // row layout of the uploaded batch: 2m rows per feature (SLAM update) or 2m - 3 (MSCKF, delayed init)
+  // UpdaterSLAM::delayed_init
+  DevBuf<double> Ppad, init_ws, dx_seq;
+  DevBuf<int32_t> init_ctr, feat_slot;
 
   // ---- features
   bool have_feats = false;
@@ -113,6 +129,7 @@ struct ovgpu_ctx {
   int chi2_table_len = 0;
   std::vector<double> h_chi2_table;
   std::vector<int32_t> h_offsets;
+  std::vector<int64_t> h_row_off;
 
   // ---- workspaces
   DevBuf<double> Hbig, gate_ws, Rws, Mt, Aaug, Yaug, dx;
@@ -304,7 +321,9 @@ void ovgpu_destroy(ovgpu_ctx *c) {
   c->meas_offsets.release(), c->meas_cc.release(), c->uv.release(), c->uvn.release(), c->row_off.release();
   c->pA.release(), c->pG.release(), c->chi2.release(), c->chi2_thr.release(), c->anchor.release(), c->status.release();
   c->chi2_table.release(), c->Hbig.release(), c->gate_ws.release(), c->Rws.release(), c->tree_nodes.release(), c->tree_nodes2.release(), c->tree_flags.release(), c->tree_err.release(), c->Mt.release(), c->Aaug.release(), c->Yaug.release();
-  c->pFej.release(), c->lm_pos.release(), c->feat_lm.release(), c->feat_lmcol.release(), c->feat_lmcov.release(), c->lm_cov.release();
+  c->pFej.release(), c->lm_val.release(), c->lm_fej.release(), c->feat_lm.release(), c->feat_lmcol.release(), c->feat_lmcov.release(), c->lm_cov.release();
+  c->feat_anchor.release(), c->lm_col.release(), c->lm_anchor.release(), c->lm_index.release(), c->Ppad.release(), c->init_ws.release(), c->dx_seq.release();
+  c->init_ctr.release(), c->feat_slot.release();
   c->dx.release(), c->flags.release(), c->given_status.release();
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
@@ -366,6 +385,7 @@ static int build_columns(ovgpu_ctx *c) {
   HIPCHK(upload(c->col_kind.p, col_kind.data(), D, s));
   HIPCHK(upload(c->col_sub.p, col_sub.data(), D, s));
   HIPCHK(upload(c->col_var.p, col_var.data(), sizeof(uint16_t) * D, s));
+  if (c->L > 0) HIPCHK(upload(c->lm_col.p, c->h_lm_col.data(), sizeof(int32_t) * c->L, s));
   HIPCHK(hipStreamSynchronize(s)); // host staging vectors go out of scope
   c->have_feats = false;           // workspaces depend on D
   return OVGPU_OK;
@@ -389,7 +409,8 @@ int ovgpu_set_state(ovgpu_ctx *c, const ovgpu_state_view *st) {
   }
   for (int i = 0; i < C; i++) c->h_vars.push_back({st->clone_cov_id[i], 6, COL_CLONE, i});
   c->N = N, c->C = C, c->K = K;
-  c->L = 0, c->h_lm_cov.clear(), c->h_lm_col.clear();
+  c->L = 0, c->lm_rep = OVGPU_REP_GLOBAL_3D, c->h_lm_cov.clear(), c->h_lm_col.clear();
+  c->row_stride = (c->dopt.feat_rep >= OVGPU_REP_ANCHORED_3D) ? 72 : 48;
   HIPCHK(c->clone_col.reserve(C));
   HIPCHK(c->calib_col.reserve(K));
   HIPCHK(c->intr_col.reserve(K));
@@ -497,56 +518,20 @@ int ovgpu_set_camera_poses(ovgpu_ctx *c, int C, int K, const double *R_GtoC, con
   return OVGPU_OK;
 }
 
-int ovgpu_set_features(ovgpu_ctx *c, const ovgpu_features_view *fv) {
-  if (!c || !fv) return set_err(OVGPU_ERR_INVALID, "null argument");
-  if (!c->have_state) return set_err(OVGPU_ERR_NO_STATE, "ovgpu_set_state must precede ovgpu_set_features");
-  if (fv->F < 0 || fv->M < 0) return set_err(OVGPU_ERR_INVALID, "negative sizes");
-  if (fv->F > 0 && (!fv->meas_offsets)) return set_err(OVGPU_ERR_INVALID, "null feature arrays");
-  if (fv->M > 0 && (!fv->uv || !fv->uvn || !fv->clone_idx || !fv->cam_idx)) return set_err(OVGPU_ERR_INVALID, "null measurement arrays");
-  HIPCHK(hipSetDevice(c->device));
-  const int F = fv->F, M = fv->M;
-  if (F > 0 && (fv->meas_offsets[0] != 0 || fv->meas_offsets[F] != M)) return set_err(OVGPU_ERR_INVALID, "meas_offsets must span [0, M]");
-  std::vector<uint16_t> cc(std::max(M, 1));
-  for (int i = 0; i < M; i++) {
-    const int cl = fv->clone_idx[i], cam = fv->cam_idx[i];
-    if (cl < 0 || cl >= c->C || cam < 0 || cam >= c->K) return set_err(OVGPU_ERR_INVALID, "measurement refers to an unknown clone / camera");
-    cc[i] = (uint16_t)((cam << 10) | cl);
-  }
+// Row layout of the stacked system for the uploaded tracks, the per-feature kernel's LDS carve and the TSQR leaf layout.
+//   MSCKF / delayed init: 2m - 3 rows per feature after the nullspace projection (UpdaterHelper.cpp:449-450);
+//   SLAM update: all 2m rows (UpdaterSLAM.cpp:381-383).
+static int set_row_layout(ovgpu_ctx *c, bool slam_rows) {
+  const int F = c->F;
   std::vector<int64_t> row_off(F + 1, 0);
-  int m_max = 0;
   for (int f = 0; f < F; f++) {
-    const int m = fv->meas_offsets[f + 1] - fv->meas_offsets[f];
-    if (m < 0) return set_err(OVGPU_ERR_INVALID, "meas_offsets not monotone");
-    m_max = std::max(m_max, m);
-    // MSCKF: rows after the nullspace projection (UpdaterHelper.cpp:449-450); SLAM (landmarks resident): all 2m rows (UpdaterSLAM.cpp:381-383)
-    row_off[f + 1] = row_off[f] + (c->L > 0 ? (m >= 1 ? 2 * m : 0) : (m >= 2 ? 2 * m - 3 : 0));
+    const int m = c->h_offsets[f + 1] - c->h_offsets[f];
+    row_off[f + 1] = row_off[f] + (slam_rows ? (m >= 1 ? 2 * m : 0) : (m >= 2 ? 2 * m - 3 : 0));
   }
-  c->F = F, c->M = M, c->m_max = m_max, c->rows_total = row_off[F];
-  c->h_offsets.assign(fv->meas_offsets, fv->meas_offsets + (F > 0 ? F + 1 : 0));
-  if (F == 0) c->h_offsets.assign(1, 0);
-
-  // chi2 table for dof 1 .. max(499, 2 m_max)  (UpdaterMSCKF.cpp:52-55; dof >= 500 is computed on the fly there, :216-222)
-  const int need = std::max(500, 2 * m_max + 1);
-  if ((int)c->h_chi2_table.size() < need) {
-    const int old = (int)c->h_chi2_table.size();
-    c->h_chi2_table.resize(need, 0.0);
-    for (int i = std::max(old, 1); i < need; i++) c->h_chi2_table[i] = chi2_quantile_95(i);
-  }
-  c->chi2_table_len = (int)c->h_chi2_table.size();
-  HIPCHK(c->chi2_table.reserve(c->chi2_table_len));
-
-  HIPCHK(c->meas_offsets.reserve(F + 1));
-  HIPCHK(c->meas_cc.reserve(M));
-  HIPCHK(c->uv.reserve((size_t)2 * M));
-  HIPCHK(c->uvn.reserve((size_t)2 * M));
-  HIPCHK(c->row_off.reserve(F + 1));
-  HIPCHK(c->pA.reserve((size_t)3 * F));
-  HIPCHK(c->pG.reserve((size_t)3 * F));
-  HIPCHK(c->chi2.reserve(F));
-  HIPCHK(c->chi2_thr.reserve(F));
-  HIPCHK(c->anchor.reserve(F));
-  HIPCHK(c->status.reserve(F));
-
+  c->rows_total = row_off[F];
+  c->h_row_off = row_off;
+  c->slam_rows = slam_rows;
+  const int m_max = c->m_max;
   // ---- per-feature kernel: LDS carve and (for long tracks) a global gate workspace
   const size_t fixed = sys_lds_fixed_bytes(std::max(m_max, 1), c->row_stride, c->D);
   int m_lds = 0;
@@ -566,19 +551,71 @@ int ovgpu_set_features(ovgpu_ctx *c, const ovgpu_features_view *fv) {
     c->gate_ws_stride = 0;
   }
   // ---- stacked system and TSQR accumulators
-  {
-    const int rct = configure_tsqr(c);
-    if (rct != OVGPU_OK) return rct;
+  const int rct = configure_tsqr(c);
+  if (rct != OVGPU_OK) return rct;
+  HIPCHK(c->row_off.reserve(F + 1));
+  HIPCHK(upload(c->row_off.p, row_off.data(), sizeof(int64_t) * (F + 1), c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return OVGPU_OK;
+}
+
+int ovgpu_set_features(ovgpu_ctx *c, const ovgpu_features_view *fv) {
+  if (!c || !fv) return set_err(OVGPU_ERR_INVALID, "null argument");
+  if (!c->have_state) return set_err(OVGPU_ERR_NO_STATE, "ovgpu_set_state must precede ovgpu_set_features");
+  if (fv->F < 0 || fv->M < 0) return set_err(OVGPU_ERR_INVALID, "negative sizes");
+  if (fv->F > 0 && (!fv->meas_offsets)) return set_err(OVGPU_ERR_INVALID, "null feature arrays");
+  if (fv->M > 0 && (!fv->uv || !fv->uvn || !fv->clone_idx || !fv->cam_idx)) return set_err(OVGPU_ERR_INVALID, "null measurement arrays");
+  HIPCHK(hipSetDevice(c->device));
+  const int F = fv->F, M = fv->M;
+  if (F > 0 && (fv->meas_offsets[0] != 0 || fv->meas_offsets[F] != M)) return set_err(OVGPU_ERR_INVALID, "meas_offsets must span [0, M]");
+  std::vector<uint16_t> cc(std::max(M, 1));
+  for (int i = 0; i < M; i++) {
+    const int cl = fv->clone_idx[i], cam = fv->cam_idx[i];
+    if (cl < 0 || cl >= c->C || cam < 0 || cam >= c->K) return set_err(OVGPU_ERR_INVALID, "measurement refers to an unknown clone / camera");
+    cc[i] = (uint16_t)((cam << 10) | cl);
   }
+  int m_max = 0;
+  for (int f = 0; f < F; f++) {
+    const int m = fv->meas_offsets[f + 1] - fv->meas_offsets[f];
+    if (m < 0) return set_err(OVGPU_ERR_INVALID, "meas_offsets not monotone");
+    m_max = std::max(m_max, m);
+  }
+  c->F = F, c->M = M, c->m_max = m_max;
+  c->h_offsets.assign(fv->meas_offsets, fv->meas_offsets + (F > 0 ? F + 1 : 0));
+  if (F == 0) c->h_offsets.assign(1, 0);
+
+  // chi2 table for dof 1 .. max(499, 2 m_max)  (UpdaterMSCKF.cpp:52-55; dof >= 500 is computed on the fly there, :216-222)
+  const int need = std::max(500, 2 * m_max + 1);
+  if ((int)c->h_chi2_table.size() < need) {
+    const int old = (int)c->h_chi2_table.size();
+    c->h_chi2_table.resize(need, 0.0);
+    for (int i = std::max(old, 1); i < need; i++) c->h_chi2_table[i] = chi2_quantile_95(i);
+  }
+  c->chi2_table_len = (int)c->h_chi2_table.size();
+  HIPCHK(c->chi2_table.reserve(c->chi2_table_len));
+
+  HIPCHK(c->meas_offsets.reserve(F + 1));
+  HIPCHK(c->meas_cc.reserve(M));
+  HIPCHK(c->uv.reserve((size_t)2 * M));
+  HIPCHK(c->uvn.reserve((size_t)2 * M));
+  HIPCHK(c->pA.reserve((size_t)3 * F));
+  HIPCHK(c->pG.reserve((size_t)3 * F));
+  HIPCHK(c->chi2.reserve(F));
+  HIPCHK(c->chi2_thr.reserve(F));
+  HIPCHK(c->anchor.reserve(F));
+  HIPCHK(c->status.reserve(F));
 
   hipStream_t s = c->stream;
   HIPCHK(upload(c->meas_offsets.p, fv->meas_offsets, sizeof(int32_t) * (F + 1), s));
   HIPCHK(upload(c->meas_cc.p, cc.data(), sizeof(uint16_t) * M, s));
   HIPCHK(upload(c->uv.p, fv->uv, sizeof(float) * 2 * M, s));
   HIPCHK(upload(c->uvn.p, fv->uvn, sizeof(float) * 2 * M, s));
-  HIPCHK(upload(c->row_off.p, row_off.data(), sizeof(int64_t) * (F + 1), s));
   HIPCHK(upload(c->chi2_table.p, c->h_chi2_table.data(), sizeof(double) * c->chi2_table_len, s));
   HIPCHK(hipStreamSynchronize(s)); // host staging vectors go out of scope
+  // rows of the stacked system: SLAM layout when landmarks are resident (the batch is for ovgpu_slam_update), MSCKF otherwise;
+  // an entry point that needs the other layout switches it (set_row_layout)
+  const int rcl = set_row_layout(c, c->L > 0);
+  if (rcl != OVGPU_OK) return rcl;
   c->have_feats = true;
   c->given_tri = false;
   return OVGPU_OK;
@@ -600,7 +637,8 @@ static int enqueue_triangulate(ovgpu_ctx *c) {
   return OVGPU_OK;
 }
 
-static int enqueue_system(ovgpu_ctx *c) {
+// f_one >= 0: only that feature, in StateHelper::initialize mode with the landmark representation init_rep
+static int enqueue_system(ovgpu_ctx *c, int f_one = -1, int init_rep = 0) {
   if (c->F == 0) return OVGPU_OK;
   SysParams p;
   p.F = c->F, p.C = c->C, p.K = c->K, p.D = c->D, p.LD = c->LD, p.N = c->N;
@@ -615,9 +653,17 @@ static int enqueue_system(ovgpu_ctx *c) {
   p.m_lds_max = c->m_lds_max, p.m_max = std::max(c->m_max, 1), p.row_stride = c->row_stride;
   p.opt = c->dopt;
   p.dbg = qr_dbg_buffer();
-  p.slam = c->L > 0 ? 1 : 0;
-  p.p_fej = c->pFej.p, p.feat_lm = c->feat_lm.p, p.feat_lmcol = c->feat_lmcol.p, p.feat_lmcov = c->feat_lmcov.p;
-  hipLaunchKernelGGL(k_system, dim3(c->sys_grid), dim3(SYS_NT), c->sys_lds_bytes, c->stream, p);
+  p.slam = c->slam_rows ? 1 : 0;
+  p.p_fej = c->pFej.p, p.feat_lm = c->feat_lm.p, p.feat_lmcol = c->feat_lmcol.p, p.feat_lmcov = c->feat_lmcov.p, p.feat_anchor = c->feat_anchor.p;
+  if (p.slam) p.opt.feat_rep = c->lm_rep; // the landmarks' representation, not the MSCKF features'
+  p.f_begin = 0, p.f_end = c->F, p.init = 0, p.init_out = nullptr, p.init_flag = nullptr;
+  int grid = c->sys_grid;
+  if (f_one >= 0) {
+    p.f_begin = f_one, p.f_end = f_one + 1, p.init = 1, p.init_out = c->init_ws.p, p.init_flag = c->init_ctr.p + 2;
+    p.opt.feat_rep = init_rep;
+    grid = 1;
+  }
+  hipLaunchKernelGGL(k_system, dim3(grid), dim3(SYS_NT), c->sys_lds_bytes, c->stream, p);
   HIPCHK(hipGetLastError());
   return OVGPU_OK;
 }
@@ -751,13 +797,25 @@ static int enqueue_compress(ovgpu_ctx *c) {
   return enqueue_merge_tree(c, W);
 }
 
-static int enqueue_ekf(ovgpu_ctx *c, const int32_t *col_cov_dev = nullptr, double sigma2 = -1.0) {
+struct EkfJob {
+  const double *R = nullptr;          // system rows [rows x LD]; nullptr: the compressed triangle in c->Rws
+  int rows = -1;                      // -1: c->D (upper triangular)
+  const int32_t *col_cov = nullptr;   // nullptr: the context's column map
+  double sigma2 = -1.0;               // < 0: the context's sigma_pix^2
+  const int32_t *pred = nullptr;      // device flag: skip everything when 0
+  double *dx = nullptr;               // nullptr: c->dx
+  bool keep_flags = false;            // do not clear the sticky error flags (a chain of updates)
+};
+
+static int enqueue_ekf(ovgpu_ctx *c, const EkfJob &job = EkfJob()) {
   EkfParams p;
-  p.N = c->N, p.D = c->D, p.LD = c->LD, p.LA = c->D + c->N + 1;
-  p.R = c->Rws.p, p.col_cov = col_cov_dev ? col_cov_dev : c->col_cov.p, p.P = c->P.p, p.Mt = c->Mt.p, p.A = c->Aaug.p, p.Y = c->Yaug.p, p.dx = c->dx.p, p.flags = c->flags.p;
-  p.sigma2 = sigma2 >= 0.0 ? sigma2 : c->dopt.sigma_pix_sq;
+  const bool tri = job.R == nullptr;
+  p.N = c->N, p.D = tri ? c->D : job.rows, p.DC = c->D, p.LD = c->LD, p.LA = p.D + c->N + 1, p.tri = tri ? 1 : 0, p.pred = job.pred;
+  p.R = tri ? c->Rws.p : job.R, p.col_cov = job.col_cov ? job.col_cov : c->col_cov.p, p.P = c->P.p, p.Mt = c->Mt.p, p.A = c->Aaug.p, p.Y = c->Yaug.p;
+  p.dx = job.dx ? job.dx : c->dx.p, p.flags = c->flags.p;
+  p.sigma2 = job.sigma2 >= 0.0 ? job.sigma2 : c->dopt.sigma_pix_sq;
   hipStream_t s = c->stream;
-  HIPCHK(hipMemsetAsync(c->flags.p, 0, 4 * sizeof(int32_t), s));
+  if (!job.keep_flags) HIPCHK(hipMemsetAsync(c->flags.p, 0, 4 * sizeof(int32_t), s));
   const int tm = (p.D + 15) / 16, tn = (p.N + 15) / 16;
   hipLaunchKernelGGL(k_ekf_mt, dim3((tm * tn + 3) / 4), dim3(256), 0, s, p);
   hipLaunchKernelGGL(k_ekf_s, dim3((tm * tm + 3) / 4), dim3(256), 0, s, p);
@@ -774,8 +832,8 @@ static int enqueue_ekf(ovgpu_ctx *c, const int32_t *col_cov_dev = nullptr, doubl
   hipLaunchKernelGGL(k_ekf_pupdate, dim3((tn * tn + 3) / 4), dim3(256), 0, s, p);
   hipLaunchKernelGGL(k_ekf_dx, dim3((p.N + 255) / 256), dim3(256), 0, s, p);
   const int n = std::max(c->C, c->K);
-  hipLaunchKernelGGL(k_boxplus, dim3((n + 255) / 256), dim3(256), 0, s, c->C, c->K, c->dx.p, c->clone_cov.p, c->calib_cov.p, c->intr_cov.p,
-                     c->clone_qp.p, c->calib_qp.p, c->intr.p);
+  hipLaunchKernelGGL(k_boxplus, dim3((n + 255) / 256), dim3(256), 0, s, c->C, c->K, p.dx, c->clone_cov.p, c->calib_cov.p, c->intr_cov.p,
+                     c->clone_qp.p, c->calib_qp.p, c->intr.p, job.pred);
   HIPCHK(hipGetLastError());
   return launch_build_tables(c);
 }
@@ -794,10 +852,14 @@ static EventPair *next_events(ovgpu_ctx *c, std::vector<EventPair> &v, size_t id
 
 enum { STAGE_LOCAL = 1, STAGE_EKF = 2 };
 
-static int enqueue_pipeline(ovgpu_ctx *c, int stages) {
+static int enqueue_pipeline(ovgpu_ctx *c, int stages, bool slam = false) {
   if (!c->have_state || c->poses_only) return set_err(OVGPU_ERR_NO_STATE, "ovgpu_set_state was never called");
   if (!c->have_feats) return set_err(OVGPU_ERR_NO_STATE, "ovgpu_set_features was never called (or the state changed since)");
   HIPCHK(hipSetDevice(c->device));
+  if (c->slam_rows != slam) { // the batch was laid out for the other updater
+    const int rcl = set_row_layout(c, slam);
+    if (rcl != OVGPU_OK) return rcl;
+  }
   EventPair *eu = nullptr, *ec = nullptr;
   if (c->timing) {
     eu = next_events(c, c->ev_update, c->ev_used);
@@ -840,7 +902,7 @@ static int read_feature_outputs(ovgpu_ctx *c, int32_t *feat_status, double *chi2
   for (int f = 0; f < F; f++) {
     if (st[f] == OVGPU_FEAT_USED) {
       n_used++;
-      rows += 2 * (offs[f + 1] - offs[f]) - (c->L > 0 ? 0 : 3); // SLAM stacks all 2m rows (no nullspace projection)
+      rows += 2 * (offs[f + 1] - offs[f]) - (c->slam_rows ? 0 : 3); // SLAM stacks all 2m rows (no nullspace projection)
     }
     // the gate is only reached by features that triangulated
     if (st[f] != OVGPU_FEAT_USED && st[f] != OVGPU_FEAT_CHI2_REJECTED) {
@@ -956,11 +1018,11 @@ int ovgpu_msckf_update_async(ovgpu_ctx *c) {
   return enqueue_pipeline(c, STAGE_LOCAL | STAGE_EKF);
 }
 
-int ovgpu_msckf_compress(ovgpu_ctx *c, int32_t *feat_status, double *chi2, double *chi2_thresh, double *p_FinG, int32_t *D_out, int32_t *rows_out,
-                         int32_t *col_cov_id, double *H, double *r, ovgpu_update_stats *stats) {
+static int compress_impl(ovgpu_ctx *c, bool slam, int32_t *feat_status, double *chi2, double *chi2_thresh, double *p_FinG, int32_t *D_out,
+                         int32_t *rows_out, int32_t *col_cov_id, double *H, double *r, ovgpu_update_stats *stats) {
   if (!c) return set_err(OVGPU_ERR_INVALID, "null ctx");
   if (stats) std::memset(stats, 0, sizeof(*stats));
-  int rc = enqueue_pipeline(c, STAGE_LOCAL);
+  int rc = enqueue_pipeline(c, STAGE_LOCAL, slam);
   if (rc != OVGPU_OK) return rc;
   ovgpu_update_stats local;
   std::memset(&local, 0, sizeof(local));
@@ -982,6 +1044,11 @@ int ovgpu_msckf_compress(ovgpu_ctx *c, int32_t *feat_status, double *chi2, doubl
   return check_tree_error(c);
 }
 
+int ovgpu_msckf_compress(ovgpu_ctx *c, int32_t *feat_status, double *chi2, double *chi2_thresh, double *p_FinG, int32_t *D_out, int32_t *rows_out,
+                         int32_t *col_cov_id, double *H, double *r, ovgpu_update_stats *stats) {
+  return compress_impl(c, false, feat_status, chi2, chi2_thresh, p_FinG, D_out, rows_out, col_cov_id, H, r, stats);
+}
+
 int ovgpu_get_state(ovgpu_ctx *c, double *P, double *clone_q_p, double *calib_q_p, double *intrinsics) {
   if (!c) return set_err(OVGPU_ERR_INVALID, "null ctx");
   if (!c->have_state || c->poses_only) return set_err(OVGPU_ERR_NO_STATE, "ovgpu_set_state was never called");
@@ -999,32 +1066,71 @@ int ovgpu_get_state(ovgpu_ctx *c, double *P, double *clone_q_p, double *calib_q_
 // ---------------------------------------------------------------------------
 // UpdaterSLAM::update (UpdaterSLAM.cpp:253-479), GLOBAL_3D landmarks
 // ---------------------------------------------------------------------------
+static LandmarkStore landmark_store(ovgpu_ctx *c) { return LandmarkStore{c->lm_val.p, c->lm_fej.p, c->lm_cov.p, c->lm_col.p, c->lm_anchor.p}; }
+
+static int reserve_landmarks(ovgpu_ctx *c, int cap, int keep) {
+  const size_t n = (size_t)std::max(cap, 1);
+  HIPCHK(c->lm_val.grow(3 * n, 3 * (size_t)keep));
+  HIPCHK(c->lm_fej.grow(3 * n, 3 * (size_t)keep));
+  HIPCHK(c->lm_cov.grow(n, keep));
+  HIPCHK(c->lm_col.grow(n, keep));
+  HIPCHK(c->lm_anchor.grow(n, keep));
+  return OVGPU_OK;
+}
+
 int ovgpu_set_landmarks(ovgpu_ctx *c, const ovgpu_landmarks_view *lm) {
   if (!c || !lm) return set_err(OVGPU_ERR_INVALID, "null argument");
   if (!c->have_state || c->poses_only) return set_err(OVGPU_ERR_NO_STATE, "ovgpu_set_state must precede ovgpu_set_landmarks");
   if (lm->L < 0 || lm->L > 4096) return set_err(OVGPU_ERR_INVALID, "bad landmark count");
   if (lm->L > 0 && (!lm->p_value || !lm->p_fej || !lm->cov_id)) return set_err(OVGPU_ERR_INVALID, "null landmark arrays");
-  if (c->dopt.feat_rep != OVGPU_REP_GLOBAL_3D) return set_err(OVGPU_ERR_INVALID, "SLAM landmarks are supported in the GLOBAL_3D representation only");
+  if (lm->feat_rep < OVGPU_REP_GLOBAL_3D || lm->feat_rep > OVGPU_REP_ANCHORED_MSCKF_INVERSE_DEPTH)
+    return set_err(OVGPU_ERR_INVALID, "SLAM landmarks: 3-dof representations only (ANCHORED_INVERSE_DEPTH_SINGLE is not supported)");
+  const bool relative = lm->feat_rep >= OVGPU_REP_ANCHORED_3D;
+  if (relative && lm->L > 0 && (!lm->anchor_cam || !lm->anchor_clone)) return set_err(OVGPU_ERR_INVALID, "anchored landmarks need anchor_cam / anchor_clone");
+  std::vector<int32_t> anc(std::max(lm->L, 1), -1);
+  for (int l = 0; l < lm->L && relative; l++) {
+    if (lm->anchor_cam[l] < 0 || lm->anchor_cam[l] >= c->K || lm->anchor_clone[l] < 0 || lm->anchor_clone[l] >= c->C)
+      return set_err(OVGPU_ERR_INVALID, "landmark anchor refers to an unknown clone / camera");
+    anc[l] = (lm->anchor_cam[l] << 10) | lm->anchor_clone[l];
+  }
   HIPCHK(hipSetDevice(c->device));
-  c->L = lm->L;
+  c->L = lm->L, c->lm_rep = lm->feat_rep;
+  c->row_stride = (relative || c->dopt.feat_rep >= OVGPU_REP_ANCHORED_3D) ? 72 : 48;
   c->h_lm_cov.assign(lm->cov_id, lm->cov_id + lm->L);
-  c->h_lm_value.assign(lm->p_value, lm->p_value + 3 * (size_t)lm->L);
-  c->h_lm_fej.assign(lm->p_fej, lm->p_fej + 3 * (size_t)lm->L);
-  HIPCHK(c->lm_pos.reserve(3 * (size_t)std::max(lm->L, 1)));
-  HIPCHK(c->lm_cov.reserve(std::max(lm->L, 1)));
+  int rc = reserve_landmarks(c, lm->L, 0);
+  if (rc != OVGPU_OK) return rc;
   if (lm->L > 0) {
-    HIPCHK(upload(c->lm_pos.p, c->h_lm_value.data(), sizeof(double) * 3 * lm->L, c->stream));
+    HIPCHK(upload(c->lm_val.p, lm->p_value, sizeof(double) * 3 * lm->L, c->stream));
+    HIPCHK(upload(c->lm_fej.p, lm->p_fej, sizeof(double) * 3 * lm->L, c->stream));
     HIPCHK(upload(c->lm_cov.p, c->h_lm_cov.data(), sizeof(int32_t) * lm->L, c->stream));
+    HIPCHK(upload(c->lm_anchor.p, anc.data(), sizeof(int32_t) * lm->L, c->stream));
   }
   return build_columns(c); // synchronises; the feature batch has to be uploaded again (row counts and D changed)
 }
 
-__global__ void k_landmark_update(int L, const double *__restrict__ dx, const int32_t *__restrict__ lm_cov, double *lm_pos) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x; // Landmark::update for a 3-dof global position: additive (Landmark.h:80-89)
-  if (t < 3 * L) lm_pos[t] += dx[lm_cov[t / 3] + t % 3];
+int ovgpu_get_landmarks(ovgpu_ctx *c, int32_t *L_out, double *value, double *fej, int32_t *cov_id, int32_t *anchor_cam, int32_t *anchor_clone) {
+  if (!c) return set_err(OVGPU_ERR_INVALID, "null ctx");
+  HIPCHK(hipSetDevice(c->device));
+  const int L = c->L;
+  if (L_out) *L_out = L;
+  hipStream_t s = c->stream;
+  std::vector<int32_t> anc(std::max(L, 1), -1);
+  if (L > 0) {
+    if (value) HIPCHK(hipMemcpyAsync(value, c->lm_val.p, sizeof(double) * 3 * L, hipMemcpyDeviceToHost, s));
+    if (fej) HIPCHK(hipMemcpyAsync(fej, c->lm_fej.p, sizeof(double) * 3 * L, hipMemcpyDeviceToHost, s));
+    if (cov_id) HIPCHK(hipMemcpyAsync(cov_id, c->lm_cov.p, sizeof(int32_t) * L, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(anc.data(), c->lm_anchor.p, sizeof(int32_t) * L, hipMemcpyDeviceToHost, s));
+  }
+  HIPCHK(hipStreamSynchronize(s));
+  for (int l = 0; l < L; l++) {
+    if (anchor_cam) anchor_cam[l] = anc[l] >= 0 ? anc[l] >> 10 : -1;
+    if (anchor_clone) anchor_clone[l] = anc[l] >= 0 ? (anc[l] & 1023) : -1;
+  }
+  return OVGPU_OK;
 }
 
-// per-feature landmark data of a SLAM batch -> device; the triangulation stage is replaced by the state's landmark estimates
+// per-feature landmark data of a SLAM batch, gathered on the device from the resident landmarks; the triangulation stage
+// is replaced by the state's landmark estimates
 static int slam_prepare(ovgpu_ctx *c, const int32_t *lm_index, ovgpu_update_stats *stats) {
   if (!c) return set_err(OVGPU_ERR_INVALID, "null ctx");
   if (c->L <= 0) return set_err(OVGPU_ERR_NO_STATE, "ovgpu_set_landmarks was never called");
@@ -1034,29 +1140,22 @@ static int slam_prepare(ovgpu_ctx *c, const int32_t *lm_index, ovgpu_update_stat
   if (stats) std::memset(stats, 0, sizeof(*stats));
   const int F = c->F;
   hipStream_t s = c->stream;
-  // per-feature landmark data; a feature without measurements is dropped (UpdaterSLAM.cpp:289-291)
-  std::vector<double> pg(3 * (size_t)std::max(F, 1)), pf(3 * (size_t)std::max(F, 1));
-  std::vector<int32_t> flm(std::max(F, 1)), fcol(std::max(F, 1)), fcov(std::max(F, 1)), st(std::max(F, 1));
-  for (int f = 0; f < F; f++) {
-    const int l = lm_index[f];
-    if (l < 0 || l >= c->L) return set_err(OVGPU_ERR_INVALID, "lm_index out of range");
-    for (int i = 0; i < 3; i++) pg[3 * f + i] = c->h_lm_value[3 * l + i], pf[3 * f + i] = c->h_lm_fej[3 * l + i];
-    flm[f] = l, fcol[f] = c->h_lm_col[l], fcov[f] = c->h_lm_cov[l];
-    st[f] = (c->h_offsets[f + 1] - c->h_offsets[f] >= 1) ? OVGPU_FEAT_USED : OVGPU_FEAT_TOO_FEW_MEAS;
-  }
-  HIPCHK(c->pFej.reserve(3 * (size_t)std::max(F, 1)));
-  HIPCHK(c->feat_lm.reserve(std::max(F, 1)));
-  HIPCHK(c->feat_lmcol.reserve(std::max(F, 1)));
-  HIPCHK(c->feat_lmcov.reserve(std::max(F, 1)));
-  HIPCHK(c->given_status.reserve(std::max(F, 1)));
+  for (int f = 0; f < F; f++)
+    if (lm_index[f] < 0 || lm_index[f] >= c->L) return set_err(OVGPU_ERR_INVALID, "lm_index out of range");
+  const size_t n = (size_t)std::max(F, 1);
+  HIPCHK(c->pFej.reserve(3 * n));
+  HIPCHK(c->feat_lm.reserve(n));
+  HIPCHK(c->feat_lmcol.reserve(n));
+  HIPCHK(c->feat_lmcov.reserve(n));
+  HIPCHK(c->feat_anchor.reserve(n));
+  HIPCHK(c->lm_index.reserve(n));
+  HIPCHK(c->given_status.reserve(n));
   if (F > 0) {
-    HIPCHK(upload(c->pG.p, pg.data(), sizeof(double) * 3 * F, s));
-    HIPCHK(upload(c->pFej.p, pf.data(), sizeof(double) * 3 * F, s));
-    HIPCHK(upload(c->feat_lm.p, flm.data(), sizeof(int32_t) * F, s));
-    HIPCHK(upload(c->feat_lmcol.p, fcol.data(), sizeof(int32_t) * F, s));
-    HIPCHK(upload(c->feat_lmcov.p, fcov.data(), sizeof(int32_t) * F, s));
-    HIPCHK(upload(c->given_status.p, st.data(), sizeof(int32_t) * F, s));
+    HIPCHK(upload(c->lm_index.p, lm_index, sizeof(int32_t) * F, s));
     HIPCHK(hipStreamSynchronize(s));
+    hipLaunchKernelGGL(k_slam_gather, dim3((F + 255) / 256), dim3(256), 0, s, F, c->lm_rep, c->lm_index.p, c->meas_offsets.p, landmark_store(c), c->pG.p,
+                       c->pA.p, c->pFej.p, c->feat_lm.p, c->feat_lmcol.p, c->feat_lmcov.p, c->feat_anchor.p, c->given_status.p);
+    HIPCHK(hipGetLastError());
   }
   c->given_tri = true; // positions come from the state: no triangulation stage
   return OVGPU_OK;
@@ -1066,15 +1165,15 @@ int ovgpu_slam_update(ovgpu_ctx *c, const int32_t *lm_index, int32_t *feat_statu
                       double *lm_out, ovgpu_update_stats *stats) {
   int rc = slam_prepare(c, lm_index, stats);
   if (rc != OVGPU_OK) return rc;
-  const int F = c->F;
   hipStream_t s = c->stream;
-  rc = enqueue_pipeline(c, STAGE_LOCAL | STAGE_EKF);
+  rc = enqueue_pipeline(c, STAGE_LOCAL | STAGE_EKF, true);
   if (rc != OVGPU_OK) return rc;
-  hipLaunchKernelGGL(k_landmark_update, dim3((3 * c->L + 255) / 256), dim3(256), 0, s, c->L, c->dx.p, c->lm_cov.p, c->lm_pos.p);
+  hipLaunchKernelGGL(k_landmark_update, dim3((3 * c->L + 255) / 256), dim3(256), 0, s, c->L, (const int32_t *)nullptr, c->dx.p, c->lm_cov.p, c->lm_val.p,
+                     (const int32_t *)nullptr);
   HIPCHK(hipGetLastError());
   rc = read_feature_outputs(c, feat_status, chi2, chi2_thresh, nullptr, stats);
   if (rc != OVGPU_OK) return rc;
-  if (lm_out) HIPCHK(hipMemcpyAsync(lm_out, c->lm_pos.p, sizeof(double) * 3 * c->L, hipMemcpyDeviceToHost, s));
+  if (lm_out) HIPCHK(hipMemcpyAsync(lm_out, c->lm_val.p, sizeof(double) * 3 * c->L, hipMemcpyDeviceToHost, s));
   return finish_update(c, dx, P_out, stats);
 }
 
@@ -1082,7 +1181,156 @@ int ovgpu_slam_compress(ovgpu_ctx *c, const int32_t *lm_index, int32_t *feat_sta
                         int32_t *rows_out, int32_t *col_cov_id, double *H, double *r, ovgpu_update_stats *stats) {
   const int rc = slam_prepare(c, lm_index, stats);
   if (rc != OVGPU_OK) return rc;
-  return ovgpu_msckf_compress(c, feat_status, chi2, chi2_thresh, nullptr, D_out, rows_out, col_cov_id, H, r, stats);
+  return compress_impl(c, true, feat_status, chi2, chi2_thresh, nullptr, D_out, rows_out, col_cov_id, H, r, stats);
+}
+
+// ---------------------------------------------------------------------------
+// UpdaterSLAM::delayed_init (UpdaterSLAM.cpp:61-251): a chain of StateHelper::initialize calls, one feature after the
+// other on the stream, no host round trip in between.  The covariance is padded to its final capacity N + 3F up front
+// (the rows / columns of landmarks that do not exist yet are zero, which every kernel of the update treats exactly), the
+// current dimension and landmark count live in a device counter.
+// ---------------------------------------------------------------------------
+int ovgpu_slam_delayed_init(ovgpu_ctx *c, int32_t feat_rep, int32_t *feat_status, double *chi2, double *chi2_thresh, int32_t *lm_cov_id,
+                            double *lm_value, double *lm_fej, int32_t *anchor_cam, int32_t *anchor_clone, double *dx_seq, int32_t *N_out,
+                            double *P_out, ovgpu_update_stats *stats) {
+  if (!c) return set_err(OVGPU_ERR_INVALID, "null ctx");
+  if (!c->have_state || c->poses_only) return set_err(OVGPU_ERR_NO_STATE, "ovgpu_set_state was never called");
+  if (!c->have_feats) return set_err(OVGPU_ERR_NO_STATE, "ovgpu_set_features was never called (or the state changed since)");
+  if (feat_rep < OVGPU_REP_GLOBAL_3D || feat_rep > OVGPU_REP_ANCHORED_MSCKF_INVERSE_DEPTH)
+    return set_err(OVGPU_ERR_INVALID, "delayed initialisation: 3-dof representations only (ANCHORED_INVERSE_DEPTH_SINGLE is not supported)");
+  if (c->L > 0 && c->lm_rep != feat_rep) return set_err(OVGPU_ERR_INVALID, "the resident landmarks use another representation");
+  HIPCHK(hipSetDevice(c->device));
+  if (stats) std::memset(stats, 0, sizeof(*stats));
+  const int F = c->F, N0 = c->N, L0 = c->L, Nmax = N0 + 3 * F;
+  hipStream_t s = c->stream;
+  // the per-feature kernel needs the anchor blocks in its row store for an anchored representation
+  const int want_stride = (feat_rep >= OVGPU_REP_ANCHORED_3D || c->dopt.feat_rep >= OVGPU_REP_ANCHORED_3D || c->lm_rep >= OVGPU_REP_ANCHORED_3D) ? 72 : 48;
+  if (c->slam_rows || want_stride != c->row_stride) {
+    c->row_stride = want_stride;
+    const int rcl = set_row_layout(c, false);
+    if (rcl != OVGPU_OK) return rcl;
+  }
+  int r_max = 1;
+  for (int f = 0; f < F; f++) r_max = std::max(r_max, 2 * (c->h_offsets[f + 1] - c->h_offsets[f]) - 3);
+  // ---- workspaces
+  int rc = reserve_landmarks(c, L0 + F, L0);
+  if (rc != OVGPU_OK) return rc;
+  HIPCHK(c->Ppad.reserve((size_t)Nmax * Nmax));
+  HIPCHK(c->init_ws.reserve((size_t)3 * c->LD + 16));
+  HIPCHK(c->init_ctr.reserve(4));
+  HIPCHK(c->feat_slot.reserve(std::max(F, 1)));
+  HIPCHK(c->dx_seq.reserve((size_t)std::max(F, 1) * Nmax));
+  HIPCHK(c->Mt.reserve((size_t)std::max(r_max, c->D) * Nmax));
+  HIPCHK(c->Aaug.reserve((size_t)std::max(r_max, c->D) * (std::max(r_max, c->D) + Nmax + 1)));
+  HIPCHK(c->Yaug.reserve((size_t)std::max(r_max, c->D) * (std::max(r_max, c->D) + Nmax + 1)));
+  HIPCHK(c->dx.reserve(Nmax));
+  // ---- 3. triangulate every feature against the clone poses at entry (UpdaterSLAM.cpp:121-144)
+  if (!c->given_tri) {
+    if ((rc = enqueue_triangulate(c)) != OVGPU_OK) return rc;
+  } else if (F > 0) {
+    HIPCHK(hipMemcpyAsync(c->status.p, c->given_status.p, sizeof(int32_t) * F, hipMemcpyDeviceToDevice, s));
+  }
+  // ---- covariance -> padded capacity
+  {
+    dim3 g((Nmax + 255) / 256, Nmax);
+    hipLaunchKernelGGL(k_cov_copy, g, dim3(256), 0, s, N0, Nmax, c->P.p, N0, c->Ppad.p, Nmax);
+    HIPCHK(hipGetLastError());
+    std::swap(c->P, c->Ppad);
+    c->N = Nmax;
+  }
+  const int32_t ctr0[4] = {N0, L0, 0, 0};
+  HIPCHK(upload(c->init_ctr.p, ctr0, sizeof(ctr0), s));
+  HIPCHK(hipStreamSynchronize(s)); // ctr0 is a stack variable
+  HIPCHK(hipMemsetAsync(c->flags.p, 0, 4 * sizeof(int32_t), s));
+  HIPCHK(hipMemsetAsync(c->dx_seq.p, 0, sizeof(double) * (size_t)std::max(F, 1) * Nmax, s));
+  HIPCHK(hipMemsetAsync(c->feat_slot.p, 0xFF, sizeof(int32_t) * std::max(F, 1), s));
+  const size_t init_lds = ((size_t)3 * c->LD + (size_t)3 * Nmax + 16) * sizeof(double);
+  // ---- 4. one feature after the other (UpdaterSLAM.cpp:147-239)
+  for (int f = 0; f < F && rc == OVGPU_OK; f++) {
+    const int m = c->h_offsets[f + 1] - c->h_offsets[f];
+    if (m < 2) continue; // :91-93, flagged OVGPU_FEAT_TOO_FEW_MEAS by the triangulation
+    if ((rc = enqueue_system(c, f, feat_rep)) != OVGPU_OK) break;
+    InitParams ip;
+    ip.N = Nmax, ip.D = c->D, ip.LD = c->LD, ip.rep = feat_rep, ip.f = f, ip.col_cov = c->col_cov.p, ip.init_out = c->init_ws.p, ip.P = c->P.p;
+    ip.sigma2 = c->dopt.sigma_pix_sq, ip.ctr = c->init_ctr.p, ip.p_FinG = c->pG.p, ip.p_FinA = c->pA.p, ip.meas_cc = c->meas_cc.p;
+    ip.anchor_meas = c->anchor.p, ip.lm = landmark_store(c), ip.feat_slot = c->feat_slot.p;
+    hipLaunchKernelGGL(k_init_invertible, dim3(1), dim3(256), init_lds, s, ip);
+    HIPCHK(hipGetLastError());
+    EkfJob job;
+    job.R = c->Hbig.p + (size_t)c->h_row_off[f] * c->LD, job.rows = 2 * m - 3, job.pred = c->init_ctr.p + 2, job.dx = c->dx_seq.p + (size_t)f * Nmax;
+    job.keep_flags = true;
+    if ((rc = enqueue_ekf(c, job)) != OVGPU_OK) break; // StateHelper.cpp:476-478
+    hipLaunchKernelGGL(k_landmark_update, dim3((3 * (L0 + F) + 255) / 256), dim3(256), 0, s, 0, (const int32_t *)(c->init_ctr.p + 1), job.dx, c->lm_cov.p,
+                       c->lm_val.p, job.pred);
+    HIPCHK(hipGetLastError());
+  }
+  // ---- results
+  int32_t ctr[4] = {N0, L0, 0, 0};
+  std::vector<int32_t> slot(std::max(F, 1), -1);
+  if (rc == OVGPU_OK) {
+    HIPCHK(hipMemcpyAsync(ctr, c->init_ctr.p, sizeof(ctr), hipMemcpyDeviceToHost, s));
+    if (F > 0) HIPCHK(hipMemcpyAsync(slot.data(), c->feat_slot.p, sizeof(int32_t) * F, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+  } else {
+    (void)hipStreamSynchronize(s);
+  }
+  const int N1 = ctr[0], L1 = ctr[1];
+  // covariance back to its own leading dimension; it is the new baseline of ovgpu_reset_state as well
+  {
+    HIPCHK(c->Ppad.reserve((size_t)N1 * N1));
+    dim3 g((N1 + 255) / 256, N1);
+    hipLaunchKernelGGL(k_cov_copy, g, dim3(256), 0, s, N1, N1, c->P.p, Nmax, c->Ppad.p, N1);
+    HIPCHK(hipGetLastError());
+    std::swap(c->P, c->Ppad);
+    c->N = N1;
+    HIPCHK(c->P0.reserve((size_t)N1 * N1));
+    HIPCHK(hipMemcpyAsync(c->P0.p, c->P.p, sizeof(double) * N1 * N1, hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipMemcpyAsync(c->clone_qp0.p, c->clone_qp.p, sizeof(double) * 7 * c->C, hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipMemcpyAsync(c->calib_qp0.p, c->calib_qp.p, sizeof(double) * 7 * c->K, hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipMemcpyAsync(c->intr0.p, c->intr.p, sizeof(double) * 8 * c->K, hipMemcpyDeviceToDevice, s));
+  }
+  if (rc != OVGPU_OK) return rc;
+  std::vector<double> val(3 * (size_t)std::max(L1, 1)), fej(3 * (size_t)std::max(L1, 1));
+  std::vector<int32_t> cov(std::max(L1, 1)), anc(std::max(L1, 1));
+  if (L1 > 0) {
+    HIPCHK(hipMemcpyAsync(val.data(), c->lm_val.p, sizeof(double) * 3 * L1, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(fej.data(), c->lm_fej.p, sizeof(double) * 3 * L1, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(cov.data(), c->lm_cov.p, sizeof(int32_t) * L1, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(anc.data(), c->lm_anchor.p, sizeof(int32_t) * L1, hipMemcpyDeviceToHost, s));
+  }
+  if (dx_seq && F > 0) HIPCHK(hipMemcpyAsync(dx_seq, c->dx_seq.p, sizeof(double) * (size_t)F * Nmax, hipMemcpyDeviceToHost, s));
+  if (P_out) HIPCHK(hipMemcpyAsync(P_out, c->P.p, sizeof(double) * (size_t)N1 * N1, hipMemcpyDeviceToHost, s));
+  int32_t flags[4] = {0, 0, 0, 0};
+  HIPCHK(hipMemcpyAsync(flags, c->flags.p, sizeof(flags), hipMemcpyDeviceToHost, s));
+  c->slam_rows = false;
+  rc = read_feature_outputs(c, feat_status, chi2, chi2_thresh, nullptr, stats); // synchronises
+  if (rc != OVGPU_OK) return rc;
+  const double qnan = std::nan("");
+  for (int f = 0; f < F; f++) {
+    const int l = slot[f];
+    if (lm_cov_id) lm_cov_id[f] = l >= 0 ? cov[l] : -1;
+    for (int i = 0; i < 3; i++) {
+      if (lm_value) lm_value[3 * f + i] = l >= 0 ? val[3 * l + i] : qnan;
+      if (lm_fej) lm_fej[3 * f + i] = l >= 0 ? fej[3 * l + i] : qnan;
+    }
+    if (anchor_cam) anchor_cam[f] = (l >= 0 && anc[l] >= 0) ? anc[l] >> 10 : -1;
+    if (anchor_clone) anchor_clone[f] = (l >= 0 && anc[l] >= 0) ? (anc[l] & 1023) : -1;
+  }
+  if (N_out) *N_out = N1;
+  if (stats) stats->n_used = L1 - L0, stats->D = c->D;
+  // the new landmarks join the resident ones and the column map
+  c->L = L1, c->lm_rep = feat_rep;
+  c->h_lm_cov.assign(cov.begin(), cov.begin() + L1);
+  c->dx.release(), c->Mt.release(), c->Aaug.release(), c->Yaug.release(); // sized by the old N below
+  HIPCHK(c->dx.reserve(N1));
+  rc = build_columns(c);
+  if (rc != OVGPU_OK) return rc;
+  int status = OVGPU_OK;
+  if (flags[0]) status = OVGPU_ERR_NOT_SPD;
+  else if (flags[1]) status = OVGPU_ERR_NEGATIVE_DIAGONAL;
+  if (stats) stats->status = status;
+  if (status != OVGPU_OK) return set_err(status, status == OVGPU_ERR_NOT_SPD ? "innovation covariance not SPD" : "negative covariance diagonal after the update");
+  return OVGPU_OK;
 }
 
 
@@ -1163,7 +1411,9 @@ int ovgpu_ekf_update(ovgpu_ctx *c, int rows, int cols, const int32_t *col_cov_id
     HIPCHK(c->Mt.reserve((size_t)cols * c->N));
     HIPCHK(c->Aaug.reserve((size_t)cols * (cols + c->N + 1)));
     HIPCHK(c->Yaug.reserve((size_t)cols * (cols + c->N + 1)));
-    rc = enqueue_ekf(c, cols_dev.p, sigma2);
+    EkfJob ej;
+    ej.col_cov = cols_dev.p, ej.sigma2 = sigma2;
+    rc = enqueue_ekf(c, ej);
     if (rc == OVGPU_OK) rc = finish_update(c, dx, P_out, nullptr);
     cols_dev.release();
   }

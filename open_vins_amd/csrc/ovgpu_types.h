@@ -69,6 +69,14 @@ struct SysParams {
   const int32_t *feat_lm;   // [F] landmark index, first Jacobian column and covariance id of its 3 dof
   const int32_t *feat_lmcol;
   const int32_t *feat_lmcov;
+  const int32_t *feat_anchor; // [F] anchored SLAM landmarks: packed (camera << 10 | clone) of the landmark's anchor
+  // feature range of this launch (the delayed initialisation runs one feature at a time)
+  int f_begin, f_end;
+  // StateHelper::initialize mode (UpdaterSLAM::delayed_init): MSCKF-style system, gate against chi2(2m), and the three
+  // rows Q1^T [H_x | res] plus R1 = Q1^T H_f that determine the new landmark go to init_out [3 * LD + 9]
+  int init;
+  double *init_out;
+  int32_t *init_flag; // [0] = 1 when the feature passed the gate
   DevOptions opt;
 };
 

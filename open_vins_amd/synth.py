@@ -215,6 +215,9 @@ class Problem:
     lm_fej: np.ndarray | None = None
     lm_cov_id: np.ndarray | None = None
     lm_index: np.ndarray | None = None
+    lm_rep: int = 0
+    lm_anchor_cam: np.ndarray | None = None
+    lm_anchor_clone: np.ndarray | None = None
 
     @property
     def F(self):
@@ -440,19 +443,63 @@ def make_problem(cfg=2, rep=0, *, C=None, K=None, F=None, track="full", fisheye=
     )
 
 
-def make_slam_problem(cfg=2, L=20, *, lm_noise=0.05, seed=None, **kw) -> Problem:
-    """A snapshot for UpdaterSLAM::update: L landmarks (GLOBAL_3D) live in the state behind the clones, each observed by
-    one track.  Estimate = truth + N(0, lm_noise), fej = estimate + N(0, lm_noise / 5); the prior covariance is rebuilt
-    for the larger state the same way make_problem does (landmark sigma = 2 lm_noise)."""
+def landmark_from_xyz(rep, p):
+    """ov_type::Landmark::set_from_xyz (Landmark.cpp:66-141): xyz -> representation coordinates, rows of p."""
+    p = np.asarray(p, dtype=np.float64)
+    if rep in (1, 3):  # GLOBAL_ / ANCHORED_FULL_INVERSE_DEPTH: (theta, phi, rho)
+        rho = 1.0 / np.linalg.norm(p, axis=-1)
+        return np.stack([np.arctan2(p[..., 1], p[..., 0]), np.arccos(rho * p[..., 2]), rho], axis=-1)
+    if rep == 4:  # ANCHORED_MSCKF_INVERSE_DEPTH: (alpha, beta, rho)
+        return np.stack([p[..., 0] / p[..., 2], p[..., 1] / p[..., 2], 1.0 / p[..., 2]], axis=-1)
+    return p.copy()
+
+
+def landmark_to_xyz(rep, v):
+    """ov_type::Landmark::get_xyz (Landmark.cpp:25-62)."""
+    v = np.asarray(v, dtype=np.float64)
+    if rep in (1, 3):
+        return np.stack([np.cos(v[..., 0]) * np.sin(v[..., 1]), np.sin(v[..., 0]) * np.sin(v[..., 1]), np.cos(v[..., 1])], axis=-1) / v[..., 2:3]
+    if rep == 4:
+        return np.stack([v[..., 0], v[..., 1], np.ones_like(v[..., 0])], axis=-1) / v[..., 2:3]
+    return v.copy()
+
+
+def make_slam_problem(cfg=2, L=20, *, lm_rep=0, lm_noise=0.05, seed=None, **kw) -> Problem:
+    """A snapshot for UpdaterSLAM::update: L landmarks live in the state behind the clones, each observed by one track.
+    Estimate = truth + N(0, lm_noise) in xyz (global, or in the anchor camera frame of the track's first measurement for an
+    anchored representation lm_rep >= 2), fej = estimate + N(0, lm_noise / 5); both are stored in representation
+    coordinates as ov_type::Landmark does.  The prior covariance is rebuilt for the larger state the same way
+    make_problem does (landmark sigma = 2 lm_noise in representation coordinates)."""
     prob = make_problem(cfg, F=L, seed=seed, **kw)
     rng = np.random.default_rng([prob.seed, 7])
     N0 = prob.N
     N = N0 + 3 * L
-    prob.lm_value = np.ascontiguousarray(prob.p_FinG_true + rng.normal(0, lm_noise, (L, 3)))
-    prob.lm_fej = np.ascontiguousarray(prob.lm_value + rng.normal(0, lm_noise / 5, (L, 3)))
+    xyz = prob.p_FinG_true + rng.normal(0, lm_noise, (L, 3))
+    xyz_fej = xyz + rng.normal(0, lm_noise / 5, (L, 3))
+    prob.lm_rep = int(lm_rep)
+    if lm_rep >= 2:
+        first = prob.meas_offsets[:-1]
+        prob.lm_anchor_cam = prob.cam_idx[first].astype(np.int32)
+        prob.lm_anchor_clone = prob.clone_idx[first].astype(np.int32)
+
+        def to_anchor(p):
+            out = np.zeros_like(p)
+            for l in range(L):
+                qc, qk = prob.clone_q_p[prob.lm_anchor_clone[l]], prob.calib_q_p[prob.lm_anchor_cam[l]]
+                R_GtoI, R_ItoC = quat_2_rot(qc[:4]), quat_2_rot(qk[:4])
+                out[l] = R_ItoC @ (R_GtoI @ (p[l] - qc[4:7])) + qk[4:7]
+            return out
+
+        xyz, xyz_fej = to_anchor(xyz), to_anchor(xyz_fej)
+    prob.lm_value = np.ascontiguousarray(landmark_from_xyz(lm_rep, xyz))
+    prob.lm_fej = np.ascontiguousarray(landmark_from_xyz(lm_rep, xyz_fej))
     prob.lm_cov_id = (N0 + 3 * np.arange(L)).astype(np.int32)
     prob.lm_index = np.arange(L, dtype=np.int32)
-    sig = np.concatenate([state_sigmas(prob.C, prob.K), np.full(3 * L, 2 * lm_noise)])
+    lm_sig = np.full((L, 3), 2 * lm_noise)
+    if lm_rep in (1, 3, 4):  # angles / normalised coordinates and an inverse depth: scale the sigma to the coordinates
+        depth = np.linalg.norm(xyz, axis=1)
+        lm_sig = np.stack([2 * lm_noise / depth, 2 * lm_noise / depth, 2 * lm_noise / depth ** 2], axis=1)
+    sig = np.concatenate([state_sigmas(prob.C, prob.K), lm_sig.reshape(-1)])
     G = np.tril(rng.normal(0, 1.0 / np.sqrt(N), (N, N)), -1)
     Lc = sig[:, None] * (np.eye(N) + 0.1 * G)
     P = Lc @ Lc.T

@@ -156,13 +156,18 @@ class UpdaterMSCKF:
         capi.check(self.lib.ovgpu_set_landmarks(self._ctx, C.byref(v.landmarks)), "ovgpu_set_landmarks")
         capi.check(self.lib.ovgpu_set_features(self._ctx, C.byref(v.features)), "ovgpu_set_features")
 
-    def slam_update(self):
+    def slam_update(self, lm_index=None):
+        """lm_index [F]: the resident landmark each uploaded track observes (default: the snapshot's)."""
         v = self._views
-        F, N, L = self.F, self.N, v.landmarks.L
+        F, N = self.F, self.N
+        Lc = C.c_int32(0)
+        capi.check(self.lib.ovgpu_get_landmarks(self._ctx, C.byref(Lc), None, None, None, None, None), "ovgpu_get_landmarks")
+        L = Lc.value
+        lm_index = v.lm_index if lm_index is None else np.ascontiguousarray(lm_index, dtype=np.int32)
         out = dict(feat_status=np.zeros(F, np.int32), chi2=np.zeros(F), chi2_thresh=np.zeros(F), dx=np.zeros(N), P=np.zeros((N, N)),
                    landmarks=np.zeros((L, 3)))
         stats = capi.UpdateStats()
-        rc = self.lib.ovgpu_slam_update(self._ctx, _ip(v.lm_index), _ip(out["feat_status"]), _dp(out["chi2"]), _dp(out["chi2_thresh"]),
+        rc = self.lib.ovgpu_slam_update(self._ctx, _ip(lm_index), _ip(out["feat_status"]), _dp(out["chi2"]), _dp(out["chi2_thresh"]),
                                         _dp(out["dx"]), _dp(out["P"]), _dp(out["landmarks"]), C.byref(stats))
         out["rc"] = rc
         capi.check(rc, "ovgpu_slam_update")
@@ -183,6 +188,41 @@ class UpdaterMSCKF:
         d, n = D.value, rows.value
         out.update(D=d, rows=n, H=np.ascontiguousarray(H.reshape(-1)[: n * d].reshape(n, d)), r=r[:n].copy(), col_cov_id=cols[:d].copy(),
                    stats=stats.as_dict())
+        return out
+
+    # ---- UpdaterSLAM::delayed_init (UpdaterSLAM.cpp:61-251) -------------
+    def delayed_init(self, feat_rep=0):
+        """Runs the delayed initialisation on the resident state and tracks (set_problem / set_slam_problem first;
+        set_triangulation optionally replaces the triangulation stage).  The state grows by 3 per accepted feature."""
+        F, N = self.F, self.N
+        Nmax = N + 3 * F
+        out = dict(feat_status=np.zeros(F, np.int32), chi2=np.zeros(F), chi2_thresh=np.zeros(F), lm_cov_id=np.zeros(F, np.int32),
+                   lm_value=np.zeros((F, 3)), lm_fej=np.zeros((F, 3)), anchor_cam=np.zeros(F, np.int32), anchor_clone=np.zeros(F, np.int32),
+                   dx_seq=np.zeros((F, Nmax)))
+        Pbuf = np.zeros(Nmax * Nmax)
+        N_out = C.c_int32(0)
+        stats = capi.UpdateStats()
+        rc = self.lib.ovgpu_slam_delayed_init(self._ctx, int(feat_rep), _ip(out["feat_status"]), _dp(out["chi2"]), _dp(out["chi2_thresh"]),
+                                              _ip(out["lm_cov_id"]), _dp(out["lm_value"]), _dp(out["lm_fej"]), _ip(out["anchor_cam"]),
+                                              _ip(out["anchor_clone"]), _dp(out["dx_seq"]), C.byref(N_out), _dp(Pbuf), C.byref(stats))
+        out["rc"] = rc
+        capi.check(rc, "ovgpu_slam_delayed_init")
+        n = N_out.value
+        out["N"] = n
+        out["P"] = Pbuf[: n * n].reshape(n, n).copy()
+        out["stats"] = stats.as_dict()
+        self.N = n
+        return out
+
+    def get_landmarks(self):
+        L = C.c_int32(0)
+        capi.check(self.lib.ovgpu_get_landmarks(self._ctx, C.byref(L), None, None, None, None, None), "ovgpu_get_landmarks")
+        n = L.value
+        out = dict(value=np.zeros((n, 3)), fej=np.zeros((n, 3)), cov_id=np.zeros(n, np.int32), anchor_cam=np.zeros(n, np.int32),
+                   anchor_clone=np.zeros(n, np.int32))
+        if n:
+            capi.check(self.lib.ovgpu_get_landmarks(self._ctx, C.byref(L), _dp(out["value"]), _dp(out["fej"]), _ip(out["cov_id"]),
+                                                    _ip(out["anchor_cam"]), _ip(out["anchor_clone"])), "ovgpu_get_landmarks")
         return out
 
     # ---- standalone helpers (UpdaterHelper::measurement_compress_inplace, StateHelper::EKFUpdate) ----

@@ -963,18 +963,19 @@ struct LocalCols {
 
 void feature_jacobian_full(const ovgpu_options &o, const ovgpu_state_view *st, const StateTables &T, const FeatMeas &fm, int rep,
                            const V3 &p_FinG_in, const V3 &p_FinA, int anchor_meas, const LocalCols &lc, double *H_f, int &nf,
-                           double *H_x, double *res, const V3 *p_FinG_fej_in = nullptr) {
+                           double *H_x, double *res, const V3 *p_FinG_fej_in = nullptr, int lm_anchor_cam = -1, int lm_anchor_clone = -1) {
   const int m = fm.m1 - fm.m0;
   const int ncols = lc.ncols;
   int anchor_cam = -1, anchor_clone = -1;
   V3 p_FinG = p_FinG_in;
   if (is_relative(rep)) { // :262-275
-    anchor_cam = fm.cam_idx[anchor_meas];
-    anchor_clone = fm.clone_idx[anchor_meas];
+    // MSCKF / delayed init: the anchor of the triangulation; a SLAM landmark carries its own (UpdaterSLAM.cpp:345-348)
+    anchor_cam = anchor_meas >= 0 ? fm.cam_idx[anchor_meas] : lm_anchor_cam;
+    anchor_clone = anchor_meas >= 0 ? fm.clone_idx[anchor_meas] : lm_anchor_clone;
     p_FinG = add(mulT(T.R_GtoI[anchor_clone], mulT(T.R_ItoC[anchor_cam], sub(p_FinA, T.p_IinC[anchor_cam]))), T.p_IinG[anchor_clone]);
   }
   // :279-283 and UpdaterMSCKF.cpp:186-194 (fej == value for MSCKF features); SLAM landmarks carry their own (UpdaterSLAM.cpp:345-353)
-  V3 p_FinG_fej = p_FinG_fej_in ? *p_FinG_fej_in : p_FinG;
+  V3 p_FinG_fej = (p_FinG_fej_in && !is_relative(rep)) ? *p_FinG_fej_in : p_FinG; // :279-283: anchored -> the "best" p_FinG
 
   RepJac rj = feature_jacobian_representation(o, T, rep, p_FinG, p_FinG_fej, p_FinA, anchor_cam, anchor_clone);
   nf = rj.nf;
@@ -1202,6 +1203,30 @@ void pose_update(const double *val, const double *dx6, double *out) {
 
 double now_s() {
   return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// Landmark::get_xyz — ov_core/src/types/Landmark.cpp:25-62 (3-dof representations)
+V3 landmark_get_xyz(int rep, const double *v) {
+  if (rep == OVGPU_REP_GLOBAL_FULL_INVERSE_DEPTH || rep == OVGPU_REP_ANCHORED_FULL_INVERSE_DEPTH)
+    return V3{{(1 / v[2]) * std::cos(v[0]) * std::sin(v[1]), (1 / v[2]) * std::sin(v[0]) * std::sin(v[1]), (1 / v[2]) * std::cos(v[1])}};
+  if (rep == OVGPU_REP_ANCHORED_MSCKF_INVERSE_DEPTH) return V3{{(1 / v[2]) * v[0], (1 / v[2]) * v[1], 1 / v[2]}};
+  return V3{{v[0], v[1], v[2]}};
+}
+
+// Landmark::set_from_xyz — Landmark.cpp:66-141
+void landmark_set_from_xyz(int rep, const V3 &p, double *v) {
+  if (rep == OVGPU_REP_GLOBAL_FULL_INVERSE_DEPTH || rep == OVGPU_REP_ANCHORED_FULL_INVERSE_DEPTH) {
+    double g_rho = 1 / norm(p);
+    double g_phi = std::acos(g_rho * p[2]);
+    double g_theta = std::atan2(p[1], p[0]);
+    v[0] = g_theta, v[1] = g_phi, v[2] = g_rho;
+    return;
+  }
+  if (rep == OVGPU_REP_ANCHORED_MSCKF_INVERSE_DEPTH) {
+    v[0] = p[0] / p[2], v[1] = p[1] / p[2], v[2] = 1 / p[2];
+    return;
+  }
+  v[0] = p[0], v[1] = p[1], v[2] = p[2];
 }
 
 } // namespace
@@ -1508,7 +1533,7 @@ int oracle_msckf_update_given(const ovgpu_options *opts, const ovgpu_state_view 
 }
 
 // ---------------------------------------------------------------------------
-// UpdaterSLAM::update — UpdaterSLAM.cpp:253-479, landmarks in GLOBAL_3D.
+// UpdaterSLAM::update — UpdaterSLAM.cpp:253-479, landmarks in any 3-dof representation (lm->feat_rep).
 // Column order: the canonical map of the MSCKF path with the landmarks merged in
 // by covariance id (the reference's is "first seen"; any order gives the same
 // update).  Unused variables keep zero columns.
@@ -1570,14 +1595,18 @@ int oracle_slam_update(const ovgpu_options *opts, const ovgpu_state_view *st, co
       continue;
     }
     const int l = lm_index[f];
-    V3 pG{{lm->p_value[3 * l], lm->p_value[3 * l + 1], lm->p_value[3 * l + 2]}};
-    V3 pF{{lm->p_fej[3 * l], lm->p_fej[3 * l + 1], lm->p_fej[3 * l + 2]}};
+    const int lrep = lm->feat_rep;
+    // :345-353: get_xyz of the landmark, in the anchor frame for an anchored representation
+    V3 pG = landmark_get_xyz(lrep, lm->p_value + 3 * l);
+    V3 pF = landmark_get_xyz(lrep, lm->p_fej + 3 * l);
     V3 pA{{NAN, NAN, NAN}};
+    int acam = -1, aclone = -1;
+    if (is_relative(lrep)) pA = pG, pG = V3{{NAN, NAN, NAN}}, acam = lm->anchor_cam[l], aclone = lm->anchor_clone[l];
     H_f.assign((size_t)2 * m * 3, 0.0);
     H_x.assign((size_t)2 * m * Dt, 0.0);
     res.assign(2 * m, 0.0);
     int nf = 3;
-    feature_jacobian_full(o, st, T, fm, OVGPU_REP_GLOBAL_3D, pG, pA, -1, lc, H_f.data(), nf, H_x.data(), res.data(), &pF); // :369
+    feature_jacobian_full(o, st, T, fm, lrep, pG, pA, -1, lc, H_f.data(), nf, H_x.data(), res.data(), &pF, acam, aclone); // :369
     for (int a = 0; a < 2 * m; a++) // :381-383  H_xf = [H_x | H_f], here the landmark columns of the big map
       for (int b = 0; b < 3; b++) H_x[(size_t)a * Dt + lm_col[l] + b] = H_f[(size_t)a * 3 + b];
     const int r = 2 * m;
@@ -1637,6 +1666,224 @@ int oracle_slam_update(const ovgpu_options *opts, const ovgpu_state_view *st, co
   if (rows_out) *rows_out = (int32_t)ct_meas;
   if (stats) *stats = stl;
   return OVGPU_OK;
+}
+
+// ---------------------------------------------------------------------------
+// UpdaterSLAM::delayed_init — UpdaterSLAM.cpp:61-251, with StateHelper::initialize
+// (StateHelper.cpp:393-482) and initialize_invertible (:484-577) restated as the
+// reference runs them: Givens separation of [H_L | H_R | res], gate, covariance
+// augmentation, EKFUpdate with the remaining rows, one feature after the other on a
+// state that changes with every accepted feature.  Column order: the canonical map
+// (zero columns for the variables a feature does not touch).
+//   lm (may be NULL / L = 0): landmarks already in the state; they receive every dx.
+// Outputs as ovgpu_slam_delayed_init; clone / calib / intrinsics / lm_existing = the
+// state after the whole call.
+// ---------------------------------------------------------------------------
+int oracle_slam_delayed_init(const ovgpu_options *opts, const ovgpu_state_view *st_in, const ovgpu_landmarks_view *lm,
+                             const ovgpu_features_view *fv, int feat_rep, const double *given_p_FinA, const double *given_p_FinG,
+                             const int32_t *given_anchor, const int32_t *given_status, int32_t *feat_status, double *chi2_out,
+                             double *chi2_thresh_out, int32_t *lm_cov_id, double *lm_value, double *lm_fej, int32_t *anchor_cam_out,
+                             int32_t *anchor_clone_out, double *dx_seq, int32_t *N_out, double *P_out, double *clone_q_p_out,
+                             double *calib_q_p_out, double *intrinsics_out, double *lm_existing_out) {
+  const ovgpu_options &o = *opts;
+  const int F = fv->F, N0 = st_in->N, C = st_in->C, K = st_in->K, Nmax = N0 + 3 * F;
+  const int L0 = lm ? lm->L : 0;
+  const double sigma2 = std::pow(o.sigma_pix, 2);
+  // mutable copy of the state
+  std::vector<double> clone_qp(st_in->clone_q_p, st_in->clone_q_p + 7 * C), calib_qp(st_in->calib_q_p, st_in->calib_q_p + 7 * K),
+      intr(st_in->intrinsics, st_in->intrinsics + 8 * K);
+  std::vector<double> P(st_in->P, st_in->P + (size_t)N0 * N0);
+  std::vector<double> lm_old(lm && L0 > 0 ? lm->p_value : nullptr, lm && L0 > 0 ? lm->p_value + 3 * L0 : nullptr);
+  int N = N0;
+  ovgpu_state_view st = *st_in;
+  st.clone_q_p = clone_qp.data(), st.calib_q_p = calib_qp.data(), st.intrinsics = intr.data();
+
+  // 2./3. clone-camera poses at entry and triangulation of every feature (:100-144)
+  StateTables T0 = build_tables(&st);
+  std::vector<int> status(F, OVGPU_FEAT_USED), anchor(F, -1);
+  std::vector<V3> pA(F, V3{{NAN, NAN, NAN}}), pG(F, V3{{NAN, NAN, NAN}});
+  for (int f = 0; f < F; f++) {
+    FeatMeas fm{fv->meas_offsets[f], fv->meas_offsets[f + 1], fv->uvn, fv->uv, fv->clone_idx, fv->cam_idx};
+    if (fm.m1 - fm.m0 < 2) { // :91-93
+      status[f] = OVGPU_FEAT_TOO_FEW_MEAS;
+      continue;
+    }
+    if (given_p_FinG) {
+      status[f] = given_status ? given_status[f] : OVGPU_FEAT_USED;
+      anchor[f] = given_anchor ? given_anchor[f] : pick_anchor(fm);
+      for (int i = 0; i < 3; i++) pG[f][i] = given_p_FinG[3 * f + i], pA[f][i] = given_p_FinA ? given_p_FinA[3 * f + i] : NAN;
+      continue;
+    }
+    anchor[f] = pick_anchor(fm);
+    bool ok = o.triangulate_1d ? single_triangulation_1d(o, T0, fm, anchor[f], pA[f], pG[f]) : single_triangulation(o, T0, fm, anchor[f], pA[f], pG[f]);
+    if (!ok) {
+      status[f] = OVGPU_FEAT_TRI_FAILED;
+      continue;
+    }
+    if (o.refine_features && !single_gaussnewton(o, T0, fm, anchor[f], pA[f], pG[f])) status[f] = OVGPU_FEAT_GN_FAILED;
+  }
+
+  ColumnMap cm = build_column_map(o, &st);
+  const int D = cm.D;
+  LocalCols lc{D, cm.calib_col.data(), cm.intr_col.data(), cm.clone_col.data()};
+  std::vector<double> chi2v(F, NAN), thrv(F, NAN);
+  std::vector<int> new_cov(F, -1);
+  std::vector<double> new_val(3 * (size_t)std::max(F, 1), NAN), new_fej(3 * (size_t)std::max(F, 1), NAN);
+  std::vector<double> dxs((size_t)std::max(F, 1) * Nmax, 0.0);
+  std::vector<double> H_f, H_x, res;
+  int status_rc = OVGPU_OK;
+
+  // 4. one feature after the other (:147-239)
+  for (int f = 0; f < F; f++) {
+    if (status[f] != OVGPU_FEAT_USED) continue;
+    FeatMeas fm{fv->meas_offsets[f], fv->meas_offsets[f + 1], fv->uvn, fv->uv, fv->clone_idx, fv->cam_idx};
+    const int m = fm.m1 - fm.m0, n = 2 * m;
+    StateTables T = build_tables(&st); // the CURRENT state estimate (FEJ values never change)
+    H_f.assign((size_t)n * 3, 0.0), H_x.assign((size_t)n * D, 0.0), res.assign(n, 0.0);
+    int nf = 3;
+    feature_jacobian_full(o, &st, T, fm, feat_rep, pG[f], pA[f], anchor[f], lc, H_f.data(), nf, H_x.data(), res.data()); // :165, fej == value (:155-162)
+    // StateHelper::initialize :429-443 — Givens on H_L, applied to H_R and res
+    for (int c2 = 0; c2 < 3; ++c2) {
+      for (int r = n - 1; r > c2; r--) {
+        double gc, gs;
+        make_givens(H_f[(size_t)(r - 1) * 3 + c2], H_f[(size_t)r * 3 + c2], gc, gs);
+        apply_givens_adj(H_f.data() + (size_t)(r - 1) * 3 + c2, H_f.data() + (size_t)r * 3 + c2, 3 - c2, gc, gs);
+        apply_givens_adj(res.data() + (r - 1), res.data() + r, 1, gc, gs);
+        apply_givens_adj(H_x.data() + (size_t)(r - 1) * D, H_x.data() + (size_t)r * D, D, gc, gs);
+      }
+    }
+    const double *Hxinit = H_x.data(), *resinit = res.data();          // :446-449 (first 3 rows)
+    const double *Hup = H_x.data() + (size_t)3 * D, *resup = res.data() + 3; // :452-454
+    const int rup = n - 3;
+    // chi2 (:459-463) with the marginal covariance of the Jacobian's variables
+    {
+      std::vector<double> HP((size_t)rup * D, 0.0), S((size_t)rup * rup, 0.0);
+      for (int a = 0; a < rup; a++)
+        for (int k = 0; k < D; k++) {
+          const double h = Hup[(size_t)a * D + k];
+          if (h == 0.0) continue;
+          const double *pk = P.data() + (size_t)cm.col_cov[k] * N;
+          for (int b = 0; b < D; b++) HP[(size_t)a * D + b] += h * pk[cm.col_cov[b]];
+        }
+      for (int a = 0; a < rup; a++)
+        for (int b = 0; b <= a; b++) {
+          double sv = 0;
+          for (int k = 0; k < D; k++) sv += HP[(size_t)a * D + k] * Hup[(size_t)b * D + k];
+          S[(size_t)a * rup + b] = sv, S[(size_t)b * rup + a] = sv;
+        }
+      for (int a = 0; a < rup; a++) S[(size_t)a * rup + a] += sigma2;
+      double chi2 = NAN;
+      if (cholesky_lower(S.data(), rup)) {
+        std::vector<double> y(resup, resup + rup);
+        cholesky_solve(S.data(), rup, y.data());
+        chi2 = 0;
+        for (int a = 0; a < rup; a++) chi2 += resup[a] * y[a];
+      }
+      const double chi2_check = chi2_quantile(n, 0.95); // :466-467: res.rows() = all 2m rows
+      chi2v[f] = chi2, thrv[f] = o.chi2_multipler * chi2_check;
+      if (chi2 > o.chi2_multipler * chi2_check) { // :468
+        status[f] = OVGPU_FEAT_CHI2_REJECTED;
+        continue;
+      }
+    }
+    // initialize_invertible :512-573
+    {
+      std::vector<double> M_a((size_t)N * 3, 0.0); // P(:, cols) Hxinit^T
+      for (int i = 0; i < N; i++)
+        for (int j = 0; j < 3; j++) {
+          double sv = 0;
+          for (int k = 0; k < D; k++) sv += P[(size_t)i * N + cm.col_cov[k]] * Hxinit[(size_t)j * D + k];
+          M_a[(size_t)i * 3 + j] = sv;
+        }
+      double Mm[9]; // H_R P_small H_R^T + R  (:541-543)
+      for (int a = 0; a < 3; a++)
+        for (int b = 0; b < 3; b++) {
+          double sv = 0;
+          for (int k = 0; k < D; k++) sv += Hxinit[(size_t)a * D + k] * M_a[(size_t)cm.col_cov[k] * 3 + b];
+          Mm[3 * a + b] = sv + (a == b ? sigma2 : 0.0);
+        }
+      // H_L^-1 of the upper-triangular 3x3 (:548)
+      const double u00 = H_f[0], u01 = H_f[1], u02 = H_f[2], u11 = H_f[4], u12 = H_f[5], u22 = H_f[8];
+      double inv[9] = {1 / u00, -u01 / (u00 * u11), (u01 * u12 - u02 * u11) / (u00 * u11 * u22), 0, 1 / u11, -u12 / (u11 * u22), 0, 0, 1 / u22};
+      double tmp[9], PLL[9];
+      // M.selfadjointView<Upper>() (:549): the upper triangle stands for both halves
+      for (int a = 0; a < 3; a++)
+        for (int b = 0; b < 3; b++) {
+          double sv = 0;
+          for (int k = 0; k < 3; k++) sv += inv[3 * a + k] * Mm[3 * std::min(k, b) + std::max(k, b)];
+          tmp[3 * a + b] = sv;
+        }
+      for (int a = 0; a < 3; a++)
+        for (int b = 0; b < 3; b++) {
+          double sv = 0;
+          for (int k = 0; k < 3; k++) sv += tmp[3 * a + k] * inv[3 * b + k];
+          PLL[3 * a + b] = sv;
+        }
+      // augment the covariance (:552-558)
+      const int N1 = N + 3;
+      std::vector<double> Pn((size_t)N1 * N1, 0.0);
+      for (int i = 0; i < N; i++) std::memcpy(Pn.data() + (size_t)i * N1, P.data() + (size_t)i * N, sizeof(double) * N);
+      for (int i = 0; i < N; i++)
+        for (int j = 0; j < 3; j++) {
+          double sv = 0;
+          for (int k = 0; k < 3; k++) sv += M_a[(size_t)i * 3 + k] * inv[3 * j + k];
+          Pn[(size_t)i * N1 + N + j] = -sv;
+          Pn[(size_t)(N + j) * N1 + i] = -sv;
+        }
+      for (int a = 0; a < 3; a++)
+        for (int b = 0; b < 3; b++) Pn[(size_t)(N + a) * N1 + N + b] = PLL[3 * a + b];
+      P.swap(Pn);
+      // the landmark: set_from_xyz (UpdaterSLAM.cpp:213-221), then update(H_Linv * res) (:569)
+      double v[3];
+      landmark_set_from_xyz(feat_rep, is_relative(feat_rep) ? pA[f] : pG[f], v);
+      for (int j = 0; j < 3; j++) {
+        new_fej[3 * f + j] = v[j];
+        double d = 0;
+        for (int k = 0; k < 3; k++) d += inv[3 * j + k] * resinit[k];
+        new_val[3 * f + j] = v[j] + d;
+      }
+      new_cov[f] = N;
+      N = N1;
+    }
+    // EKFUpdate with the updating portion (:476-478)
+    if (rup > 0) {
+      std::vector<double> dx(N, 0.0);
+      int rc = ekf_update(P.data(), N, Hup, resup, rup, D, cm.col_cov.data(), sigma2, dx.data());
+      if (rc != OVGPU_OK) status_rc = rc;
+      std::memcpy(dxs.data() + (size_t)f * Nmax, dx.data(), sizeof(double) * N);
+      // Type::update of everything in the state
+      std::vector<double> cq(7 * C), kq(7 * K), iq(8 * K);
+      oracle_apply_dx(opts, &st, dx.data(), cq.data(), kq.data(), iq.data());
+      clone_qp = cq, calib_qp = kq, intr = iq;
+      st.clone_q_p = clone_qp.data(), st.calib_q_p = calib_qp.data(), st.intrinsics = intr.data();
+      for (int l = 0; l < L0; l++)
+        for (int i = 0; i < 3; i++) lm_old[3 * l + i] += dx[lm->cov_id[l] + i];
+      for (int g = 0; g <= f; g++)
+        if (new_cov[g] >= 0)
+          for (int i = 0; i < 3; i++) new_val[3 * g + i] += dx[new_cov[g] + i];
+    }
+  }
+  for (int f = 0; f < F; f++) {
+    if (feat_status) feat_status[f] = status[f];
+    if (chi2_out) chi2_out[f] = chi2v[f];
+    if (chi2_thresh_out) chi2_thresh_out[f] = thrv[f];
+    if (lm_cov_id) lm_cov_id[f] = new_cov[f];
+    for (int i = 0; i < 3; i++) {
+      if (lm_value) lm_value[3 * f + i] = new_val[3 * f + i];
+      if (lm_fej) lm_fej[3 * f + i] = new_fej[3 * f + i];
+    }
+    const bool rel = is_relative(feat_rep) && new_cov[f] >= 0;
+    if (anchor_cam_out) anchor_cam_out[f] = rel ? fv->cam_idx[anchor[f]] : -1;
+    if (anchor_clone_out) anchor_clone_out[f] = rel ? fv->clone_idx[anchor[f]] : -1;
+  }
+  if (dx_seq) std::memcpy(dx_seq, dxs.data(), sizeof(double) * (size_t)F * Nmax);
+  if (N_out) *N_out = N;
+  if (P_out) std::memcpy(P_out, P.data(), sizeof(double) * (size_t)N * N);
+  if (clone_q_p_out) std::memcpy(clone_q_p_out, clone_qp.data(), sizeof(double) * 7 * C);
+  if (calib_q_p_out) std::memcpy(calib_q_p_out, calib_qp.data(), sizeof(double) * 7 * K);
+  if (intrinsics_out) std::memcpy(intrinsics_out, intr.data(), sizeof(double) * 8 * K);
+  if (lm_existing_out && L0 > 0) std::memcpy(lm_existing_out, lm_old.data(), sizeof(double) * 3 * L0);
+  return status_rc;
 }
 
 int oracle_msckf_update(const ovgpu_options *opts, const ovgpu_state_view *st, const ovgpu_features_view *fv, int32_t *feat_status,

@@ -111,6 +111,16 @@ int oracle_msckf_update_given(const ovgpu_options *opts, const ovgpu_state_view 
  * full Jacobian with the landmark's columns, the chi2 gate on all 2m rows (dof 2m), stacking and ONE EKFUpdate on
  * the uncompressed stack (the reference does not compress here).  H_out / res_out (rows_max x D, rows_max = 2 M)
  * return the stacked system for invariant checks; any output may be NULL.                                        */
+/* UpdaterSLAM::delayed_init (UpdaterSLAM.cpp:61-251) + StateHelper::initialize / initialize_invertible
+ * (StateHelper.cpp:393-577), restated with the reference's Givens separation.  given_* (optional) replace
+ * the triangulation stage.  Outputs as ovgpu_slam_delayed_init, plus the state after the call. */
+int oracle_slam_delayed_init(const ovgpu_options *opts, const ovgpu_state_view *st, const ovgpu_landmarks_view *lm,
+                             const ovgpu_features_view *fv, int feat_rep, const double *given_p_FinA, const double *given_p_FinG,
+                             const int32_t *given_anchor, const int32_t *given_status, int32_t *feat_status, double *chi2_out,
+                             double *chi2_thresh_out, int32_t *lm_cov_id, double *lm_value, double *lm_fej, int32_t *anchor_cam_out,
+                             int32_t *anchor_clone_out, double *dx_seq, int32_t *N_out, double *P_out, double *clone_q_p_out,
+                             double *calib_q_p_out, double *intrinsics_out, double *lm_existing_out);
+
 int oracle_slam_update(const ovgpu_options *opts, const ovgpu_state_view *st, const ovgpu_landmarks_view *lm,
                        const ovgpu_features_view *fv, const int32_t *lm_index, int32_t *feat_status, double *chi2,
                        double *chi2_thresh, double *dx, double *P_out, double *lm_out, int32_t *D_out,

@@ -182,7 +182,7 @@ def msckf_update(opts, views, want_compressed=False, given=None):
 
 
 def slam_update(opts, views, want_stack=False):
-    """UpdaterSLAM::update for GLOBAL_3D landmarks (oracle_slam_update); views must carry landmarks."""
+    """UpdaterSLAM::update (oracle_slam_update); views must carry landmarks (any 3-dof representation)."""
     lib = load()
     F, N, M = views.features.F, views.state.N, views.features.M
     L = views.landmarks.L
@@ -205,4 +205,35 @@ def slam_update(opts, views, want_stack=False):
     if want_stack:
         out["H"] = np.ascontiguousarray(H.reshape(-1)[: n * d].reshape(n, d))
         out["r"] = r[:n].copy()
+    return out
+
+
+def slam_delayed_init(opts, views, feat_rep=0, tri=None):
+    """UpdaterSLAM::delayed_init + StateHelper::initialize (oracle_slam_delayed_init).  `tri` (the dict of
+    triangulate()) replaces the triangulation stage.  views may carry landmarks already in the state."""
+    lib = load()
+    F, N, Cn, K = views.features.F, views.state.N, views.state.C, views.state.K
+    Nmax = N + 3 * F
+    L0 = views.landmarks.L if views.landmarks is not None else 0
+    out = dict(feat_status=np.zeros(F, dtype=np.int32), chi2=np.zeros(F), chi2_thresh=np.zeros(F), lm_cov_id=np.zeros(F, dtype=np.int32),
+               lm_value=np.zeros((F, 3)), lm_fej=np.zeros((F, 3)), anchor_cam=np.zeros(F, dtype=np.int32), anchor_clone=np.zeros(F, dtype=np.int32),
+               dx_seq=np.zeros((F, Nmax)), clone_q_p=np.zeros((Cn, 7)), calib_q_p=np.zeros((K, 7)), intrinsics=np.zeros((K, 8)),
+               landmarks_existing=np.zeros((L0, 3)))
+    Pbuf = np.zeros(Nmax * Nmax)
+    N_out = C.c_int32(0)
+    g = {}
+    if tri is not None:
+        g = dict(pA=np.ascontiguousarray(tri["p_FinA"], dtype=np.float64), pG=np.ascontiguousarray(tri["p_FinG"], dtype=np.float64),
+                 an=np.ascontiguousarray(tri["anchor_meas"], dtype=np.int32), st=np.ascontiguousarray(tri["status"], dtype=np.int32))
+    lib.oracle_slam_delayed_init.restype = C.c_int
+    rc = lib.oracle_slam_delayed_init(C.byref(opts), C.byref(views.state), C.byref(views.landmarks) if views.landmarks is not None else None,
+                                      C.byref(views.features), C.c_int(int(feat_rep)), _p(g["pA"]) if g else None, _p(g["pG"]) if g else None,
+                                      _pi(g["an"]) if g else None, _pi(g["st"]) if g else None, _pi(out["feat_status"]), _p(out["chi2"]),
+                                      _p(out["chi2_thresh"]), _pi(out["lm_cov_id"]), _p(out["lm_value"]), _p(out["lm_fej"]), _pi(out["anchor_cam"]),
+                                      _pi(out["anchor_clone"]), _p(out["dx_seq"]), C.byref(N_out), _p(Pbuf), _p(out["clone_q_p"]),
+                                      _p(out["calib_q_p"]), _p(out["intrinsics"]), _p(out["landmarks_existing"]) if L0 else None)
+    out["rc"] = rc
+    n = N_out.value
+    out["N"] = n
+    out["P"] = Pbuf[: n * n].reshape(n, n).copy()
     return out

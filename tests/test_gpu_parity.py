@@ -547,3 +547,150 @@ def test_triangulation_from_explicit_camera_poses(Updater, oracle):
     _check_tri(out, ref, ok)
     assert up.lib.ovgpu_msckf_update_async(up._ctx) == capi.ERR_NO_STATE
     up.close()
+
+
+# --------------------------------------------------------------------------- SLAM landmarks in other representations, delayed initialisation
+@pytest.mark.parametrize("rep", [capi.REP_GLOBAL_FULL_INVERSE_DEPTH, capi.REP_ANCHORED_3D, capi.REP_ANCHORED_FULL_INVERSE_DEPTH,
+                                 capi.REP_ANCHORED_MSCKF_INVERSE_DEPTH])
+def test_slam_update_parity_representations(Updater, oracle, rep):
+    """UpdaterSLAM::update with feat_rep_slam != GLOBAL_3D (EuRoC's default is ANCHORED_MSCKF_INVERSE_DEPTH): the landmark
+    is stored in representation coordinates, its columns are dz/dp * dp/dlambda, anchored ones add the anchor clone /
+    anchor extrinsics blocks."""
+    prob = synth.make_slam_problem(2, L=10, lm_rep=rep)
+    opts = capi.default_options(chi2_multipler=1.0)
+    ref = oracle.slam_update(opts, capi.Views(prob))
+    up = Updater(opts)
+    up.set_slam_problem(prob)
+    out = up.slam_update()
+    assert np.array_equal(out["feat_status"], ref["feat_status"]) and (ref["feat_status"] == capi.FEAT_USED).sum() >= 6
+    gate = np.isfinite(ref["chi2"])
+    np.testing.assert_allclose(out["chi2"][gate], ref["chi2"][gate], rtol=TOL_CHI2)
+    assert _rel(out["dx"], ref["dx"]) < 1e-7
+    assert _rel(out["P"], ref["P"]) < 1e-8
+    np.testing.assert_allclose(out["landmarks"], ref["landmarks"], rtol=1e-9, atol=1e-11)
+    up.close()
+
+
+def _check_delayed_init(out, ref, post):
+    assert np.array_equal(out["feat_status"], ref["feat_status"])
+    gate = np.isfinite(ref["chi2"])
+    np.testing.assert_allclose(out["chi2"][gate], ref["chi2"][gate], rtol=1e-7)
+    np.testing.assert_allclose(out["chi2_thresh"][gate], ref["chi2_thresh"][gate], rtol=1e-12)
+    assert out["N"] == ref["N"] and np.array_equal(out["lm_cov_id"], ref["lm_cov_id"])
+    acc = ref["lm_cov_id"] >= 0
+    assert np.array_equal(out["anchor_cam"], ref["anchor_cam"]) and np.array_equal(out["anchor_clone"], ref["anchor_clone"])
+    np.testing.assert_allclose(out["lm_value"][acc], ref["lm_value"][acc], rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(out["lm_fej"][acc], ref["lm_fej"][acc], rtol=1e-12, atol=1e-14)
+    assert np.isnan(out["lm_value"][~acc]).all()
+    assert _rel(out["dx_seq"], ref["dx_seq"]) < 1e-6 and not out["dx_seq"][~acc].any()
+    assert _rel(out["P"], ref["P"]) < 1e-7
+    np.testing.assert_allclose(out["P"], out["P"].T, rtol=0, atol=1e-13 * np.abs(out["P"]).max())
+    for k in ("clone_q_p", "calib_q_p", "intrinsics"):
+        assert np.abs(post[k] - ref[k]).max() < 1e-9
+
+
+@pytest.mark.parametrize("rep", [capi.REP_GLOBAL_3D, capi.REP_GLOBAL_FULL_INVERSE_DEPTH, capi.REP_ANCHORED_3D, capi.REP_ANCHORED_MSCKF_INVERSE_DEPTH])
+def test_delayed_init_parity(Updater, oracle, rep):
+    """UpdaterSLAM::delayed_init: a chain of StateHelper::initialize calls (Givens split in the oracle, Householder on the
+    GPU), each on the state the previous one left, against the oracle run with the same triangulation."""
+    prob = synth.make_problem(2, F=16, outlier_frac=0.2)
+    opts = capi.default_options(chi2_multipler=1.0)
+    v = capi.Views(prob)
+    tri = oracle.triangulate(opts, v)
+    ref = oracle.slam_delayed_init(opts, v, feat_rep=rep, tri=tri)
+    acc = ref["lm_cov_id"] >= 0
+    assert ref["rc"] == 0 and 4 <= acc.sum() < 16
+    up = Updater(opts)
+    up.set_problem(prob)
+    up.set_triangulation(tri["p_FinG"], tri["p_FinA"], tri["anchor_meas"], tri["status"])
+    out = up.delayed_init(rep)
+    post = up.get_state(P=True)
+    _check_delayed_init(out, ref, post)
+    assert post["P"].shape == out["P"].shape and np.array_equal(post["P"], out["P"])
+    lm = up.get_landmarks()
+    assert np.array_equal(lm["cov_id"], ref["lm_cov_id"][acc]) and np.array_equal(lm["value"], out["lm_value"][acc])
+    up.close()
+
+
+def _split_tracks(prob, pred, feats=None):
+    """Tracks restricted to the measurements whose clone index satisfies pred (and to the features `feats`)."""
+    feats = range(len(prob.meas_offsets) - 1) if feats is None else feats
+    keep, cnt = [], []
+    for f in feats:
+        ids = np.arange(prob.meas_offsets[f], prob.meas_offsets[f + 1])
+        ids = ids[pred(prob.clone_idx[ids])]
+        keep.append(ids)
+        cnt.append(len(ids))
+    keep = np.concatenate(keep)
+    return dict(meas_offsets=np.concatenate([[0], np.cumsum(cnt)]).astype(np.int32), uv=np.asarray(prob.uv).reshape(-1, 2)[keep].reshape(-1),
+                uvn=np.asarray(prob.uvn).reshape(-1, 2)[keep].reshape(-1),
+                clone_idx=prob.clone_idx[keep], cam_idx=prob.cam_idx[keep])
+
+
+def test_delayed_init_end_to_end_then_slam_update(Updater, oracle):
+    """Device triangulation -> delayed initialisation (older half of every track) on a state that already holds landmarks
+    -> UpdaterSLAM::update of the landmarks that were just created with the newer half of the tracks, everything
+    resident: the oracle is walked through the same steps."""
+    prob = synth.make_slam_problem(2, L=3, seed=11)
+    tracks = synth.make_problem(2, F=10, seed=11)
+    old_value = prob.lm_value.copy()
+    for k, a in _split_tracks(tracks, lambda c: c < 15).items():
+        setattr(prob, k, a)
+    opts = capi.default_options(chi2_multipler=1.0)
+    v = capi.Views(prob)
+    ref = oracle.slam_delayed_init(opts, v, feat_rep=0)
+    acc = ref["lm_cov_id"] >= 0
+    assert acc.sum() >= 5
+    up = Updater(opts)
+    up.set_slam_problem(prob)
+    out = up.delayed_init(0)
+    # device triangulation differs from the oracle's in the last digits (TOL_TRI), the chain amplifies that a little
+    assert np.array_equal(out["feat_status"], ref["feat_status"]) and out["N"] == ref["N"]
+    np.testing.assert_allclose(out["lm_value"][acc], ref["lm_value"][acc], rtol=1e-6, atol=1e-8)
+    assert _rel(out["P"], ref["P"]) < 1e-6 and _rel(out["dx_seq"], ref["dx_seq"]) < 1e-5
+    lm = up.get_landmarks()
+    assert lm["value"].shape[0] == 3 + acc.sum()
+    np.testing.assert_allclose(lm["value"][:3], ref["landmarks_existing"], rtol=1e-7, atol=1e-9)
+    assert np.abs(lm["value"][:3] - old_value).max() > 0
+    # ---- a SLAM update of the new landmarks with the newer measurements, on the resident state
+    idx = np.flatnonzero(acc)
+    newer = _split_tracks(tracks, lambda c: c >= 15, idx)
+    sub = synth.make_problem(2, F=10, seed=11)
+    p2 = synth.make_problem(2, F=10, seed=11)  # the oracle's side: the posterior of its own delayed init as the prior
+    p2.N, p2.P = ref["N"], ref["P"]
+    p2.clone_q_p, p2.calib_q_p, p2.intrinsics = ref["clone_q_p"], ref["calib_q_p"], ref["intrinsics"]
+    for k, a in newer.items():
+        setattr(p2, k, a)
+        setattr(sub, k, a)
+    p2.lm_value = np.concatenate([ref["landmarks_existing"], ref["lm_value"][acc]])
+    p2.lm_fej = np.concatenate([prob.lm_fej, ref["lm_fej"][acc]])
+    p2.lm_cov_id = np.concatenate([prob.lm_cov_id, ref["lm_cov_id"][acc]]).astype(np.int32)
+    p2.lm_index = (3 + np.arange(len(idx))).astype(np.int32)
+    ref2 = oracle.slam_update(opts, capi.Views(p2))
+    assert (ref2["feat_status"] == capi.FEAT_USED).sum() >= 3
+    up.set_features(sub)
+    out2 = up.slam_update(lm_index=p2.lm_index)
+    assert np.array_equal(out2["feat_status"], ref2["feat_status"])
+    assert _rel(out2["dx"], ref2["dx"]) < 1e-5 and _rel(out2["P"], ref2["P"]) < 1e-6
+    np.testing.assert_allclose(out2["landmarks"], ref2["landmarks"], rtol=1e-6, atol=1e-8)
+    up.close()
+
+
+def test_msckf_update_with_resident_landmarks(Updater, oracle):
+    """UpdaterMSCKF::update on a state that holds SLAM landmarks (VioManager.cpp:525 runs it before the SLAM update): the
+    landmark columns stay zero, the landmarks are corrected through their cross-covariance only."""
+    prob = synth.make_slam_problem(2, L=5, seed=3)
+    tracks = synth.make_problem(2, F=40, seed=4)
+    for k in ("meas_offsets", "uv", "uvn", "clone_idx", "cam_idx", "p_FinG_true"):
+        setattr(prob, k, getattr(tracks, k))
+    opts = capi.default_options(chi2_multipler=1.0)
+    plain = synth.make_problem(2, F=40, seed=4)
+    plain.N, plain.P = prob.N, prob.P
+    plain.clone_q_p, plain.clone_q_p_fej, plain.calib_q_p, plain.intrinsics = prob.clone_q_p, prob.clone_q_p_fej, prob.calib_q_p, prob.intrinsics
+    ref = oracle.msckf_update(opts, capi.Views(plain))
+    up = Updater(opts)
+    up.set_slam_problem(prob)
+    out = up.update()
+    assert np.array_equal(out["feat_status"], ref["feat_status"])
+    assert _rel(out["dx"], ref["dx"]) < 1e-7 and _rel(out["P"], ref["P"]) < 1e-8
+    up.close()

@@ -347,3 +347,105 @@ def test_slam_gate_rejects_a_displaced_landmark():
     prob.lm_value[3] += np.array([0.8, -0.6, 0.5])  # far outside its 0.1 m prior
     o = pyoracle.slam_update(capi.default_options(chi2_multipler=1.0), capi.Views(prob))
     assert o["feat_status"][3] == capi.FEAT_CHI2_REJECTED and o["chi2"][3] > o["chi2_thresh"][3]
+
+
+@pytest.mark.parametrize("rep", [capi.REP_GLOBAL_FULL_INVERSE_DEPTH, capi.REP_ANCHORED_3D, capi.REP_ANCHORED_MSCKF_INVERSE_DEPTH])
+def test_slam_update_in_other_representations(rep):
+    """Landmarks stored in another representation (Landmark::value() coordinates): the stack the oracle returns must
+    reproduce the posterior in information form, and the landmark columns must be the GLOBAL_3D ones chained with
+    d xyz / d lambda — checked through finite differences of get_xyz on the residual."""
+    from oracle import pyoracle
+    prob = synth.make_slam_problem(2, L=8, lm_rep=rep)
+    opts = capi.default_options(chi2_multipler=5.0)
+    v = capi.Views(prob)
+    o = pyoracle.slam_update(opts, v, want_stack=True)
+    assert o["stats"]["status"] == 0
+    used = o["feat_status"] == capi.FEAT_USED
+    assert used.sum() >= 6
+    H = np.zeros((o["rows"], prob.N))
+    H[:, o["col_cov_id"]] = o["H"]
+    Pinf = np.linalg.inv(np.linalg.inv(prob.P) + H.T @ H)
+    assert np.linalg.norm(o["P"] - Pinf) / np.linalg.norm(Pinf) < 1e-8
+    # residual(lambda + e) - residual(lambda) ~ -H_lambda e   (do_fej = 0 so the Jacobian is evaluated at the estimate)
+    opts0 = capi.default_options(chi2_multipler=1e9, do_fej=0)
+    base = pyoracle.slam_update(opts0, v, want_stack=True)
+    f = 2
+    rows = slice(int(2 * prob.meas_offsets[f]), int(2 * prob.meas_offsets[f + 1]))
+    cols = [int(np.where(base["col_cov_id"] == prob.lm_cov_id[f] + i)[0][0]) for i in range(3)]
+    for i in range(3):
+        # central differences; the residual goes through a float32 round trip (CamBase::distort_d), hence the large step
+        eps = 1e-3 * max(abs(prob.lm_value[f, i]), 0.05)
+        rr = []
+        for sgn in (+1, -1):
+            p2 = synth.make_slam_problem(2, L=8, lm_rep=rep)
+            p2.lm_value[f, i] += sgn * eps
+            rr.append(pyoracle.slam_update(opts0, capi.Views(p2), want_stack=True)["r"][rows])
+        fd = -(rr[0] - rr[1]) / (2 * eps)
+        assert np.abs(fd - base["H"][rows, cols[i]]).max() < 5e-3 * max(1.0, np.abs(fd).max())
+
+
+def _joint_information_form(prob, opts, f, pG, pA, anchor):
+    """Posterior of [state ; landmark] from the prior on the state, NO prior on the landmark and all 2m rows of feature f."""
+    from oracle import pyoracle
+    v = capi.Views(prob)
+    H_f, H_x, res = pyoracle.feature_jacobian(opts, v, f, pG, pA, anchor)
+    cols = np.zeros(H_x.shape[1], np.int32)
+    D = pyoracle.load().oracle_column_map(C.byref(opts), C.byref(v.state), cols.ctypes.data_as(C.POINTER(C.c_int32)))
+    N = prob.N
+    J = np.zeros((H_x.shape[0], N + 3))
+    J[:, cols[:D]] = H_x
+    J[:, N:] = H_f
+    info = J.T @ J / opts.sigma_pix ** 2
+    info[:N, :N] += np.linalg.inv(prob.P)
+    Pj = np.linalg.inv(info)
+    return Pj, Pj @ J.T @ res / opts.sigma_pix ** 2
+
+
+@pytest.mark.parametrize("rep", [capi.REP_GLOBAL_3D, capi.REP_ANCHORED_MSCKF_INVERSE_DEPTH])
+def test_delayed_init_of_one_feature_equals_joint_least_squares(rep):
+    """StateHelper::initialize = Givens split + invertible initialisation + EKF update with the remaining rows.  For one
+    feature that is, exactly, the linear least-squares posterior of [state; landmark] with a flat prior on the landmark."""
+    from oracle import pyoracle
+    prob = synth.make_problem(2, F=1)
+    opts = capi.default_options(chi2_multipler=1e6, feat_rep_msckf=rep)
+    v = capi.Views(prob)
+    tri = pyoracle.triangulate(opts, v)
+    assert tri["status"][0] == capi.FEAT_USED
+    o = pyoracle.slam_delayed_init(opts, v, feat_rep=rep, tri=tri)
+    assert o["rc"] == 0 and o["N"] == prob.N + 3 and o["lm_cov_id"][0] == prob.N
+    Pj, dj = _joint_information_form(prob, opts, 0, tri["p_FinG"][0], tri["p_FinA"][0], int(tri["anchor_meas"][0]))
+    assert np.linalg.norm(o["P"] - Pj) / np.linalg.norm(Pj) < 1e-7
+    np.testing.assert_allclose(o["P"], o["P"].T, atol=1e-12 * np.abs(o["P"]).max())
+    dx = o["dx_seq"][0, : prob.N + 3]
+    total = np.concatenate([dx[: prob.N], o["lm_value"][0] - o["lm_fej"][0]])
+    assert np.linalg.norm(total - dj) / np.linalg.norm(dj) < 1e-6
+    xyz = tri["p_FinA"][0] if rep >= 2 else tri["p_FinG"][0]
+    np.testing.assert_allclose(o["lm_fej"][0], synth.landmark_from_xyz(rep, xyz), rtol=1e-13)
+
+
+def test_delayed_init_chain_bookkeeping():
+    """Several features, some gated out: the covariance grows by 3 per accepted feature in feature order, rejected ones
+    leave no trace (zero dx row, no id), the posterior stays symmetric positive definite and every accepted landmark ends
+    close to the truth; an already-resident landmark receives the corrections through its cross-covariance."""
+    from oracle import pyoracle
+    prob = synth.make_slam_problem(2, L=3, seed=5)
+    prob2 = synth.make_problem(2, F=12, seed=5, outlier_frac=0.25)
+    # new tracks on the state that already holds 3 landmarks
+    for k in ("meas_offsets", "uv", "uvn", "clone_idx", "cam_idx", "p_FinG_true"):
+        setattr(prob, k, getattr(prob2, k))
+    opts = capi.default_options(chi2_multipler=1.0)
+    v = capi.Views(prob)
+    o = pyoracle.slam_delayed_init(opts, v, feat_rep=0)
+    acc = o["feat_status"] == capi.FEAT_USED
+    assert 3 <= acc.sum() < 12 and (o["feat_status"] == capi.FEAT_CHI2_REJECTED).sum() >= 1
+    assert o["N"] == prob.N + 3 * acc.sum()
+    np.testing.assert_array_equal(o["lm_cov_id"][acc], prob.N + 3 * np.arange(acc.sum()))
+    assert (o["lm_cov_id"][~acc] == -1).all() and not o["dx_seq"][~acc].any()
+    assert np.linalg.eigvalsh(0.5 * (o["P"] + o["P"].T)).min() > 0
+    err = np.linalg.norm(o["lm_value"][acc] - prob2.p_FinG_true[acc], axis=1)
+    assert (err < 0.25 * np.linalg.norm(prob2.p_FinG_true[acc], axis=1)).all()  # depth from a short baseline
+    assert np.abs(o["landmarks_existing"] - prob.lm_value).max() > 0  # moved by the updates
+    m = np.diff(prob.meas_offsets)
+    from scipy import stats as sps
+    gated = np.isfinite(o["chi2"])
+    np.testing.assert_allclose(o["chi2_thresh"][gated], sps.chi2.ppf(0.95, 2 * m[gated]), rtol=1e-10)
