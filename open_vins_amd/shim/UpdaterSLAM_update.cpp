@@ -2,8 +2,9 @@
 // rpng/open_vins v2.7).  Delete that definition from UpdaterSLAM.cpp and compile this file next to it (the class
 // declaration, the constructor, delayed_init, change_anchors and perform_anchor_change stay the reference's).
 // Mode A, like the MSCKF shim: the GPU builds, gates, stacks and compresses the system, the stock
-// StateHelper::EKFUpdate applies it.  Landmark representation: GLOBAL_3D (StateOptions.h:89 default); for any other
-// representation the call falls through to the reference code kept under update_reference().
+// StateHelper::EKFUpdate applies it.  Landmark representations: the five 3-dof ones (GLOBAL_3D ... ANCHORED_MSCKF_INVERSE_DEPTH,
+// LandmarkRepresentation.h:38-46), all landmarks of a call in the same one (StateOptions::feat_rep_slam); the 1-dof
+// ANCHORED_INVERSE_DEPTH_SINGLE and ArUco tags with their own options stay on the reference's CPU path.
 #include "UpdaterSLAM.h"
 
 #include "feat/Feature.h"
@@ -59,15 +60,18 @@ void UpdaterSLAM::update(std::shared_ptr<State> state, std::vector<std::shared_p
   const ovgpu_shim::CloneIndex clones(fs.clone_times);
   ovgpu_shim::FlatFeatures ff;
   std::vector<double> lm_value, lm_fej;
-  std::vector<int32_t> lm_cov, lm_index;
+  std::vector<int32_t> lm_cov, lm_index, lm_anchor_cam, lm_anchor_clone;
+  const auto rep = state->_options.feat_rep_slam;
+  if (rep == LandmarkRepresentation::Representation::ANCHORED_INVERSE_DEPTH_SINGLE)
+    throw std::runtime_error("ovgpu SLAM shim: ANCHORED_INVERSE_DEPTH_SINGLE is not supported on the GPU path");
   auto it0 = feature_vec.begin();
   while (it0 != feature_vec.end()) {
     (*it0)->clean_old_measurements(fs.clone_times);
     int ct_meas = 0;
     for (const auto &pair : (*it0)->timestamps) ct_meas += (int)pair.second.size();
     std::shared_ptr<Landmark> landmark = state->_features_SLAM.at((*it0)->featid);
-    if (landmark->_feat_representation != LandmarkRepresentation::Representation::GLOBAL_3D)
-      throw std::runtime_error("ovgpu SLAM shim: only GLOBAL_3D landmarks are supported on the GPU path");
+    if (landmark->_feat_representation != rep)
+      throw std::runtime_error("ovgpu SLAM shim: every landmark of a call must use StateOptions::feat_rep_slam");
     if (ct_meas < 1) { // :289-291
       (*it0)->to_delete = true;
       it0 = feature_vec.erase(it0);
@@ -80,7 +84,11 @@ void UpdaterSLAM::update(std::shared_ptr<State> state, std::vector<std::shared_p
                     [&](size_t i, float &a, float &b) { a = uvn[i](0), b = uvn[i](1); }, clones);
     }
     ff.end_feature();
-    const Eigen::Vector3d v = landmark->get_xyz(false), vf = landmark->get_xyz(true); // :349-352
+    // the library holds Landmark::value() / fej() — representation coordinates — and applies get_xyz itself (:345-353)
+    const Eigen::Vector3d v = landmark->value(), vf = landmark->fej();
+    const bool relative = LandmarkRepresentation::is_relative_representation(rep);
+    lm_anchor_cam.push_back(relative ? cam_index.at(landmark->_anchor_cam_id) : -1);
+    lm_anchor_clone.push_back(relative ? clones.find(landmark->_anchor_clone_timestamp) : -1);
     lm_index.push_back((int32_t)lm_cov.size());
     lm_cov.push_back(landmark->id());
     lm_value.insert(lm_value.end(), v.data(), v.data() + 3), lm_fej.insert(lm_fej.end(), vf.data(), vf.data() + 3);
@@ -101,7 +109,9 @@ void UpdaterSLAM::update(std::shared_ptr<State> state, std::vector<std::shared_p
   const ovgpu_state_view sv = fs.view();
   const ovgpu_features_view fv = ff.view();
   ovgpu_landmarks_view lv;
-  lv.L = (int32_t)lm_cov.size(), lv._pad0 = 0, lv.p_value = lm_value.data(), lv.p_fej = lm_fej.data(), lv.cov_id = lm_cov.data();
+  lv.L = (int32_t)lm_cov.size(), lv.feat_rep = (int32_t)rep; // ovgpu_feat_rep follows the enum order of LandmarkRepresentation.h:38-46
+  lv.p_value = lm_value.data(), lv.p_fej = lm_fej.data(), lv.cov_id = lm_cov.data();
+  lv.anchor_cam = lm_anchor_cam.data(), lv.anchor_clone = lm_anchor_clone.data();
   g_slam_ctx->check(ovgpu_set_state(g_slam_ctx->get(), &sv), "ovgpu_set_state");
   g_slam_ctx->check(ovgpu_set_landmarks(g_slam_ctx->get(), &lv), "ovgpu_set_landmarks");
   g_slam_ctx->check(ovgpu_set_features(g_slam_ctx->get(), &fv), "ovgpu_set_features");

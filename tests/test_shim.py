@@ -25,3 +25,14 @@ def test_feature_initializer_shim_keeps_the_class_api():
     for name in ("single_triangulation", "single_triangulation_1d", "single_gaussnewton"):  # FeatureInitializer.h:100-122
         assert f"bool FeatureInitializer::{name}(std::shared_ptr<Feature> feat, std::unordered_map<size_t, std::unordered_map<double, ClonePose>> &clonesCAM)" in src
     assert "ovgpu_set_camera_poses" in src and "oracle" not in src
+
+
+def test_slam_shims_keep_the_reference_signatures():
+    d = os.path.join(ROOT, "open_vins_amd", "shim")
+    upd = open(os.path.join(d, "UpdaterSLAM_update.cpp")).read()
+    ini = open(os.path.join(d, "UpdaterSLAM_delayed_init.cpp")).read()
+    # ov_msckf/src/update/UpdaterSLAM.h: update / delayed_init
+    assert "void UpdaterSLAM::update(std::shared_ptr<State> state, std::vector<std::shared_ptr<Feature>> &feature_vec)" in upd
+    assert "void UpdaterSLAM::delayed_init(std::shared_ptr<State> state, std::vector<std::shared_ptr<Feature>> &feature_vec)" in ini
+    assert "ovgpu_slam_compress" in upd and "ovgpu_slam_delayed_init" in ini and "lv.feat_rep" in upd and "lv.feat_rep" in ini
+    assert "oracle" not in upd and "oracle" not in ini
