@@ -144,7 +144,9 @@ __global__ void __launch_bounds__(SYS_NT) k_system(SysParams p) {
 #else
 #define SYS_T(i)
 #endif
-  for (int f = p.f_begin + blockIdx.x; f < p.f_end; f += gridDim.x) {
+  for (int slot = p.f_begin + blockIdx.x; slot < p.f_end; slot += gridDim.x) {
+    // longest tracks first: workgroups are handed out in blockIdx order, so the tail of the launch is made of short features
+    const int f = p.order ? p.order[slot] : slot;
     const int m0 = p.meas_offsets[f];
     const int m = p.meas_offsets[f + 1] - m0;
     const int64_t orow0 = p.row_off[f];

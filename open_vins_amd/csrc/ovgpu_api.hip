@@ -124,7 +124,7 @@ struct ovgpu_ctx {
   DevBuf<float> uv, uvn;
   DevBuf<int64_t> row_off;
   DevBuf<double> pA, pG, chi2, chi2_thr;
-  DevBuf<int32_t> anchor, status;
+  DevBuf<int32_t> anchor, status, sys_order; // sys_order: feature indices by descending track length
   DevBuf<double> chi2_table;
   int chi2_table_len = 0;
   std::vector<double> h_chi2_table;
@@ -319,7 +319,7 @@ void ovgpu_destroy(ovgpu_ctx *c) {
   c->intr_col.release(), c->col_cov.release(), c->col_kind.release(), c->col_sub.release(), c->col_var.release();
   c->tab_clone.release(), c->tab_cam.release(), c->tab_cc.release();
   c->meas_offsets.release(), c->meas_cc.release(), c->uv.release(), c->uvn.release(), c->row_off.release();
-  c->pA.release(), c->pG.release(), c->chi2.release(), c->chi2_thr.release(), c->anchor.release(), c->status.release();
+  c->pA.release(), c->pG.release(), c->chi2.release(), c->chi2_thr.release(), c->anchor.release(), c->status.release(), c->sys_order.release();
   c->chi2_table.release(), c->Hbig.release(), c->gate_ws.release(), c->Rws.release(), c->tree_nodes.release(), c->tree_nodes2.release(), c->tree_flags.release(), c->tree_err.release(), c->Mt.release(), c->Aaug.release(), c->Yaug.release();
   c->pFej.release(), c->lm_val.release(), c->lm_fej.release(), c->feat_lm.release(), c->feat_lmcol.release(), c->feat_lmcov.release(), c->lm_cov.release();
   c->feat_anchor.release(), c->lm_col.release(), c->lm_anchor.release(), c->lm_index.release(), c->Ppad.release(), c->init_ws.release(), c->dx_seq.release();
@@ -606,6 +606,13 @@ int ovgpu_set_features(ovgpu_ctx *c, const ovgpu_features_view *fv) {
   HIPCHK(c->status.reserve(F));
 
   hipStream_t s = c->stream;
+  std::vector<int32_t> order(std::max(F, 1), 0);
+  for (int f = 0; f < F; f++) order[f] = f;
+  std::stable_sort(order.begin(), order.begin() + F, [&](int32_t a, int32_t b) {
+    return fv->meas_offsets[a + 1] - fv->meas_offsets[a] > fv->meas_offsets[b + 1] - fv->meas_offsets[b];
+  });
+  HIPCHK(c->sys_order.reserve(std::max(F, 1)));
+  HIPCHK(upload(c->sys_order.p, order.data(), sizeof(int32_t) * F, s));
   HIPCHK(upload(c->meas_offsets.p, fv->meas_offsets, sizeof(int32_t) * (F + 1), s));
   HIPCHK(upload(c->meas_cc.p, cc.data(), sizeof(uint16_t) * M, s));
   HIPCHK(upload(c->uv.p, fv->uv, sizeof(float) * 2 * M, s));
@@ -656,9 +663,10 @@ static int enqueue_system(ovgpu_ctx *c, int f_one = -1, int init_rep = 0) {
   p.slam = c->slam_rows ? 1 : 0;
   p.p_fej = c->pFej.p, p.feat_lm = c->feat_lm.p, p.feat_lmcol = c->feat_lmcol.p, p.feat_lmcov = c->feat_lmcov.p, p.feat_anchor = c->feat_anchor.p;
   if (p.slam) p.opt.feat_rep = c->lm_rep; // the landmarks' representation, not the MSCKF features'
-  p.f_begin = 0, p.f_end = c->F, p.init = 0, p.init_out = nullptr, p.init_flag = nullptr;
+  p.f_begin = 0, p.f_end = c->F, p.init = 0, p.init_out = nullptr, p.init_flag = nullptr, p.order = c->sys_order.p;
   int grid = c->sys_grid;
   if (f_one >= 0) {
+    p.order = nullptr;
     p.f_begin = f_one, p.f_end = f_one + 1, p.init = 1, p.init_out = c->init_ws.p, p.init_flag = c->init_ctr.p + 2;
     p.opt.feat_rep = init_rep;
     grid = 1;

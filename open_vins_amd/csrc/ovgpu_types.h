@@ -72,6 +72,7 @@ struct SysParams {
   const int32_t *feat_anchor; // [F] anchored SLAM landmarks: packed (camera << 10 | clone) of the landmark's anchor
   // feature range of this launch (the delayed initialisation runs one feature at a time)
   int f_begin, f_end;
+  const int32_t *order;     // [F] processing order (feature indices, longest track first) or nullptr
   // StateHelper::initialize mode (UpdaterSLAM::delayed_init): MSCKF-style system, gate against chi2(2m), and the three
   // rows Q1^T [H_x | res] plus R1 = Q1^T H_f that determine the new landmark go to init_out [3 * LD + 9]
   int init;
