@@ -20,6 +20,7 @@
 #include "k_tsqr_pw.h"
 #include "k_ekf.h"
 #include "k_slam.h"
+#include "k_tsqr_blk.h"
 #include "k_system.h"
 #include "k_triangulate.h"
 #include "ovgpu_types.h"
@@ -213,6 +214,18 @@ static int launch_qr_node(ovgpu_ctx *c, int nodes, const QrNodeParams &q) {
 // leaf nodes: the "panel wave" variant (k_tsqr_pw.h), NT <= 15
 template <int QH>
 static int launch_qr_leaf_pw(ovgpu_ctx *c, int nodes, const QrNodeParams &q) {
+  // OVGPU_TSQR_LEAF=blocked: the compact-WY leaf on the matrix cores (k_tsqr_blk.h) — experimental, see DESIGN.md §4
+  static const bool blocked = [] { const char *e = std::getenv("OVGPU_TSQR_LEAF"); return e && std::string(e) == "blocked"; }();
+  if (blocked && QH == 32) {
+    static bool attr_b = false;
+    if (!attr_b) {
+      (void)hipFuncSetAttribute((const void *)blk::k_qr_leaf<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr_b = true;
+    }
+    hipLaunchKernelGGL((blk::k_qr_leaf<0>), dim3(nodes), dim3(64 * (pw::qr_node_bulk_waves(q.NT) + 1)), blk::qr_leaf_lds_bytes(q.NT), c->stream, q);
+    HIPCHK(hipGetLastError());
+    return OVGPU_OK;
+  }
   const size_t lds = pw::qr_node_lds_bytes(q.NT, QH);
   static bool attr_done = false;
   if (!attr_done) {

@@ -397,7 +397,7 @@ def test_compression_is_independent_of_the_tree_shape(Updater, oracle, kw):
     base = _compress_with_env(Updater, prob, opts, tri, OVGPU_TSQR_W=1)
     G0, g0 = base["H"].T @ base["H"], base["H"].T @ base["r"]
     for env in (dict(OVGPU_TSQR_W=2), dict(OVGPU_TSQR_W=5), dict(OVGPU_TSQR_W=64), dict(OVGPU_TSQR_W=64, OVGPU_TSQR_PIPELINE=0),
-                dict(OVGPU_TSQR_W=64, OVGPU_TSQR_OVERLAP=0), dict(OVGPU_TSQR_W=256), dict(OVGPU_TSQR_W=256, OVGPU_TSQR_OVERLAP=1)):
+                dict(OVGPU_TSQR_W=64, OVGPU_TSQR_OVERLAP=0), dict(OVGPU_TSQR_W=256), dict(OVGPU_TSQR_W=256, OVGPU_TSQR_OVERLAP=1)):  # (OVGPU_TSQR_LEAF is read once per process: tests/test_blocked_leaf.py)
         c = _compress_with_env(Updater, prob, opts, tri, **env)
         assert c["rows"] == base["rows"] and c["D"] == base["D"]
         assert np.abs(np.tril(c["H"], -1)).max() == 0.0

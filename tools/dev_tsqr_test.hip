@@ -8,6 +8,7 @@
 #include <cmath>
 #include "k_tsqr.h"
 #include "k_tsqr_pw.h"
+#include "k_tsqr_blk.h"
 using namespace ovg;
 
 template <int QH, bool TRI>
@@ -16,6 +17,11 @@ static void launch(int nodes, const QrNodeParams &q) {
   hipLaunchKernelGGL((k_qr_node<QH, TRI>), dim3(nodes), dim3(64 * ((q.NT + 1) / 2)), qr_node_lds_bytes(q.NT, QH), 0, q);
 }
 static void launch_leaf(int nodes, const QrNodeParams &q) {
+  if (getenv("BLK") && atoi(getenv("BLK"))) {
+    hipFuncSetAttribute((const void *)blk::k_qr_leaf<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL((blk::k_qr_leaf<0>), dim3(nodes), dim3(64 * (pw::qr_node_bulk_waves(q.NT) + 1)), blk::qr_leaf_lds_bytes(q.NT), 0, q);
+    return;
+  }
   hipFuncSetAttribute((const void *)pw::k_qr_node<32, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   hipLaunchKernelGGL((pw::k_qr_node<32, false>), dim3(nodes), dim3(64 * (pw::qr_node_bulk_waves(q.NT) + 1)), pw::qr_node_lds_bytes(q.NT, 32), 0, q);
 }
@@ -52,6 +58,10 @@ int main(int argc, char **argv) {
   QrNodeParams q{};
   q.D = D, q.LD = LD, q.NT = NT, q.acc = dR, q.acc_stride = 1, q.src = dA, q.src_stride = 0;
   q.rows_per_node = (rows + G - 1) / G, q.rows_total = rows, q.zero_init = 1, q.dbg = nullptr, q.progress = nullptr;
+#ifdef QR_PROFILE
+  hipMalloc((void **)&q.dbg, 1024 * 8);
+  hipMemset(q.dbg, 0, 1024 * 8);
+#endif
   if (argc > 4) q.rows_per_node = atoi(argv[4]); // e.g. all rows in node 0: the other leaves are zero triangles (steps with tau' = 0)
   // merge tree description
   std::vector<QrTreeNode> nodes;
@@ -96,6 +106,15 @@ int main(int argc, char **argv) {
   const double ge = gram_err(A, rows, R, D, LD, &wi, &wj);
   double low = 0;
   for (int i = 0; i < D; i++) for (int j = 0; j < i; j++) low = fmax(low, fabs(R[(size_t)i * LD + j]));
+#ifdef QR_PROFILE
+  if (getenv("BLK") && atoi(getenv("BLK"))) {
+    long long h[128];
+    hipMemcpy(h, q.dbg, sizeof(h), hipMemcpyDeviceToHost);
+    printf("blocked leaf, node 0, cycles per wave [loop top, factor, wait A, urgent+rows, wait B, apply/handover, -, -]\n");
+    for (int w = 0; w < 8; w++) printf("  wave %d: %8lld %8lld %8lld %8lld %8lld %8lld\n", w, h[w * 8], h[w * 8 + 1], h[w * 8 + 2], h[w * 8 + 3], h[w * 8 + 4], h[w * 8 + 5]);
+    printf("  panel wave factor phases [scalars, broadcast x, apply, G, T, publish]: %lld %lld %lld %lld %lld %lld\n", h[64 + 56], h[64 + 57], h[64 + 58], h[64 + 59], h[64 + 60], h[64 + 61]);
+  }
+#endif
   printf("D=%d rows=%d G=%d : gram rel err %.3e (worst %d,%d) lower %.1e wait-timeout %d hip=%s | leaf %.1f us, tree(%d nodes) %.1f us\n", D, rows, G, ge, wi, wj, low, err,
          hipGetErrorString(hipGetLastError()), tl * 1e3, (int)nodes.size(), tt * 1e3);
   // reference: level-by-level merges with the un-pipelined node kernel (timing only)
