@@ -507,21 +507,36 @@ __global__ void __launch_bounds__(SYS_NT) k_system(SysParams p) {
         }
         __syncthreads();
         SYS_T(0)
-        // trailing update: S[i][j] -= sum_l L[i][kb + l] L[j][kb + l]   for kb + nb <= j <= min(i, n - 1), i < n + 4
+        // trailing update: S[i][j] -= sum_l L[i][kb + l] L[j][kb + l]   for kb + nb <= j <= min(i, n - 1), i < n + 4.
+        // Register tile of 4 rows per thread: the 8 multipliers of row j are read from LDS once for 4 rows (the update is
+        // LDS-bandwidth bound: 9 reads per element with one row per thread, 3.25 with four).
         {
           const int ti = tid >> 4, tj = tid & 15;
-          for (int i = kb + nb + ti; i < n + 4; i += SYS_NT / 16) {
-            double li[CB];
+          for (int i0 = kb + nb + ti; i0 < n + 4; i0 += 64) {
+            double li[4][CB];
+            int jm[4]; // last column of each row, -1 for a row past the end
 #pragma unroll
-            for (int l2 = 0; l2 < CB; l2++) li[l2] = (l2 < nb) ? S[sidx(i, kb + l2, n)] : 0.0;
-            const int jmax = min(i, n - 1);
-#pragma unroll 2
-            for (int j = kb + nb + tj; j <= jmax; j += 16) {
-              double acc = S[sidx(i, j, n)];
+            for (int u = 0; u < 4; u++) {
+              const int i = i0 + 16 * u;
+              jm[u] = i < n + 4 ? min(i, n - 1) : -1;
 #pragma unroll
-              for (int l2 = 0; l2 < CB; l2++)
-                if (l2 < nb) acc = fma(-li[l2], S[sidx(j, kb + l2, n)], acc);
-              S[sidx(i, j, n)] = acc;
+              for (int l2 = 0; l2 < CB; l2++) li[u][l2] = (jm[u] >= 0 && l2 < nb) ? S[sidx(i, kb + l2, n)] : 0.0;
+            }
+            const int jall = max(max(jm[0], jm[1]), max(jm[2], jm[3]));
+            for (int j = kb + nb + tj; j <= jall; j += 16) {
+              double lj[CB];
+#pragma unroll
+              for (int l2 = 0; l2 < CB; l2++) lj[l2] = l2 < nb ? S[sidx(j, kb + l2, n)] : 0.0;
+#pragma unroll
+              for (int u = 0; u < 4; u++) {
+                if (j <= jm[u]) {
+                  const size_t e = sidx(i0 + 16 * u, j, n);
+                  double acc = S[e];
+#pragma unroll
+                  for (int l2 = 0; l2 < CB; l2++) acc = fma(-li[u][l2], lj[l2], acc);
+                  S[e] = acc;
+                }
+              }
             }
           }
         }
