@@ -371,6 +371,44 @@ int ovgpu_get_landmarks(ovgpu_ctx *ctx, int32_t *L_out, double *value, double *f
                         int32_t *cov_id, int32_t *anchor_cam, int32_t *anchor_clone);
 
 /* ------------------------------------------------------------------------- */
+/* Window bookkeeping on the RESIDENT covariance: the steps either   */
+/* side of the update, so that P does not cross PCIe between frames.  The means of the    */
+/* variables the library does not hold (IMU, time offset ...) stay with the caller.       */
+/* After each call the feature batch has to be uploaded again (ovgpu_set_features): clone  */
+/* indices and covariance ids changed.                                                     */
+/* ------------------------------------------------------------------------- */
+
+/* StateHelper::marginalize (StateHelper.cpp:271-339): removes rows / columns
+ * [cov_id, cov_id + size) of the covariance; every resident variable behind it moves forward by
+ * `size` (:320-323).  When a resident clone or landmark starts at cov_id it is dropped — the
+ * clones / landmarks behind it move down by one INDEX as well (StateHelper::marginalize_old_clone,
+ * marginalize_slam, :618-651); a calibration variable at cov_id stops being estimated.      */
+int ovgpu_state_marginalize(ovgpu_ctx *ctx, int32_t cov_id, int32_t size);
+
+/* StateHelper::clone of a 6-dof pose at the end of the covariance (StateHelper.cpp:341-391) plus
+ * the time-offset part of StateHelper::augment_clone (:601-615).
+ *   src_cov_id   id of the pose being cloned (State::_imu->pose(), or any 6-dof pose)
+ *   q_p, q_p_fej [7]  value and first estimate of the new clone (PoseJPL::clone copies both)
+ *   dt_cov_id    id of the camera time offset, -1 when it is not calibrated (:601)
+ *   dnc_dt [6]   [last_w ; v_I] (:603-605), read when dt_cov_id >= 0
+ *   new_cov_id   out: id of the new clone (the old covariance dimension); its clone index is the
+ *                old clone count                                                           */
+int ovgpu_state_augment_clone(ovgpu_ctx *ctx, int32_t src_cov_id, const double *q_p,
+                              const double *q_p_fej, int32_t dt_cov_id, const double *dnc_dt,
+                              int32_t *new_cov_id);
+
+/* StateHelper::EKFPropagation (StateHelper.cpp:36-114): P(new, :) = Phi P(old, :), P(new, new) =
+ * Phi P(old, old) Phi^T + Q for the contiguous block [new_cov_id, new_cov_id + n_new).
+ *   old_cov_ids [n_old]  covariance index of every COLUMN of Phi (the flattened order_OLD)
+ *   Phi [n_new * n_old] row-major, Q [n_new * n_new] (its upper triangle is used, :87)
+ * OVGPU_ERR_NEGATIVE_DIAGONAL mirrors the reference's exit on a negative diagonal (:101-113). */
+int ovgpu_state_propagate(ovgpu_ctx *ctx, int32_t new_cov_id, int32_t n_new, int32_t n_old,
+                          const int32_t *old_cov_ids, const double *Phi, const double *Q);
+
+/* Current dimension of the resident covariance and number of resident clones. */
+int ovgpu_state_dims(ovgpu_ctx *ctx, int32_t *N_out, int32_t *C_out);
+
+/* ------------------------------------------------------------------------- */
 /* the two helpers of the path as standalone calls (UpdaterZeroVelocity.cpp:183-321 */
 /* and any other updater stack a dense system and call them this way)         */
 /* ------------------------------------------------------------------------- */

@@ -185,6 +185,10 @@ def declare(lib):
         "ovgpu_measurement_compress": (C.c_int, [ctxp, C.c_int, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p, c_int32_p]),
         "ovgpu_ekf_update": (C.c_int, [ctxp, C.c_int, C.c_int, c_int32_p, c_double_p, c_double_p, C.c_double, c_double_p, c_double_p]),
         "ovgpu_set_landmarks": (C.c_int, [ctxp, C.POINTER(LandmarksView)]),
+        "ovgpu_state_marginalize": (C.c_int, [ctxp, C.c_int32, C.c_int32]),
+        "ovgpu_state_augment_clone": (C.c_int, [ctxp, C.c_int32, c_double_p, c_double_p, C.c_int32, c_double_p, c_int32_p]),
+        "ovgpu_state_propagate": (C.c_int, [ctxp, C.c_int32, C.c_int32, C.c_int32, c_int32_p, c_double_p, c_double_p]),
+        "ovgpu_state_dims": (C.c_int, [ctxp, c_int32_p, c_int32_p]),
         "ovgpu_get_landmarks": (C.c_int, [ctxp, c_int32_p, c_double_p, c_double_p, c_int32_p, c_int32_p, c_int32_p]),
         "ovgpu_slam_delayed_init": (C.c_int, [ctxp, C.c_int32, c_int32_p, c_double_p, c_double_p, c_int32_p, c_double_p, c_double_p, c_int32_p,
                                               c_int32_p, c_double_p, c_int32_p, c_double_p, C.POINTER(UpdateStats)]),

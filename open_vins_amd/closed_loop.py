@@ -86,6 +86,76 @@ def _compose(last_est, truth_last, truth_new):
     return np.concatenate([q, last_est[4:] + truth_new[4:] - truth_last[4:]]), dR
 
 
+def _frame_problem(stream, tracks, frames, N, P, clones, fej, calib, intr):
+    """The snapshot handed to the updater at one frame: state + the tracks that ended at the previous frame."""
+    C, K = stream.C, 1
+    base = 16 + 14 * K
+    idx = {f: i for i, f in enumerate(frames)}
+    offs, uv, uvn, ci = [0], [], [], []
+    for obs in tracks:
+        obs = [o for o in obs if o[0] in idx]
+        for (f, un, vn, xu, yu) in obs:
+            uv += [un, vn]
+            uvn += [xu, yu]
+            ci.append(idx[f])
+        offs.append(len(ci))
+    return synth.Problem(
+        cfg=1, seed=0, N=N, C=C, K=K, P=np.ascontiguousarray(P), clone_q_p=np.ascontiguousarray(clones),
+        clone_q_p_fej=np.ascontiguousarray(fej), clone_q_p_true=stream.truth[frames], clone_cov_id=(base + 6 * np.arange(C)).astype(np.int32),
+        calib_q_p=np.ascontiguousarray(calib), calib_q_p_true=stream.calib_true[None, :], intrinsics=np.ascontiguousarray(intr),
+        cam_is_fisheye=np.zeros(K, np.uint8), calib_cov_id=np.array([16], np.int32), intr_cov_id=np.array([22], np.int32),
+        meas_offsets=np.asarray(offs, np.int32), uv=np.asarray(uv, np.float32), uvn=np.asarray(uvn, np.float32),
+        clone_idx=np.asarray(ci, np.int32), cam_idx=np.zeros(len(ci), np.int32), p_FinG_true=np.zeros((len(tracks), 3)))
+
+
+def _initial_state(stream):
+    C, K = stream.C, 1
+    base = 16 + 14 * K
+    sig = synth.state_sigmas(C, K)
+    sig[base:] = np.tile([0.01] * 3 + [0.03] * 3, C)
+    N = base + 6 * C
+    P = np.diag(sig ** 2)
+    clones = np.stack([synth.boxplus_pose(stream.truth[i], stream.init_noise[i]) for i in range(C)])
+    calib = synth.boxplus_pose(stream.calib_true, stream.calib_noise)[None, :]
+    intr = (stream.intr_true + stream.intr_noise)[None, :]
+    return base, N, P, clones, calib, intr
+
+
+def run_resident(stream: Stream, up):
+    """The same filter with the covariance RESIDENT on the device between frames: cloning = ovgpu_state_augment_clone +
+    ovgpu_state_propagate, marginalisation = ovgpu_state_marginalize, update = ovgpu_set_features + ovgpu_msckf_update;
+    the state is uploaded once.  `up` is an open_vins_amd.updater.UpdaterMSCKF."""
+    C = stream.C
+    base, N, P, clones, calib, intr = _initial_state(stream)
+    frames = list(range(C))
+    up.set_problem(_frame_problem(stream, [], frames, N, P, clones, clones.copy(), calib, intr))
+    est, used = {frames[-1]: clones[-1].copy()}, {}
+    last = clones[-1].copy()
+    for t in range(C, stream.T):
+        new, dR = _compose(last, stream.truth[t - 1], stream.truth[t])
+        new = synth.boxplus_pose(new, stream.clone_noise[t])
+        Phi = np.zeros((6, 6))
+        Phi[:3, :3], Phi[3:, 3:] = dR, np.eye(3)
+        Q = np.diag([stream.q_theta ** 2] * 3 + [stream.q_p ** 2] * 3)
+        nid = up.state_augment_clone(base + 6 * (C - 1), new)            # StateHelper::clone of the newest pose
+        up.state_propagate(nid, nid + np.arange(6), Phi, Q)              # EKFPropagation of the new block
+        up.state_marginalize(base, 6)                                    # the oldest clone leaves the window
+        frames = frames[1:] + [t]
+        tracks = stream.tracks[t]
+        if tracks:
+            dummy = np.zeros((C, 7))
+            dummy[:, 3] = 1.0
+            up.set_features(_frame_problem(stream, tracks, frames, N, P, dummy, dummy, calib, intr))
+            out = up.update()
+            used[t] = int(np.sum(out["feat_status"] == 0))
+            last = out["clone_q_p"][-1].copy()
+        else:
+            last = up.get_state(P=False)["clone_q_p"][-1].copy()
+        est[t] = last.copy()
+    ts = sorted(est)
+    return dict(frames=np.array(ts), est=np.stack([est[t] for t in ts]), truth=stream.truth[ts], used=used)
+
+
 def run(stream: Stream, update_fn=None):
     """Runs the sliding-window filter over the stream.  update_fn(prob) -> dict(P, clone_q_p, calib_q_p, intrinsics,
     feat_status); None = no updates (dead reckoning).  Returns per-frame estimates of the newest clone and the truth."""
@@ -118,22 +188,7 @@ def run(stream: Stream, update_fn=None):
         # ---- MSCKF update with the tracks that ended at t - 1
         tracks = stream.tracks[t]
         if update_fn is not None and tracks:
-            idx = {f: i for i, f in enumerate(frames)}
-            offs, uv, uvn, ci = [0], [], [], []
-            for obs in tracks:
-                obs = [o for o in obs if o[0] in idx]
-                for (f, un, vn, xu, yu) in obs:
-                    uv += [un, vn]
-                    uvn += [xu, yu]
-                    ci.append(idx[f])
-                offs.append(len(ci))
-            prob = synth.Problem(
-                cfg=1, seed=0, N=N, C=C, K=K, P=np.ascontiguousarray(P), clone_q_p=np.ascontiguousarray(clones),
-                clone_q_p_fej=np.ascontiguousarray(fej), clone_q_p_true=stream.truth[frames], clone_cov_id=(base + 6 * np.arange(C)).astype(np.int32),
-                calib_q_p=np.ascontiguousarray(calib), calib_q_p_true=stream.calib_true[None, :], intrinsics=np.ascontiguousarray(intr),
-                cam_is_fisheye=np.zeros(K, np.uint8), calib_cov_id=np.array([16], np.int32), intr_cov_id=np.array([22], np.int32),
-                meas_offsets=np.asarray(offs, np.int32), uv=np.asarray(uv, np.float32), uvn=np.asarray(uvn, np.float32),
-                clone_idx=np.asarray(ci, np.int32), cam_idx=np.zeros(len(ci), np.int32), p_FinG_true=np.zeros((len(tracks), 3)))
+            prob = _frame_problem(stream, tracks, frames, N, P, clones, fej, calib, intr)
             out = update_fn(prob)
             P = 0.5 * (out["P"] + out["P"].T)
             clones, calib, intr = out["clone_q_p"].copy(), out["calib_q_p"].copy(), out["intrinsics"].copy()

@@ -76,6 +76,85 @@ __global__ void k_cov_copy(int n, int nd, const double *__restrict__ src, int ld
   if (i < nd && j < nd) dst[(size_t)i * ldd + j] = (i < n && j < n) ? src[(size_t)i * lds + j] : 0.0;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// window bookkeeping on the resident covariance (pure data movement: one thread per element)
+// ---------------------------------------------------------------------------------------------------
+// StateHelper::marginalize (StateHelper.cpp:271-339): dst = src without rows / columns [id, id + size).  The lower-left block is
+// the transpose of the upper-right one, as in the reference (:303-304).
+__global__ void k_cov_remove(int N, int id, int size, const double *__restrict__ src, double *__restrict__ dst) {
+  const int Nn = N - size;
+  const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+  if (i >= Nn || j >= Nn) return;
+  int si = i < id ? i : i + size, sj = j < id ? j : j + size;
+  if (i >= id && j < id) { // P(x2, x1) := P(x1, x2)^T
+    const int t = si;
+    si = sj, sj = t;
+  }
+  dst[(size_t)i * Nn + j] = src[(size_t)si * N + sj];
+}
+
+// StateHelper::clone (StateHelper.cpp:341-391): rows / columns [nid, nid + n) := those of [sid, sid + n); P has leading dimension N
+__global__ void k_cov_clone(int N, int n_old, int sid, int nid, int n, double *P) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x; // index over the OLD rows, or n_old .. n_old + n*n - 1 for the corner
+  if (i < n_old) {
+    for (int a = 0; a < n; a++) {
+      P[(size_t)i * N + nid + a] = P[(size_t)i * N + sid + a];
+      P[(size_t)(nid + a) * N + i] = P[(size_t)(sid + a) * N + i];
+    }
+  } else if (i < n_old + n * n) {
+    const int a = (i - n_old) / n, b = (i - n_old) % n;
+    P[(size_t)(nid + a) * N + nid + b] = P[(size_t)(sid + a) * N + sid + b];
+  }
+}
+
+// StateHelper::augment_clone, time-offset Jacobian (StateHelper.cpp:607-610), the two statements in the reference's order:
+// pass 0: P(:, nid + j) += P(:, dt) dnc[j];   pass 1: P(nid + i, :) += dnc[i] P(dt, :)
+__global__ void k_cov_dt(int N, int nid, int dt, const double *__restrict__ dnc, double *P, int pass) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= N) return;
+  if (pass == 0) {
+    const double pd = P[(size_t)t * N + dt];
+    for (int j = 0; j < 6; j++) P[(size_t)t * N + nid + j] += pd * dnc[j];
+  } else {
+    const double pd = P[(size_t)dt * N + t];
+    for (int i = 0; i < 6; i++) P[(size_t)(nid + i) * N + t] += dnc[i] * pd;
+  }
+}
+
+// StateHelper::EKFPropagation (StateHelper.cpp:36-114)
+//   pass 0: W[i][a]   = sum_k P[i][old_k] Phi[a][k]                        (Cov_PhiT, :77-82)
+//   pass 1: PCP[a][b] = Qsym[a][b] + sum_k Phi[a][k] W[old_k][b]           (:85-90)
+//   pass 2: P(new, :) = W^T, P(:, new) = W, P(new, new) = PCP, negative diagonal -> flags[1]   (:93-113)
+__global__ void k_cov_propagate(int N, int nid, int n_new, int n_old, const int32_t *__restrict__ old_ids, const double *__restrict__ Phi,
+                                const double *__restrict__ Q, double *P, double *W, double *PCP, int32_t *flags, int pass) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pass == 0) {
+    if (t >= N * n_new) return;
+    const int i = t / n_new, a = t % n_new;
+    double s = 0.0;
+    for (int k = 0; k < n_old; k++) s = fma(P[(size_t)i * N + old_ids[k]], Phi[(size_t)a * n_old + k], s);
+    W[t] = s;
+  } else if (pass == 1) {
+    if (t >= n_new * n_new) return;
+    const int a = t / n_new, b = t % n_new;
+    double s = a <= b ? Q[(size_t)a * n_new + b] : Q[(size_t)b * n_new + a]; // Q.selfadjointView<Upper>()
+    for (int k = 0; k < n_old; k++) s = fma(Phi[(size_t)a * n_old + k], W[(size_t)old_ids[k] * n_new + b], s);
+    PCP[t] = s;
+  } else {
+    if (t >= N * n_new) return;
+    const int i = t / n_new, a = t % n_new;
+    if (i >= nid && i < nid + n_new) {
+      const double v = PCP[(size_t)(i - nid) * n_new + a];
+      P[(size_t)i * N + nid + a] = v;
+      if (i - nid == a && v < 0.0) flags[1] = 1;
+    } else {
+      const double v = W[t];
+      P[(size_t)i * N + nid + a] = v;
+      P[(size_t)(nid + a) * N + i] = v;
+    }
+  }
+}
+
 struct InitParams {
   int N, D, LD;             // N = leading dimension of P (the padded capacity)
   int rep, f;

@@ -102,6 +102,9 @@ struct ovgpu_ctx {
   std::vector<int32_t> h_col_cov;
   struct HVar { int cov, size, kind, index; };
   std::vector<HVar> h_vars; // clones + calibrated camera variables of the resident state (landmarks are merged in by build_columns)
+  std::vector<int32_t> h_clone_cov, h_calib_cov, h_intr_cov; // covariance ids as the kernels see them (-1: not estimated)
+  DevBuf<double> prop_w, prop_in; // EKFPropagation workspaces
+  DevBuf<int32_t> prop_ids;
   // SLAM landmarks (ovgpu_set_landmarks); L > 0 switches the per-feature kernel to the UpdaterSLAM rules
   int L = 0;
   int lm_rep = OVGPU_REP_GLOBAL_3D; // representation of the resident landmarks (StateOptions::feat_rep_slam)
@@ -161,6 +164,18 @@ struct ovgpu_ctx {
   size_t ev_used = 0;
   bool timing = true;
 };
+
+// removes element `idx` of a device array of `n` records of `w` doubles / ints (through a scratch copy: the ranges overlap)
+template <class T>
+static hipError_t remove_record(DevBuf<T> &a, DevBuf<T> &tmp, int n, int w, int idx, hipStream_t s) {
+  const size_t tail = (size_t)(n - idx - 1) * w;
+  if (tail == 0) return hipSuccess;
+  hipError_t e = tmp.reserve(tail);
+  if (e != hipSuccess) return e;
+  e = hipMemcpyAsync(tmp.p, a.p + (size_t)(idx + 1) * w, tail * sizeof(T), hipMemcpyDeviceToDevice, s);
+  if (e != hipSuccess) return e;
+  return hipMemcpyAsync(a.p + (size_t)idx * w, tmp.p, tail * sizeof(T), hipMemcpyDeviceToDevice, s);
+}
 
 static hipError_t upload(void *dst, const void *src, size_t bytes, hipStream_t s) {
   if (bytes == 0) return hipSuccess;
@@ -336,7 +351,7 @@ void ovgpu_destroy(ovgpu_ctx *c) {
   c->chi2_table.release(), c->Hbig.release(), c->gate_ws.release(), c->Rws.release(), c->tree_nodes.release(), c->tree_nodes2.release(), c->tree_flags.release(), c->tree_err.release(), c->Mt.release(), c->Aaug.release(), c->Yaug.release();
   c->pFej.release(), c->lm_val.release(), c->lm_fej.release(), c->feat_lm.release(), c->feat_lmcol.release(), c->feat_lmcov.release(), c->lm_cov.release();
   c->feat_anchor.release(), c->lm_col.release(), c->lm_anchor.release(), c->lm_index.release(), c->Ppad.release(), c->init_ws.release(), c->dx_seq.release();
-  c->init_ctr.release(), c->feat_slot.release();
+  c->init_ctr.release(), c->feat_slot.release(), c->prop_w.release(), c->prop_in.release(), c->prop_ids.release();
   c->dx.release(), c->flags.release(), c->given_status.release();
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
@@ -462,6 +477,8 @@ int ovgpu_set_state(ovgpu_ctx *c, const ovgpu_state_view *st) {
     calib_cov[k] = (c->dopt.do_calib_pose && st->calib_cov_id[k] >= 0) ? st->calib_cov_id[k] : -1;
     intr_cov[k] = (c->dopt.do_calib_intr && st->intr_cov_id[k] >= 0) ? st->intr_cov_id[k] : -1;
   }
+  c->h_clone_cov.assign(st->clone_cov_id, st->clone_cov_id + C);
+  c->h_calib_cov = calib_cov, c->h_intr_cov = intr_cov;
   HIPCHK(upload(c->P.p, st->P, sizeof(double) * N * N, s));
   HIPCHK(upload(c->clone_qp.p, st->clone_q_p, sizeof(double) * 7 * C, s));
   HIPCHK(upload(c->clone_fej.p, st->clone_q_p_fej, sizeof(double) * 7 * C, s));
@@ -1354,6 +1371,201 @@ int ovgpu_slam_delayed_init(ovgpu_ctx *c, int32_t feat_rep, int32_t *feat_status
   return OVGPU_OK;
 }
 
+
+// ---------------------------------------------------------------------------
+// Window bookkeeping on the resident covariance: StateHelper::marginalize, clone / augment_clone,
+// EKFPropagation.  The host keeps the covariance ids of the resident variables; the kernels move the data.
+// ---------------------------------------------------------------------------
+// h_vars, the device copies of the ids, the column map, the pose tables and the reset baseline after a structural change
+static int rebuild_variables(ovgpu_ctx *c) {
+  const int C = c->C, K = c->K, N = c->N;
+  c->h_vars.clear();
+  for (int k = 0; k < K; k++) {
+    if (c->h_calib_cov[k] >= 0) c->h_vars.push_back({c->h_calib_cov[k], 6, COL_CALIB_POSE, k});
+    if (c->h_intr_cov[k] >= 0) c->h_vars.push_back({c->h_intr_cov[k], 8, COL_CALIB_INTR, k});
+  }
+  for (int i = 0; i < C; i++) c->h_vars.push_back({c->h_clone_cov[i], 6, COL_CLONE, i});
+  hipStream_t s = c->stream;
+  HIPCHK(c->clone_cov.reserve(C));
+  HIPCHK(c->clone_col.reserve(C));
+  HIPCHK(upload(c->clone_cov.p, c->h_clone_cov.data(), sizeof(int32_t) * C, s));
+  HIPCHK(upload(c->calib_cov.p, c->h_calib_cov.data(), sizeof(int32_t) * K, s));
+  HIPCHK(upload(c->intr_cov.p, c->h_intr_cov.data(), sizeof(int32_t) * K, s));
+  if (c->L > 0) HIPCHK(upload(c->lm_cov.p, c->h_lm_cov.data(), sizeof(int32_t) * c->L, s));
+  HIPCHK(c->tab_clone.reserve(24 * (size_t)C));
+  HIPCHK(c->tab_cc.reserve((size_t)12 * K * C));
+  HIPCHK(c->dx.reserve(N));
+  int rc = build_columns(c); // synchronises
+  if (rc != OVGPU_OK) return rc;
+  // the state as it is now is what ovgpu_reset_state goes back to
+  HIPCHK(c->P0.reserve((size_t)N * N));
+  HIPCHK(c->clone_qp0.reserve(7 * (size_t)C));
+  HIPCHK(hipMemcpyAsync(c->P0.p, c->P.p, sizeof(double) * N * N, hipMemcpyDeviceToDevice, s));
+  HIPCHK(hipMemcpyAsync(c->clone_qp0.p, c->clone_qp.p, sizeof(double) * 7 * C, hipMemcpyDeviceToDevice, s));
+  HIPCHK(hipMemcpyAsync(c->calib_qp0.p, c->calib_qp.p, sizeof(double) * 7 * K, hipMemcpyDeviceToDevice, s));
+  HIPCHK(hipMemcpyAsync(c->intr0.p, c->intr.p, sizeof(double) * 8 * K, hipMemcpyDeviceToDevice, s));
+  return launch_build_tables(c);
+}
+
+int ovgpu_state_dims(ovgpu_ctx *c, int32_t *N_out, int32_t *C_out) {
+  if (!c) return set_err(OVGPU_ERR_INVALID, "null ctx");
+  if (!c->have_state || c->poses_only) return set_err(OVGPU_ERR_NO_STATE, "ovgpu_set_state was never called");
+  if (N_out) *N_out = c->N;
+  if (C_out) *C_out = c->C;
+  return OVGPU_OK;
+}
+
+int ovgpu_state_marginalize(ovgpu_ctx *c, int32_t cov_id, int32_t size) {
+  if (!c) return set_err(OVGPU_ERR_INVALID, "null ctx");
+  if (!c->have_state || c->poses_only) return set_err(OVGPU_ERR_NO_STATE, "ovgpu_set_state was never called");
+  if (cov_id < 0 || size <= 0 || cov_id + size > c->N) return set_err(OVGPU_ERR_INVALID, "marginalised block outside the covariance");
+  HIPCHK(hipSetDevice(c->device));
+  hipStream_t s = c->stream;
+  const int N = c->N, Nn = N - size;
+  // a resident variable that starts inside the block must be exactly the block
+  auto hit = [&](int id, int sz) { return id >= 0 && id < cov_id + size && id + sz > cov_id; };
+  int drop_clone = -1, drop_lm = -1;
+  for (int i = 0; i < c->C; i++)
+    if (hit(c->h_clone_cov[i], 6)) {
+      if (c->h_clone_cov[i] != cov_id || size != 6 || c->C <= 1) return set_err(OVGPU_ERR_INVALID, "block cuts through a clone (or it is the last one)");
+      drop_clone = i;
+    }
+  for (int l = 0; l < c->L; l++)
+    if (hit(c->h_lm_cov[l], 3)) {
+      if (c->h_lm_cov[l] != cov_id || size != 3) return set_err(OVGPU_ERR_INVALID, "block cuts through a landmark");
+      drop_lm = l;
+    }
+  for (int k = 0; k < c->K; k++) {
+    if (hit(c->h_calib_cov[k], 6)) {
+      if (c->h_calib_cov[k] != cov_id || size != 6) return set_err(OVGPU_ERR_INVALID, "block cuts through a camera pose");
+      c->h_calib_cov[k] = -1;
+    }
+    if (hit(c->h_intr_cov[k], 8)) {
+      if (c->h_intr_cov[k] != cov_id || size != 8) return set_err(OVGPU_ERR_INVALID, "block cuts through camera intrinsics");
+      c->h_intr_cov[k] = -1;
+    }
+  }
+  if (drop_lm >= 0 && c->lm_rep >= OVGPU_REP_ANCHORED_3D) { /* anchors are packed clone indices: fixed up below */ }
+  // ---- covariance
+  HIPCHK(c->Ppad.reserve((size_t)std::max(Nn, 1) * std::max(Nn, 1)));
+  if (Nn > 0) {
+    dim3 g((Nn + 255) / 256, Nn);
+    hipLaunchKernelGGL(k_cov_remove, g, dim3(256), 0, s, N, (int)cov_id, (int)size, c->P.p, c->Ppad.p);
+    HIPCHK(hipGetLastError());
+  }
+  std::swap(c->P, c->Ppad);
+  c->N = Nn;
+  // ---- resident variables: ids behind the block move forward (:320-323), a dropped clone / landmark leaves its arrays
+  DevBuf<double> tmpd;
+  DevBuf<int32_t> tmpi;
+  if (drop_clone >= 0) {
+    HIPCHK(remove_record(c->clone_qp, tmpd, c->C, 7, drop_clone, s));
+    HIPCHK(remove_record(c->clone_fej, tmpd, c->C, 7, drop_clone, s));
+    c->h_clone_cov.erase(c->h_clone_cov.begin() + drop_clone);
+    c->C -= 1;
+  }
+  if (drop_lm >= 0) {
+    HIPCHK(remove_record(c->lm_val, tmpd, c->L, 3, drop_lm, s));
+    HIPCHK(remove_record(c->lm_fej, tmpd, c->L, 3, drop_lm, s));
+    HIPCHK(remove_record(c->lm_anchor, tmpi, c->L, 1, drop_lm, s));
+    c->h_lm_cov.erase(c->h_lm_cov.begin() + drop_lm);
+    c->L -= 1;
+  }
+  HIPCHK(hipStreamSynchronize(s)); // the scratch copies go out of scope
+  tmpd.release(), tmpi.release();
+  auto shift = [&](int32_t &id) { if (id > cov_id) id -= size; };
+  for (auto &id : c->h_clone_cov) shift(id);
+  for (auto &id : c->h_calib_cov) shift(id);
+  for (auto &id : c->h_intr_cov) shift(id);
+  for (auto &id : c->h_lm_cov) shift(id);
+  if (drop_clone >= 0 && c->L > 0 && c->lm_rep >= OVGPU_REP_ANCHORED_3D) {
+    // anchored landmarks refer to clone INDICES: the clones behind the dropped one moved down; a landmark anchored in the dropped
+    // clone must have been re-anchored before (UpdaterSLAM::change_anchors runs before marginalize_old_clone, VioManager.cpp:585-590)
+    std::vector<int32_t> anc(c->L);
+    HIPCHK(hipMemcpy(anc.data(), c->lm_anchor.p, sizeof(int32_t) * c->L, hipMemcpyDeviceToHost));
+    for (auto &a : anc) {
+      if (a < 0) continue;
+      const int cam = a >> 10, cl = a & 1023;
+      if (cl == drop_clone) return set_err(OVGPU_ERR_INVALID, "a resident landmark is anchored in the marginalised clone");
+      a = (cam << 10) | (cl > drop_clone ? cl - 1 : cl);
+    }
+    HIPCHK(hipMemcpy(c->lm_anchor.p, anc.data(), sizeof(int32_t) * c->L, hipMemcpyHostToDevice));
+  }
+  return rebuild_variables(c);
+}
+
+int ovgpu_state_augment_clone(ovgpu_ctx *c, int32_t src_cov_id, const double *q_p, const double *q_p_fej, int32_t dt_cov_id, const double *dnc_dt,
+                              int32_t *new_cov_id) {
+  if (!c || !q_p || !q_p_fej) return set_err(OVGPU_ERR_INVALID, "null argument");
+  if (!c->have_state || c->poses_only) return set_err(OVGPU_ERR_NO_STATE, "ovgpu_set_state was never called");
+  if (src_cov_id < 0 || src_cov_id + 6 > c->N) return set_err(OVGPU_ERR_INVALID, "cloned pose outside the covariance");
+  if (dt_cov_id >= c->N || (dt_cov_id >= 0 && !dnc_dt)) return set_err(OVGPU_ERR_INVALID, "bad time-offset argument");
+  if (c->C + 1 > OVG_MAX_CLONES) return set_err(OVGPU_ERR_CAPACITY, "too many clones");
+  HIPCHK(hipSetDevice(c->device));
+  hipStream_t s = c->stream;
+  const int N = c->N, Nn = N + 6, C = c->C;
+  // ---- covariance: grow, copy the pose's rows / columns to the end (StateHelper.cpp:348-372)
+  HIPCHK(c->Ppad.reserve((size_t)Nn * Nn));
+  {
+    dim3 g((Nn + 255) / 256, Nn);
+    hipLaunchKernelGGL(k_cov_copy, g, dim3(256), 0, s, N, Nn, c->P.p, N, c->Ppad.p, Nn);
+    std::swap(c->P, c->Ppad);
+    hipLaunchKernelGGL(k_cov_clone, dim3((N + 36 + 255) / 256), dim3(256), 0, s, Nn, N, (int)src_cov_id, N, 6, c->P.p);
+    HIPCHK(hipGetLastError());
+  }
+  if (dt_cov_id >= 0) { // :601-611
+    HIPCHK(c->prop_in.reserve(64));
+    HIPCHK(upload(c->prop_in.p, dnc_dt, sizeof(double) * 6, s));
+    HIPCHK(hipStreamSynchronize(s));
+    hipLaunchKernelGGL(k_cov_dt, dim3((Nn + 255) / 256), dim3(256), 0, s, Nn, N, (int)dt_cov_id, c->prop_in.p, c->P.p, 0);
+    hipLaunchKernelGGL(k_cov_dt, dim3((Nn + 255) / 256), dim3(256), 0, s, Nn, N, (int)dt_cov_id, c->prop_in.p, c->P.p, 1);
+    HIPCHK(hipGetLastError());
+  }
+  c->N = Nn;
+  // ---- the clone joins the resident ones (State::_clones_IMU[timestamp] = pose, :597)
+  HIPCHK(c->clone_qp.grow(7 * (size_t)(C + 1), 7 * (size_t)C));
+  HIPCHK(c->clone_fej.grow(7 * (size_t)(C + 1), 7 * (size_t)C));
+  HIPCHK(upload(c->clone_qp.p + 7 * C, q_p, sizeof(double) * 7, s));
+  HIPCHK(upload(c->clone_fej.p + 7 * C, q_p_fej, sizeof(double) * 7, s));
+  HIPCHK(hipStreamSynchronize(s));
+  c->h_clone_cov.push_back(N);
+  c->C = C + 1;
+  if (new_cov_id) *new_cov_id = N;
+  return rebuild_variables(c);
+}
+
+int ovgpu_state_propagate(ovgpu_ctx *c, int32_t new_cov_id, int32_t n_new, int32_t n_old, const int32_t *old_cov_ids, const double *Phi,
+                          const double *Q) {
+  if (!c || !old_cov_ids || !Phi || !Q) return set_err(OVGPU_ERR_INVALID, "null argument");
+  if (!c->have_state || c->poses_only) return set_err(OVGPU_ERR_NO_STATE, "ovgpu_set_state was never called");
+  if (n_new <= 0 || n_old <= 0 || new_cov_id < 0 || new_cov_id + n_new > c->N) return set_err(OVGPU_ERR_INVALID, "propagated block outside the covariance"); // :41-44
+  for (int k = 0; k < n_old; k++)
+    if (old_cov_ids[k] < 0 || old_cov_ids[k] >= c->N) return set_err(OVGPU_ERR_INVALID, "old variable outside the covariance");
+  HIPCHK(hipSetDevice(c->device));
+  hipStream_t s = c->stream;
+  const int N = c->N;
+  HIPCHK(c->prop_in.reserve((size_t)n_new * n_old + (size_t)n_new * n_new));
+  HIPCHK(c->prop_ids.reserve(n_old));
+  HIPCHK(c->prop_w.reserve((size_t)N * n_new + (size_t)n_new * n_new));
+  double *dPhi = c->prop_in.p, *dQ = dPhi + (size_t)n_new * n_old, *W = c->prop_w.p, *PCP = W + (size_t)N * n_new;
+  HIPCHK(upload(dPhi, Phi, sizeof(double) * n_new * n_old, s));
+  HIPCHK(upload(dQ, Q, sizeof(double) * n_new * n_new, s));
+  HIPCHK(upload(c->prop_ids.p, old_cov_ids, sizeof(int32_t) * n_old, s));
+  HIPCHK(hipMemsetAsync(c->flags.p, 0, 4 * sizeof(int32_t), s));
+  HIPCHK(hipStreamSynchronize(s)); // the caller's buffers may change
+  const int n1 = N * n_new;
+  for (int pass = 0; pass < 3; pass++) {
+    const int n = pass == 1 ? n_new * n_new : n1;
+    hipLaunchKernelGGL(k_cov_propagate, dim3((n + 255) / 256), dim3(256), 0, s, N, (int)new_cov_id, (int)n_new, (int)n_old, c->prop_ids.p, dPhi, dQ, c->P.p, W,
+                       PCP, c->flags.p, pass);
+  }
+  HIPCHK(hipGetLastError());
+  int32_t flags[4] = {0, 0, 0, 0};
+  HIPCHK(hipMemcpyAsync(flags, c->flags.p, sizeof(flags), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  if (flags[1]) return set_err(OVGPU_ERR_NEGATIVE_DIAGONAL, "negative covariance diagonal after the propagation");
+  return OVGPU_OK;
+}
 
 // ---------------------------------------------------------------------------
 // UpdaterHelper::measurement_compress_inplace and StateHelper::EKFUpdate as standalone calls on a

@@ -225,6 +225,33 @@ class UpdaterMSCKF:
                                                     _ip(out["anchor_cam"]), _ip(out["anchor_clone"])), "ovgpu_get_landmarks")
         return out
 
+    # ---- window bookkeeping on the resident covariance (StateHelper::marginalize / clone / EKFPropagation) ----
+    def _refresh_dims(self):
+        n, c = C.c_int32(0), C.c_int32(0)
+        capi.check(self.lib.ovgpu_state_dims(self._ctx, C.byref(n), C.byref(c)), "ovgpu_state_dims")
+        self.N, self.Cn = n.value, c.value
+
+    def state_marginalize(self, cov_id, size):
+        capi.check(self.lib.ovgpu_state_marginalize(self._ctx, int(cov_id), int(size)), "ovgpu_state_marginalize")
+        self._refresh_dims()
+
+    def state_augment_clone(self, src_cov_id, q_p, q_p_fej=None, dt_cov_id=-1, dnc_dt=None):
+        q = np.ascontiguousarray(q_p, dtype=np.float64)
+        qf = np.ascontiguousarray(q_p_fej if q_p_fej is not None else q_p, dtype=np.float64)
+        d = np.ascontiguousarray(dnc_dt, dtype=np.float64) if dnc_dt is not None else None
+        new_id = C.c_int32(0)
+        capi.check(self.lib.ovgpu_state_augment_clone(self._ctx, int(src_cov_id), _dp(q), _dp(qf), int(dt_cov_id), _dp(d), C.byref(new_id)),
+                   "ovgpu_state_augment_clone")
+        self._refresh_dims()
+        return new_id.value
+
+    def state_propagate(self, new_cov_id, old_cov_ids, Phi, Q):
+        Phi = np.ascontiguousarray(Phi, dtype=np.float64)
+        Q = np.ascontiguousarray(Q, dtype=np.float64)
+        ids = np.ascontiguousarray(old_cov_ids, dtype=np.int32)
+        rc = self.lib.ovgpu_state_propagate(self._ctx, int(new_cov_id), Phi.shape[0], Phi.shape[1], _ip(ids), _dp(Phi), _dp(Q))
+        capi.check(rc, "ovgpu_state_propagate")
+
     # ---- standalone helpers (UpdaterHelper::measurement_compress_inplace, StateHelper::EKFUpdate) ----
     def measurement_compress(self, H, res):
         H = np.ascontiguousarray(H, dtype=np.float64)

@@ -1886,6 +1886,70 @@ int oracle_slam_delayed_init(const ovgpu_options *opts, const ovgpu_state_view *
   return status_rc;
 }
 
+// ---------------------------------------------------------------------------
+// Window bookkeeping, restated on a dense row-major covariance.
+// ---------------------------------------------------------------------------
+// StateHelper::marginalize — StateHelper.cpp:271-339.  P_out is (N - size)^2.
+void oracle_marginalize(const double *P, int N, int marg_id, int marg_size, double *P_out) {
+  const int x2_size = N - marg_id - marg_size, Nn = N - marg_size;
+  for (int i = 0; i < marg_id; i++)
+    for (int j = 0; j < marg_id; j++) P_out[(size_t)i * Nn + j] = P[(size_t)i * N + j]; // P(x1, x1) :297
+  for (int i = 0; i < marg_id; i++)
+    for (int j = 0; j < x2_size; j++) P_out[(size_t)i * Nn + marg_id + j] = P[(size_t)i * N + marg_id + marg_size + j]; // P(x1, x2) :300
+  for (int i = 0; i < x2_size; i++)
+    for (int j = 0; j < marg_id; j++) P_out[(size_t)(marg_id + i) * Nn + j] = P_out[(size_t)j * Nn + marg_id + i]; // P(x2, x1) = P(x1, x2)^T :303
+  for (int i = 0; i < x2_size; i++)
+    for (int j = 0; j < x2_size; j++)
+      P_out[(size_t)(marg_id + i) * Nn + marg_id + j] = P[(size_t)(marg_id + marg_size + i) * N + marg_id + marg_size + j]; // P(x2, x2) :306
+}
+
+// StateHelper::clone of a `size`-dof variable to the end (:341-391) + augment_clone's time-offset Jacobian (:601-611).
+// P_out is (N + size)^2; dt_id < 0: no time-offset calibration.
+void oracle_augment_clone(const double *P, int N, int old_loc, int size, int dt_id, const double *dnc_dt, double *P_out) {
+  const int Nn = N + size, new_loc = N;
+  std::fill(P_out, P_out + (size_t)Nn * Nn, 0.0); // conservativeResizeLike(Zero) :349
+  for (int i = 0; i < N; i++) std::memcpy(P_out + (size_t)i * Nn, P + (size_t)i * N, sizeof(double) * N);
+  for (int a = 0; a < size; a++)
+    for (int b = 0; b < size; b++) P_out[(size_t)(new_loc + a) * Nn + new_loc + b] = P_out[(size_t)(old_loc + a) * Nn + old_loc + b]; // :370
+  for (int i = 0; i < N; i++)
+    for (int a = 0; a < size; a++) P_out[(size_t)i * Nn + new_loc + a] = P_out[(size_t)i * Nn + old_loc + a]; // :371
+  for (int a = 0; a < size; a++)
+    for (int i = 0; i < N; i++) P_out[(size_t)(new_loc + a) * Nn + i] = P_out[(size_t)(old_loc + a) * Nn + i]; // :372
+  if (dt_id >= 0) {
+    for (int i = 0; i < Nn; i++) // :607-608
+      for (int j = 0; j < size; j++) P_out[(size_t)i * Nn + new_loc + j] += P_out[(size_t)i * Nn + dt_id] * dnc_dt[j];
+    for (int a = 0; a < size; a++) // :609-610
+      for (int j = 0; j < Nn; j++) P_out[(size_t)(new_loc + a) * Nn + j] += dnc_dt[a] * P_out[(size_t)dt_id * Nn + j];
+  }
+}
+
+// StateHelper::EKFPropagation — StateHelper.cpp:36-114, in place; old_ids = covariance index of every column of Phi.
+int oracle_propagate(double *P, int N, int start_id, int n_new, int n_old, const int32_t *old_ids, const double *Phi, const double *Q) {
+  std::vector<double> Cov_PhiT((size_t)N * n_new, 0.0); // :77-82
+  for (int i = 0; i < N; i++)
+    for (int a = 0; a < n_new; a++) {
+      double sv = 0;
+      for (int k = 0; k < n_old; k++) sv += P[(size_t)i * N + old_ids[k]] * Phi[(size_t)a * n_old + k];
+      Cov_PhiT[(size_t)i * n_new + a] = sv;
+    }
+  std::vector<double> PCP((size_t)n_new * n_new); // :85-90
+  for (int a = 0; a < n_new; a++)
+    for (int b = 0; b < n_new; b++) {
+      double sv = a <= b ? Q[(size_t)a * n_new + b] : Q[(size_t)b * n_new + a];
+      for (int k = 0; k < n_old; k++) sv += Phi[(size_t)a * n_old + k] * Cov_PhiT[(size_t)old_ids[k] * n_new + b];
+      PCP[(size_t)a * n_new + b] = sv;
+    }
+  for (int a = 0; a < n_new; a++) // :93-98
+    for (int i = 0; i < N; i++) P[(size_t)(start_id + a) * N + i] = Cov_PhiT[(size_t)i * n_new + a];
+  for (int i = 0; i < N; i++)
+    for (int a = 0; a < n_new; a++) P[(size_t)i * N + start_id + a] = Cov_PhiT[(size_t)i * n_new + a];
+  for (int a = 0; a < n_new; a++)
+    for (int b = 0; b < n_new; b++) P[(size_t)(start_id + a) * N + start_id + b] = PCP[(size_t)a * n_new + b];
+  for (int i = 0; i < N; i++)
+    if (P[(size_t)i * N + i] < 0.0) return OVGPU_ERR_NEGATIVE_DIAGONAL; // :101-113
+  return OVGPU_OK;
+}
+
 int oracle_msckf_update(const ovgpu_options *opts, const ovgpu_state_view *st, const ovgpu_features_view *fv, int32_t *feat_status,
                         double *chi2_out, double *chi2_thresh_out, double *p_FinG_out, double *dx_out, double *P_out,
                         double *clone_q_p_out, double *calib_q_p_out, double *intrinsics_out, double *H_comp, double *r_comp,

@@ -121,6 +121,12 @@ int oracle_slam_delayed_init(const ovgpu_options *opts, const ovgpu_state_view *
                              int32_t *anchor_clone_out, double *dx_seq, int32_t *N_out, double *P_out, double *clone_q_p_out,
                              double *calib_q_p_out, double *intrinsics_out, double *lm_existing_out);
 
+/* Window bookkeeping: StateHelper::marginalize (StateHelper.cpp:271-339), clone + augment_clone's time-offset
+ * part (:341-391, :601-611), EKFPropagation (:36-114) on dense row-major covariances. */
+void oracle_marginalize(const double *P, int N, int marg_id, int marg_size, double *P_out);
+void oracle_augment_clone(const double *P, int N, int old_loc, int size, int dt_id, const double *dnc_dt, double *P_out);
+int oracle_propagate(double *P, int N, int start_id, int n_new, int n_old, const int32_t *old_ids, const double *Phi, const double *Q);
+
 int oracle_slam_update(const ovgpu_options *opts, const ovgpu_state_view *st, const ovgpu_landmarks_view *lm,
                        const ovgpu_features_view *fv, const int32_t *lm_index, int32_t *feat_status, double *chi2,
                        double *chi2_thresh, double *dx, double *P_out, double *lm_out, int32_t *D_out,

@@ -237,3 +237,35 @@ def slam_delayed_init(opts, views, feat_rep=0, tri=None):
     out["N"] = n
     out["P"] = Pbuf[: n * n].reshape(n, n).copy()
     return out
+
+
+def marginalize(P, marg_id, marg_size):
+    lib = load()
+    P = np.ascontiguousarray(P, dtype=np.float64)
+    N = P.shape[0]
+    out = np.zeros((N - marg_size, N - marg_size))
+    lib.oracle_marginalize.restype = None
+    lib.oracle_marginalize(_p(P), C.c_int(N), C.c_int(int(marg_id)), C.c_int(int(marg_size)), _p(out))
+    return out
+
+
+def augment_clone(P, old_loc, size=6, dt_id=-1, dnc_dt=None):
+    lib = load()
+    P = np.ascontiguousarray(P, dtype=np.float64)
+    N = P.shape[0]
+    out = np.zeros((N + size, N + size))
+    d = np.ascontiguousarray(dnc_dt if dnc_dt is not None else np.zeros(size), dtype=np.float64)
+    lib.oracle_augment_clone.restype = None
+    lib.oracle_augment_clone(_p(P), C.c_int(N), C.c_int(int(old_loc)), C.c_int(int(size)), C.c_int(int(dt_id)), _p(d), _p(out))
+    return out
+
+
+def propagate(P, start_id, old_ids, Phi, Q):
+    lib = load()
+    P = np.ascontiguousarray(P, dtype=np.float64).copy()
+    Phi = np.ascontiguousarray(Phi, dtype=np.float64)
+    Q = np.ascontiguousarray(Q, dtype=np.float64)
+    ids = np.ascontiguousarray(old_ids, dtype=np.int32)
+    lib.oracle_propagate.restype = C.c_int
+    rc = lib.oracle_propagate(_p(P), C.c_int(P.shape[0]), C.c_int(int(start_id)), C.c_int(Phi.shape[0]), C.c_int(Phi.shape[1]), _pi(ids), _p(Phi), _p(Q))
+    return rc, P

@@ -46,3 +46,19 @@ def test_ate_parity_gpu_vs_oracle(stream, oracle_run):
     assert np.abs(gpu["est"] - oracle_run["est"]).max() < 1e-8      # 52 consecutive updates, posterior fed back each time
     a_g, a_o = closed_loop.ate(gpu), closed_loop.ate(oracle_run)
     assert abs(a_g[0] - a_o[0]) < 1e-7 and abs(a_g[1] - a_o[1]) < 1e-8
+
+
+@pytest.mark.gpu
+def test_resident_window_matches_the_host_loop(stream, oracle_run):
+    """cloning, propagation of the new block, marginalisation and the update all on the RESIDENT covariance
+    (uploaded once, 52 frames): same accept sets and trajectory as the oracle-driven host loop."""
+    from open_vins_amd.updater import UpdaterMSCKF
+    up = UpdaterMSCKF(capi.default_options(**OPTS))
+    res = closed_loop.run_resident(stream, up)
+    post = up.get_state(P=True)
+    up.close()
+    assert res["used"] == oracle_run["used"]
+    assert np.abs(res["est"] - oracle_run["est"]).max() < 1e-8
+    # Phi P Phi^T + Q is formed entry by entry like the reference's (StateHelper.cpp:85-90): symmetric up to rounding only
+    assert post["P"].shape == (16 + 14 + 6 * stream.C,) * 2
+    np.testing.assert_allclose(post["P"], post["P"].T, rtol=0, atol=1e-18)

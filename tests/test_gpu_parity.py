@@ -694,3 +694,74 @@ def test_msckf_update_with_resident_landmarks(Updater, oracle):
     assert np.array_equal(out["feat_status"], ref["feat_status"])
     assert _rel(out["dx"], ref["dx"]) < 1e-7 and _rel(out["P"], ref["P"]) < 1e-8
     up.close()
+
+
+# --------------------------------------------------------------------------- window bookkeeping on the resident covariance
+def test_state_propagate_clone_marginalize_parity(Updater, oracle):
+    """StateHelper::EKFPropagation, clone / augment_clone (with the time-offset Jacobian) and marginalize on the resident P,
+    each step against the oracle applied to the covariance read back before it; then an MSCKF update on the new window."""
+    prob = synth.make_problem(2, F=60)
+    opts = capi.default_options(chi2_multipler=1.0)
+    up = Updater(opts)
+    up.set_problem(prob)
+    rng = np.random.default_rng(3)
+    N, C = prob.N, prob.C
+    # ---- EKFPropagation of the IMU block (ids 0..14, State.cpp:33-41) with a dense Phi
+    Phi = np.eye(15) + 0.05 * rng.normal(size=(15, 15))
+    Q = np.diag(rng.uniform(1e-6, 1e-4, 15))
+    Q[0, 3] = 1e-5  # only the upper triangle is read (StateHelper.cpp:87)
+    rc, ref = oracle.propagate(prob.P, 0, np.arange(15), Phi, Q)
+    up.state_propagate(0, np.arange(15), Phi, Q)
+    P1 = up.get_state(P=True)["P"]
+    assert rc == 0 and _rel(P1, ref) < 1e-14
+    # ---- augment_clone: the IMU pose (ids 0..5) cloned to the end, time offset at id 15
+    dnc = rng.normal(size=6)
+    q_new = synth.boxplus_pose(prob.clone_q_p[-1], 0.01 * rng.normal(size=6))
+    nid = up.state_augment_clone(0, q_new, dt_cov_id=15, dnc_dt=dnc)
+    P2 = up.get_state(P=True)["P"]
+    assert nid == N and up.N == N + 6 and up.Cn == C + 1
+    assert _rel(P2, oracle.augment_clone(P1, 0, 6, dt_id=15, dnc_dt=dnc)) < 1e-15
+    st = up.get_state(P=False)
+    np.testing.assert_array_equal(st["clone_q_p"][-1], q_new)
+    np.testing.assert_array_equal(st["clone_q_p"][:-1], prob.clone_q_p)
+    # ---- marginalize the oldest clone: pure data movement, bit-exact
+    old_id = int(prob.clone_cov_id[0])
+    up.state_marginalize(old_id, 6)
+    P3 = up.get_state(P=True)["P"]
+    np.testing.assert_array_equal(P3, oracle.marginalize(P2, old_id, 6))
+    st = up.get_state(P=False)
+    assert up.N == N and up.Cn == C
+    np.testing.assert_array_equal(st["clone_q_p"][:-1], prob.clone_q_p[1:])
+    # ---- the update on the shifted window: tracks without the measurements of the dropped clone, indices moved down
+    keep = prob.clone_idx > 0
+    cnt = np.add.reduceat(keep.astype(np.int64), prob.meas_offsets[:-1])
+    win = synth.make_problem(2, F=60)
+    win.meas_offsets = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int32)
+    win.uv, win.uvn = prob.uv.reshape(-1, 2)[keep].reshape(-1), prob.uvn.reshape(-1, 2)[keep].reshape(-1)
+    win.clone_idx, win.cam_idx = (prob.clone_idx[keep] - 1).astype(np.int32), prob.cam_idx[keep]
+    win.P = P3
+    win.clone_q_p = st["clone_q_p"]
+    win.clone_q_p_fej = np.vstack([prob.clone_q_p_fej[1:], q_new[None, :]])
+    win.clone_cov_id = np.concatenate([prob.clone_cov_id[:-1], [N - 6]]).astype(np.int32)  # ids behind the dropped clone moved forward
+    ref_u = oracle.msckf_update(opts, capi.Views(win))
+    up.set_features(win)
+    out = up.update()
+    assert np.array_equal(out["feat_status"], ref_u["feat_status"]) and (ref_u["feat_status"] == capi.FEAT_USED).sum() > 30
+    assert _rel(out["dx"], ref_u["dx"]) < 1e-7 and _rel(out["P"], ref_u["P"]) < 1e-8
+    up.close()
+
+
+def test_state_bookkeeping_rejects_bad_blocks(Updater):
+    prob = synth.make_problem(2, F=4)
+    up = Updater(capi.default_options())
+    up.set_problem(prob)
+    cid = int(prob.clone_cov_id[3])
+    for args in ((cid + 1, 6), (cid, 5), (prob.N - 2, 6), (-1, 3)):
+        with pytest.raises(RuntimeError):
+            up.state_marginalize(*args)
+    with pytest.raises(RuntimeError):
+        up.state_propagate(prob.N - 3, np.arange(6), np.eye(6), np.eye(6))
+    rc = up.lib.ovgpu_state_propagate(up._ctx, 0, 3, 3, np.arange(3, dtype=np.int32).ctypes.data_as(capi.c_int32_p),
+                                      np.eye(3).ctypes.data_as(capi.c_double_p), (-1e6 * np.eye(3)).ctypes.data_as(capi.c_double_p))
+    assert rc == capi.ERR_NEGATIVE_DIAGONAL
+    up.close()

@@ -449,3 +449,31 @@ def test_delayed_init_chain_bookkeeping():
     from scipy import stats as sps
     gated = np.isfinite(o["chi2"])
     np.testing.assert_allclose(o["chi2_thresh"][gated], sps.chi2.ppf(0.95, 2 * m[gated]), rtol=1e-10)
+
+
+def test_window_bookkeeping_against_dense_algebra():
+    """StateHelper::marginalize / clone (+ time-offset Jacobian) / EKFPropagation restated in the oracle vs J P J^T forms."""
+    from oracle import pyoracle
+    rng = np.random.default_rng(0)
+    A = rng.normal(size=(20, 20))
+    P = A @ A.T
+    keep = np.r_[0:5, 11:20]
+    np.testing.assert_array_equal(pyoracle.marginalize(P, 5, 6), P[np.ix_(keep, keep)])
+    d = rng.normal(size=6)
+    J = np.zeros((26, 20))
+    J[:20] = np.eye(20)
+    J[20:, 3:9] = np.eye(6)
+    np.testing.assert_array_equal(pyoracle.augment_clone(P, 3, 6), J @ P @ J.T)  # pure copies
+    J[20:, 15] = d
+    np.testing.assert_allclose(pyoracle.augment_clone(P, 3, 6, dt_id=15, dnc_dt=d), J @ P @ J.T, rtol=1e-13, atol=1e-13)
+    Phi, Q, ids = rng.normal(size=(6, 9)), np.diag(rng.uniform(0.1, 1, 6)), np.r_[2:8, 12:15]
+    rc, Pp = pyoracle.propagate(P, 2, ids, Phi, Q)
+    F = np.eye(20)
+    F[2:8, :] = 0
+    F[2:8, ids] = Phi
+    Qf = np.zeros((20, 20))
+    Qf[2:8, 2:8] = Q
+    assert rc == 0
+    np.testing.assert_allclose(Pp, F @ P @ F.T + Qf, rtol=1e-12, atol=1e-12)
+    rc, _ = pyoracle.propagate(P, 2, ids, Phi, -1e6 * np.eye(6))  # StateHelper.cpp:101-113
+    assert rc == capi.ERR_NEGATIVE_DIAGONAL
