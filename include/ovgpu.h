@@ -370,6 +370,20 @@ int ovgpu_slam_delayed_init(ovgpu_ctx *ctx, int32_t feat_rep, int32_t *feat_stat
 int ovgpu_get_landmarks(ovgpu_ctx *ctx, int32_t *L_out, double *value, double *fej,
                         int32_t *cov_id, int32_t *anchor_cam, int32_t *anchor_clone);
 
+/* UpdaterSLAM::perform_anchor_change (UpdaterSLAM.cpp:506-647) for the resident anchored landmark
+ * lm_index: its position is re-expressed in the camera `new_anchor_cam` of clone `new_anchor_clone`
+ * (value and first estimate, :536-571), and the covariance is propagated with
+ * Phi = H_f_new^-1 [H_x_old | H_f_old | -H_x_new] through StateHelper::EKFPropagation (:612-640).
+ * OVGPU_ERR_INVALID for a global representation.                                            */
+int ovgpu_slam_change_anchor(ovgpu_ctx *ctx, int32_t lm_index, int32_t new_anchor_cam,
+                             int32_t new_anchor_clone);
+
+/* UpdaterSLAM::change_anchors (UpdaterSLAM.cpp:481-504): every resident landmark anchored in clone
+ * `marg_clone` (the one about to be marginalised) moves to clone `new_clone` (the newest, the
+ * reference passes state->_timestamp), same camera.  n_changed (optional) = how many moved.  */
+int ovgpu_slam_change_anchors(ovgpu_ctx *ctx, int32_t marg_clone, int32_t new_clone,
+                              int32_t *n_changed);
+
 /* ------------------------------------------------------------------------- */
 /* Window bookkeeping on the RESIDENT covariance: the steps either   */
 /* side of the update, so that P does not cross PCIe between frames.  The means of the    */

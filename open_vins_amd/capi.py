@@ -185,6 +185,8 @@ def declare(lib):
         "ovgpu_measurement_compress": (C.c_int, [ctxp, C.c_int, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p, c_int32_p]),
         "ovgpu_ekf_update": (C.c_int, [ctxp, C.c_int, C.c_int, c_int32_p, c_double_p, c_double_p, C.c_double, c_double_p, c_double_p]),
         "ovgpu_set_landmarks": (C.c_int, [ctxp, C.POINTER(LandmarksView)]),
+        "ovgpu_slam_change_anchor": (C.c_int, [ctxp, C.c_int32, C.c_int32, C.c_int32]),
+        "ovgpu_slam_change_anchors": (C.c_int, [ctxp, C.c_int32, C.c_int32, c_int32_p]),
         "ovgpu_state_marginalize": (C.c_int, [ctxp, C.c_int32, C.c_int32]),
         "ovgpu_state_augment_clone": (C.c_int, [ctxp, C.c_int32, c_double_p, c_double_p, C.c_int32, c_double_p, c_int32_p]),
         "ovgpu_state_propagate": (C.c_int, [ctxp, C.c_int32, C.c_int32, C.c_int32, c_int32_p, c_double_p, c_double_p]),

@@ -10,6 +10,7 @@
 #pragma once
 #include "device_math.h"
 #include "ovgpu_types.h"
+#include "k_system.h"
 
 namespace ovg {
 
@@ -153,6 +154,88 @@ __global__ void k_cov_propagate(int N, int nid, int n_new, int n_old, const int3
       P[(size_t)(nid + a) * N + i] = v;
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// UpdaterSLAM::perform_anchor_change (UpdaterSLAM.cpp:506-647) for one anchored 3-dof landmark: the transition matrix of
+// the landmark's error state into the new anchor frame, Phi = H_f_new^-1 [H_x_old | H_f_old | -H_x_new], goes to `phi`
+// (3 x n_old, row-major) with the covariance index of every column in `ids`; the landmark's value / fej / anchor are
+// rewritten.  The covariance itself is then propagated by k_cov_propagate (StateHelper::EKFPropagation, Q = 0).
+// Column order: old anchor clone (6), old anchor camera extrinsics (6, if estimated), new anchor clone (6), new anchor
+// camera extrinsics (6, if estimated and another camera), landmark (3) — the reference's phi_order_OLD (:592-610).
+// One thread.
+// ---------------------------------------------------------------------------------------------------
+struct AnchorParams {
+  int rep, do_fej, l, new_cam, new_clone;
+  const double *tab_clone, *tab_cam; // [C*24], [K*12]
+  const int32_t *clone_cov, *calib_cov;
+  LandmarkStore lm;
+  double *phi;   // [3 * 27]
+  int32_t *ids;  // [27]
+  int32_t *n_old; // [1]
+};
+
+__global__ void k_anchor_change(AnchorParams p) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const int l = p.l;
+  const int old_cam = p.lm.anchor[l] >> 10, old_clone = p.lm.anchor[l] & 1023;
+  const V3 pA_old = lm_to_xyz(p.rep, p.lm.value + 3 * l), pA_old_fej = lm_to_xyz(p.rep, p.lm.fej + 3 * l);
+  double Hf_old[9], Ha_old[18], Hc_old[18], Hf_new[9], Ha_new[18], Hc_new[18];
+  anchored_rep_jacobian(p.rep, p.do_fej, p.tab_cam + 12 * old_cam, p.tab_clone + 24 * old_clone, pA_old, Hf_old, Ha_old, Hc_old); // :523-526
+  // current estimates (:536-551) and first estimates (:556-571) of the two anchor cameras
+  V3 pA_new, pA_new_fej;
+  for (int fej = 0; fej < 2; fej++) {
+    const int o = fej ? 12 : 0;
+    const M3 R_GtoOLD = mul(load_m3(p.tab_cam + 12 * old_cam), load_m3(p.tab_clone + 24 * old_clone + o));
+    const V3 p_OLDinG = load_v3(p.tab_clone + 24 * old_clone + o + 9) - mulT(R_GtoOLD, load_v3(p.tab_cam + 12 * old_cam + 9));
+    const M3 R_GtoNEW = mul(load_m3(p.tab_cam + 12 * p.new_cam), load_m3(p.tab_clone + 24 * p.new_clone + o));
+    const V3 p_NEWinG = load_v3(p.tab_clone + 24 * p.new_clone + o + 9) - mulT(R_GtoNEW, load_v3(p.tab_cam + 12 * p.new_cam + 9));
+    const M3 R_OLDtoNEW = mul(R_GtoNEW, transpose(R_GtoOLD));
+    const V3 p_OLDinNEW = mul(R_GtoNEW, p_OLDinG - p_NEWinG);
+    const V3 r = mul(R_OLDtoNEW, fej ? pA_old_fej : pA_old) + p_OLDinNEW;
+    if (fej) pA_new_fej = r;
+    else pA_new = r;
+  }
+  anchored_rep_jacobian(p.rep, p.do_fej, p.tab_cam + 12 * p.new_cam, p.tab_clone + 24 * p.new_clone, pA_new, Hf_new, Ha_new, Hc_new); // :577-580
+  // H_f_new^-1 by column-pivoted Householder QR of the 3 x 3 (:621)
+  const M3 A{Hf_new[0], Hf_new[1], Hf_new[2], Hf_new[3], Hf_new[4], Hf_new[5], Hf_new[6], Hf_new[7], Hf_new[8]};
+  const V3 c0 = colpiv_qr_solve3(A, V3{1, 0, 0}), c1 = colpiv_qr_solve3(A, V3{0, 1, 0}), c2 = colpiv_qr_solve3(A, V3{0, 0, 1});
+  const double inv[9] = {c0.x, c1.x, c2.x, c0.y, c1.y, c2.y, c0.z, c1.z, c2.z};
+  // ---- column layout
+  int n = 0, col_oc, col_ok = -1, col_nc, col_nk = -1, col_lm;
+  col_oc = n, n += 6;
+  if (p.calib_cov[old_cam] >= 0) col_ok = n, n += 6;
+  col_nc = n, n += 6;
+  if (p.calib_cov[p.new_cam] >= 0) {
+    if (p.new_cam == old_cam) col_nk = col_ok;
+    else col_nk = n, n += 6;
+  }
+  col_lm = n, n += 3;
+  for (int i = 0; i < 3 * n; i++) p.phi[i] = 0.0;
+  for (int j = 0; j < 6; j++) {
+    p.ids[col_oc + j] = p.clone_cov[old_clone] + j, p.ids[col_nc + j] = p.clone_cov[p.new_clone] + j;
+    if (col_ok >= 0) p.ids[col_ok + j] = p.calib_cov[old_cam] + j;
+    if (col_nk >= 0) p.ids[col_nk + j] = p.calib_cov[p.new_cam] + j;
+  }
+  for (int j = 0; j < 3; j++) p.ids[col_lm + j] = p.lm.cov[l] + j;
+  auto add_block = [&](int col, const double *H, int w, double sign) { // Phi(:, col ..) += sign * inv * H (3 x w)
+    for (int a = 0; a < 3; a++)
+      for (int b = 0; b < w; b++) {
+        double sv = 0.0;
+        for (int k = 0; k < 3; k++) sv = fma(inv[3 * a + k], H[w * k + b], sv);
+        p.phi[a * n + col + b] += sign * sv;
+      }
+  };
+  add_block(col_oc, Ha_old, 6, 1.0);                  // :626-628
+  if (col_ok >= 0) add_block(col_ok, Hc_old, 6, 1.0);
+  add_block(col_lm, Hf_old, 3, 1.0);                  // :631
+  add_block(col_nc, Ha_new, 6, -1.0);                 // :634-636
+  if (col_nk >= 0) add_block(col_nk, Hc_new, 6, -1.0);
+  *p.n_old = n;
+  // ---- the landmark in its new anchor (:642-647)
+  lm_from_xyz(p.rep, pA_new, p.lm.value + 3 * l);
+  lm_from_xyz(p.rep, pA_new_fej, p.lm.fej + 3 * l);
+  p.lm.anchor[l] = (p.new_cam << 10) | p.new_clone;
 }
 
 struct InitParams {

@@ -70,6 +70,47 @@ __device__ __forceinline__ void inv_depth_jac(const V3 &p, double *J) {
   J[6] = 0.0, J[7] = -(1.0 / rho) * sin_phi, J[8] = -(1.0 / (rho * rho)) * cos_phi;
 }
 
+// UpdaterHelper::get_feature_jacobian_representation, anchored representations (UpdaterHelper.cpp:84-189):
+//   dl [3x3] = d p_FinG / d lambda,  Ha [3x6] = d p_FinG / d (anchor clone pose),  Hc [3x6] = d p_FinG / d (anchor camera extrinsics)
+// tab_cam_a = (R_ItoC, p_IinC) of the anchor camera, tab_clone_a = (R_GtoI, p_IinG, R_GtoI_fej, p_IinG_fej) of the anchor clone.
+__device__ __forceinline__ void anchored_rep_jacobian(int rep, int do_fej, const double *tab_cam_a, const double *tab_clone_a, const V3 &p_FinA_in, double *dl,
+                                                      double *Ha, double *Hc) {
+  const M3 R_ItoC = load_m3(tab_cam_a);
+  const V3 p_IinC = load_v3(tab_cam_a + 9);
+  M3 R_GtoI = load_m3(tab_clone_a);
+  V3 p_IinG = load_v3(tab_clone_a + 9);
+  V3 p_FinA = p_FinA_in;
+  if (do_fej) { // :93-100
+    const V3 best = mulT(R_GtoI, mulT(R_ItoC, p_FinA_in - p_IinC)) + p_IinG;
+    R_GtoI = load_m3(tab_clone_a + 12);
+    p_IinG = load_v3(tab_clone_a + 21);
+    p_FinA = mul(R_ItoC, mul(R_GtoI, best - p_IinG)) + p_IinC;
+  }
+  const M3 R_CtoG = mul(transpose(R_GtoI), transpose(R_ItoC)); // :101
+  {
+    const M3 blk = mul(transpose(R_GtoI), skew_x(mulT(R_ItoC, p_FinA - p_IinC))); // :105
+    Ha[0] = -blk.a00, Ha[1] = -blk.a01, Ha[2] = -blk.a02, Ha[3] = 1, Ha[4] = 0, Ha[5] = 0;
+    Ha[6] = -blk.a10, Ha[7] = -blk.a11, Ha[8] = -blk.a12, Ha[9] = 0, Ha[10] = 1, Ha[11] = 0;
+    Ha[12] = -blk.a20, Ha[13] = -blk.a21, Ha[14] = -blk.a22, Ha[15] = 0, Ha[16] = 0, Ha[17] = 1;
+  }
+  {
+    const M3 blk = mul(R_CtoG, skew_x(p_FinA - p_IinC)); // :115-116
+    Hc[0] = -blk.a00, Hc[1] = -blk.a01, Hc[2] = -blk.a02, Hc[3] = -R_CtoG.a00, Hc[4] = -R_CtoG.a01, Hc[5] = -R_CtoG.a02;
+    Hc[6] = -blk.a10, Hc[7] = -blk.a11, Hc[8] = -blk.a12, Hc[9] = -R_CtoG.a10, Hc[10] = -R_CtoG.a11, Hc[11] = -R_CtoG.a12;
+    Hc[12] = -blk.a20, Hc[13] = -blk.a21, Hc[14] = -blk.a22, Hc[15] = -R_CtoG.a20, Hc[16] = -R_CtoG.a21, Hc[17] = -R_CtoG.a22;
+  }
+  M3 d{1, 0, 0, 0, 1, 0, 0, 0, 1};
+  if (rep == OVGPU_REP_ANCHORED_FULL_INVERSE_DEPTH) {
+    double J[9];
+    inv_depth_jac(p_FinA, J);
+    d = M3{J[0], J[1], J[2], J[3], J[4], J[5], J[6], J[7], J[8]};
+  } else if (rep == OVGPU_REP_ANCHORED_MSCKF_INVERSE_DEPTH) { // :157-175
+    const double alpha = p_FinA.x / p_FinA.z, beta = p_FinA.y / p_FinA.z, rho = 1.0 / p_FinA.z;
+    d = M3{1.0 / rho, 0.0, -(1.0 / (rho * rho)) * alpha, 0.0, 1.0 / rho, -(1.0 / (rho * rho)) * beta, 0.0, 0.0, -(1.0 / (rho * rho))};
+  }
+  store_m3(dl, mul(R_CtoG, d));
+}
+
 __device__ __forceinline__ double lane_bcast_d(double v, int lane) { // lane is wave-uniform
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
   return __hiloint2double(hi, lo);
@@ -192,43 +233,8 @@ __global__ void __launch_bounds__(SYS_NT) k_system(SysParams p) {
         inv_depth_jac(p.opt.do_fej ? p_FinG_fej : p_FinG, dl); // UpdaterHelper.cpp:46 (fej == value for MSCKF features)
       } else {
         // anchored (UpdaterHelper.cpp:84-189)
-        const V3 p_FinA_in = load_v3(p.p_FinA + 3 * f);
-        const M3 R_ItoC = load_m3(p.tab_cam + 12 * anchor_cam);
-        const V3 p_IinC = load_v3(p.tab_cam + 12 * anchor_cam + 9);
-        M3 R_GtoI = load_m3(p.tab_clone + 24 * anchor_clone);
-        V3 p_IinG = load_v3(p.tab_clone + 24 * anchor_clone + 9);
-        V3 p_FinA = p_FinA_in;
-        if (p.opt.do_fej) { // :93-100
-          const V3 best = mulT(R_GtoI, mulT(R_ItoC, p_FinA_in - p_IinC)) + p_IinG;
-          R_GtoI = load_m3(p.tab_clone + 24 * anchor_clone + 12);
-          p_IinG = load_v3(p.tab_clone + 24 * anchor_clone + 21);
-          p_FinA = mul(R_ItoC, mul(R_GtoI, best - p_IinG)) + p_IinC;
-        }
-        const M3 R_CtoG = mul(transpose(R_GtoI), transpose(R_ItoC)); // :101
-        {
-          const M3 blk = mul(transpose(R_GtoI), skew_x(mulT(R_ItoC, p_FinA - p_IinC))); // :105
-          double *Ha = hq + 21;
-          Ha[0] = -blk.a00, Ha[1] = -blk.a01, Ha[2] = -blk.a02, Ha[3] = 1, Ha[4] = 0, Ha[5] = 0;
-          Ha[6] = -blk.a10, Ha[7] = -blk.a11, Ha[8] = -blk.a12, Ha[9] = 0, Ha[10] = 1, Ha[11] = 0;
-          Ha[12] = -blk.a20, Ha[13] = -blk.a21, Ha[14] = -blk.a22, Ha[15] = 0, Ha[16] = 0, Ha[17] = 1;
-        }
-        {
-          const M3 blk = mul(R_CtoG, skew_x(p_FinA - p_IinC)); // :115-116
-          double *Hc = hq + 39;
-          Hc[0] = -blk.a00, Hc[1] = -blk.a01, Hc[2] = -blk.a02, Hc[3] = -R_CtoG.a00, Hc[4] = -R_CtoG.a01, Hc[5] = -R_CtoG.a02;
-          Hc[6] = -blk.a10, Hc[7] = -blk.a11, Hc[8] = -blk.a12, Hc[9] = -R_CtoG.a10, Hc[10] = -R_CtoG.a11, Hc[11] = -R_CtoG.a12;
-          Hc[12] = -blk.a20, Hc[13] = -blk.a21, Hc[14] = -blk.a22, Hc[15] = -R_CtoG.a20, Hc[16] = -R_CtoG.a21, Hc[17] = -R_CtoG.a22;
-        }
-        M3 d{1, 0, 0, 0, 1, 0, 0, 0, 1};
-        if (p.opt.feat_rep == OVGPU_REP_ANCHORED_FULL_INVERSE_DEPTH) {
-          double J[9];
-          inv_depth_jac(p_FinA, J);
-          d = M3{J[0], J[1], J[2], J[3], J[4], J[5], J[6], J[7], J[8]};
-        } else if (p.opt.feat_rep == OVGPU_REP_ANCHORED_MSCKF_INVERSE_DEPTH) { // :157-175
-          const double alpha = p_FinA.x / p_FinA.z, beta = p_FinA.y / p_FinA.z, rho = 1.0 / p_FinA.z;
-          d = M3{1.0 / rho, 0.0, -(1.0 / (rho * rho)) * alpha, 0.0, 1.0 / rho, -(1.0 / (rho * rho)) * beta, 0.0, 0.0, -(1.0 / (rho * rho))};
-        }
-        store_m3(dl, mul(R_CtoG, d));
+        anchored_rep_jacobian(p.opt.feat_rep, p.opt.do_fej, p.tab_cam + 12 * anchor_cam, p.tab_clone + 24 * anchor_clone, load_v3(p.p_FinA + 3 * f), dl,
+                              hq + 21, hq + 39);
       }
     }
     __syncthreads();

@@ -108,7 +108,7 @@ struct ovgpu_ctx {
   // SLAM landmarks (ovgpu_set_landmarks); L > 0 switches the per-feature kernel to the UpdaterSLAM rules
   int L = 0;
   int lm_rep = OVGPU_REP_GLOBAL_3D; // representation of the resident landmarks (StateOptions::feat_rep_slam)
-  std::vector<int32_t> h_lm_cov, h_lm_col;
+  std::vector<int32_t> h_lm_cov, h_lm_col, h_lm_anchor; // h_lm_anchor: packed (camera << 10 | clone) or -1, mirror of lm_anchor
   DevBuf<double> pFej, lm_val, lm_fej; // landmark values in representation coordinates (ov_type::Landmark::value / fej)
   DevBuf<int32_t> feat_lm, feat_lmcol, feat_lmcov, feat_anchor, lm_cov, lm_col, lm_anchor, lm_index;
   bool slam_rows = false; // row layout of the uploaded batch: 2m rows per feature (SLAM update) or 2m - 3 (MSCKF, delayed init)
@@ -437,7 +437,7 @@ int ovgpu_set_state(ovgpu_ctx *c, const ovgpu_state_view *st) {
   }
   for (int i = 0; i < C; i++) c->h_vars.push_back({st->clone_cov_id[i], 6, COL_CLONE, i});
   c->N = N, c->C = C, c->K = K;
-  c->L = 0, c->lm_rep = OVGPU_REP_GLOBAL_3D, c->h_lm_cov.clear(), c->h_lm_col.clear();
+  c->L = 0, c->lm_rep = OVGPU_REP_GLOBAL_3D, c->h_lm_cov.clear(), c->h_lm_col.clear(), c->h_lm_anchor.clear();
   c->row_stride = (c->dopt.feat_rep >= OVGPU_REP_ANCHORED_3D) ? 72 : 48;
   HIPCHK(c->clone_col.reserve(C));
   HIPCHK(c->calib_col.reserve(K));
@@ -1135,6 +1135,7 @@ int ovgpu_set_landmarks(ovgpu_ctx *c, const ovgpu_landmarks_view *lm) {
   c->L = lm->L, c->lm_rep = lm->feat_rep;
   c->row_stride = (relative || c->dopt.feat_rep >= OVGPU_REP_ANCHORED_3D) ? 72 : 48;
   c->h_lm_cov.assign(lm->cov_id, lm->cov_id + lm->L);
+  c->h_lm_anchor.assign(anc.begin(), anc.begin() + lm->L);
   int rc = reserve_landmarks(c, lm->L, 0);
   if (rc != OVGPU_OK) return rc;
   if (lm->L > 0) {
@@ -1359,6 +1360,7 @@ int ovgpu_slam_delayed_init(ovgpu_ctx *c, int32_t feat_rep, int32_t *feat_status
   // the new landmarks join the resident ones and the column map
   c->L = L1, c->lm_rep = feat_rep;
   c->h_lm_cov.assign(cov.begin(), cov.begin() + L1);
+  c->h_lm_anchor.assign(anc.begin(), anc.begin() + L1);
   c->dx.release(), c->Mt.release(), c->Aaug.release(), c->Yaug.release(); // sized by the old N below
   HIPCHK(c->dx.reserve(N1));
   rc = build_columns(c);
@@ -1407,6 +1409,72 @@ static int rebuild_variables(ovgpu_ctx *c) {
   return launch_build_tables(c);
 }
 
+// UpdaterSLAM::perform_anchor_change: k_anchor_change builds Phi and rewrites the landmark, k_cov_propagate applies it (Q = 0)
+static int enqueue_anchor_change(ovgpu_ctx *c, int l, int new_cam, int new_clone) {
+  const int32_t old = c->h_lm_anchor[l];
+  const int old_cam = old >> 10;
+  int n_old = 6 + 6 + 3;
+  if (c->h_calib_cov[old_cam] >= 0) n_old += 6;
+  if (c->h_calib_cov[new_cam] >= 0 && new_cam != old_cam) n_old += 6;
+  hipStream_t s = c->stream;
+  const int N = c->N;
+  HIPCHK(c->prop_in.reserve(3 * 27 + 9));
+  HIPCHK(c->prop_ids.reserve(28));
+  HIPCHK(c->prop_w.reserve((size_t)N * 3 + 9));
+  double *dPhi = c->prop_in.p, *dQ = dPhi + 3 * 27, *W = c->prop_w.p, *PCP = W + (size_t)N * 3;
+  HIPCHK(hipMemsetAsync(dQ, 0, 9 * sizeof(double), s));
+  AnchorParams ap;
+  ap.rep = c->lm_rep, ap.do_fej = c->dopt.do_fej, ap.l = l, ap.new_cam = new_cam, ap.new_clone = new_clone;
+  ap.tab_clone = c->tab_clone.p, ap.tab_cam = c->tab_cam.p, ap.clone_cov = c->clone_cov.p, ap.calib_cov = c->calib_cov.p;
+  ap.lm = landmark_store(c), ap.phi = dPhi, ap.ids = c->prop_ids.p, ap.n_old = c->prop_ids.p + 27;
+  hipLaunchKernelGGL(k_anchor_change, dim3(1), dim3(64), 0, s, ap);
+  for (int pass = 0; pass < 3; pass++) {
+    const int n = pass == 1 ? 9 : N * 3;
+    hipLaunchKernelGGL(k_cov_propagate, dim3((n + 255) / 256), dim3(256), 0, s, N, (int)c->h_lm_cov[l], 3, n_old, c->prop_ids.p, dPhi, dQ, c->P.p, W, PCP,
+                       c->flags.p, pass);
+  }
+  HIPCHK(hipGetLastError());
+  c->h_lm_anchor[l] = (new_cam << 10) | new_clone;
+  return OVGPU_OK;
+}
+
+static int anchor_change_checks(ovgpu_ctx *c) {
+  if (!c) return set_err(OVGPU_ERR_INVALID, "null ctx");
+  if (!c->have_state || c->poses_only) return set_err(OVGPU_ERR_NO_STATE, "ovgpu_set_state was never called");
+  if (c->L <= 0) return set_err(OVGPU_ERR_NO_STATE, "no resident landmarks");
+  if (c->lm_rep < OVGPU_REP_ANCHORED_3D) return set_err(OVGPU_ERR_INVALID, "the resident landmarks are not anchored");
+  HIPCHK(hipSetDevice(c->device));
+  return OVGPU_OK;
+}
+
+int ovgpu_slam_change_anchor(ovgpu_ctx *c, int32_t lm_index, int32_t new_anchor_cam, int32_t new_anchor_clone) {
+  int rc = anchor_change_checks(c);
+  if (rc != OVGPU_OK) return rc;
+  if (lm_index < 0 || lm_index >= c->L || new_anchor_cam < 0 || new_anchor_cam >= c->K || new_anchor_clone < 0 || new_anchor_clone >= c->C)
+    return set_err(OVGPU_ERR_INVALID, "landmark / camera / clone index out of range");
+  HIPCHK(hipMemsetAsync(c->flags.p, 0, 4 * sizeof(int32_t), c->stream));
+  return enqueue_anchor_change(c, lm_index, new_anchor_cam, new_anchor_clone);
+}
+
+int ovgpu_slam_change_anchors(ovgpu_ctx *c, int32_t marg_clone, int32_t new_clone, int32_t *n_changed) {
+  if (n_changed) *n_changed = 0;
+  if (c && c->have_state && !c->poses_only && (c->L <= 0 || c->lm_rep < OVGPU_REP_ANCHORED_3D)) return OVGPU_OK; // :493-496: global landmarks are skipped
+  int rc = anchor_change_checks(c);
+  if (rc != OVGPU_OK) return rc;
+  if (marg_clone < 0 || marg_clone >= c->C || new_clone < 0 || new_clone >= c->C || marg_clone == new_clone)
+    return set_err(OVGPU_ERR_INVALID, "clone index out of range");
+  HIPCHK(hipMemsetAsync(c->flags.p, 0, 4 * sizeof(int32_t), c->stream));
+  int n = 0;
+  for (int l = 0; l < c->L; l++) {
+    const int32_t a = c->h_lm_anchor[l];
+    if (a < 0 || (a & 1023) != marg_clone) continue;
+    if ((rc = enqueue_anchor_change(c, l, a >> 10, new_clone)) != OVGPU_OK) return rc; // same camera (:499-500)
+    n++;
+  }
+  if (n_changed) *n_changed = n;
+  return OVGPU_OK;
+}
+
 int ovgpu_state_dims(ovgpu_ctx *c, int32_t *N_out, int32_t *C_out) {
   if (!c) return set_err(OVGPU_ERR_INVALID, "null ctx");
   if (!c->have_state || c->poses_only) return set_err(OVGPU_ERR_NO_STATE, "ovgpu_set_state was never called");
@@ -1435,17 +1503,27 @@ int ovgpu_state_marginalize(ovgpu_ctx *c, int32_t cov_id, int32_t size) {
       if (c->h_lm_cov[l] != cov_id || size != 3) return set_err(OVGPU_ERR_INVALID, "block cuts through a landmark");
       drop_lm = l;
     }
+  int drop_calib = -1, drop_intr = -1;
   for (int k = 0; k < c->K; k++) {
     if (hit(c->h_calib_cov[k], 6)) {
       if (c->h_calib_cov[k] != cov_id || size != 6) return set_err(OVGPU_ERR_INVALID, "block cuts through a camera pose");
-      c->h_calib_cov[k] = -1;
+      drop_calib = k;
     }
     if (hit(c->h_intr_cov[k], 8)) {
       if (c->h_intr_cov[k] != cov_id || size != 8) return set_err(OVGPU_ERR_INVALID, "block cuts through camera intrinsics");
-      c->h_intr_cov[k] = -1;
+      drop_intr = k;
     }
   }
-  if (drop_lm >= 0 && c->lm_rep >= OVGPU_REP_ANCHORED_3D) { /* anchors are packed clone indices: fixed up below */ }
+  if (drop_clone >= 0 && c->L > 0 && c->lm_rep >= OVGPU_REP_ANCHORED_3D) {
+    // a landmark anchored in the clone that goes away must have been re-anchored before (UpdaterSLAM::change_anchors runs before
+    // StateHelper::marginalize_old_clone, VioManager.cpp:585-590); checked before anything is modified
+    for (int l = 0; l < c->L; l++)
+      if (l != drop_lm && c->h_lm_anchor[l] >= 0 && (c->h_lm_anchor[l] & 1023) == drop_clone)
+        return set_err(OVGPU_ERR_INVALID, "a resident landmark is anchored in the marginalised clone (ovgpu_slam_change_anchors first)");
+  }
+  // ---- nothing was modified so far; from here on the call goes through
+  if (drop_calib >= 0) c->h_calib_cov[drop_calib] = -1;
+  if (drop_intr >= 0) c->h_intr_cov[drop_intr] = -1;
   // ---- covariance
   HIPCHK(c->Ppad.reserve((size_t)std::max(Nn, 1) * std::max(Nn, 1)));
   if (Nn > 0) {
@@ -1469,6 +1547,7 @@ int ovgpu_state_marginalize(ovgpu_ctx *c, int32_t cov_id, int32_t size) {
     HIPCHK(remove_record(c->lm_fej, tmpd, c->L, 3, drop_lm, s));
     HIPCHK(remove_record(c->lm_anchor, tmpi, c->L, 1, drop_lm, s));
     c->h_lm_cov.erase(c->h_lm_cov.begin() + drop_lm);
+    c->h_lm_anchor.erase(c->h_lm_anchor.begin() + drop_lm);
     c->L -= 1;
   }
   HIPCHK(hipStreamSynchronize(s)); // the scratch copies go out of scope
@@ -1479,14 +1558,11 @@ int ovgpu_state_marginalize(ovgpu_ctx *c, int32_t cov_id, int32_t size) {
   for (auto &id : c->h_intr_cov) shift(id);
   for (auto &id : c->h_lm_cov) shift(id);
   if (drop_clone >= 0 && c->L > 0 && c->lm_rep >= OVGPU_REP_ANCHORED_3D) {
-    // anchored landmarks refer to clone INDICES: the clones behind the dropped one moved down; a landmark anchored in the dropped
-    // clone must have been re-anchored before (UpdaterSLAM::change_anchors runs before marginalize_old_clone, VioManager.cpp:585-590)
-    std::vector<int32_t> anc(c->L);
-    HIPCHK(hipMemcpy(anc.data(), c->lm_anchor.p, sizeof(int32_t) * c->L, hipMemcpyDeviceToHost));
+    // anchored landmarks refer to clone INDICES: the clones behind the dropped one moved down
+    std::vector<int32_t> &anc = c->h_lm_anchor;
     for (auto &a : anc) {
       if (a < 0) continue;
       const int cam = a >> 10, cl = a & 1023;
-      if (cl == drop_clone) return set_err(OVGPU_ERR_INVALID, "a resident landmark is anchored in the marginalised clone");
       a = (cam << 10) | (cl > drop_clone ? cl - 1 : cl);
     }
     HIPCHK(hipMemcpy(c->lm_anchor.p, anc.data(), sizeof(int32_t) * c->L, hipMemcpyHostToDevice));

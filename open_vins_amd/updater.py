@@ -225,6 +225,15 @@ class UpdaterMSCKF:
                                                     _ip(out["anchor_cam"]), _ip(out["anchor_clone"])), "ovgpu_get_landmarks")
         return out
 
+    # ---- UpdaterSLAM::change_anchors / perform_anchor_change (UpdaterSLAM.cpp:481-647) ----
+    def change_anchor(self, lm_index, new_cam, new_clone):
+        capi.check(self.lib.ovgpu_slam_change_anchor(self._ctx, int(lm_index), int(new_cam), int(new_clone)), "ovgpu_slam_change_anchor")
+
+    def change_anchors(self, marg_clone, new_clone):
+        n = C.c_int32(0)
+        capi.check(self.lib.ovgpu_slam_change_anchors(self._ctx, int(marg_clone), int(new_clone), C.byref(n)), "ovgpu_slam_change_anchors")
+        return n.value
+
     # ---- window bookkeeping on the resident covariance (StateHelper::marginalize / clone / EKFPropagation) ----
     def _refresh_dims(self):
         n, c = C.c_int32(0), C.c_int32(0)

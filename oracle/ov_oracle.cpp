@@ -1950,6 +1950,82 @@ int oracle_propagate(double *P, int N, int start_id, int n_new, int n_old, const
   return OVGPU_OK;
 }
 
+// ---------------------------------------------------------------------------
+// UpdaterSLAM::perform_anchor_change — UpdaterSLAM.cpp:506-647 for landmark l of `lm` (anchored, 3-dof).
+// P_out [N*N] = covariance after the EKFPropagation of the landmark block; value_out / fej_out [3] = the landmark in
+// its new anchor (representation coordinates).
+// ---------------------------------------------------------------------------
+int oracle_anchor_change(const ovgpu_options *opts, const ovgpu_state_view *st, const ovgpu_landmarks_view *lm, int l, int new_cam, int new_clone,
+                         double *P_out, double *value_out, double *fej_out) {
+  const ovgpu_options &o = *opts;
+  const int rep = lm->feat_rep, N = st->N;
+  if (!is_relative(rep)) return OVGPU_ERR_INVALID;
+  StateTables T = build_tables(st);
+  const int old_cam = lm->anchor_cam[l], old_clone = lm->anchor_clone[l];
+  const V3 nanv{{NAN, NAN, NAN}};
+  V3 pA_old = landmark_get_xyz(rep, lm->p_value + 3 * l), pA_old_fej = landmark_get_xyz(rep, lm->p_fej + 3 * l); // :517-518
+  RepJac jo = feature_jacobian_representation(o, T, rep, nanv, nanv, pA_old, old_cam, old_clone);               // :523-526
+  // transform between the old anchor and the new one, current (:536-551) and first estimates (:556-571)
+  V3 pA_new, pA_new_fej;
+  for (int fej = 0; fej < 2; fej++) {
+    const M3 &R_GtoIOLD = fej ? T.R_GtoI_fej[old_clone] : T.R_GtoI[old_clone];
+    const V3 &p_IOLDinG = fej ? T.p_IinG_fej[old_clone] : T.p_IinG[old_clone];
+    const M3 &R_GtoINEW = fej ? T.R_GtoI_fej[new_clone] : T.R_GtoI[new_clone];
+    const V3 &p_INEWinG = fej ? T.p_IinG_fej[new_clone] : T.p_IinG[new_clone];
+    M3 R_GtoOLD = mul(T.R_ItoC[old_cam], R_GtoIOLD);
+    V3 p_OLDinG = sub(p_IOLDinG, mulT(R_GtoOLD, T.p_IinC[old_cam]));
+    M3 R_GtoNEW = mul(T.R_ItoC[new_cam], R_GtoINEW);
+    V3 p_NEWinG = sub(p_INEWinG, mulT(R_GtoNEW, T.p_IinC[new_cam]));
+    M3 R_OLDtoNEW = mul(R_GtoNEW, transpose(R_GtoOLD));
+    V3 p_OLDinNEW = mul(R_GtoNEW, sub(p_OLDinG, p_NEWinG));
+    V3 r = add(mul(R_OLDtoNEW, fej ? pA_old_fej : pA_old), p_OLDinNEW);
+    if (fej) pA_new_fej = r;
+    else pA_new = r;
+  }
+  RepJac jn = feature_jacobian_representation(o, T, rep, nanv, nanv, pA_new, new_cam, new_clone); // :577-580
+  // phi_order_OLD (:592-610): x_order_old, then the new ones not seen yet, then the landmark
+  std::vector<int32_t> ids;
+  int col_oc = 0, col_ok = -1, col_nc, col_nk = -1, col_lm;
+  auto push = [&](int cov, int n) { for (int i = 0; i < n; i++) ids.push_back(cov + i); };
+  push(st->clone_cov_id[old_clone], 6);
+  if (jo.has_calib) col_ok = (int)ids.size(), push(st->calib_cov_id[old_cam], 6);
+  col_nc = (int)ids.size(), push(st->clone_cov_id[new_clone], 6);
+  if (jn.has_calib) {
+    if (new_cam == old_cam) col_nk = col_ok;
+    else col_nk = (int)ids.size(), push(st->calib_cov_id[new_cam], 6);
+  }
+  col_lm = (int)ids.size(), push(lm->cov_id[l], 3);
+  const int n = (int)ids.size();
+  // H_f_new^-1 (:621)
+  M3 A;
+  std::memcpy(A.a, jn.dpfg_dlambda, sizeof(A.a));
+  double inv[9];
+  for (int j = 0; j < 3; j++) {
+    V3 e{{j == 0 ? 1.0 : 0.0, j == 1 ? 1.0 : 0.0, j == 2 ? 1.0 : 0.0}};
+    V3 x = colpiv_qr_solve3(A, e);
+    for (int i = 0; i < 3; i++) inv[3 * i + j] = x[i];
+  }
+  std::vector<double> Phi((size_t)3 * n, 0.0), Q(9, 0.0);
+  auto add_block = [&](int col, const double *H, int w, double sign) {
+    for (int a = 0; a < 3; a++)
+      for (int b = 0; b < w; b++) {
+        double sv = 0;
+        for (int k = 0; k < 3; k++) sv += inv[3 * a + k] * H[w * k + b];
+        Phi[(size_t)a * n + col + b] += sign * sv;
+      }
+  };
+  add_block(col_oc, jo.H_anc, 6, 1.0); // :626-628
+  if (col_ok >= 0) add_block(col_ok, jo.H_calib, 6, 1.0);
+  add_block(col_lm, jo.dpfg_dlambda, 3, 1.0); // :631
+  add_block(col_nc, jn.H_anc, 6, -1.0);       // :634-636
+  if (col_nk >= 0) add_block(col_nk, jn.H_calib, 6, -1.0);
+  std::memcpy(P_out, st->P, sizeof(double) * (size_t)N * N);
+  const int rc = oracle_propagate(P_out, N, lm->cov_id[l], 3, n, ids.data(), Phi.data(), Q.data()); // :640
+  landmark_set_from_xyz(rep, pA_new, value_out);     // :645-646
+  landmark_set_from_xyz(rep, pA_new_fej, fej_out);
+  return rc;
+}
+
 int oracle_msckf_update(const ovgpu_options *opts, const ovgpu_state_view *st, const ovgpu_features_view *fv, int32_t *feat_status,
                         double *chi2_out, double *chi2_thresh_out, double *p_FinG_out, double *dx_out, double *P_out,
                         double *clone_q_p_out, double *calib_q_p_out, double *intrinsics_out, double *H_comp, double *r_comp,

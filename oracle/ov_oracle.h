@@ -127,6 +127,11 @@ void oracle_marginalize(const double *P, int N, int marg_id, int marg_size, doub
 void oracle_augment_clone(const double *P, int N, int old_loc, int size, int dt_id, const double *dnc_dt, double *P_out);
 int oracle_propagate(double *P, int N, int start_id, int n_new, int n_old, const int32_t *old_ids, const double *Phi, const double *Q);
 
+/* UpdaterSLAM::perform_anchor_change (UpdaterSLAM.cpp:506-647) for landmark l: covariance after the propagation and the
+ * landmark's value / fej in the new anchor (representation coordinates). */
+int oracle_anchor_change(const ovgpu_options *opts, const ovgpu_state_view *st, const ovgpu_landmarks_view *lm, int l, int new_cam, int new_clone,
+                         double *P_out, double *value_out, double *fej_out);
+
 int oracle_slam_update(const ovgpu_options *opts, const ovgpu_state_view *st, const ovgpu_landmarks_view *lm,
                        const ovgpu_features_view *fv, const int32_t *lm_index, int32_t *feat_status, double *chi2,
                        double *chi2_thresh, double *dx, double *P_out, double *lm_out, int32_t *D_out,

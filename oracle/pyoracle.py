@@ -269,3 +269,15 @@ def propagate(P, start_id, old_ids, Phi, Q):
     lib.oracle_propagate.restype = C.c_int
     rc = lib.oracle_propagate(_p(P), C.c_int(P.shape[0]), C.c_int(int(start_id)), C.c_int(Phi.shape[0]), C.c_int(Phi.shape[1]), _pi(ids), _p(Phi), _p(Q))
     return rc, P
+
+
+def anchor_change(opts, views, l, new_cam, new_clone):
+    """UpdaterSLAM::perform_anchor_change for landmark l of views.landmarks (oracle_anchor_change)."""
+    lib = load()
+    N = views.state.N
+    P = np.zeros((N, N))
+    val, fej = np.zeros(3), np.zeros(3)
+    lib.oracle_anchor_change.restype = C.c_int
+    rc = lib.oracle_anchor_change(C.byref(opts), C.byref(views.state), C.byref(views.landmarks), C.c_int(int(l)), C.c_int(int(new_cam)),
+                                  C.c_int(int(new_clone)), _p(P), _p(val), _p(fej))
+    return dict(rc=rc, P=P, value=val, fej=fej)

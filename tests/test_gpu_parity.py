@@ -765,3 +765,55 @@ def test_state_bookkeeping_rejects_bad_blocks(Updater):
                                       np.eye(3).ctypes.data_as(capi.c_double_p), (-1e6 * np.eye(3)).ctypes.data_as(capi.c_double_p))
     assert rc == capi.ERR_NEGATIVE_DIAGONAL
     up.close()
+
+
+@pytest.mark.parametrize("rep", [capi.REP_ANCHORED_3D, capi.REP_ANCHORED_MSCKF_INVERSE_DEPTH])
+def test_change_anchors_parity_then_marginalize(Updater, oracle, rep):
+    """UpdaterSLAM::change_anchors (SURVEY 8f N1): the landmarks anchored in the oldest clone move to the newest one
+    (value, first estimate, covariance through EKFPropagation) exactly as the oracle moves them one after the other; then
+    the clone can be marginalised and a SLAM update on the shifted window matches the oracle's."""
+    prob = synth.make_slam_problem(2, L=10, lm_rep=rep)
+    moved = np.flatnonzero(prob.lm_anchor_clone == 0)   # most tracks start in the oldest clone
+    other = np.flatnonzero(prob.lm_anchor_clone != 0)
+    assert len(moved) >= 3 and len(other) >= 1
+    opts = capi.default_options(chi2_multipler=1.0)
+    up = Updater(opts)
+    up.set_slam_problem(prob)
+    assert up.change_anchors(0, prob.C - 1) == len(moved)
+    ref = synth.make_slam_problem(2, L=10, lm_rep=rep)
+    for l in moved:  # the oracle, landmark by landmark, each on the covariance the previous one left
+        o = oracle.anchor_change(opts, capi.Views(ref), int(l), int(ref.lm_anchor_cam[l]), ref.C - 1)
+        assert o["rc"] == 0
+        ref.P, ref.lm_value[l], ref.lm_fej[l], ref.lm_anchor_clone[l] = o["P"], o["value"], o["fej"], ref.C - 1
+    lm = up.get_landmarks()
+    np.testing.assert_allclose(lm["value"], ref.lm_value, rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(lm["fej"], ref.lm_fej, rtol=1e-12, atol=1e-13)
+    np.testing.assert_array_equal(lm["anchor_clone"], ref.lm_anchor_clone)
+    assert _rel(up.get_state(P=True)["P"], ref.P) < 1e-12
+    k = int(other[0])
+    up.change_anchor(k, int(ref.lm_anchor_cam[k]), 0)
+    with pytest.raises(RuntimeError):  # a landmark anchored in a clone that goes away must move first; nothing is modified
+        up.state_marginalize(int(prob.clone_cov_id[0]), 6)
+    up.change_anchor(k, int(ref.lm_anchor_cam[k]), int(ref.lm_anchor_clone[k]))
+    # ---- marginalise the oldest clone, update with the remaining measurements
+    up.state_marginalize(int(prob.clone_cov_id[0]), 6)
+    post = up.get_state(P=True)
+    lm2 = up.get_landmarks()
+    np.testing.assert_array_equal(lm2["anchor_clone"], ref.lm_anchor_clone - 1)
+    keep = prob.clone_idx > 0
+    cnt = np.add.reduceat(keep.astype(np.int64), prob.meas_offsets[:-1])
+    win = synth.make_slam_problem(2, L=10, lm_rep=rep)
+    win.C, win.N = prob.C - 1, prob.N - 6
+    win.meas_offsets = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int32)
+    win.uv, win.uvn = prob.uv.reshape(-1, 2)[keep].reshape(-1), prob.uvn.reshape(-1, 2)[keep].reshape(-1)
+    win.clone_idx, win.cam_idx = (prob.clone_idx[keep] - 1).astype(np.int32), prob.cam_idx[keep]
+    win.P, win.clone_q_p, win.clone_q_p_fej = post["P"], post["clone_q_p"], prob.clone_q_p_fej[1:]
+    win.clone_cov_id = prob.clone_cov_id[:-1]
+    win.lm_value, win.lm_fej, win.lm_cov_id = lm2["value"], lm2["fej"], lm2["cov_id"]
+    win.lm_anchor_cam, win.lm_anchor_clone = lm2["anchor_cam"], lm2["anchor_clone"]
+    ref_u = oracle.slam_update(opts, capi.Views(win))
+    up.set_features(win)
+    out = up.slam_update(lm_index=win.lm_index)
+    assert np.array_equal(out["feat_status"], ref_u["feat_status"]) and (ref_u["feat_status"] == capi.FEAT_USED).sum() >= 5
+    assert _rel(out["dx"], ref_u["dx"]) < 1e-7 and _rel(out["P"], ref_u["P"]) < 1e-8
+    up.close()

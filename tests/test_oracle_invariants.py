@@ -477,3 +477,31 @@ def test_window_bookkeeping_against_dense_algebra():
     np.testing.assert_allclose(Pp, F @ P @ F.T + Qf, rtol=1e-12, atol=1e-12)
     rc, _ = pyoracle.propagate(P, 2, ids, Phi, -1e6 * np.eye(6))  # StateHelper.cpp:101-113
     assert rc == capi.ERR_NEGATIVE_DIAGONAL
+
+
+@pytest.mark.parametrize("rep", [capi.REP_ANCHORED_3D, capi.REP_ANCHORED_FULL_INVERSE_DEPTH, capi.REP_ANCHORED_MSCKF_INVERSE_DEPTH])
+def test_anchor_change_keeps_the_landmark_where_it_is(rep):
+    """UpdaterSLAM::perform_anchor_change: the landmark's global position (value and first estimate) does not move, only
+    the landmark's rows / columns of P change, P stays symmetric positive definite."""
+    from oracle import pyoracle
+    prob = synth.make_slam_problem(2, L=6, lm_rep=rep)
+    opts = capi.default_options()
+    v = capi.Views(prob)
+    l, new_clone = 2, prob.C - 1
+    cam = int(prob.lm_anchor_cam[l])
+    o = pyoracle.anchor_change(opts, v, l, cam, new_clone)
+    assert o["rc"] == 0
+
+    def to_global(val, clone, q_p):
+        qc, qk = q_p[clone], prob.calib_q_p[cam]
+        R_GtoI, R_ItoC = synth.quat_2_rot(qc[:4]), synth.quat_2_rot(qk[:4])
+        return R_GtoI.T @ (R_ItoC.T @ (synth.landmark_to_xyz(rep, val) - qk[4:7])) + qc[4:7]
+
+    old_clone = int(prob.lm_anchor_clone[l])
+    np.testing.assert_allclose(to_global(o["value"], new_clone, prob.clone_q_p), to_global(prob.lm_value[l], old_clone, prob.clone_q_p), rtol=0, atol=1e-11)
+    np.testing.assert_allclose(to_global(o["fej"], new_clone, prob.clone_q_p_fej), to_global(prob.lm_fej[l], old_clone, prob.clone_q_p_fej), rtol=0, atol=1e-11)
+    idx = int(prob.lm_cov_id[l]) + np.arange(3)
+    rest = np.setdiff1d(np.arange(prob.N), idx)
+    np.testing.assert_array_equal(o["P"][np.ix_(rest, rest)], prob.P[np.ix_(rest, rest)])
+    assert np.abs(o["P"][np.ix_(idx, idx)] - prob.P[np.ix_(idx, idx)]).max() > 0
+    assert np.linalg.eigvalsh(0.5 * (o["P"] + o["P"].T)).min() > 0
