@@ -45,6 +45,10 @@
 
 #undef QR_T
 
+// Workgroup barrier that waits for this wave's LDS traffic only.  __syncthreads() also drains the vector memory counter,
+// i.e. the first column step of every panel would wait for the L2 round trip of the next panel's prefetched accumulator rows.
+#define QR_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
 namespace ovg {
 namespace pw {
 
@@ -270,7 +274,7 @@ __device__ __forceinline__ void qr_pw_panel(double (&pa)[QH], double (&pb)[QH], 
   double r = X.Rc[colp];
   for (int k = 0; k < X.kmax; k++) {
     QR_T(0)
-    __syncthreads();
+    QR_LDS_BARRIER(); // LDS traffic only: the panel's prefetch loads need not land first
     QR_T(1)
     const int par = k & 1;
     const double rn = X.Rc[min(k + 1, 15) * X.LDP + colp]; // next step's accumulator entry, ahead of time
@@ -299,7 +303,7 @@ __device__ __forceinline__ void qr_bulk_panel(double (&ya)[QH], double (&yb)[QH]
   double ra = X.Rc[cola], rb = X.Rc[colb];
   for (int k = 0; k < X.kmax; k++) {
     QR_T(0)
-    __syncthreads();
+    QR_LDS_BARRIER(); // LDS traffic only: the panel's prefetch loads need not land first
     QR_T(1)
     if (FL == 0) continue;
     const int par = k & 1;
