@@ -817,3 +817,55 @@ def test_change_anchors_parity_then_marginalize(Updater, oracle, rep):
     assert np.array_equal(out["feat_status"], ref_u["feat_status"]) and (ref_u["feat_status"] == capi.FEAT_USED).sum() >= 5
     assert _rel(out["dx"], ref_u["dx"]) < 1e-7 and _rel(out["P"], ref_u["P"]) < 1e-8
     up.close()
+
+
+def test_slam_edge_cases(Updater, oracle):
+    """Empty and degenerate inputs of the SLAM entry points: no features, tracks too short to initialise, global
+    landmarks in change_anchors (skipped, UpdaterSLAM.cpp:493-496), a bad landmark index, a marginalised landmark."""
+    opts = capi.default_options(chi2_multipler=1.0)
+    up = Updater(opts)
+    # ---- delayed_init without features / with tracks of one measurement only
+    prob = synth.make_problem(2, F=6)
+    empty = synth.make_problem(2, F=6)
+    empty.meas_offsets = np.zeros(1, np.int32)
+    empty.uv = empty.uvn = np.zeros(0, np.float32)
+    empty.clone_idx = empty.cam_idx = np.zeros(0, np.int32)
+    up.set_problem(empty)
+    out = up.delayed_init(0)
+    assert out["N"] == prob.N and out["P"].shape == (prob.N, prob.N) and np.array_equal(out["P"], prob.P)
+    short = synth.make_problem(2, F=6)
+    first = short.meas_offsets[:-1]
+    short.uv, short.uvn = short.uv.reshape(-1, 2)[first].reshape(-1), short.uvn.reshape(-1, 2)[first].reshape(-1)
+    short.clone_idx, short.cam_idx = short.clone_idx[first], short.cam_idx[first]
+    short.meas_offsets = np.arange(7, dtype=np.int32)
+    up.set_problem(short)
+    out = up.delayed_init(0)
+    assert (out["feat_status"] == capi.FEAT_TOO_FEW_MEAS).all() and out["N"] == prob.N and (out["lm_cov_id"] == -1).all()
+    assert np.array_equal(out["P"], prob.P) and not out["dx_seq"].any()
+    # ---- global landmarks: change_anchors is a no-op, change_anchor an error; bad landmark index
+    slam = synth.make_slam_problem(2, L=5)
+    up.set_slam_problem(slam)
+    assert up.change_anchors(0, slam.C - 1) == 0
+    with pytest.raises(RuntimeError):
+        up.change_anchor(0, 0, 1)
+    with pytest.raises(RuntimeError):
+        up.slam_update(lm_index=np.array([0, 1, 2, 3, 9], np.int32))
+    # ---- StateHelper::marginalize_slam: landmark 1 leaves the state, the update of the others still matches the oracle
+    up.state_marginalize(int(slam.lm_cov_id[1]), 3)
+    lm = up.get_landmarks()
+    assert lm["value"].shape[0] == 4 and np.array_equal(lm["cov_id"], np.r_[slam.lm_cov_id[0], slam.lm_cov_id[1:4]])
+    keepf = np.array([0, 2, 3, 4])
+    sub = _split_tracks(slam, lambda c: c >= 0, keepf)
+    ref_p = synth.make_slam_problem(2, L=5)
+    for k, a in sub.items():
+        setattr(ref_p, k, a)
+    idx = np.r_[0:slam.lm_cov_id[1], slam.lm_cov_id[1] + 3:slam.N]
+    ref_p.N, ref_p.P = slam.N - 3, slam.P[np.ix_(idx, idx)]
+    ref_p.lm_value, ref_p.lm_fej, ref_p.lm_cov_id = slam.lm_value[keepf], slam.lm_fej[keepf], lm["cov_id"]
+    ref_p.lm_index = np.arange(4, dtype=np.int32)
+    ref = oracle.slam_update(opts, capi.Views(ref_p))
+    up.set_features(ref_p)
+    out = up.slam_update(lm_index=ref_p.lm_index)
+    assert np.array_equal(out["feat_status"], ref["feat_status"])
+    assert _rel(out["dx"], ref["dx"]) < 1e-7 and _rel(out["P"], ref["P"]) < 1e-8
+    up.close()
