@@ -41,7 +41,7 @@ def _rel(a, b):
     return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
 
 
-def _check_given(Updater, oracle, prob, opts, tol_dx=TOL_DX, tol_p=TOL_P):
+def _check_given(Updater, oracle, prob, opts, tol_dx=TOL_DX, tol_p=TOL_P, require_gate=True):
     """Injects the oracle's triangulation on both sides and compares everything downstream."""
     v = capi.Views(prob)
     tri = oracle.triangulate(opts, v)
@@ -56,7 +56,11 @@ def _check_given(Updater, oracle, prob, opts, tol_dx=TOL_DX, tol_p=TOL_P):
         margin = abs(ref["chi2"][f] / ref["chi2_thresh"][f] - 1.0)
         assert margin < 1e-6, f"feature {f}: status {out['feat_status'][f]} vs {ref['feat_status'][f]} (gate margin {margin})"
     gate = np.isfinite(ref["chi2"])
-    assert gate.sum() > 0
+    assert gate.sum() > 0 or not require_gate
+    if gate.sum() == 0:  # nothing triangulated: the update is a no-op on both sides
+        assert len(diff) == 0 and not out["dx"].any() and np.array_equal(out["P"], prob.P)
+        up.close()
+        return out, ref
     np.testing.assert_allclose(out["chi2"][gate], ref["chi2"][gate], rtol=TOL_CHI2)
     np.testing.assert_allclose(out["chi2_thresh"][gate], ref["chi2_thresh"][gate], rtol=1e-12)
     if len(diff) == 0:
@@ -869,3 +873,66 @@ def test_slam_edge_cases(Updater, oracle):
     assert np.array_equal(out["feat_status"], ref["feat_status"])
     assert _rel(out["dx"], ref["dx"]) < 1e-7 and _rel(out["P"], ref["P"]) < 1e-8
     up.close()
+
+
+# --------------------------------------------------------------------------- randomised shapes
+@pytest.mark.parametrize("seed", range(40))
+def test_update_parity_random_shapes(Updater, oracle, seed):
+    """A seeded sweep over window sizes, camera counts, batch sizes, track patterns, lens models, feature representations
+    and state options: ragged and tiny inputs, D from 18 to 296, with and without outliers."""
+    rng = np.random.default_rng(1000 + seed)
+    C = int(rng.integers(3, 41))
+    K = int(rng.integers(1, 5))
+    F = int(rng.integers(1, 90))
+    kw = dict(C=C, K=K, F=F, track=("full", "ragged")[int(rng.integers(2))], fisheye=bool(rng.integers(2)), seed=int(rng.integers(1 << 20)),
+              outlier_frac=float(rng.choice([0.0, 0.0, 0.3])), min_obs=int(rng.integers(2, 6)))
+    rep = int(rng.integers(0, 6))
+    flags = dict(do_fej=int(rng.integers(2)), do_calib_camera_pose=int(rng.integers(2)), do_calib_camera_intrinsics=int(rng.integers(2)))
+    prob = synth.make_problem(int(rng.choice([2, 4])), rep, **kw)
+    opts = capi.default_options(chi2_multipler=float(rng.choice([1.0, 5.0])), feat_rep_msckf=rep, **flags)
+    _check_given(Updater, oracle, prob, opts, require_gate=False)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_slam_update_parity_random_shapes(Updater, oracle, seed):
+    rng = np.random.default_rng(2000 + seed)
+    kw = dict(C=int(rng.integers(6, 31)), K=int(rng.integers(1, 4)), track=("full", "ragged")[int(rng.integers(2))], fisheye=bool(rng.integers(2)),
+              seed=int(rng.integers(1 << 20)))
+    prob = synth.make_slam_problem(2, L=int(rng.integers(1, 13)), lm_rep=int(rng.integers(0, 5)), **kw)
+    opts = capi.default_options(chi2_multipler=float(rng.choice([1.0, 5.0])), do_fej=int(rng.integers(2)),
+                                do_calib_camera_pose=int(rng.integers(2)), do_calib_camera_intrinsics=int(rng.integers(2)))
+    ref = oracle.slam_update(opts, capi.Views(prob))
+    up = Updater(opts)
+    up.set_slam_problem(prob)
+    out = up.slam_update()
+    up.close()
+    diff = np.flatnonzero(out["feat_status"] != ref["feat_status"])
+    assert all(abs(ref["chi2"][f] / ref["chi2_thresh"][f] - 1.0) < 1e-6 for f in diff)
+    if len(diff) == 0 and ref["stats"]["n_used"] > 0:
+        assert _rel(out["dx"], ref["dx"]) < 1e-6 and _rel(out["P"], ref["P"]) < 1e-7
+        np.testing.assert_allclose(out["landmarks"], ref["landmarks"], rtol=1e-8, atol=1e-10)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_delayed_init_parity_random_shapes(Updater, oracle, seed):
+    rng = np.random.default_rng(3000 + seed)
+    kw = dict(C=int(rng.integers(6, 31)), K=int(rng.integers(1, 4)), F=int(rng.integers(1, 21)), track=("full", "ragged")[int(rng.integers(2))],
+              fisheye=bool(rng.integers(2)), seed=int(rng.integers(1 << 20)), outlier_frac=float(rng.choice([0.0, 0.3])))
+    rep = int(rng.integers(0, 5))
+    prob = synth.make_problem(2, **kw)
+    opts = capi.default_options(chi2_multipler=float(rng.choice([1.0, 5.0])), do_fej=int(rng.integers(2)),
+                                do_calib_camera_pose=int(rng.integers(2)), do_calib_camera_intrinsics=int(rng.integers(2)))
+    v = capi.Views(prob)
+    tri = oracle.triangulate(opts, v)
+    ref = oracle.slam_delayed_init(opts, v, feat_rep=rep, tri=tri)
+    up = Updater(opts)
+    up.set_problem(prob)
+    up.set_triangulation(tri["p_FinG"], tri["p_FinA"], tri["anchor_meas"], tri["status"])
+    out = up.delayed_init(rep)
+    post = up.get_state(P=True)
+    up.close()
+    assert ref["rc"] == 0
+    gate = np.isfinite(ref["chi2"])
+    if gate.any() and np.abs(ref["chi2"][gate] / ref["chi2_thresh"][gate] - 1.0).min() < 1e-6:
+        pytest.skip("a feature sits on the gate threshold: the chains may legitimately diverge")
+    _check_delayed_init(out, ref, post)
