@@ -406,7 +406,7 @@ __global__ void __launch_bounds__(512) k_qr_node(QrNodeParams p) {
 #pragma unroll
       for (int i = 0; i < 8; i++) {
         const int j = 16 * (pnl + 1) + 2 * i + cp_r;
-        pre[i] = (have_next && !acc_zero && cp_ok && j < D && cp_c < LD) ? acc[(size_t)j * LD + cp_c] : 0.0;
+        pre[i] = (have_next && !acc_zero && cp_ok && j < D && cp_c < LD && cp_c >= 16 * (pnl + 1)) ? acc[(size_t)j * LD + cp_c] : 0.0; // zero left of the panel
       }
       G.owner_is_b = !(pnl < NW);
       G.owner_w = G.owner_is_b ? NT - 1 - pnl : pnl;
@@ -436,7 +436,7 @@ __global__ void __launch_bounds__(512) k_qr_node(QrNodeParams p) {
 #pragma unroll
         for (int i = 0; i < 8; i++) {
           const int row = 2 * i + cp_r, j = 16 * pnl + row;
-          if (j < D && cp_c < LD) acc[(size_t)j * LD + cp_c] = Rc[row * LDP + cp_c];
+          if (j < D && cp_c < LD && (cp_c >= 16 * pnl || acc_zero)) acc[(size_t)j * LD + cp_c] = Rc[row * LDP + cp_c];
           if (have_next) Rn[row * LDP + cp_c] = pre[i];
         }
       }
@@ -556,7 +556,8 @@ __global__ void __launch_bounds__(512) k_qr_tree(QrTreeParams p) {
 #pragma unroll
       for (int i = 0; i < 8; i++) {
         const int row = 2 * i + cp_r, j = 16 * pnl + row;
-        Rp[row * LDP + cp_c] = (j < D && cp_c < LD) ? ld_agent(acc + (size_t)j * LD + cp_c) : 0.0;
+        // a triangle's rows are zero left of the panel's first column: neither fetched nor written back (half the traffic of a node)
+        Rp[row * LDP + cp_c] = (j < D && cp_c < LD && cp_c >= 16 * pnl) ? ld_agent(acc + (size_t)j * LD + cp_c) : 0.0;
       }
     }
     const bool split = pnl >= NW;
@@ -590,7 +591,7 @@ __global__ void __launch_bounds__(512) k_qr_tree(QrTreeParams p) {
 #pragma unroll
       for (int i = 0; i < 8; i++) {
         const int row = 2 * i + cp_r, j = 16 * pnl + row;
-        if (j < D && cp_c < LD) st_agent(acc + (size_t)j * LD + cp_c, Rp[row * LDP + cp_c]);
+        if (j < D && cp_c < LD && cp_c >= 16 * pnl) st_agent(acc + (size_t)j * LD + cp_c, Rp[row * LDP + cp_c]);
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every wave drains its write-through stores before the barrier

@@ -321,7 +321,7 @@ __global__ void __launch_bounds__(512) k_qr_leaf(QrNodeParams p) {
 #pragma unroll
     for (int i = 0; i < 8; i++) {
       const int j = 16 + 2 * i + cp_r;
-      pre[i] = (NP > 1 && !acc_zero && cp_ok && j < D && cp_c < LD) ? acc[(size_t)j * LD + cp_c] : 0.0;
+      pre[i] = (NP > 1 && !acc_zero && cp_ok && j < D && cp_c < LD && cp_c >= 16) ? acc[(size_t)j * LD + cp_c] : 0.0;
     }
     __syncthreads();
 
@@ -371,7 +371,7 @@ __global__ void __launch_bounds__(512) k_qr_leaf(QrNodeParams p) {
 #pragma unroll
         for (int i = 0; i < 8; i++) {
           const int j = 16 * (pnl - 1) + 2 * i + cp_r;
-          if (j < D && cp_c < LD) {
+          if (j < D && cp_c < LD && (cp_c >= 16 * (pnl - 1) || acc_zero)) { // zero left of the panel: written only to clear a fresh accumulator
             if (publish) st_agent(acc + (size_t)j * LD + cp_c, outv[i]);
             else acc[(size_t)j * LD + cp_c] = outv[i];
           }
@@ -393,7 +393,7 @@ __global__ void __launch_bounds__(512) k_qr_leaf(QrNodeParams p) {
 #pragma unroll
       for (int i = 0; i < 8; i++) {
         const int j = 16 * (pnl + 2) + 2 * i + cp_r;
-        pre[i] = (pnl + 2 < NP && !acc_zero && cp_ok && j < D && cp_c < LD) ? acc[(size_t)j * LD + cp_c] : 0.0;
+        pre[i] = (pnl + 2 < NP && !acc_zero && cp_ok && j < D && cp_c < LD && cp_c >= 16 * (pnl + 2)) ? acc[(size_t)j * LD + cp_c] : 0.0;
       }
     }
     __syncthreads(); // the last block is applied everywhere
@@ -402,7 +402,7 @@ __global__ void __launch_bounds__(512) k_qr_leaf(QrNodeParams p) {
 #pragma unroll
       for (int i = 0; i < 8; i++) {
         const int row = 2 * i + cp_r, j = 16 * (NP - 1) + row;
-        if (j < D && cp_c < LD) {
+        if (j < D && cp_c < LD && (cp_c >= 16 * (NP - 1) || acc_zero)) {
           if (publish) st_agent(acc + (size_t)j * LD + cp_c, Rl[row * LDP + cp_c]);
           else acc[(size_t)j * LD + cp_c] = Rl[row * LDP + cp_c];
         }

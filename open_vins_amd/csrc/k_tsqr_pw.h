@@ -435,7 +435,8 @@ __global__ void __launch_bounds__(512) k_qr_node(QrNodeParams p) {
 #pragma unroll
       for (int i = 0; i < 8; i++) {
         const int j = 16 * (pnl + 1) + 2 * i + cp_r;
-        pre[i] = (have_next && !acc_zero && cp_ok && j < D && cp_c < LD) ? acc[(size_t)j * LD + cp_c] : 0.0;
+        // R is upper triangular: row j is zero left of column j, i.e. left of the panel's first column — not fetched
+        pre[i] = (have_next && !acc_zero && cp_ok && j < D && cp_c < LD && cp_c >= 16 * (pnl + 1)) ? acc[(size_t)j * LD + cp_c] : 0.0;
       }
       X.pnl = pnl, X.kmax = min(16, D - 16 * pnl), X.Rc = Rc;
 #ifdef QR_PROFILE
@@ -487,7 +488,9 @@ __global__ void __launch_bounds__(512) k_qr_node(QrNodeParams p) {
 #pragma unroll
         for (int i = 0; i < 8; i++) {
           const int row = 2 * i + cp_r, j = 16 * pnl + row;
-          if (j < D && cp_c < LD) {
+          // ... and not written back either, except by the first append of a fresh accumulator, which clears whatever the
+          // buffer held before
+          if (j < D && cp_c < LD && (cp_c >= 16 * pnl || acc_zero)) {
             if (publish) st_agent(acc + (size_t)j * LD + cp_c, Rc[row * LDP + cp_c]); // write-through: read by another CU right away
             else acc[(size_t)j * LD + cp_c] = Rc[row * LDP + cp_c];
           }
