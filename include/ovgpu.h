@@ -278,15 +278,17 @@ int ovgpu_get_state(ovgpu_ctx *ctx, double *P, double *clone_q_p,
 /* ------------------------------------------------------------------------- */
 
 /* SLAM landmarks that live in the state (State::_features_SLAM, ov_type::Landmark,
- * ov_core/src/types/Landmark.h), all in one 3-dof representation `feat_rep` (StateOptions
- * feat_rep_slam; 0 = GLOBAL_3D, the reference default, StateOptions.h:89).  The 1-dof
- * ANCHORED_INVERSE_DEPTH_SINGLE is not supported (OVGPU_ERR_INVALID).
+ * ov_core/src/types/Landmark.h), all in one representation `feat_rep` (StateOptions
+ * feat_rep_slam; 0 = GLOBAL_3D, the reference default, StateOptions.h:89).
  *   p_value [3*L]  Landmark::value()  — REPRESENTATION coordinates (xyz, (theta, phi, rho) or
  *                  (alpha, beta, rho), Landmark.cpp:66-141); the library applies
  *                  Landmark::get_xyz (Landmark.cpp:25-62) where the reference does
- *                  (UpdaterSLAM.cpp:345-353)
- *   p_fej   [3*L]  Landmark::fej()
- *   cov_id  [L]    Type::id() of the 3-dof landmark in the covariance
+ *                  (UpdaterSLAM.cpp:345-353).  ANCHORED_INVERSE_DEPTH_SINGLE: the 1-dof
+ *                  landmark is handed over as (uv_norm_zero.x, uv_norm_zero.y, value()(0)) —
+ *                  its constant bearing and its inverse depth (Landmark.cpp:57-60, :124-140);
+ *                  only the third entry is a state variable and ever changes
+ *   p_fej   [3*L]  Landmark::fej(), same convention
+ *   cov_id  [L]    Type::id() of the landmark in the covariance (3 dof; 1 for the single depth)
  *   anchor_cam, anchor_clone [L]  Landmark::_anchor_cam_id and the clone index (into the
  *                  state view's clone arrays) of _anchor_clone_timestamp; read for the anchored
  *                  representations only (may be NULL otherwise)                          */
@@ -309,6 +311,9 @@ int ovgpu_set_landmarks(ovgpu_ctx *ctx, const ovgpu_landmarks_view *lm);
  * with the landmark's own columns appended (UpdaterSLAM.cpp:369-384, no nullspace projection
  * for a full 3-dof landmark), the chi2 gate on all 2m rows against the prior with the
  * landmark's covariance (:390-420, dof = 2m), stacking (:427-447) and one EKF update (:470).
+ * A single-depth landmark contributes its depth column only: the two bearing columns of H_f are
+ * projected out of [H_x | h_rho] and the residual (:371-379), 2m - 2 rows and dof = 2m - 2; a
+ * track with one measurement leaves no row and is flagged OVGPU_FEAT_TOO_FEW_MEAS.
  * The context's options are the UpdaterSLAM's (sigma_pix, chi2_multipler of `slam`).
  * The reference stacks without compressing; here the stack goes through the same TSQR as the
  * MSCKF update first — the EKF result is the same matrix (QR is an orthogonal transform of
@@ -339,10 +344,13 @@ int ovgpu_slam_compress(ovgpu_ctx *ctx, const int32_t *lm_index, int32_t *feat_s
  * against chi2_multipler * chi2_0.95(2m) (:459-470), and for an accepted feature the covariance
  * augmentation (:541-565), the landmark's first correction (:569) and StateHelper::EKFUpdate
  * with the 2m-3 rows (:476-478).  The context's options are the UpdaterSLAM's (sigma_pix,
- * chi2_multipler of `slam`).  `feat_rep` = StateOptions::feat_rep_slam (3-dof representations;
- * must equal the representation of the resident landmarks when there are any).
+ * chi2_multipler of `slam`).  `feat_rep` = StateOptions::feat_rep_slam (must equal the
+ * representation of the resident landmarks when there are any).  ANCHORED_INVERSE_DEPTH_SINGLE:
+ * the bearing is projected out first (UpdaterSLAM.cpp:181-196), the third of the three rows
+ * initialises the 1-dof landmark and the gate uses the quantile of 2m-2 dof.
  *
- * The covariance grows by 3 per accepted feature, in feature order (new ids N, N+3, ...).
+ * The covariance grows by s = 3 (1 for the single depth) per accepted feature, in feature order
+ * (new ids N, N+s, ...); below, "3*F" in the sizes of dx_seq and P_out reads s*F.
  * Outputs (any may be NULL):
  *   feat_status, chi2, chi2_thresh [F]   as ovgpu_msckf_update (chi2 rejected ->
  *                                        OVGPU_FEAT_CHI2_REJECTED)
@@ -373,7 +381,8 @@ int ovgpu_get_landmarks(ovgpu_ctx *ctx, int32_t *L_out, double *value, double *f
 /* UpdaterSLAM::perform_anchor_change (UpdaterSLAM.cpp:506-647) for the resident anchored landmark
  * lm_index: its position is re-expressed in the camera `new_anchor_cam` of clone `new_anchor_clone`
  * (value and first estimate, :536-571), and the covariance is propagated with
- * Phi = H_f_new^-1 [H_x_old | H_f_old | -H_x_new] through StateHelper::EKFPropagation (:612-640).
+ * Phi = H_f_new^-1 [H_x_old | H_f_old | -H_x_new] through StateHelper::EKFPropagation (:612-640;
+ * the single depth uses the pseudo-inverse of its 3 x 1 Jacobian, :619).
  * OVGPU_ERR_INVALID for a global representation.                                            */
 int ovgpu_slam_change_anchor(ovgpu_ctx *ctx, int32_t lm_index, int32_t new_anchor_cam,
                              int32_t new_anchor_clone);

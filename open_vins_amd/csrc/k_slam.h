@@ -20,7 +20,9 @@ __device__ __forceinline__ V3 lm_to_xyz(int rep, const double *v) {
     const double ir = 1.0 / v[2];
     return V3{ir * cos(v[0]) * sin(v[1]), ir * sin(v[0]) * sin(v[1]), ir * cos(v[1])};
   }
-  if (rep == OVGPU_REP_ANCHORED_MSCKF_INVERSE_DEPTH) {
+  // ANCHORED_INVERSE_DEPTH_SINGLE is stored as (uv_norm_zero.x, uv_norm_zero.y, rho): only rho is a state variable, the bearing is
+  // a constant of the landmark (Landmark.cpp:57-60, :124-140) — the same formulas as the MSCKF inverse depth
+  if (rep == OVGPU_REP_ANCHORED_MSCKF_INVERSE_DEPTH || rep == OVGPU_REP_ANCHORED_INVERSE_DEPTH_SINGLE) {
     const double ir = 1.0 / v[2];
     return V3{ir * v[0], ir * v[1], ir};
   }
@@ -34,7 +36,7 @@ __device__ __forceinline__ void lm_from_xyz(int rep, const V3 &p, double *v) {
     v[0] = atan2(p.y, p.x), v[1] = acos(rho * p.z), v[2] = rho;
     return;
   }
-  if (rep == OVGPU_REP_ANCHORED_MSCKF_INVERSE_DEPTH) {
+  if (rep == OVGPU_REP_ANCHORED_MSCKF_INVERSE_DEPTH || rep == OVGPU_REP_ANCHORED_INVERSE_DEPTH_SINGLE) {
     v[0] = p.x / p.z, v[1] = p.y / p.z, v[2] = 1.0 / p.z;
     return;
   }
@@ -48,7 +50,7 @@ struct LandmarkStore {
 };
 
 // per-feature inputs of the SLAM update from the landmark each feature observes (UpdaterSLAM.cpp:333-353)
-__global__ void k_slam_gather(int F, int rep, const int32_t *__restrict__ lm_index, const int32_t *__restrict__ meas_offsets, LandmarkStore lm,
+__global__ void k_slam_gather(int F, int rep, int min_meas, const int32_t *__restrict__ lm_index, const int32_t *__restrict__ meas_offsets, LandmarkStore lm,
                               double *p_FinG, double *p_FinA, double *p_fej, int32_t *feat_lm, int32_t *feat_lmcol, int32_t *feat_lmcov,
                               int32_t *feat_anchor, int32_t *status) {
   const int f = blockIdx.x * blockDim.x + threadIdx.x;
@@ -59,16 +61,18 @@ __global__ void k_slam_gather(int F, int rep, const int32_t *__restrict__ lm_ind
   dst[3 * f] = x.x, dst[3 * f + 1] = x.y, dst[3 * f + 2] = x.z;
   p_fej[3 * f] = xf.x, p_fej[3 * f + 1] = xf.y, p_fej[3 * f + 2] = xf.z;
   feat_lm[f] = l, feat_lmcol[f] = lm.col[l], feat_lmcov[f] = lm.cov[l], feat_anchor[f] = lm.anchor[l];
-  status[f] = (meas_offsets[f + 1] - meas_offsets[f] >= 1) ? OVGPU_FEAT_USED : OVGPU_FEAT_TOO_FEW_MEAS; // UpdaterSLAM.cpp:289-291
+  // UpdaterSLAM.cpp:289-291; a single-depth landmark needs two measurements: one leaves no row after its bearing is projected out
+  status[f] = (meas_offsets[f + 1] - meas_offsets[f] >= min_meas) ? OVGPU_FEAT_USED : OVGPU_FEAT_TOO_FEW_MEAS;
 }
 
 // Landmark::update: value += dx[id .. id+2]     (L from a device counter when the count changes inside a stream of launches)
-__global__ void k_landmark_update(int L, const int32_t *__restrict__ L_dev, const double *__restrict__ dx, const int32_t *__restrict__ lm_cov,
+// sz = state dof of a landmark: 3, or 1 for a single-depth landmark whose state variable is the LAST of its three stored values
+__global__ void k_landmark_update(int L, const int32_t *__restrict__ L_dev, int sz, const double *__restrict__ dx, const int32_t *__restrict__ lm_cov,
                                   double *lm_value, const int32_t *pred) {
   if (pred && *pred == 0) return;
   const int n = L_dev ? *L_dev : L;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t < 3 * n) lm_value[t] += dx[lm_cov[t / 3] + t % 3];
+  if (t < sz * n) lm_value[3 * (t / sz) + (3 - sz) + t % sz] += dx[lm_cov[t / sz] + t % sz];
 }
 
 // dst (n x n, leading dimension ldd) <- src (leading dimension lds); the rest of dst's rows / columns up to nd is zeroed
@@ -167,6 +171,7 @@ __global__ void k_cov_propagate(int N, int nid, int n_new, int n_old, const int3
 // ---------------------------------------------------------------------------------------------------
 struct AnchorParams {
   int rep, do_fej, l, new_cam, new_clone;
+  int sz; // landmark dof: 3, or 1 (single depth: H_f is the third column of the inverse-depth Jacobian, UpdaterHelper.cpp:178-189)
   const double *tab_clone, *tab_cam; // [C*24], [K*12]
   const int32_t *clone_cov, *calib_cov;
   LandmarkStore lm;
@@ -181,7 +186,9 @@ __global__ void k_anchor_change(AnchorParams p) {
   const int old_cam = p.lm.anchor[l] >> 10, old_clone = p.lm.anchor[l] & 1023;
   const V3 pA_old = lm_to_xyz(p.rep, p.lm.value + 3 * l), pA_old_fej = lm_to_xyz(p.rep, p.lm.fej + 3 * l);
   double Hf_old[9], Ha_old[18], Hc_old[18], Hf_new[9], Ha_new[18], Hc_new[18];
-  anchored_rep_jacobian(p.rep, p.do_fej, p.tab_cam + 12 * old_cam, p.tab_clone + 24 * old_clone, pA_old, Hf_old, Ha_old, Hc_old); // :523-526
+  // the single-depth landmark uses the Jacobians of the MSCKF inverse depth (its third column is d p / d rho)
+  const int jrep = p.rep == OVGPU_REP_ANCHORED_INVERSE_DEPTH_SINGLE ? OVGPU_REP_ANCHORED_MSCKF_INVERSE_DEPTH : p.rep;
+  anchored_rep_jacobian(jrep, p.do_fej, p.tab_cam + 12 * old_cam, p.tab_clone + 24 * old_clone, pA_old, Hf_old, Ha_old, Hc_old); // :523-526
   // current estimates (:536-551) and first estimates (:556-571) of the two anchor cameras
   V3 pA_new, pA_new_fej;
   for (int fej = 0; fej < 2; fej++) {
@@ -196,11 +203,18 @@ __global__ void k_anchor_change(AnchorParams p) {
     if (fej) pA_new_fej = r;
     else pA_new = r;
   }
-  anchored_rep_jacobian(p.rep, p.do_fej, p.tab_cam + 12 * p.new_cam, p.tab_clone + 24 * p.new_clone, pA_new, Hf_new, Ha_new, Hc_new); // :577-580
-  // H_f_new^-1 by column-pivoted Householder QR of the 3 x 3 (:621)
-  const M3 A{Hf_new[0], Hf_new[1], Hf_new[2], Hf_new[3], Hf_new[4], Hf_new[5], Hf_new[6], Hf_new[7], Hf_new[8]};
-  const V3 c0 = colpiv_qr_solve3(A, V3{1, 0, 0}), c1 = colpiv_qr_solve3(A, V3{0, 1, 0}), c2 = colpiv_qr_solve3(A, V3{0, 0, 1});
-  const double inv[9] = {c0.x, c1.x, c2.x, c0.y, c1.y, c2.y, c0.z, c1.z, c2.z};
+  anchored_rep_jacobian(jrep, p.do_fej, p.tab_cam + 12 * p.new_cam, p.tab_clone + 24 * p.new_clone, pA_new, Hf_new, Ha_new, Hc_new); // :577-580
+  // H_f_new^-1 by column-pivoted Householder QR of the 3 x 3 (:621); single depth: the pseudo-inverse h^T / |h|^2 of the 3 x 1 (:619)
+  double inv[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const int j0 = 3 - p.sz; // rows of `inv` / columns of H_f that belong to the landmark's state
+  if (p.sz == 3) {
+    const M3 A{Hf_new[0], Hf_new[1], Hf_new[2], Hf_new[3], Hf_new[4], Hf_new[5], Hf_new[6], Hf_new[7], Hf_new[8]};
+    const V3 c0 = colpiv_qr_solve3(A, V3{1, 0, 0}), c1 = colpiv_qr_solve3(A, V3{0, 1, 0}), c2 = colpiv_qr_solve3(A, V3{0, 0, 1});
+    inv[0] = c0.x, inv[1] = c1.x, inv[2] = c2.x, inv[3] = c0.y, inv[4] = c1.y, inv[5] = c2.y, inv[6] = c0.z, inv[7] = c1.z, inv[8] = c2.z;
+  } else {
+    const double h0 = Hf_new[2], h1 = Hf_new[5], h2 = Hf_new[8], nn = 1.0 / (h0 * h0 + h1 * h1 + h2 * h2);
+    inv[6] = nn * h0, inv[7] = nn * h1, inv[8] = nn * h2;
+  }
   // ---- column layout
   int n = 0, col_oc, col_ok = -1, col_nc, col_nk = -1, col_lm;
   col_oc = n, n += 6;
@@ -210,27 +224,27 @@ __global__ void k_anchor_change(AnchorParams p) {
     if (p.new_cam == old_cam) col_nk = col_ok;
     else col_nk = n, n += 6;
   }
-  col_lm = n, n += 3;
-  for (int i = 0; i < 3 * n; i++) p.phi[i] = 0.0;
+  col_lm = n, n += p.sz;
+  for (int i = 0; i < p.sz * n; i++) p.phi[i] = 0.0;
   for (int j = 0; j < 6; j++) {
     p.ids[col_oc + j] = p.clone_cov[old_clone] + j, p.ids[col_nc + j] = p.clone_cov[p.new_clone] + j;
     if (col_ok >= 0) p.ids[col_ok + j] = p.calib_cov[old_cam] + j;
     if (col_nk >= 0) p.ids[col_nk + j] = p.calib_cov[p.new_cam] + j;
   }
-  for (int j = 0; j < 3; j++) p.ids[col_lm + j] = p.lm.cov[l] + j;
-  auto add_block = [&](int col, const double *H, int w, double sign) { // Phi(:, col ..) += sign * inv * H (3 x w)
-    for (int a = 0; a < 3; a++)
-      for (int b = 0; b < w; b++) {
+  for (int j = 0; j < p.sz; j++) p.ids[col_lm + j] = p.lm.cov[l] + j;
+  auto add_block = [&](int col, const double *H, int w, int b0, double sign) { // Phi(:, col ..) += sign * inv * H(:, b0 ..) (H is 3 x w)
+    for (int a = j0; a < 3; a++)
+      for (int b = b0; b < w; b++) {
         double sv = 0.0;
         for (int k = 0; k < 3; k++) sv = fma(inv[3 * a + k], H[w * k + b], sv);
-        p.phi[a * n + col + b] += sign * sv;
+        p.phi[(a - j0) * n + col + b - b0] += sign * sv;
       }
   };
-  add_block(col_oc, Ha_old, 6, 1.0);                  // :626-628
-  if (col_ok >= 0) add_block(col_ok, Hc_old, 6, 1.0);
-  add_block(col_lm, Hf_old, 3, 1.0);                  // :631
-  add_block(col_nc, Ha_new, 6, -1.0);                 // :634-636
-  if (col_nk >= 0) add_block(col_nk, Hc_new, 6, -1.0);
+  add_block(col_oc, Ha_old, 6, 0, 1.0);                  // :626-628
+  if (col_ok >= 0) add_block(col_ok, Hc_old, 6, 0, 1.0);
+  add_block(col_lm, Hf_old, 3, j0, 1.0);                 // :631 (single depth: H_f_old is the third column)
+  add_block(col_nc, Ha_new, 6, 0, -1.0);                 // :634-636
+  if (col_nk >= 0) add_block(col_nk, Hc_new, 6, 0, -1.0);
   *p.n_old = n;
   // ---- the landmark in its new anchor (:642-647)
   lm_from_xyz(p.rep, pA_new, p.lm.value + 3 * l);
@@ -241,6 +255,7 @@ __global__ void k_anchor_change(AnchorParams p) {
 struct InitParams {
   int N, D, LD;             // N = leading dimension of P (the padded capacity)
   int rep, f;
+  int sz;                   // dof of the new landmark: 3, or 1 (single depth: only the third row of the 3-row system initialises it)
   const int32_t *col_cov;   // [D]
   const double *init_out;   // [3 * LD + 9]: Q1^T [H_x | res], R1
   double *P;
@@ -299,18 +314,18 @@ __global__ void __launch_bounds__(256) k_init_invertible(InitParams p) {
   }
   __syncthreads();
   const int id = p.ctr[0], slot = p.ctr[1];
+  const int j0 = 3 - p.sz; // first row of the initialising system that belongs to the new variable
   for (int i = tid; i < N; i += 256) {
-    if (i >= id && i < id + 3) continue;
-#pragma unroll
-    for (int j = 0; j < 3; j++) { // :556-557
+    if (i >= id && i < id + p.sz) continue;
+    for (int j = j0; j < 3; j++) { // :556-557
       const double v = -t[(size_t)j * N + i];
-      p.P[(size_t)i * N + id + j] = v;
-      p.P[(size_t)(id + j) * N + i] = v;
+      p.P[(size_t)i * N + id + j - j0] = v;
+      p.P[(size_t)(id + j - j0) * N + i] = v;
     }
   }
   if (tid < 9) {
     const int j = tid / 3, k = tid % 3;
-    p.P[(size_t)(id + j) * N + id + k] = 0.5 * (PLL[3 * j + k] + PLL[3 * k + j]); // :558, symmetric by construction up to rounding
+    if (j >= j0 && k >= j0) p.P[(size_t)(id + j - j0) * N + id + k - j0] = 0.5 * (PLL[3 * j + k] + PLL[3 * k + j]); // :558, symmetric by construction up to rounding
   }
   if (tid == 0) {
     const bool relative = p.rep >= OVGPU_REP_ANCHORED_3D;
@@ -319,14 +334,14 @@ __global__ void __launch_bounds__(256) k_init_invertible(InitParams p) {
     lm_from_xyz(p.rep, V3{x[0], x[1], x[2]}, v); // UpdaterSLAM.cpp:213-221
     for (int j = 0; j < 3; j++) {
       p.lm.fej[3 * slot + j] = v[j];
-      p.lm.value[3 * slot + j] = v[j] + G[(size_t)j * LD + D]; // new_variable->update(H_Linv * res), :569
+      p.lm.value[3 * slot + j] = v[j] + (j >= j0 ? G[(size_t)j * LD + D] : 0.0); // new_variable->update(H_Linv * res), :569
     }
     p.lm.cov[slot] = id, p.lm.col[slot] = -1;
     p.lm.anchor[slot] = relative ? (int32_t)p.meas_cc[p.anchor_meas[p.f]] : -1;
     p.feat_slot[p.f] = slot;
   }
   __syncthreads();
-  if (tid == 0) p.ctr[0] = id + 3, p.ctr[1] = slot + 1;
+  if (tid == 0) p.ctr[0] = id + p.sz, p.ctr[1] = slot + 1;
 }
 
 } // namespace ovg

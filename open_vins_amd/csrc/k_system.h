@@ -209,7 +209,12 @@ __global__ void __launch_bounds__(SYS_NT) k_system(SysParams p) {
     // (a0) representation Jacobian — UpdaterHelper.cpp:32-190 (once per feature)
     // ------------------------------------------------------------------
     V3 p_FinG = load_v3(p.p_FinG + 3 * f);
-    const bool slam = p.slam != 0; // UpdaterSLAM::update: the feature is a landmark of the state (GLOBAL_3D)
+    const bool slam = p.slam != 0; // UpdaterSLAM::update: the feature is a landmark of the state
+    // Columns of H_f that are projected out (nproj) / kept as the landmark's state columns (lm_size, starting at lm_off):
+    //   MSCKF feature, delayed init          nproj 3, no landmark column
+    //   3-dof SLAM landmark                  nproj 0, columns 0..2                                  (UpdaterSLAM.cpp:381-383)
+    //   ANCHORED_INVERSE_DEPTH_SINGLE        nproj 2 (the bearing is marginalised), column 2 = depth (UpdaterSLAM.cpp:371-379)
+    const int lm_size = slam ? p.lm_size : 0, lm_off = 3 - lm_size, nproj = 3 - lm_size;
     const int lm_id = slam ? p.feat_lm[f] : -1, lm_col = slam ? p.feat_lmcol[f] : -1, lm_cov = slam ? p.feat_lmcov[f] : -1;
     V3 p_FinG_fej = slam ? load_v3(p.p_fej + 3 * f) : p_FinG; // fej == value for MSCKF features (UpdaterMSCKF.cpp:186-194)
     int anchor_cam = -1, anchor_clone = -1;
@@ -380,7 +385,7 @@ __global__ void __launch_bounds__(SYS_NT) k_system(SysParams p) {
           }
           if (lm_cov >= 0) {
 #pragma unroll
-            for (int s = 0; s < 3; s++) plm[s] = Pc[(size_t)(lm_cov + s) * N];
+            for (int s = 0; s < 3; s++) plm[s] = s >= lm_off ? Pc[(size_t)(lm_cov + s - lm_off) * N] : 0.0; // indexed by H_f column
           }
         }
 #pragma unroll
@@ -442,7 +447,7 @@ __global__ void __launch_bounds__(SYS_NT) k_system(SysParams p) {
           const int c_cl = mi[2], c_po = mi[3], c_in = mi[4];
           double hcl[6], hpo[6], hin[8], han[6], hac[6], hlm[3];
 #pragma unroll
-          for (int k = 0; k < 3; k++) hlm[k] = lm_col >= 0 ? rd[RO_HF + 3 * qa + k] : 0.0;
+          for (int k = 0; k < 3; k++) hlm[k] = (lm_col >= 0 && k >= lm_off) ? rd[RO_HF + 3 * qa + k] : 0.0; // indexed by H_f column
 #pragma unroll
           for (int k = 0; k < 6; k++) hcl[k] = rd[RO_CLONE + 6 * qa + k];
 #pragma unroll
@@ -478,7 +483,7 @@ __global__ void __launch_bounds__(SYS_NT) k_system(SysParams p) {
             }
             if (lm_col >= 0) {
 #pragma unroll
-              for (int k = 0; k < 3; k++) sv = fma(Tr[lm_col + k], hlm[k], sv);
+              for (int k = 0; k < 3; k++) sv = fma(Tr[lm_col + max(k - lm_off, 0)], hlm[k], sv);
             }
             S[sidx(r, q, n)] = sv;
           }
@@ -494,7 +499,7 @@ __global__ void __launch_bounds__(SYS_NT) k_system(SysParams p) {
       S[sidx(n, q, n)] = rd[RO_RES + qa];
       S[sidx(n + 1, q, n)] = rd[RO_HF + 3 * qa + 0];
       S[sidx(n + 2, q, n)] = rd[RO_HF + 3 * qa + 1];
-      S[sidx(n + 3, q, n)] = rd[RO_HF + 3 * qa + 2];
+      S[sidx(n + 3, q, n)] = nproj == 3 ? rd[RO_HF + 3 * qa + 2] : 0.0; // only the projected columns of H_f enter the statistic
     }
     __syncthreads();
     SYS_T(4)
@@ -564,13 +569,15 @@ __global__ void __launch_bounds__(SYS_NT) k_system(SysParams p) {
       a = wave_sum(a);
       G00 = wave_sum(G00), G01 = wave_sum(G01), G02 = wave_sum(G02), G11 = wave_sum(G11), G12 = wave_sum(G12), G22 = wave_sum(G22);
       g0 = wave_sum(g0), g1 = wave_sum(g1), g2 = wave_sum(g2);
-      const M3 G{G00, G01, G02, G01, G11, G12, G02, G12, G22};
+      // two projected columns: the third row / column of G is zero, an identity entry keeps the 3 x 3 solve well posed
+      const M3 G{G00, G01, G02, G01, G11, G12, G02, G12, nproj == 3 ? G22 : 1.0};
       const V3 g{g0, g1, g2};
       const V3 x = colpiv_qr_solve3(G, g);
-      // SLAM: the landmark is a state variable, the gate is on all n rows (UpdaterSLAM.cpp:390-405)
-      const double chi2 = slam ? a : a - dot(g, x);
-      // StateHelper::initialize gates the 2m-3 projected rows against the quantile of ALL res.rows() = 2m (StateHelper.cpp:466)
-      const int dof = (slam || p.init) ? n : n - 3;
+      // 3-dof SLAM landmark: a state variable, the gate is on all n rows (UpdaterSLAM.cpp:390-405)
+      const double chi2 = nproj == 0 ? a : a - dot(g, x);
+      // StateHelper::initialize gates the 2m-3 projected rows against the quantile of the res.rows() it was handed: 2m, or
+      // 2m-2 when the bearing was projected out before (StateHelper.cpp:466, UpdaterSLAM.cpp:181-196)
+      const int dof = p.init ? n - p.init_dof_less : n - nproj;
       const double thr = p.opt.chi2_multipler * p.chi2_table[min(dof, p.chi2_table_len - 1)]; // UpdaterMSCKF.cpp:216-222
       if (tid == 0) {
         p.chi2[f] = chi2;
@@ -591,7 +598,7 @@ __global__ void __launch_bounds__(SYS_NT) k_system(SysParams p) {
     SYS_T(6)
     // (b) Householder QR of H_f (2m x 3) -> V, tau, T   (role of UpdaterHelper.cpp:426-454)
     // ------------------------------------------------------------------
-    if (!slam && tid < 64) {
+    if (nproj > 0 && tid < 64) {
       const int lane = tid;
 #pragma unroll
       for (int k = 0; k < 3; k++) {
@@ -604,7 +611,7 @@ __global__ void __launch_bounds__(SYS_NT) k_system(SysParams p) {
         sig = wave_sum(sig);
         const double alpha = rows[(size_t)(k >> 1) * RS + RO_HF + 3 * (k & 1) + k];
         double beta = alpha, tau = 0.0, scale = 0.0;
-        if (sig > 2.2250738585072014e-308) {
+        if (sig > 2.2250738585072014e-308 && k < nproj) { // a column that stays (the depth of a single-depth landmark): H_k = I
           beta = sqrt(alpha * alpha + sig);
           if (alpha >= 0.0) beta = -beta;
           scale = 1.0 / (alpha - beta);
@@ -618,8 +625,8 @@ __global__ void __launch_bounds__(SYS_NT) k_system(SysParams p) {
           V[(size_t)r * 3 + k] = v;
         }
         if (lane == 0) hq[k] = tau, hq[58 + k] = beta; // beta_k = R1[k][k]
-        // apply H_k to the remaining columns of H_f
-        for (int c = k + 1; c < 3; c++) {
+        // apply H_k to the remaining PROJECTED columns of H_f (a column that stays is a Jacobian column of the output stage: untouched here)
+        for (int c = k + 1; c < nproj; c++) {
           double w = 0.0;
           for (int r = k + lane; r < n; r += 64) w = fma(V[(size_t)r * 3 + k], rows[(size_t)(r >> 1) * RS + RO_HF + 3 * (r & 1) + c], w);
           w = wave_sum(w) * tau;
@@ -676,7 +683,7 @@ __global__ void __launch_bounds__(SYS_NT) k_system(SysParams p) {
           if (anc_hit_p) h += rd[RO_ACAL + 6 * a + sub];
           return h;
         };
-        if (slam) { // UpdaterSLAM.cpp:381-383, :427-447: the rows go into the stack as they are, landmark columns included
+        if (nproj == 0) { // UpdaterSLAM.cpp:381-383, :427-447: the rows go into the stack as they are, landmark columns included
           double *out = p.Hbig + orow0 * LD + c;
 #pragma unroll 4
           for (int r = 0; r < n; r++) out[(size_t)r * LD] = hval(r >> 1, r & 1);
@@ -702,10 +709,10 @@ __global__ void __launch_bounds__(SYS_NT) k_system(SysParams p) {
         }
         double *out = p.Hbig + orow0 * LD + c;
 #pragma unroll 4
-        for (int r = 3; r < n; r++) {
+        for (int r = nproj; r < n; r++) {
           const double h = hval(r >> 1, r & 1);
           const double *v = V + (size_t)3 * r;
-          out[(size_t)(r - 3) * LD] = h - (v[0] * z0 + v[1] * z1 + v[2] * z2);
+          out[(size_t)(r - nproj) * LD] = h - (v[0] * z0 + v[1] * z1 + v[2] * z2);
         }
       }
     }

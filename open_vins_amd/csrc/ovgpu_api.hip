@@ -361,6 +361,9 @@ void ovgpu_destroy(ovgpu_ctx *c) {
   delete c;
 }
 
+// state dof of a resident landmark: the single-depth representation keeps its bearing as a constant (Landmark.cpp:124-140)
+static int lm_dof(int rep) { return rep == OVGPU_REP_ANCHORED_INVERSE_DEPTH_SINGLE ? 1 : 3; }
+
 static int launch_build_tables(ovgpu_ctx *c) {
   const int n = std::max(c->K * c->C, std::max(c->C, c->K));
   hipLaunchKernelGGL(k_build_tables, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->C, c->K, c->clone_qp.p, c->clone_fej.p, c->calib_qp.p,
@@ -373,7 +376,8 @@ static int launch_build_tables(ovgpu_ctx *c) {
 // covariance id.  Called by ovgpu_set_state and ovgpu_set_landmarks.
 static int build_columns(ovgpu_ctx *c) {
   std::vector<ovgpu_ctx::HVar> vars = c->h_vars;
-  for (int l = 0; l < c->L; l++) vars.push_back({c->h_lm_cov[l], 3, COL_LANDMARK, l});
+  const int lmsz = c->lm_rep == OVGPU_REP_ANCHORED_INVERSE_DEPTH_SINGLE ? 1 : 3;
+  for (int l = 0; l < c->L; l++) vars.push_back({c->h_lm_cov[l], lmsz, COL_LANDMARK, l});
   std::stable_sort(vars.begin(), vars.end(), [](const ovgpu_ctx::HVar &a, const ovgpu_ctx::HVar &b) { return a.cov < b.cov; });
   const int C = c->C, K = c->K, N = c->N;
   std::vector<int32_t> clone_col(C, -1), calib_col(K, -1), intr_col(K, -1), col_cov;
@@ -391,7 +395,7 @@ static int build_columns(ovgpu_ctx *c) {
       col_cov.push_back(v.cov + i);
       col_kind.push_back((uint8_t)v.kind);
       col_var.push_back((uint16_t)v.index);
-      col_sub.push_back((uint8_t)i);
+      col_sub.push_back((uint8_t)((v.kind == COL_LANDMARK && lmsz == 1) ? 2 : i)); // the depth is column 2 of H_f
     }
     D += v.size;
   }
@@ -556,7 +560,8 @@ static int set_row_layout(ovgpu_ctx *c, bool slam_rows) {
   std::vector<int64_t> row_off(F + 1, 0);
   for (int f = 0; f < F; f++) {
     const int m = c->h_offsets[f + 1] - c->h_offsets[f];
-    row_off[f + 1] = row_off[f] + (slam_rows ? (m >= 1 ? 2 * m : 0) : (m >= 2 ? 2 * m - 3 : 0));
+    const int proj = (c->lm_rep == OVGPU_REP_ANCHORED_INVERSE_DEPTH_SINGLE) ? 2 : 0; // the bearing of a single-depth landmark is projected out (UpdaterSLAM.cpp:371-379)
+    row_off[f + 1] = row_off[f] + (slam_rows ? (2 * m > proj ? 2 * m - proj : 0) : (m >= 2 ? 2 * m - 3 : 0));
   }
   c->rows_total = row_off[F];
   c->h_row_off = row_off;
@@ -692,13 +697,18 @@ static int enqueue_system(ovgpu_ctx *c, int f_one = -1, int init_rep = 0) {
   p.dbg = qr_dbg_buffer();
   p.slam = c->slam_rows ? 1 : 0;
   p.p_fej = c->pFej.p, p.feat_lm = c->feat_lm.p, p.feat_lmcol = c->feat_lmcol.p, p.feat_lmcov = c->feat_lmcov.p, p.feat_anchor = c->feat_anchor.p;
-  if (p.slam) p.opt.feat_rep = c->lm_rep; // the landmarks' representation, not the MSCKF features'
+  p.lm_size = 3, p.init_dof_less = 0;
+  if (p.slam) { // the landmarks' representation, not the MSCKF features'; single depth = MSCKF inverse depth Jacobians (UpdaterSLAM.cpp:338-341)
+    p.lm_size = lm_dof(c->lm_rep);
+    p.opt.feat_rep = p.lm_size == 1 ? OVGPU_REP_ANCHORED_MSCKF_INVERSE_DEPTH : c->lm_rep;
+  }
   p.f_begin = 0, p.f_end = c->F, p.init = 0, p.init_out = nullptr, p.init_flag = nullptr, p.order = c->sys_order.p;
   int grid = c->sys_grid;
   if (f_one >= 0) {
     p.order = nullptr;
     p.f_begin = f_one, p.f_end = f_one + 1, p.init = 1, p.init_out = c->init_ws.p, p.init_flag = c->init_ctr.p + 2;
-    p.opt.feat_rep = init_rep;
+    p.opt.feat_rep = init_rep == OVGPU_REP_ANCHORED_INVERSE_DEPTH_SINGLE ? OVGPU_REP_ANCHORED_MSCKF_INVERSE_DEPTH : init_rep; // UpdaterSLAM.cpp:151-155
+    p.init_dof_less = init_rep == OVGPU_REP_ANCHORED_INVERSE_DEPTH_SINGLE ? 2 : 0;
     grid = 1;
   }
   hipLaunchKernelGGL(k_system, dim3(grid), dim3(SYS_NT), c->sys_lds_bytes, c->stream, p);
@@ -940,7 +950,7 @@ static int read_feature_outputs(ovgpu_ctx *c, int32_t *feat_status, double *chi2
   for (int f = 0; f < F; f++) {
     if (st[f] == OVGPU_FEAT_USED) {
       n_used++;
-      rows += 2 * (offs[f + 1] - offs[f]) - (c->slam_rows ? 0 : 3); // SLAM stacks all 2m rows (no nullspace projection)
+      rows += 2 * (offs[f + 1] - offs[f]) - (c->slam_rows ? 3 - lm_dof(c->lm_rep) : 3); // SLAM stacks all 2m rows (2m - 2 for a single-depth landmark)
     }
     // the gate is only reached by features that triangulated
     if (st[f] != OVGPU_FEAT_USED && st[f] != OVGPU_FEAT_CHI2_REJECTED) {
@@ -1121,8 +1131,8 @@ int ovgpu_set_landmarks(ovgpu_ctx *c, const ovgpu_landmarks_view *lm) {
   if (!c->have_state || c->poses_only) return set_err(OVGPU_ERR_NO_STATE, "ovgpu_set_state must precede ovgpu_set_landmarks");
   if (lm->L < 0 || lm->L > 4096) return set_err(OVGPU_ERR_INVALID, "bad landmark count");
   if (lm->L > 0 && (!lm->p_value || !lm->p_fej || !lm->cov_id)) return set_err(OVGPU_ERR_INVALID, "null landmark arrays");
-  if (lm->feat_rep < OVGPU_REP_GLOBAL_3D || lm->feat_rep > OVGPU_REP_ANCHORED_MSCKF_INVERSE_DEPTH)
-    return set_err(OVGPU_ERR_INVALID, "SLAM landmarks: 3-dof representations only (ANCHORED_INVERSE_DEPTH_SINGLE is not supported)");
+  if (lm->feat_rep < OVGPU_REP_GLOBAL_3D || lm->feat_rep > OVGPU_REP_ANCHORED_INVERSE_DEPTH_SINGLE)
+    return set_err(OVGPU_ERR_INVALID, "unknown landmark representation");
   const bool relative = lm->feat_rep >= OVGPU_REP_ANCHORED_3D;
   if (relative && lm->L > 0 && (!lm->anchor_cam || !lm->anchor_clone)) return set_err(OVGPU_ERR_INVALID, "anchored landmarks need anchor_cam / anchor_clone");
   std::vector<int32_t> anc(std::max(lm->L, 1), -1);
@@ -1192,7 +1202,7 @@ static int slam_prepare(ovgpu_ctx *c, const int32_t *lm_index, ovgpu_update_stat
   if (F > 0) {
     HIPCHK(upload(c->lm_index.p, lm_index, sizeof(int32_t) * F, s));
     HIPCHK(hipStreamSynchronize(s));
-    hipLaunchKernelGGL(k_slam_gather, dim3((F + 255) / 256), dim3(256), 0, s, F, c->lm_rep, c->lm_index.p, c->meas_offsets.p, landmark_store(c), c->pG.p,
+    hipLaunchKernelGGL(k_slam_gather, dim3((F + 255) / 256), dim3(256), 0, s, F, c->lm_rep, lm_dof(c->lm_rep) == 1 ? 2 : 1, c->lm_index.p, c->meas_offsets.p, landmark_store(c), c->pG.p,
                        c->pA.p, c->pFej.p, c->feat_lm.p, c->feat_lmcol.p, c->feat_lmcov.p, c->feat_anchor.p, c->given_status.p);
     HIPCHK(hipGetLastError());
   }
@@ -1207,8 +1217,8 @@ int ovgpu_slam_update(ovgpu_ctx *c, const int32_t *lm_index, int32_t *feat_statu
   hipStream_t s = c->stream;
   rc = enqueue_pipeline(c, STAGE_LOCAL | STAGE_EKF, true);
   if (rc != OVGPU_OK) return rc;
-  hipLaunchKernelGGL(k_landmark_update, dim3((3 * c->L + 255) / 256), dim3(256), 0, s, c->L, (const int32_t *)nullptr, c->dx.p, c->lm_cov.p, c->lm_val.p,
-                     (const int32_t *)nullptr);
+  hipLaunchKernelGGL(k_landmark_update, dim3((3 * c->L + 255) / 256), dim3(256), 0, s, c->L, (const int32_t *)nullptr, lm_dof(c->lm_rep), c->dx.p,
+                     c->lm_cov.p, c->lm_val.p, (const int32_t *)nullptr);
   HIPCHK(hipGetLastError());
   rc = read_feature_outputs(c, feat_status, chi2, chi2_thresh, nullptr, stats);
   if (rc != OVGPU_OK) return rc;
@@ -1235,12 +1245,13 @@ int ovgpu_slam_delayed_init(ovgpu_ctx *c, int32_t feat_rep, int32_t *feat_status
   if (!c) return set_err(OVGPU_ERR_INVALID, "null ctx");
   if (!c->have_state || c->poses_only) return set_err(OVGPU_ERR_NO_STATE, "ovgpu_set_state was never called");
   if (!c->have_feats) return set_err(OVGPU_ERR_NO_STATE, "ovgpu_set_features was never called (or the state changed since)");
-  if (feat_rep < OVGPU_REP_GLOBAL_3D || feat_rep > OVGPU_REP_ANCHORED_MSCKF_INVERSE_DEPTH)
-    return set_err(OVGPU_ERR_INVALID, "delayed initialisation: 3-dof representations only (ANCHORED_INVERSE_DEPTH_SINGLE is not supported)");
+  if (feat_rep < OVGPU_REP_GLOBAL_3D || feat_rep > OVGPU_REP_ANCHORED_INVERSE_DEPTH_SINGLE)
+    return set_err(OVGPU_ERR_INVALID, "unknown landmark representation");
   if (c->L > 0 && c->lm_rep != feat_rep) return set_err(OVGPU_ERR_INVALID, "the resident landmarks use another representation");
   HIPCHK(hipSetDevice(c->device));
   if (stats) std::memset(stats, 0, sizeof(*stats));
-  const int F = c->F, N0 = c->N, L0 = c->L, Nmax = N0 + 3 * F;
+  const int lsz = lm_dof(feat_rep);
+  const int F = c->F, N0 = c->N, L0 = c->L, Nmax = N0 + lsz * F;
   hipStream_t s = c->stream;
   // the per-feature kernel needs the anchor blocks in its row store for an anchored representation
   const int want_stride = (feat_rep >= OVGPU_REP_ANCHORED_3D || c->dopt.feat_rep >= OVGPU_REP_ANCHORED_3D || c->lm_rep >= OVGPU_REP_ANCHORED_3D) ? 72 : 48;
@@ -1290,7 +1301,7 @@ int ovgpu_slam_delayed_init(ovgpu_ctx *c, int32_t feat_rep, int32_t *feat_status
     if (m < 2) continue; // :91-93, flagged OVGPU_FEAT_TOO_FEW_MEAS by the triangulation
     if ((rc = enqueue_system(c, f, feat_rep)) != OVGPU_OK) break;
     InitParams ip;
-    ip.N = Nmax, ip.D = c->D, ip.LD = c->LD, ip.rep = feat_rep, ip.f = f, ip.col_cov = c->col_cov.p, ip.init_out = c->init_ws.p, ip.P = c->P.p;
+    ip.N = Nmax, ip.D = c->D, ip.LD = c->LD, ip.rep = feat_rep, ip.f = f, ip.sz = lsz, ip.col_cov = c->col_cov.p, ip.init_out = c->init_ws.p, ip.P = c->P.p;
     ip.sigma2 = c->dopt.sigma_pix_sq, ip.ctr = c->init_ctr.p, ip.p_FinG = c->pG.p, ip.p_FinA = c->pA.p, ip.meas_cc = c->meas_cc.p;
     ip.anchor_meas = c->anchor.p, ip.lm = landmark_store(c), ip.feat_slot = c->feat_slot.p;
     hipLaunchKernelGGL(k_init_invertible, dim3(1), dim3(256), init_lds, s, ip);
@@ -1299,8 +1310,8 @@ int ovgpu_slam_delayed_init(ovgpu_ctx *c, int32_t feat_rep, int32_t *feat_status
     job.R = c->Hbig.p + (size_t)c->h_row_off[f] * c->LD, job.rows = 2 * m - 3, job.pred = c->init_ctr.p + 2, job.dx = c->dx_seq.p + (size_t)f * Nmax;
     job.keep_flags = true;
     if ((rc = enqueue_ekf(c, job)) != OVGPU_OK) break; // StateHelper.cpp:476-478
-    hipLaunchKernelGGL(k_landmark_update, dim3((3 * (L0 + F) + 255) / 256), dim3(256), 0, s, 0, (const int32_t *)(c->init_ctr.p + 1), job.dx, c->lm_cov.p,
-                       c->lm_val.p, job.pred);
+    hipLaunchKernelGGL(k_landmark_update, dim3((3 * (L0 + F) + 255) / 256), dim3(256), 0, s, 0, (const int32_t *)(c->init_ctr.p + 1), lsz, job.dx,
+                       c->lm_cov.p, c->lm_val.p, job.pred);
     HIPCHK(hipGetLastError());
   }
   // ---- results
@@ -1413,7 +1424,8 @@ static int rebuild_variables(ovgpu_ctx *c) {
 static int enqueue_anchor_change(ovgpu_ctx *c, int l, int new_cam, int new_clone) {
   const int32_t old = c->h_lm_anchor[l];
   const int old_cam = old >> 10;
-  int n_old = 6 + 6 + 3;
+  const int lsz = lm_dof(c->lm_rep);
+  int n_old = 6 + 6 + lsz;
   if (c->h_calib_cov[old_cam] >= 0) n_old += 6;
   if (c->h_calib_cov[new_cam] >= 0 && new_cam != old_cam) n_old += 6;
   hipStream_t s = c->stream;
@@ -1424,13 +1436,13 @@ static int enqueue_anchor_change(ovgpu_ctx *c, int l, int new_cam, int new_clone
   double *dPhi = c->prop_in.p, *dQ = dPhi + 3 * 27, *W = c->prop_w.p, *PCP = W + (size_t)N * 3;
   HIPCHK(hipMemsetAsync(dQ, 0, 9 * sizeof(double), s));
   AnchorParams ap;
-  ap.rep = c->lm_rep, ap.do_fej = c->dopt.do_fej, ap.l = l, ap.new_cam = new_cam, ap.new_clone = new_clone;
+  ap.rep = c->lm_rep, ap.do_fej = c->dopt.do_fej, ap.l = l, ap.new_cam = new_cam, ap.new_clone = new_clone, ap.sz = lsz;
   ap.tab_clone = c->tab_clone.p, ap.tab_cam = c->tab_cam.p, ap.clone_cov = c->clone_cov.p, ap.calib_cov = c->calib_cov.p;
   ap.lm = landmark_store(c), ap.phi = dPhi, ap.ids = c->prop_ids.p, ap.n_old = c->prop_ids.p + 27;
   hipLaunchKernelGGL(k_anchor_change, dim3(1), dim3(64), 0, s, ap);
   for (int pass = 0; pass < 3; pass++) {
-    const int n = pass == 1 ? 9 : N * 3;
-    hipLaunchKernelGGL(k_cov_propagate, dim3((n + 255) / 256), dim3(256), 0, s, N, (int)c->h_lm_cov[l], 3, n_old, c->prop_ids.p, dPhi, dQ, c->P.p, W, PCP,
+    const int n = pass == 1 ? lsz * lsz : N * lsz;
+    hipLaunchKernelGGL(k_cov_propagate, dim3((n + 255) / 256), dim3(256), 0, s, N, (int)c->h_lm_cov[l], lsz, n_old, c->prop_ids.p, dPhi, dQ, c->P.p, W, PCP,
                        c->flags.p, pass);
   }
   HIPCHK(hipGetLastError());
@@ -1499,8 +1511,8 @@ int ovgpu_state_marginalize(ovgpu_ctx *c, int32_t cov_id, int32_t size) {
       drop_clone = i;
     }
   for (int l = 0; l < c->L; l++)
-    if (hit(c->h_lm_cov[l], 3)) {
-      if (c->h_lm_cov[l] != cov_id || size != 3) return set_err(OVGPU_ERR_INVALID, "block cuts through a landmark");
+    if (hit(c->h_lm_cov[l], lm_dof(c->lm_rep))) {
+      if (c->h_lm_cov[l] != cov_id || size != lm_dof(c->lm_rep)) return set_err(OVGPU_ERR_INVALID, "block cuts through a landmark");
       drop_lm = l;
     }
   int drop_calib = -1, drop_intr = -1;

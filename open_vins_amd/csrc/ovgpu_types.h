@@ -65,6 +65,8 @@ struct SysParams {
   long long *dbg;           // profiling builds only (-DSYS_PROFILE)
   // UpdaterSLAM::update mode (landmarks live in the state): no nullspace projection, gate on all 2m rows
   int slam;
+  int lm_size;              // 3, or 1 for ANCHORED_INVERSE_DEPTH_SINGLE landmarks (the bearing columns of H_f are projected out)
+  int init_dof_less;        // init mode: 0, or 2 for a single-depth landmark (StateHelper::initialize sees 2m - 2 residual rows)
   const double *p_fej;      // [3F] first-estimate position of the feature's landmark
   const int32_t *feat_lm;   // [F] landmark index, first Jacobian column and covariance id of its 3 dof
   const int32_t *feat_lmcol;

@@ -9,8 +9,7 @@
 //
 // Without that patch keep the reference's delayed_init: it keeps working on the GPU triangulation through the
 // FeatureInitializer shim (FeatureInitializer.cpp), with the StateHelper::initialize chain on the CPU.
-// Not covered here (falls to the reference code): ArUco features (own options / representation, :166-168, :227-232) and
-// the 1-dof ANCHORED_INVERSE_DEPTH_SINGLE representation.
+// Not covered here (falls to the reference code): ArUco features (own options / representation, :166-168, :227-232).
 #include "UpdaterSLAM.h"
 
 #include "feat/Feature.h"
@@ -40,8 +39,8 @@ std::unique_ptr<ovgpu_shim::Context> g_init_ctx;
 void UpdaterSLAM::delayed_init(std::shared_ptr<State> state, std::vector<std::shared_ptr<Feature>> &feature_vec) {
   if (feature_vec.empty()) return; // :64-65
   const auto rep = state->_options.feat_rep_slam;
-  if (rep == LandmarkRepresentation::Representation::ANCHORED_INVERSE_DEPTH_SINGLE)
-    throw std::runtime_error("ovgpu delayed_init shim: ANCHORED_INVERSE_DEPTH_SINGLE is not supported on the GPU path");
+  const bool single = rep == LandmarkRepresentation::Representation::ANCHORED_INVERSE_DEPTH_SINGLE;
+  const int lsz = single ? 1 : 3; // landmark_size, :199
 
   // ---- state snapshot (same flattening as the other shims)
   ovgpu_shim::FlatState fs;
@@ -81,7 +80,13 @@ void UpdaterSLAM::delayed_init(std::shared_ptr<State> state, std::vector<std::sh
   for (const auto &kv : state->_features_SLAM) {
     const auto &lm = kv.second;
     if (lm->_feat_representation != rep) continue; // e.g. ArUco tags in another representation: corrected below through dx_seq
-    const Eigen::Vector3d v = lm->value(), vf = lm->fej();
+    Eigen::Vector3d v, vf;
+    if (single) {
+      v << lm->uv_norm_zero(0), lm->uv_norm_zero(1), lm->value()(0);
+      vf << lm->uv_norm_zero_fej(0), lm->uv_norm_zero_fej(1), lm->fej()(0);
+    } else {
+      v = lm->value(), vf = lm->fej();
+    }
     lm_value.insert(lm_value.end(), v.data(), v.data() + 3), lm_fej.insert(lm_fej.end(), vf.data(), vf.data() + 3);
     lm_cov.push_back(lm->id());
     lm_acam.push_back(relative ? cam_index.at(lm->_anchor_cam_id) : -1);
@@ -134,7 +139,7 @@ void UpdaterSLAM::delayed_init(std::shared_ptr<State> state, std::vector<std::sh
   g_init_ctx->check(ovgpu_set_state(ctx, &sv), "ovgpu_set_state");
   g_init_ctx->check(ovgpu_set_landmarks(ctx, &lv), "ovgpu_set_landmarks");
   g_init_ctx->check(ovgpu_set_features(ctx, &fv), "ovgpu_set_features");
-  const int F = fv.F, Nmax = N0 + 3 * F;
+  const int F = fv.F, Nmax = N0 + lsz * F;
   std::vector<int32_t> status(F), new_cov(F), acam(F), aclone(F);
   std::vector<double> new_val(3 * (size_t)F), new_fej(3 * (size_t)F), dx_seq((size_t)F * Nmax), Pout((size_t)Nmax * Nmax);
   int32_t N1 = 0;
@@ -178,7 +183,10 @@ void UpdaterSLAM::delayed_init(std::shared_ptr<State> state, std::vector<std::sh
     g_init_ctx->check(ovgpu_get_landmarks(ctx, &L1, nullptr, nullptr, nullptr, nullptr, nullptr), "ovgpu_get_landmarks");
     std::vector<double> lv1(3 * (size_t)L1);
     g_init_ctx->check(ovgpu_get_landmarks(ctx, &L1, lv1.data(), nullptr, nullptr, nullptr, nullptr), "ovgpu_get_landmarks");
-    for (size_t l = 0; l < old_lm.size(); l++) old_lm[l]->set_value(Eigen::Map<const Eigen::Vector3d>(lv1.data() + 3 * l));
+    for (size_t l = 0; l < old_lm.size(); l++) {
+      if (single) old_lm[l]->set_value(Eigen::Matrix<double, 1, 1>(lv1[3 * l + 2]));
+      else old_lm[l]->set_value(Eigen::Map<const Eigen::Vector3d>(lv1.data() + 3 * l));
+    }
   }
   // (c) covariance (StateHelper.cpp:552-558 grew it by 3 per accepted feature)
   ovgpu_shim::StateAccess::cov(*state) = Eigen::Map<const Eigen::Matrix<double, Eigen::Dynamic, Eigen::Dynamic, Eigen::RowMajor>>(Pout.data(), N1, N1);
@@ -192,7 +200,7 @@ void UpdaterSLAM::delayed_init(std::shared_ptr<State> state, std::vector<std::sh
       f++;
       continue;
     }
-    auto landmark = std::make_shared<Landmark>(3);
+    auto landmark = std::make_shared<Landmark>(lsz);
     landmark->_featid = (*it2)->featid;
     landmark->_feat_representation = rep;
     if (relative) {
@@ -200,8 +208,15 @@ void UpdaterSLAM::delayed_init(std::shared_ptr<State> state, std::vector<std::sh
       landmark->_anchor_clone_timestamp = fs.clone_times[aclone[f]];
     }
     landmark->_unique_camera_id = relative ? landmark->_anchor_cam_id : (*it2)->anchor_cam_id;
-    landmark->set_value(Eigen::Map<const Eigen::Vector3d>(new_val.data() + 3 * f));
-    landmark->set_fej(Eigen::Map<const Eigen::Vector3d>(new_fej.data() + 3 * f));
+    if (single) { // bearing + inverse depth (Landmark::set_from_xyz, Landmark.cpp:124-140)
+      landmark->uv_norm_zero << new_val[3 * f], new_val[3 * f + 1], 1.0;
+      landmark->uv_norm_zero_fej << new_fej[3 * f], new_fej[3 * f + 1], 1.0;
+      landmark->set_value(Eigen::Matrix<double, 1, 1>(new_val[3 * f + 2]));
+      landmark->set_fej(Eigen::Matrix<double, 1, 1>(new_fej[3 * f + 2]));
+    } else {
+      landmark->set_value(Eigen::Map<const Eigen::Vector3d>(new_val.data() + 3 * f));
+      landmark->set_fej(Eigen::Map<const Eigen::Vector3d>(new_fej.data() + 3 * f));
+    }
     landmark->set_local_id(new_cov[f]); // StateHelper.cpp:572-573
     ovgpu_shim::StateAccess::variables(*state).push_back(landmark);
     state->_features_SLAM.insert({(*it2)->featid, landmark});

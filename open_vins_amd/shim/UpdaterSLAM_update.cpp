@@ -2,9 +2,8 @@
 // rpng/open_vins v2.7).  Delete that definition from UpdaterSLAM.cpp and compile this file next to it (the class
 // declaration, the constructor, delayed_init, change_anchors and perform_anchor_change stay the reference's).
 // Mode A, like the MSCKF shim: the GPU builds, gates, stacks and compresses the system, the stock
-// StateHelper::EKFUpdate applies it.  Landmark representations: the five 3-dof ones (GLOBAL_3D ... ANCHORED_MSCKF_INVERSE_DEPTH,
-// LandmarkRepresentation.h:38-46), all landmarks of a call in the same one (StateOptions::feat_rep_slam); the 1-dof
-// ANCHORED_INVERSE_DEPTH_SINGLE and ArUco tags with their own options stay on the reference's CPU path.
+// StateHelper::EKFUpdate applies it.  Landmark representations: all six (LandmarkRepresentation.h:38-46), every landmark of a
+// call in the same one (StateOptions::feat_rep_slam); ArUco tags with their own options stay on the reference's CPU path.
 #include "UpdaterSLAM.h"
 
 #include "feat/Feature.h"
@@ -62,8 +61,7 @@ void UpdaterSLAM::update(std::shared_ptr<State> state, std::vector<std::shared_p
   std::vector<double> lm_value, lm_fej;
   std::vector<int32_t> lm_cov, lm_index, lm_anchor_cam, lm_anchor_clone;
   const auto rep = state->_options.feat_rep_slam;
-  if (rep == LandmarkRepresentation::Representation::ANCHORED_INVERSE_DEPTH_SINGLE)
-    throw std::runtime_error("ovgpu SLAM shim: ANCHORED_INVERSE_DEPTH_SINGLE is not supported on the GPU path");
+  const bool single = rep == LandmarkRepresentation::Representation::ANCHORED_INVERSE_DEPTH_SINGLE;
   auto it0 = feature_vec.begin();
   while (it0 != feature_vec.end()) {
     (*it0)->clean_old_measurements(fs.clone_times);
@@ -85,7 +83,13 @@ void UpdaterSLAM::update(std::shared_ptr<State> state, std::vector<std::shared_p
     }
     ff.end_feature();
     // the library holds Landmark::value() / fej() — representation coordinates — and applies get_xyz itself (:345-353)
-    const Eigen::Vector3d v = landmark->value(), vf = landmark->fej();
+    Eigen::Vector3d v, vf;
+    if (single) { // 1-dof landmark: constant bearing + inverse depth (Landmark.cpp:57-60, :124-140)
+      v << landmark->uv_norm_zero(0), landmark->uv_norm_zero(1), landmark->value()(0);
+      vf << landmark->uv_norm_zero_fej(0), landmark->uv_norm_zero_fej(1), landmark->fej()(0);
+    } else {
+      v = landmark->value(), vf = landmark->fej();
+    }
     const bool relative = LandmarkRepresentation::is_relative_representation(rep);
     lm_anchor_cam.push_back(relative ? cam_index.at(landmark->_anchor_cam_id) : -1);
     lm_anchor_clone.push_back(relative ? clones.find(landmark->_anchor_clone_timestamp) : -1);
@@ -115,7 +119,7 @@ void UpdaterSLAM::update(std::shared_ptr<State> state, std::vector<std::shared_p
   g_slam_ctx->check(ovgpu_set_state(g_slam_ctx->get(), &sv), "ovgpu_set_state");
   g_slam_ctx->check(ovgpu_set_landmarks(g_slam_ctx->get(), &lv), "ovgpu_set_landmarks");
   g_slam_ctx->check(ovgpu_set_features(g_slam_ctx->get(), &fv), "ovgpu_set_features");
-  const int F = fv.F, Dmax = 6 * sv.C + 14 * sv.K + 3 * lv.L;
+  const int F = fv.F, Dmax = 6 * sv.C + 14 * sv.K + 3 * lv.L; // upper bound (a single-depth landmark has one column)
   std::vector<int32_t> status(F), col_cov(Dmax);
   std::vector<double> H((size_t)Dmax * Dmax), r(Dmax);
   int32_t D = 0, rows = 0;

@@ -449,7 +449,7 @@ def landmark_from_xyz(rep, p):
     if rep in (1, 3):  # GLOBAL_ / ANCHORED_FULL_INVERSE_DEPTH: (theta, phi, rho)
         rho = 1.0 / np.linalg.norm(p, axis=-1)
         return np.stack([np.arctan2(p[..., 1], p[..., 0]), np.arccos(rho * p[..., 2]), rho], axis=-1)
-    if rep == 4:  # ANCHORED_MSCKF_INVERSE_DEPTH: (alpha, beta, rho)
+    if rep in (4, 5):  # ANCHORED_MSCKF_INVERSE_DEPTH: (alpha, beta, rho); ANCHORED_INVERSE_DEPTH_SINGLE: (bearing x, y, rho), rho the state
         return np.stack([p[..., 0] / p[..., 2], p[..., 1] / p[..., 2], 1.0 / p[..., 2]], axis=-1)
     return p.copy()
 
@@ -459,7 +459,7 @@ def landmark_to_xyz(rep, v):
     v = np.asarray(v, dtype=np.float64)
     if rep in (1, 3):
         return np.stack([np.cos(v[..., 0]) * np.sin(v[..., 1]), np.sin(v[..., 0]) * np.sin(v[..., 1]), np.cos(v[..., 1])], axis=-1) / v[..., 2:3]
-    if rep == 4:
+    if rep in (4, 5):
         return np.stack([v[..., 0], v[..., 1], np.ones_like(v[..., 0])], axis=-1) / v[..., 2:3]
     return v.copy()
 
@@ -473,7 +473,8 @@ def make_slam_problem(cfg=2, L=20, *, lm_rep=0, lm_noise=0.05, seed=None, **kw) 
     prob = make_problem(cfg, F=L, seed=seed, **kw)
     rng = np.random.default_rng([prob.seed, 7])
     N0 = prob.N
-    N = N0 + 3 * L
+    sz = 1 if lm_rep == 5 else 3  # state dof of a landmark
+    N = N0 + sz * L
     xyz = prob.p_FinG_true + rng.normal(0, lm_noise, (L, 3))
     xyz_fej = xyz + rng.normal(0, lm_noise / 5, (L, 3))
     prob.lm_rep = int(lm_rep)
@@ -493,12 +494,14 @@ def make_slam_problem(cfg=2, L=20, *, lm_rep=0, lm_noise=0.05, seed=None, **kw) 
         xyz, xyz_fej = to_anchor(xyz), to_anchor(xyz_fej)
     prob.lm_value = np.ascontiguousarray(landmark_from_xyz(lm_rep, xyz))
     prob.lm_fej = np.ascontiguousarray(landmark_from_xyz(lm_rep, xyz_fej))
-    prob.lm_cov_id = (N0 + 3 * np.arange(L)).astype(np.int32)
+    prob.lm_cov_id = (N0 + sz * np.arange(L)).astype(np.int32)
     prob.lm_index = np.arange(L, dtype=np.int32)
     lm_sig = np.full((L, 3), 2 * lm_noise)
-    if lm_rep in (1, 3, 4):  # angles / normalised coordinates and an inverse depth: scale the sigma to the coordinates
+    if lm_rep in (1, 3, 4, 5):  # angles / normalised coordinates and an inverse depth: scale the sigma to the coordinates
         depth = np.linalg.norm(xyz, axis=1)
         lm_sig = np.stack([2 * lm_noise / depth, 2 * lm_noise / depth, 2 * lm_noise / depth ** 2], axis=1)
+    if sz == 1:
+        lm_sig = lm_sig[:, 2:3]  # only the inverse depth is a state variable
     sig = np.concatenate([state_sigmas(prob.C, prob.K), lm_sig.reshape(-1)])
     G = np.tril(rng.normal(0, 1.0 / np.sqrt(N), (N, N)), -1)
     Lc = sig[:, None] * (np.eye(N) + 0.1 * G)

@@ -195,7 +195,7 @@ class UpdaterMSCKF:
         """Runs the delayed initialisation on the resident state and tracks (set_problem / set_slam_problem first;
         set_triangulation optionally replaces the triangulation stage).  The state grows by 3 per accepted feature."""
         F, N = self.F, self.N
-        Nmax = N + 3 * F
+        Nmax = N + (1 if int(feat_rep) == capi.REP_ANCHORED_INVERSE_DEPTH_SINGLE else 3) * F
         out = dict(feat_status=np.zeros(F, np.int32), chi2=np.zeros(F), chi2_thresh=np.zeros(F), lm_cov_id=np.zeros(F, np.int32),
                    lm_value=np.zeros((F, 3)), lm_fej=np.zeros((F, 3)), anchor_cam=np.zeros(F, np.int32), anchor_clone=np.zeros(F, np.int32),
                    dx_seq=np.zeros((F, Nmax)))

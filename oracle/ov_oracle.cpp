@@ -1209,7 +1209,9 @@ double now_s() {
 V3 landmark_get_xyz(int rep, const double *v) {
   if (rep == OVGPU_REP_GLOBAL_FULL_INVERSE_DEPTH || rep == OVGPU_REP_ANCHORED_FULL_INVERSE_DEPTH)
     return V3{{(1 / v[2]) * std::cos(v[0]) * std::sin(v[1]), (1 / v[2]) * std::sin(v[0]) * std::sin(v[1]), (1 / v[2]) * std::cos(v[1])}};
-  if (rep == OVGPU_REP_ANCHORED_MSCKF_INVERSE_DEPTH) return V3{{(1 / v[2]) * v[0], (1 / v[2]) * v[1], 1 / v[2]}};
+  // ANCHORED_INVERSE_DEPTH_SINGLE is passed as (uv_norm_zero.x, uv_norm_zero.y, rho): 1 / rho * uv_norm_zero (:57-60)
+  if (rep == OVGPU_REP_ANCHORED_MSCKF_INVERSE_DEPTH || rep == OVGPU_REP_ANCHORED_INVERSE_DEPTH_SINGLE)
+    return V3{{(1 / v[2]) * v[0], (1 / v[2]) * v[1], 1 / v[2]}};
   return V3{{v[0], v[1], v[2]}};
 }
 
@@ -1222,7 +1224,7 @@ void landmark_set_from_xyz(int rep, const V3 &p, double *v) {
     v[0] = g_theta, v[1] = g_phi, v[2] = g_rho;
     return;
   }
-  if (rep == OVGPU_REP_ANCHORED_MSCKF_INVERSE_DEPTH) {
+  if (rep == OVGPU_REP_ANCHORED_MSCKF_INVERSE_DEPTH || rep == OVGPU_REP_ANCHORED_INVERSE_DEPTH_SINGLE) { // :124-140: rho and the bearing
     v[0] = p[0] / p[2], v[1] = p[1] / p[2], v[2] = 1 / p[2];
     return;
   }
@@ -1553,7 +1555,7 @@ int oracle_slam_update(const ovgpu_options *opts, const ovgpu_state_view *st, co
   {
     int col = 0;
     for (const VarRef &v : cm.vars) ents.push_back({v.cov_id, v.size, (int)(&v - &cm.vars[0]), -1}), col += v.size;
-    for (int l = 0; l < L; l++) ents.push_back({lm->cov_id[l], 3, -1, l});
+    for (int l = 0; l < L; l++) ents.push_back({lm->cov_id[l], lm->feat_rep == OVGPU_REP_ANCHORED_INVERSE_DEPTH_SINGLE ? 1 : 3, -1, l});
     std::stable_sort(ents.begin(), ents.end(), [](const Ent &a, const Ent &b) { return a.cov < b.cov; });
   }
   std::vector<int> base_col(cm.vars.size(), -1), lm_col(L, -1);
@@ -1595,7 +1597,12 @@ int oracle_slam_update(const ovgpu_options *opts, const ovgpu_state_view *st, co
       continue;
     }
     const int l = lm_index[f];
-    const int lrep = lm->feat_rep;
+    const bool single = lm->feat_rep == OVGPU_REP_ANCHORED_INVERSE_DEPTH_SINGLE;
+    if (single && m < 2) { // one measurement leaves no row once the bearing is projected out
+      status[f] = OVGPU_FEAT_TOO_FEW_MEAS;
+      continue;
+    }
+    const int lrep = single ? OVGPU_REP_ANCHORED_MSCKF_INVERSE_DEPTH : lm->feat_rep; // :338-341
     // :345-353: get_xyz of the landmark, in the anchor frame for an anchored representation
     V3 pG = landmark_get_xyz(lrep, lm->p_value + 3 * l);
     V3 pF = landmark_get_xyz(lrep, lm->p_fej + 3 * l);
@@ -1607,9 +1614,21 @@ int oracle_slam_update(const ovgpu_options *opts, const ovgpu_state_view *st, co
     res.assign(2 * m, 0.0);
     int nf = 3;
     feature_jacobian_full(o, st, T, fm, lrep, pG, pA, -1, lc, H_f.data(), nf, H_x.data(), res.data(), &pF, acam, aclone); // :369
-    for (int a = 0; a < 2 * m; a++) // :381-383  H_xf = [H_x | H_f], here the landmark columns of the big map
-      for (int b = 0; b < 3; b++) H_x[(size_t)a * Dt + lm_col[l] + b] = H_f[(size_t)a * 3 + b];
-    const int r = 2 * m;
+    int r = 2 * m;
+    if (single) { // :371-379: the depth column joins the state Jacobian, the bearing columns are projected out
+      std::vector<double> Hb((size_t)2 * m * 2);
+      for (int a = 0; a < 2 * m; a++) {
+        H_x[(size_t)a * Dt + lm_col[l]] = H_f[(size_t)a * 3 + 2];
+        Hb[(size_t)a * 2] = H_f[(size_t)a * 3], Hb[(size_t)a * 2 + 1] = H_f[(size_t)a * 3 + 1];
+      }
+      nullspace_project(Hb.data(), H_x.data(), res.data(), 2 * m, 2, Dt);
+      r = 2 * m - 2;
+      std::memmove(H_x.data(), H_x.data() + (size_t)2 * Dt, sizeof(double) * (size_t)r * Dt);
+      std::memmove(res.data(), res.data() + 2, sizeof(double) * r);
+    } else {
+      for (int a = 0; a < 2 * m; a++) // :381-383  H_xf = [H_x | H_f], here the landmark columns of the big map
+        for (int b = 0; b < 3; b++) H_x[(size_t)a * Dt + lm_col[l] + b] = H_f[(size_t)a * 3 + b];
+    }
     // chi2 :390-396
     HP.assign((size_t)r * Dt, 0.0);
     for (int a = 0; a < r; a++)
@@ -1658,7 +1677,10 @@ int oracle_slam_update(const ovgpu_options *opts, const ovgpu_state_view *st, co
   if (P_out) std::memcpy(P_out, P.data(), (size_t)N * N * sizeof(double));
   if (lm_out)
     for (int l = 0; l < L; l++)
-      for (int i = 0; i < 3; i++) lm_out[3 * l + i] = lm->p_value[3 * l + i] + dx[lm->cov_id[l] + i]; // Landmark::update, Landmark.h:80-89
+      for (int i = 0; i < 3; i++) { // Landmark::update, Landmark.h:80-89 (single depth: only rho is a state variable)
+        const bool sgl = lm->feat_rep == OVGPU_REP_ANCHORED_INVERSE_DEPTH_SINGLE;
+        lm_out[3 * l + i] = lm->p_value[3 * l + i] + (sgl ? (i == 2 ? dx[lm->cov_id[l]] : 0.0) : dx[lm->cov_id[l] + i]);
+      }
   if (D_out) *D_out = Dt;
   if (col_cov_out) std::memcpy(col_cov_out, col_cov.data(), Dt * sizeof(int32_t));
   if (H_out) std::memcpy(H_out, Hx_big.data(), ct_meas * (size_t)Dt * sizeof(double));
@@ -1686,7 +1708,7 @@ int oracle_slam_delayed_init(const ovgpu_options *opts, const ovgpu_state_view *
                              int32_t *anchor_clone_out, double *dx_seq, int32_t *N_out, double *P_out, double *clone_q_p_out,
                              double *calib_q_p_out, double *intrinsics_out, double *lm_existing_out) {
   const ovgpu_options &o = *opts;
-  const int F = fv->F, N0 = st_in->N, C = st_in->C, K = st_in->K, Nmax = N0 + 3 * F;
+  const int F = fv->F, N0 = st_in->N, C = st_in->C, K = st_in->K, Nmax = N0 + (feat_rep == OVGPU_REP_ANCHORED_INVERSE_DEPTH_SINGLE ? 1 : 3) * F;
   const int L0 = lm ? lm->L : 0;
   const double sigma2 = std::pow(o.sigma_pix, 2);
   // mutable copy of the state
@@ -1737,24 +1759,48 @@ int oracle_slam_delayed_init(const ovgpu_options *opts, const ovgpu_state_view *
   for (int f = 0; f < F; f++) {
     if (status[f] != OVGPU_FEAT_USED) continue;
     FeatMeas fm{fv->meas_offsets[f], fv->meas_offsets[f + 1], fv->uvn, fv->uv, fv->clone_idx, fv->cam_idx};
-    const int m = fm.m1 - fm.m0, n = 2 * m;
+    const int m = fm.m1 - fm.m0;
+    int n = 2 * m;
     StateTables T = build_tables(&st); // the CURRENT state estimate (FEJ values never change)
+    const bool single = feat_rep == OVGPU_REP_ANCHORED_INVERSE_DEPTH_SINGLE;
+    const int jrep = single ? OVGPU_REP_ANCHORED_MSCKF_INVERSE_DEPTH : feat_rep; // :151-155
+    const int nL = single ? 1 : 3;                                                // landmark_size :199
     H_f.assign((size_t)n * 3, 0.0), H_x.assign((size_t)n * D, 0.0), res.assign(n, 0.0);
     int nf = 3;
-    feature_jacobian_full(o, &st, T, fm, feat_rep, pG[f], pA[f], anchor[f], lc, H_f.data(), nf, H_x.data(), res.data()); // :165, fej == value (:155-162)
+    feature_jacobian_full(o, &st, T, fm, jrep, pG[f], pA[f], anchor[f], lc, H_f.data(), nf, H_x.data(), res.data()); // :165, fej == value (:155-162)
+    std::vector<double> H_L; // n x nL
+    if (single) {
+      // :181-196 — the depth column joins the state Jacobian, the bearing is projected out of [H_x | h_rho] and res
+      std::vector<double> Hb((size_t)n * 2), Hxf((size_t)n * (D + 1));
+      for (int a = 0; a < n; a++) {
+        std::memcpy(Hxf.data() + (size_t)a * (D + 1), H_x.data() + (size_t)a * D, sizeof(double) * D);
+        Hxf[(size_t)a * (D + 1) + D] = H_f[(size_t)a * 3 + 2];
+        Hb[(size_t)a * 2] = H_f[(size_t)a * 3], Hb[(size_t)a * 2 + 1] = H_f[(size_t)a * 3 + 1];
+      }
+      nullspace_project(Hb.data(), Hxf.data(), res.data(), n, 2, D + 1);
+      n -= 2;
+      H_L.resize(n);
+      for (int a = 0; a < n; a++) {
+        std::memcpy(H_x.data() + (size_t)a * D, Hxf.data() + (size_t)(a + 2) * (D + 1), sizeof(double) * D);
+        H_L[a] = Hxf[(size_t)(a + 2) * (D + 1) + D];
+        res[a] = res[a + 2];
+      }
+    } else {
+      H_L.assign(H_f.begin(), H_f.begin() + (size_t)n * 3);
+    }
     // StateHelper::initialize :429-443 — Givens on H_L, applied to H_R and res
-    for (int c2 = 0; c2 < 3; ++c2) {
+    for (int c2 = 0; c2 < nL; ++c2) {
       for (int r = n - 1; r > c2; r--) {
         double gc, gs;
-        make_givens(H_f[(size_t)(r - 1) * 3 + c2], H_f[(size_t)r * 3 + c2], gc, gs);
-        apply_givens_adj(H_f.data() + (size_t)(r - 1) * 3 + c2, H_f.data() + (size_t)r * 3 + c2, 3 - c2, gc, gs);
+        make_givens(H_L[(size_t)(r - 1) * nL + c2], H_L[(size_t)r * nL + c2], gc, gs);
+        apply_givens_adj(H_L.data() + (size_t)(r - 1) * nL + c2, H_L.data() + (size_t)r * nL + c2, nL - c2, gc, gs);
         apply_givens_adj(res.data() + (r - 1), res.data() + r, 1, gc, gs);
         apply_givens_adj(H_x.data() + (size_t)(r - 1) * D, H_x.data() + (size_t)r * D, D, gc, gs);
       }
     }
-    const double *Hxinit = H_x.data(), *resinit = res.data();          // :446-449 (first 3 rows)
-    const double *Hup = H_x.data() + (size_t)3 * D, *resup = res.data() + 3; // :452-454
-    const int rup = n - 3;
+    const double *Hxinit = H_x.data(), *resinit = res.data();                  // :446-449 (first nL rows)
+    const double *Hup = H_x.data() + (size_t)nL * D, *resup = res.data() + nL; // :452-454
+    const int rup = n - nL;
     // chi2 (:459-463) with the marginal covariance of the Jacobian's variables
     {
       std::vector<double> HP((size_t)rup * D, 0.0), S((size_t)rup * rup, 0.0);
@@ -1779,7 +1825,7 @@ int oracle_slam_delayed_init(const ovgpu_options *opts, const ovgpu_state_view *
         chi2 = 0;
         for (int a = 0; a < rup; a++) chi2 += resup[a] * y[a];
       }
-      const double chi2_check = chi2_quantile(n, 0.95); // :466-467: res.rows() = all 2m rows
+      const double chi2_check = chi2_quantile(n, 0.95); // :466-467: res.rows() as handed to initialize (2m, or 2m - 2 for the single depth)
       chi2v[f] = chi2, thrv[f] = o.chi2_multipler * chi2_check;
       if (chi2 > o.chi2_multipler * chi2_check) { // :468
         status[f] = OVGPU_FEAT_CHI2_REJECTED;
@@ -1788,59 +1834,66 @@ int oracle_slam_delayed_init(const ovgpu_options *opts, const ovgpu_state_view *
     }
     // initialize_invertible :512-573
     {
-      std::vector<double> M_a((size_t)N * 3, 0.0); // P(:, cols) Hxinit^T
+      std::vector<double> M_a((size_t)N * nL, 0.0); // P(:, cols) Hxinit^T
       for (int i = 0; i < N; i++)
-        for (int j = 0; j < 3; j++) {
+        for (int j = 0; j < nL; j++) {
           double sv = 0;
           for (int k = 0; k < D; k++) sv += P[(size_t)i * N + cm.col_cov[k]] * Hxinit[(size_t)j * D + k];
-          M_a[(size_t)i * 3 + j] = sv;
+          M_a[(size_t)i * nL + j] = sv;
         }
-      double Mm[9]; // H_R P_small H_R^T + R  (:541-543)
-      for (int a = 0; a < 3; a++)
-        for (int b = 0; b < 3; b++) {
+      std::vector<double> Mm((size_t)nL * nL); // H_R P_small H_R^T + R  (:541-543)
+      for (int a = 0; a < nL; a++)
+        for (int b = 0; b < nL; b++) {
           double sv = 0;
-          for (int k = 0; k < D; k++) sv += Hxinit[(size_t)a * D + k] * M_a[(size_t)cm.col_cov[k] * 3 + b];
-          Mm[3 * a + b] = sv + (a == b ? sigma2 : 0.0);
+          for (int k = 0; k < D; k++) sv += Hxinit[(size_t)a * D + k] * M_a[(size_t)cm.col_cov[k] * nL + b];
+          Mm[(size_t)nL * a + b] = sv + (a == b ? sigma2 : 0.0);
         }
-      // H_L^-1 of the upper-triangular 3x3 (:548)
-      const double u00 = H_f[0], u01 = H_f[1], u02 = H_f[2], u11 = H_f[4], u12 = H_f[5], u22 = H_f[8];
-      double inv[9] = {1 / u00, -u01 / (u00 * u11), (u01 * u12 - u02 * u11) / (u00 * u11 * u22), 0, 1 / u11, -u12 / (u11 * u22), 0, 0, 1 / u22};
-      double tmp[9], PLL[9];
+      // H_L^-1 of the upper-triangular nL x nL (:548)
+      std::vector<double> inv((size_t)nL * nL, 0.0);
+      if (nL == 1) {
+        inv[0] = 1 / H_L[0];
+      } else {
+        const double u00 = H_L[0], u01 = H_L[1], u02 = H_L[2], u11 = H_L[4], u12 = H_L[5], u22 = H_L[8];
+        const double t9[9] = {1 / u00, -u01 / (u00 * u11), (u01 * u12 - u02 * u11) / (u00 * u11 * u22), 0, 1 / u11, -u12 / (u11 * u22), 0, 0, 1 / u22};
+        inv.assign(t9, t9 + 9);
+      }
+      std::vector<double> tmp((size_t)nL * nL), PLL((size_t)nL * nL);
       // M.selfadjointView<Upper>() (:549): the upper triangle stands for both halves
-      for (int a = 0; a < 3; a++)
-        for (int b = 0; b < 3; b++) {
+      for (int a = 0; a < nL; a++)
+        for (int b = 0; b < nL; b++) {
           double sv = 0;
-          for (int k = 0; k < 3; k++) sv += inv[3 * a + k] * Mm[3 * std::min(k, b) + std::max(k, b)];
-          tmp[3 * a + b] = sv;
+          for (int k = 0; k < nL; k++) sv += inv[(size_t)nL * a + k] * Mm[(size_t)nL * std::min(k, b) + std::max(k, b)];
+          tmp[(size_t)nL * a + b] = sv;
         }
-      for (int a = 0; a < 3; a++)
-        for (int b = 0; b < 3; b++) {
+      for (int a = 0; a < nL; a++)
+        for (int b = 0; b < nL; b++) {
           double sv = 0;
-          for (int k = 0; k < 3; k++) sv += tmp[3 * a + k] * inv[3 * b + k];
-          PLL[3 * a + b] = sv;
+          for (int k = 0; k < nL; k++) sv += tmp[(size_t)nL * a + k] * inv[(size_t)nL * b + k];
+          PLL[(size_t)nL * a + b] = sv;
         }
       // augment the covariance (:552-558)
-      const int N1 = N + 3;
+      const int N1 = N + nL;
       std::vector<double> Pn((size_t)N1 * N1, 0.0);
       for (int i = 0; i < N; i++) std::memcpy(Pn.data() + (size_t)i * N1, P.data() + (size_t)i * N, sizeof(double) * N);
       for (int i = 0; i < N; i++)
-        for (int j = 0; j < 3; j++) {
+        for (int j = 0; j < nL; j++) {
           double sv = 0;
-          for (int k = 0; k < 3; k++) sv += M_a[(size_t)i * 3 + k] * inv[3 * j + k];
+          for (int k = 0; k < nL; k++) sv += M_a[(size_t)i * nL + k] * inv[(size_t)nL * j + k];
           Pn[(size_t)i * N1 + N + j] = -sv;
           Pn[(size_t)(N + j) * N1 + i] = -sv;
         }
-      for (int a = 0; a < 3; a++)
-        for (int b = 0; b < 3; b++) Pn[(size_t)(N + a) * N1 + N + b] = PLL[3 * a + b];
+      for (int a = 0; a < nL; a++)
+        for (int b = 0; b < nL; b++) Pn[(size_t)(N + a) * N1 + N + b] = PLL[(size_t)nL * a + b];
       P.swap(Pn);
-      // the landmark: set_from_xyz (UpdaterSLAM.cpp:213-221), then update(H_Linv * res) (:569)
+      // the landmark: set_from_xyz (UpdaterSLAM.cpp:213-221), then update(H_Linv * res) (:569); a single-depth landmark is
+      // reported as (uv_norm_zero.x, uv_norm_zero.y, rho) with rho its only state variable
       double v[3];
       landmark_set_from_xyz(feat_rep, is_relative(feat_rep) ? pA[f] : pG[f], v);
-      for (int j = 0; j < 3; j++) {
-        new_fej[3 * f + j] = v[j];
+      for (int j = 0; j < 3; j++) new_fej[3 * f + j] = v[j], new_val[3 * f + j] = v[j];
+      for (int j = 0; j < nL; j++) {
         double d = 0;
-        for (int k = 0; k < 3; k++) d += inv[3 * j + k] * resinit[k];
-        new_val[3 * f + j] = v[j] + d;
+        for (int k = 0; k < nL; k++) d += inv[(size_t)nL * j + k] * resinit[k];
+        new_val[3 * f + (3 - nL) + j] += d;
       }
       new_cov[f] = N;
       N = N1;
@@ -1857,10 +1910,10 @@ int oracle_slam_delayed_init(const ovgpu_options *opts, const ovgpu_state_view *
       clone_qp = cq, calib_qp = kq, intr = iq;
       st.clone_q_p = clone_qp.data(), st.calib_q_p = calib_qp.data(), st.intrinsics = intr.data();
       for (int l = 0; l < L0; l++)
-        for (int i = 0; i < 3; i++) lm_old[3 * l + i] += dx[lm->cov_id[l] + i];
+        for (int i = 0; i < nL; i++) lm_old[3 * l + (3 - nL) + i] += dx[lm->cov_id[l] + i];
       for (int g = 0; g <= f; g++)
         if (new_cov[g] >= 0)
-          for (int i = 0; i < 3; i++) new_val[3 * g + i] += dx[new_cov[g] + i];
+          for (int i = 0; i < nL; i++) new_val[3 * g + (3 - nL) + i] += dx[new_cov[g] + i];
     }
   }
   for (int f = 0; f < F; f++) {
@@ -1961,10 +2014,13 @@ int oracle_anchor_change(const ovgpu_options *opts, const ovgpu_state_view *st, 
   const int rep = lm->feat_rep, N = st->N;
   if (!is_relative(rep)) return OVGPU_ERR_INVALID;
   StateTables T = build_tables(st);
+  const bool single = rep == OVGPU_REP_ANCHORED_INVERSE_DEPTH_SINGLE;
+  const int jrep = single ? OVGPU_REP_ANCHORED_MSCKF_INVERSE_DEPTH : rep; // H_f of the single depth = third column of the inverse-depth Jacobian (UpdaterHelper.cpp:178-189)
+  const int sz = single ? 1 : 3, j0 = 3 - sz;
   const int old_cam = lm->anchor_cam[l], old_clone = lm->anchor_clone[l];
   const V3 nanv{{NAN, NAN, NAN}};
   V3 pA_old = landmark_get_xyz(rep, lm->p_value + 3 * l), pA_old_fej = landmark_get_xyz(rep, lm->p_fej + 3 * l); // :517-518
-  RepJac jo = feature_jacobian_representation(o, T, rep, nanv, nanv, pA_old, old_cam, old_clone);               // :523-526
+  RepJac jo = feature_jacobian_representation(o, T, jrep, nanv, nanv, pA_old, old_cam, old_clone);              // :523-526
   // transform between the old anchor and the new one, current (:536-551) and first estimates (:556-571)
   V3 pA_new, pA_new_fej;
   for (int fej = 0; fej < 2; fej++) {
@@ -1982,7 +2038,7 @@ int oracle_anchor_change(const ovgpu_options *opts, const ovgpu_state_view *st, 
     if (fej) pA_new_fej = r;
     else pA_new = r;
   }
-  RepJac jn = feature_jacobian_representation(o, T, rep, nanv, nanv, pA_new, new_cam, new_clone); // :577-580
+  RepJac jn = feature_jacobian_representation(o, T, jrep, nanv, nanv, pA_new, new_cam, new_clone); // :577-580
   // phi_order_OLD (:592-610): x_order_old, then the new ones not seen yet, then the landmark
   std::vector<int32_t> ids;
   int col_oc = 0, col_ok = -1, col_nc, col_nk = -1, col_lm;
@@ -1994,33 +2050,38 @@ int oracle_anchor_change(const ovgpu_options *opts, const ovgpu_state_view *st, 
     if (new_cam == old_cam) col_nk = col_ok;
     else col_nk = (int)ids.size(), push(st->calib_cov_id[new_cam], 6);
   }
-  col_lm = (int)ids.size(), push(lm->cov_id[l], 3);
+  col_lm = (int)ids.size(), push(lm->cov_id[l], sz);
   const int n = (int)ids.size();
   // H_f_new^-1 (:621)
-  M3 A;
-  std::memcpy(A.a, jn.dpfg_dlambda, sizeof(A.a));
-  double inv[9];
-  for (int j = 0; j < 3; j++) {
-    V3 e{{j == 0 ? 1.0 : 0.0, j == 1 ? 1.0 : 0.0, j == 2 ? 1.0 : 0.0}};
-    V3 x = colpiv_qr_solve3(A, e);
-    for (int i = 0; i < 3; i++) inv[3 * i + j] = x[i];
+  double inv[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}; // rows j0.. are the landmark's
+  if (!single) {
+    M3 A;
+    std::memcpy(A.a, jn.dpfg_dlambda, sizeof(A.a));
+    for (int j = 0; j < 3; j++) {
+      V3 e{{j == 0 ? 1.0 : 0.0, j == 1 ? 1.0 : 0.0, j == 2 ? 1.0 : 0.0}};
+      V3 x = colpiv_qr_solve3(A, e);
+      for (int i = 0; i < 3; i++) inv[3 * i + j] = x[i];
+    }
+  } else { // :619  1 / |h|^2 h^T
+    const double h0 = jn.dpfg_dlambda[2], h1 = jn.dpfg_dlambda[5], h2 = jn.dpfg_dlambda[8], nn = 1.0 / (h0 * h0 + h1 * h1 + h2 * h2);
+    inv[6] = nn * h0, inv[7] = nn * h1, inv[8] = nn * h2;
   }
-  std::vector<double> Phi((size_t)3 * n, 0.0), Q(9, 0.0);
-  auto add_block = [&](int col, const double *H, int w, double sign) {
-    for (int a = 0; a < 3; a++)
-      for (int b = 0; b < w; b++) {
+  std::vector<double> Phi((size_t)sz * n, 0.0), Q((size_t)sz * sz, 0.0);
+  auto add_block = [&](int col, const double *H, int w, int b0, double sign) {
+    for (int a = j0; a < 3; a++)
+      for (int b = b0; b < w; b++) {
         double sv = 0;
         for (int k = 0; k < 3; k++) sv += inv[3 * a + k] * H[w * k + b];
-        Phi[(size_t)a * n + col + b] += sign * sv;
+        Phi[(size_t)(a - j0) * n + col + b - b0] += sign * sv;
       }
   };
-  add_block(col_oc, jo.H_anc, 6, 1.0); // :626-628
-  if (col_ok >= 0) add_block(col_ok, jo.H_calib, 6, 1.0);
-  add_block(col_lm, jo.dpfg_dlambda, 3, 1.0); // :631
-  add_block(col_nc, jn.H_anc, 6, -1.0);       // :634-636
-  if (col_nk >= 0) add_block(col_nk, jn.H_calib, 6, -1.0);
+  add_block(col_oc, jo.H_anc, 6, 0, 1.0); // :626-628
+  if (col_ok >= 0) add_block(col_ok, jo.H_calib, 6, 0, 1.0);
+  add_block(col_lm, jo.dpfg_dlambda, 3, j0, 1.0); // :631
+  add_block(col_nc, jn.H_anc, 6, 0, -1.0);        // :634-636
+  if (col_nk >= 0) add_block(col_nk, jn.H_calib, 6, 0, -1.0);
   std::memcpy(P_out, st->P, sizeof(double) * (size_t)N * N);
-  const int rc = oracle_propagate(P_out, N, lm->cov_id[l], 3, n, ids.data(), Phi.data(), Q.data()); // :640
+  const int rc = oracle_propagate(P_out, N, lm->cov_id[l], sz, n, ids.data(), Phi.data(), Q.data()); // :640
   landmark_set_from_xyz(rep, pA_new, value_out);     // :645-646
   landmark_set_from_xyz(rep, pA_new_fej, fej_out);
   return rc;

@@ -213,7 +213,7 @@ def slam_delayed_init(opts, views, feat_rep=0, tri=None):
     triangulate()) replaces the triangulation stage.  views may carry landmarks already in the state."""
     lib = load()
     F, N, Cn, K = views.features.F, views.state.N, views.state.C, views.state.K
-    Nmax = N + 3 * F
+    Nmax = N + (1 if int(feat_rep) == capi.REP_ANCHORED_INVERSE_DEPTH_SINGLE else 3) * F
     L0 = views.landmarks.L if views.landmarks is not None else 0
     out = dict(feat_status=np.zeros(F, dtype=np.int32), chi2=np.zeros(F), chi2_thresh=np.zeros(F), lm_cov_id=np.zeros(F, dtype=np.int32),
                lm_value=np.zeros((F, 3)), lm_fej=np.zeros((F, 3)), anchor_cam=np.zeros(F, dtype=np.int32), anchor_clone=np.zeros(F, dtype=np.int32),

@@ -555,7 +555,7 @@ def test_triangulation_from_explicit_camera_poses(Updater, oracle):
 
 # --------------------------------------------------------------------------- SLAM landmarks in other representations, delayed initialisation
 @pytest.mark.parametrize("rep", [capi.REP_GLOBAL_FULL_INVERSE_DEPTH, capi.REP_ANCHORED_3D, capi.REP_ANCHORED_FULL_INVERSE_DEPTH,
-                                 capi.REP_ANCHORED_MSCKF_INVERSE_DEPTH])
+                                 capi.REP_ANCHORED_MSCKF_INVERSE_DEPTH, capi.REP_ANCHORED_INVERSE_DEPTH_SINGLE])
 def test_slam_update_parity_representations(Updater, oracle, rep):
     """UpdaterSLAM::update with feat_rep_slam != GLOBAL_3D (EuRoC's default is ANCHORED_MSCKF_INVERSE_DEPTH): the landmark
     is stored in representation coordinates, its columns are dz/dp * dp/dlambda, anchored ones add the anchor clone /
@@ -593,7 +593,8 @@ def _check_delayed_init(out, ref, post):
         assert np.abs(post[k] - ref[k]).max() < 1e-9
 
 
-@pytest.mark.parametrize("rep", [capi.REP_GLOBAL_3D, capi.REP_GLOBAL_FULL_INVERSE_DEPTH, capi.REP_ANCHORED_3D, capi.REP_ANCHORED_MSCKF_INVERSE_DEPTH])
+@pytest.mark.parametrize("rep", [capi.REP_GLOBAL_3D, capi.REP_GLOBAL_FULL_INVERSE_DEPTH, capi.REP_ANCHORED_3D, capi.REP_ANCHORED_MSCKF_INVERSE_DEPTH,
+                                 capi.REP_ANCHORED_INVERSE_DEPTH_SINGLE])
 def test_delayed_init_parity(Updater, oracle, rep):
     """UpdaterSLAM::delayed_init: a chain of StateHelper::initialize calls (Givens split in the oracle, Householder on the
     GPU), each on the state the previous one left, against the oracle run with the same triangulation."""
@@ -771,7 +772,7 @@ def test_state_bookkeeping_rejects_bad_blocks(Updater):
     up.close()
 
 
-@pytest.mark.parametrize("rep", [capi.REP_ANCHORED_3D, capi.REP_ANCHORED_MSCKF_INVERSE_DEPTH])
+@pytest.mark.parametrize("rep", [capi.REP_ANCHORED_3D, capi.REP_ANCHORED_MSCKF_INVERSE_DEPTH, capi.REP_ANCHORED_INVERSE_DEPTH_SINGLE])
 def test_change_anchors_parity_then_marginalize(Updater, oracle, rep):
     """UpdaterSLAM::change_anchors (SURVEY 8f N1): the landmarks anchored in the oldest clone move to the newest one
     (value, first estimate, covariance through EKFPropagation) exactly as the oracle moves them one after the other; then
@@ -898,7 +899,7 @@ def test_slam_update_parity_random_shapes(Updater, oracle, seed):
     rng = np.random.default_rng(2000 + seed)
     kw = dict(C=int(rng.integers(6, 31)), K=int(rng.integers(1, 4)), track=("full", "ragged")[int(rng.integers(2))], fisheye=bool(rng.integers(2)),
               seed=int(rng.integers(1 << 20)))
-    prob = synth.make_slam_problem(2, L=int(rng.integers(1, 13)), lm_rep=int(rng.integers(0, 5)), **kw)
+    prob = synth.make_slam_problem(2, L=int(rng.integers(1, 13)), lm_rep=int(rng.integers(0, 6)), **kw)
     opts = capi.default_options(chi2_multipler=float(rng.choice([1.0, 5.0])), do_fej=int(rng.integers(2)),
                                 do_calib_camera_pose=int(rng.integers(2)), do_calib_camera_intrinsics=int(rng.integers(2)))
     ref = oracle.slam_update(opts, capi.Views(prob))
@@ -918,7 +919,7 @@ def test_delayed_init_parity_random_shapes(Updater, oracle, seed):
     rng = np.random.default_rng(3000 + seed)
     kw = dict(C=int(rng.integers(6, 31)), K=int(rng.integers(1, 4)), F=int(rng.integers(1, 21)), track=("full", "ragged")[int(rng.integers(2))],
               fisheye=bool(rng.integers(2)), seed=int(rng.integers(1 << 20)), outlier_frac=float(rng.choice([0.0, 0.3])))
-    rep = int(rng.integers(0, 5))
+    rep = int(rng.integers(0, 6))
     prob = synth.make_problem(2, **kw)
     opts = capi.default_options(chi2_multipler=float(rng.choice([1.0, 5.0])), do_fej=int(rng.integers(2)),
                                 do_calib_camera_pose=int(rng.integers(2)), do_calib_camera_intrinsics=int(rng.integers(2)))

@@ -505,3 +505,39 @@ def test_anchor_change_keeps_the_landmark_where_it_is(rep):
     np.testing.assert_array_equal(o["P"][np.ix_(rest, rest)], prob.P[np.ix_(rest, rest)])
     assert np.abs(o["P"][np.ix_(idx, idx)] - prob.P[np.ix_(idx, idx)]).max() > 0
     assert np.linalg.eigvalsh(0.5 * (o["P"] + o["P"].T)).min() > 0
+
+
+def test_single_depth_landmark_is_the_marginal_of_the_inverse_depth_one():
+    """ANCHORED_INVERSE_DEPTH_SINGLE projects the bearing out of every system (UpdaterSLAM.cpp:181-196, :371-379) = a flat
+    prior on the two bearing coordinates of ANCHORED_MSCKF_INVERSE_DEPTH, marginalised.  Delayed initialisation of one
+    feature must therefore give the 3-dof result restricted to (state, rho); the SLAM update must reproduce its own stack in
+    information form with 2m - 2 rows per landmark and the 0.95 quantile of 2m - 2 dof as threshold."""
+    from scipy import stats as sps
+    from oracle import pyoracle
+    p1 = synth.make_problem(2, F=1)
+    o1 = capi.default_options(chi2_multipler=1e6)
+    v1 = capi.Views(p1)
+    tri = pyoracle.triangulate(o1, v1)
+    d5 = pyoracle.slam_delayed_init(o1, v1, feat_rep=capi.REP_ANCHORED_INVERSE_DEPTH_SINGLE, tri=tri)
+    d4 = pyoracle.slam_delayed_init(o1, v1, feat_rep=capi.REP_ANCHORED_MSCKF_INVERSE_DEPTH, tri=tri)
+    N = p1.N
+    keep = np.r_[0:N, N + 2]
+    assert d5["N"] == N + 1 and d4["N"] == N + 3
+    np.testing.assert_allclose(d5["P"], d4["P"][np.ix_(keep, keep)], rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(d5["lm_value"][:, 2], d4["lm_value"][:, 2], rtol=1e-12)  # rho; the bearing stays what the triangulation gave
+    np.testing.assert_array_equal(d5["lm_value"][:, :2], d5["lm_fej"][:, :2])
+    np.testing.assert_allclose(d5["dx_seq"][0, :N], d4["dx_seq"][0, :N], rtol=1e-10, atol=1e-14)
+    m = int(np.diff(p1.meas_offsets)[0])
+    np.testing.assert_allclose(d5["chi2_thresh"][0] / 1e6, sps.chi2.ppf(0.95, 2 * m - 2), rtol=1e-10)
+    prob = synth.make_slam_problem(2, L=6, lm_rep=capi.REP_ANCHORED_INVERSE_DEPTH_SINGLE)
+    opts = capi.default_options(chi2_multipler=5.0)
+    o = pyoracle.slam_update(opts, capi.Views(prob), want_stack=True)
+    used = o["feat_status"] == capi.FEAT_USED
+    mm = np.diff(prob.meas_offsets)
+    assert used.sum() >= 4 and o["rows"] == int((2 * mm[used] - 2).sum()) and o["D"] == 6 * prob.C + 14 * prob.K + 6
+    np.testing.assert_allclose(o["chi2_thresh"][used], 5.0 * sps.chi2.ppf(0.95, 2 * mm[used] - 2), rtol=1e-10)
+    H = np.zeros((o["rows"], prob.N))
+    H[:, o["col_cov_id"]] = o["H"]
+    Pinf = np.linalg.inv(np.linalg.inv(prob.P) + H.T @ H)
+    assert np.linalg.norm(o["P"] - Pinf) / np.linalg.norm(Pinf) < 1e-9
+    np.testing.assert_array_equal(o["landmarks"][:, :2], prob.lm_value[:, :2])  # the bearing is a constant of the landmark
