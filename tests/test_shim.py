@@ -2,6 +2,8 @@
 import os
 import subprocess
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -36,3 +38,11 @@ def test_slam_shims_keep_the_reference_signatures():
     assert "void UpdaterSLAM::delayed_init(std::shared_ptr<State> state, std::vector<std::shared_ptr<Feature>> &feature_vec)" in ini
     assert "ovgpu_slam_compress" in upd and "ovgpu_slam_delayed_init" in ini and "lv.feat_rep" in upd and "lv.feat_rep" in ini
     assert "oracle" not in upd and "oracle" not in ini
+
+
+@pytest.mark.gpu
+def test_shim_drives_an_update_from_cpp():
+    """The C++ side of the boundary (ovgpu_flatten.h + the C ABI, no Python in between) on the GPU."""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "open_vins_amd", "shim"), "selftest"])
+    out = subprocess.check_output([os.path.join(ROOT, "open_vins_amd", "shim", "selftest"), "--gpu"], text=True)
+    assert "shim gpu selftest ok" in out, out
