@@ -432,6 +432,50 @@ int ovgpu_state_propagate(ovgpu_ctx *ctx, int32_t new_cov_id, int32_t n_new, int
 int ovgpu_state_dims(ovgpu_ctx *ctx, int32_t *N_out, int32_t *C_out);
 
 /* ------------------------------------------------------------------------- */
+/* A FeatureDatabase on the device: observations are appended once    */
+/* per frame, the batch of an update is assembled on the device — the host never walks the   */
+/* per-feature maps of ov_core::Feature (Feature.h:49-55) and never re-sends an observation. */
+/* The host keeps the id -> slot table and the last observation time of every track.        */
+/* ------------------------------------------------------------------------- */
+
+/* Allocates the store: up to max_tracks live tracks of up to max_obs observations each (all
+ * cameras together).  Replaces FeatureDatabase's constructor; call again to resize (drops all). */
+int ovgpu_tracks_create(ovgpu_ctx *ctx, int32_t max_tracks, int32_t max_obs);
+
+/* FeatureDatabase::update_feature (FeatureDatabase.cpp:59-85) for the n observations of one camera
+ * frame: feature featid[i] was seen by camera cam_id[i] at `timestamp` at raw pixel uv[2i..] /
+ * normalised uvn[2i..].  Unknown ids open a new track.  OVGPU_ERR_CAPACITY when the store or a
+ * track is full (nothing is appended then).                                                  */
+int ovgpu_tracks_append(ovgpu_ctx *ctx, double timestamp, int32_t n, const int64_t *featid,
+                        const int32_t *cam_id, const float *uv, const float *uvn);
+
+/* Drops tracks (Feature::to_delete + FeatureDatabase::cleanup, FeatureDatabase.cpp:211-224);
+ * unknown ids are ignored.                                                                    */
+int ovgpu_tracks_erase(ovgpu_ctx *ctx, int32_t n, const int64_t *featid);
+
+/* FeatureDatabase::features_not_containing_newer(timestamp) (FeatureDatabase.cpp:87-126): ids of the
+ * tracks whose last observation is older than `timestamp` (the lost tracks VioManager turns into
+ * MSCKF features, VioManager.cpp:366-378).  ids [capacity], n_out = how many there are.       */
+int ovgpu_tracks_not_containing_newer(ovgpu_ctx *ctx, double timestamp, int32_t capacity,
+                                      int64_t *ids, int32_t *n_out);
+
+/* Number of live tracks. */
+int ovgpu_tracks_count(ovgpu_ctx *ctx, int32_t *n_tracks);
+
+/* Builds the resident feature batch from F stored tracks — what ovgpu_set_features would receive
+ * after Feature::clean_old_measurements(clone_times) (Feature.cpp:26-53) and the shim's
+ * flattening: observations whose time is (exactly) one of clone_times [C] (index = clone index
+ * of the resident state), camera groups in ascending camera id, time order inside a group.
+ * An unknown id gives an empty track.  The state must be resident (C clones).                */
+int ovgpu_tracks_to_features(ovgpu_ctx *ctx, int32_t F, const int64_t *featid,
+                             const double *clone_times);
+
+/* Reads the resident feature batch back (any pointer may be NULL): F, M, meas_offsets [F+1],
+ * uv / uvn [2M], clone_idx / cam_idx [M].                                                    */
+int ovgpu_get_features(ovgpu_ctx *ctx, int32_t *F_out, int32_t *M_out, int32_t *meas_offsets,
+                       float *uv, float *uvn, int32_t *clone_idx, int32_t *cam_idx);
+
+/* ------------------------------------------------------------------------- */
 /* the two helpers of the path as standalone calls (UpdaterZeroVelocity.cpp:183-321 */
 /* and any other updater stack a dense system and call them this way)         */
 /* ------------------------------------------------------------------------- */

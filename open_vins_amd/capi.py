@@ -185,6 +185,13 @@ def declare(lib):
         "ovgpu_measurement_compress": (C.c_int, [ctxp, C.c_int, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p, c_int32_p]),
         "ovgpu_ekf_update": (C.c_int, [ctxp, C.c_int, C.c_int, c_int32_p, c_double_p, c_double_p, C.c_double, c_double_p, c_double_p]),
         "ovgpu_set_landmarks": (C.c_int, [ctxp, C.POINTER(LandmarksView)]),
+        "ovgpu_tracks_create": (C.c_int, [ctxp, C.c_int32, C.c_int32]),
+        "ovgpu_tracks_append": (C.c_int, [ctxp, C.c_double, C.c_int32, C.POINTER(C.c_int64), c_int32_p, c_float_p, c_float_p]),
+        "ovgpu_tracks_erase": (C.c_int, [ctxp, C.c_int32, C.POINTER(C.c_int64)]),
+        "ovgpu_tracks_not_containing_newer": (C.c_int, [ctxp, C.c_double, C.c_int32, C.POINTER(C.c_int64), c_int32_p]),
+        "ovgpu_tracks_count": (C.c_int, [ctxp, c_int32_p]),
+        "ovgpu_tracks_to_features": (C.c_int, [ctxp, C.c_int32, C.POINTER(C.c_int64), c_double_p]),
+        "ovgpu_get_features": (C.c_int, [ctxp, c_int32_p, c_int32_p, c_int32_p, c_float_p, c_float_p, c_int32_p, c_int32_p]),
         "ovgpu_slam_change_anchor": (C.c_int, [ctxp, C.c_int32, C.c_int32, C.c_int32]),
         "ovgpu_slam_change_anchors": (C.c_int, [ctxp, C.c_int32, C.c_int32, c_int32_p]),
         "ovgpu_state_marginalize": (C.c_int, [ctxp, C.c_int32, C.c_int32]),

@@ -21,6 +21,8 @@
 #include "k_ekf.h"
 #include "k_slam.h"
 #include "k_tsqr_blk.h"
+#include "k_tracks.h"
+#include <unordered_map>
 #include "k_system.h"
 #include "k_triangulate.h"
 #include "ovgpu_types.h"
@@ -112,6 +114,15 @@ struct ovgpu_ctx {
   DevBuf<double> pFej, lm_val, lm_fej; // landmark values in representation coordinates (ov_type::Landmark::value / fej)
   DevBuf<int32_t> feat_lm, feat_lmcol, feat_lmcov, feat_anchor, lm_cov, lm_col, lm_anchor, lm_index;
   bool slam_rows = false; // row layout of the uploaded batch: 2m rows per feature (SLAM update) or 2m - 3 (MSCKF, delayed init)
+  // device-resident FeatureDatabase (ovgpu_tracks_*)
+  int trk_max = 0, trk_obs = 0;
+  DevBuf<int32_t> trk_count, trk_cam, trk_slot_in, trk_cam_in, trk_sel, trk_nvalid, trk_flag;
+  DevBuf<double> trk_time, trk_clone_times;
+  DevBuf<float> trk_uv, trk_uvn, trk_uv_in, trk_uvn_in;
+  std::unordered_map<int64_t, int32_t> trk_slot_of;
+  std::vector<int32_t> trk_free, trk_h_count;
+  std::vector<double> trk_h_last;
+  std::vector<int64_t> trk_h_id;
   // UpdaterSLAM::delayed_init
   DevBuf<double> Ppad, init_ws, dx_seq;
   DevBuf<int32_t> init_ctr, feat_slot;
@@ -352,6 +363,8 @@ void ovgpu_destroy(ovgpu_ctx *c) {
   c->pFej.release(), c->lm_val.release(), c->lm_fej.release(), c->feat_lm.release(), c->feat_lmcol.release(), c->feat_lmcov.release(), c->lm_cov.release();
   c->feat_anchor.release(), c->lm_col.release(), c->lm_anchor.release(), c->lm_index.release(), c->Ppad.release(), c->init_ws.release(), c->dx_seq.release();
   c->init_ctr.release(), c->feat_slot.release(), c->prop_w.release(), c->prop_in.release(), c->prop_ids.release();
+  c->trk_count.release(), c->trk_cam.release(), c->trk_slot_in.release(), c->trk_cam_in.release(), c->trk_sel.release(), c->trk_nvalid.release(), c->trk_flag.release();
+  c->trk_time.release(), c->trk_clone_times.release(), c->trk_uv.release(), c->trk_uvn.release(), c->trk_uv_in.release(), c->trk_uvn_in.release();
   c->dx.release(), c->flags.release(), c->given_status.release();
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
@@ -594,29 +607,17 @@ static int set_row_layout(ovgpu_ctx *c, bool slam_rows) {
   return OVGPU_OK;
 }
 
-int ovgpu_set_features(ovgpu_ctx *c, const ovgpu_features_view *fv) {
-  if (!c || !fv) return set_err(OVGPU_ERR_INVALID, "null argument");
-  if (!c->have_state) return set_err(OVGPU_ERR_NO_STATE, "ovgpu_set_state must precede ovgpu_set_features");
-  if (fv->F < 0 || fv->M < 0) return set_err(OVGPU_ERR_INVALID, "negative sizes");
-  if (fv->F > 0 && (!fv->meas_offsets)) return set_err(OVGPU_ERR_INVALID, "null feature arrays");
-  if (fv->M > 0 && (!fv->uv || !fv->uvn || !fv->clone_idx || !fv->cam_idx)) return set_err(OVGPU_ERR_INVALID, "null measurement arrays");
-  HIPCHK(hipSetDevice(c->device));
-  const int F = fv->F, M = fv->M;
-  if (F > 0 && (fv->meas_offsets[0] != 0 || fv->meas_offsets[F] != M)) return set_err(OVGPU_ERR_INVALID, "meas_offsets must span [0, M]");
-  std::vector<uint16_t> cc(std::max(M, 1));
-  for (int i = 0; i < M; i++) {
-    const int cl = fv->clone_idx[i], cam = fv->cam_idx[i];
-    if (cl < 0 || cl >= c->C || cam < 0 || cam >= c->K) return set_err(OVGPU_ERR_INVALID, "measurement refers to an unknown clone / camera");
-    cc[i] = (uint16_t)((cam << 10) | cl);
-  }
+// Host bookkeeping, workspaces and the small per-batch tables of a feature batch of F tracks / M measurements whose
+// meas_offsets are `offsets` (host); the measurement payload (uv, uvn, meas_cc) is written by the caller afterwards.
+static int begin_feature_batch(ovgpu_ctx *c, int F, int M, const int32_t *offsets) {
   int m_max = 0;
   for (int f = 0; f < F; f++) {
-    const int m = fv->meas_offsets[f + 1] - fv->meas_offsets[f];
+    const int m = offsets[f + 1] - offsets[f];
     if (m < 0) return set_err(OVGPU_ERR_INVALID, "meas_offsets not monotone");
     m_max = std::max(m_max, m);
   }
   c->F = F, c->M = M, c->m_max = m_max;
-  c->h_offsets.assign(fv->meas_offsets, fv->meas_offsets + (F > 0 ? F + 1 : 0));
+  c->h_offsets.assign(offsets, offsets + (F > 0 ? F + 1 : 0));
   if (F == 0) c->h_offsets.assign(1, 0);
 
   // chi2 table for dof 1 .. max(499, 2 m_max)  (UpdaterMSCKF.cpp:52-55; dof >= 500 is computed on the fly there, :216-222)
@@ -643,17 +644,16 @@ int ovgpu_set_features(ovgpu_ctx *c, const ovgpu_features_view *fv) {
   hipStream_t s = c->stream;
   std::vector<int32_t> order(std::max(F, 1), 0);
   for (int f = 0; f < F; f++) order[f] = f;
-  std::stable_sort(order.begin(), order.begin() + F, [&](int32_t a, int32_t b) {
-    return fv->meas_offsets[a + 1] - fv->meas_offsets[a] > fv->meas_offsets[b + 1] - fv->meas_offsets[b];
-  });
+  std::stable_sort(order.begin(), order.begin() + F, [&](int32_t a, int32_t b) { return offsets[a + 1] - offsets[a] > offsets[b + 1] - offsets[b]; });
   HIPCHK(c->sys_order.reserve(std::max(F, 1)));
   HIPCHK(upload(c->sys_order.p, order.data(), sizeof(int32_t) * F, s));
-  HIPCHK(upload(c->meas_offsets.p, fv->meas_offsets, sizeof(int32_t) * (F + 1), s));
-  HIPCHK(upload(c->meas_cc.p, cc.data(), sizeof(uint16_t) * M, s));
-  HIPCHK(upload(c->uv.p, fv->uv, sizeof(float) * 2 * M, s));
-  HIPCHK(upload(c->uvn.p, fv->uvn, sizeof(float) * 2 * M, s));
+  HIPCHK(upload(c->meas_offsets.p, c->h_offsets.data(), sizeof(int32_t) * (F + 1), s));
   HIPCHK(upload(c->chi2_table.p, c->h_chi2_table.data(), sizeof(double) * c->chi2_table_len, s));
   HIPCHK(hipStreamSynchronize(s)); // host staging vectors go out of scope
+  return OVGPU_OK;
+}
+
+static int end_feature_batch(ovgpu_ctx *c) {
   // rows of the stacked system: SLAM layout when landmarks are resident (the batch is for ovgpu_slam_update), MSCKF otherwise;
   // an entry point that needs the other layout switches it (set_row_layout)
   const int rcl = set_row_layout(c, c->L > 0);
@@ -661,6 +661,32 @@ int ovgpu_set_features(ovgpu_ctx *c, const ovgpu_features_view *fv) {
   c->have_feats = true;
   c->given_tri = false;
   return OVGPU_OK;
+}
+
+int ovgpu_set_features(ovgpu_ctx *c, const ovgpu_features_view *fv) {
+  if (!c || !fv) return set_err(OVGPU_ERR_INVALID, "null argument");
+  if (!c->have_state) return set_err(OVGPU_ERR_NO_STATE, "ovgpu_set_state must precede ovgpu_set_features");
+  if (fv->F < 0 || fv->M < 0) return set_err(OVGPU_ERR_INVALID, "negative sizes");
+  if (fv->F > 0 && (!fv->meas_offsets)) return set_err(OVGPU_ERR_INVALID, "null feature arrays");
+  if (fv->M > 0 && (!fv->uv || !fv->uvn || !fv->clone_idx || !fv->cam_idx)) return set_err(OVGPU_ERR_INVALID, "null measurement arrays");
+  HIPCHK(hipSetDevice(c->device));
+  const int F = fv->F, M = fv->M;
+  if (F > 0 && (fv->meas_offsets[0] != 0 || fv->meas_offsets[F] != M)) return set_err(OVGPU_ERR_INVALID, "meas_offsets must span [0, M]");
+  std::vector<uint16_t> cc(std::max(M, 1));
+  for (int i = 0; i < M; i++) {
+    const int cl = fv->clone_idx[i], cam = fv->cam_idx[i];
+    if (cl < 0 || cl >= c->C || cam < 0 || cam >= c->K) return set_err(OVGPU_ERR_INVALID, "measurement refers to an unknown clone / camera");
+    cc[i] = (uint16_t)((cam << 10) | cl);
+  }
+  const int32_t zero = 0;
+  int rc = begin_feature_batch(c, F, M, F > 0 ? fv->meas_offsets : &zero);
+  if (rc != OVGPU_OK) return rc;
+  hipStream_t s = c->stream;
+  HIPCHK(upload(c->meas_cc.p, cc.data(), sizeof(uint16_t) * M, s));
+  HIPCHK(upload(c->uv.p, fv->uv, sizeof(float) * 2 * M, s));
+  HIPCHK(upload(c->uvn.p, fv->uvn, sizeof(float) * 2 * M, s));
+  HIPCHK(hipStreamSynchronize(s)); // host staging vectors go out of scope
+  return end_feature_batch(c);
 }
 
 // ---------------------------------------------------------------------------
@@ -1652,6 +1678,189 @@ int ovgpu_state_propagate(ovgpu_ctx *c, int32_t new_cov_id, int32_t n_new, int32
   HIPCHK(hipMemcpyAsync(flags, c->flags.p, sizeof(flags), hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
   if (flags[1]) return set_err(OVGPU_ERR_NEGATIVE_DIAGONAL, "negative covariance diagonal after the propagation");
+  return OVGPU_OK;
+}
+
+// ---------------------------------------------------------------------------
+// FeatureDatabase on the device
+// ---------------------------------------------------------------------------
+static TrackStore track_store(ovgpu_ctx *c) { return TrackStore{c->trk_obs, c->trk_count.p, c->trk_time.p, c->trk_cam.p, c->trk_uv.p, c->trk_uvn.p}; }
+
+int ovgpu_tracks_create(ovgpu_ctx *c, int32_t max_tracks, int32_t max_obs) {
+  if (!c) return set_err(OVGPU_ERR_INVALID, "null ctx");
+  if (max_tracks <= 0 || max_obs <= 0 || (int64_t)max_tracks * max_obs > ((int64_t)1 << 31)) return set_err(OVGPU_ERR_INVALID, "bad track store size");
+  HIPCHK(hipSetDevice(c->device));
+  const size_t n = (size_t)max_tracks * max_obs;
+  HIPCHK(c->trk_count.reserve(max_tracks));
+  HIPCHK(c->trk_time.reserve(n));
+  HIPCHK(c->trk_cam.reserve(n));
+  HIPCHK(c->trk_uv.reserve(2 * n));
+  HIPCHK(c->trk_uvn.reserve(2 * n));
+  HIPCHK(c->trk_flag.reserve(1));
+  HIPCHK(hipMemsetAsync(c->trk_count.p, 0, sizeof(int32_t) * max_tracks, c->stream));
+  HIPCHK(hipMemsetAsync(c->trk_flag.p, 0, sizeof(int32_t), c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  c->trk_max = max_tracks, c->trk_obs = max_obs;
+  c->trk_slot_of.clear();
+  c->trk_free.resize(max_tracks);
+  for (int i = 0; i < max_tracks; i++) c->trk_free[i] = max_tracks - 1 - i; // slot 0 is handed out first
+  c->trk_h_count.assign(max_tracks, 0), c->trk_h_last.assign(max_tracks, 0.0), c->trk_h_id.assign(max_tracks, -1);
+  return OVGPU_OK;
+}
+
+int ovgpu_tracks_count(ovgpu_ctx *c, int32_t *n_tracks) {
+  if (!c || !n_tracks) return set_err(OVGPU_ERR_INVALID, "null argument");
+  *n_tracks = (int32_t)c->trk_slot_of.size();
+  return OVGPU_OK;
+}
+
+int ovgpu_tracks_append(ovgpu_ctx *c, double timestamp, int32_t n, const int64_t *featid, const int32_t *cam_id, const float *uv, const float *uvn) {
+  if (!c) return set_err(OVGPU_ERR_INVALID, "null ctx");
+  if (c->trk_max <= 0) return set_err(OVGPU_ERR_NO_STATE, "ovgpu_tracks_create was never called");
+  if (n < 0 || (n > 0 && (!featid || !cam_id || !uv || !uvn))) return set_err(OVGPU_ERR_INVALID, "bad observation arrays");
+  if (n == 0) return OVGPU_OK;
+  HIPCHK(hipSetDevice(c->device));
+  // ---- capacity first: nothing is appended when the call cannot go through as a whole
+  {
+    std::unordered_map<int64_t, int> add;
+    size_t fresh = 0;
+    for (int i = 0; i < n; i++) {
+      if (cam_id[i] < 0 || cam_id[i] >= OVG_MAX_CAMS) return set_err(OVGPU_ERR_INVALID, "camera id out of range");
+      add[featid[i]]++;
+    }
+    for (const auto &kv : add) {
+      auto it = c->trk_slot_of.find(kv.first);
+      const int have = it == c->trk_slot_of.end() ? 0 : c->trk_h_count[it->second];
+      if (it == c->trk_slot_of.end()) fresh++;
+      if (have + kv.second > c->trk_obs) return set_err(OVGPU_ERR_CAPACITY, "a track is full");
+    }
+    if (fresh > c->trk_free.size()) return set_err(OVGPU_ERR_CAPACITY, "the track store is full");
+  }
+  std::vector<int32_t> slot(n);
+  for (int i = 0; i < n; i++) {
+    auto it = c->trk_slot_of.find(featid[i]);
+    int sl;
+    if (it == c->trk_slot_of.end()) { // FeatureDatabase.cpp:76-84: a new feature
+      sl = c->trk_free.back();
+      c->trk_free.pop_back();
+      c->trk_slot_of.emplace(featid[i], sl);
+      c->trk_h_id[sl] = featid[i], c->trk_h_count[sl] = 0;
+    } else {
+      sl = it->second;
+    }
+    slot[i] = sl;
+    c->trk_h_count[sl]++;
+    c->trk_h_last[sl] = timestamp;
+  }
+  hipStream_t s = c->stream;
+  HIPCHK(c->trk_slot_in.reserve(n));
+  HIPCHK(c->trk_cam_in.reserve(n));
+  HIPCHK(c->trk_uv_in.reserve(2 * (size_t)n));
+  HIPCHK(c->trk_uvn_in.reserve(2 * (size_t)n));
+  HIPCHK(upload(c->trk_slot_in.p, slot.data(), sizeof(int32_t) * n, s));
+  HIPCHK(upload(c->trk_cam_in.p, cam_id, sizeof(int32_t) * n, s));
+  HIPCHK(upload(c->trk_uv_in.p, uv, sizeof(float) * 2 * n, s));
+  HIPCHK(upload(c->trk_uvn_in.p, uvn, sizeof(float) * 2 * n, s));
+  hipLaunchKernelGGL(k_tracks_append, dim3((n + 255) / 256), dim3(256), 0, s, n, timestamp, c->trk_slot_in.p, c->trk_cam_in.p, c->trk_uv_in.p, c->trk_uvn_in.p,
+                     track_store(c), c->trk_flag.p);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(s)); // the caller's arrays and `slot` may go away
+  return OVGPU_OK;
+}
+
+int ovgpu_tracks_erase(ovgpu_ctx *c, int32_t n, const int64_t *featid) {
+  if (!c) return set_err(OVGPU_ERR_INVALID, "null ctx");
+  if (n < 0 || (n > 0 && !featid)) return set_err(OVGPU_ERR_INVALID, "bad id array");
+  if (c->trk_max <= 0) return set_err(OVGPU_ERR_NO_STATE, "ovgpu_tracks_create was never called");
+  HIPCHK(hipSetDevice(c->device));
+  const int32_t zero = 0;
+  for (int i = 0; i < n; i++) {
+    auto it = c->trk_slot_of.find(featid[i]);
+    if (it == c->trk_slot_of.end()) continue;
+    const int sl = it->second;
+    HIPCHK(hipMemcpyAsync(c->trk_count.p + sl, &zero, sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    c->trk_h_count[sl] = 0, c->trk_h_id[sl] = -1;
+    c->trk_free.push_back(sl);
+    c->trk_slot_of.erase(it);
+  }
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return OVGPU_OK;
+}
+
+int ovgpu_tracks_not_containing_newer(ovgpu_ctx *c, double timestamp, int32_t capacity, int64_t *ids, int32_t *n_out) {
+  if (!c || !n_out) return set_err(OVGPU_ERR_INVALID, "null argument");
+  int n = 0;
+  for (const auto &kv : c->trk_slot_of)
+    if (!(c->trk_h_last[kv.second] >= timestamp)) { // FeatureDatabase.cpp:103-108
+      if (ids && n < capacity) ids[n] = kv.first;
+      n++;
+    }
+  if (ids) std::sort(ids, ids + std::min(n, (int)capacity));
+  *n_out = n;
+  return OVGPU_OK;
+}
+
+int ovgpu_tracks_to_features(ovgpu_ctx *c, int32_t F, const int64_t *featid, const double *clone_times) {
+  if (!c) return set_err(OVGPU_ERR_INVALID, "null ctx");
+  if (!c->have_state || c->poses_only) return set_err(OVGPU_ERR_NO_STATE, "ovgpu_set_state must precede ovgpu_tracks_to_features");
+  if (c->trk_max <= 0) return set_err(OVGPU_ERR_NO_STATE, "ovgpu_tracks_create was never called");
+  if (F < 0 || (F > 0 && !featid) || !clone_times) return set_err(OVGPU_ERR_INVALID, "bad argument");
+  HIPCHK(hipSetDevice(c->device));
+  hipStream_t s = c->stream;
+  const int C = c->C, K = c->K;
+  std::vector<int32_t> sel(std::max(F, 1), -1);
+  for (int f = 0; f < F; f++) {
+    auto it = c->trk_slot_of.find(featid[f]);
+    if (it != c->trk_slot_of.end()) sel[f] = it->second;
+  }
+  HIPCHK(c->trk_sel.reserve(std::max(F, 1)));
+  HIPCHK(c->trk_nvalid.reserve(std::max(F, 1)));
+  HIPCHK(c->trk_clone_times.reserve(C));
+  HIPCHK(upload(c->trk_sel.p, sel.data(), sizeof(int32_t) * F, s));
+  HIPCHK(upload(c->trk_clone_times.p, clone_times, sizeof(double) * C, s));
+  std::vector<int32_t> offs(F + 1, 0);
+  if (F > 0) {
+    hipLaunchKernelGGL(k_tracks_gather, dim3((F + 127) / 128), dim3(128), 0, s, F, K, C, c->trk_sel.p, c->trk_clone_times.p, track_store(c), c->trk_nvalid.p,
+                       (const int32_t *)nullptr, (float *)nullptr, (float *)nullptr, (uint16_t *)nullptr, 0);
+    HIPCHK(hipGetLastError());
+    std::vector<int32_t> nv(F);
+    HIPCHK(hipMemcpyAsync(nv.data(), c->trk_nvalid.p, sizeof(int32_t) * F, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    for (int f = 0; f < F; f++) offs[f + 1] = offs[f] + nv[f];
+  } else {
+    HIPCHK(hipStreamSynchronize(s));
+  }
+  const int M = offs[F];
+  int rc = begin_feature_batch(c, F, M, offs.data());
+  if (rc != OVGPU_OK) return rc;
+  if (F > 0) {
+    hipLaunchKernelGGL(k_tracks_gather, dim3((F + 127) / 128), dim3(128), 0, s, F, K, C, c->trk_sel.p, c->trk_clone_times.p, track_store(c), c->trk_nvalid.p,
+                       (const int32_t *)c->meas_offsets.p, c->uv.p, c->uvn.p, c->meas_cc.p, 1);
+    HIPCHK(hipGetLastError());
+  }
+  return end_feature_batch(c);
+}
+
+int ovgpu_get_features(ovgpu_ctx *c, int32_t *F_out, int32_t *M_out, int32_t *meas_offsets, float *uv, float *uvn, int32_t *clone_idx, int32_t *cam_idx) {
+  if (!c) return set_err(OVGPU_ERR_INVALID, "null ctx");
+  if (!c->have_feats) return set_err(OVGPU_ERR_NO_STATE, "no feature batch is resident");
+  HIPCHK(hipSetDevice(c->device));
+  const int F = c->F, M = c->M;
+  if (F_out) *F_out = F;
+  if (M_out) *M_out = M;
+  if (meas_offsets) std::memcpy(meas_offsets, c->h_offsets.data(), sizeof(int32_t) * (F + 1));
+  hipStream_t s = c->stream;
+  std::vector<uint16_t> cc(std::max(M, 1));
+  if (M > 0) {
+    if (uv) HIPCHK(hipMemcpyAsync(uv, c->uv.p, sizeof(float) * 2 * M, hipMemcpyDeviceToHost, s));
+    if (uvn) HIPCHK(hipMemcpyAsync(uvn, c->uvn.p, sizeof(float) * 2 * M, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(cc.data(), c->meas_cc.p, sizeof(uint16_t) * M, hipMemcpyDeviceToHost, s));
+  }
+  HIPCHK(hipStreamSynchronize(s));
+  for (int i = 0; i < M; i++) {
+    if (clone_idx) clone_idx[i] = cc[i] & 1023;
+    if (cam_idx) cam_idx[i] = cc[i] >> 10;
+  }
   return OVGPU_OK;
 }
 

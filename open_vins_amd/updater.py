@@ -225,6 +225,52 @@ class UpdaterMSCKF:
                                                     _ip(out["anchor_cam"]), _ip(out["anchor_clone"])), "ovgpu_get_landmarks")
         return out
 
+    # ---- FeatureDatabase on the device (FeatureDatabase.cpp:59-126, Feature.cpp:26-53) ----
+    def tracks_create(self, max_tracks, max_obs):
+        capi.check(self.lib.ovgpu_tracks_create(self._ctx, int(max_tracks), int(max_obs)), "ovgpu_tracks_create")
+
+    def tracks_append(self, timestamp, featid, cam_id, uv, uvn):
+        ids = np.ascontiguousarray(featid, dtype=np.int64)
+        cam = np.ascontiguousarray(cam_id, dtype=np.int32)
+        uv = np.ascontiguousarray(uv, dtype=np.float32)
+        uvn = np.ascontiguousarray(uvn, dtype=np.float32)
+        rc = self.lib.ovgpu_tracks_append(self._ctx, float(timestamp), len(ids), ids.ctypes.data_as(C.POINTER(C.c_int64)), _ip(cam),
+                                          uv.ctypes.data_as(capi.c_float_p), uvn.ctypes.data_as(capi.c_float_p))
+        capi.check(rc, "ovgpu_tracks_append")
+
+    def tracks_erase(self, featid):
+        ids = np.ascontiguousarray(featid, dtype=np.int64)
+        capi.check(self.lib.ovgpu_tracks_erase(self._ctx, len(ids), ids.ctypes.data_as(C.POINTER(C.c_int64))), "ovgpu_tracks_erase")
+
+    def tracks_not_containing_newer(self, timestamp):
+        n = C.c_int32(0)
+        capi.check(self.lib.ovgpu_tracks_not_containing_newer(self._ctx, float(timestamp), 0, None, C.byref(n)), "ovgpu_tracks_not_containing_newer")
+        ids = np.zeros(max(n.value, 1), np.int64)
+        capi.check(self.lib.ovgpu_tracks_not_containing_newer(self._ctx, float(timestamp), n.value, ids.ctypes.data_as(C.POINTER(C.c_int64)), C.byref(n)),
+                   "ovgpu_tracks_not_containing_newer")
+        return ids[: n.value]
+
+    def tracks_count(self):
+        n = C.c_int32(0)
+        capi.check(self.lib.ovgpu_tracks_count(self._ctx, C.byref(n)), "ovgpu_tracks_count")
+        return n.value
+
+    def tracks_to_features(self, featid, clone_times):
+        ids = np.ascontiguousarray(featid, dtype=np.int64)
+        ct = np.ascontiguousarray(clone_times, dtype=np.float64)
+        capi.check(self.lib.ovgpu_tracks_to_features(self._ctx, len(ids), ids.ctypes.data_as(C.POINTER(C.c_int64)), _dp(ct)), "ovgpu_tracks_to_features")
+        self.F = len(ids)
+
+    def get_features(self):
+        F, M = C.c_int32(0), C.c_int32(0)
+        capi.check(self.lib.ovgpu_get_features(self._ctx, C.byref(F), C.byref(M), None, None, None, None, None), "ovgpu_get_features")
+        f, m = F.value, M.value
+        out = dict(meas_offsets=np.zeros(f + 1, np.int32), uv=np.zeros(2 * m, np.float32), uvn=np.zeros(2 * m, np.float32),
+                   clone_idx=np.zeros(m, np.int32), cam_idx=np.zeros(m, np.int32))
+        capi.check(self.lib.ovgpu_get_features(self._ctx, C.byref(F), C.byref(M), _ip(out["meas_offsets"]), out["uv"].ctypes.data_as(capi.c_float_p),
+                                               out["uvn"].ctypes.data_as(capi.c_float_p), _ip(out["clone_idx"]), _ip(out["cam_idx"])), "ovgpu_get_features")
+        return out
+
     # ---- UpdaterSLAM::change_anchors / perform_anchor_change (UpdaterSLAM.cpp:481-647) ----
     def change_anchor(self, lm_index, new_cam, new_clone):
         capi.check(self.lib.ovgpu_slam_change_anchor(self._ctx, int(lm_index), int(new_cam), int(new_clone)), "ovgpu_slam_change_anchor")

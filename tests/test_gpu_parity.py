@@ -937,3 +937,100 @@ def test_delayed_init_parity_random_shapes(Updater, oracle, seed):
     if gate.any() and np.abs(ref["chi2"][gate] / ref["chi2_thresh"][gate] - 1.0).min() < 1e-6:
         pytest.skip("a feature sits on the gate threshold: the chains may legitimately diverge")
     _check_delayed_init(out, ref, post)
+
+
+# --------------------------------------------------------------------------- FeatureDatabase on the device
+def test_track_store_builds_the_same_batch_as_the_host(Updater, oracle):
+    """Observations are appended frame by frame (FeatureDatabase::update_feature), tracks get lost, erased and re-opened;
+    the batch assembled on the device equals — bit for bit — clean_old_measurements + the shim's flattening done in numpy,
+    and an update on it equals the update on the uploaded batch."""
+    prob = synth.make_problem(2, F=4)   # the state only (30 clones, 2 cameras)
+    opts = capi.default_options(chi2_multipler=1.0)
+    up = Updater(opts)
+    up.set_problem(prob)
+    up.tracks_create(512, 96)
+    rng = np.random.default_rng(17)
+    T = 40                                   # frames; the window is the last 30
+    times = 100.0 + 0.05 * np.arange(T)
+    db = {}                                  # host FeatureDatabase: id -> list of (cam, time, uv, uvn)
+    alive = list(range(60))
+    next_id = 60
+    for t in range(T):
+        for cam in range(prob.K):
+            seen = [i for i in alive if rng.random() < 0.8]
+            if not seen:
+                continue
+            uv = rng.uniform(0, 700, (len(seen), 2)).astype(np.float32)
+            uvn = rng.uniform(-1, 1, (len(seen), 2)).astype(np.float32)
+            up.tracks_append(times[t], seen, np.full(len(seen), cam), uv, uvn)
+            for j, i in enumerate(seen):
+                db.setdefault(i, []).append((cam, times[t], uv[j], uvn[j]))
+        if t % 7 == 6:  # some tracks end, new ones start (ids are never reused by the front end, slots are)
+            lost = list(rng.choice(alive, 8, replace=False))
+            alive = [i for i in alive if i not in lost] + list(range(next_id, next_id + 8))
+            next_id += 8
+        if t == 20:     # FeatureDatabase::cleanup of used features
+            gone = [i for i in db if i not in alive][:10]
+            up.tracks_erase(gone)
+            for i in gone:
+                del db[i]
+    assert up.tracks_count() == len(db)
+    lost_ref = sorted(i for i, obs in db.items() if not max(o[1] for o in obs) >= times[T - 1])
+    np.testing.assert_array_equal(up.tracks_not_containing_newer(times[T - 1]), lost_ref)
+    # ---- the batch of an update: the lost tracks + an unknown id, window = last C frames
+    clone_times = times[T - prob.C:]
+    sel = lost_ref[:25] + [10 ** 9]
+    up.tracks_to_features(sel, clone_times)
+    got = up.get_features()
+    offs, uv, uvn, ci, cam_idx = [0], [], [], [], []
+    lut = {tt: k for k, tt in enumerate(clone_times)}
+    for i in sel:
+        obs = db.get(i, [])
+        for cam in range(prob.K):           # camera groups ascending, append (= time) order inside
+            for (c_, tt, a, b) in obs:
+                if c_ == cam and tt in lut:
+                    uv += list(a), ; uvn += list(b), ; ci.append(lut[tt]); cam_idx.append(cam)
+        offs.append(len(ci))
+    np.testing.assert_array_equal(got["meas_offsets"], offs)
+    np.testing.assert_array_equal(got["clone_idx"], ci)
+    np.testing.assert_array_equal(got["cam_idx"], cam_idx)
+    np.testing.assert_array_equal(got["uv"], np.asarray(uv, np.float32).reshape(-1))
+    np.testing.assert_array_equal(got["uvn"], np.asarray(uvn, np.float32).reshape(-1))
+    assert got["meas_offsets"][-1] == got["meas_offsets"][-2]   # the unknown id is an empty track
+    up.close()
+
+
+def test_track_store_feeds_the_update(Updater, oracle):
+    """Real tracks go through the store: the update on the device-assembled batch is bit-identical to the update on the
+    uploaded one (same bytes in, same kernels)."""
+    prob = synth.make_problem(2, F=50)
+    # the store's canonical order inside a track: camera id ascending, then time (synth starts with the camera that saw more)
+    feat_of = np.repeat(np.arange(prob.F), np.diff(prob.meas_offsets))
+    perm = np.lexsort((prob.clone_idx, prob.cam_idx, feat_of))
+    prob.uv, prob.uvn = prob.uv.reshape(-1, 2)[perm].reshape(-1), prob.uvn.reshape(-1, 2)[perm].reshape(-1)
+    prob.clone_idx, prob.cam_idx = prob.clone_idx[perm], prob.cam_idx[perm]
+    opts = capi.default_options(chi2_multipler=1.0)
+    up = Updater(opts)
+    up.set_problem(prob)
+    ref = up.update()
+    up.reset_state()
+    up.tracks_create(128, 64)
+    clone_times = 50.0 + 0.1 * np.arange(prob.C)
+    uv2, uvn2 = prob.uv.reshape(-1, 2), prob.uvn.reshape(-1, 2)
+    for cl in range(prob.C):                       # frame by frame, camera by camera, as a front end would deliver them
+        for cam in range(prob.K):
+            idx = np.flatnonzero((prob.clone_idx == cl) & (prob.cam_idx == cam))
+            if len(idx):
+                up.tracks_append(clone_times[cl], 1000 + feat_of[idx], np.full(len(idx), cam), uv2[idx], uvn2[idx])
+    up.tracks_to_features(1000 + np.arange(prob.F), clone_times)
+    got = up.get_features()
+    np.testing.assert_array_equal(got["meas_offsets"], prob.meas_offsets)
+    np.testing.assert_array_equal(got["clone_idx"], prob.clone_idx)
+    np.testing.assert_array_equal(got["cam_idx"], prob.cam_idx)
+    np.testing.assert_array_equal(got["uv"], prob.uv)
+    out = up.update()
+    for k in ("feat_status", "chi2", "dx", "P"):
+        np.testing.assert_array_equal(out[k], ref[k])
+    with pytest.raises(RuntimeError):   # a full track refuses the whole call
+        up.tracks_append(99.0, np.full(65, 5), np.zeros(65), np.zeros((65, 2)), np.zeros((65, 2)))
+    up.close()
