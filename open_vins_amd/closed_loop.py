@@ -121,16 +121,41 @@ def _initial_state(stream):
     return base, N, P, clones, calib, intr
 
 
-def run_resident(stream: Stream, up):
+def run_resident(stream: Stream, up, track_store=False):
     """The same filter with the covariance RESIDENT on the device between frames: cloning = ovgpu_state_augment_clone +
     ovgpu_state_propagate, marginalisation = ovgpu_state_marginalize, update = ovgpu_set_features + ovgpu_msckf_update;
-    the state is uploaded once.  `up` is an open_vins_amd.updater.UpdaterMSCKF."""
+    the state is uploaded once.  With track_store the observations live on the device as well: every frame appends its
+    observations (ovgpu_tracks_append), the batch of the frame's MSCKF features — the schedule of the stream: a track is used
+    at the frame after its nominal end, which run() follows too — is assembled on the device (ovgpu_tracks_to_features)
+    and the tracks are erased after use.  `up` is an open_vins_amd.updater.UpdaterMSCKF."""
     C = stream.C
     base, N, P, clones, calib, intr = _initial_state(stream)
     frames = list(range(C))
     up.set_problem(_frame_problem(stream, [], frames, N, P, clones, clones.copy(), calib, intr))
     est, used = {frames[-1]: clones[-1].copy()}, {}
     last = clones[-1].copy()
+    time_of = lambda f: 10.0 + 0.1 * f  # clone / observation time of frame f
+    by_frame, ids_at = {}, {}
+    if track_store:
+        n_tracks = sum(len(v) for v in stream.tracks.values())
+        up.tracks_create(n_tracks + 8, C + 4)
+        fid = 0
+        for t in sorted(stream.tracks):  # ids in the order the host loop meets the tracks
+            if t < C:
+                continue                  # tracks that end before the first update frame are never used by run() either
+            for obs in stream.tracks[t]:
+                for (f, un, vn, xu, yu) in obs:
+                    by_frame.setdefault(f, []).append((fid, un, vn, xu, yu))
+                ids_at.setdefault(t, []).append(fid)
+                fid += 1
+
+        def feed(f):  # the front end's delivery of frame f (one camera)
+            o = by_frame.get(f, [])
+            if o:
+                up.tracks_append(time_of(f), [x[0] for x in o], np.zeros(len(o), np.int32), np.array([[x[1], x[2]] for x in o], np.float32),
+                                 np.array([[x[3], x[4]] for x in o], np.float32))
+        for f in range(C):
+            feed(f)
     for t in range(C, stream.T):
         new, dR = _compose(last, stream.truth[t - 1], stream.truth[t])
         new = synth.boxplus_pose(new, stream.clone_noise[t])
@@ -142,13 +167,24 @@ def run_resident(stream: Stream, up):
         up.state_marginalize(base, 6)                                    # the oldest clone leaves the window
         frames = frames[1:] + [t]
         tracks = stream.tracks[t]
-        if tracks:
-            dummy = np.zeros((C, 7))
-            dummy[:, 3] = 1.0
-            up.set_features(_frame_problem(stream, tracks, frames, N, P, dummy, dummy, calib, intr))
+        if track_store:
+            feed(t)
+            ids = ids_at.get(t, [])
+            have = len(ids) > 0
+            if have:
+                up.tracks_to_features(ids, [time_of(f) for f in frames])
+        else:
+            have = bool(tracks)
+            if have:
+                dummy = np.zeros((C, 7))
+                dummy[:, 3] = 1.0
+                up.set_features(_frame_problem(stream, tracks, frames, N, P, dummy, dummy, calib, intr))
+        if have:
             out = up.update()
             used[t] = int(np.sum(out["feat_status"] == 0))
             last = out["clone_q_p"][-1].copy()
+            if track_store:
+                up.tracks_erase(ids)
         else:
             last = up.get_state(P=False)["clone_q_p"][-1].copy()
         est[t] = last.copy()

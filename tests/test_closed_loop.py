@@ -62,3 +62,17 @@ def test_resident_window_matches_the_host_loop(stream, oracle_run):
     # Phi P Phi^T + Q is formed entry by entry like the reference's (StateHelper.cpp:85-90): symmetric up to rounding only
     assert post["P"].shape == (16 + 14 + 6 * stream.C,) * 2
     np.testing.assert_allclose(post["P"], post["P"].T, rtol=0, atol=1e-18)
+
+
+@pytest.mark.gpu
+def test_resident_window_and_track_store(stream, oracle_run):
+    """SURVEY 8f N2 + N3 together: observations appended per frame to the device-resident feature database, lost tracks
+    queried, their batch assembled on the device, window bookkeeping and update on the resident covariance — the trajectory
+    of the oracle-driven host loop again."""
+    from open_vins_amd.updater import UpdaterMSCKF
+    up = UpdaterMSCKF(capi.default_options(**OPTS))
+    res = closed_loop.run_resident(stream, up, track_store=True)
+    assert up.tracks_count() == 0           # every track was used once and erased
+    up.close()
+    assert res["used"] == oracle_run["used"]
+    assert np.abs(res["est"] - oracle_run["est"]).max() < 1e-8
