@@ -53,10 +53,6 @@ __host__ __device__ inline size_t qr_leaf_lds_bytes(int NT) {
   return ((size_t)2 * 16 * (NT * 16 + 2) + (size_t)4 * YSZ + 2 * 256 + 2 * 16 + 8 * (BQ + 2) + (size_t)BQ * 64) * sizeof(double);
 }
 
-struct Lds {
-  double *Rp, *Yp1, *Yp3, *Tm, *U0, *xb, *hb;
-};
-
 // Block reflector of one panel applied to up to two tiles that hold the same rows.  cola / colb: first column of the tile.
 template <bool UA, bool UB>
 __device__ __forceinline__ void apply_block(double (&ya)[BQ], double (&yb)[BQ], const double *Yp1, const double *Yp3, const double *Tm, const double *U0,
