@@ -393,6 +393,14 @@ int ovgpu_slam_change_anchor(ovgpu_ctx *ctx, int32_t lm_index, int32_t new_ancho
 int ovgpu_slam_change_anchors(ovgpu_ctx *ctx, int32_t marg_clone, int32_t new_clone,
                               int32_t *n_changed);
 
+/* Per-feature measurement noise and gate multiplier for the uploaded batch — UpdaterSLAM keeps two
+ * UpdaterOptions, `slam` and `aruco`, and picks per feature by its id (UpdaterSLAM.cpp:227-232,
+ * :392-409).  sigma_pix / chi2_multipler [F] (either may be NULL = the context's value for every
+ * feature).  Applies to the SLAM update, the delayed initialisation and the MSCKF update alike,
+ * until the next batch is uploaded.  The rows of a feature enter the stacked system scaled by
+ * sigma_ctx / sigma_f, i.e. the returned compressed system (mode A) has the context's sigma.  */
+int ovgpu_set_feature_options(ovgpu_ctx *ctx, const double *sigma_pix, const double *chi2_multipler);
+
 /* ------------------------------------------------------------------------- */
 /* Window bookkeeping on the RESIDENT covariance: the steps either   */
 /* side of the update, so that P does not cross PCIe between frames.  The means of the    */

@@ -191,6 +191,7 @@ def declare(lib):
         "ovgpu_tracks_not_containing_newer": (C.c_int, [ctxp, C.c_double, C.c_int32, C.POINTER(C.c_int64), c_int32_p]),
         "ovgpu_tracks_count": (C.c_int, [ctxp, c_int32_p]),
         "ovgpu_tracks_to_features": (C.c_int, [ctxp, C.c_int32, C.POINTER(C.c_int64), c_double_p]),
+        "ovgpu_set_feature_options": (C.c_int, [ctxp, c_double_p, c_double_p]),
         "ovgpu_get_features": (C.c_int, [ctxp, c_int32_p, c_int32_p, c_int32_p, c_float_p, c_float_p, c_int32_p, c_int32_p]),
         "ovgpu_slam_change_anchor": (C.c_int, [ctxp, C.c_int32, C.c_int32, C.c_int32]),
         "ovgpu_slam_change_anchors": (C.c_int, [ctxp, C.c_int32, C.c_int32, c_int32_p]),

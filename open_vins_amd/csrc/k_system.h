@@ -215,6 +215,12 @@ __global__ void __launch_bounds__(SYS_NT) k_system(SysParams p) {
     //   3-dof SLAM landmark                  nproj 0, columns 0..2                                  (UpdaterSLAM.cpp:381-383)
     //   ANCHORED_INVERSE_DEPTH_SINGLE        nproj 2 (the bearing is marginalised), column 2 = depth (UpdaterSLAM.cpp:371-379)
     const int lm_size = slam ? p.lm_size : 0, lm_off = 3 - lm_size, nproj = 3 - lm_size;
+    // per-feature measurement noise and gate multiplier (UpdaterSLAM's ArUco options, UpdaterSLAM.cpp:227-232, :392-409): the
+    // rows leave the kernel scaled by sigma / sigma_f, so that the stacked system keeps ONE isotropic noise level (a QR of the
+    // stack only preserves R = sigma^2 I)
+    const double sig2_f = p.feat_sigma ? p.feat_sigma[f] * p.feat_sigma[f] : p.opt.sigma_pix_sq;
+    const double mult_f = p.feat_chi2mult ? p.feat_chi2mult[f] : p.opt.chi2_multipler;
+    const double oscale = p.feat_sigma ? sqrt(p.opt.sigma_pix_sq) / p.feat_sigma[f] : 1.0;
     const int lm_id = slam ? p.feat_lm[f] : -1, lm_col = slam ? p.feat_lmcol[f] : -1, lm_cov = slam ? p.feat_lmcov[f] : -1;
     V3 p_FinG_fej = slam ? load_v3(p.p_fej + 3 * f) : p_FinG; // fej == value for MSCKF features (UpdaterMSCKF.cpp:186-194)
     int anchor_cam = -1, anchor_clone = -1;
@@ -462,7 +468,7 @@ __global__ void __launch_bounds__(SYS_NT) k_system(SysParams p) {
             const int r = r0 + rr;
             if (q > r) continue;
             const double *Tr = Tch + (size_t)rr * D;
-            double sv = (q == r) ? p.opt.sigma_pix_sq : 0.0;
+            double sv = (q == r) ? sig2_f : 0.0;
 #pragma unroll
             for (int k = 0; k < 6; k++) sv = fma(Tr[c_cl + k], hcl[k], sv);
             if (c_po >= 0) {
@@ -578,7 +584,7 @@ __global__ void __launch_bounds__(SYS_NT) k_system(SysParams p) {
       // StateHelper::initialize gates the 2m-3 projected rows against the quantile of the res.rows() it was handed: 2m, or
       // 2m-2 when the bearing was projected out before (StateHelper.cpp:466, UpdaterSLAM.cpp:181-196)
       const int dof = p.init ? n - p.init_dof_less : n - nproj;
-      const double thr = p.opt.chi2_multipler * p.chi2_table[min(dof, p.chi2_table_len - 1)]; // UpdaterMSCKF.cpp:216-222
+      const double thr = mult_f * p.chi2_table[min(dof, p.chi2_table_len - 1)]; // UpdaterMSCKF.cpp:216-222
       if (tid == 0) {
         p.chi2[f] = chi2;
         p.chi2_thresh[f] = thr;
@@ -686,7 +692,7 @@ __global__ void __launch_bounds__(SYS_NT) k_system(SysParams p) {
         if (nproj == 0) { // UpdaterSLAM.cpp:381-383, :427-447: the rows go into the stack as they are, landmark columns included
           double *out = p.Hbig + orow0 * LD + c;
 #pragma unroll 4
-          for (int r = 0; r < n; r++) out[(size_t)r * LD] = hval(r >> 1, r & 1);
+          for (int r = 0; r < n; r++) out[(size_t)r * LD] = oscale * hval(r >> 1, r & 1);
           continue;
         }
         // y = V^T h
@@ -704,7 +710,7 @@ __global__ void __launch_bounds__(SYS_NT) k_system(SysParams p) {
 #pragma unroll
           for (int r = 0; r < 3; r++) {
             const double *v = V + (size_t)3 * r;
-            p.init_out[(size_t)r * LD + c] = hval(r >> 1, r & 1) - (v[0] * z0 + v[1] * z1 + v[2] * z2);
+            p.init_out[(size_t)r * LD + c] = oscale * (hval(r >> 1, r & 1) - (v[0] * z0 + v[1] * z1 + v[2] * z2));
           }
         }
         double *out = p.Hbig + orow0 * LD + c;
@@ -712,13 +718,13 @@ __global__ void __launch_bounds__(SYS_NT) k_system(SysParams p) {
         for (int r = nproj; r < n; r++) {
           const double h = hval(r >> 1, r & 1);
           const double *v = V + (size_t)3 * r;
-          out[(size_t)(r - nproj) * LD] = h - (v[0] * z0 + v[1] * z1 + v[2] * z2);
+          out[(size_t)(r - nproj) * LD] = oscale * (h - (v[0] * z0 + v[1] * z1 + v[2] * z2));
         }
       }
     }
     if (p.init && tid < 9) { // H_finit = R1 (3 x 3 upper triangular): Q^T H_f, diagonal = beta
       const int i = tid / 3, j = tid % 3;
-      p.init_out[(size_t)3 * LD + tid] = j < i ? 0.0 : (j == i ? hq[58 + i] : rows[(size_t)(i >> 1) * RS + RO_HF + 3 * (i & 1) + j]);
+      p.init_out[(size_t)3 * LD + tid] = oscale * (j < i ? 0.0 : (j == i ? hq[58 + i] : rows[(size_t)(i >> 1) * RS + RO_HF + 3 * (i & 1) + j]));
     }
     SYS_T(8)
   }

@@ -140,6 +140,8 @@ struct ovgpu_ctx {
   DevBuf<int64_t> row_off;
   DevBuf<double> pA, pG, chi2, chi2_thr;
   DevBuf<int32_t> anchor, status, sys_order; // sys_order: feature indices by descending track length
+  DevBuf<double> feat_sigma, feat_mult;      // per-feature noise / gate multiplier (ovgpu_set_feature_options)
+  bool have_feat_sigma = false, have_feat_mult = false;
   DevBuf<double> chi2_table;
   int chi2_table_len = 0;
   std::vector<double> h_chi2_table;
@@ -358,7 +360,7 @@ void ovgpu_destroy(ovgpu_ctx *c) {
   c->intr_col.release(), c->col_cov.release(), c->col_kind.release(), c->col_sub.release(), c->col_var.release();
   c->tab_clone.release(), c->tab_cam.release(), c->tab_cc.release();
   c->meas_offsets.release(), c->meas_cc.release(), c->uv.release(), c->uvn.release(), c->row_off.release();
-  c->pA.release(), c->pG.release(), c->chi2.release(), c->chi2_thr.release(), c->anchor.release(), c->status.release(), c->sys_order.release();
+  c->pA.release(), c->pG.release(), c->chi2.release(), c->chi2_thr.release(), c->anchor.release(), c->status.release(), c->sys_order.release(), c->feat_sigma.release(), c->feat_mult.release();
   c->chi2_table.release(), c->Hbig.release(), c->gate_ws.release(), c->Rws.release(), c->tree_nodes.release(), c->tree_nodes2.release(), c->tree_flags.release(), c->tree_err.release(), c->Mt.release(), c->Aaug.release(), c->Yaug.release();
   c->pFej.release(), c->lm_val.release(), c->lm_fej.release(), c->feat_lm.release(), c->feat_lmcol.release(), c->feat_lmcov.release(), c->lm_cov.release();
   c->feat_anchor.release(), c->lm_col.release(), c->lm_anchor.release(), c->lm_index.release(), c->Ppad.release(), c->init_ws.release(), c->dx_seq.release();
@@ -617,6 +619,7 @@ static int begin_feature_batch(ovgpu_ctx *c, int F, int M, const int32_t *offset
     m_max = std::max(m_max, m);
   }
   c->F = F, c->M = M, c->m_max = m_max;
+  c->have_feat_sigma = c->have_feat_mult = false; // per-feature options belong to a batch
   c->h_offsets.assign(offsets, offsets + (F > 0 ? F + 1 : 0));
   if (F == 0) c->h_offsets.assign(1, 0);
 
@@ -724,6 +727,7 @@ static int enqueue_system(ovgpu_ctx *c, int f_one = -1, int init_rep = 0) {
   p.slam = c->slam_rows ? 1 : 0;
   p.p_fej = c->pFej.p, p.feat_lm = c->feat_lm.p, p.feat_lmcol = c->feat_lmcol.p, p.feat_lmcov = c->feat_lmcov.p, p.feat_anchor = c->feat_anchor.p;
   p.lm_size = 3, p.init_dof_less = 0;
+  p.feat_sigma = c->have_feat_sigma ? c->feat_sigma.p : nullptr, p.feat_chi2mult = c->have_feat_mult ? c->feat_mult.p : nullptr;
   if (p.slam) { // the landmarks' representation, not the MSCKF features'; single depth = MSCKF inverse depth Jacobians (UpdaterSLAM.cpp:338-341)
     p.lm_size = lm_dof(c->lm_rep);
     p.opt.feat_rep = p.lm_size == 1 ? OVGPU_REP_ANCHORED_MSCKF_INVERSE_DEPTH : c->lm_rep;
@@ -1510,6 +1514,26 @@ int ovgpu_slam_change_anchors(ovgpu_ctx *c, int32_t marg_clone, int32_t new_clon
     n++;
   }
   if (n_changed) *n_changed = n;
+  return OVGPU_OK;
+}
+
+int ovgpu_set_feature_options(ovgpu_ctx *c, const double *sigma_pix, const double *chi2_multipler) {
+  if (!c) return set_err(OVGPU_ERR_INVALID, "null ctx");
+  if (!c->have_feats) return set_err(OVGPU_ERR_NO_STATE, "no feature batch is resident");
+  HIPCHK(hipSetDevice(c->device));
+  const int F = c->F;
+  for (int f = 0; f < F && sigma_pix; f++)
+    if (!(sigma_pix[f] > 0.0)) return set_err(OVGPU_ERR_INVALID, "sigma_pix must be positive");
+  c->have_feat_sigma = sigma_pix != nullptr && F > 0, c->have_feat_mult = chi2_multipler != nullptr && F > 0;
+  if (c->have_feat_sigma) {
+    HIPCHK(c->feat_sigma.reserve(F));
+    HIPCHK(upload(c->feat_sigma.p, sigma_pix, sizeof(double) * F, c->stream));
+  }
+  if (c->have_feat_mult) {
+    HIPCHK(c->feat_mult.reserve(F));
+    HIPCHK(upload(c->feat_mult.p, chi2_multipler, sizeof(double) * F, c->stream));
+  }
+  HIPCHK(hipStreamSynchronize(c->stream));
   return OVGPU_OK;
 }
 

@@ -66,6 +66,8 @@ struct SysParams {
   // UpdaterSLAM::update mode (landmarks live in the state): no nullspace projection, gate on all 2m rows
   int slam;
   int lm_size;              // 3, or 1 for ANCHORED_INVERSE_DEPTH_SINGLE landmarks (the bearing columns of H_f are projected out)
+  const double *feat_sigma;    // [F] per-feature sigma_pix, or nullptr (the context's)
+  const double *feat_chi2mult; // [F] per-feature chi2 multiplier, or nullptr
   int init_dof_less;        // init mode: 0, or 2 for a single-depth landmark (StateHelper::initialize sees 2m - 2 residual rows)
   const double *p_fej;      // [3F] first-estimate position of the feature's landmark
   const int32_t *feat_lm;   // [F] landmark index, first Jacobian column and covariance id of its 3 dof

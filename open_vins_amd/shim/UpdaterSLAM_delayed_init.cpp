@@ -97,6 +97,8 @@ void UpdaterSLAM::delayed_init(std::shared_ptr<State> state, std::vector<std::sh
   // ---- 1. clean the tracks (:75-96) and flatten them
   ovgpu_shim::FlatFeatures ff;
   auto it0 = feature_vec.begin();
+  std::vector<double> f_sigma, f_mult; // ArUco corners use _options_aruco (:226-232)
+  bool any_aruco = false;
   while (it0 != feature_vec.end()) {
     (*it0)->clean_old_measurements(fs.clone_times);
     int ct_meas = 0;
@@ -113,6 +115,10 @@ void UpdaterSLAM::delayed_init(std::shared_ptr<State> state, std::vector<std::sh
                     [&](size_t i, float &a, float &b) { a = uvn[i](0), b = uvn[i](1); }, clones);
     }
     ff.end_feature();
+    const bool is_aruco = (int)f.featid < state->_options.max_aruco_features; // :226-232
+    any_aruco |= is_aruco;
+    f_sigma.push_back(is_aruco ? _options_aruco.sigma_pix : _options_slam.sigma_pix);
+    f_mult.push_back(is_aruco ? _options_aruco.chi2_multipler : _options_slam.chi2_multipler);
     it0++;
   }
   if (feature_vec.empty()) return;
@@ -139,6 +145,7 @@ void UpdaterSLAM::delayed_init(std::shared_ptr<State> state, std::vector<std::sh
   g_init_ctx->check(ovgpu_set_state(ctx, &sv), "ovgpu_set_state");
   g_init_ctx->check(ovgpu_set_landmarks(ctx, &lv), "ovgpu_set_landmarks");
   g_init_ctx->check(ovgpu_set_features(ctx, &fv), "ovgpu_set_features");
+  if (any_aruco) g_init_ctx->check(ovgpu_set_feature_options(ctx, f_sigma.data(), f_mult.data()), "ovgpu_set_feature_options");
   const int F = fv.F, Nmax = N0 + lsz * F;
   std::vector<int32_t> status(F), new_cov(F), acam(F), aclone(F);
   std::vector<double> new_val(3 * (size_t)F), new_fej(3 * (size_t)F), dx_seq((size_t)F * Nmax), Pout((size_t)Nmax * Nmax);

@@ -60,6 +60,8 @@ void UpdaterSLAM::update(std::shared_ptr<State> state, std::vector<std::shared_p
   ovgpu_shim::FlatFeatures ff;
   std::vector<double> lm_value, lm_fej;
   std::vector<int32_t> lm_cov, lm_index, lm_anchor_cam, lm_anchor_clone;
+  std::vector<double> f_sigma, f_mult; // per-feature options: ArUco corners use _options_aruco (:392-394, :408-409)
+  bool any_aruco = false;
   const auto rep = state->_options.feat_rep_slam;
   const bool single = rep == LandmarkRepresentation::Representation::ANCHORED_INVERSE_DEPTH_SINGLE;
   auto it0 = feature_vec.begin();
@@ -97,6 +99,10 @@ void UpdaterSLAM::update(std::shared_ptr<State> state, std::vector<std::shared_p
     lm_cov.push_back(landmark->id());
     lm_value.insert(lm_value.end(), v.data(), v.data() + 3), lm_fej.insert(lm_fej.end(), vf.data(), vf.data() + 3);
     var_of_cov.push_back(landmark);
+    const bool is_aruco = (int)f.featid < state->_options.max_aruco_features; // :392
+    any_aruco |= is_aruco;
+    f_sigma.push_back(is_aruco ? _options_aruco.sigma_pix : _options_slam.sigma_pix);
+    f_mult.push_back(is_aruco ? _options_aruco.chi2_multipler : _options_slam.chi2_multipler);
     it0++;
   }
   if (feature_vec.empty()) return;
@@ -105,7 +111,7 @@ void UpdaterSLAM::update(std::shared_ptr<State> state, std::vector<std::shared_p
   if (!g_slam_ctx) {
     ovgpu_options o;
     ovgpu_default_options(&o);
-    o.chi2_multipler = _options_slam.chi2_multipler, o.sigma_pix = _options_slam.sigma_pix; // aruco tags use _options_aruco: keep them on the CPU path
+    o.chi2_multipler = _options_slam.chi2_multipler, o.sigma_pix = _options_slam.sigma_pix; // ArUco corners: per-feature options below
     o.do_fej = state->_options.do_fej, o.do_calib_camera_pose = state->_options.do_calib_camera_pose;
     o.do_calib_camera_intrinsics = state->_options.do_calib_camera_intrinsics, o.feat_rep_msckf = OVGPU_REP_GLOBAL_3D;
     g_slam_ctx.reset(new ovgpu_shim::Context(o));
@@ -119,6 +125,8 @@ void UpdaterSLAM::update(std::shared_ptr<State> state, std::vector<std::shared_p
   g_slam_ctx->check(ovgpu_set_state(g_slam_ctx->get(), &sv), "ovgpu_set_state");
   g_slam_ctx->check(ovgpu_set_landmarks(g_slam_ctx->get(), &lv), "ovgpu_set_landmarks");
   g_slam_ctx->check(ovgpu_set_features(g_slam_ctx->get(), &fv), "ovgpu_set_features");
+  if (any_aruco) // rows come back scaled to _options_slam.sigma_pix, so R_big below stays isotropic
+    g_slam_ctx->check(ovgpu_set_feature_options(g_slam_ctx->get(), f_sigma.data(), f_mult.data()), "ovgpu_set_feature_options");
   const int F = fv.F, Dmax = 6 * sv.C + 14 * sv.K + 3 * lv.L; // upper bound (a single-depth landmark has one column)
   std::vector<int32_t> status(F), col_cov(Dmax);
   std::vector<double> H((size_t)Dmax * Dmax), r(Dmax);

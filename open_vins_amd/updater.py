@@ -261,6 +261,15 @@ class UpdaterMSCKF:
         capi.check(self.lib.ovgpu_tracks_to_features(self._ctx, len(ids), ids.ctypes.data_as(C.POINTER(C.c_int64)), _dp(ct)), "ovgpu_tracks_to_features")
         self.F = len(ids)
 
+    def set_feature_options(self, sigma_pix=None, chi2_multipler=None):
+        """Per-feature sigma_pix / chi2 multiplier of the resident batch (UpdaterSLAM's ArUco options, UpdaterSLAM.cpp:392-409);
+        None keeps the context's value.  Cleared by the next feature upload."""
+        def arr(a):
+            return None if a is None else np.ascontiguousarray(np.broadcast_to(np.asarray(a, dtype=np.float64), (self.F,)))
+        s, m = arr(sigma_pix), arr(chi2_multipler)
+        capi.check(self.lib.ovgpu_set_feature_options(self._ctx, _dp(s) if s is not None else None, _dp(m) if m is not None else None),
+                   "ovgpu_set_feature_options")
+
     def get_features(self):
         F, M = C.c_int32(0), C.c_int32(0)
         capi.check(self.lib.ovgpu_get_features(self._ctx, C.byref(F), C.byref(M), None, None, None, None, None), "ovgpu_get_features")

@@ -1119,7 +1119,9 @@ int measurement_compress(double *H_x, double *res, int rows, int cols) {
 }
 
 // StateHelper::EKFUpdate — StateHelper.cpp:116-197 (R = sigma2 * I)
-int ekf_update(double *P, int N, const double *H, const double *res, int rows, int D, const int32_t *col_cov, double sigma2, double *dx) {
+// noise_rows (optional): the diagonal of a non-isotropic R (UpdaterSLAM stacks features with two different sigmas, UpdaterSLAM.cpp:444)
+int ekf_update(double *P, int N, const double *H, const double *res, int rows, int D, const int32_t *col_cov, double sigma2, double *dx,
+               const double *noise_rows = nullptr) {
   // M_a = P(:, cols) H^T   [N x rows]   (:137-146)
   std::vector<double> M((size_t)N * rows, 0.0);
   for (int i = 0; i < N; i++) {
@@ -1139,7 +1141,7 @@ int ekf_update(double *P, int N, const double *H, const double *res, int rows, i
     for (int b = a; b < rows; b++) {
       double s = 0;
       for (int j = 0; j < D; j++) s += Ha[j] * M[(size_t)col_cov[j] * rows + b];
-      if (a == b) s += sigma2;
+      if (a == b) s += noise_rows ? noise_rows[a] : sigma2;
       S[(size_t)a * rows + b] = s;
       S[(size_t)b * rows + a] = s;
     }
@@ -1543,9 +1545,10 @@ int oracle_msckf_update_given(const ovgpu_options *opts, const ovgpu_state_view 
 int oracle_slam_update(const ovgpu_options *opts, const ovgpu_state_view *st, const ovgpu_landmarks_view *lm, const ovgpu_features_view *fv,
                        const int32_t *lm_index, int32_t *feat_status, double *chi2_out, double *chi2_thresh_out, double *dx_out, double *P_out,
                        double *lm_out, int32_t *D_out, int32_t *col_cov_out, double *H_out, double *res_out, int32_t *rows_out,
-                       ovgpu_update_stats *stats) {
+                       ovgpu_update_stats *stats, const double *feat_sigma, const double *feat_chi2mult) {
   const ovgpu_options &o = *opts;
   const int F = fv->F, N = st->N, L = lm->L;
+  std::vector<double> noise_rows; // R_big's diagonal when the features do not share one sigma (:444)
   StateTables T = build_tables(st);
   ColumnMap cm = build_column_map(o, st);
   const double sigma2 = std::pow(o.sigma_pix, 2);
@@ -1645,7 +1648,9 @@ int oracle_slam_update(const ovgpu_options *opts, const ovgpu_state_view *st, co
         for (int k = 0; k < Dt; k++) sv += HP[(size_t)a * Dt + k] * H_x[(size_t)b * Dt + k];
         S[(size_t)a * r + b] = sv, S[(size_t)b * r + a] = sv;
       }
-    for (int a = 0; a < r; a++) S[(size_t)a * r + a] += sigma2;
+    const double sig2_f = feat_sigma ? feat_sigma[f] * feat_sigma[f] : sigma2;               // :392-394
+    const double mult_f = feat_chi2mult ? feat_chi2mult[f] : o.chi2_multipler;              // :408-409
+    for (int a = 0; a < r; a++) S[(size_t)a * r + a] += sig2_f;
     double chi2 = NAN;
     if (cholesky_lower(S.data(), r)) {
       std::vector<double> y(res.begin(), res.end());
@@ -1654,11 +1659,12 @@ int oracle_slam_update(const ovgpu_options *opts, const ovgpu_state_view *st, co
       for (int a = 0; a < r; a++) chi2 += res[a] * y[a];
     }
     const double chi2_check = (r < 500) ? chi2_table[r] : chi2_quantile(r, 0.95); // :399-405
-    chi2v[f] = chi2, thrv[f] = o.chi2_multipler * chi2_check;
-    if (chi2 > o.chi2_multipler * chi2_check) { // :410
+    chi2v[f] = chi2, thrv[f] = mult_f * chi2_check;
+    if (chi2 > mult_f * chi2_check) { // :410
       status[f] = OVGPU_FEAT_CHI2_REJECTED;
       continue;
     }
+    if (feat_sigma) noise_rows.insert(noise_rows.end(), r, sig2_f);
     std::memcpy(Hx_big.data() + ct_meas * (size_t)Dt, H_x.data(), (size_t)r * Dt * sizeof(double)); // :427-447
     std::memcpy(res_big.data() + ct_meas, res.data(), r * sizeof(double));
     ct_meas += r;
@@ -1668,7 +1674,9 @@ int oracle_slam_update(const ovgpu_options *opts, const ovgpu_state_view *st, co
   ovgpu_update_stats stl;
   std::memset(&stl, 0, sizeof(stl));
   stl.n_used = n_used, stl.n_rows = (int)ct_meas, stl.D = Dt, stl.n_rows_comp = (int)ct_meas;
-  if (ct_meas >= 1) stl.status = ekf_update(P.data(), N, Hx_big.data(), res_big.data(), (int)ct_meas, Dt, col_cov.data(), sigma2, dx.data()); // :470
+  if (ct_meas >= 1)
+    stl.status = ekf_update(P.data(), N, Hx_big.data(), res_big.data(), (int)ct_meas, Dt, col_cov.data(), sigma2, dx.data(),
+                            feat_sigma ? noise_rows.data() : nullptr); // :470
   if (feat_status)
     for (int f = 0; f < F; f++) feat_status[f] = status[f];
   if (chi2_out) std::memcpy(chi2_out, chi2v.data(), F * sizeof(double));
@@ -1706,7 +1714,8 @@ int oracle_slam_delayed_init(const ovgpu_options *opts, const ovgpu_state_view *
                              const int32_t *given_anchor, const int32_t *given_status, int32_t *feat_status, double *chi2_out,
                              double *chi2_thresh_out, int32_t *lm_cov_id, double *lm_value, double *lm_fej, int32_t *anchor_cam_out,
                              int32_t *anchor_clone_out, double *dx_seq, int32_t *N_out, double *P_out, double *clone_q_p_out,
-                             double *calib_q_p_out, double *intrinsics_out, double *lm_existing_out) {
+                             double *calib_q_p_out, double *intrinsics_out, double *lm_existing_out, const double *feat_sigma,
+                             const double *feat_chi2mult) {
   const ovgpu_options &o = *opts;
   const int F = fv->F, N0 = st_in->N, C = st_in->C, K = st_in->K, Nmax = N0 + (feat_rep == OVGPU_REP_ANCHORED_INVERSE_DEPTH_SINGLE ? 1 : 3) * F;
   const int L0 = lm ? lm->L : 0;
@@ -1765,6 +1774,8 @@ int oracle_slam_delayed_init(const ovgpu_options *opts, const ovgpu_state_view *
     const bool single = feat_rep == OVGPU_REP_ANCHORED_INVERSE_DEPTH_SINGLE;
     const int jrep = single ? OVGPU_REP_ANCHORED_MSCKF_INVERSE_DEPTH : feat_rep; // :151-155
     const int nL = single ? 1 : 3;                                                // landmark_size :199
+    const double sig2_f = feat_sigma ? feat_sigma[f] * feat_sigma[f] : sigma2;    // :226-228
+    const double mult_f = feat_chi2mult ? feat_chi2mult[f] : o.chi2_multipler;   // :231-232
     H_f.assign((size_t)n * 3, 0.0), H_x.assign((size_t)n * D, 0.0), res.assign(n, 0.0);
     int nf = 3;
     feature_jacobian_full(o, &st, T, fm, jrep, pG[f], pA[f], anchor[f], lc, H_f.data(), nf, H_x.data(), res.data()); // :165, fej == value (:155-162)
@@ -1817,7 +1828,7 @@ int oracle_slam_delayed_init(const ovgpu_options *opts, const ovgpu_state_view *
           for (int k = 0; k < D; k++) sv += HP[(size_t)a * D + k] * Hup[(size_t)b * D + k];
           S[(size_t)a * rup + b] = sv, S[(size_t)b * rup + a] = sv;
         }
-      for (int a = 0; a < rup; a++) S[(size_t)a * rup + a] += sigma2;
+      for (int a = 0; a < rup; a++) S[(size_t)a * rup + a] += sig2_f;
       double chi2 = NAN;
       if (cholesky_lower(S.data(), rup)) {
         std::vector<double> y(resup, resup + rup);
@@ -1826,8 +1837,8 @@ int oracle_slam_delayed_init(const ovgpu_options *opts, const ovgpu_state_view *
         for (int a = 0; a < rup; a++) chi2 += resup[a] * y[a];
       }
       const double chi2_check = chi2_quantile(n, 0.95); // :466-467: res.rows() as handed to initialize (2m, or 2m - 2 for the single depth)
-      chi2v[f] = chi2, thrv[f] = o.chi2_multipler * chi2_check;
-      if (chi2 > o.chi2_multipler * chi2_check) { // :468
+      chi2v[f] = chi2, thrv[f] = mult_f * chi2_check;
+      if (chi2 > mult_f * chi2_check) { // :468
         status[f] = OVGPU_FEAT_CHI2_REJECTED;
         continue;
       }
@@ -1846,7 +1857,7 @@ int oracle_slam_delayed_init(const ovgpu_options *opts, const ovgpu_state_view *
         for (int b = 0; b < nL; b++) {
           double sv = 0;
           for (int k = 0; k < D; k++) sv += Hxinit[(size_t)a * D + k] * M_a[(size_t)cm.col_cov[k] * nL + b];
-          Mm[(size_t)nL * a + b] = sv + (a == b ? sigma2 : 0.0);
+          Mm[(size_t)nL * a + b] = sv + (a == b ? sig2_f : 0.0);
         }
       // H_L^-1 of the upper-triangular nL x nL (:548)
       std::vector<double> inv((size_t)nL * nL, 0.0);
@@ -1901,7 +1912,7 @@ int oracle_slam_delayed_init(const ovgpu_options *opts, const ovgpu_state_view *
     // EKFUpdate with the updating portion (:476-478)
     if (rup > 0) {
       std::vector<double> dx(N, 0.0);
-      int rc = ekf_update(P.data(), N, Hup, resup, rup, D, cm.col_cov.data(), sigma2, dx.data());
+      int rc = ekf_update(P.data(), N, Hup, resup, rup, D, cm.col_cov.data(), sig2_f, dx.data());
       if (rc != OVGPU_OK) status_rc = rc;
       std::memcpy(dxs.data() + (size_t)f * Nmax, dx.data(), sizeof(double) * N);
       // Type::update of everything in the state

@@ -119,7 +119,8 @@ int oracle_slam_delayed_init(const ovgpu_options *opts, const ovgpu_state_view *
                              const int32_t *given_anchor, const int32_t *given_status, int32_t *feat_status, double *chi2_out,
                              double *chi2_thresh_out, int32_t *lm_cov_id, double *lm_value, double *lm_fej, int32_t *anchor_cam_out,
                              int32_t *anchor_clone_out, double *dx_seq, int32_t *N_out, double *P_out, double *clone_q_p_out,
-                             double *calib_q_p_out, double *intrinsics_out, double *lm_existing_out);
+                             double *calib_q_p_out, double *intrinsics_out, double *lm_existing_out, const double *feat_sigma,
+                             const double *feat_chi2mult);
 
 /* Window bookkeeping: StateHelper::marginalize (StateHelper.cpp:271-339), clone + augment_clone's time-offset
  * part (:341-391, :601-611), EKFPropagation (:36-114) on dense row-major covariances. */
@@ -136,7 +137,7 @@ int oracle_slam_update(const ovgpu_options *opts, const ovgpu_state_view *st, co
                        const ovgpu_features_view *fv, const int32_t *lm_index, int32_t *feat_status, double *chi2,
                        double *chi2_thresh, double *dx, double *P_out, double *lm_out, int32_t *D_out,
                        int32_t *col_cov_id, double *H_out, double *res_out, int32_t *rows_out,
-                       ovgpu_update_stats *stats);
+                       ovgpu_update_stats *stats, const double *feat_sigma, const double *feat_chi2mult);
 
 #ifdef __cplusplus
 }

@@ -181,8 +181,16 @@ def msckf_update(opts, views, want_compressed=False, given=None):
     return out
 
 
-def slam_update(opts, views, want_stack=False):
-    """UpdaterSLAM::update (oracle_slam_update); views must carry landmarks (any 3-dof representation)."""
+def _opt_arr(a, F):
+    if a is None:
+        return None, None
+    a = np.ascontiguousarray(np.broadcast_to(np.asarray(a, dtype=np.float64), (F,)))
+    return a, _p(a)
+
+
+def slam_update(opts, views, want_stack=False, feat_sigma=None, feat_chi2mult=None):
+    """UpdaterSLAM::update (oracle_slam_update); views must carry landmarks.  feat_sigma / feat_chi2mult: per-feature
+    sigma_pix and chi2 multiplier (the ArUco options of UpdaterSLAM.cpp:392-409)."""
     lib = load()
     F, N, M = views.features.F, views.state.N, views.features.M
     L = views.landmarks.L
@@ -194,10 +202,13 @@ def slam_update(opts, views, want_stack=False):
     H = np.zeros((2 * max(M, 1), Dmax)) if want_stack else None
     r = np.zeros(2 * max(M, 1)) if want_stack else None
     stats = capi.UpdateStats()
+    _fs, fs_p = _opt_arr(feat_sigma, F)
+    _fm, fm_p = _opt_arr(feat_chi2mult, F)
     lib.oracle_slam_update.restype = C.c_int
     rc = lib.oracle_slam_update(C.byref(opts), C.byref(views.state), C.byref(views.landmarks), C.byref(views.features), _pi(views.lm_index),
                                 _pi(out["feat_status"]), _p(out["chi2"]), _p(out["chi2_thresh"]), _p(out["dx"]), _p(out["P"]), _p(out["landmarks"]),
-                                C.byref(D), _pi(cols), _p(H) if want_stack else None, _p(r) if want_stack else None, C.byref(rows), C.byref(stats))
+                                C.byref(D), _pi(cols), _p(H) if want_stack else None, _p(r) if want_stack else None, C.byref(rows), C.byref(stats),
+                                fs_p, fm_p)
     assert rc == 0
     d, n = D.value, rows.value
     out["D"], out["rows"], out["col_cov_id"] = d, n, cols[:d].copy()
@@ -208,7 +219,7 @@ def slam_update(opts, views, want_stack=False):
     return out
 
 
-def slam_delayed_init(opts, views, feat_rep=0, tri=None):
+def slam_delayed_init(opts, views, feat_rep=0, tri=None, feat_sigma=None, feat_chi2mult=None):
     """UpdaterSLAM::delayed_init + StateHelper::initialize (oracle_slam_delayed_init).  `tri` (the dict of
     triangulate()) replaces the triangulation stage.  views may carry landmarks already in the state."""
     lib = load()
@@ -225,13 +236,15 @@ def slam_delayed_init(opts, views, feat_rep=0, tri=None):
     if tri is not None:
         g = dict(pA=np.ascontiguousarray(tri["p_FinA"], dtype=np.float64), pG=np.ascontiguousarray(tri["p_FinG"], dtype=np.float64),
                  an=np.ascontiguousarray(tri["anchor_meas"], dtype=np.int32), st=np.ascontiguousarray(tri["status"], dtype=np.int32))
+    _fs, fs_p = _opt_arr(feat_sigma, F)
+    _fm, fm_p = _opt_arr(feat_chi2mult, F)
     lib.oracle_slam_delayed_init.restype = C.c_int
     rc = lib.oracle_slam_delayed_init(C.byref(opts), C.byref(views.state), C.byref(views.landmarks) if views.landmarks is not None else None,
                                       C.byref(views.features), C.c_int(int(feat_rep)), _p(g["pA"]) if g else None, _p(g["pG"]) if g else None,
                                       _pi(g["an"]) if g else None, _pi(g["st"]) if g else None, _pi(out["feat_status"]), _p(out["chi2"]),
                                       _p(out["chi2_thresh"]), _pi(out["lm_cov_id"]), _p(out["lm_value"]), _p(out["lm_fej"]), _pi(out["anchor_cam"]),
                                       _pi(out["anchor_clone"]), _p(out["dx_seq"]), C.byref(N_out), _p(Pbuf), _p(out["clone_q_p"]),
-                                      _p(out["calib_q_p"]), _p(out["intrinsics"]), _p(out["landmarks_existing"]) if L0 else None)
+                                      _p(out["calib_q_p"]), _p(out["intrinsics"]), _p(out["landmarks_existing"]) if L0 else None, fs_p, fm_p)
     out["rc"] = rc
     n = N_out.value
     out["N"] = n

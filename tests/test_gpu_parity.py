@@ -617,6 +617,64 @@ def test_delayed_init_parity(Updater, oracle, rep):
     up.close()
 
 
+def _aruco_options(F, seed):
+    """Mixed per-feature options as UpdaterSLAM applies them: tag corners (landmark id < 4 * max_aruco) use sigma_pix_aruco
+    and aruco_chi2_multipler, the others the SLAM values."""
+    rng = np.random.default_rng(seed)
+    tag = rng.random(F) < 0.4
+    return np.where(tag, 2.5, 1.0), np.where(tag, 3.0, 1.0)
+
+
+@pytest.mark.parametrize("rep", [capi.REP_GLOBAL_3D, capi.REP_ANCHORED_MSCKF_INVERSE_DEPTH, capi.REP_ANCHORED_INVERSE_DEPTH_SINGLE])
+def test_slam_update_per_feature_options(Updater, oracle, rep):
+    """UpdaterSLAM.cpp:392-409, :444: ArUco landmarks carry their own sigma_pix and chi2 multiplier; R_big is then diagonal but not
+    isotropic.  The device scales each feature's rows by sigma / sigma_f so that ONE noise level describes the stack (which
+    is what lets the stack be compressed), the oracle uses the reference's R_big."""
+    prob = synth.make_slam_problem(2, L=12, lm_rep=rep)
+    opts = capi.default_options(chi2_multipler=1.0)
+    v = capi.Views(prob)
+    sig, mult = _aruco_options(v.features.F, 3)
+    ref = oracle.slam_update(opts, v, feat_sigma=sig, feat_chi2mult=mult)
+    base = oracle.slam_update(opts, v)
+    assert not np.array_equal(ref["feat_status"], base["feat_status"]) or _rel(ref["dx"], base["dx"]) > 1e-3  # the options matter
+    up = Updater(opts)
+    up.set_slam_problem(prob)
+    up.set_feature_options(sig, mult)
+    out = up.slam_update()
+    assert np.array_equal(out["feat_status"], ref["feat_status"])
+    gate = np.isfinite(ref["chi2"])
+    np.testing.assert_allclose(out["chi2"][gate], ref["chi2"][gate], rtol=TOL_CHI2)
+    np.testing.assert_allclose(out["chi2_thresh"][gate], ref["chi2_thresh"][gate], rtol=1e-12)
+    assert _rel(out["dx"], ref["dx"]) < 1e-7 and _rel(out["P"], ref["P"]) < 1e-8
+    assert np.abs(out["landmarks"] - ref["landmarks"]).max() < 1e-9
+    # the options belong to the batch: the next upload runs with the context's values again
+    up.set_slam_problem(prob)
+    out2 = up.slam_update()
+    assert np.array_equal(out2["feat_status"], base["feat_status"]) and _rel(out2["dx"], base["dx"]) < 1e-7
+    up.close()
+
+
+@pytest.mark.parametrize("rep", [capi.REP_GLOBAL_3D, capi.REP_ANCHORED_INVERSE_DEPTH_SINGLE])
+def test_delayed_init_per_feature_options(Updater, oracle, rep):
+    """UpdaterSLAM.cpp:226-232: delayed initialisation of ArUco corners with their own noise and gate."""
+    prob = synth.make_problem(2, F=16, outlier_frac=0.2)
+    opts = capi.default_options(chi2_multipler=1.0)
+    v = capi.Views(prob)
+    tri = oracle.triangulate(opts, v)
+    sig, mult = _aruco_options(16, 5)
+    ref = oracle.slam_delayed_init(opts, v, feat_rep=rep, tri=tri, feat_sigma=sig, feat_chi2mult=mult)
+    base = oracle.slam_delayed_init(opts, v, feat_rep=rep, tri=tri)
+    assert ref["rc"] == 0 and (ref["lm_cov_id"] >= 0).sum() >= 4
+    assert ref["N"] != base["N"] or _rel(ref["P"], base["P"]) > 1e-4
+    up = Updater(opts)
+    up.set_problem(prob)
+    up.set_triangulation(tri["p_FinG"], tri["p_FinA"], tri["anchor_meas"], tri["status"])
+    up.set_feature_options(sig, mult)
+    out = up.delayed_init(rep)
+    _check_delayed_init(out, ref, up.get_state(P=True))
+    up.close()
+
+
 def _split_tracks(prob, pred, feats=None):
     """Tracks restricted to the measurements whose clone index satisfies pred (and to the features `feats`)."""
     feats = range(len(prob.meas_offsets) - 1) if feats is None else feats

@@ -340,6 +340,33 @@ def test_slam_update_equals_information_form():
     assert np.abs(o["landmarks"] - prob.p_FinG_true)[used].mean() < np.abs(prob.lm_value - prob.p_FinG_true)[used].mean()
 
 
+def test_slam_update_with_per_feature_noise_equals_weighted_information_form():
+    """UpdaterSLAM.cpp:392-409, :444: with per-feature sigmas the posterior is (P^-1 + H^T R^-1 H)^-1 with the diagonal R_big of
+    the accepted features; a constant per-feature sigma is the same as the global option."""
+    from open_vins_amd import capi, synth
+    from oracle import pyoracle
+    prob = synth.make_slam_problem(2, L=10)
+    v = capi.Views(prob)
+    F = v.features.F
+    same = pyoracle.slam_update(capi.default_options(chi2_multipler=1.0, sigma_pix=2.0), v)
+    const = pyoracle.slam_update(capi.default_options(chi2_multipler=1.0, sigma_pix=1.0), v, feat_sigma=np.full(F, 2.0))
+    assert np.array_equal(same["feat_status"], const["feat_status"])
+    np.testing.assert_allclose(const["P"], same["P"], rtol=1e-12, atol=1e-18)
+    sig = np.where(np.arange(F) % 3 == 0, 2.0, 1.0)
+    mult = np.where(np.arange(F) % 3 == 0, 1e6, 1.0)
+    opts = capi.default_options(chi2_multipler=1.0)
+    o = pyoracle.slam_update(opts, v, want_stack=True, feat_sigma=sig, feat_chi2mult=mult)
+    assert np.all(o["feat_status"][::3] == capi.FEAT_USED)  # the wide gate lets every third feature through
+    m = np.diff(prob.meas_offsets)
+    used = o["feat_status"] == capi.FEAT_USED
+    w = np.concatenate([np.full(2 * m[f], 1.0 / sig[f] ** 2) for f in range(F) if used[f]])
+    H = np.zeros((o["rows"], prob.N))
+    H[:, o["col_cov_id"]] = o["H"]
+    Pinf = np.linalg.inv(np.linalg.inv(prob.P) + H.T @ (w[:, None] * H))
+    assert np.linalg.norm(o["P"] - Pinf) / np.linalg.norm(Pinf) < 1e-9
+    assert np.linalg.norm(o["dx"] - Pinf @ H.T @ (w * o["r"])) / np.linalg.norm(o["dx"]) < 1e-6
+
+
 def test_slam_gate_rejects_a_displaced_landmark():
     from open_vins_amd import capi, synth
     from oracle import pyoracle
