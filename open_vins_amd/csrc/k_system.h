@@ -591,6 +591,7 @@ __global__ void __launch_bounds__(SYS_NT) k_system(SysParams p) {
         const bool reject = chi2 > thr; // :225
         hq[57] = reject ? 1.0 : 0.0;
         if (reject) p.status[f] = OVGPU_FEAT_CHI2_REJECTED;
+        else if (p.rows_used) atomicAdd(p.rows_used, n_out);
         if (p.init) p.init_flag[0] = reject ? 0 : 1;
       }
     }

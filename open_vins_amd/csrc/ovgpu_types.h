@@ -82,6 +82,7 @@ struct SysParams {
   int init;
   double *init_out;
   int32_t *init_flag; // [0] = 1 when the feature passed the gate
+  int32_t *rows_used; // optional counter: rows of the stack that belong to accepted features
   DevOptions opt;
 };
 

@@ -390,6 +390,48 @@ def _compress_with_env(Updater, prob, opts, tri, **env):
     return cmp
 
 
+def _update_with_env(Updater, prob, opts, tri, **env):
+    import os
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update({k: str(v) for k, v in env.items()})
+    try:
+        up = Updater(opts)
+        up.set_problem(prob)
+        up.set_triangulation(tri["p_FinG"], tri["p_FinA"], tri["anchor_meas"], tri["status"])
+        out = up.update()
+        up.close()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    return out
+
+
+@pytest.mark.parametrize("kw", [dict(F=300), dict(cfg=4, F=120), dict(F=200, K=1, C=12), dict(F=3), dict(F=150, track="ragged"),
+                                dict(F=40, C=6, K=1)])
+def test_cholesky_qr_compression_gives_the_householder_posterior(Updater, oracle, kw):
+    """The on-device update compresses with R = chol([H r]^T [H r]) on the matrix cores (k_gram.h) unless OVGPU_COMPRESS=tsqr:
+    both factors satisfy R^T R = H^T H, so dx and P agree (far inside the parity tolerance against the oracle, which compresses
+    with Givens rotations like the reference).  LD = 209 / 237 / 87 / 51 columns: 14, 15, 6 and 4 column tiles; F = 3 has fewer
+    rows than columns."""
+    kw = dict(kw)
+    prob = synth.make_problem(kw.pop("cfg", 2), **kw)
+    opts = capi.default_options(chi2_multipler=1.0)
+    v = capi.Views(prob)
+    tri = oracle.triangulate(opts, v)
+    ref = oracle.msckf_update(opts, v, given=tri)
+    a = _update_with_env(Updater, prob, opts, tri, OVGPU_COMPRESS="tsqr")
+    b = _update_with_env(Updater, prob, opts, tri, OVGPU_COMPRESS="cholqr")
+    b2 = _update_with_env(Updater, prob, opts, tri, OVGPU_COMPRESS="cholqr")
+    assert np.array_equal(a["feat_status"], ref["feat_status"]) and np.array_equal(b["feat_status"], ref["feat_status"])
+    assert b["stats"]["status"] == 0 and np.array_equal(b["P"], b["P"].T)
+    assert np.array_equal(b["dx"], b2["dx"]) and np.array_equal(b["P"], b2["P"])  # ordered sums: reproducible bit for bit
+    assert _rel(b["dx"], a["dx"]) < 1e-8 and _rel(b["P"], a["P"]) < 1e-9
+    assert _rel(b["dx"], ref["dx"]) < 1e-7 and _rel(b["P"], ref["P"]) < 1e-8
+
+
 @pytest.mark.parametrize("kw", [dict(F=300), dict(cfg=4, F=120), dict(F=200, K=1, C=12)])
 def test_compression_is_independent_of_the_tree_shape(Updater, oracle, kw):
     """QR([R_1; R_2; ...]) = QR of the full stack: any number of leaves, and the pipelined single-launch merge
