@@ -7,12 +7,15 @@ A "step" is one complete UpdaterMSCKF::update (triangulate + refine -> Jacobians
 measurement compression -> EKF update) of the BASELINE.json configs[1] snapshot (rpng_sim stereo, 30 clones,
 800 MSCKF features, N = 224, D = 208) with every input already resident in HBM.  At N > 1 (one process per GPU,
 launched by torch.distributed.run) the features are sharded: every rank holds its own 800-feature shard on the
-same prior (weak scaling), compresses it locally, the D x (D+1) triangles are all-gathered over RCCL and every
-rank applies the identical merge + EKF update.  value = features of all ranks / max-over-ranks time.
+same prior (weak scaling), accumulates the Gram matrix of its stack, the Gram matrices are summed by ONE all-reduce
+over RCCL (triangles all-gathered + merged for short stacks) and every rank applies the identical factorisation +
+EKF update.  value = features of all ranks / max-over-ranks time.
 
 Rank 0 prints ONE JSON line with the contract fields plus
-  roofline     : the dominant kernel (measurement compression, a tall-skinny Householder QR in f64), algorithmic
-                 FLOPs of SURVEY.md §8(d) (2 r D^2 per feature) over its HIP-event time on the kernel's stream
+  roofline     : the dominant kernel — since the compression moved to the matrix cores that is k_system (per-feature
+                 Jacobians, nullspace projection, chi2 gate; f64 vector FMA) — algorithmic FLOPs of SURVEY.md §8(d)
+                 over its HIP-event time on the kernel's stream; `compression` holds the same figures for the
+                 measurement compression (k_gram + k_gram_reduce + k_gram_chol; 2 r D^2 algorithmic FLOPs per feature)
   cpu_baseline : the oracle (float64 restatement of the reference's serial Eigen path) on the host cores, 1 thread.
 """
 import argparse
@@ -98,8 +101,11 @@ def main():
     out = None
     if rank == 0:
         flops_total, flops_compress = synth.algorithmic_flops(prob)
-        ms_c = kt["ms_compress"]
-        achieved = flops_compress / (ms_c * 1e-3) / 1e12 if ms_c > 0 else 0.0
+        flops_system = synth.algorithmic_flops_system(prob)
+        ms_c, ms_s = kt["ms_compress"], kt["ms_system"]
+        achieved_c = flops_compress / (ms_c * 1e-3) / 1e12 if ms_c > 0 else 0.0
+        achieved = flops_system / (ms_s * 1e-3) / 1e12 if ms_s > 0 else 0.0
+        traffic = pmc_traffic_bytes()
         out = {
             "metric": "MSCKF features/sec per EKF update (30-clone state)",
             "value": value,
@@ -120,15 +126,22 @@ def main():
                 "measurements_per_gpu": prob.M, "parallelism": f"feature-shard x{world}" if world > 1 else "single GPU",
             },
             "roofline": {
-                "kernel": "measurement compression = TSQR leaf (pw::k_qr_node<32,false>) + pipelined merge tree (k_qr_tree), timed together with HIP events",
+                "kernel": "k_system (one feature per workgroup: Jacobians, nullspace projection, chi2 gate against the prior P; f64 vector "
+                          "FMA, peak = the f64 MFMA peak), timed with HIP events on the context's stream",
                 "bound": "mfma",
                 "achieved": achieved,
                 "peak": PEAK_FP64_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": achieved / PEAK_FP64_TFLOPS,
-                "traffic": pmc_traffic_bytes(),
-                "algorithmic_flops_per_launch": flops_compress,
-                "avg_ms_per_launch": ms_c,
+                "traffic": traffic.get("k_system") if traffic else None,
+                "algorithmic_flops_per_launch": flops_system,
+                "avg_ms_per_launch": ms_s,
+                "compression": {
+                    "kernel": "k_gram<NT> (MFMA rank-k update of [H r]^T [H r]) + k_gram_reduce + k_gram_chol, timed together",
+                    "achieved": achieved_c, "frac": achieved_c / PEAK_FP64_TFLOPS, "algorithmic_flops_per_launch": flops_compress,
+                    "executed_mfma_flops_per_launch": flops_compress / 2.0, "avg_ms_per_launch": ms_c,
+                    "traffic": traffic.get("compression") if traffic else None,
+                },
                 "update_ms_device": kt["ms_update"],
                 "update_algorithmic_tflops": flops_total / (kt["ms_update"] * 1e-3) / 1e12 if kt["ms_update"] > 0 else 0.0,
             },
@@ -144,17 +157,19 @@ def main():
 
 
 def pmc_traffic_bytes():
-    """HBM bytes per compression launch (leaf + tree) from the committed rocprofv3 PMC passes (profiles/r01_pmc.json:
-    FETCH_SIZE and WRITE_SIZE in separate passes, read side doubled as MI355X_MICROARCH.md prescribes for gfx950).
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r01_pmc.json: FETCH_SIZE and WRITE_SIZE in
+    separate passes, read side doubled as MI355X_MICROARCH.md prescribes for gfx950): {"k_system": ..., "compression": ...}.
     The counters cannot be collected inside this process; None when the file is absent."""
     path = os.path.join(ROOT, "profiles", "r01_pmc.json")
     if not os.path.exists(path):
         return None
     k = json.load(open(path))["kernels"]
-    tot = 0.0
-    for name in ("leaf k_qr_node<32,false>", "tree k_qr_tree<28>"):
-        tot += 1024.0 * (2.0 * k[name]["FETCH_SIZE_KiB"] + k[name]["WRITE_SIZE_KiB"])
-    return tot
+
+    def tot(names):
+        if not all(n in k for n in names):
+            return None
+        return sum(1024.0 * (2.0 * k[n]["FETCH_SIZE_KiB"] + k[n]["WRITE_SIZE_KiB"]) for n in names)
+    return {"k_system": tot(["k_system"]), "compression": tot(["k_gram", "k_gram_reduce", "k_gram_chol"])}
 
 
 def cpu_baseline(prob, opts):

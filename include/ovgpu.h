@@ -528,6 +528,18 @@ int ovgpu_msckf_merge_update(ovgpu_ctx *ctx, const void *tris_dev, int G,
                              double *dx, double *P_out,
                              ovgpu_update_stats *stats);
 
+/* The same exchange in Gram form (k_gram.h): every GPU accumulates G_g = [H_g | r_g]^T [H_g | r_g] of its
+ * shard, the shards' sum is ONE all-reduce of ovgpu_gram_len() doubles (a 16 ceil((D+1)/16) square, row
+ * major, + 1 trailing double = the accepted-row count), and every rank factors the sum and applies
+ * the identical update.  Needs D <= 255.  The caller falls back to the triangle exchange above when
+ * the summed row count is below 4 (D + 1) (short stacks: see DESIGN.md section 4).  Replaces the
+ * same stretch of UpdaterMSCKF::update as ovgpu_msckf_local / ovgpu_msckf_merge_update.            */
+int ovgpu_gram_len(ovgpu_ctx *ctx, int64_t *n_doubles);
+int ovgpu_msckf_local_gram(ovgpu_ctx *ctx, int32_t *feat_status, double *chi2, double *chi2_thresh,
+                           double *p_FinG, void *gram_dev, ovgpu_update_stats *stats);
+int ovgpu_msckf_gram_update(ovgpu_ctx *ctx, const void *gram_dev, double *dx, double *P_out,
+                            ovgpu_update_stats *stats);
+
 /* ------------------------------------------------------------------------- */
 /* camera models                                                              */
 /* ------------------------------------------------------------------------- */
@@ -561,11 +573,15 @@ int ovgpu_synchronize(ovgpu_ctx *ctx);
 /* hipStream_t of the context, as an integer (for hipEvent timing). */
 uint64_t ovgpu_stream(ovgpu_ctx *ctx);
 
-/* Time in ms of the dominant kernel (measurement compression) and of the
+/* Time in ms of the measurement compression (all its launches) and of the
  * whole update, averaged over the launches since the last call with
  * reset != 0; measured with HIP events on the context's stream.              */
 int ovgpu_kernel_times(ovgpu_ctx *ctx, int reset, double *ms_compress_avg,
                        double *ms_update_avg, int64_t *n_launches);
+
+/* Average time in ms of the per-feature kernel (Jacobians, nullspace projection, chi2 gate:
+ * k_system) over the same launches; call BEFORE ovgpu_kernel_times(reset = 1).              */
+int ovgpu_system_time(ovgpu_ctx *ctx, double *ms_system_avg, int64_t *n_launches);
 
 #ifdef __cplusplus
 }

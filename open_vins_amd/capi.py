@@ -209,12 +209,16 @@ def declare(lib):
         "ovgpu_triangle_len": (C.c_int, [ctxp, C.POINTER(C.c_int64)]),
         "ovgpu_msckf_local": (C.c_int, [ctxp, c_int32_p, c_double_p, c_double_p, c_double_p, vp, C.POINTER(UpdateStats)]),
         "ovgpu_msckf_merge_update": (C.c_int, [ctxp, vp, C.c_int, c_double_p, c_double_p, C.POINTER(UpdateStats)]),
+        "ovgpu_gram_len": (C.c_int, [ctxp, C.POINTER(C.c_int64)]),
+        "ovgpu_msckf_local_gram": (C.c_int, [ctxp, c_int32_p, c_double_p, c_double_p, c_double_p, vp, C.POINTER(UpdateStats)]),
+        "ovgpu_msckf_gram_update": (C.c_int, [ctxp, vp, c_double_p, c_double_p, C.POINTER(UpdateStats)]),
         "ovgpu_cam_distort": (C.c_int, [ctxp, C.c_int, c_double_p, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p]),
         "ovgpu_reset_state": (C.c_int, [ctxp]),
         "ovgpu_msckf_update_async": (C.c_int, [ctxp]),
         "ovgpu_synchronize": (C.c_int, [ctxp]),
         "ovgpu_stream": (C.c_uint64, [ctxp]),
         "ovgpu_kernel_times": (C.c_int, [ctxp, C.c_int, c_double_p, c_double_p, C.POINTER(C.c_int64)]),
+        "ovgpu_system_time": (C.c_int, [ctxp, c_double_p, C.POINTER(C.c_int64)]),
     }
     for name, (res, args) in S.items():
         fn = getattr(lib, name)  # AttributeError if the library does not export it

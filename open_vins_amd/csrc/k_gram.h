@@ -35,7 +35,7 @@ struct GramParams {
   int LD, NT;             // row length of the stack (D + 1) and its 16-column tiles
   int64_t rows_total;
   const double *H;        // [rows_total x LD]
-  double *part;           // [gridDim.x][NT (NT + 1) / 2][4][64] partial tiles in accumulator layout
+  double *part;           // [gridDim.x][NT (NT + 1) / 2][2][64][2] partial tiles (see gram_put)
 };
 
 __host__ __device__ inline int pair_index(int NT, int ti, int tj) { return ti * NT - (ti * (ti - 1)) / 2 + (tj - ti); }
@@ -76,13 +76,15 @@ template <int W, int NTC> __device__ __forceinline__ void gram_stage(const doubl
   }
 }
 
-// partial tiles -> memory, accumulator layout (register q, lane): element (16 ti + 4 q + (lane >> 4), 16 tj + (lane & 15))
+// partial tiles -> memory: registers (2 h, 2 h + 1) of a lane side by side, two 16-byte stores per tile (a store instruction
+// holds the issuing wavefront for hundreds of cycles whatever its width); slot h * 128 + 2 * lane + e of a tile is register
+// q = 2 h + e of that lane = element (16 ti + 4 q + (lane >> 4), 16 tj + (lane & 15))
 template <int W> __device__ __forceinline__ void gram_put(double *out, int NT, int lane, const d4 (&acc)[GR_ACC]) {
   using WR = WaveRows<W>;
   auto put = [&](int ti, int tj, const d4 &a) {
     if (ti < NT && tj < NT) {
-      double *o = out + (size_t)pair_index(NT, ti, tj) * 256 + lane;
-      o[0] = a[0], o[64] = a[1], o[128] = a[2], o[192] = a[3];
+      double2 *o = reinterpret_cast<double2 *>(out + (size_t)pair_index(NT, ti, tj) * 256) + lane;
+      o[0] = double2{a[0], a[1]}, o[64] = double2{a[2], a[3]};
     }
   };
 #pragma unroll
@@ -187,7 +189,7 @@ __global__ void __launch_bounds__(256) k_gram_reduce(int NT, int nparts, const d
   }
   for (; w < nparts; w++) s0 += src[(size_t)w * NP * 256];
   const double s = (s0 + s1) + (s2 + s3);
-  const int q = t >> 6, lane = t & 63;
+  const int q = 2 * (t >> 7) + (t & 1), lane = (t >> 1) & 63; // slot t = h * 128 + 2 * lane + e holds register q = 2 h + e
   const int i = 16 * ti + 4 * q + (lane >> 4), j = 16 * tj + (lane & 15);
   G[(size_t)i * LG + j] = s;
   if (ti != tj) G[(size_t)j * LG + i] = s;
@@ -201,7 +203,8 @@ __global__ void __launch_bounds__(256) k_gram_reduce(int NT, int nparts, const d
 // below k.  The publish buffers alternate, so step k + 1 never overwrites what a slow wavefront still reads.  Finished rows
 // collect in LDS and leave in bursts of 16 rows written by all 16 wavefronts: a global store costs the issuing wavefront
 // ~600 cycles, which on the owner's critical path was most of the step (measured: 2.0 us per row, 0.4 ms per factorisation).
-constexpr int CH_NB = 8;
+constexpr int CH_NB = 8; // blocks per dimension: LD <= 256; the kernel is instantiated per block count (a run-time count puts every
+                         // multiply-add behind its own scalar branch)
 constexpr int CH_FLUSH = 16;
 __device__ __forceinline__ double rsqrt_f64(double d) {
   double y = __builtin_amdgcn_rsq(d);
@@ -212,6 +215,7 @@ __device__ __forceinline__ double rsqrt_f64(double d) {
 }
 inline size_t chol_lds_bytes(int LD) { return (size_t)2 * CH_FLUSH * LD * sizeof(double); }
 
+template <int NB>
 __global__ void __launch_bounds__(1024) k_gram_chol(int D, int LD, int LG, const double *G, double *out, int32_t *n_dropped) {
   extern __shared__ double rstore[]; // [2][CH_FLUSH][LD] finished rows on their way to memory
   __shared__ __attribute__((aligned(16))) double rowbuf[2][32 * CH_NB];
@@ -219,14 +223,13 @@ __global__ void __launch_bounds__(1024) k_gram_chol(int D, int LD, int LG, const
   __shared__ int okflag[2];
   __shared__ int drops;
   const int tid = threadIdx.x, ti = tid >> 5, tj = tid & 31;
-  const int NB = (LD + 31) / 32;
-  double a[CH_NB][CH_NB];
+  double a[NB][NB];
 #pragma unroll
-  for (int bi = 0; bi < CH_NB; bi++)
+  for (int bi = 0; bi < NB; bi++)
 #pragma unroll
-    for (int bj = 0; bj < CH_NB; bj++) {
+    for (int bj = 0; bj < NB; bj++) {
       a[bi][bj] = 0.0;
-      if (bj >= bi && bj < NB) {
+      if (bj >= bi) {
         const int i = ti + 32 * bi, j = tj + 32 * bj;
         if (i < LD && j < LD) a[bi][bj] = G[(size_t)i * LG + j];
       }
@@ -240,7 +243,7 @@ __global__ void __launch_bounds__(1024) k_gram_chol(int D, int LD, int LG, const
     if ((tid >> 6) == ((k & 31) >> 1)) { // the wavefront that holds row k (both halves run the shuffle)
       double dv = 0.0;
 #pragma unroll
-      for (int b = 0; b < CH_NB; b++)
+      for (int b = 0; b < NB; b++)
         if (b == bk) dv = a[b][b];
       const double d = __shfl(dv, 32 * ((k & 31) & 1) + (k & 31), 64); // element (k, k): thread ti = tj = k & 31
       const bool ok = d > 1e-15 * diag0[k] && d > 0.0;
@@ -248,11 +251,10 @@ __global__ void __launch_bounds__(1024) k_gram_chol(int D, int LD, int LG, const
       if (ti == (k & 31)) {
         double *o = rstore + ((size_t)((k / CH_FLUSH) & 1) * CH_FLUSH + (k % CH_FLUSH)) * LD;
 #pragma unroll
-        for (int bi = 0; bi < CH_NB; bi++)
+        for (int bi = 0; bi < NB; bi++)
           if (bi == bk) {
 #pragma unroll
-            for (int bj = 0; bj < CH_NB; bj++)
-              if (bj < NB) {
+            for (int bj = 0; bj < NB; bj++) {
                 const double r = bj >= bi ? a[bi][bj] * inv : 0.0;
                 rb[((bj >> 1) * 32 + tj) * 2 + (bj & 1)] = r;
                 const int j = tj + 32 * bj;
@@ -267,21 +269,21 @@ __global__ void __launch_bounds__(1024) k_gram_chol(int D, int LD, int LG, const
     }
     __syncthreads();
     if (okflag[k & 1]) {
-      double ri[CH_NB], rj[CH_NB];
+      constexpr int NP = (NB + 1) / 2;
+      double ri[2 * NP], rj[2 * NP];
 #pragma unroll
-      for (int m = 0; m < CH_NB / 2; m++) {
+      for (int m = 0; m < NP; m++) {
         ri[2 * m] = ri[2 * m + 1] = rj[2 * m] = rj[2 * m + 1] = 0.0;
-        if (2 * m + 1 >= bk && 2 * m < NB) { // blocks left of the pivot's block are dead
+        if (2 * m + 1 >= bk) { // blocks left of the pivot's block are dead
           const double2 vi = *reinterpret_cast<const double2 *>(rb + (m * 32 + ti) * 2), vj = *reinterpret_cast<const double2 *>(rb + (m * 32 + tj) * 2);
           ri[2 * m] = vi.x, ri[2 * m + 1] = vi.y, rj[2 * m] = vj.x, rj[2 * m + 1] = vj.y;
         }
       }
 #pragma unroll
-      for (int bi = 0; bi < CH_NB; bi++) {
-        if (bi < NB && 32 * bi + 31 > k) { // the block row still has rows below k
+      for (int bi = 0; bi < NB; bi++) {
+        if (32 * bi + 31 > k) { // the block row still has rows below k
 #pragma unroll
-          for (int bj = 0; bj < CH_NB; bj++)
-            if (bj >= bi && bj < NB) a[bi][bj] = fma(-ri[bi], rj[bj], a[bi][bj]);
+          for (int bj = bi; bj < NB; bj++) a[bi][bj] = fma(-ri[bi], rj[bj], a[bi][bj]);
         }
       }
     }

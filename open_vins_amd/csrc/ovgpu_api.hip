@@ -180,7 +180,7 @@ struct ovgpu_ctx {
   int row_stride = 48;
 
   // ---- timing
-  std::vector<EventPair> ev_compress, ev_update;
+  std::vector<EventPair> ev_compress, ev_update, ev_system;
   size_t ev_used = 0;
   bool timing = true;
 };
@@ -297,6 +297,15 @@ template <int NTC> static void launch_gram(int G, const gram::GramParams &g, hip
   hipLaunchKernelGGL(gram::k_gram<NTC>, dim3(G), dim3(256), gram::gram_lds_bytes(), s, g);
 }
 
+template <int NB> static void launch_gram_chol(hipStream_t s, int D, int LD, int LG, const double *G, double *out, int32_t *dropped) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void *)gram::k_gram_chol<NB>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(gram::k_gram_chol<NB>, dim3(1), dim3(1024), gram::chol_lds_bytes(LD), s, D, LD, LG, G, out, dropped);
+}
+
 extern "C" {
 
 const char *ovgpu_last_error(void) { return g_err.c_str(); }
@@ -368,6 +377,10 @@ void ovgpu_destroy(ovgpu_ctx *c) {
     if (e.b) (void)hipEventDestroy(e.b);
   }
   for (auto &e : c->ev_update) {
+    if (e.a) (void)hipEventDestroy(e.a);
+    if (e.b) (void)hipEventDestroy(e.b);
+  }
+  for (auto &e : c->ev_system) {
     if (e.a) (void)hipEventDestroy(e.a);
     if (e.b) (void)hipEventDestroy(e.b);
   }
@@ -850,13 +863,13 @@ static int enqueue_merge_tree(ovgpu_ctx *c, int G, bool leaves_live = false, hip
 }
 
 // R = chol([H | r]^T [H | r]) on the matrix cores (k_gram.h): partial Gram matrices per workgroup, ordered sum, Cholesky
-static int enqueue_compress_gram(ovgpu_ctx *c) {
+static int enqueue_gram_factor(ovgpu_ctx *c);
+static int enqueue_compress_gram(ovgpu_ctx *c, bool factor = true) {
   const int D = c->D, LD = c->LD, NT = (LD + 15) / 16, NP = NT * (NT + 1) / 2, LG = 16 * NT;
   const int64_t nchunks = (c->rows_total + gram::GR_ROWS - 1) / gram::GR_ROWS;
   const int G = (int)std::max<int64_t>(1, std::min<int64_t>(c->num_cu, nchunks));
   HIPCHK(c->gram_part.reserve((size_t)G * NP * 256));
   HIPCHK(c->gram_G.reserve((size_t)LG * LG));
-  HIPCHK(c->gram_dropped.reserve(1));
   gram::GramParams g;
   g.LD = LD, g.NT = NT, g.rows_total = c->rows_total, g.H = c->Hbig.p, g.part = c->gram_part.p;
   switch ((NT + 1) / 2) {
@@ -869,14 +882,27 @@ static int enqueue_compress_gram(ovgpu_ctx *c) {
   case 7: launch_gram<14>(G, g, c->stream); break;
   default: launch_gram<16>(G, g, c->stream); break;
   }
-  static bool chol_attr = false;
-  if (!chol_attr) {
-    (void)hipFuncSetAttribute((const void *)gram::k_gram_chol, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-    chol_attr = true;
-  }
   hipLaunchKernelGGL(gram::k_gram_reduce, dim3(NP), dim3(256), 0, c->stream, NT, G, c->gram_part.p, c->gram_G.p);
-  hipLaunchKernelGGL(gram::k_gram_chol, dim3(1), dim3(1024), gram::chol_lds_bytes(LD), c->stream, D, LD, LG, c->gram_G.p, c->Rws.p, c->gram_dropped.p);
   HIPCHK(hipGetLastError());
+  return factor ? enqueue_gram_factor(c) : OVGPU_OK;
+}
+
+// Cholesky of c->gram_G into c->Rws; from here on the EKF stage refines dx against gram_G
+static int enqueue_gram_factor(ovgpu_ctx *c) {
+  const int D = c->D, LD = c->LD, LG = 16 * ((LD + 15) / 16);
+  HIPCHK(c->gram_dropped.reserve(1));
+  switch ((LD + 31) / 32) {
+  case 1: launch_gram_chol<1>(c->stream, D, LD, LG, c->gram_G.p, c->Rws.p, c->gram_dropped.p); break;
+  case 2: launch_gram_chol<2>(c->stream, D, LD, LG, c->gram_G.p, c->Rws.p, c->gram_dropped.p); break;
+  case 3: launch_gram_chol<3>(c->stream, D, LD, LG, c->gram_G.p, c->Rws.p, c->gram_dropped.p); break;
+  case 4: launch_gram_chol<4>(c->stream, D, LD, LG, c->gram_G.p, c->Rws.p, c->gram_dropped.p); break;
+  case 5: launch_gram_chol<5>(c->stream, D, LD, LG, c->gram_G.p, c->Rws.p, c->gram_dropped.p); break;
+  case 6: launch_gram_chol<6>(c->stream, D, LD, LG, c->gram_G.p, c->Rws.p, c->gram_dropped.p); break;
+  case 7: launch_gram_chol<7>(c->stream, D, LD, LG, c->gram_G.p, c->Rws.p, c->gram_dropped.p); break;
+  default: launch_gram_chol<8>(c->stream, D, LD, LG, c->gram_G.p, c->Rws.p, c->gram_dropped.p); break;
+  }
+  HIPCHK(hipGetLastError());
+  c->gram_valid = true;
   return OVGPU_OK;
 }
 
@@ -993,7 +1019,7 @@ static EventPair *next_events(ovgpu_ctx *c, std::vector<EventPair> &v, size_t id
 enum { STAGE_LOCAL = 1, STAGE_EKF = 2 };
 
 // factor_stays: the compressed factor is consumed on the device (EKF update, cross-GPU merge) and never shown to the caller
-static int enqueue_pipeline(ovgpu_ctx *c, int stages, bool slam = false, bool factor_stays = false) {
+static int enqueue_pipeline(ovgpu_ctx *c, int stages, bool slam = false, bool factor_stays = false, bool gram_only = false) {
   if (!c->have_state || c->poses_only) return set_err(OVGPU_ERR_NO_STATE, "ovgpu_set_state was never called");
   if (!c->have_feats) return set_err(OVGPU_ERR_NO_STATE, "ovgpu_set_features was never called (or the state changed since)");
   HIPCHK(hipSetDevice(c->device));
@@ -1001,12 +1027,13 @@ static int enqueue_pipeline(ovgpu_ctx *c, int stages, bool slam = false, bool fa
     const int rcl = set_row_layout(c, slam);
     if (rcl != OVGPU_OK) return rcl;
   }
-  EventPair *eu = nullptr, *ec = nullptr;
+  EventPair *eu = nullptr, *ec = nullptr, *es = nullptr;
   if (c->timing) {
     eu = next_events(c, c->ev_update, c->ev_used);
     ec = next_events(c, c->ev_compress, c->ev_used);
-    if (eu && ec) c->ev_used++;
-    else eu = ec = nullptr;
+    es = next_events(c, c->ev_system, c->ev_used);
+    if (eu && ec && es) c->ev_used++;
+    else eu = ec = es = nullptr;
   }
   if (eu) HIPCHK(hipEventRecord(eu->a, c->stream));
   int rc = OVGPU_OK;
@@ -1015,21 +1042,29 @@ static int enqueue_pipeline(ovgpu_ctx *c, int stages, bool slam = false, bool fa
       // the gate overwrites status; restore the caller's per-feature status for this run
       if (c->F > 0) HIPCHK(hipMemcpyAsync(c->status.p, c->given_status.p, sizeof(int32_t) * c->F, hipMemcpyDeviceToDevice, c->stream));
     } else if ((rc = enqueue_triangulate(c)) != OVGPU_OK) return rc;
+    if (es) HIPCHK(hipEventRecord(es->a, c->stream));
     if ((rc = enqueue_system(c)) != OVGPU_OK) return rc;
-    if (ec) HIPCHK(hipEventRecord(ec->a, c->stream));
+    if (es) HIPCHK(hipEventRecord(es->b, c->stream));
     // Cholesky-QR (k_gram.h) only for tall stacks: with few accepted rows per column the weak (not null) directions of H lose
     // information of order sqrt(eps) with the dropped pivots (measured |dP| / |P| = 2e-9 on a 74 x 72 stack, below 1e-10 from
     // 4 rows per column on), and the TSQR of a short stack is cheap.  The accepted-row count is known only after the gate:
     // one 4-byte read-back (~20 us) decides.
     bool use_gram = (factor_stays || (stages & STAGE_EKF) != 0) && c->compress_gram && (c->LD + 15) / 16 <= gram::GR_NT && c->F > 0 &&
                     c->rows_total >= (int64_t)4 * c->LD;
-    if (use_gram) {
+    if (use_gram && !gram_only) {
       int32_t used = 0;
       HIPCHK(hipMemcpyAsync(&used, c->rows_used.p, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
       HIPCHK(hipStreamSynchronize(c->stream));
       use_gram = used >= 4 * c->LD;
     }
-    if ((rc = enqueue_compress(c, use_gram)) != OVGPU_OK) return rc;
+    if (ec) HIPCHK(hipEventRecord(ec->a, c->stream));
+    if (gram_only) { // the sharded update sums Gram matrices across GPUs before anything is factored
+      if ((c->LD + 15) / 16 > gram::GR_NT) return set_err(OVGPU_ERR_CAPACITY, "the Gram route holds at most 255 Jacobian columns");
+      rc = enqueue_compress_gram(c, false);
+    } else {
+      rc = enqueue_compress(c, use_gram);
+    }
+    if (rc != OVGPU_OK) return rc;
     if (ec) HIPCHK(hipEventRecord(ec->b, c->stream));
   }
   if (stages & STAGE_EKF) {
@@ -2079,6 +2114,75 @@ int ovgpu_msckf_local(ovgpu_ctx *c, int32_t *feat_status, double *chi2, double *
   return OVGPU_OK;
 }
 
+// ---- the same exchange in Gram form: G_total = sum over GPUs of [H_g | r_g]^T [H_g | r_g] is ONE all-reduce (sum) of
+// 16 NT x 16 NT doubles + the accepted-row count; every rank then factors and updates identically
+__global__ void k_gram_count(double *dst, const int32_t *rows_used) { dst[0] = (double)rows_used[0]; }
+
+int ovgpu_gram_len(ovgpu_ctx *c, int64_t *n_doubles) {
+  if (!c || !n_doubles) return set_err(OVGPU_ERR_INVALID, "null argument");
+  if (!c->have_state || c->poses_only) return set_err(OVGPU_ERR_NO_STATE, "ovgpu_set_state was never called");
+  const int NT = (c->LD + 15) / 16;
+  if (NT > gram::GR_NT) return set_err(OVGPU_ERR_CAPACITY, "the Gram route holds at most 255 Jacobian columns");
+  *n_doubles = (int64_t)256 * NT * NT + 1;
+  return OVGPU_OK;
+}
+
+int ovgpu_msckf_local_gram(ovgpu_ctx *c, int32_t *feat_status, double *chi2, double *chi2_thresh, double *p_FinG, void *gram_dev,
+                           ovgpu_update_stats *stats) {
+  if (!c || !gram_dev) return set_err(OVGPU_ERR_INVALID, "null argument");
+  if (stats) std::memset(stats, 0, sizeof(*stats));
+  int rc = enqueue_pipeline(c, STAGE_LOCAL, false, true, true);
+  if (rc != OVGPU_OK) return rc;
+  const size_t n = (size_t)256 * ((c->LD + 15) / 16) * ((c->LD + 15) / 16);
+  double *dst = static_cast<double *>(gram_dev);
+  if (c->F > 0) {
+    HIPCHK(hipMemcpyAsync(dst, c->gram_G.p, sizeof(double) * n, hipMemcpyDeviceToDevice, c->stream));
+    hipLaunchKernelGGL(k_gram_count, dim3(1), dim3(1), 0, c->stream, dst + n, c->rows_used.p);
+    HIPCHK(hipGetLastError());
+  } else {
+    HIPCHK(hipMemsetAsync(dst, 0, sizeof(double) * (n + 1), c->stream));
+  }
+  if (feat_status || chi2 || chi2_thresh || p_FinG || stats) {
+    rc = read_feature_outputs(c, feat_status, chi2, chi2_thresh, p_FinG, stats);
+    if (rc != OVGPU_OK) return rc;
+    fill_times(c, stats);
+  } else {
+    HIPCHK(hipStreamSynchronize(c->stream)); // gram_dev is consumed by another library's stream (RCCL)
+  }
+  return OVGPU_OK;
+}
+
+int ovgpu_msckf_gram_update(ovgpu_ctx *c, const void *gram_dev, double *dx, double *P_out, ovgpu_update_stats *stats) {
+  if (!c || !gram_dev) return set_err(OVGPU_ERR_INVALID, "bad argument");
+  if (!c->have_state || c->poses_only) return set_err(OVGPU_ERR_NO_STATE, "ovgpu_set_state was never called");
+  const int NT = (c->LD + 15) / 16;
+  if (NT > gram::GR_NT) return set_err(OVGPU_ERR_CAPACITY, "the Gram route holds at most 255 Jacobian columns");
+  HIPCHK(hipSetDevice(c->device));
+  const size_t n = (size_t)256 * NT * NT;
+  HIPCHK(c->gram_G.reserve(n));
+  HIPCHK(c->Rws.reserve((size_t)16 * c->D * c->LD));
+  hipStream_t s = c->stream;
+  HIPCHK(hipMemcpyAsync(c->gram_G.p, gram_dev, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
+  int rc = enqueue_gram_factor(c);
+  if (rc != OVGPU_OK) return rc;
+  rc = enqueue_ekf(c);
+  if (rc != OVGPU_OK) return rc;
+  if (stats) {
+    std::memset(stats, 0, sizeof(*stats));
+    stats->D = c->D;
+    stats->n_rows_comp = c->D;
+  }
+  int32_t flags[4] = {0, 0, 0, 0};
+  HIPCHK(hipMemcpyAsync(flags, c->flags.p, sizeof(flags), hipMemcpyDeviceToHost, s));
+  if (dx) HIPCHK(hipMemcpyAsync(dx, c->dx.p, sizeof(double) * c->N, hipMemcpyDeviceToHost, s));
+  if (P_out) HIPCHK(hipMemcpyAsync(P_out, c->P.p, sizeof(double) * c->N * c->N, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  const int status = flags[0] ? OVGPU_ERR_NOT_SPD : (flags[1] ? OVGPU_ERR_NEGATIVE_DIAGONAL : OVGPU_OK);
+  if (stats) stats->status = status;
+  if (status != OVGPU_OK) return set_err(status, "EKF update failed");
+  return OVGPU_OK;
+}
+
 int ovgpu_msckf_merge_update(ovgpu_ctx *c, const void *tris_dev, int G, double *dx, double *P_out, ovgpu_update_stats *stats) {
   if (!c || !tris_dev || G < 1) return set_err(OVGPU_ERR_INVALID, "bad argument");
   if (!c->have_state || c->poses_only) return set_err(OVGPU_ERR_NO_STATE, "ovgpu_set_state was never called");
@@ -2166,6 +2270,22 @@ int ovgpu_debug_qr_cycles(long long *out128) {
   return hipMemcpy(out128, qr_dbg_buffer(), 128 * sizeof(long long), hipMemcpyDeviceToHost) == hipSuccess ? OVGPU_OK : OVGPU_ERR_HIP;
 }
 #endif
+
+int ovgpu_system_time(ovgpu_ctx *c, double *ms_system_avg, int64_t *n_launches) {
+  if (!c) return set_err(OVGPU_ERR_INVALID, "null ctx");
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  double ss = 0;
+  int64_t n = 0;
+  for (size_t i = 0; i < c->ev_used && i < c->ev_system.size(); i++) {
+    float a = 0.f;
+    if (hipEventElapsedTime(&a, c->ev_system[i].a, c->ev_system[i].b) != hipSuccess) continue;
+    ss += a, n++;
+  }
+  if (ms_system_avg) *ms_system_avg = n ? ss / n : 0.0;
+  if (n_launches) *n_launches = n;
+  return OVGPU_OK;
+}
 
 int ovgpu_kernel_times(ovgpu_ctx *c, int reset, double *ms_compress_avg, double *ms_update_avg, int64_t *n_launches) {
   if (!c) return set_err(OVGPU_ERR_INVALID, "null ctx");

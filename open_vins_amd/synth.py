@@ -533,3 +533,19 @@ def algorithmic_flops(prob: Problem):
         comp += 2 * r * D * D
     tot += 4 * N * D * D + 2.33 * D ** 3 + N * N * D
     return tot, comp
+
+
+def algorithmic_flops_system(prob: Problem):
+    """The share of algorithmic_flops() that the per-feature kernel (k_system) carries: Jacobians a6-a8 (100 m + 400 m), nullspace
+    projection a10 (36 m (d_f + 3)) and the chi2 gate a11 (2 r d_f^2 + r^2 d_f + r^3 / 3 + 2 r^2); the triangulation (935 m of
+    the 1035 m term) and the compression run in their own kernels."""
+    tot = 0.0
+    for f in range(prob.F):
+        a, b = int(prob.meas_offsets[f]), int(prob.meas_offsets[f + 1])
+        m = b - a
+        if m < 2:
+            continue
+        r = 2 * m - 3
+        d_f = 6 * len(set(prob.clone_idx[a:b].tolist())) + 14 * len(set(prob.cam_idx[a:b].tolist()))
+        tot += 500 * m + 36 * m * (d_f + 3) + (2 * r * d_f ** 2 + r * r * d_f + r ** 3 / 3 + 2 * r * r)
+    return tot

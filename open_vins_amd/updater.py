@@ -368,6 +368,42 @@ class UpdaterMSCKF:
         out["stats"] = stats.as_dict()
         return out
 
+    # the same exchange in Gram form: one all-reduce (sum) instead of an all-gather + merge
+    def gram_len(self):
+        """Doubles of the Gram buffer (16 ceil((D+1)/16) squared + the accepted-row count), or 0 when this state does not
+        fit the Gram route (D > 255) or OVGPU_COMPRESS=tsqr selects the Householder exchange."""
+        import os
+        if os.environ.get("OVGPU_COMPRESS", "") == "tsqr" or self.triangle_len() > 255 * 256:
+            return 0
+        n = C.c_int64(0)
+        capi.check(self.lib.ovgpu_gram_len(self._ctx, C.byref(n)), "ovgpu_gram_len")
+        return n.value
+
+    def local_gram(self, gram_dev_ptr, want_outputs=True):
+        F = self.F
+        out = dict(feat_status=np.zeros(F, np.int32), chi2=np.zeros(F), chi2_thresh=np.zeros(F), p_FinG=np.zeros((F, 3)))
+        stats = capi.UpdateStats()
+        if want_outputs:
+            rc = self.lib.ovgpu_msckf_local_gram(self._ctx, _ip(out["feat_status"]), _dp(out["chi2"]), _dp(out["chi2_thresh"]), _dp(out["p_FinG"]),
+                                                 C.c_void_p(gram_dev_ptr), C.byref(stats))
+        else:
+            rc = self.lib.ovgpu_msckf_local_gram(self._ctx, None, None, None, None, C.c_void_p(gram_dev_ptr), None)
+        capi.check(rc, "ovgpu_msckf_local_gram")
+        out["stats"] = stats.as_dict()
+        return out
+
+    def gram_update(self, gram_dev_ptr, want_outputs=True):
+        N = self.N
+        out = dict(dx=np.zeros(N), P=np.zeros((N, N)))
+        stats = capi.UpdateStats()
+        if want_outputs:
+            rc = self.lib.ovgpu_msckf_gram_update(self._ctx, C.c_void_p(gram_dev_ptr), _dp(out["dx"]), _dp(out["P"]), C.byref(stats))
+        else:
+            rc = self.lib.ovgpu_msckf_gram_update(self._ctx, C.c_void_p(gram_dev_ptr), None, None, None)
+        capi.check(rc, "ovgpu_msckf_gram_update")
+        out["stats"] = stats.as_dict()
+        return out
+
     # ---- benchmarking hooks ---------------------------------------------
     def update_async(self):
         capi.check(self.lib.ovgpu_msckf_update_async(self._ctx), "ovgpu_msckf_update_async")
@@ -377,5 +413,7 @@ class UpdaterMSCKF:
 
     def kernel_times(self, reset=True):
         a, b, n = C.c_double(0), C.c_double(0), C.c_int64(0)
+        sy, ns = C.c_double(0), C.c_int64(0)
+        capi.check(self.lib.ovgpu_system_time(self._ctx, C.byref(sy), C.byref(ns)), "ovgpu_system_time")
         capi.check(self.lib.ovgpu_kernel_times(self._ctx, 1 if reset else 0, C.byref(a), C.byref(b), C.byref(n)), "ovgpu_kernel_times")
-        return dict(ms_compress=a.value, ms_update=b.value, launches=n.value)
+        return dict(ms_compress=a.value, ms_update=b.value, launches=n.value, ms_system=sy.value)

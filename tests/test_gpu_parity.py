@@ -338,6 +338,56 @@ def test_sharded_update_equals_unsharded(Updater, oracle):
     full.close()
 
 
+def test_sharded_gram_exchange_equals_unsharded(Updater, oracle):
+    """The Gram form of the exchange (parallel.py): the shards' Gram matrices ADD UP to the Gram matrix of the full stack, so
+    two contexts' buffers summed (what the all-reduce does) and factored once give the single-context update; the trailing
+    element carries the accepted-row count."""
+    import torch
+    from open_vins_amd import parallel
+    prob = synth.make_problem(2, F=120)
+    opts = capi.default_options(chi2_multipler=1.0)
+    v = capi.Views(prob)
+    tri = oracle.triangulate(opts, v)
+    ref = oracle.msckf_update(opts, v, given=tri)
+    full = Updater(opts)
+    full.set_problem(prob)
+    full.set_triangulation(tri["p_FinG"], tri["p_FinA"], tri["anchor_meas"], tri["status"])
+    one = full.update()
+    G = 2
+    total, ups = None, []
+    for rank in range(G):
+        ids = parallel.shard_features(prob.meas_offsets, rank, G)
+        sub = prob.subset(ids)
+        u = Updater(opts)
+        u.set_problem(sub)
+        anchor_local = tri["anchor_meas"][ids] - prob.meas_offsets[ids] + sub.meas_offsets[:-1]
+        u.set_triangulation(tri["p_FinG"][ids], tri["p_FinA"][ids], anchor_local, tri["status"][ids])
+        n = u.gram_len()
+        assert n == (16 * 14) ** 2 + 1
+        t = torch.empty(n, dtype=torch.float64, device="cuda")
+        u.local_gram(t.data_ptr(), want_outputs=False)
+        total = t if total is None else total + t
+        ups.append(u)
+    torch.cuda.synchronize()
+    assert int(total[-1].item()) == ref["stats"]["n_rows"]
+    Gm = total[:-1].reshape(224, 224).cpu().numpy()
+    assert np.array_equal(Gm, Gm.T) and not Gm[209:, :].any()
+    out = ups[1].gram_update(total.data_ptr())
+    assert _rel(out["P"], one["P"]) < 1e-10 and _rel(out["dx"], one["dx"]) < 1e-9
+    assert _rel(out["P"], ref["P"]) < 1e-9 and _rel(out["dx"], ref["dx"]) < 1e-7
+    # and through the protocol driver (world size 1: no collective, same code path)
+    class _Dist:
+        @staticmethod
+        def get_world_size():
+            return 1
+    full.reset_state()
+    drv = parallel.distributed_update(parallel.GpuShardBackend(full), _Dist, torch.device("cuda"))
+    assert _rel(drv["P"], one["P"]) < 1e-12 and _rel(drv["dx"], one["dx"]) < 1e-10
+    for u in ups:
+        u.close()
+    full.close()
+
+
 # --------------------------------------------------------------------------- BASELINE.json full sizes: properties
 def test_cfg2_full_size_against_oracle(Updater, oracle):
     """configs[1]: 30 clones, stereo, 800 features — the bench workload, compared with the oracle directly."""

@@ -48,7 +48,38 @@ class OracleShardBackend:
         return dict(P=P, dx=dx, status=st)
 
 
-def _worker(rank, world, port, q):
+class OracleGramBackend(OracleShardBackend):
+    """The Gram-form protocol (one all-reduce): the shard's Gram matrix is built from the oracle's compressed triangle
+    ([R z]^T [R z] = [H r]^T [H r]), the summed matrix is factored by a plain semi-definite Cholesky."""
+
+    def gram_len(self):
+        self.LG = 16 * ((self.D + 1 + 15) // 16)
+        return self.LG * self.LG + 1
+
+    def local_gram_into(self, tensor):
+        out = self.o.msckf_update(self.opts, self.v, want_compressed=True)
+        r = out["rows_comp"]
+        A = np.zeros((r, self.D + 1))
+        A[:, : self.D] = out["H_comp"]
+        A[:, self.D] = out["r_comp"]
+        G = np.zeros((self.LG, self.LG))
+        G[: self.D + 1, : self.D + 1] = A.T @ A
+        tensor.copy_(torch.from_numpy(np.concatenate([G.reshape(-1), [float(out["stats"]["n_rows"])]])))
+
+    def gram_update_from(self, tensor, want_outputs=True):
+        n = self.D + 1
+        S = tensor.numpy()[:-1].reshape(self.LG, self.LG)[:n, :n].copy()
+        d0 = np.diag(S).copy()
+        R = np.zeros((n, n))
+        for k in range(n):
+            if S[k, k] > 1e-15 * d0[k] and S[k, k] > 0:
+                R[k, k:] = S[k, k:] / np.sqrt(S[k, k])
+                S[k + 1:, k + 1:] -= np.outer(R[k, k + 1:], R[k, k + 1:])
+        st, P, dx = self.o.ekf_update(self.prob.P, R[: self.D, : self.D], R[: self.D, self.D], self.cols, self.opts.sigma_pix ** 2)
+        return dict(P=P, dx=dx, status=st, route="gram")
+
+
+def _worker(rank, world, port, q, gram=False):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -58,9 +89,9 @@ def _worker(rank, world, port, q):
     prob = synth.make_problem(2, F=48, C=10)
     opts = capi.default_options(chi2_multipler=1.0)
     ids = parallel.shard_features(prob.meas_offsets, rank, world)
-    backend = OracleShardBackend(prob, opts, ids)
+    backend = (OracleGramBackend if gram else OracleShardBackend)(prob, opts, ids)
     out = parallel.distributed_update(backend, dist, torch.device("cpu"))
-    q.put((rank, out["P"], out["dx"], ids))
+    q.put((rank, out["P"], out["dx"], ids, out.get("route", "triangles")))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -84,19 +115,22 @@ def test_shard_assignment_is_a_balanced_partition():
         assert max(loads) - min(loads) <= np.diff(prob.meas_offsets).max()
 
 
-def test_two_rank_sharded_update_matches_single_process(oracle):
+@pytest.mark.parametrize("gram", [False, True])
+def test_two_rank_sharded_update_matches_single_process(oracle, gram):
+    """gram = False: all-gather of triangles + merge; gram = True: all-reduce of Gram matrices (parallel.py)."""
     from open_vins_amd import capi, synth
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, gram)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
+    assert all(r[4] == ("gram" if gram else "triangles") for r in res)
     # every rank ends with the same posterior, bit for bit
     np.testing.assert_array_equal(res[0][1], res[1][1])
     np.testing.assert_array_equal(res[0][2], res[1][2])
