@@ -271,79 +271,82 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
   return v;
 }
 
+// (loads are issued unconditionally on clamped indices and masked when their values are USED: a load behind a branch, or a
+// select right behind a load, makes the compiler wait for every outstanding load first, and the kernel is all load latency)
 __global__ void __launch_bounds__(1024) k_ekf_dx_refine(EkfParams p, const double *__restrict__ G, int LG, double *rho) {
   if (p.pred && *p.pred == 0) return;
   __shared__ double vD[256], w[256], ss[256], part[4][256];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, D = p.D, N = p.N, LA = p.LA;
   if (tid < D) vD[tid] = p.dx[p.col_cov[tid]];
   __syncthreads();
-  // the matrix-vector products: one wavefront per row, four rows in flight (a row's loads take ~1 us from L2)
-  for (int c0 = wv; c0 < D; c0 += 64) { // g' = g - G dx_D
-    double a[4] = {0.0, 0.0, 0.0, 0.0};
+  // the matrix-vector products: one wavefront per row, eight rows in flight
+  for (int c0 = wv; c0 < D; c0 += 128) { // g' = g - G dx_D
+    double a[8];
+    const double *row[8];
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
-      const int c = c0 + 16 * u;
-      if (c < D)
-        for (int j = lane; j < D; j += 64) a[u] = fma(G[(size_t)c * LG + j], vD[j], a[u]);
+    for (int u = 0; u < 8; u++) a[u] = 0.0, row[u] = G + (size_t)min(c0 + 16 * u, D - 1) * LG;
+    for (int j = lane; j < D; j += 64) {
+      const double x = vD[j];
+#pragma unroll
+      for (int u = 0; u < 8; u++) a[u] = fma(row[u][j], x, a[u]);
     }
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
-      const int c = c0 + 16 * u;
+    for (int u = 0; u < 8; u++) {
       const double r = wave_sum_f64(a[u]);
-      if (lane == 0 && c < D) w[c] = G[(size_t)c * LG + D] - r;
+      if (lane == 0 && c0 + 16 * u < D) w[c0 + 16 * u] = row[u][D] - r;
     }
   }
   __syncthreads();
-  for (int i0 = wv; i0 < N; i0 += 64) { // rho = P(:, cols) g' / sigma^2 - dx
-    double a[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int i0 = wv; i0 < N; i0 += 128) { // rho = P(:, cols) g' / sigma^2 - dx
+    double a[8];
+    const double *row[8];
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
-      const int i = i0 + 16 * u;
-      if (i < N)
-        for (int c = lane; c < D; c += 64) a[u] = fma(p.P[(size_t)i * N + p.col_cov[c]], w[c], a[u]);
+    for (int u = 0; u < 8; u++) a[u] = 0.0, row[u] = p.P + (size_t)min(i0 + 16 * u, N - 1) * N;
+    for (int c = lane; c < D; c += 64) {
+      const double x = w[c];
+      const int cc = p.col_cov[c];
+#pragma unroll
+      for (int u = 0; u < 8; u++) a[u] = fma(row[u][cc], x, a[u]);
     }
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
-      const int i = i0 + 16 * u;
+    for (int u = 0; u < 8; u++) {
       const double r = wave_sum_f64(a[u]);
+      const int i = i0 + 16 * u;
       if (lane == 0 && i < N) rho[i] = r / p.sigma2 - p.dx[i];
     }
   }
   __syncthreads();
   if (tid < D) vD[tid] = rho[p.col_cov[tid]];
   __syncthreads();
-  for (int k0 = wv; k0 < D; k0 += 64) { // t = R rho_D (w is free again)
-    double a[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int k0 = wv; k0 < D; k0 += 128) { // t = R rho_D (w is free again; R has explicit zeros left of its diagonal)
+    double a[8];
+    const double *row[8];
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
-      const int kr = k0 + 16 * u;
-      if (kr < D)
-        for (int c = lane; c < D; c += 64)
-          if (c >= kr) a[u] = fma(p.R[(size_t)kr * p.LD + c], vD[c], a[u]);
+    for (int u = 0; u < 8; u++) a[u] = 0.0, row[u] = p.R + (size_t)min(k0 + 16 * u, D - 1) * p.LD;
+    for (int c = lane; c < D; c += 64) {
+      const double x = vD[c];
+#pragma unroll
+      for (int u = 0; u < 8; u++) a[u] = fma(row[u][c], x, a[u]);
     }
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
-      const int kr = k0 + 16 * u;
+    for (int u = 0; u < 8; u++) {
       const double r = wave_sum_f64(a[u]);
-      if (lane == 0 && kr < D) w[kr] = r;
+      if (lane == 0 && k0 + 16 * u < D) w[k0 + 16 * u] = r;
     }
   }
   __syncthreads();
   // s = U^-T t by forward substitution: thread k carries t_k; the 16 x 16 diagonal block is solved inside its wavefront
   // with lane shuffles, the rows below take the 16 new entries of s from LDS after one barrier per block
-  const int k = tid;
+  const int k = tid, kc = min(k, D - 1);
   double t = k < D ? w[k] : 0.0;
-  const double rd = k < D ? 1.0 / p.Y[(size_t)k * LA + k] : 0.0;
+  const double rd = 1.0 / p.Y[(size_t)kc * LA + kc];
   double u[16];
 #pragma unroll
-  for (int a = 0; a < 16; a++) u[a] = (a < D && k < D && k > a) ? p.Y[(size_t)a * LA + k] : 0.0;
+  for (int a = 0; a < 16; a++) u[a] = p.Y[(size_t)min(a, D - 1) * LA + kc];
   for (int ib = 0; ib < D; ib += 16) {
     double un[16];
 #pragma unroll
-    for (int a = 0; a < 16; a++) { // rows of the next block, in flight while this one is solved
-      const int i = ib + 16 + a;
-      un[a] = (i < D && k < D && k > i) ? p.Y[(size_t)i * LA + k] : 0.0;
-    }
+    for (int a = 0; a < 16; a++) un[a] = p.Y[(size_t)min(ib + 16 + a, D - 1) * LA + kc]; // next block, in flight during the solve
     const bool solver = wv == (ib >> 6);
     if (solver) {
 #pragma unroll
@@ -351,14 +354,14 @@ __global__ void __launch_bounds__(1024) k_ekf_dx_refine(EkfParams p, const doubl
         const int i = ib + a;
         const double s = __shfl(t * rd, i & 63, 64);
         if (k == i) ss[i] = s;
-        if (k > i) t = fma(-u[a], s, t);
+        if (k > i && k < D && i < D) t = fma(-u[a], s, t);
       }
     }
     __syncthreads();
     if (!solver) {
 #pragma unroll
       for (int a = 0; a < 16; a++)
-        if (ib + a < D) t = fma(-u[a], ss[ib + a], t);
+        if (ib + a < D && k > ib + a && k < D) t = fma(-u[a], ss[ib + a], t);
     }
 #pragma unroll
     for (int a = 0; a < 16; a++) u[a] = un[a];
@@ -367,21 +370,17 @@ __global__ void __launch_bounds__(1024) k_ekf_dx_refine(EkfParams p, const doubl
   const int q = tid >> 8, il = tid & 255; // dx += rho - Y^T s, the sum over k in four parts
   for (int i0 = 0; i0 < N; i0 += 256) {
     const int i = i0 + il;
-    double a = 0.0;
-    if (i < N) {
-      const double *Y = p.Y + D + i;
-      double b0 = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0;
-      int kk = q;
-      for (; kk + 12 < D; kk += 16) {
-        b0 = fma(Y[(size_t)kk * LA], ss[kk], b0);
-        b1 = fma(Y[(size_t)(kk + 4) * LA], ss[kk + 4], b1);
-        b2 = fma(Y[(size_t)(kk + 8) * LA], ss[kk + 8], b2);
-        b3 = fma(Y[(size_t)(kk + 12) * LA], ss[kk + 12], b3);
-      }
-      for (; kk < D; kk += 4) b0 = fma(Y[(size_t)kk * LA], ss[kk], b0);
-      a = (b0 + b1) + (b2 + b3);
+    const double *Y = p.Y + D + min(i, N - 1);
+    double b0 = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0;
+    int kk = q;
+    for (; kk + 12 < D; kk += 16) {
+      b0 = fma(Y[(size_t)kk * LA], ss[kk], b0);
+      b1 = fma(Y[(size_t)(kk + 4) * LA], ss[kk + 4], b1);
+      b2 = fma(Y[(size_t)(kk + 8) * LA], ss[kk + 8], b2);
+      b3 = fma(Y[(size_t)(kk + 12) * LA], ss[kk + 12], b3);
     }
-    part[q][il] = a;
+    for (; kk < D; kk += 4) b0 = fma(Y[(size_t)kk * LA], ss[kk], b0);
+    part[q][il] = (b0 + b1) + (b2 + b3);
     __syncthreads();
     if (q == 0 && i < N) p.dx[i] += rho[i] - ((part[0][il] + part[1][il]) + (part[2][il] + part[3][il]));
     __syncthreads();

@@ -113,29 +113,29 @@ template <int NTC> __global__ void __launch_bounds__(256) k_gram(GramParams p) {
   // global -> LDS staging: element e = tid + 256 q of a stage sits in row e / LD, column e % LD.  Loads are clamped, not
   // predicated (no per-lane control flow); elements past the end of the stack become zero rows, elements past the stage
   // go to a scratch slot no wavefront reads.
-  const int nq = (GR_ROWS * LD + 255) / 256;
+  constexpr int NQ = 2 * NTC; // >= ceil(GR_ROWS * LD / 256): a compile-time count keeps the loads in ONE basic block (behind
+                              // per-load branches the compiler waits for all outstanding loads before each one: measured, the
+                              // staging then costs more than the matrix products)
   const int row0 = tid / LD, col0 = tid - row0 * LD, step_r = 256 / LD, step_c = 256 - step_r * LD;
   constexpr int SCRATCH = GR_LS - 1; // column 271 of row 0
-  double v[GR_MAXLOAD];
-  auto fetch = [&](int chunk) {
+  double v[NQ];
+  int left = 0; // valid doubles of the stage in flight
+  auto fetch = [&](int chunk) { // issues the loads and nothing that consumes them: the values are first touched in stash()
     const int64_t first = (int64_t)chunk * GR_ROWS;
     const int64_t left64 = (p.rows_total - first) * LD; // doubles of the stack from this stage on (>= LD)
-    const int left = (int)(left64 < (int64_t)GR_ROWS * LD ? left64 : (int64_t)GR_ROWS * LD);
+    left = (int)(left64 < (int64_t)GR_ROWS * LD ? left64 : (int64_t)GR_ROWS * LD);
     const double *src = p.H + first * LD;
 #pragma unroll
-    for (int q = 0; q < GR_MAXLOAD; q++) {
-      if (q < nq) { // uniform
-        const int e = tid + 256 * q;
-        const double x = src[e < left ? e : left - 1];
-        v[q] = e < left ? x : 0.0;
-      }
+    for (int q = 0; q < NQ; q++) {
+      const int e = tid + 256 * q;
+      v[q] = src[e < left ? e : left - 1];
     }
   };
   auto stash = [&](double *buf) {
     int r = row0, cc = col0;
 #pragma unroll
-    for (int q = 0; q < GR_MAXLOAD; q++) {
-      if (q < nq) buf[r < GR_ROWS ? r * GR_LS + cc : SCRATCH] = v[q];
+    for (int q = 0; q < NQ; q++) {
+      buf[r < GR_ROWS ? r * GR_LS + cc : SCRATCH] = (tid + 256 * q) < left ? v[q] : 0.0;
       r += step_r, cc += step_c;
       if (cc >= LD) cc -= LD, r++;
     }
