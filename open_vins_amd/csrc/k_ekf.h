@@ -387,6 +387,117 @@ __global__ void __launch_bounds__(1024) k_ekf_dx_refine(EkfParams p, const doubl
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// EKF update from the Gram matrix of the stack (k_gram.h), in coordinates whitened by the PRIOR.
+//
+// With G = H^T H, g = H^T r (columns of the involved variables "D"), P_DD = U1^T U1 and B = U1^-T P(D, :):
+//     T = I + U1 G U1^T / sigma^2  = C^T C          (symmetric, eigenvalues >= 1: the Cholesky never sees a small pivot)
+//     P' = P - B^T B + Y2^T Y2,   Y2 = C^-T B        (= P - P(:,D) (P_DD^-1 - P_DD^-1 P'_DD P_DD^-1) P(D,:), P'_DD = U1^T T^-1 U1)
+//     dx = Y2^T y2,               y2 = C^-T (U1 g / sigma^2)
+// which is StateHelper::EKFUpdate (StateHelper.cpp:116-197) written for the information H^T R^-1 H instead of H.  Why not
+// R = chol(G) followed by the usual update: G is singular along the unobservable directions and weak wherever few features
+// constrain a variable; its Cholesky factor drops / garbles information of order eps |G| there, and the filter's covariance is
+// LARGE exactly in those directions — measured on the 52-frame closed loop: trajectory off by 6e-6 against 7e-14 with the
+// Householder compression.  Here every rounding error is relative to the prior: delta P' / P ~ eps |T|.
+// Both factorisations run through k_ekf_chol_step (carry columns [B | h]).
+// ---------------------------------------------------------------------------------------------------
+struct TformParams {
+  int N, D, LA, LG;
+  const int32_t *col_cov;
+  const double *G;   // [LG x LG] Gram matrix of [H | r], symmetric
+  const double *P;   // [N x N]
+  double *A;         // [D x LA] work matrix of the factorisation in flight
+  const double *Y1;  // [D x LA] = [U1 | B | 0] once the first factorisation is done
+  double *W;         // [D x D]
+  double inv_sigma2;
+};
+
+// A = [P_DD | P(D, :) | 0]      one thread per element
+__global__ void k_tf_gather(TformParams p) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (int64_t)p.D * p.LA) return;
+  const int r = (int)(e / p.LA), c = (int)(e - (int64_t)r * p.LA);
+  const double *Pr = p.P + (size_t)p.col_cov[r] * p.N;
+  p.A[e] = c < p.D ? Pr[p.col_cov[c]] : (c < p.D + p.N ? Pr[c - p.D] : 0.0);
+}
+
+// W = G U1^T       one wavefront per 16x16 tile
+__global__ void __launch_bounds__(256) k_tf_w(TformParams p) {
+  const int lane = threadIdx.x & 63;
+  const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int tm = (p.D + 15) / 16;
+  if (tile >= tm * tm) return;
+  const int r0 = (tile / tm) * 16, c0 = (tile % tm) * 16;
+  auto fa = [&](int i, int k) { const int r = r0 + i; return r < p.D ? p.G[(size_t)r * p.LG + k] : 0.0; };
+  auto fb = [&](int k, int j) { const int c = c0 + j; return (c < p.D && k >= c) ? p.Y1[(size_t)c * p.LA + k] : 0.0; };
+  const double4_t acc = mfma_tile(fa, fb, p.D, lane);
+  const int col = c0 + (lane & 15);
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const int row = r0 + (lane >> 4) + 4 * q;
+    if (row < p.D && col < p.D) p.W[(size_t)row * p.D + col] = acc[q];
+  }
+}
+
+// A[:, 0:D] = I + U1 W / sigma^2      one wavefront per 16x16 tile
+__global__ void __launch_bounds__(256) k_tf_t(TformParams p) {
+  const int lane = threadIdx.x & 63;
+  const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int tm = (p.D + 15) / 16;
+  if (tile >= tm * tm) return;
+  const int r0 = (tile / tm) * 16, c0 = (tile % tm) * 16;
+  auto fa = [&](int i, int k) { const int r = r0 + i; return (r < p.D && k >= r) ? p.Y1[(size_t)r * p.LA + k] : 0.0; };
+  auto fb = [&](int k, int j) { const int c = c0 + j; return c < p.D ? p.W[(size_t)k * p.D + c] : 0.0; };
+  const double4_t acc = mfma_tile(fa, fb, p.D, lane);
+  const int col = c0 + (lane & 15);
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const int row = r0 + (lane >> 4) + 4 * q;
+    if (row < p.D && col < p.D) p.A[(size_t)row * p.LA + col] = acc[q] * p.inv_sigma2 + (row == col ? 1.0 : 0.0);
+  }
+}
+
+// A[:, D : D+N] = B (from Y1);  A[:, D+N] = h = U1 g / sigma^2       one wavefront per row
+__global__ void __launch_bounds__(256) k_tf_bh(TformParams p) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= p.D) return;
+  const double *y = p.Y1 + (size_t)r * p.LA;
+  double *a = p.A + (size_t)r * p.LA;
+  for (int c = lane; c < p.N; c += 64) a[p.D + c] = y[p.D + c];
+  double s = 0.0;
+  for (int k = r + lane; k < p.D; k += 64) s = fma(y[k], p.G[(size_t)k * p.LG + p.D], s);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (lane == 0) a[p.D + p.N] = s * p.inv_sigma2;
+}
+
+// P' = P - (B^T B - Y2^T Y2)      one wavefront per 16x16 tile of P; both products are symmetric tile by tile
+__global__ void __launch_bounds__(256) k_tf_pupdate(EkfParams p, const double *Y1) {
+  const int lane = threadIdx.x & 63;
+  const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int tn = (p.N + 15) / 16;
+  if (tile >= tn * tn) return;
+  const int r0 = (tile / tn) * 16, c0 = (tile % tn) * 16;
+  const double *B = Y1 + p.D, *Y = p.Y + p.D;
+  auto fa1 = [&](int i, int k) { const int r = r0 + i; return (r < p.N) ? B[(size_t)k * p.LA + r] : 0.0; };
+  auto fb1 = [&](int k, int j) { const int c = c0 + j; return (c < p.N) ? B[(size_t)k * p.LA + c] : 0.0; };
+  auto fa2 = [&](int i, int k) { const int r = r0 + i; return (r < p.N) ? Y[(size_t)k * p.LA + r] : 0.0; };
+  auto fb2 = [&](int k, int j) { const int c = c0 + j; return (c < p.N) ? Y[(size_t)k * p.LA + c] : 0.0; };
+  const double4_t bb = mfma_tile(fa1, fb1, p.D, lane);
+  const double4_t yy = mfma_tile(fa2, fb2, p.D, lane);
+  const int col = c0 + (lane & 15);
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const int row = r0 + (lane >> 4) + 4 * q;
+    if (row < p.N && col < p.N) {
+      const double v = p.P[(size_t)row * p.N + col] - (bb[q] - yy[q]); // nothing accepted: G = 0, Y2 = B bit for bit, P' = P exactly
+      p.P[(size_t)row * p.N + col] = v;
+      if (row == col && v < 0.0) p.flags[1] = 1; // StateHelper.cpp:172-182
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------
 // box-plus of the resident tables (Type::update of the variables the GPU holds)
 // ---------------------------------------------------------------------------

@@ -167,10 +167,13 @@ struct ovgpu_ctx {
   DevBuf<int32_t> tree_err;      // [1] sticky: a node of the pipelined tree ran into its wait bound
   int tree_G = 0;
   bool tree_pipelined = true;
-  // measurement compression of the on-device update: 1 = Cholesky-QR on the matrix cores (k_gram.h), 0 = Householder TSQR.
-  // Whenever the factor itself leaves the device (mode A, ovgpu_measurement_compress) the TSQR runs.  OVGPU_COMPRESS=tsqr|cholqr
+  // measurement compression of the on-device update (OVGPU_COMPRESS = gram | tsqr | cholqr):
+  //   1 gram    the Gram matrix of the stack on the matrix cores (k_gram.h) + the EKF update in prior-whitened form (k_ekf.h)
+  //   0 tsqr    Householder TSQR + the reference-shaped update; always used when the factor itself leaves the device (mode A,
+  //             ovgpu_measurement_compress) and beyond 255 columns
+  //   2 cholqr  R = chol(Gram) + dx refinement for tall stacks (kept as the measured negative result of DESIGN.md section 4)
   int compress_gram = 1;
-  DevBuf<double> gram_part, gram_G, gram_rho;
+  DevBuf<double> gram_part, gram_G, gram_rho, Yaug2;
   bool gram_valid = false; // c->Rws holds chol(gram_G): the EKF stage refines dx against gram_G
   DevBuf<int32_t> gram_dropped, rows_used; // rows_used: rows of accepted features, counted by k_system
   int sys_grid = 1;
@@ -355,7 +358,7 @@ int ovgpu_create(const ovgpu_options *opts, int device, ovgpu_ctx **out) {
   c->row_stride = (d.feat_rep >= OVGPU_REP_ANCHORED_3D) ? 72 : 48;
   // allow the large dynamic LDS carve of the per-feature kernel
   if (const char *e = std::getenv("OVGPU_TSQR_PIPELINE")) c->tree_pipelined = std::atoi(e) != 0;
-  if (const char *e = std::getenv("OVGPU_COMPRESS")) c->compress_gram = std::string(e) == "tsqr" ? 0 : 1;
+  if (const char *e = std::getenv("OVGPU_COMPRESS")) c->compress_gram = std::string(e) == "tsqr" ? 0 : (std::string(e) == "cholqr" ? 2 : 1);
   if (const char *e = std::getenv("OVGPU_TSQR_OVERLAP")) c->tree_overlap = std::atoi(e) != 0 ? 1 : 0;
   if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess)
@@ -398,6 +401,7 @@ void ovgpu_destroy(ovgpu_ctx *c) {
   c->trk_count.release(), c->trk_cam.release(), c->trk_slot_in.release(), c->trk_cam_in.release(), c->trk_sel.release(), c->trk_nvalid.release(), c->trk_flag.release();
   c->trk_time.release(), c->trk_clone_times.release(), c->trk_uv.release(), c->trk_uvn.release(), c->trk_uv_in.release(), c->trk_uvn_in.release();
   c->dx.release(), c->flags.release(), c->given_status.release();
+  c->gram_part.release(), c->gram_G.release(), c->gram_rho.release(), c->Yaug2.release(), c->gram_dropped.release(), c->rows_used.release();
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
@@ -1004,6 +1008,52 @@ static int enqueue_ekf(ovgpu_ctx *c, const EkfJob &job = EkfJob()) {
   return launch_build_tables(c);
 }
 
+// EKF update straight from the Gram matrix in c->gram_G (k_ekf.h, "whitened by the prior"): two Cholesky-with-carry passes
+// through k_ekf_chol_step — P_DD carrying P(D, :), then T = I + U1 G U1^T / sigma^2 carrying [B | U1 g / sigma^2]
+static int enqueue_chol_carry(ovgpu_ctx *c, const EkfParams &p) {
+  const int TM = (p.D + 15) / 16, TL = (p.LA + 15) / 16;
+  for (int kb = 0; kb < p.D; kb += 16) {
+    const int tb = kb / 16;
+    int jobs = TL - tb; // writers of the finished rows
+    for (int it = tb + 1; it < TM; it++) jobs += TL - it;
+    hipLaunchKernelGGL(k_ekf_chol_step, dim3((jobs + 3) / 4), dim3(256), 0, c->stream, p, kb);
+  }
+  HIPCHK(hipGetLastError());
+  return OVGPU_OK;
+}
+
+static int enqueue_ekf_gram(ovgpu_ctx *c) {
+  const int D = c->D, N = c->N, LA = D + N + 1;
+  HIPCHK(c->Yaug2.reserve((size_t)D * LA));
+  EkfParams p;
+  p.N = N, p.D = D, p.DC = D, p.LD = c->LD, p.LA = LA, p.tri = 1, p.pred = nullptr;
+  p.R = nullptr, p.col_cov = c->col_cov.p, p.P = c->P.p, p.Mt = c->Mt.p, p.A = c->Aaug.p, p.Y = c->Yaug.p;
+  p.dx = c->dx.p, p.flags = c->flags.p, p.sigma2 = c->dopt.sigma_pix_sq;
+  TformParams t;
+  t.N = N, t.D = D, t.LA = LA, t.LG = 16 * ((c->LD + 15) / 16), t.col_cov = c->col_cov.p, t.G = c->gram_G.p, t.P = c->P.p;
+  t.A = c->Aaug.p, t.Y1 = c->Yaug.p, t.W = c->Mt.p, t.inv_sigma2 = 1.0 / c->dopt.sigma_pix_sq;
+  hipStream_t s = c->stream;
+  HIPCHK(hipMemsetAsync(c->flags.p, 0, 4 * sizeof(int32_t), s));
+  const int tm = (D + 15) / 16, tn = (N + 15) / 16;
+  const int64_t elems = (int64_t)D * LA;
+  hipLaunchKernelGGL(k_tf_gather, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, s, t);
+  int rc = enqueue_chol_carry(c, p); // Y1 = [U1 | B | 0] in c->Yaug
+  if (rc != OVGPU_OK) return rc;
+  hipLaunchKernelGGL(k_tf_w, dim3((tm * tm + 3) / 4), dim3(256), 0, s, t);
+  hipLaunchKernelGGL(k_tf_t, dim3((tm * tm + 3) / 4), dim3(256), 0, s, t);
+  hipLaunchKernelGGL(k_tf_bh, dim3((D + 3) / 4), dim3(256), 0, s, t);
+  p.Y = c->Yaug2.p;
+  rc = enqueue_chol_carry(c, p); // Y2 = [C | C^-T B | C^-T h] in c->Yaug2
+  if (rc != OVGPU_OK) return rc;
+  hipLaunchKernelGGL(k_ekf_dx, dim3((N + 255) / 256), dim3(256), 0, s, p);
+  hipLaunchKernelGGL(k_tf_pupdate, dim3((tn * tn + 3) / 4), dim3(256), 0, s, p, (const double *)c->Yaug.p);
+  const int n = std::max(c->C, c->K);
+  hipLaunchKernelGGL(k_boxplus, dim3((n + 255) / 256), dim3(256), 0, s, c->C, c->K, p.dx, c->clone_cov.p, c->calib_cov.p, c->intr_cov.p,
+                     c->clone_qp.p, c->calib_qp.p, c->intr.p, (const int32_t *)nullptr);
+  HIPCHK(hipGetLastError());
+  return launch_build_tables(c);
+}
+
 static EventPair *next_events(ovgpu_ctx *c, std::vector<EventPair> &v, size_t idx) {
   if (idx >= v.size()) {
     if (v.size() >= 8192) return nullptr;
@@ -1028,6 +1078,7 @@ static int enqueue_pipeline(ovgpu_ctx *c, int stages, bool slam = false, bool fa
     if (rcl != OVGPU_OK) return rcl;
   }
   EventPair *eu = nullptr, *ec = nullptr, *es = nullptr;
+  bool tform = false;
   if (c->timing) {
     eu = next_events(c, c->ev_update, c->ev_used);
     ec = next_events(c, c->ev_compress, c->ev_used);
@@ -1045,30 +1096,29 @@ static int enqueue_pipeline(ovgpu_ctx *c, int stages, bool slam = false, bool fa
     if (es) HIPCHK(hipEventRecord(es->a, c->stream));
     if ((rc = enqueue_system(c)) != OVGPU_OK) return rc;
     if (es) HIPCHK(hipEventRecord(es->b, c->stream));
-    // Cholesky-QR (k_gram.h) only for tall stacks: with few accepted rows per column the weak (not null) directions of H lose
-    // information of order sqrt(eps) with the dropped pivots (measured |dP| / |P| = 2e-9 on a 74 x 72 stack, below 1e-10 from
-    // 4 rows per column on), and the TSQR of a short stack is cheap.  The accepted-row count is known only after the gate:
-    // one 4-byte read-back (~20 us) decides.
-    bool use_gram = (factor_stays || (stages & STAGE_EKF) != 0) && c->compress_gram && (c->LD + 15) / 16 <= gram::GR_NT && c->F > 0 &&
-                    c->rows_total >= (int64_t)4 * c->LD;
-    if (use_gram && !gram_only) {
+    // which compression (see ovgpu_ctx::compress_gram)
+    const bool fits = (c->LD + 15) / 16 <= gram::GR_NT && c->F > 0;
+    tform = !gram_only && c->compress_gram == 1 && fits && (stages & STAGE_EKF) != 0;
+    bool cholqr = !gram_only && c->compress_gram == 2 && fits && (factor_stays || (stages & STAGE_EKF) != 0) && c->rows_total >= (int64_t)4 * c->LD;
+    if (cholqr) { // tall stacks only, and the accepted-row count is known only after the gate: one 4-byte read-back
       int32_t used = 0;
       HIPCHK(hipMemcpyAsync(&used, c->rows_used.p, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
       HIPCHK(hipStreamSynchronize(c->stream));
-      use_gram = used >= 4 * c->LD;
+      cholqr = used >= 4 * c->LD;
     }
     if (ec) HIPCHK(hipEventRecord(ec->a, c->stream));
-    if (gram_only) { // the sharded update sums Gram matrices across GPUs before anything is factored
+    if (gram_only || tform) { // Gram matrix only: summed across GPUs (sharded update) or consumed by the prior-whitened EKF update
       if ((c->LD + 15) / 16 > gram::GR_NT) return set_err(OVGPU_ERR_CAPACITY, "the Gram route holds at most 255 Jacobian columns");
+      c->gram_valid = false;
       rc = enqueue_compress_gram(c, false);
     } else {
-      rc = enqueue_compress(c, use_gram);
+      rc = enqueue_compress(c, cholqr);
     }
     if (rc != OVGPU_OK) return rc;
     if (ec) HIPCHK(hipEventRecord(ec->b, c->stream));
   }
   if (stages & STAGE_EKF) {
-    if ((rc = enqueue_ekf(c)) != OVGPU_OK) return rc;
+    if ((rc = tform ? enqueue_ekf_gram(c) : enqueue_ekf(c)) != OVGPU_OK) return rc;
   }
   if (eu) HIPCHK(hipEventRecord(eu->b, c->stream));
   return OVGPU_OK;
@@ -2163,9 +2213,7 @@ int ovgpu_msckf_gram_update(ovgpu_ctx *c, const void *gram_dev, double *dx, doub
   HIPCHK(c->Rws.reserve((size_t)16 * c->D * c->LD));
   hipStream_t s = c->stream;
   HIPCHK(hipMemcpyAsync(c->gram_G.p, gram_dev, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
-  int rc = enqueue_gram_factor(c);
-  if (rc != OVGPU_OK) return rc;
-  rc = enqueue_ekf(c);
+  int rc = enqueue_ekf_gram(c);
   if (rc != OVGPU_OK) return rc;
   if (stats) {
     std::memset(stats, 0, sizeof(*stats));

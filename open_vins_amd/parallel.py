@@ -7,11 +7,11 @@ reduction — QR of the stacked triangles has the same R^T R as QR of the full s
 one all-gather of G triangles over RCCL/xGMI (G * D * (D+1) * 8 B: 2.8 MB at D = 208, 8 GPUs), after which every
 rank runs the identical merge + EKF update and ends with bit-identical (dx, P) without a broadcast.
 
-When the device compresses through the Gram matrix (csrc/k_gram.h: tall stacks, D <= 255) the exchange is simpler still:
+When the device compresses through the Gram matrix (csrc/k_gram.h, D <= 255) the exchange is simpler still:
 [H | r]^T [H | r] of the full stack is the SUM of the shards' Gram matrices, i.e. one all-reduce of (16 ceil((D+1)/16))^2
-doubles (0.4 MB at D = 208) whose last element carries the accepted-row count; every rank factors the sum and updates.
-A sum below 4 (D + 1) rows (short stack: the Cholesky factor of a Gram matrix loses accuracy there) falls back to the
-triangle exchange — all ranks see the same count, so they branch together.
+doubles (0.4 MB at D = 208; the trailing element carries the accepted-row count); every rank then applies the identical
+prior-whitened update (k_ekf.h) to the sum.  Backends without the Gram protocol, D > 255 and OVGPU_COMPRESS=tsqr use the
+triangle exchange.
 
 `backend` below is anything with `triangle_len()`, `local_into(tensor)` and `merge_update_from(tensor, G)`:
 the product uses GpuShardBackend (thin wrapper over updater.UpdaterMSCKF); the CPU gloo tests inject a host
@@ -70,9 +70,7 @@ def distributed_update(backend, dist, device, want_outputs=True):
             dist.all_reduce(gram, op=dist.ReduceOp.SUM)
             if gram.is_cuda:
                 torch.cuda.current_stream(device).synchronize()
-        ld = int(round((1.0 + (1.0 + 4.0 * n) ** 0.5) / 2.0))  # n = D (D + 1)  ->  D + 1
-        if float(gram[-1]) >= 4 * ld:
-            return backend.gram_update_from(gram, want_outputs)
+        return backend.gram_update_from(gram, want_outputs)
     mine = torch.empty(n, dtype=torch.float64, device=device)
     backend.local_into(mine)  # synchronises the context's stream before returning
     if world == 1:

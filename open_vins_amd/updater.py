@@ -373,7 +373,7 @@ class UpdaterMSCKF:
         """Doubles of the Gram buffer (16 ceil((D+1)/16) squared + the accepted-row count), or 0 when this state does not
         fit the Gram route (D > 255) or OVGPU_COMPRESS=tsqr selects the Householder exchange."""
         import os
-        if os.environ.get("OVGPU_COMPRESS", "") == "tsqr" or self.triangle_len() > 255 * 256:
+        if os.environ.get("OVGPU_COMPRESS", "") in ("tsqr", "cholqr") or self.triangle_len() > 255 * 256:
             return 0
         n = C.c_int64(0)
         capi.check(self.lib.ovgpu_gram_len(self._ctx, C.byref(n)), "ovgpu_gram_len")

@@ -461,11 +461,13 @@ def _update_with_env(Updater, prob, opts, tri, **env):
 
 @pytest.mark.parametrize("kw", [dict(F=300), dict(cfg=4, F=120), dict(F=200, K=1, C=12), dict(F=3), dict(F=150, track="ragged"),
                                 dict(F=40, C=6, K=1)])
-def test_cholesky_qr_compression_gives_the_householder_posterior(Updater, oracle, kw):
-    """The on-device update compresses with R = chol([H r]^T [H r]) on the matrix cores (k_gram.h) unless OVGPU_COMPRESS=tsqr:
-    both factors satisfy R^T R = H^T H, so dx and P agree (far inside the parity tolerance against the oracle, which compresses
-    with Givens rotations like the reference).  LD = 209 / 237 / 87 / 51 columns: 14, 15, 6 and 4 column tiles; F = 3 has fewer
-    rows than columns."""
+def test_gram_route_gives_the_householder_posterior(Updater, oracle, kw):
+    """The on-device update accumulates the Gram matrix [H r]^T [H r] on the matrix cores (k_gram.h) and updates in coordinates
+    whitened by the prior (k_ekf.h) unless OVGPU_COMPRESS=tsqr selects the Householder TSQR + the reference-shaped update:
+    same dx and P, far inside the parity tolerance against the oracle (which compresses with Givens rotations like the
+    reference).  LD = 209 / 237 / 87 / 51 columns: 14, 15, 6 and 4 column tiles; F = 3 has hardly more rows than columns.
+    OVGPU_COMPRESS=cholqr (R = chol(Gram) + dx refinement, tall stacks only) is the documented negative result: it holds
+    the parity tolerance on these snapshots but not in the closed loop (tests/test_closed_loop.py runs the default)."""
     kw = dict(kw)
     prob = synth.make_problem(kw.pop("cfg", 2), **kw)
     opts = capi.default_options(chi2_multipler=1.0)
@@ -473,13 +475,15 @@ def test_cholesky_qr_compression_gives_the_householder_posterior(Updater, oracle
     tri = oracle.triangulate(opts, v)
     ref = oracle.msckf_update(opts, v, given=tri)
     a = _update_with_env(Updater, prob, opts, tri, OVGPU_COMPRESS="tsqr")
-    b = _update_with_env(Updater, prob, opts, tri, OVGPU_COMPRESS="cholqr")
-    b2 = _update_with_env(Updater, prob, opts, tri, OVGPU_COMPRESS="cholqr")
-    assert np.array_equal(a["feat_status"], ref["feat_status"]) and np.array_equal(b["feat_status"], ref["feat_status"])
-    assert b["stats"]["status"] == 0 and np.array_equal(b["P"], b["P"].T)
+    b = _update_with_env(Updater, prob, opts, tri, OVGPU_COMPRESS="gram")
+    b2 = _update_with_env(Updater, prob, opts, tri, OVGPU_COMPRESS="gram")
+    c = _update_with_env(Updater, prob, opts, tri, OVGPU_COMPRESS="cholqr")
+    for o in (a, b, c):
+        assert np.array_equal(o["feat_status"], ref["feat_status"]) and o["stats"]["status"] == 0 and np.array_equal(o["P"], o["P"].T)
     assert np.array_equal(b["dx"], b2["dx"]) and np.array_equal(b["P"], b2["P"])  # ordered sums: reproducible bit for bit
-    assert _rel(b["dx"], a["dx"]) < 1e-8 and _rel(b["P"], a["P"]) < 1e-9
-    assert _rel(b["dx"], ref["dx"]) < 1e-7 and _rel(b["P"], ref["P"]) < 1e-8
+    assert _rel(b["dx"], a["dx"]) < 1e-9 and _rel(b["P"], a["P"]) < 1e-10
+    assert _rel(b["dx"], ref["dx"]) < 1e-8 and _rel(b["P"], ref["P"]) < 1e-9
+    assert _rel(c["dx"], ref["dx"]) < 1e-7 and _rel(c["P"], ref["P"]) < 1e-8
 
 
 @pytest.mark.parametrize("kw", [dict(F=300), dict(cfg=4, F=120), dict(F=200, K=1, C=12)])
