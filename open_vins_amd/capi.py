@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -235,6 +236,14 @@ def load():
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()'). "
                 "There is no CPU fallback.")
+        # torch first when it is installed: its wheel bundles its own HIP runtime, and a process that loads libovgpu.so (linked
+        # against /opt/rocm's) BEFORE importing torch ends up with two runtimes of which torch's sees no device (measured on the
+        # GPU box: torch.cuda.is_available() turns False).  The sharded update and the benchmark need both in one process.
+        if "torch" not in sys.modules and not os.environ.get("OVGPU_NO_TORCH_PRELOAD"):
+            try:
+                import torch  # noqa: F401
+            except Exception:
+                pass
         lib = C.CDLL(LIB_PATH)
         declare(lib)
         _lib = lib

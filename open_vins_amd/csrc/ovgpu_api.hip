@@ -174,6 +174,7 @@ struct ovgpu_ctx {
   //   2 cholqr  R = chol(Gram) + dx refinement for tall stacks (kept as the measured negative result of DESIGN.md section 4)
   int compress_gram = 1;
   DevBuf<double> gram_part, gram_G, gram_rho, Yaug2;
+  bool prior_overlap = true; // OVGPU_PRIOR_OVERLAP=0: factor the prior block after the compression instead of next to it
   bool gram_valid = false; // c->Rws holds chol(gram_G): the EKF stage refines dx against gram_G
   DevBuf<int32_t> gram_dropped, rows_used; // rows_used: rows of accepted features, counted by k_system
   int sys_grid = 1;
@@ -358,6 +359,7 @@ int ovgpu_create(const ovgpu_options *opts, int device, ovgpu_ctx **out) {
   c->row_stride = (d.feat_rep >= OVGPU_REP_ANCHORED_3D) ? 72 : 48;
   // allow the large dynamic LDS carve of the per-feature kernel
   if (const char *e = std::getenv("OVGPU_TSQR_PIPELINE")) c->tree_pipelined = std::atoi(e) != 0;
+  if (const char *e = std::getenv("OVGPU_PRIOR_OVERLAP")) c->prior_overlap = std::atoi(e) != 0;
   if (const char *e = std::getenv("OVGPU_COMPRESS")) c->compress_gram = std::string(e) == "tsqr" ? 0 : (std::string(e) == "cholqr" ? 2 : 1);
   if (const char *e = std::getenv("OVGPU_TSQR_OVERLAP")) c->tree_overlap = std::atoi(e) != 0 ? 1 : 0;
   if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
@@ -1010,19 +1012,23 @@ static int enqueue_ekf(ovgpu_ctx *c, const EkfJob &job = EkfJob()) {
 
 // EKF update straight from the Gram matrix in c->gram_G (k_ekf.h, "whitened by the prior"): two Cholesky-with-carry passes
 // through k_ekf_chol_step — P_DD carrying P(D, :), then T = I + U1 G U1^T / sigma^2 carrying [B | U1 g / sigma^2]
-static int enqueue_chol_carry(ovgpu_ctx *c, const EkfParams &p) {
+static int enqueue_chol_carry(ovgpu_ctx *c, const EkfParams &p, hipStream_t s) {
   const int TM = (p.D + 15) / 16, TL = (p.LA + 15) / 16;
   for (int kb = 0; kb < p.D; kb += 16) {
     const int tb = kb / 16;
     int jobs = TL - tb; // writers of the finished rows
     for (int it = tb + 1; it < TM; it++) jobs += TL - it;
-    hipLaunchKernelGGL(k_ekf_chol_step, dim3((jobs + 3) / 4), dim3(256), 0, c->stream, p, kb);
+    hipLaunchKernelGGL(k_ekf_chol_step, dim3((jobs + 3) / 4), dim3(256), 0, s, p, kb);
   }
   HIPCHK(hipGetLastError());
   return OVGPU_OK;
 }
 
-static int enqueue_ekf_gram(ovgpu_ctx *c) {
+// prior_on: the factorisation of the prior block (it needs nothing from this update's measurements) goes to that stream
+// and is awaited through c->ev_join; prior_done: it has been enqueued already
+static int enqueue_ekf_gram(ovgpu_ctx *c, int part = 3) {
+  // part 1: P_DD = U1^T U1 carrying P(D, :) (depends on the prior only; on c->stream2 when part == 1, behind ev_fork / ev_join)
+  // part 2: everything that needs the Gram matrix; part 3: both, on the context's stream
   const int D = c->D, N = c->N, LA = D + N + 1;
   HIPCHK(c->Yaug2.reserve((size_t)D * LA));
   EkfParams p;
@@ -1033,25 +1039,37 @@ static int enqueue_ekf_gram(ovgpu_ctx *c) {
   t.N = N, t.D = D, t.LA = LA, t.LG = 16 * ((c->LD + 15) / 16), t.col_cov = c->col_cov.p, t.G = c->gram_G.p, t.P = c->P.p;
   t.A = c->Aaug.p, t.Y1 = c->Yaug.p, t.W = c->Mt.p, t.inv_sigma2 = 1.0 / c->dopt.sigma_pix_sq;
   hipStream_t s = c->stream;
-  HIPCHK(hipMemsetAsync(c->flags.p, 0, 4 * sizeof(int32_t), s));
   const int tm = (D + 15) / 16, tn = (N + 15) / 16;
-  const int64_t elems = (int64_t)D * LA;
-  hipLaunchKernelGGL(k_tf_gather, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, s, t);
-  int rc = enqueue_chol_carry(c, p); // Y1 = [U1 | B | 0] in c->Yaug
-  if (rc != OVGPU_OK) return rc;
-  hipLaunchKernelGGL(k_tf_w, dim3((tm * tm + 3) / 4), dim3(256), 0, s, t);
-  hipLaunchKernelGGL(k_tf_t, dim3((tm * tm + 3) / 4), dim3(256), 0, s, t);
-  hipLaunchKernelGGL(k_tf_bh, dim3((D + 3) / 4), dim3(256), 0, s, t);
-  p.Y = c->Yaug2.p;
-  rc = enqueue_chol_carry(c, p); // Y2 = [C | C^-T B | C^-T h] in c->Yaug2
-  if (rc != OVGPU_OK) return rc;
-  hipLaunchKernelGGL(k_ekf_dx, dim3((N + 255) / 256), dim3(256), 0, s, p);
-  hipLaunchKernelGGL(k_tf_pupdate, dim3((tn * tn + 3) / 4), dim3(256), 0, s, p, (const double *)c->Yaug.p);
-  const int n = std::max(c->C, c->K);
-  hipLaunchKernelGGL(k_boxplus, dim3((n + 255) / 256), dim3(256), 0, s, c->C, c->K, p.dx, c->clone_cov.p, c->calib_cov.p, c->intr_cov.p,
-                     c->clone_qp.p, c->calib_qp.p, c->intr.p, (const int32_t *)nullptr);
-  HIPCHK(hipGetLastError());
-  return launch_build_tables(c);
+  int rc = OVGPU_OK;
+  if (part & 1) {
+    HIPCHK(hipMemsetAsync(c->flags.p, 0, 4 * sizeof(int32_t), s));
+    hipStream_t sp = s;
+    if (part == 1) { // everything enqueued so far (the previous update's tail reads these buffers) precedes the side stream's work
+      HIPCHK(hipEventRecord(c->ev_fork, s));
+      HIPCHK(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+      sp = c->stream2;
+    }
+    const int64_t elems = (int64_t)D * LA;
+    hipLaunchKernelGGL(k_tf_gather, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, sp, t);
+    if ((rc = enqueue_chol_carry(c, p, sp)) != OVGPU_OK) return rc; // Y1 = [U1 | B | 0] in c->Yaug
+    if (part == 1) HIPCHK(hipEventRecord(c->ev_join, sp));
+  }
+  if (part & 2) {
+    if (part == 2) HIPCHK(hipStreamWaitEvent(s, c->ev_join, 0));
+    hipLaunchKernelGGL(k_tf_w, dim3((tm * tm + 3) / 4), dim3(256), 0, s, t);
+    hipLaunchKernelGGL(k_tf_t, dim3((tm * tm + 3) / 4), dim3(256), 0, s, t);
+    hipLaunchKernelGGL(k_tf_bh, dim3((D + 3) / 4), dim3(256), 0, s, t);
+    p.Y = c->Yaug2.p;
+    if ((rc = enqueue_chol_carry(c, p, s)) != OVGPU_OK) return rc; // Y2 = [C | C^-T B | C^-T h] in c->Yaug2
+    hipLaunchKernelGGL(k_ekf_dx, dim3((N + 255) / 256), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(k_tf_pupdate, dim3((tn * tn + 3) / 4), dim3(256), 0, s, p, (const double *)c->Yaug.p);
+    const int n = std::max(c->C, c->K);
+    hipLaunchKernelGGL(k_boxplus, dim3((n + 255) / 256), dim3(256), 0, s, c->C, c->K, p.dx, c->clone_cov.p, c->calib_cov.p, c->intr_cov.p,
+                       c->clone_qp.p, c->calib_qp.p, c->intr.p, (const int32_t *)nullptr);
+    HIPCHK(hipGetLastError());
+    return launch_build_tables(c);
+  }
+  return OVGPU_OK;
 }
 
 static EventPair *next_events(ovgpu_ctx *c, std::vector<EventPair> &v, size_t idx) {
@@ -1088,6 +1106,11 @@ static int enqueue_pipeline(ovgpu_ctx *c, int stages, bool slam = false, bool fa
   }
   if (eu) HIPCHK(hipEventRecord(eu->a, c->stream));
   int rc = OVGPU_OK;
+  const bool fits = (c->LD + 15) / 16 <= gram::GR_NT && c->F > 0;
+  tform = !gram_only && c->compress_gram == 1 && fits && (stages & STAGE_EKF) != 0 && (stages & STAGE_LOCAL) != 0;
+  // the prior block's factorisation needs nothing from the measurements: it runs next to the per-feature kernels
+  const bool side = tform && c->stream2 != nullptr && c->ev_fork != nullptr && c->ev_join != nullptr && c->prior_overlap;
+  if (side && (rc = enqueue_ekf_gram(c, 1)) != OVGPU_OK) return rc;
   if (stages & STAGE_LOCAL) {
     if (c->given_tri) {
       // the gate overwrites status; restore the caller's per-feature status for this run
@@ -1097,8 +1120,6 @@ static int enqueue_pipeline(ovgpu_ctx *c, int stages, bool slam = false, bool fa
     if ((rc = enqueue_system(c)) != OVGPU_OK) return rc;
     if (es) HIPCHK(hipEventRecord(es->b, c->stream));
     // which compression (see ovgpu_ctx::compress_gram)
-    const bool fits = (c->LD + 15) / 16 <= gram::GR_NT && c->F > 0;
-    tform = !gram_only && c->compress_gram == 1 && fits && (stages & STAGE_EKF) != 0;
     bool cholqr = !gram_only && c->compress_gram == 2 && fits && (factor_stays || (stages & STAGE_EKF) != 0) && c->rows_total >= (int64_t)4 * c->LD;
     if (cholqr) { // tall stacks only, and the accepted-row count is known only after the gate: one 4-byte read-back
       int32_t used = 0;
@@ -1118,7 +1139,7 @@ static int enqueue_pipeline(ovgpu_ctx *c, int stages, bool slam = false, bool fa
     if (ec) HIPCHK(hipEventRecord(ec->b, c->stream));
   }
   if (stages & STAGE_EKF) {
-    if ((rc = tform ? enqueue_ekf_gram(c) : enqueue_ekf(c)) != OVGPU_OK) return rc;
+    if ((rc = tform ? enqueue_ekf_gram(c, side ? 2 : 3) : enqueue_ekf(c)) != OVGPU_OK) return rc;
   }
   if (eu) HIPCHK(hipEventRecord(eu->b, c->stream));
   return OVGPU_OK;
