@@ -174,6 +174,7 @@ struct ovgpu_ctx {
   //   2 cholqr  R = chol(Gram) + dx refinement for tall stacks (kept as the measured negative result of DESIGN.md section 4)
   int compress_gram = 1;
   DevBuf<double> gram_part, gram_G, gram_rho, Yaug2;
+  bool prior_pending = false; // the sharded update's local stage has started the prior block's factorisation on stream2
   bool prior_overlap = true; // OVGPU_PRIOR_OVERLAP=0: factor the prior block after the compression instead of next to it
   bool gram_valid = false; // c->Rws holds chol(gram_G): the EKF stage refines dx against gram_G
   DevBuf<int32_t> gram_dropped, rows_used; // rows_used: rows of accepted features, counted by k_system
@@ -377,6 +378,7 @@ void ovgpu_destroy(ovgpu_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
+  if (c->stream2) (void)hipStreamSynchronize(c->stream2); // a prior-block factorisation nobody joined
   for (auto &e : c->ev_compress) {
     if (e.a) (void)hipEventDestroy(e.a);
     if (e.b) (void)hipEventDestroy(e.b);
@@ -476,6 +478,7 @@ static int build_columns(ovgpu_ctx *c) {
 
 int ovgpu_set_state(ovgpu_ctx *c, const ovgpu_state_view *st) {
   if (!c || !st) return set_err(OVGPU_ERR_INVALID, "null argument");
+  c->prior_pending = false; // the covariance changes: a prior-block factorisation started for a sharded update is stale
   if (st->N <= 0 || st->C <= 0 || st->K <= 0) return set_err(OVGPU_ERR_INVALID, "empty state");
   if (st->C > OVG_MAX_CLONES || st->K > OVG_MAX_CAMS) return set_err(OVGPU_ERR_CAPACITY, "too many clones / cameras");
   if (!st->P || !st->clone_q_p || !st->clone_q_p_fej || !st->clone_cov_id || !st->calib_q_p || !st->intrinsics || !st->cam_is_fisheye ||
@@ -559,6 +562,7 @@ int ovgpu_set_state(ovgpu_ctx *c, const ovgpu_state_view *st) {
 
 int ovgpu_reset_state(ovgpu_ctx *c) {
   if (!c) return set_err(OVGPU_ERR_INVALID, "null ctx");
+  c->prior_pending = false; // the covariance changes: a prior-block factorisation started for a sharded update is stale
   if (!c->have_state || c->poses_only) return set_err(OVGPU_ERR_NO_STATE, "ovgpu_set_state was never called");
   hipStream_t s = c->stream;
   HIPCHK(hipMemcpyAsync(c->P.p, c->P0.p, sizeof(double) * c->N * c->N, hipMemcpyDeviceToDevice, s));
@@ -976,6 +980,7 @@ struct EkfJob {
 };
 
 static int enqueue_ekf(ovgpu_ctx *c, const EkfJob &job = EkfJob()) {
+  c->prior_pending = false;
   EkfParams p;
   const bool tri = job.R == nullptr;
   p.N = c->N, p.D = tri ? c->D : job.rows, p.DC = c->D, p.LD = c->LD, p.LA = p.D + c->N + 1, p.tri = tri ? 1 : 0, p.pred = job.pred;
@@ -1030,6 +1035,7 @@ static int enqueue_ekf_gram(ovgpu_ctx *c, int part = 3) {
   // part 1: P_DD = U1^T U1 carrying P(D, :) (depends on the prior only; on c->stream2 when part == 1, behind ev_fork / ev_join)
   // part 2: everything that needs the Gram matrix; part 3: both, on the context's stream
   const int D = c->D, N = c->N, LA = D + N + 1;
+  if (part == 3) c->prior_pending = false;
   HIPCHK(c->Yaug2.reserve((size_t)D * LA));
   EkfParams p;
   p.N = N, p.D = D, p.DC = D, p.LD = c->LD, p.LA = LA, p.tri = 1, p.pred = nullptr;
@@ -1454,6 +1460,7 @@ int ovgpu_slam_delayed_init(ovgpu_ctx *c, int32_t feat_rep, int32_t *feat_status
                             double *lm_value, double *lm_fej, int32_t *anchor_cam, int32_t *anchor_clone, double *dx_seq, int32_t *N_out,
                             double *P_out, ovgpu_update_stats *stats) {
   if (!c) return set_err(OVGPU_ERR_INVALID, "null ctx");
+  c->prior_pending = false; // the covariance changes: a prior-block factorisation started for a sharded update is stale
   if (!c->have_state || c->poses_only) return set_err(OVGPU_ERR_NO_STATE, "ovgpu_set_state was never called");
   if (!c->have_feats) return set_err(OVGPU_ERR_NO_STATE, "ovgpu_set_features was never called (or the state changed since)");
   if (feat_rep < OVGPU_REP_GLOBAL_3D || feat_rep > OVGPU_REP_ANCHORED_INVERSE_DEPTH_SINGLE)
@@ -1633,6 +1640,7 @@ static int rebuild_variables(ovgpu_ctx *c) {
 
 // UpdaterSLAM::perform_anchor_change: k_anchor_change builds Phi and rewrites the landmark, k_cov_propagate applies it (Q = 0)
 static int enqueue_anchor_change(ovgpu_ctx *c, int l, int new_cam, int new_clone) {
+  c->prior_pending = false;
   const int32_t old = c->h_lm_anchor[l];
   const int old_cam = old >> 10;
   const int lsz = lm_dof(c->lm_rep);
@@ -1728,6 +1736,7 @@ int ovgpu_state_dims(ovgpu_ctx *c, int32_t *N_out, int32_t *C_out) {
 
 int ovgpu_state_marginalize(ovgpu_ctx *c, int32_t cov_id, int32_t size) {
   if (!c) return set_err(OVGPU_ERR_INVALID, "null ctx");
+  c->prior_pending = false; // the covariance changes: a prior-block factorisation started for a sharded update is stale
   if (!c->have_state || c->poses_only) return set_err(OVGPU_ERR_NO_STATE, "ovgpu_set_state was never called");
   if (cov_id < 0 || size <= 0 || cov_id + size > c->N) return set_err(OVGPU_ERR_INVALID, "marginalised block outside the covariance");
   HIPCHK(hipSetDevice(c->device));
@@ -1816,6 +1825,7 @@ int ovgpu_state_marginalize(ovgpu_ctx *c, int32_t cov_id, int32_t size) {
 int ovgpu_state_augment_clone(ovgpu_ctx *c, int32_t src_cov_id, const double *q_p, const double *q_p_fej, int32_t dt_cov_id, const double *dnc_dt,
                               int32_t *new_cov_id) {
   if (!c || !q_p || !q_p_fej) return set_err(OVGPU_ERR_INVALID, "null argument");
+  c->prior_pending = false; // the covariance changes: a prior-block factorisation started for a sharded update is stale
   if (!c->have_state || c->poses_only) return set_err(OVGPU_ERR_NO_STATE, "ovgpu_set_state was never called");
   if (src_cov_id < 0 || src_cov_id + 6 > c->N) return set_err(OVGPU_ERR_INVALID, "cloned pose outside the covariance");
   if (dt_cov_id >= c->N || (dt_cov_id >= 0 && !dnc_dt)) return set_err(OVGPU_ERR_INVALID, "bad time-offset argument");
@@ -1856,6 +1866,7 @@ int ovgpu_state_augment_clone(ovgpu_ctx *c, int32_t src_cov_id, const double *q_
 int ovgpu_state_propagate(ovgpu_ctx *c, int32_t new_cov_id, int32_t n_new, int32_t n_old, const int32_t *old_cov_ids, const double *Phi,
                           const double *Q) {
   if (!c || !old_cov_ids || !Phi || !Q) return set_err(OVGPU_ERR_INVALID, "null argument");
+  c->prior_pending = false; // the covariance changes: a prior-block factorisation started for a sharded update is stale
   if (!c->have_state || c->poses_only) return set_err(OVGPU_ERR_NO_STATE, "ovgpu_set_state was never called");
   if (n_new <= 0 || n_old <= 0 || new_cov_id < 0 || new_cov_id + n_new > c->N) return set_err(OVGPU_ERR_INVALID, "propagated block outside the covariance"); // :41-44
   for (int k = 0; k < n_old; k++)
@@ -2202,7 +2213,17 @@ int ovgpu_msckf_local_gram(ovgpu_ctx *c, int32_t *feat_status, double *chi2, dou
                            ovgpu_update_stats *stats) {
   if (!c || !gram_dev) return set_err(OVGPU_ERR_INVALID, "null argument");
   if (stats) std::memset(stats, 0, sizeof(*stats));
-  int rc = enqueue_pipeline(c, STAGE_LOCAL, false, true, true);
+  if (!c->have_state || c->poses_only) return set_err(OVGPU_ERR_NO_STATE, "ovgpu_set_state was never called");
+  HIPCHK(hipSetDevice(c->device));
+  int rc = OVGPU_OK;
+  // the prior block's factorisation of the update that follows (ovgpu_msckf_gram_update) needs nothing from the measurements
+  // or from the other ranks: it runs on the second stream next to the local stage and the all-reduce
+  c->prior_pending = false;
+  if ((c->LD + 15) / 16 <= gram::GR_NT && c->stream2 && c->ev_fork && c->ev_join && c->prior_overlap) {
+    if ((rc = enqueue_ekf_gram(c, 1)) != OVGPU_OK) return rc;
+    c->prior_pending = true;
+  }
+  rc = enqueue_pipeline(c, STAGE_LOCAL, false, true, true);
   if (rc != OVGPU_OK) return rc;
   const size_t n = (size_t)256 * ((c->LD + 15) / 16) * ((c->LD + 15) / 16);
   double *dst = static_cast<double *>(gram_dev);
@@ -2234,7 +2255,8 @@ int ovgpu_msckf_gram_update(ovgpu_ctx *c, const void *gram_dev, double *dx, doub
   HIPCHK(c->Rws.reserve((size_t)16 * c->D * c->LD));
   hipStream_t s = c->stream;
   HIPCHK(hipMemcpyAsync(c->gram_G.p, gram_dev, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
-  int rc = enqueue_ekf_gram(c);
+  int rc = enqueue_ekf_gram(c, c->prior_pending ? 2 : 3);
+  c->prior_pending = false;
   if (rc != OVGPU_OK) return rc;
   if (stats) {
     std::memset(stats, 0, sizeof(*stats));
