@@ -247,7 +247,10 @@ int ovgpu_set_triangulation(ovgpu_ctx *ctx, const double *p_FinA, const double *
  * The resident covariance, clone and calibration tables are updated in place
  * (box-plus of JPLQuat.h:114-125 / PoseJPL.h:74-91 / Vec.h:55-58), FEJ values
  * untouched, so a following call sees the posterior, as VioManager's
- * successive updater calls do (VioManager.cpp:525-547).                      */
+ * successive updater calls do (VioManager.cpp:525-547).
+ * The device does not factor the stack on this call: it accumulates [H | r]^T [H | r] on the matrix cores
+ * and applies the update in coordinates whitened by the prior (same dx, P' as compress -> EKFUpdate;
+ * DESIGN.md section 4).  Environment OVGPU_COMPRESS=tsqr keeps the reference's order.     */
 int ovgpu_msckf_update(ovgpu_ctx *ctx, int32_t *feat_status, double *chi2,
                        double *chi2_thresh, double *p_FinG, double *dx,
                        double *P_out, ovgpu_update_stats *stats);

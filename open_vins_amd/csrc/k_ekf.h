@@ -56,6 +56,8 @@ struct EkfParams {
   double *dx;       // [N]
   int32_t *flags;   // [0] = 1 if S not SPD, [1] = 1 if a diagonal of P' is negative
   double sigma2;
+  const double *diag0 = nullptr; // optional [D]: the matrix's own diagonal before the factorisation; a pivot below 1e-12 of it
+                                 // counts as not SPD (numerically singular prior block of the Gram-form update)
 };
 
 // Mt = R * P(cols, :)     grid: tiles(D/16) x tiles(N/16) wavefronts, 4 per block
@@ -147,7 +149,7 @@ __global__ void __launch_bounds__(256) k_ekf_chol_step(EkfParams p, int kb) {
 #pragma unroll
   for (int k = 0; k < 16; k++) {
     const double dk = ekf_bcast(u[k], k);
-    if (!(dk > 0.0) && it < 0 && jt == tb && lane == 0) p.flags[0] = 1;
+    if ((!(dk > 0.0) || (p.diag0 && k < nb && dk <= 1e-12 * p.diag0[kb + k])) && it < 0 && jt == tb && lane == 0) p.flags[0] = 1;
     const double d = sqrt(dk), inv = 1.0 / d;
     dinv[k] = inv;
     u[k] = ((lane & 15) == k) ? d : u[k] * inv; // row k of U (lanes j > k); lanes j < k hold zeros there
@@ -409,8 +411,14 @@ struct TformParams {
   double *A;         // [D x LA] work matrix of the factorisation in flight
   const double *Y1;  // [D x LA] = [U1 | B | 0] once the first factorisation is done
   double *W;         // [D x D]
+  double *diag0;     // [D] diagonal of P_DD (k_tf_gather)
   double inv_sigma2;
+  const int32_t *go; // 0: the prior block was not positive definite — everything after its factorisation is skipped (nothing
+                     // is written to P, dx = 0), and the host repeats the update through the Householder route
 };
+
+// go = the first factorisation succeeded (flags[0] is its not-SPD flag)
+__global__ void k_tf_go(const int32_t *flags, int32_t *go) { go[0] = flags[0] == 0 ? 1 : 0; }
 
 // A = [P_DD | P(D, :) | 0]      one thread per element
 __global__ void k_tf_gather(TformParams p) {
@@ -419,6 +427,7 @@ __global__ void k_tf_gather(TformParams p) {
   const int r = (int)(e / p.LA), c = (int)(e - (int64_t)r * p.LA);
   const double *Pr = p.P + (size_t)p.col_cov[r] * p.N;
   p.A[e] = c < p.D ? Pr[p.col_cov[c]] : (c < p.D + p.N ? Pr[c - p.D] : 0.0);
+  if (c == r) p.diag0[r] = Pr[p.col_cov[r]];
 }
 
 // W = G U1^T       one wavefront per 16x16 tile
@@ -426,7 +435,7 @@ __global__ void __launch_bounds__(256) k_tf_w(TformParams p) {
   const int lane = threadIdx.x & 63;
   const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int tm = (p.D + 15) / 16;
-  if (tile >= tm * tm) return;
+  if (tile >= tm * tm || *p.go == 0) return;
   const int r0 = (tile / tm) * 16, c0 = (tile % tm) * 16;
   auto fa = [&](int i, int k) { const int r = r0 + i; return r < p.D ? p.G[(size_t)r * p.LG + k] : 0.0; };
   auto fb = [&](int k, int j) { const int c = c0 + j; return (c < p.D && k >= c) ? p.Y1[(size_t)c * p.LA + k] : 0.0; };
@@ -444,7 +453,7 @@ __global__ void __launch_bounds__(256) k_tf_t(TformParams p) {
   const int lane = threadIdx.x & 63;
   const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int tm = (p.D + 15) / 16;
-  if (tile >= tm * tm) return;
+  if (tile >= tm * tm || *p.go == 0) return;
   const int r0 = (tile / tm) * 16, c0 = (tile % tm) * 16;
   auto fa = [&](int i, int k) { const int r = r0 + i; return (r < p.D && k >= r) ? p.Y1[(size_t)r * p.LA + k] : 0.0; };
   auto fb = [&](int k, int j) { const int c = c0 + j; return c < p.D ? p.W[(size_t)k * p.D + c] : 0.0; };
@@ -461,7 +470,7 @@ __global__ void __launch_bounds__(256) k_tf_t(TformParams p) {
 __global__ void __launch_bounds__(256) k_tf_bh(TformParams p) {
   const int lane = threadIdx.x & 63;
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (r >= p.D) return;
+  if (r >= p.D || *p.go == 0) return;
   const double *y = p.Y1 + (size_t)r * p.LA;
   double *a = p.A + (size_t)r * p.LA;
   for (int c = lane; c < p.N; c += 64) a[p.D + c] = y[p.D + c];
@@ -477,7 +486,7 @@ __global__ void __launch_bounds__(256) k_tf_pupdate(EkfParams p, const double *Y
   const int lane = threadIdx.x & 63;
   const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int tn = (p.N + 15) / 16;
-  if (tile >= tn * tn) return;
+  if (tile >= tn * tn || (p.pred && *p.pred == 0)) return;
   const int r0 = (tile / tn) * 16, c0 = (tile % tn) * 16;
   const double *B = Y1 + p.D, *Y = p.Y + p.D;
   auto fa1 = [&](int i, int k) { const int r = r0 + i; return (r < p.N) ? B[(size_t)k * p.LA + r] : 0.0; };

@@ -1,22 +1,24 @@
-// k_gram.h — measurement compression on the matrix cores: R = chol([H | r]^T [H | r]).
+// k_gram.h — the Gram matrix of the stacked measurement system on the matrix cores: G = [H | r]^T [H | r].
 //
-// UpdaterHelper::measurement_compress_inplace (UpdaterHelper.cpp:376-433) replaces the stacked system [H | r] by the
-// triangular factor of its QR decomposition.  The factor is determined by the Gram matrix alone, R^T R = [H | r]^T [H | r],
-// and the Gram matrix is a rank-k update — the one shape of this path that runs on v_mfma_f64_16x16x4_f64 at full rate:
+// UpdaterHelper::measurement_compress_inplace (UpdaterHelper.cpp:456-487) replaces the stacked system [H | r] by the
+// triangular factor of its QR decomposition before StateHelper::EKFUpdate; all the update needs from the stack is
+// H^T H and H^T r, and that is a rank-k update — the one shape of this path that runs on v_mfma_f64_16x16x4_f64 at full rate:
 //
 //   k_gram         one workgroup per CU streams its share of the rows through LDS once (coalesced, double buffered) and
 //                  keeps the upper triangle of the 16x16-tile grid of G in accumulator registers, 34 tiles per wavefront;
-//   k_gram_reduce  sums the per-workgroup partials in a fixed order (no atomics: the result is reproducible bit for bit);
-//   k_gram_chol    right-looking Cholesky of the (LD x LD) sum inside ONE workgroup, the matrix held in registers
-//                  (block-cyclic over 32 x 32 threads), one barrier per row; non-positive pivots — the stack of an MSCKF
-//                  update is rank deficient along the unobservable directions — leave a zero row, which drops
-//                  information of the size of the rounding error of G.
+//   k_gram_reduce  sums the per-workgroup partials in a fixed order (no atomics: the result is reproducible bit for bit).
 //
-// What this costs against the Householder TSQR (k_tsqr*.h): forming G squares the condition number, so directions the
-// measurements do not constrain carry spurious information of order eps * |G| instead of eps^2 * |G|.  The EKF update is a
-// well-conditioned function of G as long as the prior P is proper: measured on the cfg-2 stack (77178 x 209, singular)
-// |dP| / |P| = 2e-11 and |ddx| / |dx| = 3e-10 against the Householder route, 3e-9 with a prior 10^4 times weaker
-// (tools/dev_gram_accuracy.py).  The TSQR stays the route whenever R itself leaves the device (mode A).
+// The default route feeds G straight into the EKF update written in coordinates whitened by the prior (k_ekf.h,
+// "EKF update from the Gram matrix"): no factor of G is ever formed.  Across GPUs Gram matrices simply add (one all-reduce).
+//
+//   k_gram_chol    (OVGPU_COMPRESS=cholqr only) right-looking Cholesky of the (LD x LD) sum inside ONE workgroup, the
+//                  matrix held in registers (block-cyclic over 32 x 32 threads), one barrier per row; non-positive pivots —
+//                  the stack of an MSCKF update is rank deficient along the unobservable directions — leave a zero row.
+//                  This is the measured NEGATIVE result of DESIGN.md section 4: forming and factoring G squares the
+//                  condition number, the factor carries errors of order eps |G| in the directions the measurements do not
+//                  constrain, and a filter's covariance is large exactly there.  Snapshot parity holds on tall stacks
+//                  (|dP| / |P| = 2e-11 on the 77178 x 209 cfg-2 stack, tools/dev_gram_accuracy.py), the 52-frame closed loop
+//                  drifts 6e-6 (tools/dev_closed_loop_dev.py; Householder TSQR and the prior-whitened update: 1e-13).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

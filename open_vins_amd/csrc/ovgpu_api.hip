@@ -174,6 +174,8 @@ struct ovgpu_ctx {
   //   2 cholqr  R = chol(Gram) + dx refinement for tall stacks (kept as the measured negative result of DESIGN.md section 4)
   int compress_gram = 1;
   DevBuf<double> gram_part, gram_G, gram_rho, Yaug2;
+  bool last_update_tform = false; // the last EKF stage enqueued was the Gram-form one (finish_update may fall back)
+  bool force_tsqr = false;        // one-shot: the next pipeline takes the Householder route
   bool prior_pending = false; // the sharded update's local stage has started the prior block's factorisation on stream2
   bool prior_overlap = true; // OVGPU_PRIOR_OVERLAP=0: factor the prior block after the compression instead of next to it
   bool gram_valid = false; // c->Rws holds chol(gram_G): the EKF stage refines dx against gram_G
@@ -981,6 +983,7 @@ struct EkfJob {
 
 static int enqueue_ekf(ovgpu_ctx *c, const EkfJob &job = EkfJob()) {
   c->prior_pending = false;
+  c->last_update_tform = false;
   EkfParams p;
   const bool tri = job.R == nullptr;
   p.N = c->N, p.D = tri ? c->D : job.rows, p.DC = c->D, p.LD = c->LD, p.LA = p.D + c->N + 1, p.tri = tri ? 1 : 0, p.pred = job.pred;
@@ -1037,13 +1040,14 @@ static int enqueue_ekf_gram(ovgpu_ctx *c, int part = 3) {
   const int D = c->D, N = c->N, LA = D + N + 1;
   if (part == 3) c->prior_pending = false;
   HIPCHK(c->Yaug2.reserve((size_t)D * LA));
+  HIPCHK(c->gram_rho.reserve(std::max(N, D)));
   EkfParams p;
   p.N = N, p.D = D, p.DC = D, p.LD = c->LD, p.LA = LA, p.tri = 1, p.pred = nullptr;
   p.R = nullptr, p.col_cov = c->col_cov.p, p.P = c->P.p, p.Mt = c->Mt.p, p.A = c->Aaug.p, p.Y = c->Yaug.p;
   p.dx = c->dx.p, p.flags = c->flags.p, p.sigma2 = c->dopt.sigma_pix_sq;
   TformParams t;
   t.N = N, t.D = D, t.LA = LA, t.LG = 16 * ((c->LD + 15) / 16), t.col_cov = c->col_cov.p, t.G = c->gram_G.p, t.P = c->P.p;
-  t.A = c->Aaug.p, t.Y1 = c->Yaug.p, t.W = c->Mt.p, t.inv_sigma2 = 1.0 / c->dopt.sigma_pix_sq;
+  t.A = c->Aaug.p, t.Y1 = c->Yaug.p, t.W = c->Mt.p, t.inv_sigma2 = 1.0 / c->dopt.sigma_pix_sq, t.go = c->flags.p + 3, t.diag0 = c->gram_rho.p;
   hipStream_t s = c->stream;
   const int tm = (D + 15) / 16, tn = (N + 15) / 16;
   int rc = OVGPU_OK;
@@ -1057,11 +1061,15 @@ static int enqueue_ekf_gram(ovgpu_ctx *c, int part = 3) {
     }
     const int64_t elems = (int64_t)D * LA;
     hipLaunchKernelGGL(k_tf_gather, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, sp, t);
+    p.diag0 = c->gram_rho.p;
     if ((rc = enqueue_chol_carry(c, p, sp)) != OVGPU_OK) return rc; // Y1 = [U1 | B | 0] in c->Yaug
+    p.diag0 = nullptr;
     if (part == 1) HIPCHK(hipEventRecord(c->ev_join, sp));
   }
   if (part & 2) {
     if (part == 2) HIPCHK(hipStreamWaitEvent(s, c->ev_join, 0));
+    hipLaunchKernelGGL(k_tf_go, dim3(1), dim3(1), 0, s, (const int32_t *)c->flags.p, c->flags.p + 3);
+    p.pred = c->flags.p + 3; // a prior block that is not positive definite: skip, the host falls back (finish_update)
     hipLaunchKernelGGL(k_tf_w, dim3((tm * tm + 3) / 4), dim3(256), 0, s, t);
     hipLaunchKernelGGL(k_tf_t, dim3((tm * tm + 3) / 4), dim3(256), 0, s, t);
     hipLaunchKernelGGL(k_tf_bh, dim3((D + 3) / 4), dim3(256), 0, s, t);
@@ -1071,8 +1079,9 @@ static int enqueue_ekf_gram(ovgpu_ctx *c, int part = 3) {
     hipLaunchKernelGGL(k_tf_pupdate, dim3((tn * tn + 3) / 4), dim3(256), 0, s, p, (const double *)c->Yaug.p);
     const int n = std::max(c->C, c->K);
     hipLaunchKernelGGL(k_boxplus, dim3((n + 255) / 256), dim3(256), 0, s, c->C, c->K, p.dx, c->clone_cov.p, c->calib_cov.p, c->intr_cov.p,
-                       c->clone_qp.p, c->calib_qp.p, c->intr.p, (const int32_t *)nullptr);
+                       c->clone_qp.p, c->calib_qp.p, c->intr.p, (const int32_t *)(c->flags.p + 3));
     HIPCHK(hipGetLastError());
+    c->last_update_tform = true;
     return launch_build_tables(c);
   }
   return OVGPU_OK;
@@ -1113,7 +1122,8 @@ static int enqueue_pipeline(ovgpu_ctx *c, int stages, bool slam = false, bool fa
   if (eu) HIPCHK(hipEventRecord(eu->a, c->stream));
   int rc = OVGPU_OK;
   const bool fits = (c->LD + 15) / 16 <= gram::GR_NT && c->F > 0;
-  tform = !gram_only && c->compress_gram == 1 && fits && (stages & STAGE_EKF) != 0 && (stages & STAGE_LOCAL) != 0;
+  tform = !gram_only && c->compress_gram == 1 && !c->force_tsqr && fits && (stages & STAGE_EKF) != 0 && (stages & STAGE_LOCAL) != 0;
+  c->force_tsqr = false;
   // the prior block's factorisation needs nothing from the measurements: it runs next to the per-feature kernels
   const bool side = tform && c->stream2 != nullptr && c->ev_fork != nullptr && c->ev_join != nullptr && c->prior_overlap;
   if (side && (rc = enqueue_ekf_gram(c, 1)) != OVGPU_OK) return rc;
@@ -1275,7 +1285,18 @@ int ovgpu_msckf_update(ovgpu_ctx *c, int32_t *feat_status, double *chi2, double 
   if (rc != OVGPU_OK) return rc;
   rc = read_feature_outputs(c, feat_status, chi2, chi2_thresh, p_FinG, stats);
   if (rc != OVGPU_OK) return rc;
-  return finish_update(c, dx, P_out, stats);
+  rc = finish_update(c, dx, P_out, stats);
+  if (rc == OVGPU_ERR_NOT_SPD && c->last_update_tform) {
+    // the Gram-form update factors the PRIOR block, which a semi-definite prior (e.g. two perfectly correlated variables) fails;
+    // nothing was modified (every kernel behind that factorisation was skipped): repeat through the Householder route, whose
+    // S = R P R^T + sigma^2 I is positive definite for any valid covariance
+    c->force_tsqr = true;
+    if (stats) std::memset(stats, 0, sizeof(*stats));
+    if ((rc = enqueue_pipeline(c, STAGE_LOCAL | STAGE_EKF)) != OVGPU_OK) return rc;
+    if ((rc = read_feature_outputs(c, feat_status, chi2, chi2_thresh, p_FinG, stats)) != OVGPU_OK) return rc;
+    rc = finish_update(c, dx, P_out, stats);
+  }
+  return rc;
 }
 
 int ovgpu_msckf_update_async(ovgpu_ctx *c) {
@@ -1440,7 +1461,19 @@ int ovgpu_slam_update(ovgpu_ctx *c, const int32_t *lm_index, int32_t *feat_statu
   rc = read_feature_outputs(c, feat_status, chi2, chi2_thresh, nullptr, stats);
   if (rc != OVGPU_OK) return rc;
   if (lm_out) HIPCHK(hipMemcpyAsync(lm_out, c->lm_val.p, sizeof(double) * 3 * c->L, hipMemcpyDeviceToHost, s));
-  return finish_update(c, dx, P_out, stats);
+  rc = finish_update(c, dx, P_out, stats);
+  if (rc == OVGPU_ERR_NOT_SPD && c->last_update_tform) { // semi-definite prior block: see ovgpu_msckf_update
+    c->force_tsqr = true;
+    if (stats) std::memset(stats, 0, sizeof(*stats));
+    if ((rc = enqueue_pipeline(c, STAGE_LOCAL | STAGE_EKF, true)) != OVGPU_OK) return rc;
+    hipLaunchKernelGGL(k_landmark_update, dim3((3 * c->L + 255) / 256), dim3(256), 0, s, c->L, (const int32_t *)nullptr, lm_dof(c->lm_rep), c->dx.p,
+                       c->lm_cov.p, c->lm_val.p, (const int32_t *)nullptr);
+    HIPCHK(hipGetLastError());
+    if ((rc = read_feature_outputs(c, feat_status, chi2, chi2_thresh, nullptr, stats)) != OVGPU_OK) return rc;
+    if (lm_out) HIPCHK(hipMemcpyAsync(lm_out, c->lm_val.p, sizeof(double) * 3 * c->L, hipMemcpyDeviceToHost, s));
+    rc = finish_update(c, dx, P_out, stats);
+  }
+  return rc;
 }
 
 int ovgpu_slam_compress(ovgpu_ctx *c, const int32_t *lm_index, int32_t *feat_status, double *chi2, double *chi2_thresh, int32_t *D_out,

@@ -486,6 +486,32 @@ def test_gram_route_gives_the_householder_posterior(Updater, oracle, kw):
     assert _rel(c["dx"], ref["dx"]) < 1e-7 and _rel(c["P"], ref["P"]) < 1e-8
 
 
+def test_semi_definite_prior_takes_the_householder_route(Updater, oracle):
+    """The Gram-form update factors the PRIOR block of the involved variables.  A valid covariance may be singular there (here:
+    the newest clone an exact copy of the one before, as right after StateHelper::clone of a pose that already is a clone): the
+    device notices (pivot below 1e-12 of the diagonal), skips everything behind that factorisation — nothing modified — and the
+    call repeats through the Householder route, whose S = R P R^T + sigma^2 I is positive definite for any covariance."""
+    prob = synth.make_problem(2, F=120)
+    A = np.eye(prob.N)
+    i, j = int(prob.clone_cov_id[28]), int(prob.clone_cov_id[29])      # the two newest of the 30 clones
+    A[j:j + 6, :] = 0.0
+    A[j:j + 6, i:i + 6] = np.eye(6)
+    prob.P = A @ prob.P @ A.T            # positive semi-definite, rank N - 6
+    opts = capi.default_options(chi2_multipler=1.0)
+    v = capi.Views(prob)
+    tri = oracle.triangulate(opts, v)
+    ref = oracle.msckf_update(opts, v, given=tri)
+    assert ref["stats"]["status"] == 0 and ref["stats"]["n_used"] > 30
+    up = Updater(opts)
+    up.set_problem(prob)
+    up.set_triangulation(tri["p_FinG"], tri["p_FinA"], tri["anchor_meas"], tri["status"])
+    out = up.update()
+    assert out["stats"]["status"] == 0 and np.array_equal(out["feat_status"], ref["feat_status"])
+    assert _rel(out["dx"], ref["dx"]) < 1e-7 and _rel(out["P"], ref["P"]) < 1e-8
+    assert np.abs(out["clone_q_p"] - ref["clone_q_p"]).max() < 1e-9
+    up.close()
+
+
 @pytest.mark.parametrize("kw", [dict(F=300), dict(cfg=4, F=120), dict(F=200, K=1, C=12)])
 def test_compression_is_independent_of_the_tree_shape(Updater, oracle, kw):
     """QR([R_1; R_2; ...]) = QR of the full stack: any number of leaves, and the pipelined single-launch merge
