@@ -105,7 +105,7 @@ def main():
         ms_c, ms_s = kt["ms_compress"], kt["ms_system"]
         achieved_c = flops_compress / (ms_c * 1e-3) / 1e12 if ms_c > 0 else 0.0
         achieved = flops_system / (ms_s * 1e-3) / 1e12 if ms_s > 0 else 0.0
-        traffic = pmc_traffic_bytes()
+        traffic = pmc_traffic_bytes() if (args.cfg == 2 and args.features is None) else None  # the committed passes are of the default workload
         gram = os.environ.get("OVGPU_COMPRESS", "gram") not in ("tsqr", "cholqr") and world == 1
         # the Gram route executes r D^2 multiply-adds for what SURVEY.md 8(d) counts as 2 r D^2 (Householder-equivalent):
         # its roofline fraction is quoted on the EXECUTED flops, the algorithmic rate beside it
