@@ -567,10 +567,15 @@ int ovgpu_cam_distort(ovgpu_ctx *ctx, int is_fisheye, const double *cam8, int n,
 int ovgpu_reset_state(ovgpu_ctx *ctx);
 
 /* Enqueues one complete update (as ovgpu_msckf_update) on the context's
- * stream without any host read-back or synchronisation.                      */
+ * stream without any host read-back or synchronisation.  Its status
+ * (OVGPU_ERR_NOT_SPD, OVGPU_ERR_NEGATIVE_DIAGONAL) is returned by the next
+ * ovgpu_synchronize.  Unlike ovgpu_msckf_update it cannot repeat the update through
+ * the Householder route when the prior block of the involved variables is
+ * numerically singular: the state is then left untouched and NOT_SPD reported.  */
 int ovgpu_msckf_update_async(ovgpu_ctx *ctx);
 
-/* Blocks until the context's stream is idle. */
+/* Blocks until the context's stream is idle; returns the status of a preceding
+ * ovgpu_msckf_update_async. */
 int ovgpu_synchronize(ovgpu_ctx *ctx);
 
 /* hipStream_t of the context, as an integer (for hipEvent timing). */

@@ -31,7 +31,6 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 constexpr int GR_ROWS = 32;  // rows of the stack per LDS stage
 constexpr int GR_LS = 272;   // LDS row stride in doubles (17 * 16 >= 256 columns; consecutive rows start half an LDS line apart)
 constexpr int GR_NT = 16;    // tile-grid capacity: LD <= 256
-constexpr int GR_MAXLOAD = GR_ROWS; // doubles per thread and stage at LD = 256
 
 struct GramParams {
   int LD, NT;             // row length of the stack (D + 1) and its 16-column tiles

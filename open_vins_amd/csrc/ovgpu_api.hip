@@ -174,6 +174,7 @@ struct ovgpu_ctx {
   //   2 cholqr  R = chol(Gram) + dx refinement for tall stacks (kept as the measured negative result of DESIGN.md section 4)
   int compress_gram = 1;
   DevBuf<double> gram_part, gram_G, gram_rho, Yaug2;
+  bool async_pending = false;     // ovgpu_msckf_update_async since the last ovgpu_synchronize
   bool last_update_tform = false; // the last EKF stage enqueued was the Gram-form one (finish_update may fall back)
   bool force_tsqr = false;        // one-shot: the next pipeline takes the Householder route
   bool prior_pending = false; // the sharded update's local stage has started the prior block's factorisation on stream2
@@ -1301,6 +1302,7 @@ int ovgpu_msckf_update(ovgpu_ctx *c, int32_t *feat_status, double *chi2, double 
 
 int ovgpu_msckf_update_async(ovgpu_ctx *c) {
   if (!c) return set_err(OVGPU_ERR_INVALID, "null ctx");
+  c->async_pending = true;
   return enqueue_pipeline(c, STAGE_LOCAL | STAGE_EKF);
 }
 
@@ -2381,6 +2383,13 @@ int ovgpu_synchronize(ovgpu_ctx *c) {
   if (!c) return set_err(OVGPU_ERR_INVALID, "null ctx");
   HIPCHK(hipSetDevice(c->device));
   HIPCHK(hipStreamSynchronize(c->stream));
+  if (c->async_pending) { // the status of the last ovgpu_msckf_update_async (a synchronous call reports its own)
+    c->async_pending = false;
+    int32_t flags[4] = {0, 0, 0, 0};
+    HIPCHK(hipMemcpy(flags, c->flags.p, sizeof(flags), hipMemcpyDeviceToHost));
+    if (flags[0]) return set_err(OVGPU_ERR_NOT_SPD, c->last_update_tform ? "prior block of the involved variables not positive definite (state untouched; ovgpu_msckf_update falls back to the Householder route)" : "innovation covariance not SPD");
+    if (flags[1]) return set_err(OVGPU_ERR_NEGATIVE_DIAGONAL, "negative covariance diagonal after the update");
+  }
   return check_tree_error(c);
 }
 
