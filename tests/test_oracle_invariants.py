@@ -367,6 +367,42 @@ def test_slam_update_with_per_feature_noise_equals_weighted_information_form():
     assert np.linalg.norm(o["dx"] - Pinf @ H.T @ (w * o["r"])) / np.linalg.norm(o["dx"]) < 1e-6
 
 
+def test_prior_whitened_information_form_equals_the_kalman_form():
+    """The algebra the device's default route relies on (csrc/k_ekf.h, "EKF update from the Gram matrix"): with G = H^T H,
+    g = H^T r, P_DD = U1^T U1, B = U1^-T P(D,:), T = I + U1 G U1^T / s^2 = C^T C, Y2 = C^-T B:
+    P' = P - (B^T B - Y2^T Y2) and dx = Y2^T C^-T (U1 g / s^2) reproduce StateHelper::EKFUpdate — also when H is rank deficient
+    (the MSCKF stack always is) and when nothing is measured (G = 0 gives P' = P, dx = 0)."""
+    from scipy.linalg import cholesky, solve_triangular
+    from open_vins_amd import capi, synth
+    from oracle import pyoracle
+    prob = synth.make_problem(2, F=48, C=10)
+    opts = capi.default_options(chi2_multipler=1.0)
+    v = capi.Views(prob)
+    o = pyoracle.msckf_update(opts, v, want_compressed=True)
+    assert o["stats"]["n_used"] > 20
+    cols = pyoracle.column_map(opts, v)
+    H, r = o["H_comp"], o["r_comp"]          # R^T R = H^T H of the full stack, R^T z = H^T r
+    assert np.linalg.matrix_rank(H) < H.shape[1]  # gauge directions: the stack is rank deficient
+    s2 = opts.sigma_pix ** 2
+
+    def whitened(G, g):
+        P = prob.P
+        U1 = cholesky(P[np.ix_(cols, cols)])                    # upper, U1^T U1 = P_DD
+        B = solve_triangular(U1, P[cols, :], trans="T")
+        T = np.eye(len(cols)) + U1 @ G @ U1.T / s2
+        C = cholesky(T)
+        Y2 = solve_triangular(C, B, trans="T")
+        y2 = solve_triangular(C, U1 @ g / s2, trans="T")
+        return P - (B.T @ B - Y2.T @ Y2), Y2.T @ y2, np.linalg.eigvalsh(T)
+
+    P1, dx1, ev = whitened(H.T @ H, H.T @ r)
+    assert ev.min() > 1.0 - 1e-9                                # eigenvalues of T are >= 1: no small pivots
+    assert np.linalg.norm(P1 - o["P"]) / np.linalg.norm(o["P"]) < 1e-11
+    assert np.linalg.norm(dx1 - o["dx"]) / np.linalg.norm(o["dx"]) < 1e-9
+    P0, dx0, _ = whitened(np.zeros((len(cols), len(cols))), np.zeros(len(cols)))
+    assert np.abs(P0 - prob.P).max() < 1e-15 and not dx0.any()
+
+
 def test_slam_gate_rejects_a_displaced_landmark():
     from open_vins_amd import capi, synth
     from oracle import pyoracle
