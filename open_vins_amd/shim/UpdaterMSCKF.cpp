@@ -18,6 +18,9 @@
 
 #include "ovgpu.h"
 #include "ovgpu_flatten.h"
+#ifdef OVGPU_SHIM_MODE_B
+#include "ovgpu_state_access.h" // needs `friend struct ovgpu_shim::StateAccess;` in State.h
+#endif
 
 using namespace ov_core;
 using namespace ov_type;
@@ -116,8 +119,16 @@ void UpdaterMSCKF::update(std::shared_ptr<State> state, std::vector<std::shared_
   int32_t D = 0, rows = 0;
   ovgpu_update_stats stats;
   g_ctx->check(ovgpu_triangulate(g_ctx->get(), pA.data(), nullptr, anchor.data(), nullptr), "ovgpu_triangulate"); // Feature::p_FinA / anchor
+#ifdef OVGPU_SHIM_MODE_B
+  // mode B: the device applies the update itself (Gram matrix of the stack on the matrix cores + the update whitened by the
+  // prior: half the time of compress -> EKFUpdate, same dx and P'); dx and P' come back and are written through StateAccess
+  std::vector<double> dx_dev((size_t)sv.N), P_dev((size_t)sv.N * sv.N);
+  g_ctx->check(ovgpu_msckf_update(g_ctx->get(), status.data(), nullptr, nullptr, pG.data(), dx_dev.data(), P_dev.data(), &stats), "ovgpu_msckf_update");
+  rows = stats.n_rows;
+#else
   g_ctx->check(ovgpu_msckf_compress(g_ctx->get(), status.data(), nullptr, nullptr, pG.data(), &D, &rows, col_cov.data(), H.data(), r.data(), &stats),
                "ovgpu_msckf_compress");
+#endif
 
   // ---- side effects on the features: triangulation results, erase the rejected, flag the used
   size_t f = 0;
@@ -138,6 +149,10 @@ void UpdaterMSCKF::update(std::shared_ptr<State> state, std::vector<std::shared_
   }
   if (rows < 1) return; // :266-268 / :276-278
 
+#ifdef OVGPU_SHIM_MODE_B
+  ovgpu_shim::StateAccess::apply_update(*state, P_dev.data(), dx_dev.data(), sv.N); // StateHelper.cpp:166-195
+  return;
+#endif
   // ---- 6. the stock EKF update on the compressed system (UpdaterMSCKF.cpp:280-285)
   std::vector<std::shared_ptr<Type>> Hx_order_big;
   for (int c = 0; c < D;) {

@@ -20,17 +20,12 @@
 
 #include "ovgpu.h"
 #include "ovgpu_flatten.h"
+#include "ovgpu_state_access.h"
 
 using namespace ov_core;
 using namespace ov_type;
 using namespace ov_msckf;
 
-namespace ovgpu_shim {
-struct StateAccess {
-  static Eigen::MatrixXd &cov(State &s) { return s._Cov; }
-  static std::vector<std::shared_ptr<Type>> &variables(State &s) { return s._variables; }
-};
-} // namespace ovgpu_shim
 
 namespace {
 std::unique_ptr<ovgpu_shim::Context> g_init_ctx;

@@ -14,6 +14,9 @@
 
 #include "ovgpu.h"
 #include "ovgpu_flatten.h"
+#ifdef OVGPU_SHIM_MODE_B
+#include "ovgpu_state_access.h" // needs `friend struct ovgpu_shim::StateAccess;` in State.h
+#endif
 
 using namespace ov_core;
 using namespace ov_type;
@@ -132,9 +135,18 @@ void UpdaterSLAM::update(std::shared_ptr<State> state, std::vector<std::shared_p
   std::vector<double> H((size_t)Dmax * Dmax), r(Dmax);
   int32_t D = 0, rows = 0;
   ovgpu_update_stats stats;
+#ifdef OVGPU_SHIM_MODE_B
+  // mode B: the update is applied on the device (ovgpu_slam_update); dx and P' are written back through StateAccess.  Landmark
+  // values follow from dx like every other variable (Landmark::update = Vec::update), so nothing else has to come back.
+  std::vector<double> dx_dev((size_t)sv.N), P_dev((size_t)sv.N * sv.N);
+  g_slam_ctx->check(ovgpu_slam_update(g_slam_ctx->get(), lm_index.data(), status.data(), nullptr, nullptr, dx_dev.data(), P_dev.data(), nullptr, &stats),
+                    "ovgpu_slam_update");
+  rows = stats.n_rows;
+#else
   g_slam_ctx->check(ovgpu_slam_compress(g_slam_ctx->get(), lm_index.data(), status.data(), nullptr, nullptr, &D, &rows, col_cov.data(), H.data(),
                                         r.data(), &stats),
                     "ovgpu_slam_compress");
+#endif
 
   // ---- side effects (UpdaterSLAM.cpp:410-420, :452-454): rejected tracks erased and flagged, fail count bumped; used tracks flagged
   size_t f = 0;
@@ -151,6 +163,10 @@ void UpdaterSLAM::update(std::shared_ptr<State> state, std::vector<std::shared_p
   }
   if (rows < 1) return; // :456-458
 
+#ifdef OVGPU_SHIM_MODE_B
+  ovgpu_shim::StateAccess::apply_update(*state, P_dev.data(), dx_dev.data(), sv.N); // StateHelper.cpp:166-196
+  return;
+#endif
   // ---- 5. the stock EKF update on the compressed system (:470)
   std::vector<std::shared_ptr<Type>> Hx_order_big;
   for (int c = 0; c < D;) {

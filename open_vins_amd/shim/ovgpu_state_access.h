@@ -1,0 +1,33 @@
+// ovgpu_state_access.h — the one piece of OpenVINS a mode-B integration has to open up.
+//
+// State::_Cov and State::_variables are private with `friend class StateHelper;` (ov_msckf/src/state/State.h:182-192).  The shims
+// that let the GPU apply the EKF update itself (mode B: dx and P' come back, no StateHelper::EKFUpdate on the host) write
+// them through this struct; the maintainer adds ONE line to State.h, next to the existing friend declaration:
+//
+//     friend struct ovgpu_shim::StateAccess;
+//
+// (and `namespace ovgpu_shim { struct StateAccess; }` before the class).  Without it the shims build in mode A
+// (compressed (H, r) -> the stock StateHelper::EKFUpdate), which needs no change to the reference at all.
+#pragma once
+#include <Eigen/Eigen>
+#include <memory>
+#include <vector>
+
+#include "state/State.h"
+
+namespace ovgpu_shim {
+struct StateAccess {
+  static Eigen::MatrixXd &cov(ov_msckf::State &s) { return s._Cov; }
+  static std::vector<std::shared_ptr<ov_type::Type>> &variables(ov_msckf::State &s) { return s._variables; }
+
+  // StateHelper::EKFUpdate's tail (StateHelper.cpp:166-196) with the numbers computed on the device: P' row-major N x N, dx N.
+  // The negative-diagonal check of :171-182 has already happened on the device (OVGPU_ERR_NEGATIVE_DIAGONAL).
+  static void apply_update(ov_msckf::State &s, const double *P_rowmajor, const double *dx, int N) {
+    s._Cov = Eigen::Map<const Eigen::Matrix<double, Eigen::Dynamic, Eigen::Dynamic, Eigen::RowMajor>>(P_rowmajor, N, N);
+    const Eigen::Map<const Eigen::VectorXd> d(dx, N);
+    for (auto &var : s._variables) var->update(d.segment(var->id(), var->size())); // :185-187
+    if (s._options.do_calib_camera_intrinsics) // the camera objects carry the intrinsics as well (:191-196)
+      for (auto const &calib : s._cam_intrinsics) s._cam_intrinsics_cameras.at(calib.first)->set_value(calib.second->value());
+  }
+};
+} // namespace ovgpu_shim

@@ -40,6 +40,19 @@ def test_slam_shims_keep_the_reference_signatures():
     assert "oracle" not in upd and "oracle" not in ini
 
 
+def test_mode_b_switch_of_the_update_shims():
+    """-DOVGPU_SHIM_MODE_B: the device applies the update (ovgpu_msckf_update / ovgpu_slam_update) and the shim writes dx, P'
+    back through StateAccess (the tail of StateHelper::EKFUpdate, StateHelper.cpp:166-196); without it the stock
+    StateHelper::EKFUpdate runs on the compressed system."""
+    d = os.path.join(ROOT, "open_vins_amd", "shim")
+    acc = open(os.path.join(d, "ovgpu_state_access.h")).read()
+    assert "s._Cov" in acc and "var->update(" in acc and "_cam_intrinsics_cameras" in acc and "do_calib_camera_intrinsics" in acc
+    for name, call in (("UpdaterMSCKF.cpp", "ovgpu_msckf_update("), ("UpdaterSLAM_update.cpp", "ovgpu_slam_update(")):
+        src = open(os.path.join(d, name)).read()
+        assert src.count("#ifdef OVGPU_SHIM_MODE_B") == 3 and call in src and "StateAccess::apply_update(*state" in src
+        assert "StateHelper::EKFUpdate(state, Hx_order_big, Hx_big, res_big, R_big)" in src  # mode A stays the default
+
+
 @pytest.mark.gpu
 def test_shim_drives_an_update_from_cpp():
     """The C++ side of the boundary (ovgpu_flatten.h + the C ABI, no Python in between) on the GPU."""
