@@ -875,7 +875,8 @@ static int enqueue_merge_tree(ovgpu_ctx *c, int G, bool leaves_live = false, hip
   return OVGPU_OK;
 }
 
-// R = chol([H | r]^T [H | r]) on the matrix cores (k_gram.h): partial Gram matrices per workgroup, ordered sum, Cholesky
+// G = [H | r]^T [H | r] on the matrix cores (k_gram.h): partial Gram matrices per workgroup, ordered sum; factor = true (the
+// cholqr route only) adds R = chol(G)
 static int enqueue_gram_factor(ovgpu_ctx *c);
 static int enqueue_compress_gram(ovgpu_ctx *c, bool factor = true) {
   const int D = c->D, LD = c->LD, NT = (LD + 15) / 16, NP = NT * (NT + 1) / 2, LG = 16 * NT;
@@ -919,12 +920,13 @@ static int enqueue_gram_factor(ovgpu_ctx *c) {
   return OVGPU_OK;
 }
 
-static int enqueue_compress(ovgpu_ctx *c, bool factor_stays = false) {
+// cholqr: R = chol(Gram) instead of the Householder TSQR (OVGPU_COMPRESS=cholqr, tall stacks)
+static int enqueue_compress(ovgpu_ctx *c, bool cholqr = false) {
   const int D = c->D, LD = c->LD;
   const int NT = (LD + 15) / 16;
   const int W = c->W;
   c->gram_valid = false;
-  if (factor_stays && c->compress_gram && NT <= gram::GR_NT) {
+  if (cholqr && NT <= gram::GR_NT) {
     c->gram_valid = true;
     return enqueue_compress_gram(c);
   }
