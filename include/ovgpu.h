@@ -96,7 +96,33 @@ typedef struct {
   int32_t do_calib_camera_pose;       /* calib_cam_extrinsics               */
   int32_t do_calib_camera_intrinsics; /* calib_cam_intrinsics               */
   int32_t feat_rep_msckf;             /* ovgpu_feat_rep                     */
+  /* Library switches.  Everything that can change the arithmetic route of   */
+  /* an update is an option of the context, never the environment; 0 is the  */
+  /* default of every field (a zero-initialised tail behaves like            */
+  /* ovgpu_default_options).                                                  */
+  int32_t compress_route;    /* ovgpu_compress_route of the on-device update */
+  int32_t gram_no_whiten;    /* 1: Gram matrix of the raw stack, whitened    */
+                             /* afterwards (round-1 form; loses accuracy     */
+                             /* when the prior is large along the            */
+                             /* unobservable directions)*/
+  int32_t no_prior_overlap;  /* 1: factor the prior block on the main stream */
+  int32_t tsqr_workers;      /* leaf nodes of the Householder TSQR, 0 = one  */
+                             /* per compute unit                             */
+  int32_t tsqr_no_pipeline;  /* 1: merge tree level by level                 */
+  int32_t tsqr_overlap;      /* 0 auto, 1 merge tree next to the leaves,     */
+                             /* 2 never                                      */
+  int32_t tsqr_leaf_blocked; /* 1: experimental compact-WY leaf (k_tsqr_blk) */
+  int32_t no_timing;         /* 1: no HIP events around the stages           */
 } ovgpu_options;
+
+/* Measurement compression (UpdaterHelper.cpp:456-487) of ovgpu_msckf_update / ovgpu_slam_update:           */
+typedef enum {
+  OVGPU_COMPRESS_GRAM = 0,   /* Gram matrix of the prior-whitened stack on the matrix cores + the update in */
+                             /* whitened coordinates (default; D <= 255 columns)                            */
+  OVGPU_COMPRESS_TSQR = 1,   /* Householder TSQR + the reference-shaped update (always used when the factor */
+                             /* itself is returned: ovgpu_msckf_compress, ovgpu_measurement_compress)       */
+  OVGPU_COMPRESS_CHOLQR = 2  /* R = chol(Gram): kept as the measured negative result of DESIGN.md section 4  */
+} ovgpu_compress_route;
 
 /* Fills *o with the reference defaults. */
 void ovgpu_default_options(ovgpu_options *o);

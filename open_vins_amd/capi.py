@@ -20,6 +20,7 @@ ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_NEGATIVE_DIAGONAL, ERR_NOT_SPD, ERR_CAP
 FEAT_USED, FEAT_TOO_FEW_MEAS, FEAT_TRI_FAILED, FEAT_GN_FAILED, FEAT_CHI2_REJECTED = 0, 1, 2, 3, 4
 REP_GLOBAL_3D, REP_GLOBAL_FULL_INVERSE_DEPTH, REP_ANCHORED_3D = 0, 1, 2
 REP_ANCHORED_FULL_INVERSE_DEPTH, REP_ANCHORED_MSCKF_INVERSE_DEPTH, REP_ANCHORED_INVERSE_DEPTH_SINGLE = 3, 4, 5
+COMPRESS_GRAM, COMPRESS_TSQR, COMPRESS_CHOLQR = 0, 1, 2
 
 c_double_p = C.POINTER(C.c_double)
 c_float_p = C.POINTER(C.c_float)
@@ -37,6 +38,8 @@ class Options(C.Structure):
         ("max_cond_number", C.c_double),
         ("do_fej", C.c_int32), ("do_calib_camera_pose", C.c_int32), ("do_calib_camera_intrinsics", C.c_int32),
         ("feat_rep_msckf", C.c_int32),
+        ("compress_route", C.c_int32), ("gram_no_whiten", C.c_int32), ("no_prior_overlap", C.c_int32), ("tsqr_workers", C.c_int32),
+        ("tsqr_no_pipeline", C.c_int32), ("tsqr_overlap", C.c_int32), ("tsqr_leaf_blocked", C.c_int32), ("no_timing", C.c_int32),
     ]
 
 

@@ -413,6 +413,8 @@ struct TformParams {
   double *W;         // [D x D]
   double *diag0;     // [D] diagonal of P_DD (k_tf_gather)
   double inv_sigma2;
+  int whitened;      // 1: G is the Gram matrix of the WHITENED stack [H U1^T | r] (k_system with SysParams::Lw): T = I + G / sigma^2
+  double *Lw;        // [D x D] L = U1^T with explicit zeros above the diagonal (k_tf_lt), read by the per-feature kernel
   const int32_t *go; // 0: the prior block was not positive definite — everything after its factorisation is skipped (nothing
                      // is written to P, dx = 0), and the host repeats the update through the Householder route
 };
@@ -428,6 +430,22 @@ __global__ void k_tf_gather(TformParams p) {
   const double *Pr = p.P + (size_t)p.col_cov[r] * p.N;
   p.A[e] = c < p.D ? Pr[p.col_cov[c]] : (c < p.D + p.N ? Pr[c - p.D] : 0.0);
   if (c == r) p.diag0[r] = Pr[p.col_cov[r]];
+}
+
+// L = U1^T, row-major, zeros above the diagonal      one thread per element
+__global__ void k_tf_lt(TformParams p) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= p.D * p.D) return;
+  const int s = e / p.D, c = e - s * p.D;
+  p.Lw[e] = c <= s ? p.Y1[(size_t)c * p.LA + s] : 0.0;
+}
+
+// whitened Gram matrix: A[:, 0:D] = I + G / sigma^2      one thread per element
+__global__ void k_tf_a(TformParams p) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= p.D * p.D || *p.go == 0) return;
+  const int r = e / p.D, c = e - r * p.D;
+  p.A[(size_t)r * p.LA + c] = p.G[(size_t)r * p.LG + c] * p.inv_sigma2 + (r == c ? 1.0 : 0.0);
 }
 
 // W = G U1^T       one wavefront per 16x16 tile
@@ -474,6 +492,10 @@ __global__ void __launch_bounds__(256) k_tf_bh(TformParams p) {
   const double *y = p.Y1 + (size_t)r * p.LA;
   double *a = p.A + (size_t)r * p.LA;
   for (int c = lane; c < p.N; c += 64) a[p.D + c] = y[p.D + c];
+  if (p.whitened) { // the stack was whitened row by row: column D of its Gram matrix is U1 g already
+    if (lane == 0) a[p.D + p.N] = p.G[(size_t)r * p.LG + p.D] * p.inv_sigma2;
+    return;
+  }
   double s = 0.0;
   for (int k = r + lane; k < p.D; k += 64) s = fma(y[k], p.G[(size_t)k * p.LG + p.D], s);
 #pragma unroll

@@ -665,8 +665,16 @@ __global__ void __launch_bounds__(SYS_NT) k_system(SysParams p) {
     SYS_T(7)
     // (d) stack: thread-per-column, rows 3..n-1 of Q^T [H_x | res] -> Hbig   (UpdaterMSCKF.cpp:237-255)
     // ------------------------------------------------------------------
+    // Whitened output (p.Lw != nullptr, the Gram route): the rows leave as Q^T [H_x L | res] with P_DD = L L^T the Cholesky
+    // factor of the prior block of the involved variables (L = U1^T of k_ekf.h).  The update works on T = I + (H L)^T (H L) / s^2;
+    // forming H L row by row BEFORE the Gram accumulation keeps every rounding error relative to the prior: along the
+    // unobservable directions (H x = 0 only by cancellation across columns, and the prior is LARGE exactly there) the rows of
+    // H L vanish to eps |H| |L| and their Gram contribution to eps^2, where U1 (H^T H) U1^T would carry eps |H|^2 |U1|^2
+    // (measured: |dP| / |P| 5e-8 at a 10 m gauge sigma, against 3e-13 for this form and 6e-13 for the reference's own S = H P H^T + R).
+    const bool whiten = p.Lw != nullptr;
     {
       const double T00 = hq[3], T01 = hq[4], T02 = hq[5], T11 = hq[6], T12 = hq[7], T22 = hq[8];
+      double *wv = Tch; // [3][LD]  V^T [H_x | res] before the whitening (the T chunk is free after the gate)
       for (int c = tid; c < LD; c += SYS_NT) {
         int kind = COL_RESIDUAL, var = 0, sub = 0;
         if (c < D) kind = p.col_kind[c], var = p.col_var[c], sub = p.col_sub[c];
@@ -691,6 +699,7 @@ __global__ void __launch_bounds__(SYS_NT) k_system(SysParams p) {
           return h;
         };
         if (nproj == 0) { // UpdaterSLAM.cpp:381-383, :427-447: the rows go into the stack as they are, landmark columns included
+          if (whiten) continue; // written by the whitening pass below
           double *out = p.Hbig + orow0 * LD + c;
 #pragma unroll 4
           for (int r = 0; r < n; r++) out[(size_t)r * LD] = oscale * hval(r >> 1, r & 1);
@@ -704,6 +713,10 @@ __global__ void __launch_bounds__(SYS_NT) k_system(SysParams p) {
           const double *v = V + (size_t)6 * i;
           y0 = fma(v[0], h0, y0), y1 = fma(v[1], h0, y1), y2 = fma(v[2], h0, y2);
           y0 = fma(v[3], h1, y0), y1 = fma(v[4], h1, y1), y2 = fma(v[5], h1, y2);
+        }
+        if (whiten) { // V^T (H L) = (V^T H) L: the three rows are whitened below, as one dense product
+          wv[c] = y0, wv[LD + c] = y1, wv[2 * LD + c] = y2;
+          continue;
         }
         // z = T^T y
         const double z0 = T00 * y0, z1 = T01 * y0 + T11 * y1, z2 = T02 * y0 + T12 * y1 + T22 * y2;
@@ -720,6 +733,113 @@ __global__ void __launch_bounds__(SYS_NT) k_system(SysParams p) {
           const double h = hval(r >> 1, r & 1);
           const double *v = V + (size_t)3 * r;
           out[(size_t)(r - nproj) * LD] = oscale * (h - (v[0] * z0 + v[1] * z1 + v[2] * z2));
+        }
+      }
+      if (whiten) {
+        __syncthreads(); // wv complete
+        // thread c owns column c of [H_x L | res]: (H L)[r][c] = sum over the blocks of row r of H[r][s] L[s][c].  The access
+        // pattern of T = H P above with L in place of P: consecutive threads read consecutive addresses of a row of L; the 14
+        // calibration rows are shared by all measurements of a camera, the anchor / landmark rows by the whole feature.
+        for (int c = tid; c < LD; c += SYS_NT) {
+          const bool isres = c >= D;
+          const int cq = isres ? D - 1 : c; // clamped: the residual column is not whitened, its loads are masked below
+          const double *Lc = p.Lw + cq;
+          double z0 = 0.0, z1 = 0.0, z2 = 0.0;
+          if (nproj > 0) {
+            double y0 = 0.0, y1 = 0.0, y2 = 0.0;
+            if (isres) {
+              y0 = wv[D], y1 = wv[LD + D], y2 = wv[2 * LD + D];
+            } else {
+              // L is lower triangular: rows s < c of column c are zero
+              double a0 = 0.0, a1 = 0.0, a2 = 0.0, b0 = 0.0, b1 = 0.0, b2 = 0.0;
+              int s = c;
+              for (; s + 1 < D; s += 2) {
+                const double l0 = Lc[(size_t)s * D], l1 = Lc[(size_t)(s + 1) * D];
+                a0 = fma(wv[s], l0, a0), a1 = fma(wv[LD + s], l0, a1), a2 = fma(wv[2 * LD + s], l0, a2);
+                b0 = fma(wv[s + 1], l1, b0), b1 = fma(wv[LD + s + 1], l1, b1), b2 = fma(wv[2 * LD + s + 1], l1, b2);
+              }
+              if (s < D) {
+                const double l0 = Lc[(size_t)s * D];
+                a0 = fma(wv[s], l0, a0), a1 = fma(wv[LD + s], l0, a1), a2 = fma(wv[2 * LD + s], l0, a2);
+              }
+              y0 = a0 + b0, y1 = a1 + b1, y2 = a2 + b2;
+            }
+            z0 = T00 * y0, z1 = T01 * y0 + T11 * y1, z2 = T02 * y0 + T12 * y1 + T22 * y2; // z = T^T y
+          }
+          double lcp[6] = {0, 0, 0, 0, 0, 0}, lci[8] = {0, 0, 0, 0, 0, 0, 0, 0}, lac[6] = {0, 0, 0, 0, 0, 0}, lap[6] = {0, 0, 0, 0, 0, 0};
+          double llm[3] = {0, 0, 0};
+          if (anc_ccol >= 0) {
+#pragma unroll
+            for (int s = 0; s < 6; s++) lac[s] = Lc[(size_t)(anc_ccol + s) * D];
+          }
+          if (anc_pcol >= 0) {
+#pragma unroll
+            for (int s = 0; s < 6; s++) lap[s] = Lc[(size_t)(anc_pcol + s) * D];
+          }
+          if (lm_col >= 0) {
+#pragma unroll
+            for (int s = 0; s < 3; s++) llm[s] = s >= lm_off ? Lc[(size_t)(lm_col + s - lm_off) * D] : 0.0; // indexed by H_f column
+          }
+          int lcam = -1;
+          double *out = p.Hbig + orow0 * LD + c;
+          for (int i0 = 0; i0 < m; i0 += SYS_RCM) {
+            const int mc = min(SYS_RCM, m - i0);
+            double lcl[SYS_RCM][6]; // the clone rows of the chunk: all loads in flight before the first FMA
+#pragma unroll
+            for (int ii = 0; ii < SYS_RCM; ii++) {
+              const double *Lr = Lc + (size_t)minfo[8 * (i0 + min(ii, mc - 1)) + 2] * D;
+#pragma unroll
+              for (int s = 0; s < 6; s++) lcl[ii][s] = Lr[(size_t)s * D];
+            }
+#pragma unroll
+            for (int ii = 0; ii < SYS_RCM; ii++) {
+              if (ii < mc) {
+                const int i = i0 + ii;
+                const int *mi = minfo + 8 * i;
+                const double *rd = rows + (size_t)i * RS;
+                if (mi[0] != lcam) {
+                  lcam = mi[0];
+                  if (mi[3] >= 0) {
+#pragma unroll
+                    for (int s = 0; s < 6; s++) lcp[s] = Lc[(size_t)(mi[3] + s) * D];
+                  }
+                  if (mi[4] >= 0) {
+#pragma unroll
+                    for (int s = 0; s < 8; s++) lci[s] = Lc[(size_t)(mi[4] + s) * D];
+                  }
+                }
+                double t0 = 0.0, t1 = 0.0;
+#pragma unroll
+                for (int s = 0; s < 6; s++) t0 = fma(rd[RO_CLONE + s], lcl[ii][s], t0), t1 = fma(rd[RO_CLONE + 6 + s], lcl[ii][s], t1);
+                if (mi[3] >= 0) {
+#pragma unroll
+                  for (int s = 0; s < 6; s++) t0 = fma(rd[RO_CPOSE + s], lcp[s], t0), t1 = fma(rd[RO_CPOSE + 6 + s], lcp[s], t1);
+                }
+                if (mi[4] >= 0) {
+#pragma unroll
+                  for (int s = 0; s < 8; s++) t0 = fma(rd[RO_CINTR + s], lci[s], t0), t1 = fma(rd[RO_CINTR + 8 + s], lci[s], t1);
+                }
+                if (anc_ccol >= 0) {
+#pragma unroll
+                  for (int s = 0; s < 6; s++) t0 = fma(rd[RO_ANC + s], lac[s], t0), t1 = fma(rd[RO_ANC + 6 + s], lac[s], t1);
+                }
+                if (anc_pcol >= 0) {
+#pragma unroll
+                  for (int s = 0; s < 6; s++) t0 = fma(rd[RO_ACAL + s], lap[s], t0), t1 = fma(rd[RO_ACAL + 6 + s], lap[s], t1);
+                }
+                if (lm_col >= 0) {
+#pragma unroll
+                  for (int s = 0; s < 3; s++) t0 = fma(rd[RO_HF + s], llm[s], t0), t1 = fma(rd[RO_HF + 3 + s], llm[s], t1);
+                }
+                if (isres) t0 = rd[RO_RES], t1 = rd[RO_RES + 1];
+                const double *v = V + (size_t)6 * i;
+                const int r = 2 * i;
+                if (nproj > 0) t0 -= v[0] * z0 + v[1] * z1 + v[2] * z2, t1 -= v[3] * z0 + v[4] * z1 + v[5] * z2; // V is not formed otherwise
+                if (r >= nproj) out[(size_t)(r - nproj) * LD] = oscale * t0;
+                if (r + 1 >= nproj) out[(size_t)(r + 1 - nproj) * LD] = oscale * t1;
+              }
+            }
+          }
         }
       }
     }

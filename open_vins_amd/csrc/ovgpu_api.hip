@@ -173,12 +173,17 @@ struct ovgpu_ctx {
   //             ovgpu_measurement_compress) and beyond 255 columns
   //   2 cholqr  R = chol(Gram) + dx refinement for tall stacks (kept as the measured negative result of DESIGN.md section 4)
   int compress_gram = 1;
-  DevBuf<double> gram_part, gram_G, gram_rho, Yaug2;
+  DevBuf<double> gram_part, gram_G, gram_rho, Yaug2, Lw; // Lw: L = U1^T of the prior block (k_tf_lt), read by the per-feature kernel
+  bool whiten = true;           // options.gram_no_whiten == 0: the stack is whitened by the prior BEFORE its Gram matrix is formed
+  bool gram_is_whitened = false; // c->gram_G / the Gram buffer handed out by the last local stage is the whitened stack's
+  bool prior_on_side = false;   // the pending prior-block factorisation runs on stream2 (ev_join marks its end)
+  int tsqr_workers = 0;         // options.tsqr_workers
+  bool leaf_blocked = false;    // options.tsqr_leaf_blocked
   bool async_pending = false;     // ovgpu_msckf_update_async since the last ovgpu_synchronize
   bool last_update_tform = false; // the last EKF stage enqueued was the Gram-form one (finish_update may fall back)
   bool force_tsqr = false;        // one-shot: the next pipeline takes the Householder route
   bool prior_pending = false; // the sharded update's local stage has started the prior block's factorisation on stream2
-  bool prior_overlap = true; // OVGPU_PRIOR_OVERLAP=0: factor the prior block after the compression instead of next to it
+  bool prior_overlap = true; // options.no_prior_overlap == 0: the prior block is factored on the second stream
   bool gram_valid = false; // c->Rws holds chol(gram_G): the EKF stage refines dx against gram_G
   DevBuf<int32_t> gram_dropped, rows_used; // rows_used: rows of accepted features, counted by k_system
   int sys_grid = 1;
@@ -257,9 +262,8 @@ static int launch_qr_node(ovgpu_ctx *c, int nodes, const QrNodeParams &q) {
 // leaf nodes: the "panel wave" variant (k_tsqr_pw.h), NT <= 15
 template <int QH>
 static int launch_qr_leaf_pw(ovgpu_ctx *c, int nodes, const QrNodeParams &q) {
-  // OVGPU_TSQR_LEAF=blocked: the compact-WY leaf on the matrix cores (k_tsqr_blk.h) — experimental, see DESIGN.md §4
-  static const bool blocked = [] { const char *e = std::getenv("OVGPU_TSQR_LEAF"); return e && std::string(e) == "blocked"; }();
-  if (blocked && QH == 32) {
+  // options.tsqr_leaf_blocked: the compact-WY leaf on the matrix cores (k_tsqr_blk.h) — experimental, see DESIGN.md §4
+  if (c->leaf_blocked && QH == 32) {
     static bool attr_b = false;
     if (!attr_b) {
       (void)hipFuncSetAttribute((const void *)blk::k_qr_leaf<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -362,17 +366,24 @@ int ovgpu_create(const ovgpu_options *opts, int device, ovgpu_ctx **out) {
   if (d.feat_rep == OVGPU_REP_ANCHORED_INVERSE_DEPTH_SINGLE) d.feat_rep = OVGPU_REP_ANCHORED_MSCKF_INVERSE_DEPTH; // UpdaterMSCKF.cpp:180-183
   c->row_stride = (d.feat_rep >= OVGPU_REP_ANCHORED_3D) ? 72 : 48;
   // allow the large dynamic LDS carve of the per-feature kernel
-  if (const char *e = std::getenv("OVGPU_TSQR_PIPELINE")) c->tree_pipelined = std::atoi(e) != 0;
-  if (const char *e = std::getenv("OVGPU_PRIOR_OVERLAP")) c->prior_overlap = std::atoi(e) != 0;
-  if (const char *e = std::getenv("OVGPU_COMPRESS")) c->compress_gram = std::string(e) == "tsqr" ? 0 : (std::string(e) == "cholqr" ? 2 : 1);
-  if (const char *e = std::getenv("OVGPU_TSQR_OVERLAP")) c->tree_overlap = std::atoi(e) != 0 ? 1 : 0;
+  // library switches are options of the context, not of the environment (include/ovgpu.h)
+  if (opts->compress_route < 0 || opts->compress_route > OVGPU_COMPRESS_CHOLQR || opts->tsqr_overlap < 0 || opts->tsqr_overlap > 2 || opts->tsqr_workers < 0) {
+    delete c;
+    return set_err(OVGPU_ERR_INVALID, "bad library switch in ovgpu_options");
+  }
+  c->tree_pipelined = opts->tsqr_no_pipeline == 0;
+  c->prior_overlap = opts->no_prior_overlap == 0;
+  c->compress_gram = opts->compress_route == OVGPU_COMPRESS_TSQR ? 0 : (opts->compress_route == OVGPU_COMPRESS_CHOLQR ? 2 : 1);
+  c->tree_overlap = opts->tsqr_overlap == 0 ? -1 : (opts->tsqr_overlap == 1 ? 1 : 0);
+  c->whiten = opts->gram_no_whiten == 0;
+  c->tsqr_workers = opts->tsqr_workers;
+  c->leaf_blocked = opts->tsqr_leaf_blocked != 0;
   if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess)
     c->tree_overlap = 0;
   (void)hipFuncSetAttribute((const void *)k_system, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_limit);
   (void)hipFuncSetAttribute((const void *)k_triangulate, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_limit);
-  const char *tenv = std::getenv("OVGPU_TIMING");
-  c->timing = !(tenv && tenv[0] == '0');
+  c->timing = opts->no_timing == 0;
   *out = c;
   return OVGPU_OK;
 }
@@ -408,7 +419,7 @@ void ovgpu_destroy(ovgpu_ctx *c) {
   c->trk_count.release(), c->trk_cam.release(), c->trk_slot_in.release(), c->trk_cam_in.release(), c->trk_sel.release(), c->trk_nvalid.release(), c->trk_flag.release();
   c->trk_time.release(), c->trk_clone_times.release(), c->trk_uv.release(), c->trk_uvn.release(), c->trk_uv_in.release(), c->trk_uvn_in.release();
   c->dx.release(), c->flags.release(), c->given_status.release();
-  c->gram_part.release(), c->gram_G.release(), c->gram_rho.release(), c->Yaug2.release(), c->gram_dropped.release(), c->rows_used.release();
+  c->gram_part.release(), c->gram_G.release(), c->gram_rho.release(), c->Yaug2.release(), c->gram_dropped.release(), c->rows_used.release(), c->Lw.release();
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
@@ -581,8 +592,7 @@ static int configure_tsqr(ovgpu_ctx *c) {
   const int D = c->D, LD = c->LD;
   HIPCHK(c->Hbig.reserve((size_t)std::max<int64_t>(c->rows_total, 1) * LD));
   const int64_t blk = 4 * QR_LEAF_Q;
-  const char *wenv = std::getenv("OVGPU_TSQR_W");
-  const int64_t target = std::max<int64_t>(1, wenv ? std::atoll(wenv) : c->num_cu);
+  const int64_t target = std::max<int64_t>(1, c->tsqr_workers > 0 ? c->tsqr_workers : c->num_cu);
   int64_t rpn = (c->rows_total + target - 1) / target;
   rpn = std::max<int64_t>(blk, ((rpn + blk - 1) / blk) * blk);
   if (rpn < 2 * blk && c->rows_total > 2 * blk) rpn = 2 * blk; // a leaf shorter than D rows compresses nothing
@@ -752,7 +762,8 @@ static int enqueue_triangulate(ovgpu_ctx *c) {
 }
 
 // f_one >= 0: only that feature, in StateHelper::initialize mode with the landmark representation init_rep
-static int enqueue_system(ovgpu_ctx *c, int f_one = -1, int init_rep = 0) {
+// whiten: the rows leave as [H L | r] with L = c->Lw (the prior block's factor must be complete on this stream)
+static int enqueue_system(ovgpu_ctx *c, int f_one = -1, int init_rep = 0, bool whiten = false) {
   if (c->F == 0) return OVGPU_OK;
   SysParams p;
   p.F = c->F, p.C = c->C, p.K = c->K, p.D = c->D, p.LD = c->LD, p.N = c->N;
@@ -778,6 +789,7 @@ static int enqueue_system(ovgpu_ctx *c, int f_one = -1, int init_rep = 0) {
   p.f_begin = 0, p.f_end = c->F, p.init = 0, p.init_out = nullptr, p.init_flag = nullptr, p.order = c->sys_order.p;
   HIPCHK(c->rows_used.reserve(1));
   p.rows_used = c->rows_used.p;
+  p.Lw = (whiten && f_one < 0) ? c->Lw.p : nullptr;
   int grid = c->sys_grid;
   if (f_one < 0) HIPCHK(hipMemsetAsync(c->rows_used.p, 0, sizeof(int32_t), c->stream));
   if (f_one >= 0) {
@@ -1035,15 +1047,14 @@ static int enqueue_chol_carry(ovgpu_ctx *c, const EkfParams &p, hipStream_t s) {
   return OVGPU_OK;
 }
 
-// prior_on: the factorisation of the prior block (it needs nothing from this update's measurements) goes to that stream
-// and is awaited through c->ev_join; prior_done: it has been enqueued already
-static int enqueue_ekf_gram(ovgpu_ctx *c, int part = 3) {
-  // part 1: P_DD = U1^T U1 carrying P(D, :) (depends on the prior only; on c->stream2 when part == 1, behind ev_fork / ev_join)
-  // part 2: everything that needs the Gram matrix; part 3: both, on the context's stream
+// part 1: P_DD = U1^T U1 carrying P(D, :), and L = U1^T for the per-feature kernel.  Depends on the prior only; side = true puts it
+//         on c->stream2 behind ev_fork, ev_join marks its end (c->prior_on_side)
+// part 2: everything that needs the Gram matrix in c->gram_G (c->gram_is_whitened says of which stack); part 3: both, on the context's stream
+static int enqueue_ekf_gram(ovgpu_ctx *c, int part, bool side = false) {
   const int D = c->D, N = c->N, LA = D + N + 1;
-  if (part == 3) c->prior_pending = false;
   HIPCHK(c->Yaug2.reserve((size_t)D * LA));
   HIPCHK(c->gram_rho.reserve(std::max(N, D)));
+  HIPCHK(c->Lw.reserve((size_t)D * D));
   EkfParams p;
   p.N = N, p.D = D, p.DC = D, p.LD = c->LD, p.LA = LA, p.tri = 1, p.pred = nullptr;
   p.R = nullptr, p.col_cov = c->col_cov.p, p.P = c->P.p, p.Mt = c->Mt.p, p.A = c->Aaug.p, p.Y = c->Yaug.p;
@@ -1051,30 +1062,42 @@ static int enqueue_ekf_gram(ovgpu_ctx *c, int part = 3) {
   TformParams t;
   t.N = N, t.D = D, t.LA = LA, t.LG = 16 * ((c->LD + 15) / 16), t.col_cov = c->col_cov.p, t.G = c->gram_G.p, t.P = c->P.p;
   t.A = c->Aaug.p, t.Y1 = c->Yaug.p, t.W = c->Mt.p, t.inv_sigma2 = 1.0 / c->dopt.sigma_pix_sq, t.go = c->flags.p + 3, t.diag0 = c->gram_rho.p;
+  t.whitened = c->gram_is_whitened ? 1 : 0, t.Lw = c->Lw.p;
   hipStream_t s = c->stream;
   const int tm = (D + 15) / 16, tn = (N + 15) / 16;
   int rc = OVGPU_OK;
   if (part & 1) {
+    if (c->prior_on_side) HIPCHK(hipStreamWaitEvent(s, c->ev_join, 0)); // a factorisation nobody joined still owns the work matrices
     HIPCHK(hipMemsetAsync(c->flags.p, 0, 4 * sizeof(int32_t), s));
     hipStream_t sp = s;
-    if (part == 1) { // everything enqueued so far (the previous update's tail reads these buffers) precedes the side stream's work
+    c->prior_on_side = false;
+    if (side && part == 1) { // everything enqueued so far (the previous update's tail reads these buffers) precedes the side stream's work
       HIPCHK(hipEventRecord(c->ev_fork, s));
       HIPCHK(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
       sp = c->stream2;
+      c->prior_on_side = true;
     }
     const int64_t elems = (int64_t)D * LA;
     hipLaunchKernelGGL(k_tf_gather, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, sp, t);
     p.diag0 = c->gram_rho.p;
     if ((rc = enqueue_chol_carry(c, p, sp)) != OVGPU_OK) return rc; // Y1 = [U1 | B | 0] in c->Yaug
     p.diag0 = nullptr;
-    if (part == 1) HIPCHK(hipEventRecord(c->ev_join, sp));
+    hipLaunchKernelGGL(k_tf_lt, dim3((unsigned)((D * D + 255) / 256)), dim3(256), 0, sp, t);
+    HIPCHK(hipGetLastError());
+    if (c->prior_on_side) HIPCHK(hipEventRecord(c->ev_join, sp));
+    c->prior_pending = true;
   }
   if (part & 2) {
-    if (part == 2) HIPCHK(hipStreamWaitEvent(s, c->ev_join, 0));
+    if (c->prior_on_side) HIPCHK(hipStreamWaitEvent(s, c->ev_join, 0));
+    c->prior_pending = false, c->prior_on_side = false;
     hipLaunchKernelGGL(k_tf_go, dim3(1), dim3(1), 0, s, (const int32_t *)c->flags.p, c->flags.p + 3);
     p.pred = c->flags.p + 3; // a prior block that is not positive definite: skip, the host falls back (finish_update)
-    hipLaunchKernelGGL(k_tf_w, dim3((tm * tm + 3) / 4), dim3(256), 0, s, t);
-    hipLaunchKernelGGL(k_tf_t, dim3((tm * tm + 3) / 4), dim3(256), 0, s, t);
+    if (t.whitened) {
+      hipLaunchKernelGGL(k_tf_a, dim3((unsigned)((D * D + 255) / 256)), dim3(256), 0, s, t);
+    } else {
+      hipLaunchKernelGGL(k_tf_w, dim3((tm * tm + 3) / 4), dim3(256), 0, s, t);
+      hipLaunchKernelGGL(k_tf_t, dim3((tm * tm + 3) / 4), dim3(256), 0, s, t);
+    }
     hipLaunchKernelGGL(k_tf_bh, dim3((D + 3) / 4), dim3(256), 0, s, t);
     p.Y = c->Yaug2.p;
     if ((rc = enqueue_chol_carry(c, p, s)) != OVGPU_OK) return rc; // Y2 = [C | C^-T B | C^-T h] in c->Yaug2
@@ -1127,17 +1150,23 @@ static int enqueue_pipeline(ovgpu_ctx *c, int stages, bool slam = false, bool fa
   const bool fits = (c->LD + 15) / 16 <= gram::GR_NT && c->F > 0;
   tform = !gram_only && c->compress_gram == 1 && !c->force_tsqr && fits && (stages & STAGE_EKF) != 0 && (stages & STAGE_LOCAL) != 0;
   c->force_tsqr = false;
-  // the prior block's factorisation needs nothing from the measurements: it runs next to the per-feature kernels
-  const bool side = tform && c->stream2 != nullptr && c->ev_fork != nullptr && c->ev_join != nullptr && c->prior_overlap;
-  if (side && (rc = enqueue_ekf_gram(c, 1)) != OVGPU_OK) return rc;
+  // The prior block's factorisation needs nothing from the measurements: it runs on the second stream next to the
+  // triangulation.  With the whitened stack (default) the per-feature kernel reads its factor L, so it joins before that kernel;
+  // otherwise only the update itself waits for it.
+  const bool need_prior = (tform || (gram_only && fits)) && (stages & STAGE_LOCAL) != 0;
+  const bool whiten = need_prior && c->whiten;
+  const bool side = need_prior && c->stream2 != nullptr && c->ev_fork != nullptr && c->ev_join != nullptr && c->prior_overlap;
+  if (need_prior && (rc = enqueue_ekf_gram(c, 1, side)) != OVGPU_OK) return rc;
   if (stages & STAGE_LOCAL) {
     if (c->given_tri) {
       // the gate overwrites status; restore the caller's per-feature status for this run
       if (c->F > 0) HIPCHK(hipMemcpyAsync(c->status.p, c->given_status.p, sizeof(int32_t) * c->F, hipMemcpyDeviceToDevice, c->stream));
     } else if ((rc = enqueue_triangulate(c)) != OVGPU_OK) return rc;
+    if (whiten && c->prior_on_side) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join, 0));
     if (es) HIPCHK(hipEventRecord(es->a, c->stream));
-    if ((rc = enqueue_system(c)) != OVGPU_OK) return rc;
+    if ((rc = enqueue_system(c, -1, 0, whiten)) != OVGPU_OK) return rc;
     if (es) HIPCHK(hipEventRecord(es->b, c->stream));
+    if (need_prior) c->gram_is_whitened = whiten;
     // which compression (see ovgpu_ctx::compress_gram)
     bool cholqr = !gram_only && c->compress_gram == 2 && fits && (factor_stays || (stages & STAGE_EKF) != 0) && c->rows_total >= (int64_t)4 * c->LD;
     if (cholqr) { // tall stacks only, and the accepted-row count is known only after the gate: one 4-byte read-back
@@ -1158,7 +1187,7 @@ static int enqueue_pipeline(ovgpu_ctx *c, int stages, bool slam = false, bool fa
     if (ec) HIPCHK(hipEventRecord(ec->b, c->stream));
   }
   if (stages & STAGE_EKF) {
-    if ((rc = tform ? enqueue_ekf_gram(c, side ? 2 : 3) : enqueue_ekf(c)) != OVGPU_OK) return rc;
+    if ((rc = tform ? enqueue_ekf_gram(c, 2) : enqueue_ekf(c)) != OVGPU_OK) return rc;
   }
   if (eu) HIPCHK(hipEventRecord(eu->b, c->stream));
   return OVGPU_OK;
@@ -2253,13 +2282,9 @@ int ovgpu_msckf_local_gram(ovgpu_ctx *c, int32_t *feat_status, double *chi2, dou
   if (!c->have_state || c->poses_only) return set_err(OVGPU_ERR_NO_STATE, "ovgpu_set_state was never called");
   HIPCHK(hipSetDevice(c->device));
   int rc = OVGPU_OK;
-  // the prior block's factorisation of the update that follows (ovgpu_msckf_gram_update) needs nothing from the measurements
-  // or from the other ranks: it runs on the second stream next to the local stage and the all-reduce
+  // the prior block's factorisation (its factor whitens the local stack, and the update that follows, ovgpu_msckf_gram_update,
+  // continues from it) is enqueued by the pipeline: second stream, next to the triangulation
   c->prior_pending = false;
-  if ((c->LD + 15) / 16 <= gram::GR_NT && c->stream2 && c->ev_fork && c->ev_join && c->prior_overlap) {
-    if ((rc = enqueue_ekf_gram(c, 1)) != OVGPU_OK) return rc;
-    c->prior_pending = true;
-  }
   rc = enqueue_pipeline(c, STAGE_LOCAL, false, true, true);
   if (rc != OVGPU_OK) return rc;
   const size_t n = (size_t)256 * ((c->LD + 15) / 16) * ((c->LD + 15) / 16);
@@ -2292,6 +2317,7 @@ int ovgpu_msckf_gram_update(ovgpu_ctx *c, const void *gram_dev, double *dx, doub
   HIPCHK(c->Rws.reserve((size_t)16 * c->D * c->LD));
   hipStream_t s = c->stream;
   HIPCHK(hipMemcpyAsync(c->gram_G.p, gram_dev, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
+  // the Gram matrices of all ranks were formed with this rank's own factor of the (replicated) prior: c->gram_is_whitened
   int rc = enqueue_ekf_gram(c, c->prior_pending ? 2 : 3);
   c->prior_pending = false;
   if (rc != OVGPU_OK) return rc;

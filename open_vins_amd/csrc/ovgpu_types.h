@@ -83,6 +83,8 @@ struct SysParams {
   double *init_out;
   int32_t *init_flag; // [0] = 1 when the feature passed the gate
   int32_t *rows_used; // optional counter: rows of the stack that belong to accepted features
+  const double *Lw;   // [D x D] row-major, lower triangular with explicit zeros above the diagonal: L = U1^T, P_DD = L L^T (k_ekf.h).
+                      // Non-null: the rows leave the kernel whitened by the prior, Q^T [H_x L | res] (the Gram route)
   DevOptions opt;
 };
 

@@ -443,6 +443,43 @@ def make_problem(cfg=2, rep=0, *, C=None, K=None, F=None, track="full", fisheye=
     )
 
 
+def realistic_prior(prob: Problem, sigma_g_p=1.0, sigma_g_th=0.05, q_th=5e-5, q_p=1e-5, seed=0):
+    """A prior covariance shaped like a live sliding window instead of make_problem's generic SPD matrix.
+
+    The oldest clone carries the accumulated GLOBAL uncertainty (sigma_g_p metres, sigma_g_th radians: position and
+    yaw of a VIO drift without bound), every later clone is the previous one plus the IMU's noise over one camera
+    period (q_th rad, q_p m; the chain StateHelper::clone / augment_clone builds, StateHelper.cpp:341-391, with
+    Propagator.cpp:76-137 adding Q_d at IMU level, and the lever arm of the rotation error), and the IMU pose is an
+    exact copy of the newest clone (the state right after the cloning step: P is singular, its clone / calibration
+    block is not).  Consecutive clones are then correlated to 1 - (q / sigma_g)^2: cond(P_DD) = 1e8 ... 1e16 for the
+    defaults and beyond, and P is LARGE exactly along the directions the measurements do not see.
+    Returns the N x N matrix (prob.P is not modified)."""
+    rng = np.random.default_rng([int(seed), 11])
+    N, C, K = prob.N, prob.C, prob.K
+    sig = state_sigmas(C, K)
+    c0 = int(prob.clone_cov_id[0])
+    A = np.zeros((N, N))
+    Gm = np.tril(rng.normal(0, 1 / np.sqrt(N), (N, N)), -1)
+    L = sig[:, None] * (np.eye(N) + 0.1 * Gm)
+    A[:c0, :c0] = L[:c0, :c0]  # IMU velocity / biases, dt, calibration: State.cpp:150-164 priors, mildly correlated
+    for c in range(C):
+        i = c0 + 6 * c
+        if c == 0:
+            A[i:i + 3, i:i + 3] = np.eye(3) * sigma_g_th
+            A[i + 3:i + 6, i + 3:i + 6] = np.eye(3) * sigma_g_p
+            A[i:i + 6, :c0] = 0.05 * rng.normal(0, 1, (6, c0)) * np.array([sigma_g_th] * 3 + [sigma_g_p] * 3)[:, None] / np.sqrt(c0)
+        else:
+            A[i:i + 6, :] = A[i - 6:i, :]
+            dp = prob.clone_q_p[c, 4:7] - prob.clone_q_p[c - 1, 4:7]
+            A[i + 3:i + 6, :] += -skew(dp) @ A[i - 6:i - 3, :]
+            A[i:i + 3, i:i + 3] += np.eye(3) * q_th
+            A[i + 3:i + 6, i + 3:i + 6] += np.eye(3) * q_p
+    iN = c0 + 6 * (C - 1)
+    A[0:6, :] = A[iN:iN + 6, :]
+    P = A @ A.T
+    return np.ascontiguousarray(0.5 * (P + P.T))
+
+
 def landmark_from_xyz(rep, p):
     """ov_type::Landmark::set_from_xyz (Landmark.cpp:66-141): xyz -> representation coordinates, rows of p."""
     p = np.asarray(p, dtype=np.float64)

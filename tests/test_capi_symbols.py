@@ -34,12 +34,27 @@ def test_library_exports_every_declared_symbol():
     assert set(capi.declare(lib)) == set(declared)
 
 
-def test_struct_layouts_match_header():
-    # sizes the C compiler produces for the PODs of include/ovgpu.h (checked against a compiled probe in build())
-    assert C.sizeof(capi.Options) == 2 * 8 + 4 * 4 + 9 * 8 + 4 * 4
-    assert C.sizeof(capi.StateView) == 4 * 4 + 9 * 8
-    assert C.sizeof(capi.FeaturesView) == 2 * 4 + 5 * 8
-    assert C.sizeof(capi.UpdateStats) == 6 * 4 + 6 * 4
+def test_struct_layouts_match_header(tmp_path):
+    """sizeof / offsetof of every field of the PODs of include/ovgpu.h as gcc lays them out, against the ctypes mirror."""
+    import subprocess
+    structs = {"ovgpu_options": capi.Options, "ovgpu_state_view": capi.StateView, "ovgpu_features_view": capi.FeaturesView,
+               "ovgpu_landmarks_view": capi.LandmarksView, "ovgpu_update_stats": capi.UpdateStats}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "ovgpu.h"', 'int main(void) {']
+    for cname, cls in structs.items():
+        lines.append(f'  printf("{cname} %zu\\n", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'  printf("{cname}.{fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ['  return 0;', '}']
+    src = tmp_path / "probe.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "probe"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = dict(l.split() for l in subprocess.check_output([str(exe)], text=True).splitlines())
+    for cname, cls in structs.items():
+        assert int(got[cname]) == C.sizeof(cls), cname
+        for fname, _ in cls._fields_:
+            assert int(got[f"{cname}.{fname}"]) == getattr(cls, fname).offset, f"{cname}.{fname}"
+    assert C.sizeof(capi.Options) == 2 * 8 + 4 * 4 + 9 * 8 + 4 * 4 + 8 * 4
 
 
 def test_default_options_are_the_reference_defaults():
@@ -50,6 +65,8 @@ def test_default_options_are_the_reference_defaults():
     assert (o.triangulate_1d, o.refine_features, o.max_runs) == (0, 1, 5)  # FeatureInitializerOptions.h:36-42
     assert (o.init_lamda, o.max_lamda, o.min_dx, o.min_dcost, o.lam_mult) == (1e-3, 1e10, 1e-6, 1e-6, 10.0)
     assert (o.min_dist, o.max_dist, o.max_baseline, o.max_cond_number) == (0.10, 60.0, 40.0, 10000.0)
+    # library switches: zero = default route (whitened Gram matrix, prior block factored on the side stream, timing on)
+    assert (o.compress_route, o.gram_no_whiten, o.no_prior_overlap, o.tsqr_workers, o.tsqr_no_pipeline, o.tsqr_overlap, o.tsqr_leaf_blocked, o.no_timing) == (0,) * 8
 
 
 def test_chi2_quantile_host_helper():

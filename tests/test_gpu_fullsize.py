@@ -1,0 +1,211 @@
+"""GPU parity at BASELINE.json's full sizes, against the CPU ORACLE (never GPU against GPU), the prior-conditioning
+sweep of the default (Gram / prior-whitened) route, and the camera models called directly.
+
+  * configs[2] (2000 features), one rank's shard of configs[3] (4 cameras, 1250 features), north_star's 10 000-feature
+    batch on the 30-clone state, configs[4] geometry (50 clones, 4 cameras, D = 356) at F >= 200: accept sets, chi2, dx
+    (rel 1e-8), P (rel-Frobenius 1e-9) with the oracle's triangulation injected on both sides.
+  * conditioning: priors built like a live window (synth.realistic_prior), cond(P_DD) 1e4 ... 3e16, each compared with
+    an extended-precision (numpy longdouble, 64-bit mantissa) evaluation of the same update.  The oracle — the reference's
+    own S = H P H^T + R form — loses accuracy with the conditioning too; the GPU must stay within 1e-9 (P) / 1e-8 (dx) or
+    within a small factor of the oracle's own error, whichever is larger.
+"""
+import numpy as np
+import pytest
+
+from open_vins_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+LD = np.longdouble
+
+
+@pytest.fixture(scope="module")
+def Updater():
+    import torch
+    assert torch.cuda.is_available(), "these tests need a GPU"
+    from open_vins_amd.updater import UpdaterMSCKF
+    return UpdaterMSCKF
+
+
+def _rel(a, b):
+    return float(np.linalg.norm(np.asarray(a - b, dtype=np.float64)) / max(np.linalg.norm(np.asarray(b, dtype=np.float64)), 1e-300))
+
+
+def _parity(Updater, oracle, prob, opts, tol_dx=1e-8, tol_p=1e-9, **fields):
+    v = capi.Views(prob)
+    tri = oracle.triangulate(opts, v)
+    ref = oracle.msckf_update(opts, v, given=tri)
+    up = Updater(opts)
+    up.set_problem(prob)
+    up.set_triangulation(tri["p_FinG"], tri["p_FinA"], tri["anchor_meas"], tri["status"])
+    out = up.update()
+    up.close()
+    diff = np.nonzero(out["feat_status"] != ref["feat_status"])[0]
+    for f in diff:
+        assert abs(ref["chi2"][f] / ref["chi2_thresh"][f] - 1.0) < 1e-6, f
+    gate = np.isfinite(ref["chi2"])
+    np.testing.assert_allclose(out["chi2"][gate], ref["chi2"][gate], rtol=1e-8)
+    assert ref["stats"]["n_used"] > 0.8 * prob.F
+    if len(diff) == 0:
+        assert _rel(out["dx"], ref["dx"]) < tol_dx, _rel(out["dx"], ref["dx"])
+        assert _rel(out["P"], ref["P"]) < tol_p, _rel(out["P"], ref["P"])
+        assert np.array_equal(out["P"], out["P"].T)
+        assert np.abs(out["clone_q_p"] - ref["clone_q_p"]).max() < 1e-9
+    return out, ref
+
+
+def test_cfg3_full_size_against_oracle(Updater, oracle):
+    """BASELINE configs[2]: 30 clones + online calibration, 2000 features (93 k measurements)."""
+    prob = synth.make_problem(3)
+    assert prob.F == 2000 and prob.N == 224
+    _parity(Updater, oracle, prob, capi.default_options(chi2_multipler=1.0))
+
+
+def test_cfg4_shard_against_oracle(Updater, oracle):
+    """One of 8 ranks' share of BASELINE configs[3]: 4 cameras, N = 252, D = 236, 1250 features of ~100 observations."""
+    prob = synth.make_problem(4, F=1250)
+    assert prob.K == 4 and prob.N == 252
+    _parity(Updater, oracle, prob, capi.default_options(chi2_multipler=1.0))
+
+
+def test_10k_features_against_oracle(Updater, oracle):
+    """north_star's target batch on one GPU: 10 000 MSCKF features on the 30-clone / 15-dof-calibration state."""
+    prob = synth.make_problem(2, F=10000)
+    assert prob.F == 10000
+    _parity(Updater, oracle, prob, capi.default_options(chi2_multipler=1.0))
+
+
+def test_cfg5_geometry_against_oracle(Updater, oracle):
+    """BASELINE configs[4] geometry: 50 clones, 4 cameras, N = 372, D = 356 columns (23 column tiles), tracks of up to 200."""
+    prob = synth.make_problem(5, F=240)
+    assert prob.C == 50 and prob.K == 4 and prob.N == 372
+    _parity(Updater, oracle, prob, capi.default_options(chi2_multipler=1.0))
+
+
+# --------------------------------------------------------------------------- conditioning of the prior
+def _chol_upper_ld(A):
+    A = A.astype(LD)
+    n = A.shape[0]
+    U = np.zeros_like(A)
+    for k in range(n):
+        d = A[k, k] - (U[:k, k] ** 2).sum()
+        U[k, k] = np.sqrt(d)
+        U[k, k + 1:] = (A[k, k + 1:] - U[:k, k] @ U[:k, k + 1:]) / U[k, k]
+    return U
+
+
+def _fsub_ld(U, B):  # U^-T B
+    B = B.astype(LD)
+    Y = np.zeros_like(B)
+    for i in range(U.shape[0]):
+        Y[i] = (B[i] - U[:i, i] @ Y[:i]) / U[i, i]
+    return Y
+
+
+def extended_precision_update(P, cols, R, rc, sigma2):
+    """StateHelper::EKFUpdate for the compressed system (R, rc) evaluated with 64-bit mantissas (x86 long double), in
+    the prior-whitened form (every factorisation is of a well-conditioned matrix; residual error ~1e-19 cond)."""
+    D = len(cols)
+    Pl = P.astype(LD)
+    U1 = _chol_upper_ld(Pl[np.ix_(cols, cols)])
+    Z = R.astype(LD) @ U1.T
+    T = np.eye(D, dtype=LD) + (Z.T @ Z) / LD(sigma2)
+    B = _fsub_ld(U1, Pl[cols, :])
+    Ct = _chol_upper_ld(T)
+    Y2 = _fsub_ld(Ct, B)
+    y2 = _fsub_ld(Ct, ((Z.T @ rc.astype(LD)) / LD(sigma2))[:, None])[:, 0]
+    return Pl - (B.T @ B - Y2.T @ Y2), Y2.T @ y2
+
+
+SWEEP = [  # sigma of the global position / yaw, per-clone process noise (rad, m): cond(P_DD) 1e6 ... 3e16
+    dict(sigma_g_p=0.05, sigma_g_th=0.01, q_th=1e-3, q_p=5e-3),
+    dict(sigma_g_p=0.3, sigma_g_th=0.02, q_th=2e-4, q_p=1e-4),
+    dict(sigma_g_p=1.0, sigma_g_th=0.05, q_th=5e-5, q_p=1e-5),
+    dict(sigma_g_p=3.0, sigma_g_th=0.1, q_th=5e-5, q_p=1e-5),
+    dict(sigma_g_p=10.0, sigma_g_th=0.2, q_th=5e-5, q_p=1e-5),
+    dict(sigma_g_p=10.0, sigma_g_th=0.2, q_th=5e-6, q_p=1e-6),
+]
+
+
+# The snapshot's clone estimates are 2 cm / 0.5 deg off the truth, far outside what these tight priors allow: the gate would
+# reject every feature.  The sweep is about the linear algebra, so the gate is opened (chi2_multipler 1e12: every feature is
+# stacked) and the chi2 VALUES are compared instead.
+GATE_OPEN = 1e12
+
+
+@pytest.mark.parametrize("kw", SWEEP)
+def test_prior_conditioning_sweep(Updater, oracle, kw):
+    prob = synth.make_problem(2, F=300)
+    prob.P = synth.realistic_prior(prob, **kw)
+    opts = capi.default_options(chi2_multipler=GATE_OPEN)
+    v = capi.Views(prob)
+    tri = oracle.triangulate(opts, v)
+    ref = oracle.msckf_update(opts, v, want_compressed=True, given=tri)
+    cols = oracle.column_map(opts, v)
+    PDD = prob.P[np.ix_(cols, cols)]
+    ev = np.linalg.eigvalsh(PDD)
+    cond = ev[-1] / max(ev[0], 1e-300)
+    P_true, dx_true = extended_precision_update(prob.P, cols, ref["H_comp"], ref["r_comp"], opts.sigma_pix ** 2)
+    e_ref = (_rel(ref["P"].astype(LD), P_true), _rel(ref["dx"].astype(LD), dx_true))
+    up = Updater(opts)
+    up.set_problem(prob)
+    up.set_triangulation(tri["p_FinG"], tri["p_FinA"], tri["anchor_meas"], tri["status"])
+    out = up.update()
+    up.close()
+    assert out["stats"]["status"] == 0
+    assert np.array_equal(out["feat_status"], ref["feat_status"]) and ref["stats"]["n_used"] > 250
+    gate = np.isfinite(ref["chi2"])
+    np.testing.assert_allclose(out["chi2"][gate], ref["chi2"][gate], rtol=1e-7)
+    e_gpu = (_rel(out["P"].astype(LD), P_true), _rel(out["dx"].astype(LD), dx_true))
+    print(f"cond(P_DD) {cond:.1e}: |dP|/|P| gpu {e_gpu[0]:.1e} oracle {e_ref[0]:.1e}; |ddx|/|dx| gpu {e_gpu[1]:.1e} oracle {e_ref[1]:.1e}; "
+          f"gpu vs oracle P {_rel(out['P'], ref['P']):.1e} dx {_rel(out['dx'], ref['dx']):.1e}")
+    assert e_gpu[0] < max(1e-9, 5 * e_ref[0]), (cond, e_gpu, e_ref)
+    assert e_gpu[1] < max(1e-8, 10 * e_ref[1]), (cond, e_gpu, e_ref)
+    assert np.array_equal(out["P"], out["P"].T) and np.linalg.eigvalsh(out["P"]).min() > -1e-9 * np.abs(np.diag(out["P"])).max()
+
+
+def test_round1_route_loses_the_gauge(Updater, oracle):
+    """Why the stack is whitened BEFORE its Gram matrix is formed: options.gram_no_whiten = 1 (Gram matrix of the raw stack,
+    U1 G U1^T afterwards — round 1's form) carries eps |H|^2 sigma_g^2 into the unobservable directions."""
+    prob = synth.make_problem(2, F=300)
+    prob.P = synth.realistic_prior(prob, sigma_g_p=10.0, sigma_g_th=0.2)
+    opts = capi.default_options(chi2_multipler=GATE_OPEN)
+    v = capi.Views(prob)
+    tri = oracle.triangulate(opts, v)
+    ref = oracle.msckf_update(opts, v, given=tri)
+    assert ref["stats"]["n_used"] > 250
+    errs = {}
+    for nw in (0, 1):
+        up = Updater(capi.default_options(chi2_multipler=GATE_OPEN, gram_no_whiten=nw))
+        up.set_problem(prob)
+        up.set_triangulation(tri["p_FinG"], tri["p_FinA"], tri["anchor_meas"], tri["status"])
+        out = up.update()
+        up.close()
+        errs[nw] = _rel(out["P"], ref["P"])
+    print("gram then whiten", errs[1], "whiten then gram", errs[0])
+    assert errs[0] < 1e-9 and errs[1] > 10 * errs[0]
+
+
+# --------------------------------------------------------------------------- camera models, called directly
+@pytest.mark.parametrize("fish", [0, 1])
+def test_camera_models_bit_exact(Updater, oracle, fish):
+    """CamRadtan / CamEqui::distort_d with the float round trip of CamBase.h:130-135 and compute_distort_jacobian
+    (CamRadtan.h:127-198, CamEqui.h:136-230): the distorted pixel is bit-exact, the Jacobians agree to round-off."""
+    up = Updater(capi.default_options())
+    lib = oracle.load()
+    dp = capi.c_double_p
+    rng = np.random.default_rng(fish)
+    cam = np.array((synth._INTRINSICS_EQUI if fish else synth._INTRINSICS)[0])
+    n = 20000
+    uvn = rng.uniform(-0.6, 0.6, (n, 2))
+    uvn[:4] = [[0, 0], [1e-12, 0], [0, -1e-9], [0.6, -0.6]]
+    uv, a, b = np.zeros((n, 2)), np.zeros((n, 4)), np.zeros((n, 16))
+    capi.check(up.lib.ovgpu_cam_distort(up._ctx, fish, cam.ctypes.data_as(dp), n, uvn.ctypes.data_as(dp), uv.ctypes.data_as(dp),
+                                        a.ctypes.data_as(dp), b.ctypes.data_as(dp)), "ovgpu_cam_distort")
+    uv2, a2, b2 = np.zeros((n, 2)), np.zeros((n, 4)), np.zeros((n, 16))
+    for i in range(n):
+        lib.oracle_cam_distort(cam.ctypes.data_as(dp), fish, uvn[i].ctypes.data_as(dp), uv2[i].ctypes.data_as(dp), a2[i].ctypes.data_as(dp),
+                               b2[i].ctypes.data_as(dp))
+    up.close()
+    assert np.array_equal(uv, uv2), f"{(uv != uv2).sum()} of {uv.size} pixels differ"
+    assert np.abs(a - a2).max() <= 1e-12 * np.abs(a2).max()
+    assert np.abs(b - b2).max() <= 1e-12 * max(np.abs(b2).max(), 1.0)

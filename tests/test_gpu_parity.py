@@ -420,42 +420,32 @@ def test_cfg3_full_size_properties(Updater):
 
 
 # --------------------------------------------------------------------------- measurement compression variants
-def _compress_with_env(Updater, prob, opts, tri, **env):
-    """The TSQR shape is read from the environment when a context is created / the features are uploaded."""
-    import os
-    old = {k: os.environ.get(k) for k in env}
-    os.environ.update({k: str(v) for k, v in env.items()})
-    try:
-        up = Updater(opts)
-        up.set_problem(prob)
-        up.set_triangulation(tri["p_FinG"], tri["p_FinA"], tri["anchor_meas"], tri["status"])
-        cmp = up.compress()
-        up.close()
-    finally:
-        for k, v in old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+def _opts_with(opts, **fields):
+    """A copy of the options with library switches set (include/ovgpu.h: they are fields of ovgpu_options, not environment)."""
+    import ctypes
+    o = capi.Options()
+    ctypes.memmove(ctypes.byref(o), ctypes.byref(opts), ctypes.sizeof(o))
+    for k, v in fields.items():
+        assert hasattr(o, k), k
+        setattr(o, k, v)
+    return o
+
+
+def _compress_with(Updater, prob, opts, tri, **fields):
+    up = Updater(_opts_with(opts, **fields))
+    up.set_problem(prob)
+    up.set_triangulation(tri["p_FinG"], tri["p_FinA"], tri["anchor_meas"], tri["status"])
+    cmp = up.compress()
+    up.close()
     return cmp
 
 
-def _update_with_env(Updater, prob, opts, tri, **env):
-    import os
-    old = {k: os.environ.get(k) for k in env}
-    os.environ.update({k: str(v) for k, v in env.items()})
-    try:
-        up = Updater(opts)
-        up.set_problem(prob)
-        up.set_triangulation(tri["p_FinG"], tri["p_FinA"], tri["anchor_meas"], tri["status"])
-        out = up.update()
-        up.close()
-    finally:
-        for k, v in old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+def _update_with(Updater, prob, opts, tri, **fields):
+    up = Updater(_opts_with(opts, **fields))
+    up.set_problem(prob)
+    up.set_triangulation(tri["p_FinG"], tri["p_FinA"], tri["anchor_meas"], tri["status"])
+    out = up.update()
+    up.close()
     return out
 
 
@@ -463,10 +453,10 @@ def _update_with_env(Updater, prob, opts, tri, **env):
                                 dict(F=40, C=6, K=1)])
 def test_gram_route_gives_the_householder_posterior(Updater, oracle, kw):
     """The on-device update accumulates the Gram matrix [H r]^T [H r] on the matrix cores (k_gram.h) and updates in coordinates
-    whitened by the prior (k_ekf.h) unless OVGPU_COMPRESS=tsqr selects the Householder TSQR + the reference-shaped update:
+    whitened by the prior (k_ekf.h) unless options.compress_route = OVGPU_COMPRESS_TSQR selects the Householder TSQR + the reference-shaped update:
     same dx and P, far inside the parity tolerance against the oracle (which compresses with Givens rotations like the
     reference).  LD = 209 / 237 / 87 / 51 columns: 14, 15, 6 and 4 column tiles; F = 3 has hardly more rows than columns.
-    OVGPU_COMPRESS=cholqr (R = chol(Gram) + dx refinement, tall stacks only) is the documented negative result: it holds
+    OVGPU_COMPRESS_CHOLQR (R = chol(Gram) + dx refinement, tall stacks only) is the documented negative result: it holds
     the parity tolerance on these snapshots but not in the closed loop (tests/test_closed_loop.py runs the default)."""
     kw = dict(kw)
     prob = synth.make_problem(kw.pop("cfg", 2), **kw)
@@ -474,10 +464,10 @@ def test_gram_route_gives_the_householder_posterior(Updater, oracle, kw):
     v = capi.Views(prob)
     tri = oracle.triangulate(opts, v)
     ref = oracle.msckf_update(opts, v, given=tri)
-    a = _update_with_env(Updater, prob, opts, tri, OVGPU_COMPRESS="tsqr")
-    b = _update_with_env(Updater, prob, opts, tri, OVGPU_COMPRESS="gram")
-    b2 = _update_with_env(Updater, prob, opts, tri, OVGPU_COMPRESS="gram")
-    c = _update_with_env(Updater, prob, opts, tri, OVGPU_COMPRESS="cholqr")
+    a = _update_with(Updater, prob, opts, tri, compress_route=capi.COMPRESS_TSQR)
+    b = _update_with(Updater, prob, opts, tri, compress_route=capi.COMPRESS_GRAM)
+    b2 = _update_with(Updater, prob, opts, tri, compress_route=capi.COMPRESS_GRAM)
+    c = _update_with(Updater, prob, opts, tri, compress_route=capi.COMPRESS_CHOLQR)
     for o in (a, b, c):
         assert np.array_equal(o["feat_status"], ref["feat_status"]) and o["stats"]["status"] == 0 and np.array_equal(o["P"], o["P"].T)
     assert np.array_equal(b["dx"], b2["dx"]) and np.array_equal(b["P"], b2["P"])  # ordered sums: reproducible bit for bit
@@ -520,11 +510,11 @@ def test_compression_is_independent_of_the_tree_shape(Updater, oracle, kw):
     prob = synth.make_problem(kw.pop("cfg", 2), **kw)
     opts = capi.default_options(chi2_multipler=1.0)
     tri = oracle.triangulate(opts, capi.Views(prob))
-    base = _compress_with_env(Updater, prob, opts, tri, OVGPU_TSQR_W=1)
+    base = _compress_with(Updater, prob, opts, tri, tsqr_workers=1)
     G0, g0 = base["H"].T @ base["H"], base["H"].T @ base["r"]
-    for env in (dict(OVGPU_TSQR_W=2), dict(OVGPU_TSQR_W=5), dict(OVGPU_TSQR_W=64), dict(OVGPU_TSQR_W=64, OVGPU_TSQR_PIPELINE=0),
-                dict(OVGPU_TSQR_W=64, OVGPU_TSQR_OVERLAP=0), dict(OVGPU_TSQR_W=256), dict(OVGPU_TSQR_W=256, OVGPU_TSQR_OVERLAP=1)):  # (OVGPU_TSQR_LEAF is read once per process: tests/test_blocked_leaf.py)
-        c = _compress_with_env(Updater, prob, opts, tri, **env)
+    for env in (dict(tsqr_workers=2), dict(tsqr_workers=5), dict(tsqr_workers=64), dict(tsqr_workers=64, tsqr_no_pipeline=1),
+                dict(tsqr_workers=64, tsqr_overlap=2), dict(tsqr_workers=256), dict(tsqr_workers=256, tsqr_overlap=1)):
+        c = _compress_with(Updater, prob, opts, tri, **env)
         assert c["rows"] == base["rows"] and c["D"] == base["D"]
         assert np.abs(np.tril(c["H"], -1)).max() == 0.0
         assert np.linalg.norm(c["H"].T @ c["H"] - G0) / np.linalg.norm(G0) < 1e-12, env
