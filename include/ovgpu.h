@@ -113,6 +113,15 @@ typedef struct {
                              /* 2 never                                      */
   int32_t tsqr_leaf_blocked; /* 1: experimental compact-WY leaf (k_tsqr_blk) */
   int32_t no_timing;         /* 1: no HIP events around the stages           */
+  int32_t no_fast_feature_kernel; /* 1: always the general per-feature       */
+                             /* kernel (k_system) instead of the MSCKF fast  */
+                             /* path (k_feat: gate matrix in registers)      */
+  int32_t _pad1;
+  double prior_pivot_tol;    /* Gram route: a pivot of the prior block's      */
+                             /* Cholesky factorisation below this fraction of */
+                             /* its diagonal entry sends the update through   */
+                             /* the Householder route instead (0 = 1e-13:     */
+                             /* cond(P_DD) beyond ~1e13) */
 } ovgpu_options;
 
 /* Measurement compression (UpdaterHelper.cpp:456-487) of ovgpu_msckf_update / ovgpu_slam_update:           */
@@ -606,6 +615,14 @@ int ovgpu_synchronize(ovgpu_ctx *ctx);
 
 /* hipStream_t of the context, as an integer (for hipEvent timing). */
 uint64_t ovgpu_stream(ovgpu_ctx *ctx);
+
+/* Which route the last ovgpu_msckf_update / ovgpu_slam_update took: OVGPU_COMPRESS_GRAM, or OVGPU_COMPRESS_TSQR when it was
+ * selected or when the prior block failed the pivot test of the Gram route (ovgpu_options::prior_pivot_tol). */
+int ovgpu_last_update_route(ovgpu_ctx *ctx);
+
+/* Developer aid (no reference counterpart): per-phase cycle counters of workgroup 0 of the per-feature kernel.
+ * enable != 0 allocates / clears 512 counters, out512 != NULL reads them back first. */
+int ovgpu_debug_cycles(ovgpu_ctx *ctx, int enable, long long *out512);
 
 /* Time in ms of the measurement compression (all its launches) and of the
  * whole update, averaged over the launches since the last call with

@@ -40,6 +40,7 @@ class Options(C.Structure):
         ("feat_rep_msckf", C.c_int32),
         ("compress_route", C.c_int32), ("gram_no_whiten", C.c_int32), ("no_prior_overlap", C.c_int32), ("tsqr_workers", C.c_int32),
         ("tsqr_no_pipeline", C.c_int32), ("tsqr_overlap", C.c_int32), ("tsqr_leaf_blocked", C.c_int32), ("no_timing", C.c_int32),
+        ("no_fast_feature_kernel", C.c_int32), ("_pad1", C.c_int32), ("prior_pivot_tol", C.c_double),
     ]
 
 
@@ -221,6 +222,8 @@ def declare(lib):
         "ovgpu_msckf_update_async": (C.c_int, [ctxp]),
         "ovgpu_synchronize": (C.c_int, [ctxp]),
         "ovgpu_stream": (C.c_uint64, [ctxp]),
+        "ovgpu_last_update_route": (C.c_int, [ctxp]),
+        "ovgpu_debug_cycles": (C.c_int, [ctxp, C.c_int, C.POINTER(C.c_longlong)]),
         "ovgpu_kernel_times": (C.c_int, [ctxp, C.c_int, c_double_p, c_double_p, C.POINTER(C.c_int64)]),
         "ovgpu_system_time": (C.c_int, [ctxp, c_double_p, C.POINTER(C.c_int64)]),
     }

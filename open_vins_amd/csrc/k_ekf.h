@@ -56,8 +56,9 @@ struct EkfParams {
   double *dx;       // [N]
   int32_t *flags;   // [0] = 1 if S not SPD, [1] = 1 if a diagonal of P' is negative
   double sigma2;
-  const double *diag0 = nullptr; // optional [D]: the matrix's own diagonal before the factorisation; a pivot below 1e-12 of it
+  const double *diag0 = nullptr; // optional [D]: the matrix's own diagonal before the factorisation; a pivot below pivot_tol of it
                                  // counts as not SPD (numerically singular prior block of the Gram-form update)
+  double pivot_tol = 1e-13;
 };
 
 // Mt = R * P(cols, :)     grid: tiles(D/16) x tiles(N/16) wavefronts, 4 per block
@@ -149,7 +150,7 @@ __global__ void __launch_bounds__(256) k_ekf_chol_step(EkfParams p, int kb) {
 #pragma unroll
   for (int k = 0; k < 16; k++) {
     const double dk = ekf_bcast(u[k], k);
-    if ((!(dk > 0.0) || (p.diag0 && k < nb && dk <= 1e-12 * p.diag0[kb + k])) && it < 0 && jt == tb && lane == 0) p.flags[0] = 1;
+    if ((!(dk > 0.0) || (p.diag0 && k < nb && dk <= p.pivot_tol * p.diag0[kb + k])) && it < 0 && jt == tb && lane == 0) p.flags[0] = 1;
     const double d = sqrt(dk), inv = 1.0 / d;
     dinv[k] = inv;
     u[k] = ((lane & 15) == k) ? d : u[k] * inv; // row k of U (lanes j > k); lanes j < k hold zeros there

@@ -165,6 +165,163 @@ __device__ __forceinline__ void gate_chol_panel(double *S, int n, int kb, int nb
   }
 }
 
+// One measurement's two sparse Jacobian rows (UpdaterHelper.cpp:314-421) -> rd, its column / covariance bookkeeping -> mi[8]:
+// camera, clone, first column of the clone / extrinsic / intrinsic blocks (-1: not estimated), their covariance ids.
+// gm = index of the measurement in the batch; hq = the feature's representation scratch ([12..20] dpfg_dlambda, [21..38] H_anc,
+// [39..56] H_calib).  Shared by the general per-feature kernel (k_system) and the MSCKF fast path (k_feat.h).
+__device__ __forceinline__ void sys_measurement_rows(const SysParams &p, int gm, const V3 &p_FinG, const V3 &p_FinG_fej, bool relative, const double *hq,
+                                                     int *mi, double *rd) {
+    const int code = p.meas_cc[gm];
+    const int cam = code >> 10, cl = code & 1023;
+    const int ccol = p.clone_col[cl], pcol = p.calib_col[cam], icol = p.intr_col[cam];
+    mi[0] = cam, mi[1] = cl, mi[2] = ccol, mi[3] = pcol, mi[4] = icol;
+    mi[5] = p.col_cov[ccol];
+    mi[6] = pcol >= 0 ? p.col_cov[pcol] : -1;
+    mi[7] = icol >= 0 ? p.col_cov[icol] : -1;
+
+    const M3 R_ItoC = load_m3(p.tab_cam + 12 * cam);
+    const V3 p_IinC = load_v3(p.tab_cam + 12 * cam + 9);
+    const CamIntr ci = load_cam(p.intr + 8 * cam);
+    const bool fish = p.fisheye[cam] != 0;
+    const double *tc = p.tab_clone + 24 * cl;
+    M3 R_GtoIi = load_m3(tc);
+    V3 p_IiinG = load_v3(tc + 9);
+    V3 p_FinIi = mul(R_GtoIi, p_FinG - p_IiinG);  // :334
+    V3 p_FinCi = mul(R_ItoC, p_FinIi) + p_IinC;   // :337
+    const double un = p_FinCi.x / p_FinCi.z, vn = p_FinCi.y / p_FinCi.z;
+    double ud, vd;
+    if (fish)
+      equi_distort_d(ci, un, vn, ud, vd); // :343 (float round trip, Q2)
+    else
+      radtan_distort_d(ci, un, vn, ud, vd);
+    rd[RO_RES] = (double)p.uv[2 * gm] - ud; // :346-348
+    rd[RO_RES + 1] = (double)p.uv[2 * gm + 1] - vd;
+    if (p.opt.do_fej) { // :354-363  (uv_norm is deliberately NOT recomputed, Q4)
+      R_GtoIi = load_m3(tc + 12);
+      p_IiinG = load_v3(tc + 21);
+      p_FinIi = mul(R_GtoIi, p_FinG_fej - p_IiinG); // p_FinG_fej == p_FinG for MSCKF features (Q5), the landmark's fej for SLAM
+      p_FinCi = mul(R_ItoC, p_FinIi) + p_IinC;
+    }
+    double dzn[4], dze[16];
+    if (fish)
+      equi_jacobian(ci, un, vn, dzn, dze); // :367
+    else
+      radtan_jacobian(ci, un, vn, dzn, dze);
+    const double iz = 1.0 / p_FinCi.z;
+    const double n02 = -p_FinCi.x * iz * iz, n12 = -p_FinCi.y * iz * iz; // :370-371
+    // dz_dpfc = dz_dzn * dzn_dpfc (2x3)
+    const double a00 = dzn[0] * iz, a01 = dzn[1] * iz, a02 = dzn[0] * n02 + dzn[1] * n12;
+    const double a10 = dzn[2] * iz, a11 = dzn[3] * iz, a12 = dzn[2] * n02 + dzn[3] * n12;
+    const M3 dpfc_dpfg = mul(R_ItoC, R_GtoIi); // :374
+    // dz_dpfg = dz_dpfc * dpfc_dpfg
+    const double g00 = a00 * dpfc_dpfg.a00 + a01 * dpfc_dpfg.a10 + a02 * dpfc_dpfg.a20;
+    const double g01 = a00 * dpfc_dpfg.a01 + a01 * dpfc_dpfg.a11 + a02 * dpfc_dpfg.a21;
+    const double g02 = a00 * dpfc_dpfg.a02 + a01 * dpfc_dpfg.a12 + a02 * dpfc_dpfg.a22;
+    const double g10 = a10 * dpfc_dpfg.a00 + a11 * dpfc_dpfg.a10 + a12 * dpfc_dpfg.a20;
+    const double g11 = a10 * dpfc_dpfg.a01 + a11 * dpfc_dpfg.a11 + a12 * dpfc_dpfg.a21;
+    const double g12 = a10 * dpfc_dpfg.a02 + a11 * dpfc_dpfg.a12 + a12 * dpfc_dpfg.a22;
+    // H_f = dz_dpfg * dpfg_dlambda (:389)
+    const double *dl = hq + 12;
+    rd[RO_HF + 0] = g00 * dl[0] + g01 * dl[3] + g02 * dl[6];
+    rd[RO_HF + 1] = g00 * dl[1] + g01 * dl[4] + g02 * dl[7];
+    rd[RO_HF + 2] = g00 * dl[2] + g01 * dl[5] + g02 * dl[8];
+    rd[RO_HF + 3] = g10 * dl[0] + g11 * dl[3] + g12 * dl[6];
+    rd[RO_HF + 4] = g10 * dl[1] + g11 * dl[4] + g12 * dl[7];
+    rd[RO_HF + 5] = g10 * dl[2] + g11 * dl[5] + g12 * dl[8];
+    // clone block = dz_dpfc * [R_ItoC skew(p_FinIi), -dpfc_dpfg]  (:377-392)
+    const M3 Rsk = mul(R_ItoC, skew_x(p_FinIi));
+    rd[RO_CLONE + 0] = a00 * Rsk.a00 + a01 * Rsk.a10 + a02 * Rsk.a20;
+    rd[RO_CLONE + 1] = a00 * Rsk.a01 + a01 * Rsk.a11 + a02 * Rsk.a21;
+    rd[RO_CLONE + 2] = a00 * Rsk.a02 + a01 * Rsk.a12 + a02 * Rsk.a22;
+    rd[RO_CLONE + 3] = -g00, rd[RO_CLONE + 4] = -g01, rd[RO_CLONE + 5] = -g02;
+    rd[RO_CLONE + 6] = a10 * Rsk.a00 + a11 * Rsk.a10 + a12 * Rsk.a20;
+    rd[RO_CLONE + 7] = a10 * Rsk.a01 + a11 * Rsk.a11 + a12 * Rsk.a21;
+    rd[RO_CLONE + 8] = a10 * Rsk.a02 + a11 * Rsk.a12 + a12 * Rsk.a22;
+    rd[RO_CLONE + 9] = -g10, rd[RO_CLONE + 10] = -g11, rd[RO_CLONE + 11] = -g12;
+    // extrinsics: dz_dpfc * [skew(p_FinCi - p_IinC), I]  (:404-413)
+    {
+      const M3 sk = skew_x(p_FinCi - p_IinC);
+      rd[RO_CPOSE + 0] = a00 * sk.a00 + a01 * sk.a10 + a02 * sk.a20;
+      rd[RO_CPOSE + 1] = a00 * sk.a01 + a01 * sk.a11 + a02 * sk.a21;
+      rd[RO_CPOSE + 2] = a00 * sk.a02 + a01 * sk.a12 + a02 * sk.a22;
+      rd[RO_CPOSE + 3] = a00, rd[RO_CPOSE + 4] = a01, rd[RO_CPOSE + 5] = a02;
+      rd[RO_CPOSE + 6] = a10 * sk.a00 + a11 * sk.a10 + a12 * sk.a20;
+      rd[RO_CPOSE + 7] = a10 * sk.a01 + a11 * sk.a11 + a12 * sk.a21;
+      rd[RO_CPOSE + 8] = a10 * sk.a02 + a11 * sk.a12 + a12 * sk.a22;
+      rd[RO_CPOSE + 9] = a10, rd[RO_CPOSE + 10] = a11, rd[RO_CPOSE + 11] = a12;
+    }
+    // intrinsics (:416-418)
+#pragma unroll
+    for (int s = 0; s < 16; s++) rd[RO_CINTR + s] = dze[s];
+    if (relative) { // representation extras (:396-398): dz_dpfg * H_anc, dz_dpfg * H_calib
+      const double *Ha = hq + 21, *Hc = hq + 39;
+#pragma unroll
+      for (int s = 0; s < 6; s++) {
+        rd[RO_ANC + s] = g00 * Ha[s] + g01 * Ha[6 + s] + g02 * Ha[12 + s];
+        rd[RO_ANC + 6 + s] = g10 * Ha[s] + g11 * Ha[6 + s] + g12 * Ha[12 + s];
+        rd[RO_ACAL + s] = g00 * Hc[s] + g01 * Hc[6 + s] + g02 * Hc[12 + s];
+        rd[RO_ACAL + 6 + s] = g10 * Hc[s] + g11 * Hc[6 + s] + g12 * Hc[12 + s];
+      }
+    }
+}
+
+// Householder QR of H_f (2m x 3, stored in the row store) by ONE wavefront -> V (n x 3, unit lower trapezoidal), hq[0..2] = tau,
+// hq[3..8] = T of the compact WY form Q = I - V T V^T, hq[58..60] = diag(R1)   (role of UpdaterHelper.cpp:426-454).
+// Only the first nproj columns are reflected (a column that stays is a Jacobian column of the output stage).
+__device__ __forceinline__ void sys_hf_householder(double *rows, int RS, double *V, double *hq, int n, int nproj, int lane) {
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    // column k, rows k..n-1 (H_f element (row, k) lives at rows[(row>>1)*RS + 3*(row&1) + k])
+    double sig = 0.0;
+    for (int r = k + 1 + lane; r < n; r += 64) {
+      const double x = rows[(size_t)(r >> 1) * RS + RO_HF + 3 * (r & 1) + k];
+      sig = fma(x, x, sig);
+    }
+    sig = wave_sum(sig);
+    const double alpha = rows[(size_t)(k >> 1) * RS + RO_HF + 3 * (k & 1) + k];
+    double beta = alpha, tau = 0.0, scale = 0.0;
+    if (sig > 2.2250738585072014e-308 && k < nproj) { // a column that stays (the depth of a single-depth landmark): H_k = I
+      beta = sqrt(alpha * alpha + sig);
+      if (alpha >= 0.0) beta = -beta;
+      scale = 1.0 / (alpha - beta);
+      tau = (beta - alpha) / beta;
+    }
+    // v_k
+    for (int r = lane; r < n; r += 64) {
+      double v = 0.0;
+      if (r == k) v = 1.0;
+      else if (r > k) v = rows[(size_t)(r >> 1) * RS + RO_HF + 3 * (r & 1) + k] * scale;
+      V[(size_t)r * 3 + k] = v;
+    }
+    if (lane == 0) hq[k] = tau, hq[58 + k] = beta; // beta_k = R1[k][k]
+    // apply H_k to the remaining PROJECTED columns of H_f (a column that stays is a Jacobian column of the output stage: untouched here)
+    for (int c = k + 1; c < nproj; c++) {
+      double w = 0.0;
+      for (int r = k + lane; r < n; r += 64) w = fma(V[(size_t)r * 3 + k], rows[(size_t)(r >> 1) * RS + RO_HF + 3 * (r & 1) + c], w);
+      w = wave_sum(w) * tau;
+      for (int r = k + lane; r < n; r += 64) {
+        double *x = &rows[(size_t)(r >> 1) * RS + RO_HF + 3 * (r & 1) + c];
+        *x = fma(-w, V[(size_t)r * 3 + k], *x);
+      }
+    }
+  }
+  // T of the compact WY form Q = I - V T V^T (forward, column-wise)
+  double v01 = 0, v02 = 0, v12 = 0;
+  for (int r = lane; r < n; r += 64) {
+    const double a = V[(size_t)r * 3], b = V[(size_t)r * 3 + 1], c = V[(size_t)r * 3 + 2];
+    v01 = fma(a, b, v01), v02 = fma(a, c, v02), v12 = fma(b, c, v12);
+  }
+  v01 = wave_sum(v01), v02 = wave_sum(v02), v12 = wave_sum(v12);
+  if (lane == 0) {
+    const double t0 = hq[0], t1 = hq[1], t2 = hq[2];
+    const double T00 = t0, T11 = t1, T22 = t2;
+    const double T01 = -t1 * (T00 * v01);
+    const double T02 = -t2 * (T00 * v02 + T01 * v12);
+    const double T12 = -t2 * (T11 * v12);
+    hq[3] = T00, hq[4] = T01, hq[5] = T02, hq[6] = T11, hq[7] = T12, hq[8] = T22;
+  }
+}
+
 __global__ void __launch_bounds__(SYS_NT) k_system(SysParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
@@ -254,102 +411,7 @@ __global__ void __launch_bounds__(SYS_NT) k_system(SysParams p) {
     SYS_T(1)
     // (a) per-measurement sparse Jacobian rows — UpdaterHelper.cpp:314-421
     // ------------------------------------------------------------------
-    for (int i = tid; i < m; i += SYS_NT) {
-      const int code = p.meas_cc[m0 + i];
-      const int cam = code >> 10, cl = code & 1023;
-      int *mi = minfo + 8 * i;
-      const int ccol = p.clone_col[cl], pcol = p.calib_col[cam], icol = p.intr_col[cam];
-      mi[0] = cam, mi[1] = cl, mi[2] = ccol, mi[3] = pcol, mi[4] = icol;
-      mi[5] = p.col_cov[ccol];
-      mi[6] = pcol >= 0 ? p.col_cov[pcol] : -1;
-      mi[7] = icol >= 0 ? p.col_cov[icol] : -1;
-      double *rd = rows + (size_t)i * RS;
-
-      const M3 R_ItoC = load_m3(p.tab_cam + 12 * cam);
-      const V3 p_IinC = load_v3(p.tab_cam + 12 * cam + 9);
-      const CamIntr ci = load_cam(p.intr + 8 * cam);
-      const bool fish = p.fisheye[cam] != 0;
-      const double *tc = p.tab_clone + 24 * cl;
-      M3 R_GtoIi = load_m3(tc);
-      V3 p_IiinG = load_v3(tc + 9);
-      V3 p_FinIi = mul(R_GtoIi, p_FinG - p_IiinG);  // :334
-      V3 p_FinCi = mul(R_ItoC, p_FinIi) + p_IinC;   // :337
-      const double un = p_FinCi.x / p_FinCi.z, vn = p_FinCi.y / p_FinCi.z;
-      double ud, vd;
-      if (fish)
-        equi_distort_d(ci, un, vn, ud, vd); // :343 (float round trip, Q2)
-      else
-        radtan_distort_d(ci, un, vn, ud, vd);
-      rd[RO_RES] = (double)p.uv[2 * (m0 + i)] - ud; // :346-348
-      rd[RO_RES + 1] = (double)p.uv[2 * (m0 + i) + 1] - vd;
-      if (p.opt.do_fej) { // :354-363  (uv_norm is deliberately NOT recomputed, Q4)
-        R_GtoIi = load_m3(tc + 12);
-        p_IiinG = load_v3(tc + 21);
-        p_FinIi = mul(R_GtoIi, p_FinG_fej - p_IiinG); // p_FinG_fej == p_FinG for MSCKF features (Q5), the landmark's fej for SLAM
-        p_FinCi = mul(R_ItoC, p_FinIi) + p_IinC;
-      }
-      double dzn[4], dze[16];
-      if (fish)
-        equi_jacobian(ci, un, vn, dzn, dze); // :367
-      else
-        radtan_jacobian(ci, un, vn, dzn, dze);
-      const double iz = 1.0 / p_FinCi.z;
-      const double n02 = -p_FinCi.x * iz * iz, n12 = -p_FinCi.y * iz * iz; // :370-371
-      // dz_dpfc = dz_dzn * dzn_dpfc (2x3)
-      const double a00 = dzn[0] * iz, a01 = dzn[1] * iz, a02 = dzn[0] * n02 + dzn[1] * n12;
-      const double a10 = dzn[2] * iz, a11 = dzn[3] * iz, a12 = dzn[2] * n02 + dzn[3] * n12;
-      const M3 dpfc_dpfg = mul(R_ItoC, R_GtoIi); // :374
-      // dz_dpfg = dz_dpfc * dpfc_dpfg
-      const double g00 = a00 * dpfc_dpfg.a00 + a01 * dpfc_dpfg.a10 + a02 * dpfc_dpfg.a20;
-      const double g01 = a00 * dpfc_dpfg.a01 + a01 * dpfc_dpfg.a11 + a02 * dpfc_dpfg.a21;
-      const double g02 = a00 * dpfc_dpfg.a02 + a01 * dpfc_dpfg.a12 + a02 * dpfc_dpfg.a22;
-      const double g10 = a10 * dpfc_dpfg.a00 + a11 * dpfc_dpfg.a10 + a12 * dpfc_dpfg.a20;
-      const double g11 = a10 * dpfc_dpfg.a01 + a11 * dpfc_dpfg.a11 + a12 * dpfc_dpfg.a21;
-      const double g12 = a10 * dpfc_dpfg.a02 + a11 * dpfc_dpfg.a12 + a12 * dpfc_dpfg.a22;
-      // H_f = dz_dpfg * dpfg_dlambda (:389)
-      const double *dl = hq + 12;
-      rd[RO_HF + 0] = g00 * dl[0] + g01 * dl[3] + g02 * dl[6];
-      rd[RO_HF + 1] = g00 * dl[1] + g01 * dl[4] + g02 * dl[7];
-      rd[RO_HF + 2] = g00 * dl[2] + g01 * dl[5] + g02 * dl[8];
-      rd[RO_HF + 3] = g10 * dl[0] + g11 * dl[3] + g12 * dl[6];
-      rd[RO_HF + 4] = g10 * dl[1] + g11 * dl[4] + g12 * dl[7];
-      rd[RO_HF + 5] = g10 * dl[2] + g11 * dl[5] + g12 * dl[8];
-      // clone block = dz_dpfc * [R_ItoC skew(p_FinIi), -dpfc_dpfg]  (:377-392)
-      const M3 Rsk = mul(R_ItoC, skew_x(p_FinIi));
-      rd[RO_CLONE + 0] = a00 * Rsk.a00 + a01 * Rsk.a10 + a02 * Rsk.a20;
-      rd[RO_CLONE + 1] = a00 * Rsk.a01 + a01 * Rsk.a11 + a02 * Rsk.a21;
-      rd[RO_CLONE + 2] = a00 * Rsk.a02 + a01 * Rsk.a12 + a02 * Rsk.a22;
-      rd[RO_CLONE + 3] = -g00, rd[RO_CLONE + 4] = -g01, rd[RO_CLONE + 5] = -g02;
-      rd[RO_CLONE + 6] = a10 * Rsk.a00 + a11 * Rsk.a10 + a12 * Rsk.a20;
-      rd[RO_CLONE + 7] = a10 * Rsk.a01 + a11 * Rsk.a11 + a12 * Rsk.a21;
-      rd[RO_CLONE + 8] = a10 * Rsk.a02 + a11 * Rsk.a12 + a12 * Rsk.a22;
-      rd[RO_CLONE + 9] = -g10, rd[RO_CLONE + 10] = -g11, rd[RO_CLONE + 11] = -g12;
-      // extrinsics: dz_dpfc * [skew(p_FinCi - p_IinC), I]  (:404-413)
-      {
-        const M3 sk = skew_x(p_FinCi - p_IinC);
-        rd[RO_CPOSE + 0] = a00 * sk.a00 + a01 * sk.a10 + a02 * sk.a20;
-        rd[RO_CPOSE + 1] = a00 * sk.a01 + a01 * sk.a11 + a02 * sk.a21;
-        rd[RO_CPOSE + 2] = a00 * sk.a02 + a01 * sk.a12 + a02 * sk.a22;
-        rd[RO_CPOSE + 3] = a00, rd[RO_CPOSE + 4] = a01, rd[RO_CPOSE + 5] = a02;
-        rd[RO_CPOSE + 6] = a10 * sk.a00 + a11 * sk.a10 + a12 * sk.a20;
-        rd[RO_CPOSE + 7] = a10 * sk.a01 + a11 * sk.a11 + a12 * sk.a21;
-        rd[RO_CPOSE + 8] = a10 * sk.a02 + a11 * sk.a12 + a12 * sk.a22;
-        rd[RO_CPOSE + 9] = a10, rd[RO_CPOSE + 10] = a11, rd[RO_CPOSE + 11] = a12;
-      }
-      // intrinsics (:416-418)
-#pragma unroll
-      for (int s = 0; s < 16; s++) rd[RO_CINTR + s] = dze[s];
-      if (relative) { // representation extras (:396-398): dz_dpfg * H_anc, dz_dpfg * H_calib
-        const double *Ha = hq + 21, *Hc = hq + 39;
-#pragma unroll
-        for (int s = 0; s < 6; s++) {
-          rd[RO_ANC + s] = g00 * Ha[s] + g01 * Ha[6 + s] + g02 * Ha[12 + s];
-          rd[RO_ANC + 6 + s] = g10 * Ha[s] + g11 * Ha[6 + s] + g12 * Ha[12 + s];
-          rd[RO_ACAL + s] = g00 * Hc[s] + g01 * Hc[6 + s] + g02 * Hc[12 + s];
-          rd[RO_ACAL + 6 + s] = g10 * Hc[s] + g11 * Hc[6 + s] + g12 * Hc[12 + s];
-        }
-      }
-    }
+    for (int i = tid; i < m; i += SYS_NT) sys_measurement_rows(p, m0 + i, p_FinG, p_FinG_fej, relative, hq, minfo + 8 * i, rows + (size_t)i * RS);
     __syncthreads();
 
     const int anc_ccol = relative ? p.clone_col[anchor_clone] : -1;
@@ -605,60 +667,7 @@ __global__ void __launch_bounds__(SYS_NT) k_system(SysParams p) {
     SYS_T(6)
     // (b) Householder QR of H_f (2m x 3) -> V, tau, T   (role of UpdaterHelper.cpp:426-454)
     // ------------------------------------------------------------------
-    if (nproj > 0 && tid < 64) {
-      const int lane = tid;
-#pragma unroll
-      for (int k = 0; k < 3; k++) {
-        // column k, rows k..n-1 (H_f element (row, k) lives at rows[(row>>1)*RS + 3*(row&1) + k])
-        double sig = 0.0;
-        for (int r = k + 1 + lane; r < n; r += 64) {
-          const double x = rows[(size_t)(r >> 1) * RS + RO_HF + 3 * (r & 1) + k];
-          sig = fma(x, x, sig);
-        }
-        sig = wave_sum(sig);
-        const double alpha = rows[(size_t)(k >> 1) * RS + RO_HF + 3 * (k & 1) + k];
-        double beta = alpha, tau = 0.0, scale = 0.0;
-        if (sig > 2.2250738585072014e-308 && k < nproj) { // a column that stays (the depth of a single-depth landmark): H_k = I
-          beta = sqrt(alpha * alpha + sig);
-          if (alpha >= 0.0) beta = -beta;
-          scale = 1.0 / (alpha - beta);
-          tau = (beta - alpha) / beta;
-        }
-        // v_k
-        for (int r = lane; r < n; r += 64) {
-          double v = 0.0;
-          if (r == k) v = 1.0;
-          else if (r > k) v = rows[(size_t)(r >> 1) * RS + RO_HF + 3 * (r & 1) + k] * scale;
-          V[(size_t)r * 3 + k] = v;
-        }
-        if (lane == 0) hq[k] = tau, hq[58 + k] = beta; // beta_k = R1[k][k]
-        // apply H_k to the remaining PROJECTED columns of H_f (a column that stays is a Jacobian column of the output stage: untouched here)
-        for (int c = k + 1; c < nproj; c++) {
-          double w = 0.0;
-          for (int r = k + lane; r < n; r += 64) w = fma(V[(size_t)r * 3 + k], rows[(size_t)(r >> 1) * RS + RO_HF + 3 * (r & 1) + c], w);
-          w = wave_sum(w) * tau;
-          for (int r = k + lane; r < n; r += 64) {
-            double *x = &rows[(size_t)(r >> 1) * RS + RO_HF + 3 * (r & 1) + c];
-            *x = fma(-w, V[(size_t)r * 3 + k], *x);
-          }
-        }
-      }
-      // T of the compact WY form Q = I - V T V^T (forward, column-wise)
-      double v01 = 0, v02 = 0, v12 = 0;
-      for (int r = lane; r < n; r += 64) {
-        const double a = V[(size_t)r * 3], b = V[(size_t)r * 3 + 1], c = V[(size_t)r * 3 + 2];
-        v01 = fma(a, b, v01), v02 = fma(a, c, v02), v12 = fma(b, c, v12);
-      }
-      v01 = wave_sum(v01), v02 = wave_sum(v02), v12 = wave_sum(v12);
-      if (lane == 0) {
-        const double t0 = hq[0], t1 = hq[1], t2 = hq[2];
-        const double T00 = t0, T11 = t1, T22 = t2;
-        const double T01 = -t1 * (T00 * v01);
-        const double T02 = -t2 * (T00 * v02 + T01 * v12);
-        const double T12 = -t2 * (T11 * v12);
-        hq[3] = T00, hq[4] = T01, hq[5] = T02, hq[6] = T11, hq[7] = T12, hq[8] = T22;
-      }
-    }
+    if (nproj > 0 && tid < 64) sys_hf_householder(rows, RS, V, hq, n, nproj, tid);
     __syncthreads();
 
     // ------------------------------------------------------------------

@@ -25,6 +25,7 @@
 #include "k_gram.h"
 #include <unordered_map>
 #include "k_system.h"
+#include "k_feat.h"
 #include "k_triangulate.h"
 #include "ovgpu_types.h"
 
@@ -174,9 +175,18 @@ struct ovgpu_ctx {
   //   2 cholqr  R = chol(Gram) + dx refinement for tall stacks (kept as the measured negative result of DESIGN.md section 4)
   int compress_gram = 1;
   DevBuf<double> gram_part, gram_G, gram_rho, Yaug2, Lw; // Lw: L = U1^T of the prior block (k_tf_lt), read by the per-feature kernel
+  double prior_pivot_tol = 1e-13; // options.prior_pivot_tol
+  int last_route = OVGPU_COMPRESS_GRAM; // route of the last update (ovgpu_last_update_route)
   bool whiten = true;           // options.gram_no_whiten == 0: the stack is whitened by the prior BEFORE its Gram matrix is formed
   bool gram_is_whitened = false; // c->gram_G / the Gram buffer handed out by the last local stage is the whitened stack's
   bool prior_on_side = false;   // the pending prior-block factorisation runs on stream2 (ev_join marks its end)
+  int feat_variant = 0;         // MSCKF fast path of the per-feature stage (k_feat.h) for this batch: 0 none, 1 <4,11>, 2 <8,17>
+  int feat_nt_max = 0, feat_grid = 0;
+  size_t feat_lds = 0;
+  bool no_feat_kernel = false;  // options.no_fast_feature_kernel
+  DevBuf<int32_t> feat_counter, fs_minfo, fs_meas_feat; // fs_*: the row store of the fast path (feat::FeatStore)
+  DevBuf<double> fs_rows, fs_V, fs_z;
+  DevBuf<long long> dbg_cycles; // ovgpu_debug_cycles: per-phase cycle counters of workgroup 0 of the per-feature kernel
   int tsqr_workers = 0;         // options.tsqr_workers
   bool leaf_blocked = false;    // options.tsqr_leaf_blocked
   bool async_pending = false;     // ovgpu_msckf_update_async since the last ovgpu_synchronize
@@ -376,8 +386,10 @@ int ovgpu_create(const ovgpu_options *opts, int device, ovgpu_ctx **out) {
   c->compress_gram = opts->compress_route == OVGPU_COMPRESS_TSQR ? 0 : (opts->compress_route == OVGPU_COMPRESS_CHOLQR ? 2 : 1);
   c->tree_overlap = opts->tsqr_overlap == 0 ? -1 : (opts->tsqr_overlap == 1 ? 1 : 0);
   c->whiten = opts->gram_no_whiten == 0;
+  c->prior_pivot_tol = opts->prior_pivot_tol > 0.0 ? opts->prior_pivot_tol : 1e-13;
   c->tsqr_workers = opts->tsqr_workers;
   c->leaf_blocked = opts->tsqr_leaf_blocked != 0;
+  c->no_feat_kernel = opts->no_fast_feature_kernel != 0;
   if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess)
     c->tree_overlap = 0;
@@ -419,7 +431,8 @@ void ovgpu_destroy(ovgpu_ctx *c) {
   c->trk_count.release(), c->trk_cam.release(), c->trk_slot_in.release(), c->trk_cam_in.release(), c->trk_sel.release(), c->trk_nvalid.release(), c->trk_flag.release();
   c->trk_time.release(), c->trk_clone_times.release(), c->trk_uv.release(), c->trk_uvn.release(), c->trk_uv_in.release(), c->trk_uvn_in.release();
   c->dx.release(), c->flags.release(), c->given_status.release();
-  c->gram_part.release(), c->gram_G.release(), c->gram_rho.release(), c->Yaug2.release(), c->gram_dropped.release(), c->rows_used.release(), c->Lw.release();
+  c->gram_part.release(), c->gram_G.release(), c->gram_rho.release(), c->Yaug2.release(), c->gram_dropped.release(), c->rows_used.release(), c->Lw.release(), c->feat_counter.release(), c->dbg_cycles.release();
+  c->fs_minfo.release(), c->fs_meas_feat.release(), c->fs_rows.release(), c->fs_V.release(), c->fs_z.release();
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
@@ -653,6 +666,35 @@ static int set_row_layout(ovgpu_ctx *c, bool slam_rows) {
   } else {
     c->gate_ws_stride = 0;
   }
+  // ---- MSCKF fast path (k_feat.h): gate matrix in registers, several workgroups per CU
+  c->feat_variant = 0;
+  if (!slam_rows && !c->no_feat_kernel && c->dopt.feat_rep < OVGPU_REP_ANCHORED_3D && c->L == 0 && m_max >= 2 && c->K * c->C <= 8192 && c->D >= 16) {
+    const int nt = (2 * m_max + 15) / 16, tiles = nt * (nt + 1) / 2 + nt;
+    // 1: <4 wavefronts, 11 tiles each>, two workgroups per CU; 2: <8, 17>, one per CU
+    const int variant = tiles <= 4 * 11 ? 1 : (tiles <= 8 * 17 ? 2 : 0);
+    if (variant) {
+      const feat::FeatLds lo = feat::feat_lds_layout(m_max, c->row_stride, c->D, c->LD, c->K * c->C, nt);
+      if (lo.total <= (size_t)c->lds_limit) {
+        const int per_cu = std::max(1, std::min(variant == 1 ? 2 : 1, (int)((size_t)c->lds_limit / lo.total)));
+        c->feat_variant = variant, c->feat_nt_max = nt, c->feat_lds = lo.total;
+        c->feat_grid = std::max(1, std::min(F, c->num_cu * per_cu));
+        if (feat::feat_qr_lds_per_wave(m_max, c->LD, c->K * c->C) * 4 > (size_t)c->lds_limit) c->feat_variant = 0;
+      }
+    }
+  }
+  if (c->feat_variant) { // row store of the fast path
+    const int M = std::max(c->M, 1);
+    HIPCHK(c->fs_rows.reserve((size_t)M * c->row_stride));
+    HIPCHK(c->fs_minfo.reserve((size_t)M * 8));
+    HIPCHK(c->fs_V.reserve((size_t)M * 6));
+    HIPCHK(c->fs_z.reserve((size_t)std::max(F, 1) * 3 * c->LD));
+    HIPCHK(c->fs_meas_feat.reserve(M));
+    std::vector<int32_t> mf(M, 0);
+    for (int f = 0; f < F; f++)
+      for (int i = c->h_offsets[f]; i < c->h_offsets[f + 1]; i++) mf[i] = f;
+    HIPCHK(upload(c->fs_meas_feat.p, mf.data(), sizeof(int32_t) * c->M, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+  }
   // ---- stacked system and TSQR accumulators
   const int rct = configure_tsqr(c);
   if (rct != OVGPU_OK) return rct;
@@ -777,7 +819,7 @@ static int enqueue_system(ovgpu_ctx *c, int f_one = -1, int init_rep = 0, bool w
   p.row_off = c->row_off.p, p.Hbig = c->Hbig.p, p.ws = c->gate_ws.p, p.ws_stride = c->gate_ws_stride;
   p.m_lds_max = c->m_lds_max, p.m_max = std::max(c->m_max, 1), p.row_stride = c->row_stride;
   p.opt = c->dopt;
-  p.dbg = qr_dbg_buffer();
+  p.dbg = c->dbg_cycles.p ? c->dbg_cycles.p : qr_dbg_buffer();
   p.slam = c->slam_rows ? 1 : 0;
   p.p_fej = c->pFej.p, p.feat_lm = c->feat_lm.p, p.feat_lmcol = c->feat_lmcol.p, p.feat_lmcov = c->feat_lmcov.p, p.feat_anchor = c->feat_anchor.p;
   p.lm_size = 3, p.init_dof_less = 0;
@@ -799,6 +841,28 @@ static int enqueue_system(ovgpu_ctx *c, int f_one = -1, int init_rep = 0, bool w
     p.opt.feat_rep = init_rep == OVGPU_REP_ANCHORED_INVERSE_DEPTH_SINGLE ? OVGPU_REP_ANCHORED_MSCKF_INVERSE_DEPTH : init_rep; // UpdaterSLAM.cpp:151-155
     p.init_dof_less = init_rep == OVGPU_REP_ANCHORED_INVERSE_DEPTH_SINGLE ? 2 : 0;
     grid = 1;
+  }
+  // the MSCKF fast path: whitened output, global representation, one noise level (k_feat.h)
+  if (p.Lw && c->feat_variant && !p.slam && !p.feat_sigma && !p.feat_chi2mult) {
+    HIPCHK(c->feat_counter.reserve(1));
+    HIPCHK(hipMemsetAsync(c->feat_counter.p, 0, sizeof(int32_t), c->stream));
+    p.work_counter = c->feat_counter.p;
+    static bool attr_done = false;
+    if (!attr_done) {
+      (void)hipFuncSetAttribute((const void *)feat::k_feat<4, 11, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_limit);
+      (void)hipFuncSetAttribute((const void *)feat::k_feat<8, 17, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_limit);
+      (void)hipFuncSetAttribute((const void *)feat::k_feat_qr, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_limit);
+      attr_done = true;
+    }
+    feat::FeatStore st{c->fs_rows.p, c->fs_minfo.p, c->fs_V.p, c->fs_z.p, c->fs_meas_feat.p};
+    hipLaunchKernelGGL(feat::k_feat_rows, dim3((c->M + 255) / 256), dim3(256), 0, c->stream, p, st, c->M);
+    hipLaunchKernelGGL(feat::k_feat_qr, dim3((c->F + 3) / 4), dim3(256), 4 * feat::feat_qr_lds_per_wave(p.m_max, c->LD, c->K * c->C), c->stream, p, st);
+    const double *sr = st.rows, *sV = st.V, *sz = st.z;
+    const int32_t *sm = st.minfo;
+    if (c->feat_variant == 1) hipLaunchKernelGGL((feat::k_feat<4, 11, 2>), dim3(c->feat_grid), dim3(256), c->feat_lds, c->stream, p, c->feat_nt_max, sr, sm, sV, sz);
+    else hipLaunchKernelGGL((feat::k_feat<8, 17, 2>), dim3(c->feat_grid), dim3(512), c->feat_lds, c->stream, p, c->feat_nt_max, sr, sm, sV, sz);
+    HIPCHK(hipGetLastError());
+    return OVGPU_OK;
   }
   hipLaunchKernelGGL(k_system, dim3(grid), dim3(SYS_NT), c->sys_lds_bytes, c->stream, p);
   HIPCHK(hipGetLastError());
@@ -1079,7 +1143,7 @@ static int enqueue_ekf_gram(ovgpu_ctx *c, int part, bool side = false) {
     }
     const int64_t elems = (int64_t)D * LA;
     hipLaunchKernelGGL(k_tf_gather, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, sp, t);
-    p.diag0 = c->gram_rho.p;
+    p.diag0 = c->gram_rho.p, p.pivot_tol = c->prior_pivot_tol;
     if ((rc = enqueue_chol_carry(c, p, sp)) != OVGPU_OK) return rc; // Y1 = [U1 | B | 0] in c->Yaug
     p.diag0 = nullptr;
     hipLaunchKernelGGL(k_tf_lt, dim3((unsigned)((D * D + 255) / 256)), dim3(256), 0, sp, t);
@@ -1188,6 +1252,7 @@ static int enqueue_pipeline(ovgpu_ctx *c, int stages, bool slam = false, bool fa
   }
   if (stages & STAGE_EKF) {
     if ((rc = tform ? enqueue_ekf_gram(c, 2) : enqueue_ekf(c)) != OVGPU_OK) return rc;
+    c->last_route = tform ? OVGPU_COMPRESS_GRAM : OVGPU_COMPRESS_TSQR;
   }
   if (eu) HIPCHK(hipEventRecord(eu->b, c->stream));
   return OVGPU_OK;
@@ -2420,6 +2485,24 @@ int ovgpu_synchronize(ovgpu_ctx *c) {
   }
   return check_tree_error(c);
 }
+
+// Developer aid: enable != 0 allocates and clears 512 cycle counters that workgroup 0 of the per-feature kernel accumulates
+// (k_feat: slots 200..210 = its phases); out512 != NULL reads them back.
+int ovgpu_debug_cycles(ovgpu_ctx *c, int enable, long long *out512) {
+  if (!c) return set_err(OVGPU_ERR_INVALID, "null ctx");
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (out512 && c->dbg_cycles.p) HIPCHK(hipMemcpy(out512, c->dbg_cycles.p, 512 * sizeof(long long), hipMemcpyDeviceToHost));
+  if (enable) {
+    HIPCHK(c->dbg_cycles.reserve(512));
+    HIPCHK(hipMemset(c->dbg_cycles.p, 0, 512 * sizeof(long long)));
+  } else if (!out512) {
+    c->dbg_cycles.release();
+  }
+  return OVGPU_OK;
+}
+
+int ovgpu_last_update_route(ovgpu_ctx *c) { return c ? c->last_route : -1; }
 
 uint64_t ovgpu_stream(ovgpu_ctx *c) { return c ? (uint64_t)(uintptr_t)c->stream : 0; }
 

@@ -85,6 +85,7 @@ struct SysParams {
   int32_t *rows_used; // optional counter: rows of the stack that belong to accepted features
   const double *Lw;   // [D x D] row-major, lower triangular with explicit zeros above the diagonal: L = U1^T, P_DD = L L^T (k_ekf.h).
                       // Non-null: the rows leave the kernel whitened by the prior, Q^T [H_x L | res] (the Gram route)
+  int32_t *work_counter; // k_feat: next feature slot to hand out (zeroed before the launch)
   DevOptions opt;
 };
 

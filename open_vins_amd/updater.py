@@ -113,6 +113,7 @@ class UpdaterMSCKF:
         if check:
             capi.check(rc, "ovgpu_msckf_update")
         out["stats"] = stats.as_dict()
+        out["route"] = self.lib.ovgpu_last_update_route(self._ctx)  # capi.COMPRESS_GRAM / COMPRESS_TSQR (chosen, or the fallback)
         out.update(self.get_state(P=False))
         return out
 

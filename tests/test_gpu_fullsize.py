@@ -134,6 +134,10 @@ GATE_OPEN = 1e12
 
 @pytest.mark.parametrize("kw", SWEEP)
 def test_prior_conditioning_sweep(Updater, oracle, kw):
+    """Every prior of the sweep through (i) the default options — the Gram route while the prior block's Cholesky pivots stay above
+    1e-13 of their diagonal entries, the Householder route beyond — and (ii) the Gram route FORCED (pivot tolerance 1e-300), which is
+    how the switch-over point was measured: whitened before the Gram accumulation, the route holds the tolerance over the whole
+    sweep, cond(P_DD) = 3e16 included, so the switch is a safety margin and not an accuracy cliff."""
     prob = synth.make_problem(2, F=300)
     prob.P = synth.realistic_prior(prob, **kw)
     opts = capi.default_options(chi2_multipler=GATE_OPEN)
@@ -146,21 +150,26 @@ def test_prior_conditioning_sweep(Updater, oracle, kw):
     cond = ev[-1] / max(ev[0], 1e-300)
     P_true, dx_true = extended_precision_update(prob.P, cols, ref["H_comp"], ref["r_comp"], opts.sigma_pix ** 2)
     e_ref = (_rel(ref["P"].astype(LD), P_true), _rel(ref["dx"].astype(LD), dx_true))
-    up = Updater(opts)
-    up.set_problem(prob)
-    up.set_triangulation(tri["p_FinG"], tri["p_FinA"], tri["anchor_meas"], tri["status"])
-    out = up.update()
-    up.close()
-    assert out["stats"]["status"] == 0
-    assert np.array_equal(out["feat_status"], ref["feat_status"]) and ref["stats"]["n_used"] > 250
+    assert ref["stats"]["n_used"] > 250
     gate = np.isfinite(ref["chi2"])
-    np.testing.assert_allclose(out["chi2"][gate], ref["chi2"][gate], rtol=1e-7)
-    e_gpu = (_rel(out["P"].astype(LD), P_true), _rel(out["dx"].astype(LD), dx_true))
-    print(f"cond(P_DD) {cond:.1e}: |dP|/|P| gpu {e_gpu[0]:.1e} oracle {e_ref[0]:.1e}; |ddx|/|dx| gpu {e_gpu[1]:.1e} oracle {e_ref[1]:.1e}; "
-          f"gpu vs oracle P {_rel(out['P'], ref['P']):.1e} dx {_rel(out['dx'], ref['dx']):.1e}")
-    assert e_gpu[0] < max(1e-9, 5 * e_ref[0]), (cond, e_gpu, e_ref)
-    assert e_gpu[1] < max(1e-8, 10 * e_ref[1]), (cond, e_gpu, e_ref)
-    assert np.array_equal(out["P"], out["P"].T) and np.linalg.eigvalsh(out["P"]).min() > -1e-9 * np.abs(np.diag(out["P"])).max()
+    for forced in (False, True):
+        up = Updater(capi.default_options(chi2_multipler=GATE_OPEN, prior_pivot_tol=1e-300 if forced else 0.0))
+        up.set_problem(prob)
+        up.set_triangulation(tri["p_FinG"], tri["p_FinA"], tri["anchor_meas"], tri["status"])
+        out = up.update()
+        up.close()
+        assert out["stats"]["status"] == 0
+        assert np.array_equal(out["feat_status"], ref["feat_status"])
+        np.testing.assert_allclose(out["chi2"][gate], ref["chi2"][gate], rtol=1e-7)
+        e_gpu = (_rel(out["P"].astype(LD), P_true), _rel(out["dx"].astype(LD), dx_true))
+        print(f"cond(P_DD) {cond:.1e} route {'gram' if out['route'] == capi.COMPRESS_GRAM else 'tsqr'}{' (forced)' if forced else ''}: "
+              f"|dP|/|P| gpu {e_gpu[0]:.1e} oracle {e_ref[0]:.1e}; |ddx|/|dx| gpu {e_gpu[1]:.1e} oracle {e_ref[1]:.1e}; "
+              f"gpu vs oracle P {_rel(out['P'], ref['P']):.1e} dx {_rel(out['dx'], ref['dx']):.1e}")
+        if forced:
+            assert out["route"] == capi.COMPRESS_GRAM
+        assert e_gpu[0] < max(1e-9, 5 * e_ref[0]), (cond, forced, e_gpu, e_ref)
+        assert e_gpu[1] < max(1e-8, 10 * e_ref[1]), (cond, forced, e_gpu, e_ref)
+        assert np.array_equal(out["P"], out["P"].T) and np.linalg.eigvalsh(out["P"]).min() > -1e-9 * np.abs(np.diag(out["P"])).max()
 
 
 def test_round1_route_loses_the_gauge(Updater, oracle):
@@ -175,11 +184,12 @@ def test_round1_route_loses_the_gauge(Updater, oracle):
     assert ref["stats"]["n_used"] > 250
     errs = {}
     for nw in (0, 1):
-        up = Updater(capi.default_options(chi2_multipler=GATE_OPEN, gram_no_whiten=nw))
+        up = Updater(capi.default_options(chi2_multipler=GATE_OPEN, gram_no_whiten=nw, prior_pivot_tol=1e-300))
         up.set_problem(prob)
         up.set_triangulation(tri["p_FinG"], tri["p_FinA"], tri["anchor_meas"], tri["status"])
         out = up.update()
         up.close()
+        assert out["route"] == capi.COMPRESS_GRAM
         errs[nw] = _rel(out["P"], ref["P"])
     print("gram then whiten", errs[1], "whiten then gram", errs[0])
     assert errs[0] < 1e-9 and errs[1] > 10 * errs[0]
