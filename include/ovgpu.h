@@ -116,7 +116,8 @@ typedef struct {
   int32_t no_fast_feature_kernel; /* 1: always the general per-feature       */
                              /* kernel (k_system) instead of the MSCKF fast  */
                              /* path (k_feat: gate matrix in registers)      */
-  int32_t _pad1;
+  int32_t no_single_launch_cholesky; /* 1: the Cholesky-with-carry factorisations run as one launch per 16 rows */
+                             /* (k_ekf_chol_step) instead of the pipelined single launch (k_chol.h)           */
   double prior_pivot_tol;    /* Gram route: a pivot of the prior block's      */
                              /* Cholesky factorisation below this fraction of */
                              /* its diagonal entry sends the update through   */
@@ -615,6 +616,42 @@ int ovgpu_synchronize(ovgpu_ctx *ctx);
 
 /* hipStream_t of the context, as an integer (for hipEvent timing). */
 uint64_t ovgpu_stream(ovgpu_ctx *ctx);
+
+/* ------------------------------------------------------------------------- */
+/* Multi-GPU.  Features shard across GPUs, one exchange: the   */
+/* Gram matrices of the (identically whitened) shards add, so the exchange is */
+/* ONE all-reduce of (16 ceil((D+1)/16))^2 doubles over RCCL / xGMI on the    */
+/* context's stream; every GPU then applies the identical update.  With the   */
+/* Householder route (or more than 255 columns) the D x (D+1) triangles are   */
+/* all-gathered and merged instead.  RCCL is loaded at run time.              */
+/* ------------------------------------------------------------------------- */
+typedef struct { char internal[128]; } ovgpu_comm_id; /* = ncclUniqueId */
+
+/* One process per GPU (torchrun / MPI): rank 0 draws an id, the host program distributes the 128 bytes by its own means, every
+ * rank joins.  world == 1 is valid (no collective is issued). */
+int ovgpu_comm_unique_id(ovgpu_comm_id *id);
+int ovgpu_comm_init_rank(ovgpu_ctx *ctx, const ovgpu_comm_id *id, int rank, int world);
+int ovgpu_comm_destroy(ovgpu_ctx *ctx);
+
+/* UpdaterMSCKF::update of THIS rank's shard (uploaded with ovgpu_set_features on the replicated state): local stage, exchange and
+ * update are enqueued back to back on the context's stream, no host synchronisation in between.  Per-feature outputs are the
+ * shard's; dx / P_out are identical on every rank.  _async returns after enqueueing (status through ovgpu_synchronize). */
+int ovgpu_msckf_update_sharded(ovgpu_ctx *ctx, int32_t *feat_status, double *chi2, double *chi2_thresh, double *p_FinG, double *dx, double *P_out,
+                               ovgpu_update_stats *stats);
+int ovgpu_msckf_update_sharded_async(ovgpu_ctx *ctx);
+
+/* One host process driving several GPUs (the reference's host is ONE C++ process: VioManager.cpp:155-156, :518-526).
+ * devices == NULL: 0 .. n-1.  set_features deals the tracks round-robin by length; the update returns every output in the
+ * caller's feature order. */
+typedef struct ovgpu_multi ovgpu_multi;
+int ovgpu_multi_create(const ovgpu_options *opts, int n, const int *devices, ovgpu_multi **out);
+void ovgpu_multi_destroy(ovgpu_multi *m);
+int ovgpu_multi_size(ovgpu_multi *m);
+ovgpu_ctx *ovgpu_multi_ctx(ovgpu_multi *m, int i);
+int ovgpu_multi_set_state(ovgpu_multi *m, const ovgpu_state_view *st);
+int ovgpu_multi_set_features(ovgpu_multi *m, const ovgpu_features_view *fv);
+int ovgpu_multi_msckf_update(ovgpu_multi *m, int32_t *feat_status, double *chi2, double *chi2_thresh, double *p_FinG, double *dx, double *P_out,
+                             ovgpu_update_stats *stats);
 
 /* Which route the last ovgpu_msckf_update / ovgpu_slam_update took: OVGPU_COMPRESS_GRAM, or OVGPU_COMPRESS_TSQR when it was
  * selected or when the prior block failed the pivot test of the Gram route (ovgpu_options::prior_pivot_tol). */

@@ -40,7 +40,7 @@ class Options(C.Structure):
         ("feat_rep_msckf", C.c_int32),
         ("compress_route", C.c_int32), ("gram_no_whiten", C.c_int32), ("no_prior_overlap", C.c_int32), ("tsqr_workers", C.c_int32),
         ("tsqr_no_pipeline", C.c_int32), ("tsqr_overlap", C.c_int32), ("tsqr_leaf_blocked", C.c_int32), ("no_timing", C.c_int32),
-        ("no_fast_feature_kernel", C.c_int32), ("_pad1", C.c_int32), ("prior_pivot_tol", C.c_double),
+        ("no_fast_feature_kernel", C.c_int32), ("no_single_launch_cholesky", C.c_int32), ("prior_pivot_tol", C.c_double),
     ]
 
 
@@ -223,6 +223,18 @@ def declare(lib):
         "ovgpu_synchronize": (C.c_int, [ctxp]),
         "ovgpu_stream": (C.c_uint64, [ctxp]),
         "ovgpu_last_update_route": (C.c_int, [ctxp]),
+        "ovgpu_comm_unique_id": (C.c_int, [vp]),
+        "ovgpu_comm_init_rank": (C.c_int, [ctxp, vp, C.c_int, C.c_int]),
+        "ovgpu_comm_destroy": (C.c_int, [ctxp]),
+        "ovgpu_msckf_update_sharded": (C.c_int, [ctxp, c_int32_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, C.POINTER(UpdateStats)]),
+        "ovgpu_msckf_update_sharded_async": (C.c_int, [ctxp]),
+        "ovgpu_multi_create": (C.c_int, [C.POINTER(Options), C.c_int, c_int32_p, C.POINTER(vp)]),
+        "ovgpu_multi_destroy": (None, [vp]),
+        "ovgpu_multi_size": (C.c_int, [vp]),
+        "ovgpu_multi_ctx": (vp, [vp, C.c_int]),
+        "ovgpu_multi_set_state": (C.c_int, [vp, C.POINTER(StateView)]),
+        "ovgpu_multi_set_features": (C.c_int, [vp, C.POINTER(FeaturesView)]),
+        "ovgpu_multi_msckf_update": (C.c_int, [vp, c_int32_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, C.POINTER(UpdateStats)]),
         "ovgpu_debug_cycles": (C.c_int, [ctxp, C.c_int, C.POINTER(C.c_longlong)]),
         "ovgpu_kernel_times": (C.c_int, [ctxp, C.c_int, c_double_p, c_double_p, C.POINTER(C.c_int64)]),
         "ovgpu_system_time": (C.c_int, [ctxp, c_double_p, C.POINTER(C.c_int64)]),

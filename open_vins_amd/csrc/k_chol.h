@@ -4,18 +4,21 @@
 // [B | h]) used to be 13 launches of k_ekf_chol_step each — a chain of 16-row steps in which every launch boundary, and every
 // wavefront refactoring the diagonal block for itself, sat on the critical path (26 launches = 0.29 ms of a 1.15 ms update).
 //
-//   workgroup 0 ("factor")   8 wavefronts hold the upper triangle of A as 16 x 16 tiles in REGISTERS (accumulator layout of
-//                            v_mfma_f64_16x16x4_f64; tile columns j and 15 - j to one wavefront: 17 tiles each).  Step k:
-//                              the owner of tile (k, k) factors it (k_feat.h: diag_tile_factor, U_kk^-1 falls out of the same
-//                              instruction stream)                                                    -> LDS, barrier
+//   k_chol_factor            ONE workgroup: 15 wavefronts hold the upper triangle of A as 16 x 16 tiles in REGISTERS (accumulator
+//                            layout of v_mfma_f64_16x16x4_f64; tiles dealt round-robin, 10 per wavefront), a 16th runs the
+//                            chain of diagonal tiles and holds nothing else (the factorisation of a tile needs ~90 registers: in
+//                            a wavefront that also holds tiles they end up in scratch, and scratch latency on the chain).  Step k:
+//                              the owner of tile (k, k) hands it over through LDS, the chain wavefront factors it (k_feat.h:
+//                              diag_tile_factor, U_kk^-1 falls out of the same instruction stream)     -> LDS, barrier
 //                              every wavefront: W_kj = U_kk^-T S_kj on the matrix cores, W_kj -> LDS row panel, Y and (transposed) L
 //                                                                                                     -> barrier, publish step k
 //                              every wavefront: S_ij -= W_ki^T W_kj, operands from the LDS row panel
 //                            The hand-offs of the chain are LDS + s_barrier; nothing leaves the compute unit on the critical path.
-//   workgroups 1..           one wavefront per 16 carried columns (all 16-row tiles of those columns in registers).  They follow
-//                            the factor workgroup through a per-step flag in memory (release / acquire at agent scope, bounded
-//                            spin), read U_kk^-1 and the row panel from L2 and apply the same two products.  They trail the
-//                            chain by one step.
+//   k_chol_follow            (second stream) one wavefront per 16 carried columns (all 16-row tiles of those columns in registers).  They follow
+//                            the factor workgroup through a per-step counter in memory (bounded spin): the factor workgroup's
+//                            wavefronts write U_kk^-1 and the row panel through to memory (sc1 stores) and count
+//                            themselves in one step later, the followers read past the caches.  No fence, no vmcnt wait and
+//                            no store sits on the factor workgroup's chain.
 //
 // Padding: rows / columns D .. 16 ceil(D / 16) - 1 of A behave as an identity block and the carried columns are tiled from
 // column D on, so no tile mixes matrix and carried columns; nothing outside [D x LA] is read or written.
@@ -39,125 +42,163 @@ struct CholParams {
   int32_t *prog;          // [16] step k published (zeroed before the launch)
   double *uinv;           // [16][256] U_kk^-1 of every step, row-major
   int32_t *err;           // sticky: a follower ran into its wait bound
+  long long *dbg;         // optional cycle counters (developer aid)
 };
 
 constexpr int CH_TMAX = 16;  // tile rows: D <= 256
 constexpr int CH_NW = 8;     // wavefronts per workgroup
-constexpr int CH_SLOTS = 17; // tiles per factor wavefront
 
 __device__ __forceinline__ double ld_a(const CholParams &p, int r, int c) { // element (r, c) of the padded matrix part
   return (r < p.D && c < p.D) ? p.A[(size_t)r * p.LA + c] : (r == c ? 1.0 : 0.0);
 }
 
-__global__ void __launch_bounds__(64 * CH_NW, 2) k_chol_pipe(CholParams p) {
+constexpr int CH_FW = 15;  // tile wavefronts of the factor workgroup (wavefront 15 runs the diagonal chain and holds no tiles)
+constexpr int CH_FT = 10;  // tiles per wavefront: 16 * 17 / 2 = 136 <= 15 * 10
+
+__global__ void __launch_bounds__(64 * (CH_FW + 1), 4) k_chol_factor(CholParams p) {
   __shared__ __attribute__((aligned(16))) double panel[CH_TMAX][256];
   __shared__ __attribute__((aligned(16))) double st[2][256];
   if (p.pred && *p.pred == 0) return;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, cl = lane & 15;
-  const int D = p.D, LA = p.LA, TM = (D + 15) >> 4;
+  const int D = p.D, LA = p.LA, TM = (D + 15) >> 4, NTT = TM * (TM + 1) / 2;
+  // Barriers of the chain order LDS traffic only; memory traffic is fire-and-forget.  Data for the followers leaves with
+  // write-through stores (sc1), and a wavefront adds itself to prog[k - 1] one step LATER, when those stores have long completed
+  // (a release fence or a vmcnt(0) wait right behind the stores would sit on the chain: 2-6 us per step).
+  auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+  auto st_dev = [](double *ptr, double v) { __hip_atomic_store(ptr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+  auto arrive = [&](int k) { // this wavefront's stores of step k are complete
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) (void)__hip_atomic_fetch_add(p.prog + k, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
 
-  if (blockIdx.x == 0) {
-    // ------------------------------------------------------------------ factor workgroup
-    // slot s of wavefront w: s <= w -> tile (s, w); else tile (s - w - 1, 15 - w)
-    d4 acc[CH_SLOTS];
-#pragma unroll
-    for (int s = 0; s < CH_SLOTS; s++) {
-      const int i = s <= wv ? s : s - wv - 1, j = s <= wv ? wv : 15 - wv;
-      d4 v = {0.0, 0.0, 0.0, 0.0};
-      if (j < TM && i <= j) {
-#pragma unroll
-        for (int q = 0; q < 4; q++) v[q] = ld_a(p, 16 * i + g + 4 * q, 16 * j + cl);
-      }
-      acc[s] = v;
-    }
+  if (wv == CH_FW) {
+    // ------------------------------------------------------------------ the diagonal chain: one wavefront, no tiles of its own
+    const long long t_begin = clock64();
+    long long t_diag = 0;
     for (int k = 0; k < TM; k++) {
-      // (1) diagonal tile
-      const int ow = k < 8 ? k : 15 - k; // tile (k, k): column k < 8 -> wavefront k, slot k; column k >= 8 -> wavefront 15 - k, slot 16
-      if (wv == ow) {
-        const int slot = k < 8 ? k : 16;
-        d4 av = {0.0, 0.0, 0.0, 0.0};
+      lds_barrier(); // B0: tile (k, k) is in st[0]
+      const long long t_d0 = clock64();
+      const bool bad = feat::diag_tile_factor_u(st[0], st[1], lane, p.diag0 ? p.diag0 + 16 * k : nullptr, p.pivot_tol, D - 16 * k);
+      if (bad && lane == 0) p.flags[0] = 1;
+      t_diag += clock64() - t_d0;
+      lds_barrier(); // B1: U_kk^-1 is in st[1], U_kk in st[0]
+      if (k > 0) arrive(k - 1);
 #pragma unroll
-        for (int s = 0; s < CH_SLOTS; s++)
-          if (s == slot) av = acc[s];
-#pragma unroll
-        for (int q = 0; q < 4; q++) st[0][(g + 4 * q) * 16 + cl] = av[q];
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        // (the pivots appear inside the chain: the routine reports the smallest one, relative to the matrix's own diagonal)
-        const double worst = feat::diag_tile_factor_u(st[0], st[1], lane, p.diag0 ? p.diag0 + 16 * k : nullptr, D - 16 * k);
-        if (!(worst > (p.diag0 ? p.pivot_tol : 0.0)) && lane == 0) p.flags[0] = 1;
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        // U_kk (st[0], row-major, zeros below the diagonal) -> Y and L^T; U_kk^-1 (st[1]) -> memory for the followers
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-          const int r = 16 * k + g + 4 * q, c = 16 * k + cl;
-          const double u = st[0][(g + 4 * q) * 16 + cl];
-          if (r < D && c < D) {
-            p.Y[(size_t)r * LA + c] = u;
-            if (p.Lt) p.Lt[(size_t)c * D + r] = u;
-          }
-          p.uinv[(size_t)k * 256 + (g + 4 * q) * 16 + cl] = st[1][(g + 4 * q) * 16 + cl];
+      for (int q = 0; q < 4; q++) { // U_kk -> Y and L; U_kk^-1 -> memory for the followers
+        const int r = 16 * k + g + 4 * q, c = 16 * k + cl;
+        const double u = st[0][(g + 4 * q) * 16 + cl];
+        if (r < D && c < D) {
+          p.Y[(size_t)r * LA + c] = u;
+          if (p.Lt) p.Lt[(size_t)c * D + r] = u;
         }
+        st_dev(p.uinv + (size_t)k * 256 + (g + 4 * q) * 16 + cl, st[1][(g + 4 * q) * 16 + cl]);
       }
-      __syncthreads();
-      // (2) row panel W_kj = U_kk^-T S_kj
-      {
-        double ua[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) ua[u] = st[1][(4 * u + g) * 16 + cl];
-#pragma unroll
-        for (int s = 0; s < CH_SLOTS; s++) {
-          const int i = s <= wv ? s : s - wv - 1, j = s <= wv ? wv : 15 - wv;
-          if (i == k && j > k && j < TM) {
-            d4 w = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int u = 0; u < 4; u++) FEAT_MFMA(ua[u], acc[s][u], w);
-            acc[s] = w;
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-              panel[j][(g + 4 * q) * 16 + cl] = w[q];
-              const int r = 16 * k + g + 4 * q, c = 16 * j + cl;
-              if (r < D && c < D) {
-                p.Y[(size_t)r * LA + c] = w[q];
-                if (p.Lt) p.Lt[(size_t)c * D + r] = w[q];
-              }
-            }
-          }
-        }
-        // rows of U below the diagonal of this tile row: zeros in Y (the factor is dense upper triangular there)
-        for (int e = tid; e < 16 * 16 * k; e += 64 * CH_NW) {
-          const int r = 16 * k + (e & 15), c = e >> 4;
-          if (r < D) p.Y[(size_t)r * LA + c] = 0.0;
-        }
+      // rows of U left of the diagonal tile: zeros in Y
+      for (int e = lane; e < 16 * 16 * k; e += 64) {
+        const int r = 16 * k + (e & 15), c = e >> 4;
+        if (r < D) p.Y[(size_t)r * LA + c] = 0.0;
       }
-      __syncthreads(); // panel complete; all stores of the step issued and waited for (vmcnt(0) precedes the barrier)
-      if (tid == 0) { // publish step k to the followers
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_store(p.prog + k, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      // (3) trailing update S_ij -= W_ki^T W_kj
-#pragma unroll
-      for (int s = 0; s < CH_SLOTS; s++) {
-        const int i = s <= wv ? s : s - wv - 1, j = s <= wv ? wv : 15 - wv;
-        if (i > k && i <= j && j < TM) {
-          double a[4], b[4];
-#pragma unroll
-          for (int u = 0; u < 4; u++) a[u] = -panel[i][(4 * u + g) * 16 + cl], b[u] = panel[j][(4 * u + g) * 16 + cl];
-#pragma unroll
-          for (int u = 0; u < 4; u++) FEAT_MFMA(a[u], b[u], acc[s]);
-        }
-      }
-      // no barrier: the next step's diagonal tile goes through st[], its panel writes come behind its first barrier
+      lds_barrier(); // B2
     }
+    arrive(TM - 1);
+    if (p.dbg && lane == 0) p.dbg[300] += clock64() - t_begin, p.dbg[301] += t_diag, p.dbg[302] += 1;
     return;
   }
 
-  // -------------------------------------------------------------------- followers: one wavefront per 16 carried columns
-  const int jc = (blockIdx.x - 1) * CH_NW + wv; // carried tile
+  // -------------------------------------------------------------------- tile wavefronts: linear tile index t = s CH_FW + wv over the upper triangle, column by column
+  int tij[CH_FT]; // (j << 8) | i, or -1
+  d4 acc[CH_FT];
+#pragma unroll
+  for (int s = 0; s < CH_FT; s++) {
+    const int t = s * CH_FW + wv;
+    int i = -1, j = 0;
+    if (t < NTT) {
+      while ((j + 1) * (j + 2) / 2 <= t) j++;
+      i = t - j * (j + 1) / 2;
+    }
+    tij[s] = i < 0 ? -1 : ((j << 8) | i);
+    d4 v = {0.0, 0.0, 0.0, 0.0};
+    if (i >= 0) {
+#pragma unroll
+      for (int q = 0; q < 4; q++) v[q] = ld_a(p, 16 * i + g + 4 * q, 16 * j + cl);
+    }
+    acc[s] = v;
+  }
+#define CTI(s) (tij[s] & 255)
+#define CTJ(s) (tij[s] >> 8)
+  for (int k = 0; k < TM; k++) {
+    // (1) the diagonal tile goes to the chain wavefront
+    const int tkk = k * (k + 1) / 2 + k;
+    if (tkk % CH_FW == wv) {
+      const int slot = tkk / CH_FW;
+      d4 av = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int s = 0; s < CH_FT; s++)
+        if (s == slot) av = acc[s];
+#pragma unroll
+      for (int q = 0; q < 4; q++) st[0][(g + 4 * q) * 16 + cl] = av[q];
+    }
+    lds_barrier(); // B0
+    lds_barrier(); // B1
+    // (2) row panel W_kj = U_kk^-T S_kj -> LDS (for the trailing update) and memory (final: the tile is not needed here again).
+    //     One copy of the code, the register slot is selected at run time; the stores are fire-and-forget.
+    if (k > 0) arrive(k - 1); // the previous row's stores were issued a step ago
+    {
+      double ua[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) ua[u] = st[1][(4 * u + g) * 16 + cl];
+      for (int j = k + 1; j < TM; j++) {
+        const int t = j * (j + 1) / 2 + k;
+        if (t % CH_FW != wv) continue;
+        const int slot = t / CH_FW;
+        d4 sv = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s = 0; s < CH_FT; s++)
+          if (s == slot) sv = acc[s];
+        d4 w = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int u = 0; u < 4; u++) FEAT_MFMA(ua[u], sv[u], w);
+        double *pt = panel[j];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          pt[(g + 4 * q) * 16 + cl] = w[q];
+          const int r = 16 * k + g + 4 * q, c = 16 * j + cl;
+          if (r < D && c < D) {
+            st_dev(p.Y + (size_t)r * LA + c, w[q]);
+            if (p.Lt) p.Lt[(size_t)c * D + r] = w[q];
+          }
+        }
+      }
+    }
+    lds_barrier(); // B2
+    // (3) trailing update S_ij -= W_ki^T W_kj
+#pragma unroll
+    for (int s = 0; s < CH_FT; s++) {
+      if (tij[s] >= 0 && CTI(s) > k) {
+        const double *pi = panel[CTI(s)], *pj = panel[CTJ(s)];
+        double a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) a[u] = -pi[(4 * u + g) * 16 + cl], b[u] = pj[(4 * u + g) * 16 + cl];
+#pragma unroll
+        for (int u = 0; u < 4; u++) FEAT_MFMA(a[u], b[u], acc[s]);
+      }
+    }
+  }
+  arrive(TM - 1);
+#undef CTI
+#undef CTJ
+}
+
+// followers: one wavefront per 16 carried columns (launched on a second stream next to k_chol_factor)
+__global__ void __launch_bounds__(64 * CH_NW, 2) k_chol_follow(CholParams p) {
+  if (p.pred && *p.pred == 0) return;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, cl = lane & 15;
+  const int D = p.D, LA = p.LA, TM = (D + 15) >> 4;
+  const int jc = blockIdx.x * CH_NW + wv; // carried tile
   const int c0 = D + 16 * jc;
   if (c0 >= LA) return;
   const int col = c0 + cl;
@@ -175,20 +216,25 @@ __global__ void __launch_bounds__(64 * CH_NW, 2) k_chol_pipe(CholParams p) {
     }
     acc[i] = v;
   }
+  const long long f_begin = clock64();
+  long long f_wait = 0;
   for (int k = 0; k < TM; k++) {
     // wait for step k of the factor workgroup
+    const long long f_w0 = clock64();
     int spins = 0;
-    while (__hip_atomic_load(p.prog + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+    while (__hip_atomic_load(p.prog + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < CH_FW + 1) {
       __builtin_amdgcn_s_sleep(2);
       if (++spins > (1 << 22)) {
         if (lane == 0) p.err[0] = 1;
         return;
       }
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    f_wait += clock64() - f_w0;
+    // the factor workgroup's data was written through (sc1 stores): sc1 loads read it past this CU's L1
+    auto ld_sys = [](const double *ptr) { return __hip_atomic_load(ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
     double ua[4];
 #pragma unroll
-    for (int u = 0; u < 4; u++) ua[u] = p.uinv[(size_t)k * 256 + (4 * u + g) * 16 + cl];
+    for (int u = 0; u < 4; u++) ua[u] = ld_sys(p.uinv + (size_t)k * 256 + (4 * u + g) * 16 + cl);
     d4 w = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int i = 0; i < CH_TMAX; i++) {
@@ -213,7 +259,7 @@ __global__ void __launch_bounds__(64 * CH_NW, 2) k_chol_pipe(CholParams p) {
 #pragma unroll
         for (int u = 0; u < 4; u++) {
           const int r = 16 * k + 4 * u + g, c = 16 * i + cl;
-          wa[ii][u] = (i > k && i < TM && r < D && c < D) ? p.Y[(size_t)r * LA + c] : 0.0;
+          wa[ii][u] = (i > k && i < TM && r < D && c < D) ? ld_sys(p.Y + (size_t)r * LA + c) : 0.0;
         }
       }
 #pragma unroll
@@ -226,6 +272,7 @@ __global__ void __launch_bounds__(64 * CH_NW, 2) k_chol_pipe(CholParams p) {
       }
     }
   }
+  if (p.dbg && blockIdx.x == 0 && tid == 0) p.dbg[303] += clock64() - f_begin, p.dbg[304] += f_wait;
 }
 
 } // namespace chol

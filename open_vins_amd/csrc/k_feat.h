@@ -46,7 +46,7 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 constexpr int FT_CH = 8; // measurements per chunk = 16 rows = one tile row of the gate matrix
 
 struct FeatLds {
-  size_t minfo, rows, rhs, V, big, stage, sched, total;
+  size_t minfo, rows, rhs, big, stage, sched, total;
 };
 
 // nt_max = tile rows of the longest track the instantiation accepts
@@ -61,7 +61,6 @@ __host__ __device__ inline FeatLds feat_lds_layout(int m_max, int RS, int D, int
   L.minfo = take((size_t)m_max * 8 * sizeof(int));
   L.rows = take((size_t)m_max * RS * sizeof(double));
   L.rhs = take((size_t)16 * nt_max * 4 * sizeof(double));
-  L.V = take((size_t)16 * nt_max * 3 * sizeof(double));
   const size_t tch = (size_t)2 * FT_CH * D, pan = (size_t)(nt_max + 1) * 256;
   L.big = take((tch > pan ? tch : pan) * sizeof(double));
   L.stage = take(2 * 256 * sizeof(double));
@@ -90,9 +89,9 @@ __device__ __forceinline__ void rsqrt_pair(double dk, double &inv, double &d) {
 // every row i below, the multipliers broadcast from the matrix lanes.  The identity lanes end up with the columns of U^-T =
 // rows of U^-1, written row-major to st1.  The next pivot's reciprocal square root is started as soon as its row is updated,
 // ahead of the other rows' updates (the chain of a step is the 16 dependent rsq / Newton sequences, not the updates).
-// WRITE_U: U itself goes back to st0 (row-major, zeros below the diagonal).  Returns the smallest pivot, relative to diag0[k]
-// when diag0 is given (first nb pivots only: the rest belong to the identity padding of a partial last tile).
-template <bool WRITE_U> __device__ __forceinline__ double diag_tile_factor_t(double *st0, double *st1, int lane, const double *diag0, int nb) {
+// WRITE_U: U itself goes back to st0 (row-major, zeros below the diagonal).  Returns true when a pivot is not above
+// tol * diag0[k] (above 0 without diag0); first nb pivots only: the rest belong to the identity padding of a partial last tile.
+template <bool WRITE_U> __device__ __forceinline__ bool diag_tile_factor_t(double *st0, double *st1, int lane, const double *diag0, double tol, int nb) {
   const int j = lane & 15;
   const bool rhsl = (lane >> 4) == 1;
   double u[16];
@@ -101,16 +100,12 @@ template <bool WRITE_U> __device__ __forceinline__ double diag_tile_factor_t(dou
     const double a = st0[i * 16 + j];
     u[i] = rhsl ? (i == j ? 1.0 : 0.0) : (i <= j ? a : 0.0);
   }
-  double worst = 1e300;
+  bool bad = false;
   double dk = bcast_lane(u[0], 0), inv, d;
   rsqrt_pair(dk, inv, d);
 #pragma unroll
   for (int k = 0; k < 16; k++) {
-    if (WRITE_U) {
-      const double ref = (diag0 && k < nb) ? diag0[k] : 1.0;
-      const double ratio = k < nb ? dk / ref : 1.0;
-      worst = ratio < worst || !(ratio == ratio) ? ratio : worst;
-    }
+    if (WRITE_U && k < nb) bad = bad || !(dk > (diag0 ? tol * diag0[k] : 0.0));
     u[k] = (!rhsl && j == k) ? d : u[k] * inv;
     if (k < 15) {
       u[k + 1] = fma(-bcast_lane(u[k], k + 1), u[k], u[k + 1]); // U[k][i] comes from matrix lane i
@@ -127,11 +122,11 @@ template <bool WRITE_U> __device__ __forceinline__ double diag_tile_factor_t(dou
 #pragma unroll
     for (int i = 0; i < 16; i++) st0[i * 16 + j] = i <= j ? u[i] : 0.0; // column j of U
   }
-  return worst;
+  return bad;
 }
-__device__ __forceinline__ void diag_tile_factor(double *st0, double *st1, int lane) { (void)diag_tile_factor_t<false>(st0, st1, lane, nullptr, 16); }
-__device__ __forceinline__ double diag_tile_factor_u(double *st0, double *st1, int lane, const double *diag0, int nb) {
-  return diag_tile_factor_t<true>(st0, st1, lane, diag0, nb);
+__device__ __forceinline__ void diag_tile_factor(double *st0, double *st1, int lane) { (void)diag_tile_factor_t<false>(st0, st1, lane, nullptr, 0.0, 16); }
+__device__ __forceinline__ bool diag_tile_factor_u(double *st0, double *st1, int lane, const double *diag0, double tol, int nb) {
+  return diag_tile_factor_t<true>(st0, st1, lane, diag0, tol, nb);
 }
 
 #define FEAT_MFMA(a, b, c) c = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0)
@@ -270,8 +265,94 @@ __global__ void __launch_bounds__(256) k_feat_qr(SysParams p, FeatStore st) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-// k_feat: one feature per workgroup — the gate (T = H P, S0 tiles in registers, blocked Cholesky on the matrix cores, chi2) and,
-// for accepted features, the projected whitened rows.  NW wavefronts per workgroup, TPW gate tiles per wavefront:
+// k_feat_out: rows 3.. of Q^T [H L | r] = [H L | r] - V z of every accepted feature -> the stacked system (zero rows for the others).
+// One workgroup per feature, thread = column; no LDS: every Jacobian value / reflector entry is a scalar-cache operand, the rows
+// of L come from L2 (GY measurements ahead).  L is lower triangular and the calibration columns come first, so a clone block
+// contributes nothing to the columns right of it and only the first wavefront's columns see the calibration blocks.
+// Runs after the gate (k_feat) AND after the prior block's factorisation (L, z): the gate itself needs neither, which is what lets
+// that factorisation run next to it on the second stream.
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_feat_out(SysParams p, const double *__restrict__ rowsG, const int32_t *__restrict__ minfoG,
+                                                   const double *__restrict__ VG, const double *__restrict__ zG) {
+  const int tid = threadIdx.x, colt = tid;
+  const int D = p.D, LD = p.LD, RS = p.row_stride;
+  const int c = colt, cq = c < D ? c : D - 1;
+  const double *Lc = p.Lw + cq;
+  constexpr int MH = 1, half = 0;
+  for (int slot = blockIdx.x; slot < p.F; slot += gridDim.x) {
+    const int f = __builtin_amdgcn_readfirstlane(p.order ? p.order[slot] : slot);
+    const int m0 = __builtin_amdgcn_readfirstlane(p.meas_offsets[f]);
+    const int m = __builtin_amdgcn_readfirstlane(p.meas_offsets[f + 1]) - m0;
+    const int64_t orow0 = p.row_off[f];
+    const int n_out = (int)(p.row_off[f + 1] - orow0);
+    if (p.status[f] != OVGPU_FEAT_USED) {
+      for (int64_t e = tid; e < (int64_t)n_out * LD; e += 256) p.Hbig[orow0 * LD + e] = 0.0;
+      continue;
+    }
+    const double *frow = rowsG + (size_t)m0 * RS;
+    const int32_t *finfo = minfoG + (size_t)8 * m0;
+    const double *Vl = VG + (size_t)6 * m0;
+    if (c < LD) {
+      const double *zf = zG + (size_t)f * 3 * LD + c;
+      const double z0 = zf[0], z1 = zf[LD], z2 = zf[2 * LD];
+      double lcp[6] = {0, 0, 0, 0, 0, 0}, lci[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      int cam_l = -1;
+      const int cw0 = colt & ~63; // smallest column of this wavefront: blocks of L above it contribute nothing
+      double *out = p.Hbig + orow0 * LD + c;
+      constexpr int GY = 4;
+#pragma unroll 1
+      for (int ib = half * GY; ib < m; ib += MH * GY) {
+        double lcl[GY][6];
+#pragma unroll
+        for (int ii = 0; ii < GY; ii++) {
+          const int i = min(ib + ii, m - 1);
+          const int ccol = finfo[8 * i + 2];
+          const double *Lr = Lc + (size_t)ccol * D;
+          const bool live = ccol + 5 >= cw0; // wave-uniform
+#pragma unroll
+          for (int s = 0; s < 6; s++) lcl[ii][s] = live ? Lr[(size_t)s * D] : 0.0;
+        }
+#pragma unroll
+        for (int ii = 0; ii < GY; ii++) {
+          const int i = ib + ii;
+          if (i < m) {
+            const int32_t *mi = finfo + 8 * i;
+            const double *rd = frow + (size_t)i * RS;
+            const int camv = mi[0], cc2 = mi[2], cc3 = mi[3], cc4 = mi[4];
+            double t0 = 0.0, t1 = 0.0, s0 = 0.0, s1 = 0.0;
+            if (cc2 + 5 >= cw0) {
+#pragma unroll
+              for (int s = 0; s < 6; s++) t0 = fma(rd[RO_CLONE + s], lcl[ii][s], t0), t1 = fma(rd[RO_CLONE + 6 + s], lcl[ii][s], t1);
+            }
+            if ((cc3 >= 0 && cc3 + 5 >= cw0) || (cc4 >= 0 && cc4 + 7 >= cw0)) { // first wavefront only
+              if (camv != cam_l) {
+                cam_l = camv;
+#pragma unroll
+                for (int s = 0; s < 6; s++) lcp[s] = cc3 >= 0 ? Lc[(size_t)(cc3 + s) * D] : 0.0;
+#pragma unroll
+                for (int s = 0; s < 8; s++) lci[s] = cc4 >= 0 ? Lc[(size_t)(cc4 + s) * D] : 0.0;
+              }
+#pragma unroll
+              for (int s = 0; s < 6; s++) s0 = fma(rd[RO_CPOSE + s], lcp[s], s0), s1 = fma(rd[RO_CPOSE + 6 + s], lcp[s], s1);
+#pragma unroll
+              for (int s = 0; s < 8; s++) s0 = fma(rd[RO_CINTR + s], lci[s], s0), s1 = fma(rd[RO_CINTR + 8 + s], lci[s], s1);
+            }
+            t0 += s0, t1 += s1;
+            if (c == D) t0 = rd[RO_RES], t1 = rd[RO_RES + 1]; // the residual column is not whitened
+            const double *v = Vl + (size_t)6 * i;
+            t0 -= v[0] * z0 + v[1] * z1 + v[2] * z2, t1 -= v[3] * z0 + v[4] * z1 + v[5] * z2;
+            const int r = 2 * i;
+            if (r >= 3) out[(size_t)(r - 3) * LD] = t0;
+            if (r + 1 >= 3) out[(size_t)(r + 1 - 3) * LD] = t1;
+          }
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// k_feat: one feature per workgroup — the gate: T = H P, S0 tiles in registers, blocked Cholesky on the matrix cores, chi2.  NW wavefronts per workgroup, TPW gate tiles per wavefront:
 // NT (NT + 1) / 2 + NT <= NW * TPW for every feature of the batch.
 // The row store arrives as separate restrict-qualified parameters: reads at wave-uniform indices become scalar loads.
 // ---------------------------------------------------------------------------------------------------
@@ -291,7 +372,6 @@ __global__ void __launch_bounds__(64 * NW, OCC)
   int *minfo = reinterpret_cast<int *>(smem + lo.minfo);
   double *rows = reinterpret_cast<double *>(smem + lo.rows);
   double *rhs = reinterpret_cast<double *>(smem + lo.rhs);
-  double *Vl = reinterpret_cast<double *>(smem + lo.V);
   double *Tch = reinterpret_cast<double *>(smem + lo.big);
   double *panel = Tch; // the Cholesky's row panel takes the T chunk's place once the gate matrix is complete
   double *st0 = reinterpret_cast<double *>(smem + lo.stage), *st1 = st0 + 256;
@@ -300,7 +380,6 @@ __global__ void __launch_bounds__(64 * NW, OCC)
   const int c = colt;               // this thread's column of [H_x | r]
   const int cq = c < D ? c : D - 1; // clamped for loads
   const double *Pc = p.P + p.col_cov[cq];
-  const double *Lc = p.Lw + cq;
 
   long long tlast = 0;
   const bool prof = p.dbg != nullptr && blockIdx.x == 0 && tid == 0;
@@ -322,10 +401,7 @@ __global__ void __launch_bounds__(64 * NW, OCC)
     const int m = __builtin_amdgcn_readfirstlane(p.meas_offsets[f + 1]) - m0;
     const int64_t orow0 = p.row_off[f];
     const int n_out = (int)(p.row_off[f + 1] - orow0); // 2m - 3 (0 when m < 2)
-    if (p.status[f] != OVGPU_FEAT_USED) { // failed before the gate: its rows of the stacked system are zero
-      for (int64_t e = tid; e < (int64_t)n_out * LD; e += NTH) p.Hbig[orow0 * LD + e] = 0.0;
-      continue;
-    }
+    if (p.status[f] != OVGPU_FEAT_USED) continue; // failed before the gate (k_feat_out writes its zero rows)
     const int n = 2 * m, NT = (n + 15) >> 4, NTT = NT * (NT + 1) / 2, ntiles = NTT + NT;
     // this wavefront's tiles: linear index t = s NW + wv over the upper triangle column by column, then the right-hand-side column NT
     int tij[TPW]; // (j << 8) | i, or -1 for an unused slot
@@ -350,7 +426,6 @@ __global__ void __launch_bounds__(64 * NW, OCC)
     // ------------------------------------------------------------------ (a) LDS copies for the per-lane reads of the gate's tiles: rows, bookkeeping, [r | H_f]
     for (int e = tid; e < m * RS; e += NTH) rows[e] = frow[e];
     for (int e = tid; e < 8 * m; e += NTH) minfo[e] = finfo[e];
-    for (int e = tid; e < 6 * m; e += NTH) Vl[e] = VG[(size_t)6 * m0 + e];
     for (int i = tid; i < 8 * NT; i += NTH) {
       double *q0 = rhs + (size_t)8 * i;
       if (i < m) {
@@ -562,69 +637,8 @@ __global__ void __launch_bounds__(64 * NW, OCC)
     }
     __syncthreads();
     FEAT_T(8)
-    if (sched[1]) { // rejected: zero rows
-      for (int64_t e = tid; e < (int64_t)n_out * LD; e += NTH) p.Hbig[orow0 * LD + e] = 0.0;
-      continue;
-    }
+    // (the rows of the stacked system are written by k_feat_out, which reads the status)
 
-    // ------------------------------------------------------------------ (h) rows 3.. of Q^T [H L | r] = [H L | r] - V z -> HBM (thread = column; the gate's registers are free)
-    // L is lower triangular and the calibration columns come first: only the first wavefront's columns see the calibration blocks
-    if (c < LD) {
-      const double *zf = zG + (size_t)f * 3 * LD + c;
-      const double z0 = zf[0], z1 = zf[LD], z2 = zf[2 * LD];
-      double lcp[6] = {0, 0, 0, 0, 0, 0}, lci[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      int cam_l = -1;
-      const int cw0 = colt & ~63; // smallest column of this wavefront: blocks of L above it contribute nothing
-      double *out = p.Hbig + orow0 * LD + c;
-      constexpr int GY = 4;
-#pragma unroll 1
-      for (int ib = half * GY; ib < m; ib += MH * GY) {
-        double lcl[GY][6];
-#pragma unroll
-        for (int ii = 0; ii < GY; ii++) {
-          const int i = min(ib + ii, m - 1);
-          const int ccol = finfo[8 * i + 2];
-          const double *Lr = Lc + (size_t)ccol * D;
-          const bool live = ccol + 5 >= cw0; // wave-uniform
-#pragma unroll
-          for (int s = 0; s < 6; s++) lcl[ii][s] = live ? Lr[(size_t)s * D] : 0.0;
-        }
-#pragma unroll
-        for (int ii = 0; ii < GY; ii++) {
-          const int i = ib + ii;
-          if (i < m) {
-            const int32_t *mi = finfo + 8 * i;
-            const double *rd = frow + (size_t)i * RS;
-            const int camv = mi[0], cc2 = mi[2], cc3 = mi[3], cc4 = mi[4];
-            double t0 = 0.0, t1 = 0.0, s0 = 0.0, s1 = 0.0;
-            if (cc2 + 5 >= cw0) {
-#pragma unroll
-              for (int s = 0; s < 6; s++) t0 = fma(rd[RO_CLONE + s], lcl[ii][s], t0), t1 = fma(rd[RO_CLONE + 6 + s], lcl[ii][s], t1);
-            }
-            if ((cc3 >= 0 && cc3 + 5 >= cw0) || (cc4 >= 0 && cc4 + 7 >= cw0)) { // first wavefront only
-              if (camv != cam_l) {
-                cam_l = camv;
-#pragma unroll
-                for (int s = 0; s < 6; s++) lcp[s] = cc3 >= 0 ? Lc[(size_t)(cc3 + s) * D] : 0.0;
-#pragma unroll
-                for (int s = 0; s < 8; s++) lci[s] = cc4 >= 0 ? Lc[(size_t)(cc4 + s) * D] : 0.0;
-              }
-#pragma unroll
-              for (int s = 0; s < 6; s++) s0 = fma(rd[RO_CPOSE + s], lcp[s], s0), s1 = fma(rd[RO_CPOSE + 6 + s], lcp[s], s1);
-#pragma unroll
-              for (int s = 0; s < 8; s++) s0 = fma(rd[RO_CINTR + s], lci[s], s0), s1 = fma(rd[RO_CINTR + 8 + s], lci[s], s1);
-            }
-            t0 += s0, t1 += s1;
-            if (c == D) t0 = rd[RO_RES], t1 = rd[RO_RES + 1]; // the residual column is not whitened
-            const double *v = Vl + (size_t)6 * i;
-            t0 -= v[0] * z0 + v[1] * z1 + v[2] * z2, t1 -= v[3] * z0 + v[4] * z1 + v[5] * z2;
-            const int r = 2 * i;
-            if (r >= 3) out[(size_t)(r - 3) * LD] = t0;
-            if (r + 1 >= 3) out[(size_t)(r + 1 - 3) * LD] = t1;
-          }
-        }
-      }
-    }
     FEAT_T(10)
   }
 #undef FEAT_T

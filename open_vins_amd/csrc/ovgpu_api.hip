@@ -24,8 +24,10 @@
 #include "k_tracks.h"
 #include "k_gram.h"
 #include <unordered_map>
+#include <dlfcn.h>
 #include "k_system.h"
 #include "k_feat.h"
+#include "k_chol.h"
 #include "k_triangulate.h"
 #include "ovgpu_types.h"
 
@@ -159,7 +161,8 @@ struct ovgpu_ctx {
                                               // compression and the cross-GPU merge alternate in the sharded update)
   int tree_G2 = 0;
   // leaf / tree overlap: the merge tree runs on a second stream next to the leaf kernel's last append
-  hipStream_t stream2 = nullptr;
+  hipStream_t stream2 = nullptr, stream3 = nullptr; // stream3: followers of the single-launch Cholesky
+  hipEvent_t ev_cf = nullptr, ev_cj = nullptr, ev_rows = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   DevBuf<int32_t> leaf_flags; // [W] panels of the last append finished by each leaf node
   int tree_overlap = -1; // -1: only when leaves and merge nodes all get a CU of their own; 0 / 1 force it (OVGPU_TSQR_OVERLAP)
@@ -186,6 +189,14 @@ struct ovgpu_ctx {
   bool no_feat_kernel = false;  // options.no_fast_feature_kernel
   DevBuf<int32_t> feat_counter, fs_minfo, fs_meas_feat; // fs_*: the row store of the fast path (feat::FeatStore)
   DevBuf<double> fs_rows, fs_V, fs_z;
+  void *comm = nullptr;        // ncclComm_t of this rank (ovgpu_comm_init_rank / ovgpu_multi_create)
+  int comm_rank = 0, comm_world = 1;
+  DevBuf<double> comm_buf;     // gathered triangles of the Householder exchange
+  DevBuf<int32_t> chol_prog;   // [2][16] per-step flags of the single-launch Cholesky (k_chol.h), one set per factorisation in flight
+  DevBuf<double> chol_uinv;    // [2][16][256]
+  int chol_slot = 0;
+  bool no_chol_pipe = false;   // options.no_single_launch_cholesky
+  int Lw_D = -1;               // column count c->Lw was zeroed for (its upper triangle stays zero)
   DevBuf<long long> dbg_cycles; // ovgpu_debug_cycles: per-phase cycle counters of workgroup 0 of the per-feature kernel
   int tsqr_workers = 0;         // options.tsqr_workers
   bool leaf_blocked = false;    // options.tsqr_leaf_blocked
@@ -390,6 +401,11 @@ int ovgpu_create(const ovgpu_options *opts, int device, ovgpu_ctx **out) {
   c->tsqr_workers = opts->tsqr_workers;
   c->leaf_blocked = opts->tsqr_leaf_blocked != 0;
   c->no_feat_kernel = opts->no_fast_feature_kernel != 0;
+  c->no_chol_pipe = opts->no_single_launch_cholesky != 0;
+  if (hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_cf, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_cj, hipEventDisableTiming) != hipSuccess)
+    c->no_chol_pipe = true;
+  if (hipEventCreateWithFlags(&c->ev_rows, hipEventDisableTiming) != hipSuccess) c->no_feat_kernel = true;
   if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess)
     c->tree_overlap = 0;
@@ -432,10 +448,16 @@ void ovgpu_destroy(ovgpu_ctx *c) {
   c->trk_time.release(), c->trk_clone_times.release(), c->trk_uv.release(), c->trk_uvn.release(), c->trk_uv_in.release(), c->trk_uvn_in.release();
   c->dx.release(), c->flags.release(), c->given_status.release();
   c->gram_part.release(), c->gram_G.release(), c->gram_rho.release(), c->Yaug2.release(), c->gram_dropped.release(), c->rows_used.release(), c->Lw.release(), c->feat_counter.release(), c->dbg_cycles.release();
+  c->chol_prog.release(), c->chol_uinv.release();
   c->fs_minfo.release(), c->fs_meas_feat.release(), c->fs_rows.release(), c->fs_V.release(), c->fs_z.release();
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
+  c->comm_buf.release();
+  if (c->stream3) (void)hipStreamSynchronize(c->stream3), (void)hipStreamDestroy(c->stream3);
+  if (c->ev_cf) (void)hipEventDestroy(c->ev_cf);
+  if (c->ev_cj) (void)hipEventDestroy(c->ev_cj);
+  if (c->ev_rows) (void)hipEventDestroy(c->ev_rows);
   c->leaf_flags.release();
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -854,16 +876,28 @@ static int enqueue_system(ovgpu_ctx *c, int f_one = -1, int init_rep = 0, bool w
       (void)hipFuncSetAttribute((const void *)feat::k_feat_qr, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_limit);
       attr_done = true;
     }
+    // rows (per measurement) -> gate (needs P only) -> projected whitened rows (need L and z).  The prior block's factorisation and
+    // the reflector / z kernel behind it run on the second stream NEXT TO the gate; only the output kernel waits for them.
     feat::FeatStore st{c->fs_rows.p, c->fs_minfo.p, c->fs_V.p, c->fs_z.p, c->fs_meas_feat.p};
-    hipLaunchKernelGGL(feat::k_feat_rows, dim3((c->M + 255) / 256), dim3(256), 0, c->stream, p, st, c->M);
-    hipLaunchKernelGGL(feat::k_feat_qr, dim3((c->F + 3) / 4), dim3(256), 4 * feat::feat_qr_lds_per_wave(p.m_max, c->LD, c->K * c->C), c->stream, p, st);
     const double *sr = st.rows, *sV = st.V, *sz = st.z;
     const int32_t *sm = st.minfo;
+    hipLaunchKernelGGL(feat::k_feat_rows, dim3((c->M + 255) / 256), dim3(256), 0, c->stream, p, st, c->M);
+    hipStream_t sq = c->stream;
+    if (c->prior_on_side) {
+      HIPCHK(hipEventRecord(c->ev_rows, c->stream));
+      HIPCHK(hipStreamWaitEvent(c->stream2, c->ev_rows, 0));
+      sq = c->stream2;
+    }
+    hipLaunchKernelGGL(feat::k_feat_qr, dim3((c->F + 3) / 4), dim3(256), 4 * feat::feat_qr_lds_per_wave(p.m_max, c->LD, c->K * c->C), sq, p, st);
+    if (c->prior_on_side) HIPCHK(hipEventRecord(c->ev_join, sq));
     if (c->feat_variant == 1) hipLaunchKernelGGL((feat::k_feat<4, 11, 2>), dim3(c->feat_grid), dim3(256), c->feat_lds, c->stream, p, c->feat_nt_max, sr, sm, sV, sz);
     else hipLaunchKernelGGL((feat::k_feat<8, 17, 2>), dim3(c->feat_grid), dim3(512), c->feat_lds, c->stream, p, c->feat_nt_max, sr, sm, sV, sz);
+    if (c->prior_on_side) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join, 0));
+    hipLaunchKernelGGL(feat::k_feat_out, dim3(std::max(1, std::min(c->F, 8 * c->num_cu))), dim3(256), 0, c->stream, p, sr, sm, sV, sz);
     HIPCHK(hipGetLastError());
     return OVGPU_OK;
   }
+  if (p.Lw && c->prior_on_side) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join, 0)); // the general kernel reads L from its first instruction on
   hipLaunchKernelGGL(k_system, dim3(grid), dim3(SYS_NT), c->sys_lds_bytes, c->stream, p);
   HIPCHK(hipGetLastError());
   return OVGPU_OK;
@@ -1060,6 +1094,8 @@ struct EkfJob {
   bool keep_flags = false;            // do not clear the sticky error flags (a chain of updates)
 };
 
+static int enqueue_chol_carry(ovgpu_ctx *c, const EkfParams &p, hipStream_t s, double *Lt);
+
 static int enqueue_ekf(ovgpu_ctx *c, const EkfJob &job = EkfJob()) {
   c->prior_pending = false;
   c->last_update_tform = false;
@@ -1074,15 +1110,10 @@ static int enqueue_ekf(ovgpu_ctx *c, const EkfJob &job = EkfJob()) {
   const int tm = (p.D + 15) / 16, tn = (p.N + 15) / 16;
   hipLaunchKernelGGL(k_ekf_mt, dim3((tm * tn + 3) / 4), dim3(256), 0, s, p);
   hipLaunchKernelGGL(k_ekf_s, dim3((tm * tm + 3) / 4), dim3(256), 0, s, p);
-  // Cholesky of S carried through [Mt | c]: one launch per block of 16 rows, one wavefront per trailing 16x16 tile
+  // Cholesky of S carried through [Mt | c]
   {
-    const int TM = (p.D + 15) / 16, TL = (p.LA + 15) / 16;
-    for (int kb = 0; kb < p.D; kb += 16) {
-      const int tb = kb / 16;
-      int jobs = TL - tb; // writers of the finished rows
-      for (int it = tb + 1; it < TM; it++) jobs += TL - it;
-      hipLaunchKernelGGL(k_ekf_chol_step, dim3((jobs + 3) / 4), dim3(256), 0, s, p, kb);
-    }
+    const int rcc = enqueue_chol_carry(c, p, s, nullptr);
+    if (rcc != OVGPU_OK) return rcc;
   }
   hipLaunchKernelGGL(k_ekf_dx, dim3((p.N + 255) / 256), dim3(256), 0, s, p);
   if (tri && c->gram_valid && p.D <= 256) { // needs the prior P: before k_ekf_pupdate
@@ -1099,13 +1130,40 @@ static int enqueue_ekf(ovgpu_ctx *c, const EkfJob &job = EkfJob()) {
 
 // EKF update straight from the Gram matrix in c->gram_G (k_ekf.h, "whitened by the prior"): two Cholesky-with-carry passes
 // through k_ekf_chol_step — P_DD carrying P(D, :), then T = I + U1 G U1^T / sigma^2 carrying [B | U1 g / sigma^2]
-static int enqueue_chol_carry(ovgpu_ctx *c, const EkfParams &p, hipStream_t s) {
+static int enqueue_chol_carry(ovgpu_ctx *c, const EkfParams &p, hipStream_t s, double *Lt) {
+  if (!c->no_chol_pipe && p.D <= 16 * chol::CH_TMAX && p.D >= 1) {
+    // one launch: the factor workgroup's chain stays inside a compute unit, the carried columns follow through flags (k_chol.h)
+    HIPCHK(c->chol_prog.reserve(2 * 16));
+    HIPCHK(c->chol_uinv.reserve((size_t)2 * 16 * 256));
+    const int slot = (c->chol_slot++) & 1; // two factorisations may be in flight on the two streams
+    chol::CholParams q;
+    q.D = p.D, q.LA = p.LA, q.A = p.A, q.Y = p.Y, q.Lt = Lt, q.flags = p.flags, q.diag0 = p.diag0, q.pivot_tol = p.pivot_tol, q.pred = p.pred;
+    q.prog = c->chol_prog.p + 16 * slot, q.uinv = c->chol_uinv.p + (size_t)slot * 16 * 256, q.err = p.flags + 2, q.dbg = c->dbg_cycles.p;
+    HIPCHK(hipMemsetAsync(q.prog, 0, 16 * sizeof(int32_t), s));
+    const int carried = (p.LA - p.D + 15) / 16;
+    // the followers run next to the factor workgroup: same stream order is not enough (they would start after it), so they go to
+    // the context's helper stream behind an event and join again
+    hipStream_t sf = c->stream3;
+    HIPCHK(hipEventRecord(c->ev_cf, s));
+    HIPCHK(hipStreamWaitEvent(sf, c->ev_cf, 0));
+    hipLaunchKernelGGL(chol::k_chol_factor, dim3(1), dim3(64 * (chol::CH_FW + 1)), 0, s, q);
+    if (carried > 0) hipLaunchKernelGGL(chol::k_chol_follow, dim3((carried + chol::CH_NW - 1) / chol::CH_NW), dim3(64 * chol::CH_NW), 0, sf, q);
+    HIPCHK(hipEventRecord(c->ev_cj, sf));
+    HIPCHK(hipStreamWaitEvent(s, c->ev_cj, 0));
+    HIPCHK(hipGetLastError());
+    return OVGPU_OK;
+  }
   const int TM = (p.D + 15) / 16, TL = (p.LA + 15) / 16;
   for (int kb = 0; kb < p.D; kb += 16) {
     const int tb = kb / 16;
     int jobs = TL - tb; // writers of the finished rows
     for (int it = tb + 1; it < TM; it++) jobs += TL - it;
     hipLaunchKernelGGL(k_ekf_chol_step, dim3((jobs + 3) / 4), dim3(256), 0, s, p, kb);
+  }
+  if (Lt) {
+    TformParams t;
+    t.D = p.D, t.LA = p.LA, t.Y1 = p.Y, t.Lw = Lt;
+    hipLaunchKernelGGL(k_tf_lt, dim3((unsigned)((p.D * p.D + 255) / 256)), dim3(256), 0, s, t);
   }
   HIPCHK(hipGetLastError());
   return OVGPU_OK;
@@ -1119,6 +1177,10 @@ static int enqueue_ekf_gram(ovgpu_ctx *c, int part, bool side = false) {
   HIPCHK(c->Yaug2.reserve((size_t)D * LA));
   HIPCHK(c->gram_rho.reserve(std::max(N, D)));
   HIPCHK(c->Lw.reserve((size_t)D * D));
+  if (c->Lw_D != D) { // the factorisation writes the lower triangle only
+    HIPCHK(hipMemsetAsync(c->Lw.p, 0, sizeof(double) * D * D, c->stream));
+    c->Lw_D = D;
+  }
   EkfParams p;
   p.N = N, p.D = D, p.DC = D, p.LD = c->LD, p.LA = LA, p.tri = 1, p.pred = nullptr;
   p.R = nullptr, p.col_cov = c->col_cov.p, p.P = c->P.p, p.Mt = c->Mt.p, p.A = c->Aaug.p, p.Y = c->Yaug.p;
@@ -1144,10 +1206,8 @@ static int enqueue_ekf_gram(ovgpu_ctx *c, int part, bool side = false) {
     const int64_t elems = (int64_t)D * LA;
     hipLaunchKernelGGL(k_tf_gather, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, sp, t);
     p.diag0 = c->gram_rho.p, p.pivot_tol = c->prior_pivot_tol;
-    if ((rc = enqueue_chol_carry(c, p, sp)) != OVGPU_OK) return rc; // Y1 = [U1 | B | 0] in c->Yaug
+    if ((rc = enqueue_chol_carry(c, p, sp, c->Lw.p)) != OVGPU_OK) return rc; // Y1 = [U1 | B | 0] in c->Yaug, L = U1^T in c->Lw
     p.diag0 = nullptr;
-    hipLaunchKernelGGL(k_tf_lt, dim3((unsigned)((D * D + 255) / 256)), dim3(256), 0, sp, t);
-    HIPCHK(hipGetLastError());
     if (c->prior_on_side) HIPCHK(hipEventRecord(c->ev_join, sp));
     c->prior_pending = true;
   }
@@ -1164,7 +1224,7 @@ static int enqueue_ekf_gram(ovgpu_ctx *c, int part, bool side = false) {
     }
     hipLaunchKernelGGL(k_tf_bh, dim3((D + 3) / 4), dim3(256), 0, s, t);
     p.Y = c->Yaug2.p;
-    if ((rc = enqueue_chol_carry(c, p, s)) != OVGPU_OK) return rc; // Y2 = [C | C^-T B | C^-T h] in c->Yaug2
+    if ((rc = enqueue_chol_carry(c, p, s, nullptr)) != OVGPU_OK) return rc; // Y2 = [C | C^-T B | C^-T h] in c->Yaug2
     hipLaunchKernelGGL(k_ekf_dx, dim3((N + 255) / 256), dim3(256), 0, s, p);
     hipLaunchKernelGGL(k_tf_pupdate, dim3((tn * tn + 3) / 4), dim3(256), 0, s, p, (const double *)c->Yaug.p);
     const int n = std::max(c->C, c->K);
@@ -1226,7 +1286,6 @@ static int enqueue_pipeline(ovgpu_ctx *c, int stages, bool slam = false, bool fa
       // the gate overwrites status; restore the caller's per-feature status for this run
       if (c->F > 0) HIPCHK(hipMemcpyAsync(c->status.p, c->given_status.p, sizeof(int32_t) * c->F, hipMemcpyDeviceToDevice, c->stream));
     } else if ((rc = enqueue_triangulate(c)) != OVGPU_OK) return rc;
-    if (whiten && c->prior_on_side) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join, 0));
     if (es) HIPCHK(hipEventRecord(es->a, c->stream));
     if ((rc = enqueue_system(c, -1, 0, whiten)) != OVGPU_OK) return rc;
     if (es) HIPCHK(hipEventRecord(es->b, c->stream));
@@ -1368,6 +1427,7 @@ static int finish_update(ovgpu_ctx *c, double *dx, double *P_out, ovgpu_update_s
   int status = OVGPU_OK;
   if (flags[0]) status = OVGPU_ERR_NOT_SPD;
   else if (flags[1]) status = OVGPU_ERR_NEGATIVE_DIAGONAL;
+  if (flags[2]) return set_err(OVGPU_ERR_HIP, "single-launch Cholesky: a follower workgroup timed out waiting for the factor workgroup (options.no_single_launch_cholesky = 1 selects the step-wise kernels)");
   if (stats) stats->status = status;
   fill_times(c, stats);
   if (status != OVGPU_OK) return set_err(status, status == OVGPU_ERR_NOT_SPD ? "innovation covariance not SPD" : "negative covariance diagonal after the update");
@@ -1728,6 +1788,7 @@ int ovgpu_slam_delayed_init(ovgpu_ctx *c, int32_t feat_rep, int32_t *feat_status
   int status = OVGPU_OK;
   if (flags[0]) status = OVGPU_ERR_NOT_SPD;
   else if (flags[1]) status = OVGPU_ERR_NEGATIVE_DIAGONAL;
+  if (flags[2]) return set_err(OVGPU_ERR_HIP, "single-launch Cholesky: a follower workgroup timed out waiting for the factor workgroup (options.no_single_launch_cholesky = 1 selects the step-wise kernels)");
   if (stats) stats->status = status;
   if (status != OVGPU_OK) return set_err(status, status == OVGPU_ERR_NOT_SPD ? "innovation covariance not SPD" : "negative covariance diagonal after the update");
   return OVGPU_OK;
@@ -2547,6 +2608,320 @@ int ovgpu_kernel_times(ovgpu_ctx *c, int reset, double *ms_compress_avg, double 
   if (ms_update_avg) *ms_update_avg = n ? su / n : 0.0;
   if (n_launches) *n_launches = n;
   if (reset) c->ev_used = 0;
+  return OVGPU_OK;
+}
+
+} // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Native multi-GPU exchange: features shard across GPUs, every GPU accumulates the Gram matrix of ITS whitened
+// stack (the prior and therefore its factor L are replicated, so the stacks are whitened identically), ONE ncclAllReduce (sum)
+// of 16 NT x 16 NT doubles on the context's stream, every GPU applies the identical update.  No host synchronisation between the
+// local stage, the collective and the update; the prior block's factorisation runs on the second stream next to all of it.
+// RCCL is resolved at run time (dlopen librccl.so.1: the copy already in the process, e.g. PyTorch's, is reused).
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+struct Rccl {
+  void *h = nullptr;
+  int (*GetUniqueId)(void *) = nullptr;
+  int (*CommInitRank)(void **, int, ovgpu_comm_id, int) = nullptr;
+  int (*CommInitAll)(void **, int, const int *) = nullptr;
+  int (*CommDestroy)(void *) = nullptr;
+  int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+  int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  const char *(*GetErrorString)(int) = nullptr;
+  bool ok = false;
+};
+Rccl &rccl() {
+  static Rccl r;
+  static bool tried = false;
+  if (tried) return r;
+  tried = true;
+  for (const char *name : {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"}) {
+    r.h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+    if (r.h) break;
+  }
+  if (!r.h) return r;
+  auto sym = [&](const char *n) { return dlsym(r.h, n); };
+  r.GetUniqueId = (int (*)(void *))sym("ncclGetUniqueId");
+  r.CommInitRank = (int (*)(void **, int, ovgpu_comm_id, int))sym("ncclCommInitRank");
+  r.CommInitAll = (int (*)(void **, int, const int *))sym("ncclCommInitAll");
+  r.CommDestroy = (int (*)(void *))sym("ncclCommDestroy");
+  r.AllReduce = (int (*)(const void *, void *, size_t, int, int, void *, hipStream_t))sym("ncclAllReduce");
+  r.AllGather = (int (*)(const void *, void *, size_t, int, void *, hipStream_t))sym("ncclAllGather");
+  r.GroupStart = (int (*)())sym("ncclGroupStart");
+  r.GroupEnd = (int (*)())sym("ncclGroupEnd");
+  r.GetErrorString = (const char *(*)(int))sym("ncclGetErrorString");
+  r.ok = r.GetUniqueId && r.CommInitRank && r.CommInitAll && r.CommDestroy && r.AllReduce && r.AllGather && r.GroupStart && r.GroupEnd;
+  return r;
+}
+constexpr int NCCL_DOUBLE = 8, NCCL_SUM = 0; // rccl.h: ncclFloat64 = 8, ncclSum = 0
+int nccl_err(int rc, const char *what) {
+  Rccl &r = rccl();
+  return set_err(OVGPU_ERR_HIP, std::string(what) + ": " + (r.GetErrorString ? r.GetErrorString(rc) : "RCCL error") + " (" + std::to_string(rc) + ")");
+}
+} // namespace
+
+// the local stage of a sharded update up to (not including) the exchange; gram: which protocol this state uses
+static int sharded_local(ovgpu_ctx *c, bool &gram) {
+  gram = c->compress_gram == 1 && (c->LD + 15) / 16 <= gram::GR_NT;
+  const int rc = enqueue_pipeline(c, STAGE_LOCAL, false, true, gram);
+  if (rc == OVGPU_OK && gram && c->F == 0) { // an empty shard: nothing was whitened here, but the sum it joins is the other ranks' whitened Gram matrix
+    const size_t n = (size_t)256 * ((c->LD + 15) / 16) * ((c->LD + 15) / 16);
+    HIPCHK(c->gram_G.reserve(n));
+    c->gram_is_whitened = c->whiten;
+  }
+  return rc;
+}
+// the exchange and the update behind it, all on the context's stream; grouped: the caller brackets several ranks' calls with
+// ncclGroupStart / ncclGroupEnd (single-process multi-device)
+static int sharded_exchange(ovgpu_ctx *c, bool gram) {
+  Rccl &r = rccl();
+  const int G = c->comm_world;
+  if (gram) {
+    const size_t n = (size_t)256 * ((c->LD + 15) / 16) * ((c->LD + 15) / 16);
+    if (c->F == 0) HIPCHK(hipMemsetAsync(c->gram_G.p, 0, sizeof(double) * n, c->stream)); // an empty shard contributes nothing
+    if (G > 1) {
+      const int rc = r.AllReduce(c->gram_G.p, c->gram_G.p, n, NCCL_DOUBLE, NCCL_SUM, c->comm, c->stream);
+      if (rc != 0) return nccl_err(rc, "ncclAllReduce");
+    }
+    return OVGPU_OK;
+  }
+  const size_t tri = (size_t)c->D * c->LD;
+  HIPCHK(c->comm_buf.reserve(tri * G));
+  if (G > 1) {
+    const int rc = r.AllGather(c->Rws.p, c->comm_buf.p, tri, NCCL_DOUBLE, c->comm, c->stream);
+    if (rc != 0) return nccl_err(rc, "ncclAllGather");
+  }
+  return OVGPU_OK;
+}
+static int sharded_update(ovgpu_ctx *c, bool gram) {
+  if (gram) return enqueue_ekf_gram(c, c->prior_pending ? 2 : 3);
+  const int G = c->comm_world;
+  if (G > 1) {
+    const size_t tri = (size_t)c->D * c->LD;
+    HIPCHK(c->Rws.reserve(std::max<size_t>((size_t)G, 16) * tri));
+    HIPCHK(hipMemcpyAsync(c->Rws.p, c->comm_buf.p, sizeof(double) * tri * G, hipMemcpyDeviceToDevice, c->stream));
+    const int rc = enqueue_merge_tree(c, G);
+    if (rc != OVGPU_OK) return rc;
+  }
+  return enqueue_ekf(c);
+}
+
+extern "C" {
+
+int ovgpu_comm_unique_id(ovgpu_comm_id *id) {
+  if (!id) return set_err(OVGPU_ERR_INVALID, "null argument");
+  Rccl &r = rccl();
+  if (!r.ok) return set_err(OVGPU_ERR_HIP, "RCCL (librccl.so.1) is not available in this process");
+  const int rc = r.GetUniqueId(id);
+  return rc == 0 ? OVGPU_OK : nccl_err(rc, "ncclGetUniqueId");
+}
+
+int ovgpu_comm_init_rank(ovgpu_ctx *c, const ovgpu_comm_id *id, int rank, int world) {
+  if (!c || !id || world < 1 || rank < 0 || rank >= world) return set_err(OVGPU_ERR_INVALID, "bad argument");
+  Rccl &r = rccl();
+  if (!r.ok) return set_err(OVGPU_ERR_HIP, "RCCL (librccl.so.1) is not available in this process");
+  HIPCHK(hipSetDevice(c->device));
+  if (c->comm) (void)r.CommDestroy(c->comm), c->comm = nullptr;
+  const int rc = r.CommInitRank(&c->comm, world, *id, rank);
+  if (rc != 0) return nccl_err(rc, "ncclCommInitRank");
+  c->comm_rank = rank, c->comm_world = world;
+  return OVGPU_OK;
+}
+
+int ovgpu_comm_destroy(ovgpu_ctx *c) {
+  if (!c) return set_err(OVGPU_ERR_INVALID, "null ctx");
+  if (c->comm) {
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    (void)rccl().CommDestroy(c->comm);
+    c->comm = nullptr;
+  }
+  c->comm_rank = 0, c->comm_world = 1;
+  return OVGPU_OK;
+}
+
+int ovgpu_msckf_update_sharded_async(ovgpu_ctx *c) {
+  if (!c) return set_err(OVGPU_ERR_INVALID, "null ctx");
+  if (c->comm_world > 1 && !c->comm) return set_err(OVGPU_ERR_NO_STATE, "ovgpu_comm_init_rank was never called");
+  bool gram = false;
+  int rc = sharded_local(c, gram);
+  if (rc != OVGPU_OK) return rc;
+  if ((rc = sharded_exchange(c, gram)) != OVGPU_OK) return rc;
+  c->async_pending = true;
+  return sharded_update(c, gram);
+}
+
+int ovgpu_msckf_update_sharded(ovgpu_ctx *c, int32_t *feat_status, double *chi2, double *chi2_thresh, double *p_FinG, double *dx, double *P_out,
+                               ovgpu_update_stats *stats) {
+  if (!c) return set_err(OVGPU_ERR_INVALID, "null ctx");
+  if (stats) std::memset(stats, 0, sizeof(*stats));
+  int rc = ovgpu_msckf_update_sharded_async(c);
+  if (rc != OVGPU_OK) return rc;
+  c->async_pending = false;
+  if ((rc = read_feature_outputs(c, feat_status, chi2, chi2_thresh, p_FinG, stats)) != OVGPU_OK) return rc;
+  return finish_update(c, dx, P_out, stats);
+}
+
+} // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------------
+// One host process, several GPUs (the reference's host is ONE C++ process, VioManager.cpp:155-156, :518-526): a set of contexts,
+// the feature batch dealt round-robin by track length, the exchange grouped over the set's communicators.
+// ---------------------------------------------------------------------------------------------------------------------
+struct ovgpu_multi {
+  std::vector<ovgpu_ctx *> ctx;
+  std::vector<std::vector<int32_t>> feat_of; // per device: global feature index of each local feature
+  int F = 0;
+};
+
+extern "C" {
+
+int ovgpu_multi_create(const ovgpu_options *opts, int n, const int *devices, ovgpu_multi **out) {
+  if (!opts || !out || n < 1) return set_err(OVGPU_ERR_INVALID, "bad argument");
+  *out = nullptr;
+  Rccl &r = rccl();
+  if (n > 1 && !r.ok) return set_err(OVGPU_ERR_HIP, "RCCL (librccl.so.1) is not available in this process");
+  ovgpu_multi *m = new ovgpu_multi();
+  std::vector<int> devs(n);
+  for (int i = 0; i < n; i++) devs[i] = devices ? devices[i] : i;
+  for (int i = 0; i < n; i++) {
+    ovgpu_ctx *c = nullptr;
+    const int rc = ovgpu_create(opts, devs[i], &c);
+    if (rc != OVGPU_OK) {
+      for (auto *x : m->ctx) ovgpu_destroy(x);
+      delete m;
+      return rc;
+    }
+    m->ctx.push_back(c);
+  }
+  if (n > 1) {
+    std::vector<void *> comms(n, nullptr);
+    const int rc = r.CommInitAll(comms.data(), n, devs.data());
+    if (rc != 0) {
+      for (auto *x : m->ctx) ovgpu_destroy(x);
+      delete m;
+      return nccl_err(rc, "ncclCommInitAll");
+    }
+    for (int i = 0; i < n; i++) m->ctx[i]->comm = comms[i], m->ctx[i]->comm_rank = i, m->ctx[i]->comm_world = n;
+  }
+  m->feat_of.resize(n);
+  *out = m;
+  return OVGPU_OK;
+}
+
+void ovgpu_multi_destroy(ovgpu_multi *m) {
+  if (!m) return;
+  for (auto *c : m->ctx) {
+    (void)ovgpu_comm_destroy(c);
+    ovgpu_destroy(c);
+  }
+  delete m;
+}
+
+int ovgpu_multi_size(ovgpu_multi *m) { return m ? (int)m->ctx.size() : 0; }
+ovgpu_ctx *ovgpu_multi_ctx(ovgpu_multi *m, int i) { return (m && i >= 0 && i < (int)m->ctx.size()) ? m->ctx[i] : nullptr; }
+
+int ovgpu_multi_set_state(ovgpu_multi *m, const ovgpu_state_view *st) {
+  if (!m || !st) return set_err(OVGPU_ERR_INVALID, "null argument");
+  for (auto *c : m->ctx) {
+    const int rc = ovgpu_set_state(c, st);
+    if (rc != OVGPU_OK) return rc;
+  }
+  return OVGPU_OK;
+}
+
+int ovgpu_multi_set_features(ovgpu_multi *m, const ovgpu_features_view *fv) {
+  if (!m || !fv) return set_err(OVGPU_ERR_INVALID, "null argument");
+  const int G = (int)m->ctx.size(), F = fv->F;
+  // tracks sorted by length (the order VioManager.cpp:509-518 produces), dealt round-robin: every GPU gets the same mix
+  std::vector<int32_t> order(F);
+  for (int f = 0; f < F; f++) order[f] = f;
+  std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
+    return fv->meas_offsets[a + 1] - fv->meas_offsets[a] > fv->meas_offsets[b + 1] - fv->meas_offsets[b];
+  });
+  m->F = F;
+  for (int g = 0; g < G; g++) {
+    std::vector<int32_t> &mine = m->feat_of[g];
+    mine.clear();
+    for (int k = g; k < F; k += G) mine.push_back(order[k]);
+    std::sort(mine.begin(), mine.end());
+    std::vector<int32_t> offs(1, 0), cl, cam;
+    std::vector<float> uv, uvn;
+    for (int32_t f : mine) {
+      for (int i = fv->meas_offsets[f]; i < fv->meas_offsets[f + 1]; i++) {
+        uv.push_back(fv->uv[2 * i]), uv.push_back(fv->uv[2 * i + 1]);
+        uvn.push_back(fv->uvn[2 * i]), uvn.push_back(fv->uvn[2 * i + 1]);
+        cl.push_back(fv->clone_idx[i]), cam.push_back(fv->cam_idx[i]);
+      }
+      offs.push_back((int32_t)cl.size());
+    }
+    ovgpu_features_view sub;
+    sub.F = (int32_t)mine.size(), sub.M = (int32_t)cl.size();
+    sub.meas_offsets = offs.data(), sub.uv = uv.data(), sub.uvn = uvn.data(), sub.clone_idx = cl.data(), sub.cam_idx = cam.data();
+    const int rc = ovgpu_set_features(m->ctx[g], &sub); // synchronous upload: the staging vectors may go
+    if (rc != OVGPU_OK) return rc;
+  }
+  return OVGPU_OK;
+}
+
+int ovgpu_multi_msckf_update(ovgpu_multi *m, int32_t *feat_status, double *chi2, double *chi2_thresh, double *p_FinG, double *dx, double *P_out,
+                             ovgpu_update_stats *stats) {
+  if (!m) return set_err(OVGPU_ERR_INVALID, "null argument");
+  if (stats) std::memset(stats, 0, sizeof(*stats));
+  const int G = (int)m->ctx.size();
+  Rccl &r = rccl();
+  std::vector<char> gram(G, 0);
+  int rc = OVGPU_OK;
+  for (int g = 0; g < G; g++) { // local stages, asynchronous on every device
+    bool gr = false;
+    if ((rc = sharded_local(m->ctx[g], gr)) != OVGPU_OK) return rc;
+    gram[g] = gr;
+  }
+  if (G > 1) (void)r.GroupStart();
+  for (int g = 0; g < G; g++) {
+    HIPCHK(hipSetDevice(m->ctx[g]->device));
+    if ((rc = sharded_exchange(m->ctx[g], gram[g])) != OVGPU_OK) break;
+  }
+  if (G > 1) {
+    const int rg = r.GroupEnd();
+    if (rc == OVGPU_OK && rg != 0) rc = nccl_err(rg, "ncclGroupEnd");
+  }
+  if (rc != OVGPU_OK) return rc;
+  for (int g = 0; g < G; g++) {
+    HIPCHK(hipSetDevice(m->ctx[g]->device));
+    if ((rc = sharded_update(m->ctx[g], gram[g])) != OVGPU_OK) return rc;
+  }
+  // outputs: per-feature results from the shard that owns the feature, (dx, P') from device 0 (identical on all)
+  ovgpu_update_stats total;
+  std::memset(&total, 0, sizeof(total));
+  for (int g = 0; g < G; g++) {
+    ovgpu_ctx *c = m->ctx[g];
+    HIPCHK(hipSetDevice(c->device));
+    const int Fl = c->F;
+    std::vector<int32_t> st(Fl);
+    std::vector<double> c2(Fl), th(Fl), pg((size_t)3 * Fl);
+    ovgpu_update_stats loc;
+    std::memset(&loc, 0, sizeof(loc));
+    if ((rc = read_feature_outputs(c, st.data(), c2.data(), th.data(), pg.data(), &loc)) != OVGPU_OK) return rc;
+    for (int k = 0; k < Fl; k++) {
+      const int f = m->feat_of[g][k];
+      if (feat_status) feat_status[f] = st[k];
+      if (chi2) chi2[f] = c2[k];
+      if (chi2_thresh) chi2_thresh[f] = th[k];
+      if (p_FinG) std::memcpy(p_FinG + (size_t)3 * f, pg.data() + (size_t)3 * k, 3 * sizeof(double));
+    }
+    total.n_used += loc.n_used, total.n_rows += loc.n_rows, total.D = loc.D;
+    ovgpu_update_stats fin;
+    std::memset(&fin, 0, sizeof(fin));
+    if ((rc = finish_update(c, g == 0 ? dx : nullptr, g == 0 ? P_out : nullptr, &fin)) != OVGPU_OK) return rc;
+    if (g == 0) total.status = fin.status, total.ms_total = fin.ms_total, total.ms_compress = fin.ms_compress, total.ms_system = fin.ms_system, total.ms_update = fin.ms_update;
+  }
+  total.n_rows_comp = total.n_rows > 0 ? total.D : 0;
+  if (stats) *stats = total;
   return OVGPU_OK;
 }
 

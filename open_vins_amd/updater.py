@@ -405,6 +405,40 @@ class UpdaterMSCKF:
         return out
 
     # ---- benchmarking hooks ---------------------------------------------
+    # ---- native multi-GPU exchange (RCCL inside the library, on the update's own stream)
+    def comm_init(self, dist, device):
+        """Joins this context to an RCCL communicator of dist.get_world_size() ranks: rank 0 draws the id, torch.distributed carries
+        the 128 bytes (the host program's own transport; the C ABI only needs the bytes)."""
+        import torch
+        rank, world = dist.get_rank(), dist.get_world_size()
+        idbuf = C.create_string_buffer(128)
+        if rank == 0:
+            capi.check(self.lib.ovgpu_comm_unique_id(idbuf), "ovgpu_comm_unique_id")
+        t = torch.tensor(list(idbuf.raw), dtype=torch.uint8, device=device)
+        dist.broadcast(t, src=0)
+        idbuf = C.create_string_buffer(bytes(t.cpu().tolist()), 128)
+        capi.check(self.lib.ovgpu_comm_init_rank(self._ctx, idbuf, rank, world), "ovgpu_comm_init_rank")
+
+    def comm_init_single(self):
+        """A communicator of one rank (no collective is issued): the native sharded entry points on a single GPU."""
+        idbuf = C.create_string_buffer(128)
+        capi.check(self.lib.ovgpu_comm_unique_id(idbuf), "ovgpu_comm_unique_id")
+        capi.check(self.lib.ovgpu_comm_init_rank(self._ctx, idbuf, 0, 1), "ovgpu_comm_init_rank")
+
+    def update_sharded_async(self):
+        capi.check(self.lib.ovgpu_msckf_update_sharded_async(self._ctx), "ovgpu_msckf_update_sharded_async")
+
+    def update_sharded(self):
+        F, N = self.F, self.N
+        out = dict(feat_status=np.zeros(F, np.int32), chi2=np.zeros(F), chi2_thresh=np.zeros(F), p_FinG=np.zeros((F, 3)),
+                   dx=np.zeros(N), P=np.zeros((N, N)))
+        stats = capi.UpdateStats()
+        capi.check(self.lib.ovgpu_msckf_update_sharded(self._ctx, _ip(out["feat_status"]), _dp(out["chi2"]), _dp(out["chi2_thresh"]), _dp(out["p_FinG"]),
+                                                       _dp(out["dx"]), _dp(out["P"]), C.byref(stats)), "ovgpu_msckf_update_sharded")
+        out["stats"] = stats.as_dict()
+        out.update(self.get_state(P=False))
+        return out
+
     def update_async(self):
         capi.check(self.lib.ovgpu_msckf_update_async(self._ctx), "ovgpu_msckf_update_async")
 
@@ -417,3 +451,43 @@ class UpdaterMSCKF:
         capi.check(self.lib.ovgpu_system_time(self._ctx, C.byref(sy), C.byref(ns)), "ovgpu_system_time")
         capi.check(self.lib.ovgpu_kernel_times(self._ctx, 1 if reset else 0, C.byref(a), C.byref(b), C.byref(n)), "ovgpu_kernel_times")
         return dict(ms_compress=a.value, ms_update=b.value, launches=n.value, ms_system=sy.value)
+
+
+class MultiUpdater:
+    """ovgpu_multi_*: ONE host process driving several GPUs (the reference's host is one C++ process); devices = list of HIP device
+    indices (the same index may not appear twice: RCCL refuses two ranks on one GPU)."""
+
+    def __init__(self, options=None, devices=(0,)):
+        self.lib = capi.load()
+        self.options = options if options is not None else capi.default_options()
+        self._m = C.c_void_p()
+        devs = np.ascontiguousarray(devices, dtype=np.int32)
+        capi.check(self.lib.ovgpu_multi_create(C.byref(self.options), len(devs), _ip(devs), C.byref(self._m)), "ovgpu_multi_create")
+        self._views = None
+
+    def close(self):
+        if getattr(self, "_m", None) is not None and self._m:
+            self.lib.ovgpu_multi_destroy(self._m)
+            self._m = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_problem(self, prob):
+        self._views = capi.Views(prob)
+        capi.check(self.lib.ovgpu_multi_set_state(self._m, C.byref(self._views.state)), "ovgpu_multi_set_state")
+        capi.check(self.lib.ovgpu_multi_set_features(self._m, C.byref(self._views.features)), "ovgpu_multi_set_features")
+        self.F, self.N = self._views.features.F, self._views.state.N
+
+    def update(self):
+        F, N = self.F, self.N
+        out = dict(feat_status=np.zeros(F, np.int32), chi2=np.zeros(F), chi2_thresh=np.zeros(F), p_FinG=np.zeros((F, 3)),
+                   dx=np.zeros(N), P=np.zeros((N, N)))
+        stats = capi.UpdateStats()
+        capi.check(self.lib.ovgpu_multi_msckf_update(self._m, _ip(out["feat_status"]), _dp(out["chi2"]), _dp(out["chi2_thresh"]), _dp(out["p_FinG"]),
+                                                     _dp(out["dx"]), _dp(out["P"]), C.byref(stats)), "ovgpu_multi_msckf_update")
+        out["stats"] = stats.as_dict()
+        return out

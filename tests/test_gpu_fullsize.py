@@ -219,3 +219,49 @@ def test_camera_models_bit_exact(Updater, oracle, fish):
     assert np.array_equal(uv, uv2), f"{(uv != uv2).sum()} of {uv.size} pixels differ"
     assert np.abs(a - a2).max() <= 1e-12 * np.abs(a2).max()
     assert np.abs(b - b2).max() <= 1e-12 * max(np.abs(b2).max(), 1.0)
+
+
+# --------------------------------------------------------------------------- native multi-GPU entry points
+def test_native_sharded_update_world_of_one(Updater, oracle):
+    """ovgpu_comm_init_rank + ovgpu_msckf_update_sharded with a communicator of ONE rank (this box has one GPU: RCCL refuses two
+    ranks on a device): the native local stage -> exchange -> update chain on one stream must give the plain update bit for bit,
+    for the Gram exchange and for the triangle exchange of the Householder route."""
+    prob = synth.make_problem(2, F=300)
+    for route in (capi.COMPRESS_GRAM, capi.COMPRESS_TSQR):
+        opts = capi.default_options(chi2_multipler=1.0, compress_route=route)
+        a = Updater(opts)
+        a.set_problem(prob)
+        ref = a.update()
+        a.close()
+        b = Updater(opts)
+        b.set_problem(prob)
+        b.comm_init_single()
+        out = b.update_sharded()
+        b.reset_state()
+        b.update_sharded_async()
+        b.synchronize()
+        again = b.get_state()
+        b.close()
+        assert np.array_equal(out["feat_status"], ref["feat_status"])
+        assert np.array_equal(out["dx"], ref["dx"]) and np.array_equal(out["P"], ref["P"])
+        assert np.array_equal(again["P"], ref["P"])
+
+
+def test_single_process_multi_device_api(oracle):
+    """ovgpu_multi_*: the one-process host interface (feature dealing, per-feature outputs back in the caller's order) on a set of
+    one device — the only set this box offers — against the oracle."""
+    from open_vins_amd.updater import MultiUpdater
+    prob = synth.make_problem(2, F=200, outlier_frac=0.2)
+    opts = capi.default_options(chi2_multipler=1.0)
+    ref = oracle.msckf_update(opts, capi.Views(prob))
+    m = MultiUpdater(opts, devices=[0])
+    m.set_problem(prob)
+    out = m.update()
+    m.close()
+    assert np.array_equal(out["feat_status"], ref["feat_status"])
+    gate = np.isfinite(ref["chi2"])
+    np.testing.assert_allclose(out["chi2"][gate], ref["chi2"][gate], rtol=1e-7)
+    ok = ref["feat_status"] == capi.FEAT_USED
+    assert np.abs(out["p_FinG"][ok] - ref["p_FinG"][ok]).max() < 1e-9
+    assert _rel(out["dx"], ref["dx"]) < 1e-7 and _rel(out["P"], ref["P"]) < 1e-8
+    assert out["stats"]["n_used"] == ref["stats"]["n_used"]

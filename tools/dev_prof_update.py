@@ -1,0 +1,29 @@
+"""Developer script (GPU): N default updates of a BASELINE config, for rocprofv3 --kernel-trace --stats."""
+import sys, os
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+from open_vins_amd import synth, capi
+from open_vins_amd.updater import UpdaterMSCKF
+cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+F = int(sys.argv[2]) if len(sys.argv) > 2 else None
+n = int(sys.argv[3]) if len(sys.argv) > 3 else 25
+kw = {}
+for a in sys.argv[4:]:
+    k, v = a.split("=")
+    kw[k] = int(v)
+prob = synth.make_problem(cfg, F=F)
+up = UpdaterMSCKF(capi.default_options(chi2_multipler=1.0, **kw))
+up.set_problem(prob)
+up.update()
+import ctypes as C
+up.lib.ovgpu_debug_cycles(up._ctx, 1, None)
+for _ in range(n):
+    up.reset_state()
+    up.update_async()
+up.synchronize()
+print(up.kernel_times())
+cyc = (C.c_longlong * 512)()
+up.lib.ovgpu_debug_cycles(up._ctx, 0, cyc)
+c = list(cyc[300:305])
+if c[2]:
+    print(f"k_chol_pipe per call: factor WG {c[0] / c[2] / 1e3:.1f} kcyc (diag phase {c[1] / c[2] / 1e3:.1f}), follower WG 1 {c[3] / c[2] / 1e3:.1f} kcyc (waiting {c[4] / c[2] / 1e3:.1f})")
+up.close()
