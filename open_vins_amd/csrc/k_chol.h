@@ -33,7 +33,7 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 struct CholParams {
   int D, LA;              // A: D x D in the first D columns of the [D x LA] row-major work matrix, LA - D carried columns
   const double *A;        // [D x LA] input (not modified)
-  double *Y;              // [D x LA] output [U | U^-T C] (U upper triangular, zeros below its diagonal are written too)
+  double *Y;              // [D x LA] output [U | U^-T C] (U upper triangular; entries left of the diagonal TILES are not written)
   double *Lt;             // optional [D x D]: U^T (lower triangular; the caller keeps the upper part zero)
   int32_t *flags;         // [0] = 1 when a pivot is not positive (or below pivot_tol * diag0)
   const double *diag0;    // optional [D]
@@ -80,26 +80,27 @@ __global__ void __launch_bounds__(64 * (CH_FW + 1), 4) k_chol_factor(CholParams 
     for (int k = 0; k < TM; k++) {
       lds_barrier(); // B0: tile (k, k) is in st[0]
       const long long t_d0 = clock64();
-      const bool bad = feat::diag_tile_factor_u(st[0], st[1], lane, p.diag0 ? p.diag0 + 16 * k : nullptr, p.pivot_tol, D - 16 * k);
+      d4 sv, ev;
+#pragma unroll
+      for (int q = 0; q < 4; q++) sv[q] = st[0][(g + 4 * q) * 16 + cl];
+      __builtin_amdgcn_wave_barrier(); // st[0] becomes the factorisation's scratch
+      const bool bad = feat::diag_tile_factor_blk(sv, ev, st[0], lane, p.diag0 ? p.diag0 + 16 * k : nullptr, p.pivot_tol, D - 16 * k);
       if (bad && lane == 0) p.flags[0] = 1;
+#pragma unroll
+      for (int q = 0; q < 4; q++) st[1][cl * 16 + g + 4 * q] = ev[q]; // U^-T in accumulator layout -> U^-1 row-major
       t_diag += clock64() - t_d0;
-      lds_barrier(); // B1: U_kk^-1 is in st[1], U_kk in st[0]
+      lds_barrier(); // B1: U_kk^-1 is in st[1]
       if (k > 0) arrive(k - 1);
 #pragma unroll
       for (int q = 0; q < 4; q++) { // U_kk -> Y and L; U_kk^-1 -> memory for the followers
         const int r = 16 * k + g + 4 * q, c = 16 * k + cl;
-        const double u = st[0][(g + 4 * q) * 16 + cl];
         if (r < D && c < D) {
-          p.Y[(size_t)r * LA + c] = u;
-          if (p.Lt) p.Lt[(size_t)c * D + r] = u;
+          p.Y[(size_t)r * LA + c] = sv[q];
+          if (p.Lt) p.Lt[(size_t)c * D + r] = sv[q];
         }
-        st_dev(p.uinv + (size_t)k * 256 + (g + 4 * q) * 16 + cl, st[1][(g + 4 * q) * 16 + cl]);
+        st_dev(p.uinv + (size_t)k * 256 + cl * 16 + g + 4 * q, ev[q]);
       }
-      // rows of U left of the diagonal tile: zeros in Y
-      for (int e = lane; e < 16 * 16 * k; e += 64) {
-        const int r = 16 * k + (e & 15), c = e >> 4;
-        if (r < D) p.Y[(size_t)r * LA + c] = 0.0;
-      }
+      // (Y left of the diagonal tile is never read: the consumers of U take k >= row only)
       lds_barrier(); // B2
     }
     arrive(TM - 1);

@@ -131,6 +131,79 @@ __device__ __forceinline__ bool diag_tile_factor_u(double *st0, double *st1, int
 
 #define FEAT_MFMA(a, b, c) c = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0)
 
+// Cholesky of one 16 x 16 diagonal tile by a whole wavefront, blocked by 4 with the rank-4 updates on the matrix cores.
+//   s   in: the tile S in accumulator layout (lane (g, c): rows g, g+4, g+8, g+12 of column c); out: U (upper triangular, S = U^T U)
+//   e   out: U^-T in accumulator layout (the identity carried through the same elimination)
+//   sh  128 doubles of LDS scratch private to the wavefront
+// Block step b (rows / columns 4b .. 4b+3): the four rows of [S | I] go through LDS; EVERY lane factors the 4 x 4 diagonal block
+// redundantly (four dependent rsq / Newton sequences, no cross-lane traffic) and forward-substitutes its own column of both
+// halves, which gives rows 4b .. 4b+3 of U and of U^-T; the remaining rows take ONE v_mfma_f64_16x16x4_f64 each:
+// S -= W^T W, E -= W^T W2, with lane (g, c) supplying W[g][c] as the A and as the B operand.
+// The lane-per-column form above needs 120 lane broadcasts per tile (~10 k cycles); this one ~3.5 k.
+// Returns true when a pivot is not above tol * diag0[k] (above 0 without diag0); pivots k >= nb belong to the identity padding.
+__device__ __forceinline__ bool diag_tile_factor_blk(d4 &s, d4 &e, double *sh, int lane, const double *diag0, double tol, int nb) {
+  const int g = lane >> 4, cl = lane & 15;
+#pragma unroll
+  for (int q = 0; q < 4; q++) e[q] = (g + 4 * q == cl) ? 1.0 : 0.0;
+  bool bad = false;
+#pragma unroll
+  for (int b = 0; b < 4; b++) {
+    const int kb = 4 * b;
+    sh[g * 16 + cl] = s[b], sh[64 + g * 16 + cl] = e[b];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    double a[4][4], sv[4], ev[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+#pragma unroll
+      for (int c2 = r; c2 < 4; c2++) a[r][c2] = sh[r * 16 + kb + c2]; // the diagonal block (upper part): same address in every lane
+      sv[r] = cl >= kb ? sh[r * 16 + cl] : 0.0;                          // columns left of the block are finished: nothing to eliminate
+      ev[r] = sh[64 + r * 16 + cl];
+    }
+    // 4 x 4 Cholesky a = u^T u, every lane for itself; w = u^-T sv, w2 = u^-T ev alongside
+    double u[4][4], inv[4], w[4], w2[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      double dk = a[r][r];
+#pragma unroll
+      for (int t = 0; t < r; t++) dk = fma(-u[t][r], u[t][r], dk);
+      if (kb + r < nb) bad = bad || !(dk > (diag0 ? tol * diag0[kb + r] : 0.0));
+      double d;
+      rsqrt_pair(dk, inv[r], d);
+      u[r][r] = d;
+#pragma unroll
+      for (int c2 = r + 1; c2 < 4; c2++) {
+        double v = a[r][c2];
+#pragma unroll
+        for (int t = 0; t < r; t++) v = fma(-u[t][r], u[t][c2], v);
+        u[r][c2] = v * inv[r];
+      }
+      double x = sv[r], y = ev[r];
+#pragma unroll
+      for (int t = 0; t < r; t++) x = fma(-u[t][r], w[t], x), y = fma(-u[t][r], w2[t], y);
+      w[r] = x * inv[r], w2[r] = y * inv[r];
+      if (cl >= kb && cl < kb + r) w[r] = 0.0; // the block's own columns: w is the column of U11, exactly zero below its diagonal
+    }
+    // own row of the block: lane (g, c) holds row kb + g
+    double wg = w[0], w2g = w2[0];
+#pragma unroll
+    for (int r = 1; r < 4; r++) wg = g == r ? w[r] : wg, w2g = g == r ? w2[r] : w2g;
+    s[b] = wg, e[b] = w2g;
+    if (b < 3) { // rows below the block
+      d4 us = {0.0, 0.0, 0.0, 0.0}, ue = {0.0, 0.0, 0.0, 0.0};
+      FEAT_MFMA(-wg, wg, us);
+      FEAT_MFMA(-wg, w2g, ue);
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        if (q > b) s[q] += us[q], e[q] += ue[q];
+      }
+    }
+    __builtin_amdgcn_wave_barrier(); // sh is rewritten by the next block step
+  }
+  return bad;
+}
+
 // Row store in HBM, written by k_feat_rows: per measurement RS doubles (the sparse Jacobian rows of k_system.h, offsets RO_*) and
 // 8 ints (camera, clone, first column of the clone / extrinsic / intrinsic block, their covariance ids).
 struct FeatStore {
@@ -556,11 +629,10 @@ __global__ void __launch_bounds__(64 * NW, OCC)
 #pragma unroll
           for (int s = 0; s < TPW; s++)
             if (s == slot_t) av = acc[s];
+          d4 ev;
+          (void)diag_tile_factor_blk(av, ev, st0, lane, nullptr, 0.0, 16);
 #pragma unroll
-          for (int q = 0; q < 4; q++) st0[(g + 4 * q) * 16 + cl] = av[q];
-          __builtin_amdgcn_wave_barrier();
-          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-          diag_tile_factor(st0, st1, lane);
+          for (int q = 0; q < 4; q++) st1[cl * 16 + g + 4 * q] = ev[q]; // U^-T in accumulator layout -> U^-1 row-major
         }
       }
       __syncthreads();

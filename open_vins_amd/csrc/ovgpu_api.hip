@@ -134,6 +134,7 @@ struct ovgpu_ctx {
   // ---- features
   bool have_feats = false;
   bool given_tri = false; // positions supplied by ovgpu_set_triangulation
+  bool given_has_anchor = false; // ... together with the anchor measurements
   std::vector<int32_t> h_given_status;
   DevBuf<int32_t> given_status;
   int F = 0, M = 0, m_max = 0;
@@ -1404,6 +1405,7 @@ int ovgpu_set_triangulation(ovgpu_ctx *c, const double *p_FinA, const double *p_
   }
   HIPCHK(hipStreamSynchronize(s));
   c->given_tri = true;
+  c->given_has_anchor = anchor_meas != nullptr;
   return OVGPU_OK;
 }
 
@@ -1761,6 +1763,10 @@ int ovgpu_slam_delayed_init(ovgpu_ctx *c, int32_t feat_rep, int32_t *feat_status
   if (P_out) HIPCHK(hipMemcpyAsync(P_out, c->P.p, sizeof(double) * (size_t)N1 * N1, hipMemcpyDeviceToHost, s));
   int32_t flags[4] = {0, 0, 0, 0};
   HIPCHK(hipMemcpyAsync(flags, c->flags.p, sizeof(flags), hipMemcpyDeviceToHost, s));
+  std::vector<int32_t> tri_am(std::max(F, 1), -1);
+  std::vector<uint16_t> tri_cc(std::max(c->M, 1), 0);
+  if (F > 0 && (!c->given_tri || c->given_has_anchor)) HIPCHK(hipMemcpyAsync(tri_am.data(), c->anchor.p, sizeof(int32_t) * F, hipMemcpyDeviceToHost, s));
+  if (c->M > 0) HIPCHK(hipMemcpyAsync(tri_cc.data(), c->meas_cc.p, sizeof(uint16_t) * c->M, hipMemcpyDeviceToHost, s));
   c->slam_rows = false;
   rc = read_feature_outputs(c, feat_status, chi2, chi2_thresh, nullptr, stats); // synchronises
   if (rc != OVGPU_OK) return rc;
@@ -1772,8 +1778,12 @@ int ovgpu_slam_delayed_init(ovgpu_ctx *c, int32_t feat_rep, int32_t *feat_status
       if (lm_value) lm_value[3 * f + i] = l >= 0 ? val[3 * l + i] : qnan;
       if (lm_fej) lm_fej[3 * f + i] = l >= 0 ? fej[3 * l + i] : qnan;
     }
-    if (anchor_cam) anchor_cam[f] = (l >= 0 && anc[l] >= 0) ? anc[l] >> 10 : -1;
-    if (anchor_clone) anchor_clone[f] = (l >= 0 && anc[l] >= 0) ? (anc[l] & 1023) : -1;
+    // anchored landmark: its anchor; otherwise the anchor of the triangulation (FeatureInitializer.cpp:36-46 writes it into the
+    // Feature for every representation, and UpdaterSLAM.cpp:214 takes Landmark::_unique_camera_id from it)
+    const int tri_anchor = (f < (int)tri_am.size() && tri_am[f] >= 0 && tri_am[f] < (int)tri_cc.size()) ? (int)tri_cc[tri_am[f]] : -1;
+    const int a = (l >= 0 && anc[l] >= 0) ? anc[l] : tri_anchor;
+    if (anchor_cam) anchor_cam[f] = a >= 0 ? a >> 10 : -1;
+    if (anchor_clone) anchor_clone[f] = a >= 0 ? (a & 1023) : -1;
   }
   if (N_out) *N_out = N1;
   if (stats) stats->n_used = L1 - L0, stats->D = c->D;
