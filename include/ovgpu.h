@@ -255,6 +255,14 @@ int ovgpu_triangulate(ovgpu_ctx *ctx, double *p_FinA, double *p_FinG,
  * resident) until the next ovgpu_set_state.                                                                      */
 int ovgpu_set_camera_poses(ovgpu_ctx *ctx, int C, int K, const double *R_GtoC, const double *p_CinG);
 
+/* Reads back what the triangulation stage of the LAST pipeline call on the current features left on the device
+ * (ovgpu_msckf_compress / _update / ovgpu_slam_delayed_init triangulate internally): p_FinA / p_FinG (3 doubles per
+ * feature) and the anchor measurement index, the values the reference stores on the Feature
+ * (FeatureInitializer.cpp:45-46, :109-110, :333-335).  Saves the separate ovgpu_triangulate call (and the second
+ * triangulation it would cost) when a caller wants both the compressed system and the Feature side effects.
+ * Any pointer may be NULL.  Entries of features that failed triangulation are unspecified. */
+int ovgpu_get_triangulation(ovgpu_ctx *ctx, double *p_FinA, double *p_FinG, int32_t *anchor_meas);
+
 /* Supplies the feature positions instead of triangulating them: the updates that
  * follow (until the next ovgpu_set_features) skip the triangulation stage and use
  * these values.  This is the situation of UpdaterSLAM::update, where the landmark

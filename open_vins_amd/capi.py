@@ -181,6 +181,7 @@ def declare(lib):
         "ovgpu_set_camera_poses": (C.c_int, [ctxp, C.c_int, C.c_int, c_double_p, c_double_p]),
         "ovgpu_set_features": (C.c_int, [ctxp, C.POINTER(FeaturesView)]),
         "ovgpu_triangulate": (C.c_int, [ctxp, c_double_p, c_double_p, c_int32_p, c_int32_p]),
+        "ovgpu_get_triangulation": (C.c_int, [ctxp, c_double_p, c_double_p, c_int32_p]),
         "ovgpu_set_triangulation": (C.c_int, [ctxp, c_double_p, c_double_p, c_int32_p, c_int32_p]),
         "ovgpu_msckf_update": (C.c_int, [ctxp, c_int32_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p,
                                          C.POINTER(UpdateStats)]),

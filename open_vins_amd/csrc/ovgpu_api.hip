@@ -1381,6 +1381,22 @@ int ovgpu_triangulate(ovgpu_ctx *c, double *p_FinA, double *p_FinG, int32_t *anc
   return OVGPU_OK;
 }
 
+int ovgpu_get_triangulation(ovgpu_ctx *c, double *p_FinA, double *p_FinG, int32_t *anchor_meas) {
+  if (!c) return set_err(OVGPU_ERR_INVALID, "null ctx");
+  if (!c->have_state || !c->have_feats) return set_err(OVGPU_ERR_NO_STATE, "state / features not set");
+  HIPCHK(hipSetDevice(c->device));
+  const int F = c->F;
+  hipStream_t s = c->stream;
+  if (F > 0) {
+    if ((p_FinA && !c->pA.p) || (p_FinG && !c->pG.p) || (anchor_meas && !c->anchor.p)) return set_err(OVGPU_ERR_NO_STATE, "no triangulation has run on these features");
+    if (p_FinA) HIPCHK(hipMemcpyAsync(p_FinA, c->pA.p, sizeof(double) * 3 * F, hipMemcpyDeviceToHost, s));
+    if (p_FinG) HIPCHK(hipMemcpyAsync(p_FinG, c->pG.p, sizeof(double) * 3 * F, hipMemcpyDeviceToHost, s));
+    if (anchor_meas) HIPCHK(hipMemcpyAsync(anchor_meas, c->anchor.p, sizeof(int32_t) * F, hipMemcpyDeviceToHost, s));
+  }
+  HIPCHK(hipStreamSynchronize(s));
+  return OVGPU_OK;
+}
+
 int ovgpu_set_triangulation(ovgpu_ctx *c, const double *p_FinA, const double *p_FinG, const int32_t *anchor_meas, const int32_t *status) {
   if (!c || !p_FinG) return set_err(OVGPU_ERR_INVALID, "null argument");
   if (!c->have_state || !c->have_feats) return set_err(OVGPU_ERR_NO_STATE, "state / features not set");

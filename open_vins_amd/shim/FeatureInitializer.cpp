@@ -1,14 +1,16 @@
-// Drop-in replacement for ov_core/src/feat/FeatureInitializer.cpp (rpng/open_vins v2.7): the class of
-// FeatureInitializer.h:40-159 with its single-feature entry points served by libovgpu.
+// Drop-in replacement for ov_core/src/feat/FeatureInitializer.cpp (rpng/open_vins v2.7): the class of FeatureInitializer.h:40-159
+// with its single-feature entry points served by libovgpu.
 //
 // The reference calls these per feature inside loops (UpdaterMSCKF.cpp:117-142, UpdaterSLAM.cpp:113-147,
-// VioManagerHelper.cpp:251-293).  The MSCKF shim does not go through here (it hands the whole batch to
-// ovgpu_msckf_compress); this file keeps the class usable for the remaining callers (delayed_init,
-// retriangulate_active_tracks): one feature = a batch of one.  single_triangulation runs the device triangulation
-// WITHOUT the Gauss-Newton refinement (a context created with refine_features = 0), single_gaussnewton the refinement
-// on top of the position the feature carries, exactly the two-step protocol of the reference.
+// VioManagerHelper.cpp:251-293).  The MSCKF shim does not go through here (it hands the whole batch to the library); this file
+// keeps the class usable for the remaining callers: one feature = a batch of one.  single_triangulation runs the device
+// triangulation WITHOUT the Gauss-Newton refinement (a context with refine_features = 0); single_gaussnewton runs triangulation +
+// refinement in one pass from the same measurements, which reproduces the reference's two-call sequence when — as in every call
+// site of the reference — the refinement follows the triangulation of the same feature (a caller that seeds Feature::p_FinA
+// itself before single_gaussnewton is not supported).  Contexts are keyed by the option values of the calling instance.
 #include "FeatureInitializer.h"
 
+#include <cstring>
 #include <memory>
 #include <stdexcept>
 #include <unordered_map>
@@ -20,25 +22,21 @@
 using namespace ov_core;
 
 namespace {
-struct Contexts {
-  std::unique_ptr<ovgpu_shim::Context> tri, tri1d, full;
-};
-Contexts &contexts(const FeatureInitializerOptions &f) {
-  static Contexts ctx;
-  if (!ctx.tri) {
-    ovgpu_options o;
-    ovgpu_default_options(&o);
-    o.max_runs = f.max_runs, o.init_lamda = f.init_lamda, o.max_lamda = f.max_lamda, o.min_dx = f.min_dx, o.min_dcost = f.min_dcost;
-    o.lam_mult = f.lam_mult, o.min_dist = f.min_dist, o.max_dist = f.max_dist, o.max_baseline = f.max_baseline, o.max_cond_number = f.max_cond_number;
-    o.refine_features = 0, o.triangulate_1d = 0;
-    ctx.tri.reset(new ovgpu_shim::Context(o));
-    o.triangulate_1d = 1;
-    ctx.tri1d.reset(new ovgpu_shim::Context(o));
-    o.triangulate_1d = f.triangulate_1d, o.refine_features = 1;
-    ctx.full.reset(new ovgpu_shim::Context(o));
-  }
-  return ctx;
+ovgpu_shim::Context &context(const FeatureInitializerOptions &f, int refine, int one_d) {
+  ovgpu_options o;
+  std::memset(&o, 0, sizeof(o));
+  ovgpu_default_options(&o);
+  o.max_runs = f.max_runs, o.init_lamda = f.init_lamda, o.max_lamda = f.max_lamda, o.min_dx = f.min_dx, o.min_dcost = f.min_dcost;
+  o.lam_mult = f.lam_mult, o.min_dist = f.min_dist, o.max_dist = f.max_dist, o.max_baseline = f.max_baseline, o.max_cond_number = f.max_cond_number;
+  o.refine_features = refine, o.triangulate_1d = one_d;
+  static std::vector<std::pair<ovgpu_options, std::unique_ptr<ovgpu_shim::Context>>> cache;
+  for (auto &e : cache)
+    if (std::memcmp(&e.first, &o, sizeof(o)) == 0) return *e.second;
+  cache.emplace_back(o, std::unique_ptr<ovgpu_shim::Context>(new ovgpu_shim::Context(o)));
+  return *cache.back().second;
 }
+
+typedef std::unordered_map<size_t, std::unordered_map<double, FeatureInitializer::ClonePose>> ClonesCam;
 
 // flattens clonesCAM (camera id -> clone time -> ClonePose) and one feature; returns false when < 2 usable measurements
 struct OneFeature {
@@ -47,12 +45,11 @@ struct OneFeature {
   ovgpu_shim::FlatFeatures ff;
   int C = 0, K = 0;
 };
-bool flatten(const std::shared_ptr<Feature> &feat, std::unordered_map<size_t, std::unordered_map<double, FeatureInitializer::ClonePose>> &clonesCAM,
-             OneFeature &o) {
+bool flatten(const std::shared_ptr<Feature> &feat, ClonesCam &clonesCAM, OneFeature &o) {
   std::unordered_map<double, int> tindex;
-  for (const auto &cam : clonesCAM) {
+  for (auto &cam : clonesCAM) {
     o.cam_ids.push_back(cam.first);
-    for (const auto &t : cam.second)
+    for (auto &t : cam.second)
       if (!tindex.count(t.first)) tindex[t.first] = (int)o.times.size(), o.times.push_back(t.first);
   }
   o.K = (int)o.cam_ids.size(), o.C = (int)o.times.size();
@@ -60,7 +57,7 @@ bool flatten(const std::shared_ptr<Feature> &feat, std::unordered_map<size_t, st
   std::unordered_map<size_t, int> cindex;
   for (int k = 0; k < o.K; k++) {
     cindex[o.cam_ids[k]] = k;
-    for (const auto &t : clonesCAM.at(o.cam_ids[k])) {
+    for (auto &t : clonesCAM.at(o.cam_ids[k])) { // ClonePose::Rot() / pos() are not const (FeatureInitializer.h:78-81)
       const int i = k * o.C + tindex.at(t.first);
       const Eigen::Matrix<double, 3, 3, Eigen::RowMajor> Rm = t.second.Rot();
       const Eigen::Vector3d pv = t.second.pos();
@@ -79,8 +76,7 @@ bool flatten(const std::shared_ptr<Feature> &feat, std::unordered_map<size_t, st
   return total >= 2;
 }
 
-bool run(ovgpu_shim::Context &ctx, const std::shared_ptr<Feature> &feat,
-         std::unordered_map<size_t, std::unordered_map<double, FeatureInitializer::ClonePose>> &clonesCAM) {
+bool run(ovgpu_shim::Context &ctx, const std::shared_ptr<Feature> &feat, ClonesCam &clonesCAM) {
   OneFeature o;
   if (!flatten(feat, clonesCAM, o)) return false;
   ctx.check(ovgpu_set_camera_poses(ctx.get(), o.C, o.K, o.R.data(), o.p.data()), "ovgpu_set_camera_poses");
@@ -101,15 +97,13 @@ bool run(ovgpu_shim::Context &ctx, const std::shared_ptr<Feature> &feat,
 } // namespace
 
 bool FeatureInitializer::single_triangulation(std::shared_ptr<Feature> feat, std::unordered_map<size_t, std::unordered_map<double, ClonePose>> &clonesCAM) {
-  return run(*contexts(_options).tri, feat, clonesCAM);
+  return run(context(_options, 0, 0), feat, clonesCAM);
 }
 
 bool FeatureInitializer::single_triangulation_1d(std::shared_ptr<Feature> feat, std::unordered_map<size_t, std::unordered_map<double, ClonePose>> &clonesCAM) {
-  return run(*contexts(_options).tri1d, feat, clonesCAM);
+  return run(context(_options, 0, 1), feat, clonesCAM);
 }
 
-// The reference refines the position left in the feature by a preceding single_triangulation call; the device kernel
-// triangulates and refines in one pass from the same measurements, which reproduces that two-call sequence.
 bool FeatureInitializer::single_gaussnewton(std::shared_ptr<Feature> feat, std::unordered_map<size_t, std::unordered_map<double, ClonePose>> &clonesCAM) {
-  return run(*contexts(_options).full, feat, clonesCAM);
+  return run(context(_options, 1, _options.triangulate_1d ? 1 : 0), feat, clonesCAM);
 }

@@ -26,8 +26,12 @@ struct StateAccess {
     s._Cov = Eigen::Map<const Eigen::Matrix<double, Eigen::Dynamic, Eigen::Dynamic, Eigen::RowMajor>>(P_rowmajor, N, N);
     const Eigen::Map<const Eigen::VectorXd> d(dx, N);
     for (auto &var : s._variables) var->update(d.segment(var->id(), var->size())); // :185-187
-    if (s._options.do_calib_camera_intrinsics) // the camera objects carry the intrinsics as well (:191-196)
-      for (auto const &calib : s._cam_intrinsics) s._cam_intrinsics_cameras.at(calib.first)->set_value(calib.second->value());
+    refresh_cameras(s);
+  }
+  // the camera objects carry the intrinsics as well and the trackers undistort through them (StateHelper.cpp:191-196)
+  static void refresh_cameras(ov_msckf::State &s) {
+    if (!s._options.do_calib_camera_intrinsics) return;
+    for (auto const &calib : s._cam_intrinsics) s._cam_intrinsics_cameras.at(calib.first)->set_value(calib.second->value());
   }
 };
 } // namespace ovgpu_shim

@@ -92,6 +92,13 @@ class UpdaterMSCKF:
                    "ovgpu_triangulate")
         return out
 
+    def get_triangulation(self):
+        """What the triangulation stage of the last compress / update / delayed_init left on the device (no second pass)."""
+        F = self.F
+        out = dict(p_FinA=np.zeros((F, 3)), p_FinG=np.zeros((F, 3)), anchor_meas=np.zeros(F, np.int32))
+        capi.check(self.lib.ovgpu_get_triangulation(self._ctx, _dp(out["p_FinA"]), _dp(out["p_FinG"]), _ip(out["anchor_meas"])), "ovgpu_get_triangulation")
+        return out
+
     def set_triangulation(self, p_FinG, p_FinA=None, anchor_meas=None, status=None):
         """Positions supplied by the caller (UpdaterSLAM::update path, stage-wise parity tests)."""
         self._given = [np.ascontiguousarray(p_FinG, dtype=np.float64),

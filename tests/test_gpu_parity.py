@@ -261,6 +261,28 @@ def test_mode_a_compressed_system(Updater, oracle):
     up.close()
 
 
+def test_compress_leaves_the_triangulation_readable(Updater, oracle):
+    """Mode A of the shim: ONE triangulation — ovgpu_msckf_compress runs it, ovgpu_get_triangulation reads back what the Feature
+    objects need (anchor, p_FinA, p_FinG); the values are those of a stand-alone ovgpu_triangulate on the same batch, bit for bit."""
+    prob = synth.make_problem(2, F=120)
+    opts = capi.default_options(chi2_multipler=1.0)
+    up = Updater(opts)
+    up.set_problem(prob)
+    cmp = up.compress()
+    got = up.get_triangulation()
+    up2 = Updater(opts)
+    up2.set_problem(prob)
+    tri = up2.triangulate()
+    ok = tri["status"] == 0
+    assert ok.sum() > 100 and np.array_equal(np.isin(cmp["feat_status"], (0, 4)), ok)  # used or gated out = triangulated
+    np.testing.assert_array_equal(got["anchor_meas"][ok], tri["anchor_meas"][ok])
+    np.testing.assert_array_equal(got["p_FinA"][ok], tri["p_FinA"][ok])
+    np.testing.assert_array_equal(got["p_FinG"][ok], tri["p_FinG"][ok])
+    ref = oracle.triangulate(opts, capi.Views(prob))
+    assert np.abs(got["p_FinG"][ok] - ref["p_FinG"][ok]).max() < TOL_TRI
+    up.close(), up2.close()
+
+
 def test_consecutive_updates_see_the_posterior(Updater, oracle):
     """VioManager calls the updaters back to back on the evolving state (VioManager.cpp:525-547)."""
     prob = synth.make_problem(2, F=60)
