@@ -123,6 +123,11 @@ typedef struct {
                              /* its diagonal entry sends the update through   */
                              /* the Householder route instead (0 = 1e-13:     */
                              /* cond(P_DD) beyond ~1e13) */
+  int32_t feature_kernel_shape; /* MSCKF fast path: 0 = chosen from the longest */
+                             /* track; 1 = 4 wavefronts x 11 gate tiles, 2 = 8 x */
+                             /* 17 (tuning / tests; a shape the batch does not   */
+                             /* fit falls back to the automatic choice)          */
+  int32_t reserved0;         /* keep 0                                        */
 } ovgpu_options;
 
 /* Measurement compression (UpdaterHelper.cpp:456-487) of ovgpu_msckf_update / ovgpu_slam_update:           */

@@ -31,6 +31,10 @@
 //    T = H P and Y = H L as dense 16 x 80 tile products on the matrix cores 0.59 ms (the clone blocks are zero-padded 8x and
 //    FP64 MFMA has no rate advantage over FP64 FMA); calibration part on the matrix cores + clone part on the vector units,
 //    at 2 or at 4 wavefronts per SIMD, 0.48 - 0.54 ms.
+//    Measured alternatives of the gate matrix's tiles (2000 features; the per-lane dot products below: 191 kcycles per workgroup and
+//    update): T chunk x sparse-gathered Jacobian rows on the matrix cores, 4-column steps selected by a per-tile-row bit mask, four
+//    steps in flight: 246 kcycles (each step needs a gathered LDS operand and its own select; the 17 useful steps of a tile do not
+//    amortise the set-up).  Jacobian operands of the T sweep as LDS broadcast reads instead of scalar loads: 391 vs 278 kcycles.
 //  * Work is handed out through an atomic counter, longest tracks first.
 //
 // Restrictions (the host falls back to k_system otherwise): MSCKF features (3 projected columns, no landmark columns), global
@@ -434,7 +438,7 @@ __global__ void __launch_bounds__(64 * NW, OCC)
     k_feat(SysParams p, int nt_max, const double *__restrict__ rowsG, const int32_t *__restrict__ minfoG, const double *__restrict__ VG,
            const double *__restrict__ zG) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int NTH = 64 * NW, MH = NW / 4, CHM = FT_CH / MH, GL = 4; // CHM measurements of a chunk per thread, loaded GL at a time
+  constexpr int NTH = 64 * NW, MH = NW / 4, CHM = FT_CH / MH, GL = CHM < 4 ? CHM : 4; // CHM measurements of a chunk per thread, loaded GL at a time
   static_assert(NW % 4 == 0 && CHM % GL == 0, "wavefronts come in groups of four (one column sweep of 256 threads each)");
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -497,8 +501,20 @@ __global__ void __launch_bounds__(64 * NW, OCC)
     const int32_t *finfo = minfoG + (size_t)8 * m0;
 
     // ------------------------------------------------------------------ (a) LDS copies for the per-lane reads of the gate's tiles: rows, bookkeeping, [r | H_f]
-    for (int e = tid; e < m * RS; e += NTH) rows[e] = frow[e];
-    for (int e = tid; e < 8 * m; e += NTH) minfo[e] = finfo[e];
+    if ((RS & 1) == 0) { // 16-byte copies, four in flight per thread
+      const double2 *src = reinterpret_cast<const double2 *>(frow);
+      double2 *dst = reinterpret_cast<double2 *>(rows);
+      const int n2 = (m * RS) >> 1;
+#pragma unroll 4
+      for (int e = tid; e < n2; e += NTH) dst[e] = src[e];
+    } else {
+      for (int e = tid; e < m * RS; e += NTH) rows[e] = frow[e];
+    }
+    {
+      const int4 *src = reinterpret_cast<const int4 *>(finfo);
+      int4 *dst = reinterpret_cast<int4 *>(minfo);
+      for (int e = tid; e < 2 * m; e += NTH) dst[e] = src[e];
+    }
     for (int i = tid; i < 8 * NT; i += NTH) {
       double *q0 = rhs + (size_t)8 * i;
       if (i < m) {

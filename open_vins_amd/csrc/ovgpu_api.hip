@@ -197,6 +197,7 @@ struct ovgpu_ctx {
   DevBuf<double> chol_uinv;    // [2][16][256]
   int chol_slot = 0;
   bool no_chol_pipe = false;   // options.no_single_launch_cholesky
+  int feat_shape = 0;          // options.feature_kernel_shape
   int Lw_D = -1;               // column count c->Lw was zeroed for (its upper triangle stays zero)
   DevBuf<long long> dbg_cycles; // ovgpu_debug_cycles: per-phase cycle counters of workgroup 0 of the per-feature kernel
   int tsqr_workers = 0;         // options.tsqr_workers
@@ -403,6 +404,7 @@ int ovgpu_create(const ovgpu_options *opts, int device, ovgpu_ctx **out) {
   c->leaf_blocked = opts->tsqr_leaf_blocked != 0;
   c->no_feat_kernel = opts->no_fast_feature_kernel != 0;
   c->no_chol_pipe = opts->no_single_launch_cholesky != 0;
+  c->feat_shape = opts->feature_kernel_shape;
   if (hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_cf, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_cj, hipEventDisableTiming) != hipSuccess)
     c->no_chol_pipe = true;
@@ -693,12 +695,14 @@ static int set_row_layout(ovgpu_ctx *c, bool slam_rows) {
   c->feat_variant = 0;
   if (!slam_rows && !c->no_feat_kernel && c->dopt.feat_rep < OVGPU_REP_ANCHORED_3D && c->L == 0 && m_max >= 2 && c->K * c->C <= 8192 && c->D >= 16) {
     const int nt = (2 * m_max + 15) / 16, tiles = nt * (nt + 1) / 2 + nt;
-    // 1: <4 wavefronts, 11 tiles each>, two workgroups per CU; 2: <8, 17>, one per CU
-    const int variant = tiles <= 4 * 11 ? 1 : (tiles <= 8 * 17 ? 2 : 0);
+    // 1: <4 wavefronts, 11 tiles each>; 2: <8, 17> (one workgroup per CU: 256 registers per lane); up to two workgroups per CU
+    int variant = tiles <= 4 * 11 ? 1 : (tiles <= 8 * 17 ? 2 : 0);
+    if (c->feat_shape == 1 && tiles <= 4 * 11) variant = 1;
+    if (c->feat_shape == 2 && tiles <= 8 * 17) variant = 2;
     if (variant) {
       const feat::FeatLds lo = feat::feat_lds_layout(m_max, c->row_stride, c->D, c->LD, c->K * c->C, nt);
       if (lo.total <= (size_t)c->lds_limit) {
-        const int per_cu = std::max(1, std::min(variant == 1 ? 2 : 1, (int)((size_t)c->lds_limit / lo.total)));
+        const int per_cu = std::max(1, std::min(2, (int)((size_t)c->lds_limit / lo.total)));
         c->feat_variant = variant, c->feat_nt_max = nt, c->feat_lds = lo.total;
         c->feat_grid = std::max(1, std::min(F, c->num_cu * per_cu));
         if (feat::feat_qr_lds_per_wave(m_max, c->LD, c->K * c->C) * 4 > (size_t)c->lds_limit) c->feat_variant = 0;

@@ -54,7 +54,7 @@ def test_struct_layouts_match_header(tmp_path):
         assert int(got[cname]) == C.sizeof(cls), cname
         for fname, _ in cls._fields_:
             assert int(got[f"{cname}.{fname}"]) == getattr(cls, fname).offset, f"{cname}.{fname}"
-    assert C.sizeof(capi.Options) == 2 * 8 + 4 * 4 + 9 * 8 + 4 * 4 + 10 * 4 + 8
+    assert C.sizeof(capi.Options) == 2 * 8 + 4 * 4 + 9 * 8 + 4 * 4 + 10 * 4 + 8 + 2 * 4
 
 
 def test_default_options_are_the_reference_defaults():

@@ -709,14 +709,22 @@ def test_slam_update_parity_representations(Updater, oracle, rep):
     up.close()
 
 
-def _check_delayed_init(out, ref, post):
+def _check_delayed_init(out, ref, post, prob=None, tri=None):
     assert np.array_equal(out["feat_status"], ref["feat_status"])
     gate = np.isfinite(ref["chi2"])
     np.testing.assert_allclose(out["chi2"][gate], ref["chi2"][gate], rtol=1e-7)
     np.testing.assert_allclose(out["chi2_thresh"][gate], ref["chi2_thresh"][gate], rtol=1e-12)
     assert out["N"] == ref["N"] and np.array_equal(out["lm_cov_id"], ref["lm_cov_id"])
     acc = ref["lm_cov_id"] >= 0
-    assert np.array_equal(out["anchor_cam"], ref["anchor_cam"]) and np.array_equal(out["anchor_clone"], ref["anchor_clone"])
+    # anchored landmarks report their anchor; every other feature the anchor of its triangulation (FeatureInitializer.cpp:36-46
+    # writes it into the Feature for every representation; UpdaterSLAM.cpp:214 takes Landmark::_unique_camera_id from it)
+    anchored = ref["anchor_cam"] >= 0
+    assert np.array_equal(out["anchor_cam"][anchored], ref["anchor_cam"][anchored]) and np.array_equal(out["anchor_clone"][anchored], ref["anchor_clone"][anchored])
+    if prob is not None and tri is not None:
+        am = tri["anchor_meas"]
+        want_cam = np.where(am >= 0, prob.cam_idx[np.maximum(am, 0)], -1)
+        want_clone = np.where(am >= 0, prob.clone_idx[np.maximum(am, 0)], -1)
+        assert np.array_equal(out["anchor_cam"][~anchored], want_cam[~anchored]) and np.array_equal(out["anchor_clone"][~anchored], want_clone[~anchored])
     np.testing.assert_allclose(out["lm_value"][acc], ref["lm_value"][acc], rtol=1e-8, atol=1e-10)
     np.testing.assert_allclose(out["lm_fej"][acc], ref["lm_fej"][acc], rtol=1e-12, atol=1e-14)
     assert np.isnan(out["lm_value"][~acc]).all()
@@ -744,7 +752,7 @@ def test_delayed_init_parity(Updater, oracle, rep):
     up.set_triangulation(tri["p_FinG"], tri["p_FinA"], tri["anchor_meas"], tri["status"])
     out = up.delayed_init(rep)
     post = up.get_state(P=True)
-    _check_delayed_init(out, ref, post)
+    _check_delayed_init(out, ref, post, prob, tri)
     assert post["P"].shape == out["P"].shape and np.array_equal(post["P"], out["P"])
     lm = up.get_landmarks()
     assert np.array_equal(lm["cov_id"], ref["lm_cov_id"][acc]) and np.array_equal(lm["value"], out["lm_value"][acc])

@@ -26,4 +26,9 @@ up.lib.ovgpu_debug_cycles(up._ctx, 0, cyc)
 c = list(cyc[300:305])
 if c[2]:
     print(f"k_chol_pipe per call: factor WG {c[0] / c[2] / 1e3:.1f} kcyc (diag phase {c[1] / c[2] / 1e3:.1f}), follower WG 1 {c[3] / c[2] / 1e3:.1f} kcyc (waiting {c[4] / c[2] / 1e3:.1f})")
+ph = list(cyc[200:211])
+if sum(ph):
+    tot = sum(ph)
+    names = {0: "copy", 3: "T sweep", 4: "S0 tiles", 5: "diag factor", 6: "row panel", 7: "trailing", 8: "chi2", 10: "tail"}
+    print("k_feat workgroup 0 phases (% of its cycles):", ", ".join(f"{names.get(i, i)} {100 * v / tot:.1f}" for i, v in enumerate(ph) if v), f"| total {tot / (n + 1) / 1e3:.0f} kcyc per update")
 up.close()

@@ -1,19 +1,29 @@
 #!/bin/bash
-# Round-end measurement on the GPU box: full GPU test suite, smoke, bench (1 GPU), rocprofv3 kernel stats and the two PMC
-# passes of the same bench command.  Everything lands under gpurun_out/final/ (copied to profiles/ by hand afterwards).
+# Round-end measurement on the GPU box: full GPU test suite, smoke, bench (1 GPU), rocprofv3 kernel stats and the PMC passes of
+# the same bench command.  Everything lands under gpurun_out/final/; the text summaries are copied to profiles/ by hand.
 set -u
-OUT=/root/repo/gpurun_out/final
+TAG=${1:-final}
+OUT=/root/repo/gpurun_out/$TAG
 mkdir -p $OUT
 cd /root/repo
-timeout 600 python -m pytest tests -q -m gpu 2>&1 | tail -12 > $OUT/pytest_gpu.txt
-timeout 120 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.txt 2>&1
-timeout 120 python bench.py > $OUT/bench.json 2> $OUT/bench.err
-timeout 60 python bench.py --features 10000 --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_10k.json 2>> $OUT/bench.err
-timeout 60 python bench.py --features 2000 --steps 10 --warmup 2 --no-cpu-baseline > $OUT/bench_2k.json 2>> $OUT/bench.err
-OVGPU_COMPRESS=tsqr timeout 60 python bench.py --steps 20 --warmup 3 --no-cpu-baseline > $OUT/bench_tsqr.json 2>> $OUT/bench.err
-OVGPU_COMPRESS=cholqr timeout 60 python bench.py --steps 20 --warmup 3 --no-cpu-baseline > $OUT/bench_cholqr.json 2>> $OUT/bench.err
+if [ "${SKIP_TESTS:-0}" != 1 ]; then
+  timeout 900 python -m pytest tests -q -m gpu -p no:cacheprovider 2>&1 | tail -12 > $OUT/pytest_gpu.txt
+  timeout 120 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.txt 2>&1
+fi
+timeout 300 python bench.py > $OUT/bench.json 2> $OUT/bench.err
+timeout 120 python bench.py --cfg 2 --steps 50 --warmup 5 --no-cpu-baseline --no-extras > $OUT/bench_cfg2.json 2>> $OUT/bench.err
+timeout 120 python bench.py --cfg 4 --steps 10 --warmup 2 --no-cpu-baseline --no-extras > $OUT/bench_cfg4_one_gpu.json 2>> $OUT/bench.err
+timeout 120 python bench.py --route tsqr --steps 20 --warmup 3 --no-cpu-baseline --no-extras > $OUT/bench_tsqr.json 2>> $OUT/bench.err
 cd /tmp && export TMPDIR=/tmp
-timeout 120 rocprofv3 --kernel-trace --stats -d $OUT/prof_stats -o s -- python /root/repo/bench.py --steps 20 --warmup 5 --no-cpu-baseline > /dev/null 2>&1
-timeout 120 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/prof_fetch -o f -- python /root/repo/bench.py --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
-timeout 120 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/prof_write -o w -- python /root/repo/bench.py --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
-cat $OUT/pytest_gpu.txt; cat $OUT/smoke.txt | tail -2; cut -c1-400 $OUT/bench.json; echo; cut -c1-250 $OUT/bench_10k.json; echo; cut -c1-250 $OUT/bench_tsqr.json; echo; ls -R $OUT | head -30
+B="python /root/repo/bench.py --no-cpu-baseline --no-extras"
+timeout 180 rocprofv3 --kernel-trace --stats -d $OUT/prof_stats -o s -- $B --steps 20 --warmup 5 > /dev/null 2>&1
+timeout 180 rocprofv3 --kernel-trace --stats -d $OUT/prof_stats2 -o s -- $B --cfg 2 --steps 20 --warmup 5 > /dev/null 2>&1
+timeout 180 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/prof_fetch -o f -- $B --steps 5 --warmup 2 > /dev/null 2>&1
+timeout 180 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/prof_write -o w -- $B --steps 5 --warmup 2 > /dev/null 2>&1
+timeout 180 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY -d $OUT/prof_sq1 -o q -- $B --steps 5 --warmup 2 > /dev/null 2>&1
+timeout 180 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_SALU -d $OUT/prof_sq2 -o q -- $B --steps 5 --warmup 2 > /dev/null 2>&1
+cd /root/repo
+for d in prof_stats prof_stats2; do f=$(find $OUT/$d -name "*.db" | head -1); [ -n "$f" ] && python tools/prof_summary.py $f $d > $OUT/${d}.txt; done
+for d in prof_fetch prof_write prof_sq1 prof_sq2; do f=$(find $OUT/$d -name "*.db" | head -1); [ -n "$f" ] && python tools/pmc_summary.py $f $d > $OUT/${d}.txt; done
+find $OUT -name "*.db" -size +20M -delete
+cat $OUT/pytest_gpu.txt 2>/dev/null; tail -2 $OUT/smoke.txt 2>/dev/null; cut -c1-600 $OUT/bench.json; echo; cut -c1-250 $OUT/bench_cfg2.json; echo; cut -c1-250 $OUT/bench_cfg4_one_gpu.json; echo; head -20 $OUT/prof_stats.txt
