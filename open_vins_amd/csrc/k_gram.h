@@ -8,6 +8,16 @@
 //                  keeps the upper triangle of the 16x16-tile grid of G in accumulator registers, 34 tiles per wavefront;
 //   k_gram_reduce  sums the per-workgroup partials in a fixed order (no atomics: the result is reproducible bit for bit).
 //
+// Measured alternatives (2000 features x 30 clones x 2 cameras, 194 k rows x 209 columns; k_feat_out 0.19 ms + k_gram 0.22 ms):
+//   * the projected rows produced inside this kernel instead of staged from HBM (k_feat_out fused in; all wavefronts produce then
+//     accumulate / 4 + 4 / 8 + 4 role-specialised wavefronts; Jacobian operands as scalar loads or as LDS broadcasts):
+//     0.43 - 0.57 ms.  v_mfma_f64 and v_fma_f64 share the FP64 datapath of a SIMD, so producer and accumulator wavefronts take
+//     turns instead of overlapping, and at one or two producer wavefronts per SIMD nothing hides the producer's own latencies
+//     (k_feat_out runs eight per SIMD).
+//   * 12 wavefronts (8 accumulating with 13-17 tiles each + 4 staging, 168 registers): 0.46 ms — the accumulator tiles of the
+//     eight per-wavefront instantiations no longer fit next to their operands, and spill reloads inside the k-step loop stall the
+//     matrix cores.  This kernel's 27-34 tiles per wavefront need 172 + 256 registers: one wavefront per SIMD, by design.
+//
 // The default route feeds G straight into the EKF update written in coordinates whitened by the prior (k_ekf.h,
 // "EKF update from the Gram matrix"): no factor of G is ever formed.  Across GPUs Gram matrices simply add (one all-reduce).
 //
