@@ -488,6 +488,12 @@ int ovgpu_state_augment_clone(ovgpu_ctx *ctx, int32_t src_cov_id, const double *
 int ovgpu_state_propagate(ovgpu_ctx *ctx, int32_t new_cov_id, int32_t n_new, int32_t n_old,
                           const int32_t *old_cov_ids, const double *Phi, const double *Q);
 
+/* StateHelper::get_marginal_covariance (StateHelper.cpp:226-258) on the RESIDENT covariance:
+ * out [n x n, row-major] = P restricted to the covariance indices cov_idx [n] (any order, e.g. the dofs of
+ * the variables of an H_order).  UpdaterZeroVelocity's chi2 test (UpdaterZeroVelocity.cpp:193-203) reads the
+ * IMU orientation / bias block this way.                                                                   */
+int ovgpu_state_marginal_covariance(ovgpu_ctx *ctx, int32_t n, const int32_t *cov_idx, double *out);
+
 /* Current dimension of the resident covariance and number of resident clones. */
 int ovgpu_state_dims(ovgpu_ctx *ctx, int32_t *N_out, int32_t *C_out);
 
@@ -518,6 +524,26 @@ int ovgpu_tracks_erase(ovgpu_ctx *ctx, int32_t n, const int64_t *featid);
  * MSCKF features, VioManager.cpp:366-378).  ids [capacity], n_out = how many there are.       */
 int ovgpu_tracks_not_containing_newer(ovgpu_ctx *ctx, double timestamp, int32_t capacity,
                                       int64_t *ids, int32_t *n_out);
+
+/* ---- VioManager::retriangulate_active_tracks (VioManagerHelper.cpp:190-387), SURVEY.md row N4 -------------
+ * The running linear triangulation of the tracks alive in the newest frame.  Per call = per camera frame:
+ * the n newest observations (TrackBase::get_last_obs / get_last_ids), grouped by camera in the order of
+ * CameraData::sensor_ids, WITHOUT the features that are SLAM landmarks (:248-250: the state estimate takes
+ * priority; the caller appends those from the state, :311-327).  cam_id = camera INDEX of the state view,
+ * uv = distorted pixel, uvn = CamBase::undistort_cv of it, clone_index = the clone of the frame (:199).
+ * The library keeps A, b and the observation count of every track on the device between calls
+ * (active_feat_linsys_*, VioManager.h); tracks that are not in this call are dropped (:305-309).
+ * Outputs, one entry per distinct track in order of first appearance: out_featid, out_p_FinG (3 doubles, NaN
+ * until the track has more than three observations and passes the condition-number / depth checks, :275-299)
+ * and out_uvd (pixel in cam0 and depth in the current cam0 frame, NaN unless the track is triangulated, seen
+ * by camera index cam0 in this frame, has depth >= 0.1 and lies inside img_w x img_h, :345-379; cam0 = -1:
+ * never).  Arrays of capacity n.  max_cond_number / min_dist / max_dist come from the context's options. */
+int ovgpu_retriangulate(ovgpu_ctx *ctx, int32_t clone_index, int32_t n, const int64_t *featid,
+                        const int32_t *cam_id, const float *uv, const float *uvn, int32_t cam0,
+                        int32_t img_w, int32_t img_h, int32_t *n_tracks, int64_t *out_featid,
+                        double *out_p_FinG, double *out_uvd);
+/* Forgets every running system (a reset of the front end). */
+int ovgpu_retriangulate_reset(ovgpu_ctx *ctx);
 
 /* Number of live tracks. */
 int ovgpu_tracks_count(ovgpu_ctx *ctx, int32_t *n_tracks);

@@ -24,6 +24,7 @@ COMPRESS_GRAM, COMPRESS_TSQR, COMPRESS_CHOLQR = 0, 1, 2
 
 c_double_p = C.POINTER(C.c_double)
 c_float_p = C.POINTER(C.c_float)
+c_int64_p = C.POINTER(C.c_int64)
 c_int32_p = C.POINTER(C.c_int32)
 c_uint8_p = C.POINTER(C.c_uint8)
 
@@ -182,6 +183,10 @@ def declare(lib):
         "ovgpu_set_camera_poses": (C.c_int, [ctxp, C.c_int, C.c_int, c_double_p, c_double_p]),
         "ovgpu_set_features": (C.c_int, [ctxp, C.POINTER(FeaturesView)]),
         "ovgpu_triangulate": (C.c_int, [ctxp, c_double_p, c_double_p, c_int32_p, c_int32_p]),
+        "ovgpu_state_marginal_covariance": (C.c_int, [ctxp, C.c_int32, c_int32_p, c_double_p]),
+        "ovgpu_retriangulate": (C.c_int, [ctxp, C.c_int32, C.c_int32, c_int64_p, c_int32_p, c_float_p, c_float_p, C.c_int32, C.c_int32, C.c_int32, c_int32_p,
+                                          c_int64_p, c_double_p, c_double_p]),
+        "ovgpu_retriangulate_reset": (C.c_int, [ctxp]),
         "ovgpu_get_triangulation": (C.c_int, [ctxp, c_double_p, c_double_p, c_int32_p]),
         "ovgpu_set_triangulation": (C.c_int, [ctxp, c_double_p, c_double_p, c_int32_p, c_int32_p]),
         "ovgpu_msckf_update": (C.c_int, [ctxp, c_int32_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p,

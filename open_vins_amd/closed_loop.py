@@ -28,14 +28,18 @@ def _rot(q):
 class Stream:
     """Truth, tracks and noise of one closed-loop run; identical for every updater under test."""
 
-    def __init__(self, C=12, feats_per_frame=50, seed=7, sigma_px=1.0, q_theta=np.deg2rad(0.15), q_p=0.01):
+    def __init__(self, C=12, feats_per_frame=50, seed=7, sigma_px=1.0, q_theta=np.deg2rad(0.15), q_p=0.01, T=None):
         rng = np.random.default_rng(seed)
-        traj = synth.load_traj_window()
-        self.T = traj.shape[0]
-        q = traj[:, 4:8].copy()
-        q[q[:, 3] < 0] *= -1
-        q /= np.linalg.norm(q, axis=1, keepdims=True)
-        self.truth = np.hstack([q, traj[:, 1:4]])
+        if T is None:
+            traj = synth.load_traj_window()
+            self.T = traj.shape[0]
+            q = traj[:, 4:8].copy()
+            q[q[:, 3] < 0] *= -1
+            q /= np.linalg.norm(q, axis=1, keepdims=True)
+            self.truth = np.hstack([q, traj[:, 1:4]])
+        else:
+            self.T = T
+            self.truth = _analytic_trajectory(T)
         self.C = C
         Tm = np.asarray(synth._T_IMU_CAM[0])
         R_CtoI, p_CinI = Tm[:, :3], Tm[:, 3]
@@ -75,6 +79,21 @@ class Stream:
                 if len(obs) >= 5:
                     self.tracks[t_use].append(obs)
                     made += 1
+
+
+def _analytic_trajectory(T, dt=0.1):
+    """A long smooth trajectory for closed loops beyond the 64-pose fixture: ~1 m/s on a 4 m circle with a vertical wobble, yawing
+    with the motion, roll / pitch of a few degrees.  Rows [q_GtoI (JPL), p_IinG] like the fixture."""
+    out = np.zeros((T, 7))
+    for i in range(T):
+        t = dt * i
+        yaw, pitch, roll = 0.25 * t, 0.08 * np.sin(0.9 * t), 0.06 * np.cos(0.7 * t)
+        cz, sz, cy, sy, cx, sx = np.cos(yaw), np.sin(yaw), np.cos(pitch), np.sin(pitch), np.cos(roll), np.sin(roll)
+        R_ItoG = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]]) @ np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]]) @ np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
+        q = synth.rot_2_quat(R_ItoG.T)
+        out[i, :4] = -q if q[3] < 0 else q
+        out[i, 4:] = [4.0 * np.cos(0.25 * t), 4.0 * np.sin(0.25 * t), 1.0 + 0.3 * np.sin(0.6 * t)]
+    return out
 
 
 def _compose(last_est, truth_last, truth_new):

@@ -86,6 +86,12 @@ __global__ void k_cov_copy(int n, int nd, const double *__restrict__ src, int ld
 // ---------------------------------------------------------------------------------------------------
 // StateHelper::marginalize (StateHelper.cpp:271-339): dst = src without rows / columns [id, id + size).  The lower-left block is
 // the transpose of the upper-right one, as in the reference (:303-304).
+// StateHelper::get_marginal_covariance (StateHelper.cpp:226-258): out[i][j] = P[idx[i]][idx[j]]
+__global__ void k_cov_gather(int N, int n, const int32_t *__restrict__ idx, const double *__restrict__ P, double *__restrict__ out) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n * n) out[t] = P[(size_t)idx[t / n] * N + idx[t % n]];
+}
+
 __global__ void k_cov_remove(int N, int id, int size, const double *__restrict__ src, double *__restrict__ dst) {
   const int Nn = N - size;
   const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;

@@ -29,6 +29,7 @@
 #include "k_feat.h"
 #include "k_chol.h"
 #include "k_triangulate.h"
+#include "k_retri.h"
 #include "ovgpu_types.h"
 
 using namespace ovg;
@@ -124,6 +125,13 @@ struct ovgpu_ctx {
   DevBuf<double> trk_time, trk_clone_times;
   DevBuf<float> trk_uv, trk_uvn, trk_uv_in, trk_uvn_in;
   std::unordered_map<int64_t, int32_t> trk_slot_of;
+  // ovgpu_retriangulate: the running linear systems of the active tracks, two generations (k_retri.h)
+  std::unordered_map<int64_t, int32_t> retri_slot_of;
+  DevBuf<double> retri_sys[2], retri_pos, retri_uvd;
+  DevBuf<int32_t> retri_int, marg_idx;
+  DevBuf<double> marg_out;
+  DevBuf<float> retri_f;
+  int retri_gen = 0;
   std::vector<int32_t> trk_free, trk_h_count;
   std::vector<double> trk_h_last;
   std::vector<int64_t> trk_h_id;
@@ -441,6 +449,7 @@ void ovgpu_destroy(ovgpu_ctx *c) {
   c->clone_cov.release(), c->calib_cov.release(), c->intr_cov.release(), c->clone_col.release(), c->calib_col.release();
   c->intr_col.release(), c->col_cov.release(), c->col_kind.release(), c->col_sub.release(), c->col_var.release();
   c->tab_clone.release(), c->tab_cam.release(), c->tab_cc.release();
+  c->retri_sys[0].release(), c->retri_sys[1].release(), c->retri_pos.release(), c->retri_uvd.release(), c->retri_int.release(), c->retri_f.release(), c->marg_idx.release(), c->marg_out.release();
   c->meas_offsets.release(), c->meas_cc.release(), c->uv.release(), c->uvn.release(), c->row_off.release();
   c->pA.release(), c->pG.release(), c->chi2.release(), c->chi2_thr.release(), c->anchor.release(), c->status.release(), c->sys_order.release(), c->feat_sigma.release(), c->feat_mult.release();
   c->chi2_table.release(), c->Hbig.release(), c->gate_ws.release(), c->Rws.release(), c->tree_nodes.release(), c->tree_nodes2.release(), c->tree_flags.release(), c->tree_err.release(), c->Mt.release(), c->Aaug.release(), c->Yaug.release();
@@ -1956,6 +1965,23 @@ int ovgpu_state_dims(ovgpu_ctx *c, int32_t *N_out, int32_t *C_out) {
   return OVGPU_OK;
 }
 
+int ovgpu_state_marginal_covariance(ovgpu_ctx *c, int32_t n, const int32_t *cov_idx, double *out) {
+  if (!c || !cov_idx || !out) return set_err(OVGPU_ERR_INVALID, "null argument");
+  if (!c->have_state || c->poses_only) return set_err(OVGPU_ERR_NO_STATE, "ovgpu_set_state was never called");
+  if (n < 1 || n > 1024) return set_err(OVGPU_ERR_INVALID, "1 .. 1024 covariance indices");
+  for (int i = 0; i < n; i++)
+    if (cov_idx[i] < 0 || cov_idx[i] >= c->N) return set_err(OVGPU_ERR_INVALID, "covariance index outside the state");
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(c->marg_idx.reserve(n));
+  HIPCHK(c->marg_out.reserve((size_t)n * n));
+  HIPCHK(upload(c->marg_idx.p, cov_idx, sizeof(int32_t) * n, c->stream));
+  hipLaunchKernelGGL(k_cov_gather, dim3((n * n + 255) / 256), dim3(256), 0, c->stream, c->N, n, c->marg_idx.p, c->P.p, c->marg_out.p);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(out, c->marg_out.p, sizeof(double) * n * n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return OVGPU_OK;
+}
+
 int ovgpu_state_marginalize(ovgpu_ctx *c, int32_t cov_id, int32_t size) {
   if (!c) return set_err(OVGPU_ERR_INVALID, "null ctx");
   c->prior_pending = false; // the covariance changes: a prior-block factorisation started for a sharded update is stale
@@ -2143,6 +2169,84 @@ int ovgpu_tracks_create(ovgpu_ctx *c, int32_t max_tracks, int32_t max_obs) {
   c->trk_free.resize(max_tracks);
   for (int i = 0; i < max_tracks; i++) c->trk_free[i] = max_tracks - 1 - i; // slot 0 is handed out first
   c->trk_h_count.assign(max_tracks, 0), c->trk_h_last.assign(max_tracks, 0.0), c->trk_h_id.assign(max_tracks, -1);
+  return OVGPU_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// VioManager::retriangulate_active_tracks (VioManagerHelper.cpp:190-387)
+// ---------------------------------------------------------------------------------------------------
+int ovgpu_retriangulate_reset(ovgpu_ctx *c) {
+  if (!c) return set_err(OVGPU_ERR_INVALID, "null ctx");
+  c->retri_slot_of.clear();
+  return OVGPU_OK;
+}
+
+int ovgpu_retriangulate(ovgpu_ctx *c, int32_t clone_index, int32_t n, const int64_t *featid, const int32_t *cam_id, const float *uv, const float *uvn,
+                        int32_t cam0, int32_t img_w, int32_t img_h, int32_t *n_tracks, int64_t *out_featid, double *out_p_FinG, double *out_uvd) {
+  if (!c || !n_tracks) return set_err(OVGPU_ERR_INVALID, "null argument");
+  if (!c->have_state) return set_err(OVGPU_ERR_NO_STATE, "ovgpu_set_state (or ovgpu_set_camera_poses) was never called");
+  if (n < 0 || (n > 0 && (!featid || !cam_id || !uv || !uvn || !out_featid || !out_p_FinG || !out_uvd))) return set_err(OVGPU_ERR_INVALID, "bad observation arrays");
+  if (clone_index < 0 || clone_index >= c->C) return set_err(OVGPU_ERR_INVALID, "clone_index outside the window");
+  if (cam0 >= c->K) return set_err(OVGPU_ERR_INVALID, "cam0 is not a camera of the state");
+  HIPCHK(hipSetDevice(c->device));
+  // ---- group the frame's observations by track, in order of first appearance; observations of a track keep the frame's camera order
+  std::unordered_map<int64_t, int32_t> slot_now;
+  std::vector<int64_t> ids;
+  std::vector<int32_t> tr_of(n);
+  for (int i = 0; i < n; i++) {
+    if (cam_id[i] < 0 || cam_id[i] >= c->K) return set_err(OVGPU_ERR_INVALID, "camera index outside the state's cameras");
+    auto it = slot_now.find(featid[i]);
+    if (it == slot_now.end()) it = slot_now.emplace(featid[i], (int32_t)ids.size()).first, ids.push_back(featid[i]);
+    tr_of[i] = it->second;
+  }
+  const int T = (int)ids.size();
+  *n_tracks = T;
+  if (T == 0) { // no track is alive: every system is dropped (:305-309)
+    c->retri_slot_of.clear();
+    return OVGPU_OK;
+  }
+  std::vector<int32_t> ints((size_t)(T + 1) + n + T, 0); // obs_off | obs_cam | old_slot
+  int32_t *off = ints.data(), *ocam = off + T + 1, *old = ocam + n;
+  for (int i = 0; i < n; i++) off[tr_of[i] + 1]++;
+  for (int t = 0; t < T; t++) off[t + 1] += off[t];
+  std::vector<int32_t> fill(off, off + T);
+  std::vector<float> fl((size_t)4 * n);
+  for (int i = 0; i < n; i++) {
+    const int j = fill[tr_of[i]]++;
+    ocam[j] = cam_id[i];
+    fl[2 * j] = uv[2 * i], fl[2 * j + 1] = uv[2 * i + 1];
+    fl[(size_t)2 * n + 2 * j] = uvn[2 * i], fl[(size_t)2 * n + 2 * j + 1] = uvn[2 * i + 1];
+  }
+  for (int t = 0; t < T; t++) {
+    auto it = c->retri_slot_of.find(ids[t]);
+    old[t] = it == c->retri_slot_of.end() ? -1 : it->second;
+  }
+  const int g = c->retri_gen;
+  HIPCHK(c->retri_sys[g ^ 1].reserve((size_t)13 * T));
+  HIPCHK(c->retri_sys[g].reserve(13));
+  HIPCHK(c->retri_pos.reserve((size_t)3 * T));
+  HIPCHK(c->retri_uvd.reserve((size_t)3 * T));
+  HIPCHK(c->retri_int.reserve(ints.size()));
+  HIPCHK(c->retri_f.reserve(fl.size()));
+  hipStream_t s = c->stream;
+  HIPCHK(upload(c->retri_int.p, ints.data(), sizeof(int32_t) * ints.size(), s));
+  HIPCHK(upload(c->retri_f.p, fl.data(), sizeof(float) * fl.size(), s));
+  RetriParams p;
+  p.n_tracks = T, p.C = c->C, p.clone = clone_index;
+  p.obs_off = c->retri_int.p, p.obs_cam = c->retri_int.p + T + 1, p.old_slot = c->retri_int.p + T + 1 + n;
+  p.obs_uv = c->retri_f.p, p.obs_uvn = c->retri_f.p + (size_t)2 * n;
+  p.old_sys = c->retri_sys[g].p, p.new_sys = c->retri_sys[g ^ 1].p, p.tab_cc = c->tab_cc.p;
+  p.cam0 = cam0, p.img_w = img_w, p.img_h = img_h;
+  p.max_cond = c->dopt.max_cond_number, p.min_dist = c->dopt.min_dist, p.max_dist = c->dopt.max_dist;
+  p.out_pos = c->retri_pos.p, p.out_uvd = c->retri_uvd.p;
+  hipLaunchKernelGGL(k_retriangulate, dim3((T + 255) / 256), dim3(256), 0, s, p);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(out_p_FinG, c->retri_pos.p, sizeof(double) * 3 * T, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipMemcpyAsync(out_uvd, c->retri_uvd.p, sizeof(double) * 3 * T, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  std::copy(ids.begin(), ids.end(), out_featid);
+  c->retri_gen = g ^ 1;
+  c->retri_slot_of.swap(slot_now); // only the tracks of this frame stay alive
   return OVGPU_OK;
 }
 

@@ -99,6 +99,25 @@ class UpdaterMSCKF:
         capi.check(self.lib.ovgpu_get_triangulation(self._ctx, _dp(out["p_FinA"]), _dp(out["p_FinG"]), _ip(out["anchor_meas"])), "ovgpu_get_triangulation")
         return out
 
+    # ---- VioManager::retriangulate_active_tracks ------------------------
+    def retriangulate(self, clone_index, featid, cam_idx, uv, uvn, cam0=0, img_w=752, img_h=480):
+        """One camera frame of the running linear triangulation of the active tracks (SLAM features left out by the caller)."""
+        featid = np.ascontiguousarray(featid, dtype=np.int64)
+        cam_idx = np.ascontiguousarray(cam_idx, dtype=np.int32)
+        uv = np.ascontiguousarray(uv, dtype=np.float32)
+        uvn = np.ascontiguousarray(uvn, dtype=np.float32)
+        n = len(featid)
+        ids = np.zeros(max(n, 1), np.int64)
+        pos, uvd = np.zeros((max(n, 1), 3)), np.zeros((max(n, 1), 3))
+        nt = C.c_int32(0)
+        capi.check(self.lib.ovgpu_retriangulate(self._ctx, int(clone_index), n, featid.ctypes.data_as(capi.c_int64_p), _ip(cam_idx),
+                                                uv.ctypes.data_as(capi.c_float_p), uvn.ctypes.data_as(capi.c_float_p), int(cam0), int(img_w), int(img_h),
+                                                C.byref(nt), ids.ctypes.data_as(capi.c_int64_p), _dp(pos), _dp(uvd)), "ovgpu_retriangulate")
+        return dict(featid=ids[:nt.value].copy(), p_FinG=pos[:nt.value].copy(), uvd=uvd[:nt.value].copy())
+
+    def retriangulate_reset(self):
+        capi.check(self.lib.ovgpu_retriangulate_reset(self._ctx), "ovgpu_retriangulate_reset")
+
     def set_triangulation(self, p_FinG, p_FinA=None, anchor_meas=None, status=None):
         """Positions supplied by the caller (UpdaterSLAM::update path, stage-wise parity tests)."""
         self._given = [np.ascontiguousarray(p_FinG, dtype=np.float64),
@@ -323,6 +342,28 @@ class UpdaterMSCKF:
         ids = np.ascontiguousarray(old_cov_ids, dtype=np.int32)
         rc = self.lib.ovgpu_state_propagate(self._ctx, int(new_cov_id), Phi.shape[0], Phi.shape[1], _ip(ids), _dp(Phi), _dp(Q))
         capi.check(rc, "ovgpu_state_propagate")
+
+    def marginal_covariance(self, cov_idx):
+        idx = np.ascontiguousarray(cov_idx, dtype=np.int32)
+        out = np.zeros((len(idx), len(idx)))
+        capi.check(self.lib.ovgpu_state_marginal_covariance(self._ctx, len(idx), _ip(idx), _dp(out)), "ovgpu_state_marginal_covariance")
+        return out
+
+    def zupt(self, H, res, cov_idx, Q_bias, noise_mult, chi2_multipler=1.0, apply=True):
+        """The linear algebra of UpdaterZeroVelocity::try_update (UpdaterZeroVelocity.cpp:183-203, :266-277) on the resident state:
+        H [m x 9] over the dofs cov_idx (orientation 3, gyro bias 3, accelerometer bias 3), whitened residual res.  Returns chi2,
+        its threshold and — when it passes and apply is set — dx, P after the bias propagation and the update."""
+        Hc, rc = self.measurement_compress(H, res)                       # :183-186
+        Pm = self.marginal_covariance(cov_idx)                            # :193
+        Pm[3:9, 3:9] += Q_bias                                            # :194-196
+        S = Hc @ Pm @ Hc.T + noise_mult * np.eye(len(rc))                 # :197
+        chi2 = float(rc @ np.linalg.solve(S, rc))                         # :198
+        thr = chi2_multipler * float(self.lib.ovgpu_chi2_quantile_95(len(rc)))  # :201-208
+        out = dict(chi2=chi2, chi2_thresh=thr, rows=len(rc), accepted=chi2 <= thr)
+        if out["accepted"] and apply:
+            self.state_propagate(int(cov_idx[3]), list(cov_idx[3:9]), np.eye(6), Q_bias)  # :268-274
+            out["dx"], out["P"] = self.ekf_update(Hc, rc, cov_idx, noise_mult)           # :277
+        return out
 
     # ---- standalone helpers (UpdaterHelper::measurement_compress_inplace, StateHelper::EKFUpdate) ----
     def measurement_compress(self, H, res):

@@ -76,3 +76,38 @@ def test_resident_window_and_track_store(stream, oracle_run):
     up.close()
     assert res["used"] == oracle_run["used"]
     assert np.abs(res["est"] - oracle_run["est"]).max() < 1e-8
+
+
+@pytest.mark.gpu
+def test_long_loop_with_imu_level_process_noise():
+    """500 consecutive updates with the posterior fed back, process noise at IMU level (5e-5 rad, 1e-5 m per clone step): the window's
+    clones are then correlated to 1e-5 of their prior sigma and cond(P_DD) grows over the run to the values of the conditioning sweep
+    (tests/test_gpu_fullsize.py).  Same stream through the oracle and through the GPU's default (Gram / prior-whitened) route.
+    A gate decision that falls within rounding of its threshold may differ; from there on the two filters see different measurements,
+    so the comparison runs up to the first such frame (and requires it to be late) and bounds the divergence after it."""
+    from open_vins_amd.updater import UpdaterMSCKF
+    stream = closed_loop.Stream(C=12, feats_per_frame=40, seed=11, q_theta=5e-5, q_p=1e-5, T=512)
+    opts = capi.default_options(**OPTS)
+    ref = closed_loop.run(stream, lambda prob: pyoracle.msckf_update(opts, capi.Views(prob)))
+    up = UpdaterMSCKF(opts)
+    routes = []
+
+    def gpu_update(prob):
+        up.set_problem(prob)
+        out = up.update()
+        routes.append(out["route"])
+        return out
+
+    gpu = closed_loop.run(stream, gpu_update)
+    up.close()
+    assert len(ref["used"]) == 500 and np.mean(list(ref["used"].values())) > 25
+    assert all(r == capi.COMPRESS_GRAM for r in routes)            # the prior never failed the pivot test: no Householder fall-back
+    frames = sorted(ref["used"])
+    same = [gpu["used"][t] == ref["used"][t] for t in frames]
+    first_diff = same.index(False) if False in same else len(frames)
+    assert first_diff >= 100, first_diff
+    k = first_diff + (stream.C - 1)                                # index into est (est starts at the last initial clone)
+    assert np.abs(gpu["est"][:k] - ref["est"][:k]).max() < 1e-8
+    assert np.abs(gpu["est"] - ref["est"]).max() < 1e-4            # after a differing gate decision: same filter, one measurement apart
+    a_g, a_o = closed_loop.ate(gpu), closed_loop.ate(ref)
+    assert abs(a_g[0] - a_o[0]) < 1e-4 and abs(a_g[1] - a_o[1]) < 1e-3

@@ -1234,3 +1234,102 @@ def test_track_store_feeds_the_update(Updater, oracle):
     with pytest.raises(RuntimeError):   # a full track refuses the whole call
         up.tracks_append(99.0, np.full(65, 5), np.zeros(65), np.zeros((65, 2)), np.zeros((65, 2)))
     up.close()
+
+
+def test_retriangulation_of_the_active_tracks(Updater):
+    """SURVEY row N4, VioManager::retriangulate_active_tracks (VioManagerHelper.cpp:190-387): nine frames of a stereo rig, tracks
+    entering, missing frames and returning; the device's running systems against the oracle's maps after EVERY frame."""
+    from oracle import retri_oracle
+    from tests.retri_scene import Scene
+    sc = Scene(T=9, n_pts=60, noise=2e-3, p_see=(0.85, 0.7), seed=5)
+    opts = capi.default_options()
+    up = Updater(opts)
+    R, p = sc.pose_table()
+    capi.check(up.lib.ovgpu_set_camera_poses(up._ctx, sc.T, sc.K, R.ctypes.data_as(capi.c_double_p), p.ctypes.data_as(capi.c_double_p)), "ovgpu_set_camera_poses")
+    at = retri_oracle.ActiveTracks(opts.max_cond_number, opts.min_dist, opts.max_dist)
+    n_tri = n_uvd = 0
+    for t in range(sc.T):
+        ref_pos, ref_uvd = at.frame(sc.R_GtoI[t], sc.p_IinG[t], sc.cams(), sc.obs[t], 752, 480)
+        out = up.retriangulate(t, *sc.flat(t), cam0=0, img_w=752, img_h=480)
+        assert sorted(out["featid"].tolist()) == sorted(at.count)                       # exactly the tracks alive in this frame
+        got = {int(f): q for f, q in zip(out["featid"], out["p_FinG"]) if not np.isnan(q[0])}
+        assert set(got) == set(ref_pos)
+        for f, q in got.items():
+            assert np.abs(q - ref_pos[f]).max() < 1e-9 * max(1.0, np.abs(ref_pos[f]).max())
+        guvd = {int(f): q for f, q in zip(out["featid"], out["uvd"]) if not np.isnan(q[0])}
+        assert set(guvd) == set(ref_uvd)
+        for f, q in guvd.items():
+            assert q[0] == ref_uvd[f][0] and q[1] == ref_uvd[f][1] and abs(q[2] - ref_uvd[f][2]) < 1e-9
+        n_tri += len(got)
+        n_uvd += len(guvd)
+    assert n_tri > 100 and n_uvd > 60
+    up.retriangulate_reset()
+    out = up.retriangulate(0, *sc.flat(0))
+    assert np.isnan(out["p_FinG"]).all()                                                 # every system was dropped
+    up.close()
+
+
+def test_zero_velocity_update_algebra(Updater, oracle):
+    """SURVEY row N4: the linear algebra of UpdaterZeroVelocity::try_update (UpdaterZeroVelocity.cpp:100-203, :266-277) on the resident
+    state through the standalone entry points — compression of the whitened IMU system, the chi2 test on the marginal covariance of
+    (orientation, gyro bias, accelerometer bias) with the bias random walk added, bias propagation, EKFUpdate with R = multiplier x I
+    — against the same sequence composed from the oracle's functions."""
+    prob = synth.make_problem(2, F=4)
+    rng = np.random.default_rng(17)
+    n_imu, dt, sig_w, sig_a, sig_wb, sig_ab, mult = 21, 0.005, 1.6968e-4, 2.0e-3, 1.9393e-5, 3.0e-3, 10.0
+    idx = np.r_[0:3, 9:12, 12:15].astype(np.int32)          # q, bg, ba of the IMU block (State.cpp: q p v bg ba)
+    R_GtoI, g = synth.quat_2_rot(prob.clone_q_p[-1, :4]), np.array([0.0, 0.0, 9.81])
+    m = 6 * (n_imu - 1)
+    H, res = np.zeros((m, 9)), np.zeros(m)
+    w_om, w_ac = np.sqrt(dt) / sig_w, np.sqrt(dt) / sig_a       # :127-129
+    for i in range(n_imu - 1):
+        w_hat = rng.normal(0, 2e-4, 3)                           # a resting IMU: gyro noise, accelerometer = gravity + noise
+        a_hat = R_GtoI @ g + rng.normal(0, 3e-3, 3)
+        res[6 * i:6 * i + 3] = -w_om * w_hat                                           # :132
+        res[6 * i + 3:6 * i + 6] = -w_ac * (a_hat - R_GtoI @ g)                        # :134
+        H[6 * i:6 * i + 3, 3:6] = -w_om * np.eye(3)                                    # :141
+        Rg = R_GtoI @ g
+        H[6 * i + 3:6 * i + 6, 0:3] = -w_ac * np.array([[0, -Rg[2], Rg[1]], [Rg[2], 0, -Rg[0]], [-Rg[1], Rg[0], 0]])  # :143
+        H[6 * i + 3:6 * i + 6, 6:9] = -w_ac * np.eye(3)                                # :144
+    dt_sum = dt * (n_imu - 1)
+    Qb = np.diag([dt_sum * sig_wb ** 2] * 3 + [dt_sum * sig_ab ** 2] * 3)              # :188-190
+    # ---- the oracle's sequence
+    Hc, rc = oracle.measurement_compress(H, res)
+    Pm = prob.P[np.ix_(idx, idx)].copy()
+    Pm[3:, 3:] += Qb
+    S = Hc @ Pm @ Hc.T + mult * np.eye(len(rc))
+    chi2_ref = float(rc @ np.linalg.solve(S, rc))
+    st0, P1 = oracle.propagate(prob.P, 9, np.arange(9, 15), np.eye(6), Qb)
+    st, P2, dx_ref = oracle.ekf_update(P1, Hc, rc, idx, mult)
+    assert st0 == 0 and st == 0 and len(rc) == 9
+    # ---- the device
+    up = Updater(capi.default_options(chi2_multipler=1.0))
+    up.set_problem(prob)
+    np.testing.assert_array_equal(up.marginal_covariance(idx), prob.P[np.ix_(idx, idx)])
+    out = up.zupt(H, res, idx, Qb, mult)
+    assert out["rows"] == 9 and out["accepted"]
+    # Every IMU sample contributes the same 6 x 9 Jacobian [0 -w I 0; -w skew(R g) 0 -w I]: H has rank 6, and the compressed 9 x 9
+    # system keeps, next to the 6 directions of range(H), THREE directions of the residual space that depend on the elimination order
+    # (Givens sweeps in the reference, Householder here).  Their residual entries shift chi2 by (entry)^2 / multiplier and touch
+    # nothing else: dx and P' do not see them.  Compared: chi2 of the part inside range(H), which every valid compression shares, and
+    # the device's chi2 against numpy on the device's own compressed system.
+    Hg, rg = up.measurement_compress(H, res)
+
+    def chi2_in_range(Hm, rm):
+        U, sv, _ = np.linalg.svd(Hm)
+        k = int((sv > 1e-9 * sv[0]).sum())
+        assert k == 6
+        Hk, rk = U[:, :k].T @ Hm, U[:, :k].T @ rm
+        return float(rk @ np.linalg.solve(Hk @ Pm @ Hk.T + mult * np.eye(k), rk))
+    assert abs(chi2_in_range(Hg, rg) / chi2_in_range(Hc, rc) - 1.0) < 1e-9
+    Sg = Hg @ Pm @ Hg.T + mult * np.eye(9)
+    assert abs(out["chi2"] / float(rg @ np.linalg.solve(Sg, rg)) - 1.0) < 1e-12
+    assert abs(out["chi2_thresh"] - oracle.chi2_quantile_95(9)) < 1e-9
+    assert _rel(out["dx"], dx_ref) < 1e-8 and _rel(out["P"], P2) < 1e-10
+    # a moving IMU (1 rad/s) fails the test and nothing is touched
+    res2 = res.copy()
+    res2[0::6] += -w_om * 1.0
+    again = up.zupt(H, res2, idx, Qb, mult)
+    assert not again["accepted"] and "dx" not in again
+    np.testing.assert_array_equal(up.get_state()["P"], out["P"])
+    up.close()

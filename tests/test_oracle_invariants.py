@@ -604,3 +604,64 @@ def test_single_depth_landmark_is_the_marginal_of_the_inverse_depth_one():
     Pinf = np.linalg.inv(np.linalg.inv(prob.P) + H.T @ H)
     assert np.linalg.norm(o["P"] - Pinf) / np.linalg.norm(Pinf) < 1e-9
     np.testing.assert_array_equal(o["landmarks"][:, :2], prob.lm_value[:, :2])  # the bearing is a constant of the landmark
+
+
+# ---------------------------------------------------------------------------------------------------
+# retriangulation of the active tracks (oracle/retri_oracle.py, VioManagerHelper.cpp:190-387)
+# ---------------------------------------------------------------------------------------------------
+def _run_retri(scene, **kw):
+    from oracle import retri_oracle
+    at = retri_oracle.ActiveTracks(**kw)
+    hist = []
+    for t in range(scene.T):
+        pos, uvd = at.frame(scene.R_GtoI[t], scene.p_IinG[t], scene.cams(), scene.obs[t], 752, 480)
+        hist.append((dict(pos), dict(uvd), dict(at.count)))
+    return hist
+
+
+def test_retriangulation_recovers_noise_free_truth():
+    from tests.retri_scene import Scene
+    sc = Scene(T=9, n_pts=30, noise=0.0, p_see=(1.0, 1.0))
+    hist = _run_retri(sc)
+    assert not hist[2][0]                                     # fewer than four observations: nothing yet (:275)
+    pos, uvd, count = hist[-1]
+    assert len(pos) >= 25 and max(count.values()) == sc.T      # one observation per FRAME is kept for a known track (:268-272)
+    for fid, p in pos.items():
+        assert np.abs(p - sc.pts[fid - 100]).max() < 1e-5      # float32 normalised coordinates
+    for fid, d in uvd.items():
+        pc = sc.R_ItoC[0] @ (sc.R_GtoI[-1] @ (pos[fid] - sc.p_IinG[-1])) + sc.p_IinC[0]
+        assert abs(d[2] - pc[2]) < 1e-12 and 0 <= d[0] < 752 and 0 <= d[1] < 480
+
+
+def test_retriangulation_drops_tracks_that_miss_a_frame():
+    from tests.retri_scene import Scene
+    sc = Scene(T=8, n_pts=20, noise=0.0, p_see=(1.0, 1.0))
+    fid = sc.obs[5][0][0][0]
+    for k in (0, 1):
+        sc.obs[5][k] = [o for o in sc.obs[5][k] if o[0] != fid]  # the track is lost in frame 5 and re-detected in frame 6
+    hist = _run_retri(sc)
+    assert fid in hist[4][0] and fid not in hist[5][2]
+    assert hist[6][2][fid] == 1 and hist[7][2][fid] == 2 and fid not in hist[7][0]
+
+
+def test_retriangulation_multi_camera_bookkeeping():
+    """:264-272: a known track adds each camera's observation to the OLD system (the last camera's survives), a new track keeps
+    the first camera's."""
+    from oracle import retri_oracle
+    from tests.retri_scene import Scene
+    sc = Scene(T=3, n_pts=5, noise=0.0, p_see=(1.0, 1.0))
+    at = retri_oracle.ActiveTracks()
+    at.frame(sc.R_GtoI[0], sc.p_IinG[0], sc.cams(), sc.obs[0], 752, 480)
+    fid, _, pn0 = sc.obs[0][0][0]
+
+    def Ai(t, k, pn):
+        R_GtoC = sc.R_ItoC[k] @ sc.R_GtoI[t]
+        b = R_GtoC.T @ np.array([float(pn[0]), float(pn[1]), 1.0])
+        B = retri_oracle.skew_x(b / np.linalg.norm(b))
+        return B.T @ B
+    np.testing.assert_allclose(at.A[fid], Ai(0, 0, pn0), atol=1e-15)    # new track: camera 0's only
+    A_old = at.A[fid].copy()
+    at.frame(sc.R_GtoI[1], sc.p_IinG[1], sc.cams(), sc.obs[1], 752, 480)
+    pn1 = [o for o in sc.obs[1][1] if o[0] == fid][0][2]
+    np.testing.assert_allclose(at.A[fid], A_old + Ai(1, 1, pn1), atol=1e-15)  # known track: old + camera 1's
+    assert at.count[fid] == 2

@@ -45,6 +45,15 @@ def test_mode_b_only_units_need_the_friend_line(unit):
     assert r.returncode != 0 and "private" in r.stderr
 
 
+def test_helper_headers_compile_in_a_caller():
+    """ovgpu_zupt.h / ovgpu_retri.h are header-only helpers called FROM reference code (UpdaterZeroVelocity::try_update,
+    VioManager::retriangulate_active_tracks); tests/shim_mock/probe_helpers.cpp instantiates them the way those callers would."""
+    cmd = ["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Werror", "-DOVGPU_SHIM_MODE_B", f"-I{MOCK}", f"-I{MOCK}/update", f"-I{MOCK}/feat",
+           f"-I{ROOT}/include", f"-I{SHIM}", os.path.join(MOCK, "probe_helpers.cpp")]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+
+
 def test_every_shim_source_is_covered():
     assert sorted(f for f in os.listdir(SHIM) if f.endswith(".cpp") and f != "selftest.cpp") == sorted(UNITS)
 
@@ -73,7 +82,7 @@ def test_dropin_units_keep_the_reference_signatures():
 
 
 def test_no_shim_source_touches_the_oracle_or_the_environment():
-    for name in list(UNITS) + ["ovgpu_shim_common.h", "ovgpu_flatten.h", "ovgpu_state_access.h"]:
+    for name in list(UNITS) + ["ovgpu_shim_common.h", "ovgpu_flatten.h", "ovgpu_state_access.h", "ovgpu_zupt.h", "ovgpu_retri.h"]:
         s = _src(name)
         assert "oracle" not in s and "getenv" not in s, name
 
