@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-end measurement on the GPU box: full GPU test suite, smoke, bench (1 GPU), rocprofv3 kernel stats and the PMC passes of
-# the same bench command.  Everything lands under gpurun_out/final/; the text summaries are copied to profiles/ by hand.
+# the same bench command.  Everything lands under gpurun_out/<tag>/; tools/collect_profiles.sh copies the summaries to profiles/.
 set -u
 TAG=${1:-final}
 OUT=/root/repo/gpurun_out/$TAG
@@ -10,20 +10,23 @@ if [ "${SKIP_TESTS:-0}" != 1 ]; then
   timeout 900 python -m pytest tests -q -m gpu -p no:cacheprovider 2>&1 | tail -12 > $OUT/pytest_gpu.txt
   timeout 120 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.txt 2>&1
 fi
+timeout 300 python -m pytest tests/test_gpu_fullsize.py -q -s -p no:cacheprovider -k "conditioning_sweep or round1_route" 2>&1 | grep "cond(P_DD)\|gram then\|passed\|failed" > $OUT/conditioning_sweep.txt
 timeout 300 python bench.py > $OUT/bench.json 2> $OUT/bench.err
 timeout 120 python bench.py --cfg 2 --steps 50 --warmup 5 --no-cpu-baseline --no-extras > $OUT/bench_cfg2.json 2>> $OUT/bench.err
+timeout 120 python bench.py --cfg 2 --features 10000 --steps 10 --warmup 2 --no-cpu-baseline --no-extras > $OUT/bench_stereo_10k.json 2>> $OUT/bench.err
 timeout 120 python bench.py --cfg 4 --steps 10 --warmup 2 --no-cpu-baseline --no-extras > $OUT/bench_cfg4_one_gpu.json 2>> $OUT/bench.err
 timeout 120 python bench.py --route tsqr --steps 20 --warmup 3 --no-cpu-baseline --no-extras > $OUT/bench_tsqr.json 2>> $OUT/bench.err
+(timeout 150 python tools/dev_prof_update.py 5 240 2 2>&1 | grep ms_update) > $OUT/cfg5_240_features.txt
 cd /tmp && export TMPDIR=/tmp
 B="python /root/repo/bench.py --no-cpu-baseline --no-extras"
 timeout 180 rocprofv3 --kernel-trace --stats -d $OUT/prof_stats -o s -- $B --steps 20 --warmup 5 > /dev/null 2>&1
 timeout 180 rocprofv3 --kernel-trace --stats -d $OUT/prof_stats2 -o s -- $B --cfg 2 --steps 20 --warmup 5 > /dev/null 2>&1
 timeout 180 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/prof_fetch -o f -- $B --steps 5 --warmup 2 > /dev/null 2>&1
 timeout 180 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/prof_write -o w -- $B --steps 5 --warmup 2 > /dev/null 2>&1
-timeout 180 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY -d $OUT/prof_sq1 -o q -- $B --steps 5 --warmup 2 > /dev/null 2>&1
-timeout 180 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_SALU -d $OUT/prof_sq2 -o q -- $B --steps 5 --warmup 2 > /dev/null 2>&1
+timeout 180 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY -d $OUT/prof_sq1 -o q -- $B --steps 5 --warmup 2 > /dev/null 2>&1
+timeout 180 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS -d $OUT/prof_sq2 -o q -- $B --steps 5 --warmup 2 > /dev/null 2>&1
 cd /root/repo
 for d in prof_stats prof_stats2; do f=$(find $OUT/$d -name "*.db" | head -1); [ -n "$f" ] && python tools/prof_summary.py $f $d > $OUT/${d}.txt; done
 for d in prof_fetch prof_write prof_sq1 prof_sq2; do f=$(find $OUT/$d -name "*.db" | head -1); [ -n "$f" ] && python tools/pmc_summary.py $f $d > $OUT/${d}.txt; done
-find $OUT -name "*.db" -size +20M -delete
-cat $OUT/pytest_gpu.txt 2>/dev/null; tail -2 $OUT/smoke.txt 2>/dev/null; cut -c1-600 $OUT/bench.json; echo; cut -c1-250 $OUT/bench_cfg2.json; echo; cut -c1-250 $OUT/bench_cfg4_one_gpu.json; echo; head -20 $OUT/prof_stats.txt
+rm -rf $OUT/prof_stats $OUT/prof_stats2 $OUT/prof_fetch $OUT/prof_write $OUT/prof_sq1 $OUT/prof_sq2
+cat $OUT/pytest_gpu.txt 2>/dev/null; tail -2 $OUT/smoke.txt 2>/dev/null; cut -c1-400 $OUT/bench.json; echo; for f in bench_cfg2 bench_stereo_10k bench_cfg4_one_gpu bench_tsqr; do cut -c1-200 $OUT/$f.json; echo; done; cat $OUT/cfg5_240_features.txt; cat $OUT/conditioning_sweep.txt | cut -c1-200; head -24 $OUT/prof_stats.txt | cut -c1-60,72-128
