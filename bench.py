@@ -49,6 +49,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the PCIe-inclusive and the secondary (weak / single-GPU reference) measurements")
     ap.add_argument("--route", choices=["gram", "tsqr"], default="gram")
+    ap.add_argument("--gram-fp32", action="store_true", help="BASELINE configs[4]'s fp32 compression: Gram matrix accumulated on v_mfma_f32_16x16x4_f32")
     return ap.parse_args(argv)
 
 
@@ -113,7 +114,7 @@ def main(argv=None):
 
     cfg = args.cfg if args.cfg is not None else (CFG_SINGLE if world == 1 else CFG_MULTI)
     route = capi.COMPRESS_GRAM if args.route == "gram" else capi.COMPRESS_TSQR
-    opts = capi.default_options(chi2_multipler=1.0, compress_route=route)  # config/rpng_sim/estimator_config.yaml:100-101
+    opts = capi.default_options(chi2_multipler=1.0, compress_route=route, gram_fp32=1 if args.gram_fp32 else 0)  # config/rpng_sim/estimator_config.yaml:100-101
 
     def fence():
         torch.cuda.synchronize()
@@ -200,7 +201,7 @@ def main(argv=None):
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "f64",
+            "dtype": "f64 (Gram accumulation: f32 products, f64 totals per 32 rows)" if args.gram_fp32 else "f64",
             "data": "synthetic",
             "config": {
                 "workload": (f"BASELINE.json configs[{cfg - 1}]: {prob.K}-camera radtan rig, {prob.C}-clone window, {prob.F} MSCKF features/update"

@@ -127,7 +127,11 @@ typedef struct {
                              /* track; 1 = 4 wavefronts x 11 gate tiles, 2 = 8 x */
                              /* 17 (tuning / tests; a shape the batch does not   */
                              /* fit falls back to the automatic choice)          */
-  int32_t reserved0;         /* keep 0                                        */
+  int32_t gram_fp32;         /* 1: the Gram matrix of the (prior-whitened)    */
+                             /* stack is accumulated in fp32 on                */
+                             /* v_mfma_f32_16x16x4_f32 — BASELINE configs[4]'s */
+                             /* "fp32 compressed-QR"; dx 1e-4 / P 1e-3 of the  */
+                             /* f64 result (tests/test_gpu_fullsize.py)        */
 } ovgpu_options;
 
 /* Measurement compression (UpdaterHelper.cpp:456-487) of ovgpu_msckf_update / ovgpu_slam_update:           */

@@ -42,7 +42,7 @@ class Options(C.Structure):
         ("compress_route", C.c_int32), ("gram_no_whiten", C.c_int32), ("no_prior_overlap", C.c_int32), ("tsqr_workers", C.c_int32),
         ("tsqr_no_pipeline", C.c_int32), ("tsqr_overlap", C.c_int32), ("tsqr_leaf_blocked", C.c_int32), ("no_timing", C.c_int32),
         ("no_fast_feature_kernel", C.c_int32), ("no_single_launch_cholesky", C.c_int32), ("prior_pivot_tol", C.c_double),
-        ("feature_kernel_shape", C.c_int32), ("reserved0", C.c_int32),
+        ("feature_kernel_shape", C.c_int32), ("gram_fp32", C.c_int32),
     ]
 
 

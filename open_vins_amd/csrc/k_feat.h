@@ -349,13 +349,23 @@ __global__ void __launch_bounds__(256) k_feat_qr(SysParams p, FeatStore st) {
 // Runs after the gate (k_feat) AND after the prior block's factorisation (L, z): the gate itself needs neither, which is what lets
 // that factorisation run next to it on the second stream.
 // ---------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_feat_out(SysParams p, const double *__restrict__ rowsG, const int32_t *__restrict__ minfoG,
-                                                   const double *__restrict__ VG, const double *__restrict__ zG) {
-  const int tid = threadIdx.x, colt = tid;
+// NC = columns per lane.  NC = 2 (128 threads: columns t and t + 128) halves the number of wavefronts that stream a feature's
+// Jacobian records through the scalar cache and the scalar bookkeeping per multiply-add — the two things the ablation of this kernel
+// found it to be bound by.
+template <int NC>
+__global__ void __launch_bounds__(256 / NC) k_feat_out(SysParams p, const double *__restrict__ rowsG, const int32_t *__restrict__ minfoG,
+                                                        const double *__restrict__ VG, const double *__restrict__ zG) {
+  constexpr int NTH = 256 / NC;
+  const int tid = threadIdx.x;
   const int D = p.D, LD = p.LD, RS = p.row_stride;
-  const int c = colt, cq = c < D ? c : D - 1;
-  const double *Lc = p.Lw + cq;
-  constexpr int MH = 1, half = 0;
+  int cN[NC], cw0[NC];
+  const double *Lc[NC];
+#pragma unroll
+  for (int e = 0; e < NC; e++) {
+    cN[e] = tid + NTH * e;                       // this lane's columns of [H L | r]
+    cw0[e] = (tid & ~63) + NTH * e;              // smallest column of the wavefront in segment e: blocks of L above it contribute nothing
+    Lc[e] = p.Lw + (cN[e] < D ? cN[e] : D - 1);
+  }
   for (int slot = blockIdx.x; slot < p.F; slot += gridDim.x) {
     const int f = __builtin_amdgcn_readfirstlane(p.order ? p.order[slot] : slot);
     const int m0 = __builtin_amdgcn_readfirstlane(p.meas_offsets[f]);
@@ -363,31 +373,37 @@ __global__ void __launch_bounds__(256) k_feat_out(SysParams p, const double *__r
     const int64_t orow0 = p.row_off[f];
     const int n_out = (int)(p.row_off[f + 1] - orow0);
     if (p.status[f] != OVGPU_FEAT_USED) {
-      for (int64_t e = tid; e < (int64_t)n_out * LD; e += 256) p.Hbig[orow0 * LD + e] = 0.0;
+      for (int64_t e = tid; e < (int64_t)n_out * LD; e += NTH) p.Hbig[orow0 * LD + e] = 0.0;
       continue;
     }
     const double *frow = rowsG + (size_t)m0 * RS;
     const int32_t *finfo = minfoG + (size_t)8 * m0;
     const double *Vl = VG + (size_t)6 * m0;
-    if (c < LD) {
-      const double *zf = zG + (size_t)f * 3 * LD + c;
-      const double z0 = zf[0], z1 = zf[LD], z2 = zf[2 * LD];
-      double lcp[6] = {0, 0, 0, 0, 0, 0}, lci[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (cN[0] < LD) {
+      double z[NC][3];
+#pragma unroll
+      for (int e = 0; e < NC; e++) {
+        const double *zf = zG + (size_t)f * 3 * LD + (cN[e] < LD ? cN[e] : 0);
+        z[e][0] = zf[0], z[e][1] = zf[LD], z[e][2] = zf[2 * LD];
+      }
+      double lcp[6] = {0, 0, 0, 0, 0, 0}, lci[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // calibration rows of L: segment 0 only (its columns come first)
       int cam_l = -1;
-      const int cw0 = colt & ~63; // smallest column of this wavefront: blocks of L above it contribute nothing
-      double *out = p.Hbig + orow0 * LD + c;
-      constexpr int GY = 4;
+      double *out = p.Hbig + orow0 * LD;
+      constexpr int GY = NC == 1 ? 4 : 2;
 #pragma unroll 1
-      for (int ib = half * GY; ib < m; ib += MH * GY) {
-        double lcl[GY][6];
+      for (int ib = 0; ib < m; ib += GY) {
+        double lcl[GY][NC][6];
 #pragma unroll
         for (int ii = 0; ii < GY; ii++) {
           const int i = min(ib + ii, m - 1);
           const int ccol = finfo[8 * i + 2];
-          const double *Lr = Lc + (size_t)ccol * D;
-          const bool live = ccol + 5 >= cw0; // wave-uniform
 #pragma unroll
-          for (int s = 0; s < 6; s++) lcl[ii][s] = live ? Lr[(size_t)s * D] : 0.0;
+          for (int e = 0; e < NC; e++) {
+            const double *Lr = Lc[e] + (size_t)ccol * D;
+            const bool live = ccol + 5 >= cw0[e]; // wave-uniform
+#pragma unroll
+            for (int s = 0; s < 6; s++) lcl[ii][e][s] = live ? Lr[(size_t)s * D] : 0.0;
+          }
         }
 #pragma unroll
         for (int ii = 0; ii < GY; ii++) {
@@ -396,31 +412,41 @@ __global__ void __launch_bounds__(256) k_feat_out(SysParams p, const double *__r
             const int32_t *mi = finfo + 8 * i;
             const double *rd = frow + (size_t)i * RS;
             const int camv = mi[0], cc2 = mi[2], cc3 = mi[3], cc4 = mi[4];
-            double t0 = 0.0, t1 = 0.0, s0 = 0.0, s1 = 0.0;
-            if (cc2 + 5 >= cw0) {
+            double t0[NC], t1[NC];
 #pragma unroll
-              for (int s = 0; s < 6; s++) t0 = fma(rd[RO_CLONE + s], lcl[ii][s], t0), t1 = fma(rd[RO_CLONE + 6 + s], lcl[ii][s], t1);
+            for (int e = 0; e < NC; e++) {
+              t0[e] = 0.0, t1[e] = 0.0;
+              if (cc2 + 5 >= cw0[e]) {
+#pragma unroll
+                for (int s = 0; s < 6; s++) t0[e] = fma(rd[RO_CLONE + s], lcl[ii][e][s], t0[e]), t1[e] = fma(rd[RO_CLONE + 6 + s], lcl[ii][e][s], t1[e]);
+              }
             }
-            if ((cc3 >= 0 && cc3 + 5 >= cw0) || (cc4 >= 0 && cc4 + 7 >= cw0)) { // first wavefront only
+            if ((cc3 >= 0 && cc3 + 5 >= cw0[0]) || (cc4 >= 0 && cc4 + 7 >= cw0[0])) { // first wavefront, first segment only
               if (camv != cam_l) {
                 cam_l = camv;
 #pragma unroll
-                for (int s = 0; s < 6; s++) lcp[s] = cc3 >= 0 ? Lc[(size_t)(cc3 + s) * D] : 0.0;
+                for (int s = 0; s < 6; s++) lcp[s] = cc3 >= 0 ? Lc[0][(size_t)(cc3 + s) * D] : 0.0;
 #pragma unroll
-                for (int s = 0; s < 8; s++) lci[s] = cc4 >= 0 ? Lc[(size_t)(cc4 + s) * D] : 0.0;
+                for (int s = 0; s < 8; s++) lci[s] = cc4 >= 0 ? Lc[0][(size_t)(cc4 + s) * D] : 0.0;
               }
+              double s0 = 0.0, s1 = 0.0;
 #pragma unroll
               for (int s = 0; s < 6; s++) s0 = fma(rd[RO_CPOSE + s], lcp[s], s0), s1 = fma(rd[RO_CPOSE + 6 + s], lcp[s], s1);
 #pragma unroll
               for (int s = 0; s < 8; s++) s0 = fma(rd[RO_CINTR + s], lci[s], s0), s1 = fma(rd[RO_CINTR + 8 + s], lci[s], s1);
+              t0[0] += s0, t1[0] += s1;
             }
-            t0 += s0, t1 += s1;
-            if (c == D) t0 = rd[RO_RES], t1 = rd[RO_RES + 1]; // the residual column is not whitened
             const double *v = Vl + (size_t)6 * i;
-            t0 -= v[0] * z0 + v[1] * z1 + v[2] * z2, t1 -= v[3] * z0 + v[4] * z1 + v[5] * z2;
             const int r = 2 * i;
-            if (r >= 3) out[(size_t)(r - 3) * LD] = t0;
-            if (r + 1 >= 3) out[(size_t)(r + 1 - 3) * LD] = t1;
+#pragma unroll
+            for (int e = 0; e < NC; e++) {
+              if (cN[e] == D) t0[e] = rd[RO_RES], t1[e] = rd[RO_RES + 1]; // the residual column is not whitened
+              t0[e] -= v[0] * z[e][0] + v[1] * z[e][1] + v[2] * z[e][2], t1[e] -= v[3] * z[e][0] + v[4] * z[e][1] + v[5] * z[e][2];
+              if (cN[e] < LD) {
+                if (r >= 3) out[(size_t)(r - 3) * LD + cN[e]] = t0[e];
+                if (r + 1 >= 3) out[(size_t)(r + 1 - 3) * LD + cN[e]] = t1[e];
+              }
+            }
           }
         }
       }

@@ -32,6 +32,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace ovg {
 namespace gram {
@@ -40,7 +41,8 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 
 constexpr int GR_ROWS = 32;  // rows of the stack per LDS stage
 constexpr int GR_LS = 272;   // LDS row stride in doubles (17 * 16 >= 256 columns; consecutive rows start half an LDS line apart)
-constexpr int GR_NT = 16;    // tile-grid capacity: LD <= 256
+constexpr int GR_NT = 16;    // tile-grid capacity of k_gram: LD <= 256
+constexpr int GR_NT_BLK = 24; // of the block variant k_gram_blk (three column windows of 8 tiles): LD <= 384
 
 struct GramParams {
   int LD, NT;             // row length of the stack (D + 1) and its 16-column tiles
@@ -179,6 +181,145 @@ template <int NTC> __global__ void __launch_bounds__(256) k_gram(GramParams p) {
   case 2: gram_put<2>(out, NT, lane, acc); break;
   default: gram_put<3>(out, NT, lane, acc); break;
   }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// More than 16 tile columns (BASELINE configs[4]: 50 clones, D = 356, 23 tile columns): the tile grid no longer fits the
+// accumulator registers of one workgroup, so it is cut into 8 x 8-tile blocks (column windows of 128) and blockIdx.y picks
+// the block pair (a <= b): every workgroup streams its rows once per pair, stages the two column windows in LDS and keeps the
+// 64 tiles of the block as 16 per wavefront (tile rows 2 w, 2 w + 1 of window a against all 8 tile columns of window b: ten
+// operand reads for sixteen matrix instructions).  Diagonal blocks compute both triangles; the reduction writes what lies on
+// or above the diagonal and mirrors it.  A fall-back shape: it reads the stack NB (NB + 1) / 2 times.
+// ---------------------------------------------------------------------------------------------------
+constexpr int GB_T = 8;            // tiles per window
+constexpr int GB_W = 16 * GB_T;    // columns per window
+constexpr int GB_LS = 2 * GB_W + 8; // LDS row stride (window a | window b), 264: consecutive rows start a quarter line apart
+inline size_t gram_blk_lds_bytes() { return (size_t)2 * GR_ROWS * GB_LS * sizeof(double); }
+__host__ __device__ inline void gram_blk_pair(int NB, int idx, int &a, int &b) { // idx -> (a, b), a <= b < NB, row by row
+  a = 0;
+  while (idx >= NB - a) idx -= NB - a, a++;
+  b = a + idx;
+}
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+// F32 = the fp32 variant BASELINE configs[4] names ("fp32 compressed-QR"): the staged rows are rounded to float, the products run
+// on v_mfma_f32_16x16x4_f32 (twice the FP64 rate, half the LDS traffic) and the partial tiles leave as doubles.  The accumulator
+// of that instruction holds rows 4 (lane >> 4) + q of column lane & 15 — not the f64 layout — so the tile is written element by
+// element into the slots the reduction expects.
+template <bool F32> __global__ void __launch_bounds__(256) k_gram_blk(GramParams p, int NB) {
+  extern __shared__ double gram_lds[];
+  typedef typename std::conditional<F32, float, double>::type S;
+  typedef typename std::conditional<F32, f4, d4>::type A4;
+  S *lds = reinterpret_cast<S *>(gram_lds);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int LD = p.LD;
+  int wa, wb;
+  gram_blk_pair(NB, blockIdx.y, wa, wb);
+  const int ca0 = wa * GB_W, cb0 = wb * GB_W;
+  const int64_t nchunks = (p.rows_total + GR_ROWS - 1) / GR_ROWS;
+  const int chunk_begin = (int)((nchunks * blockIdx.x) / gridDim.x), chunk_end = (int)((nchunks * (blockIdx.x + 1)) / gridDim.x);
+  A4 acc[2 * GB_T];
+  d4 tot[F32 ? 2 * GB_T : 1];
+#pragma unroll
+  for (int i = 0; i < 2 * GB_T; i++) acc[i] = A4{0, 0, 0, 0};
+#pragma unroll
+  for (int i = 0; i < (F32 ? 2 * GB_T : 1); i++) tot[i] = d4{0.0, 0.0, 0.0, 0.0};
+  // staging: thread t owns column t & 127 of window (t >> 7) and walks the 32 rows of a stage; columns beyond LD are zero
+  const int win = tid >> 7, wc = tid & 127;
+  const int gc = (win ? cb0 : ca0) + wc;
+  const bool live = gc < LD;
+  double v[GR_ROWS];
+  auto fetch = [&](int chunk) {
+    const int64_t first = (int64_t)chunk * GR_ROWS;
+#pragma unroll
+    for (int r = 0; r < GR_ROWS; r++) {
+      const int64_t row = first + r < p.rows_total ? first + r : p.rows_total - 1;
+      v[r] = p.H[row * LD + (live ? gc : 0)];
+    }
+  };
+  auto stash = [&](S *buf, int chunk) {
+    const int64_t first = (int64_t)chunk * GR_ROWS;
+#pragma unroll
+    for (int r = 0; r < GR_ROWS; r++) buf[r * GB_LS + win * GB_W + wc] = (live && first + r < p.rows_total) ? (S)v[r] : (S)0;
+  };
+  if (chunk_begin < chunk_end) {
+    fetch(chunk_begin);
+    stash(lds, chunk_begin);
+  }
+  __syncthreads();
+  const int g = lane >> 4, cl = lane & 15;
+  for (int chunk = chunk_begin; chunk < chunk_end; chunk++) {
+    const S *cur = lds + (size_t)((chunk - chunk_begin) & 1) * GR_ROWS * GB_LS;
+    S *nxt = lds + (size_t)((chunk - chunk_begin + 1) & 1) * GR_ROWS * GB_LS;
+    const bool more = chunk + 1 < chunk_end;
+    if (more) fetch(chunk + 1);
+#pragma unroll 2
+    for (int k0 = 0; k0 < GR_ROWS; k0 += 4) {
+      const S *rowp = cur + (k0 + g) * GB_LS + cl;
+      const S a0 = rowp[16 * (2 * wave)], a1 = rowp[16 * (2 * wave + 1)];
+      S b[GB_T];
+#pragma unroll
+      for (int j = 0; j < GB_T; j++) b[j] = rowp[GB_W + 16 * j];
+#pragma unroll
+      for (int j = 0; j < GB_T; j++) {
+        if constexpr (F32) {
+          acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b[j], acc[j], 0, 0, 0);
+          acc[GB_T + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b[j], acc[GB_T + j], 0, 0, 0);
+        } else {
+          GRAM_MFMA(a0, b[j], acc[j]);
+          GRAM_MFMA(a1, b[j], acc[GB_T + j]);
+        }
+      }
+    }
+    if constexpr (F32) { // the fp32 sums of one 32-row stage join f64 totals: the rounding of a long fp32 accumulation is the larger
+                         // part of the variant's error (measured at 50 clones x 500 features: dx 1.9e-4 without, see the test)
+#pragma unroll
+      for (int i = 0; i < 2 * GB_T; i++) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) tot[i][q] += (double)acc[i][q];
+        acc[i] = A4{0, 0, 0, 0};
+      }
+    }
+    if (more) stash(nxt, chunk + 1);
+    __syncthreads();
+  }
+  // partial tiles: [pair][workgroup][64 tiles][256], tile (i, j) of the block at index 8 i + j, slots as gram_put writes them:
+  // slot h * 128 + 2 * lane' + e = element (4 (2 h + e) + (lane' >> 4), lane' & 15)
+  double *out = p.part + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (GB_T * GB_T) * 256;
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < GB_T; j++) {
+      double *o = out + (size_t)((2 * wave + i) * GB_T + j) * 256;
+      const A4 &t = acc[i * GB_T + j];
+      if constexpr (F32) { // register q of lane (g, cl) is element (4 g + q, cl): slot (h = g >> 1, e = g & 1, lane' = 16 q + cl)
+#pragma unroll
+        for (int q = 0; q < 4; q++) o[(g >> 1) * 128 + 2 * (16 * q + cl) + (g & 1)] = tot[i * GB_T + j][q];
+      } else {
+        double2 *o2 = reinterpret_cast<double2 *>(o) + lane;
+        o2[0] = double2{t[0], t[1]}, o2[64] = double2{t[2], t[3]};
+      }
+    }
+}
+
+// one workgroup per tile of each block pair: ordered sum over the workgroups, written to G [LG x LG] with its mirror image
+__global__ void __launch_bounds__(256) k_gram_blk_reduce(int NB, int NT, int nparts, const double *part, double *G) {
+  const int LG = 16 * NT, t = threadIdx.x;
+  int wa, wb;
+  gram_blk_pair(NB, blockIdx.y, wa, wb);
+  const int ti = wa * GB_T + blockIdx.x / GB_T, tj = wb * GB_T + blockIdx.x % GB_T;
+  if (ti >= NT || tj >= NT || ti > tj) return; // outside the grid / the lower triangle of a diagonal block
+  const double *src = part + ((size_t)blockIdx.y * nparts * (GB_T * GB_T) + blockIdx.x) * 256 + t;
+  double s0 = 0, s1 = 0;
+  int w = 0;
+  for (; w + 2 <= nparts; w += 2) s0 += src[(size_t)w * (GB_T * GB_T) * 256], s1 += src[(size_t)(w + 1) * (GB_T * GB_T) * 256];
+  if (w < nparts) s0 += src[(size_t)w * (GB_T * GB_T) * 256];
+  const double s = s0 + s1;
+  const int q = 2 * (t >> 7) + (t & 1), lane = (t >> 1) & 63; // slot t = h * 128 + 2 * lane + e holds register q = 2 h + e
+  const int i = 16 * ti + 4 * q + (lane >> 4), j = 16 * tj + (lane & 15);
+  G[(size_t)i * LG + j] = s;
+  if (ti != tj) G[(size_t)j * LG + i] = s;
 }
 
 // Sum of the partials, workgroup order; one workgroup per tile pair writes the tile and its mirror image into the dense

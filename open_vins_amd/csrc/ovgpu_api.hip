@@ -206,6 +206,7 @@ struct ovgpu_ctx {
   int chol_slot = 0;
   bool no_chol_pipe = false;   // options.no_single_launch_cholesky
   int feat_shape = 0;          // options.feature_kernel_shape
+  bool gram_fp32 = false;      // options.gram_fp32
   int Lw_D = -1;               // column count c->Lw was zeroed for (its upper triangle stays zero)
   DevBuf<long long> dbg_cycles; // ovgpu_debug_cycles: per-phase cycle counters of workgroup 0 of the per-feature kernel
   int tsqr_workers = 0;         // options.tsqr_workers
@@ -413,6 +414,7 @@ int ovgpu_create(const ovgpu_options *opts, int device, ovgpu_ctx **out) {
   c->no_feat_kernel = opts->no_fast_feature_kernel != 0;
   c->no_chol_pipe = opts->no_single_launch_cholesky != 0;
   c->feat_shape = opts->feature_kernel_shape;
+  c->gram_fp32 = opts->gram_fp32 != 0;
   if (hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_cf, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_cj, hipEventDisableTiming) != hipSuccess)
     c->no_chol_pipe = true;
@@ -706,8 +708,8 @@ static int set_row_layout(ovgpu_ctx *c, bool slam_rows) {
     const int nt = (2 * m_max + 15) / 16, tiles = nt * (nt + 1) / 2 + nt;
     // 1: <4 wavefronts, 11 tiles each>; 2: <8, 17> (one workgroup per CU: 256 registers per lane); up to two workgroups per CU
     int variant = tiles <= 4 * 11 ? 1 : (tiles <= 8 * 17 ? 2 : 0);
-    if (c->feat_shape == 1 && tiles <= 4 * 11) variant = 1;
-    if (c->feat_shape == 2 && tiles <= 8 * 17) variant = 2;
+    if ((c->feat_shape & 15) == 1 && tiles <= 4 * 11) variant = 1;
+    if ((c->feat_shape & 15) == 2 && tiles <= 8 * 17) variant = 2;
     if (variant) {
       const feat::FeatLds lo = feat::feat_lds_layout(m_max, c->row_stride, c->D, c->LD, c->K * c->C, nt);
       if (lo.total <= (size_t)c->lds_limit) {
@@ -907,7 +909,8 @@ static int enqueue_system(ovgpu_ctx *c, int f_one = -1, int init_rep = 0, bool w
     if (c->feat_variant == 1) hipLaunchKernelGGL((feat::k_feat<4, 11, 2>), dim3(c->feat_grid), dim3(256), c->feat_lds, c->stream, p, c->feat_nt_max, sr, sm, sV, sz);
     else hipLaunchKernelGGL((feat::k_feat<8, 17, 2>), dim3(c->feat_grid), dim3(512), c->feat_lds, c->stream, p, c->feat_nt_max, sr, sm, sV, sz);
     if (c->prior_on_side) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join, 0));
-    hipLaunchKernelGGL(feat::k_feat_out, dim3(std::max(1, std::min(c->F, 8 * c->num_cu))), dim3(256), 0, c->stream, p, sr, sm, sV, sz);
+    if (c->feat_shape & 16) hipLaunchKernelGGL(feat::k_feat_out<1>, dim3(std::max(1, std::min(c->F, 8 * c->num_cu))), dim3(256), 0, c->stream, p, sr, sm, sV, sz);
+    else hipLaunchKernelGGL(feat::k_feat_out<2>, dim3(std::max(1, std::min(c->F, 16 * c->num_cu))), dim3(128), 0, c->stream, p, sr, sm, sV, sz);
     HIPCHK(hipGetLastError());
     return OVGPU_OK;
   }
@@ -1010,6 +1013,22 @@ static int enqueue_compress_gram(ovgpu_ctx *c, bool factor = true) {
   HIPCHK(c->gram_G.reserve((size_t)LG * LG));
   gram::GramParams g;
   g.LD = LD, g.NT = NT, g.rows_total = c->rows_total, g.H = c->Hbig.p, g.part = c->gram_part.p;
+  if (NT > gram::GR_NT || c->gram_fp32) { // more than 255 columns (configs[4]), or its fp32 variant: 8 x 8-tile blocks of the grid, one block pair per blockIdx.y
+    const int NB = (NT + gram::GB_T - 1) / gram::GB_T, pairs = NB * (NB + 1) / 2;
+    HIPCHK(c->gram_part.reserve((size_t)pairs * G * gram::GB_T * gram::GB_T * 256));
+    g.part = c->gram_part.p;
+    static bool attr_done = false;
+    if (!attr_done) {
+      (void)hipFuncSetAttribute((const void *)gram::k_gram_blk<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute((const void *)gram::k_gram_blk<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr_done = true;
+    }
+    if (c->gram_fp32) hipLaunchKernelGGL(gram::k_gram_blk<true>, dim3(G, pairs), dim3(256), gram::gram_blk_lds_bytes() / 2, c->stream, g, NB);
+    else hipLaunchKernelGGL(gram::k_gram_blk<false>, dim3(G, pairs), dim3(256), gram::gram_blk_lds_bytes(), c->stream, g, NB);
+    hipLaunchKernelGGL(gram::k_gram_blk_reduce, dim3(gram::GB_T * gram::GB_T, pairs), dim3(256), 0, c->stream, NB, NT, G, c->gram_part.p, c->gram_G.p);
+    HIPCHK(hipGetLastError());
+    return factor ? set_err(OVGPU_ERR_CAPACITY, "the Cholesky-QR variant holds at most 255 Jacobian columns") : OVGPU_OK;
+  }
   switch ((NT + 1) / 2) {
   case 1: launch_gram<2>(G, g, c->stream); break;
   case 2: launch_gram<4>(G, g, c->stream); break;
@@ -1285,7 +1304,7 @@ static int enqueue_pipeline(ovgpu_ctx *c, int stages, bool slam = false, bool fa
   }
   if (eu) HIPCHK(hipEventRecord(eu->a, c->stream));
   int rc = OVGPU_OK;
-  const bool fits = (c->LD + 15) / 16 <= gram::GR_NT && c->F > 0;
+  const bool fits = (c->LD + 15) / 16 <= gram::GR_NT_BLK && c->F > 0;
   tform = !gram_only && c->compress_gram == 1 && !c->force_tsqr && fits && (stages & STAGE_EKF) != 0 && (stages & STAGE_LOCAL) != 0;
   c->force_tsqr = false;
   // The prior block's factorisation needs nothing from the measurements: it runs on the second stream next to the
@@ -1314,7 +1333,7 @@ static int enqueue_pipeline(ovgpu_ctx *c, int stages, bool slam = false, bool fa
     }
     if (ec) HIPCHK(hipEventRecord(ec->a, c->stream));
     if (gram_only || tform) { // Gram matrix only: summed across GPUs (sharded update) or consumed by the prior-whitened EKF update
-      if ((c->LD + 15) / 16 > gram::GR_NT) return set_err(OVGPU_ERR_CAPACITY, "the Gram route holds at most 255 Jacobian columns");
+      if ((c->LD + 15) / 16 > gram::GR_NT_BLK) return set_err(OVGPU_ERR_CAPACITY, "the Gram route holds at most 383 Jacobian columns");
       c->gram_valid = false;
       rc = enqueue_compress_gram(c, false);
     } else {
@@ -2530,7 +2549,7 @@ int ovgpu_gram_len(ovgpu_ctx *c, int64_t *n_doubles) {
   if (!c || !n_doubles) return set_err(OVGPU_ERR_INVALID, "null argument");
   if (!c->have_state || c->poses_only) return set_err(OVGPU_ERR_NO_STATE, "ovgpu_set_state was never called");
   const int NT = (c->LD + 15) / 16;
-  if (NT > gram::GR_NT) return set_err(OVGPU_ERR_CAPACITY, "the Gram route holds at most 255 Jacobian columns");
+  if (NT > gram::GR_NT_BLK) return set_err(OVGPU_ERR_CAPACITY, "the Gram route holds at most 383 Jacobian columns");
   *n_doubles = (int64_t)256 * NT * NT + 1;
   return OVGPU_OK;
 }
@@ -2570,7 +2589,7 @@ int ovgpu_msckf_gram_update(ovgpu_ctx *c, const void *gram_dev, double *dx, doub
   if (!c || !gram_dev) return set_err(OVGPU_ERR_INVALID, "bad argument");
   if (!c->have_state || c->poses_only) return set_err(OVGPU_ERR_NO_STATE, "ovgpu_set_state was never called");
   const int NT = (c->LD + 15) / 16;
-  if (NT > gram::GR_NT) return set_err(OVGPU_ERR_CAPACITY, "the Gram route holds at most 255 Jacobian columns");
+  if (NT > gram::GR_NT_BLK) return set_err(OVGPU_ERR_CAPACITY, "the Gram route holds at most 383 Jacobian columns");
   HIPCHK(hipSetDevice(c->device));
   const size_t n = (size_t)256 * NT * NT;
   HIPCHK(c->gram_G.reserve(n));
@@ -2800,7 +2819,7 @@ int nccl_err(int rc, const char *what) {
 
 // the local stage of a sharded update up to (not including) the exchange; gram: which protocol this state uses
 static int sharded_local(ovgpu_ctx *c, bool &gram) {
-  gram = c->compress_gram == 1 && (c->LD + 15) / 16 <= gram::GR_NT;
+  gram = c->compress_gram == 1 && (c->LD + 15) / 16 <= gram::GR_NT_BLK;
   const int rc = enqueue_pipeline(c, STAGE_LOCAL, false, true, gram);
   if (rc == OVGPU_OK && gram && c->F == 0) { // an empty shard: nothing was whitened here, but the sum it joins is the other ranks' whitened Gram matrix
     const size_t n = (size_t)256 * ((c->LD + 15) / 16) * ((c->LD + 15) / 16);

@@ -7,10 +7,10 @@ reduction — QR of the stacked triangles has the same R^T R as QR of the full s
 one all-gather of G triangles over RCCL/xGMI (G * D * (D+1) * 8 B: 2.8 MB at D = 208, 8 GPUs), after which every
 rank runs the identical merge + EKF update and ends with bit-identical (dx, P) without a broadcast.
 
-When the device compresses through the Gram matrix (csrc/k_gram.h, D <= 255) the exchange is simpler still:
+When the device compresses through the Gram matrix (csrc/k_gram.h, D <= 383) the exchange is simpler still:
 [H | r]^T [H | r] of the full stack is the SUM of the shards' Gram matrices, i.e. one all-reduce of (16 ceil((D+1)/16))^2
 doubles (0.4 MB at D = 208; the trailing element carries the accepted-row count); every rank then applies the identical
-prior-whitened update (k_ekf.h) to the sum.  Backends without the Gram protocol, D > 255 and OVGPU_COMPRESS=tsqr use the
+prior-whitened update (k_ekf.h) to the sum.  Backends without the Gram protocol, D > 383 and compress_route = TSQR use the
 triangle exchange.
 
 `backend` below is anything with `triangle_len()`, `local_into(tensor)` and `merge_update_from(tensor, G)`:

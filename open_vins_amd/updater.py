@@ -420,8 +420,8 @@ class UpdaterMSCKF:
     # the same exchange in Gram form: one all-reduce (sum) instead of an all-gather + merge
     def gram_len(self):
         """Doubles of the Gram buffer (16 ceil((D+1)/16) squared + the accepted-row count), or 0 when this state does not
-        fit the Gram route (D > 255) or options.compress_route selects the Householder exchange."""
-        if self.options.compress_route != capi.COMPRESS_GRAM or self.triangle_len() > 255 * 256:
+        fit the Gram route (D > 383) or options.compress_route selects the Householder exchange."""
+        if self.options.compress_route != capi.COMPRESS_GRAM or self.triangle_len() > 383 * 384:
             return 0
         n = C.c_int64(0)
         capi.check(self.lib.ovgpu_gram_len(self._ctx, C.byref(n)), "ovgpu_gram_len")

@@ -15,6 +15,7 @@ cp $SRC/bench_cfg2.json ${P}_bench_cfg2_800_features.json
 cp $SRC/bench_stereo_10k.json ${P}_bench_stereo_10k_features.json
 cp $SRC/bench_cfg4_one_gpu.json ${P}_bench_cfg4_one_gpu.json
 cp $SRC/bench_tsqr.json ${P}_bench_tsqr_route.json
-cp $SRC/cfg5_240_features.txt ${P}_cfg5_240_features.txt
+cp $SRC/bench_cfg5_share_f64.json ${P}_bench_cfg5_one_gpu_share.json
+cp $SRC/bench_cfg5_share_fp32_gram.json ${P}_bench_cfg5_one_gpu_share_fp32_gram.json
 python tools/make_pmc_json.py $SRC/prof_fetch.txt $SRC/prof_write.txt 3 ${P}_pmc.json
 ls -la profiles | grep $2

@@ -16,7 +16,8 @@ timeout 120 python bench.py --cfg 2 --steps 50 --warmup 5 --no-cpu-baseline --no
 timeout 120 python bench.py --cfg 2 --features 10000 --steps 10 --warmup 2 --no-cpu-baseline --no-extras > $OUT/bench_stereo_10k.json 2>> $OUT/bench.err
 timeout 120 python bench.py --cfg 4 --steps 10 --warmup 2 --no-cpu-baseline --no-extras > $OUT/bench_cfg4_one_gpu.json 2>> $OUT/bench.err
 timeout 120 python bench.py --route tsqr --steps 20 --warmup 3 --no-cpu-baseline --no-extras > $OUT/bench_tsqr.json 2>> $OUT/bench.err
-(timeout 150 python tools/dev_prof_update.py 5 240 2 2>&1 | grep ms_update) > $OUT/cfg5_240_features.txt
+timeout 200 python bench.py --cfg 5 --features 2500 --steps 5 --warmup 1 --no-cpu-baseline --no-extras > $OUT/bench_cfg5_share_f64.json 2>> $OUT/bench.err
+timeout 200 python bench.py --cfg 5 --features 2500 --gram-fp32 --steps 5 --warmup 1 --no-cpu-baseline --no-extras > $OUT/bench_cfg5_share_fp32_gram.json 2>> $OUT/bench.err
 cd /tmp && export TMPDIR=/tmp
 B="python /root/repo/bench.py --no-cpu-baseline --no-extras"
 timeout 180 rocprofv3 --kernel-trace --stats -d $OUT/prof_stats -o s -- $B --steps 20 --warmup 5 > /dev/null 2>&1
@@ -29,4 +30,4 @@ cd /root/repo
 for d in prof_stats prof_stats2; do f=$(find $OUT/$d -name "*.db" | head -1); [ -n "$f" ] && python tools/prof_summary.py $f $d > $OUT/${d}.txt; done
 for d in prof_fetch prof_write prof_sq1 prof_sq2; do f=$(find $OUT/$d -name "*.db" | head -1); [ -n "$f" ] && python tools/pmc_summary.py $f $d > $OUT/${d}.txt; done
 rm -rf $OUT/prof_stats $OUT/prof_stats2 $OUT/prof_fetch $OUT/prof_write $OUT/prof_sq1 $OUT/prof_sq2
-cat $OUT/pytest_gpu.txt 2>/dev/null; tail -2 $OUT/smoke.txt 2>/dev/null; cut -c1-400 $OUT/bench.json; echo; for f in bench_cfg2 bench_stereo_10k bench_cfg4_one_gpu bench_tsqr; do cut -c1-200 $OUT/$f.json; echo; done; cat $OUT/cfg5_240_features.txt; cat $OUT/conditioning_sweep.txt | cut -c1-200; head -24 $OUT/prof_stats.txt | cut -c1-60,72-128
+cat $OUT/pytest_gpu.txt 2>/dev/null; tail -2 $OUT/smoke.txt 2>/dev/null; cut -c1-400 $OUT/bench.json; echo; for f in bench_cfg2 bench_stereo_10k bench_cfg4_one_gpu bench_tsqr; do cut -c1-200 $OUT/$f.json; echo; done; for f in bench_cfg5_share_f64 bench_cfg5_share_fp32_gram; do cut -c1-200 $OUT/$f.json; echo; done; cat $OUT/conditioning_sweep.txt | cut -c1-200; head -24 $OUT/prof_stats.txt | cut -c1-60,72-128
