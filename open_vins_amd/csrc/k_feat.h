@@ -464,12 +464,14 @@ __global__ void __launch_bounds__(64 * NW, OCC)
     k_feat(SysParams p, int nt_max, const double *__restrict__ rowsG, const int32_t *__restrict__ minfoG, const double *__restrict__ VG,
            const double *__restrict__ zG) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int NTH = 64 * NW, MH = NW / 4, CHM = FT_CH / MH, GL = CHM < 4 ? CHM : 4; // CHM measurements of a chunk per thread, loaded GL at a time
-  static_assert(NW % 4 == 0 && CHM % GL == 0, "wavefronts come in groups of four (one column sweep of 256 threads each)");
+  constexpr int NCG = TPW <= 11 ? 2 : 1;                        // columns per lane in the T sweep (the wide shape has no registers to spare)
+  constexpr int CGT = 256 / NCG, MH = 64 * NW / CGT, CHM = FT_CH / MH; // threads per column group, groups, measurements of a chunk per group
+  constexpr int NTH = 64 * NW, GL = CHM < 4 / NCG ? CHM : 4 / NCG; // CHM measurements of a chunk per thread, loaded GL at a time
+  static_assert(NW % 4 == 0 && FT_CH % MH == 0 && CHM % GL == 0, "column groups of 256 / NCG threads, each sweeping its share of a chunk's measurements");
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, cl = lane & 15;
-  const int colt = tid & 255, half = __builtin_amdgcn_readfirstlane(tid >> 8);
+  const int colt = tid % CGT, half = __builtin_amdgcn_readfirstlane(tid / CGT);
   const int D = p.D, LD = p.LD, N = p.N, RS = p.row_stride;
   const FeatLds lo = feat_lds_layout(p.m_max, RS, D, LD, p.K * p.C, nt_max);
   int *minfo = reinterpret_cast<int *>(smem + lo.minfo);
@@ -480,9 +482,9 @@ __global__ void __launch_bounds__(64 * NW, OCC)
   double *st0 = reinterpret_cast<double *>(smem + lo.stage), *st1 = st0 + 256;
   int *sched = reinterpret_cast<int *>(smem + lo.sched);
   const double sig2 = p.opt.sigma_pix_sq;
-  const int c = colt;               // this thread's column of [H_x | r]
-  const int cq = c < D ? c : D - 1; // clamped for loads
-  const double *Pc = p.P + p.col_cov[cq];
+  const double *Pc[NCG]; // this thread's columns of P: colt, colt + CGT
+#pragma unroll
+  for (int e = 0; e < NCG; e++) Pc[e] = p.P + p.col_cov[min(colt + CGT * e, D - 1)];
 
   long long tlast = 0;
   const bool prof = p.dbg != nullptr && blockIdx.x == 0 && tid == 0;
@@ -558,21 +560,32 @@ __global__ void __launch_bounds__(64 * NW, OCC)
     // ------------------------------------------------------------------ (d) T = H P chunk by chunk (thread = column) -> the gate matrix's tiles
     // Every Jacobian value is wave-uniform: read from the row store through the scalar cache it is an SGPR operand of the
     // multiply-add.  The 14 calibration rows of P are loaded once per camera, the 6 clone rows GL measurements ahead.
+    // Two columns per lane (NCG): half as many wavefronts stream each record through the scalar cache, and the scalar bookkeeping
+    // per multiply-add halves (T sweep 278 -> 238 kcycles per workgroup at 2000 features).
     {
-      double pcp[6] = {0, 0, 0, 0, 0, 0}, pci[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      double pcp[NCG][6], pci[NCG][8];
+#pragma unroll
+      for (int e = 0; e < NCG; e++) {
+#pragma unroll
+        for (int s = 0; s < 6; s++) pcp[e][s] = 0.0;
+#pragma unroll
+        for (int s = 0; s < 8; s++) pci[e][s] = 0.0;
+      }
       int cam_p = -1;
       for (int I = 0; I < NT; I++) {
         const int i_first = FT_CH * I;
-        if (c < D) {
+        if (colt < D) {
 #pragma unroll 1
           for (int gq = 0; gq < CHM; gq += GL) {
-            double pcl[GL][6];
+            double pcl[GL][NCG][6];
 #pragma unroll
             for (int ii = 0; ii < GL; ii++) {
               const int i = min(i_first + MH * (gq + ii) + half, m - 1);
-              const double *Pr = Pc + (size_t)finfo[8 * i + 5] * N;
+              const size_t prow = (size_t)finfo[8 * i + 5] * N;
 #pragma unroll
-              for (int s = 0; s < 6; s++) pcl[ii][s] = Pr[(size_t)s * N];
+              for (int e = 0; e < NCG; e++)
+#pragma unroll
+                for (int s = 0; s < 6; s++) pcl[ii][e][s] = Pc[e][prow + (size_t)s * N];
             }
 #pragma unroll
             for (int ii = 0; ii < GL; ii++) {
@@ -584,28 +597,37 @@ __global__ void __launch_bounds__(64 * NW, OCC)
                 const int camv = mi[0], cv6 = mi[6], cv7 = mi[7];
                 if (camv != cam_p) {
                   cam_p = camv;
+#pragma unroll
+                  for (int e = 0; e < NCG; e++) {
+                    if (cv6 >= 0) {
+#pragma unroll
+                      for (int s = 0; s < 6; s++) pcp[e][s] = Pc[e][(size_t)(cv6 + s) * N];
+                    }
+                    if (cv7 >= 0) {
+#pragma unroll
+                      for (int s = 0; s < 8; s++) pci[e][s] = Pc[e][(size_t)(cv7 + s) * N];
+                    }
+                  }
+                }
+#pragma unroll
+                for (int e = 0; e < NCG; e++) {
+                  double t0 = 0.0, t1 = 0.0, s0 = 0.0, s1 = 0.0;
+#pragma unroll
+                  for (int s = 0; s < 6; s++) t0 = fma(rd[RO_CLONE + s], pcl[ii][e][s], t0), t1 = fma(rd[RO_CLONE + 6 + s], pcl[ii][e][s], t1);
                   if (cv6 >= 0) {
 #pragma unroll
-                    for (int s = 0; s < 6; s++) pcp[s] = Pc[(size_t)(cv6 + s) * N];
+                    for (int s = 0; s < 6; s++) s0 = fma(rd[RO_CPOSE + s], pcp[e][s], s0), s1 = fma(rd[RO_CPOSE + 6 + s], pcp[e][s], s1);
                   }
                   if (cv7 >= 0) {
 #pragma unroll
-                    for (int s = 0; s < 8; s++) pci[s] = Pc[(size_t)(cv7 + s) * N];
+                    for (int s = 0; s < 8; s++) t0 = fma(rd[RO_CINTR + s], pci[e][s], t0), t1 = fma(rd[RO_CINTR + 8 + s], pci[e][s], t1);
+                  }
+                  const int c = colt + CGT * e;
+                  if (c < D) {
+                    Tch[(size_t)(2 * lr) * D + c] = t0 + s0;
+                    Tch[(size_t)(2 * lr + 1) * D + c] = t1 + s1;
                   }
                 }
-                double t0 = 0.0, t1 = 0.0, s0 = 0.0, s1 = 0.0;
-#pragma unroll
-                for (int s = 0; s < 6; s++) t0 = fma(rd[RO_CLONE + s], pcl[ii][s], t0), t1 = fma(rd[RO_CLONE + 6 + s], pcl[ii][s], t1);
-                if (cv6 >= 0) {
-#pragma unroll
-                  for (int s = 0; s < 6; s++) s0 = fma(rd[RO_CPOSE + s], pcp[s], s0), s1 = fma(rd[RO_CPOSE + 6 + s], pcp[s], s1);
-                }
-                if (cv7 >= 0) {
-#pragma unroll
-                  for (int s = 0; s < 8; s++) t0 = fma(rd[RO_CINTR + s], pci[s], t0), t1 = fma(rd[RO_CINTR + 8 + s], pci[s], t1);
-                }
-                Tch[(size_t)(2 * lr) * D + c] = t0 + s0;
-                Tch[(size_t)(2 * lr + 1) * D + c] = t1 + s1;
               }
             }
           }
