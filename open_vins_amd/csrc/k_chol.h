@@ -58,11 +58,14 @@ constexpr int CH_FT = 10;  // tiles per wavefront: 16 * 17 / 2 = 136 <= 15 * 10
 __global__ void __launch_bounds__(64 * (CH_FW + 1), 4) k_chol_factor(CholParams p) {
   __shared__ __attribute__((aligned(16))) double panel[CH_TMAX][256];
   __shared__ __attribute__((aligned(16))) double st[2][256];
+  __shared__ int diag_ready; // number of diagonal tiles handed to the chain wavefront so far (look-ahead hand-over, see below)
   if (p.pred && *p.pred == 0) return;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, cl = lane & 15;
   const int D = p.D, LA = p.LA, TM = (D + 15) >> 4, NTT = TM * (TM + 1) / 2;
+  if (tid == 0) diag_ready = 0;
+  __syncthreads();
   // Barriers of the chain order LDS traffic only; memory traffic is fire-and-forget.  Data for the followers leaves with
   // write-through stores (sc1), and a wavefront adds itself to prog[k - 1] one step LATER, when those stores have long completed
   // (a release fence or a vmcnt(0) wait right behind the stores would sit on the chain: 2-6 us per step).
@@ -78,7 +81,11 @@ __global__ void __launch_bounds__(64 * (CH_FW + 1), 4) k_chol_factor(CholParams 
     const long long t_begin = clock64();
     long long t_diag = 0;
     for (int k = 0; k < TM; k++) {
-      lds_barrier(); // B0: tile (k, k) is in st[0]
+      // Look-ahead: the owner of tile (k, k) brings it up to date FIRST in the trailing update of step k - 1, parks it in st[0] and
+      // raises diag_ready; this wavefront factors it while the others are still in that trailing update.  (st[0] / st[1] are free
+      // then: the panel solve of step k - 1 read st[1] before barrier B2, which this wavefront has passed.)
+      while (__hip_atomic_load(&diag_ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= k) __builtin_amdgcn_s_sleep(1);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       const long long t_d0 = clock64();
       d4 sv, ev;
 #pragma unroll
@@ -89,6 +96,7 @@ __global__ void __launch_bounds__(64 * (CH_FW + 1), 4) k_chol_factor(CholParams 
 #pragma unroll
       for (int q = 0; q < 4; q++) st[1][cl * 16 + g + 4 * q] = ev[q]; // U^-T in accumulator layout -> U^-1 row-major
       t_diag += clock64() - t_d0;
+      lds_barrier(); // B0 (kept so that every wavefront counts the same barriers)
       lds_barrier(); // B1: U_kk^-1 is in st[1]
       if (k > 0) arrive(k - 1);
 #pragma unroll
@@ -129,18 +137,21 @@ __global__ void __launch_bounds__(64 * (CH_FW + 1), 4) k_chol_factor(CholParams 
   }
 #define CTI(s) (tij[s] & 255)
 #define CTJ(s) (tij[s] >> 8)
+  // hands diagonal tile kd (already up to date in this wavefront's registers) to the chain wavefront
+  auto hand_over = [&](int kd) {
+    const int slot = (kd * (kd + 1) / 2 + kd) / CH_FW;
+    d4 av = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s = 0; s < CH_FT; s++)
+      if (s == slot) av = acc[s];
+#pragma unroll
+    for (int q = 0; q < 4; q++) st[0][(g + 4 * q) * 16 + cl] = av[q];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_store(&diag_ready, kd + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  };
+  if (wv == 0) hand_over(0); // tile (0, 0): t = 0 belongs to wavefront 0
   for (int k = 0; k < TM; k++) {
-    // (1) the diagonal tile goes to the chain wavefront
-    const int tkk = k * (k + 1) / 2 + k;
-    if (tkk % CH_FW == wv) {
-      const int slot = tkk / CH_FW;
-      d4 av = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int s = 0; s < CH_FT; s++)
-        if (s == slot) av = acc[s];
-#pragma unroll
-      for (int q = 0; q < 4; q++) st[0][(g + 4 * q) * 16 + cl] = av[q];
-    }
+    // (1) the diagonal tile is already with the chain wavefront (hand_over in the previous trailing update)
     lds_barrier(); // B0
     lds_barrier(); // B1
     // (2) row panel W_kj = U_kk^-T S_kj -> LDS (for the trailing update) and memory (final: the tile is not needed here again).
@@ -174,10 +185,29 @@ __global__ void __launch_bounds__(64 * (CH_FW + 1), 4) k_chol_factor(CholParams 
       }
     }
     lds_barrier(); // B2
-    // (3) trailing update S_ij -= W_ki^T W_kj
+    // (3) trailing update S_ij -= W_ki^T W_kj; the next diagonal tile first, and straight to the chain wavefront
+    const int tnext = (k + 1) * (k + 2) / 2 + k + 1;
+    const bool own_next = k + 1 < TM && tnext % CH_FW == wv;
+    const int slot_next = own_next ? tnext / CH_FW : -1;
+    if (own_next) {
+      const double *pi = panel[k + 1];
+      double a[4], b[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) b[u] = pi[(4 * u + g) * 16 + cl], a[u] = -b[u];
+      d4 av = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int s = 0; s < CH_FT; s++)
+        if (s == slot_next) av = acc[s];
+#pragma unroll
+      for (int u = 0; u < 4; u++) FEAT_MFMA(a[u], b[u], av);
+#pragma unroll
+      for (int s = 0; s < CH_FT; s++)
+        if (s == slot_next) acc[s] = av;
+      hand_over(k + 1);
+    }
 #pragma unroll
     for (int s = 0; s < CH_FT; s++) {
-      if (tij[s] >= 0 && CTI(s) > k) {
+      if (tij[s] >= 0 && CTI(s) > k && s != slot_next) {
         const double *pi = panel[CTI(s)], *pj = panel[CTJ(s)];
         double a[4], b[4];
 #pragma unroll
