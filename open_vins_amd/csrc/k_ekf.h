@@ -239,8 +239,7 @@ __global__ void __launch_bounds__(256) k_ekf_pupdate(EkfParams p) {
 }
 
 // dx = Y^T y     (one thread per state dof)
-__global__ void k_ekf_dx(EkfParams p) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void ekf_dx_item(const EkfParams &p, int i) {
   if (i >= p.N) return;
   if (p.pred && *p.pred == 0) { // no update: the correction is zero
     p.dx[i] = 0.0;
@@ -259,6 +258,7 @@ __global__ void k_ekf_dx(EkfParams p) {
   for (; r < p.D; r++) s0 = fma(Y[(size_t)r * p.LA + i], y[(size_t)r * p.LA], s0);
   p.dx[i] = (s0 + s1) + (s2 + s3);
 }
+__global__ void k_ekf_dx(EkfParams p) { ekf_dx_item(p, blockIdx.x * blockDim.x + threadIdx.x); }
 
 // One step of iterative refinement of dx against the Gram matrix of the stack (k_gram.h).  A Cholesky factor of the
 // rank-deficient G = H^T H reproduces G to rounding error, but the component of g = H^T r along the numerically dependent
@@ -505,9 +505,7 @@ __global__ void __launch_bounds__(256) k_tf_bh(TformParams p) {
 }
 
 // P' = P - (B^T B - Y2^T Y2)      one wavefront per 16x16 tile of P; both products are symmetric tile by tile
-__global__ void __launch_bounds__(256) k_tf_pupdate(EkfParams p, const double *Y1) {
-  const int lane = threadIdx.x & 63;
-  const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+__device__ __forceinline__ void tf_pupdate_tile(const EkfParams &p, const double *Y1, int tile, int lane) {
   const int tn = (p.N + 15) / 16;
   if (tile >= tn * tn || (p.pred && *p.pred == 0)) return;
   const int r0 = (tile / tn) * 16, c0 = (tile % tn) * 16;
@@ -528,6 +526,9 @@ __global__ void __launch_bounds__(256) k_tf_pupdate(EkfParams p, const double *Y
       if (row == col && v < 0.0) p.flags[1] = 1; // StateHelper.cpp:172-182
     }
   }
+}
+__global__ void __launch_bounds__(256) k_tf_pupdate(EkfParams p, const double *Y1) {
+  tf_pupdate_tile(p, Y1, blockIdx.x * 4 + (threadIdx.x >> 6), threadIdx.x & 63);
 }
 
 // ---------------------------------------------------------------------------
@@ -550,16 +551,19 @@ __device__ __forceinline__ void pose_boxplus(double *qp, const double *dx6) {
   qp[4] += dx6[3], qp[5] += dx6[4], qp[6] += dx6[5]; // PoseJPL.h:88
 }
 
-__global__ void k_boxplus(int C, int K, const double *__restrict__ dx, const int32_t *__restrict__ clone_cov, const int32_t *__restrict__ calib_cov,
-                          const int32_t *__restrict__ intr_cov, double *clone_qp, double *calib_qp, double *intr, const int32_t *pred) {
-  if (pred && *pred == 0) return; // a zero correction would still renormalise the quaternions
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void boxplus_item(int t, int C, int K, const double *dx, const int32_t *clone_cov, const int32_t *calib_cov,
+                                             const int32_t *intr_cov, double *clone_qp, double *calib_qp, double *intr) {
   if (t < C) pose_boxplus(clone_qp + 7 * t, dx + clone_cov[t]);
   if (t < K) {
     if (calib_cov[t] >= 0) pose_boxplus(calib_qp + 7 * t, dx + calib_cov[t]);
     if (intr_cov[t] >= 0)
       for (int i = 0; i < 8; i++) intr[8 * t + i] += dx[intr_cov[t] + i]; // Vec::update, Vec.h:55-58
   }
+}
+__global__ void k_boxplus(int C, int K, const double *__restrict__ dx, const int32_t *__restrict__ clone_cov, const int32_t *__restrict__ calib_cov,
+                          const int32_t *__restrict__ intr_cov, double *clone_qp, double *calib_qp, double *intr, const int32_t *pred) {
+  if (pred && *pred == 0) return; // a zero correction would still renormalise the quaternions
+  boxplus_item(blockIdx.x * blockDim.x + threadIdx.x, C, K, dx, clone_cov, calib_cov, intr_cov, clone_qp, calib_qp, intr);
 }
 
 } // namespace ovg

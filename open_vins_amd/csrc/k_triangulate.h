@@ -19,10 +19,8 @@ namespace ovg {
 //         per cam   [12]: R_ItoC(9) p_IinC(3)
 //         per (cam, clone) [12]: R_GtoC(9) p_CinG(3)        index k*C + c
 // ---------------------------------------------------------------------------
-__global__ void k_build_tables(int C, int K, const double *__restrict__ clone_qp, const double *__restrict__ clone_fej,
-                               const double *__restrict__ calib_qp, double *__restrict__ tab_clone, double *__restrict__ tab_cam,
-                               double *__restrict__ tab_cc) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void build_tables_item(int t, int C, int K, const double *clone_qp, const double *clone_fej, const double *calib_qp,
+                                                  double *tab_clone, double *tab_cam, double *tab_cc) {
   if (t < C) {
     const double *q = clone_qp + 7 * t;
     const double *qf = clone_fej + 7 * t;
@@ -49,6 +47,12 @@ __global__ void k_build_tables(int C, int K, const double *__restrict__ clone_qp
     store_m3(tab_cc + 12 * t, R_GtoC);
     store_v3(tab_cc + 12 * t + 9, p);
   }
+}
+
+__global__ void k_build_tables(int C, int K, const double *__restrict__ clone_qp, const double *__restrict__ clone_fej,
+                               const double *__restrict__ calib_qp, double *__restrict__ tab_clone, double *__restrict__ tab_cam,
+                               double *__restrict__ tab_cc) {
+  build_tables_item(blockIdx.x * blockDim.x + threadIdx.x, C, K, clone_qp, clone_fej, calib_qp, tab_clone, tab_cam, tab_cc);
 }
 
 struct RelPose {

@@ -29,6 +29,7 @@
 #include "k_feat.h"
 #include "k_chol.h"
 #include "k_triangulate.h"
+#include "k_tail.h"
 #include "k_retri.h"
 #include "ovgpu_types.h"
 
@@ -1258,14 +1259,17 @@ static int enqueue_ekf_gram(ovgpu_ctx *c, int part, bool side = false) {
     hipLaunchKernelGGL(k_tf_bh, dim3((D + 3) / 4), dim3(256), 0, s, t);
     p.Y = c->Yaug2.p;
     if ((rc = enqueue_chol_carry(c, p, s, nullptr)) != OVGPU_OK) return rc; // Y2 = [C | C^-T B | C^-T h] in c->Yaug2
-    hipLaunchKernelGGL(k_ekf_dx, dim3((N + 255) / 256), dim3(256), 0, s, p);
-    hipLaunchKernelGGL(k_tf_pupdate, dim3((tn * tn + 3) / 4), dim3(256), 0, s, p, (const double *)c->Yaug.p);
-    const int n = std::max(c->C, c->K);
-    hipLaunchKernelGGL(k_boxplus, dim3((n + 255) / 256), dim3(256), 0, s, c->C, c->K, p.dx, c->clone_cov.p, c->calib_cov.p, c->intr_cov.p,
-                       c->clone_qp.p, c->calib_qp.p, c->intr.p, (const int32_t *)(c->flags.p + 3));
+    // covariance tiles + (dx -> box-plus -> pose tables) in one launch (k_tail.h; measured on one box: 1.227 -> 1.197 ms at 2000 features,
+    // 0.737 -> 0.704 ms at 800, against the four separate launches)
+    TailTables tt;
+    tt.C = c->C, tt.K = c->K, tt.clone_cov = c->clone_cov.p, tt.calib_cov = c->calib_cov.p, tt.intr_cov = c->intr_cov.p;
+    tt.clone_qp = c->clone_qp.p, tt.calib_qp = c->calib_qp.p, tt.intr = c->intr.p, tt.clone_fej = c->clone_fej.p;
+    tt.tab_clone = c->tab_clone.p, tt.tab_cam = c->tab_cam.p, tt.tab_cc = c->tab_cc.p;
+    const int nb = (tn * tn + 3) / 4;
+    hipLaunchKernelGGL(k_tf_tail, dim3(nb + 1), dim3(256), 0, s, p, (const double *)c->Yaug.p, tt, nb);
     HIPCHK(hipGetLastError());
     c->last_update_tform = true;
-    return launch_build_tables(c);
+    return OVGPU_OK;
   }
   return OVGPU_OK;
 }
