@@ -31,4 +31,24 @@ __global__ void __launch_bounds__(256) k_tf_tail(EkfParams p, const double *Y1, 
   for (int i = threadIdx.x; i < n2; i += 256) build_tables_item(i, t.C, t.K, t.clone_qp, t.clone_fej, t.calib_qp, t.tab_clone, t.tab_cam, t.tab_cc);
 }
 
+
+// ovgpu_reset_state in one launch: the prior copies of the covariance and of the resident poses / calibration come back, and the
+// pose tables are rebuilt FROM the saved values (four device-to-device copies + a table kernel before: five launches of ~5 us,
+// visible in a bench loop that resets the prior before every update).
+struct RestoreParams {
+  int N2, nC, nK7, nK8, C, K;
+  double *P, *clone_qp, *calib_qp, *intr;
+  const double *P0, *clone_qp0, *calib_qp0, *intr0, *clone_fej;
+  double *tab_clone, *tab_cam, *tab_cc;
+};
+__global__ void __launch_bounds__(256) k_restore_state(RestoreParams r) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < r.N2) r.P[i] = r.P0[i];
+  if (i < r.nC) r.clone_qp[i] = r.clone_qp0[i];
+  if (i < r.nK7) r.calib_qp[i] = r.calib_qp0[i];
+  if (i < r.nK8) r.intr[i] = r.intr0[i];
+  const int nt = r.K * r.C > (r.C > r.K ? r.C : r.K) ? r.K * r.C : (r.C > r.K ? r.C : r.K);
+  if (i < nt) build_tables_item(i, r.C, r.K, r.clone_qp0, r.clone_fej, r.calib_qp0, r.tab_clone, r.tab_cam, r.tab_cc);
+}
+
 } // namespace ovg

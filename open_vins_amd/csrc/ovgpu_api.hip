@@ -89,6 +89,8 @@ struct EventPair {
 
 } // namespace
 
+enum { CTRL_FLAGS = 1, CTRL_ROWS = 2, CTRL_COUNTER = 4, CTRL_PROG0 = 8, CTRL_PROG1 = 16, CTRL_INTS = 64 };
+
 struct ovgpu_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -203,6 +205,11 @@ struct ovgpu_ctx {
   int comm_rank = 0, comm_world = 1;
   DevBuf<double> comm_buf;     // gathered triangles of the Householder exchange
   DevBuf<int32_t> chol_prog;   // [2][16] per-step flags of the single-launch Cholesky (k_chol.h), one set per factorisation in flight
+  // flags (4), rows_used (1), feat_counter (1) and chol_prog (32) are views into ONE block, zeroed by one memset at the start of a
+  // pipeline call; ctrl_clean says which of them have not been touched since (bits CTRL_*), so that the places that used to zero
+  // them one by one (five 5-us launches per update) skip it
+  DevBuf<int32_t> ctrl;
+  unsigned ctrl_clean = 0;
   DevBuf<double> chol_uinv;    // [2][16][256]
   int chol_slot = 0;
   bool no_chol_pipe = false;   // options.no_single_launch_cholesky
@@ -387,6 +394,12 @@ int ovgpu_create(const ovgpu_options *opts, int device, ovgpu_ctx **out) {
   c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   c->lds_limit = (int)std::min<size_t>(prop.sharedMemPerBlock, 160 * 1024);
   HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  HIPCHK(c->ctrl.reserve(CTRL_INTS));
+  HIPCHK(hipMemset(c->ctrl.p, 0, CTRL_INTS * sizeof(int32_t)));
+  c->flags.p = c->ctrl.p, c->flags.cap = 4;               // views: never released on their own
+  c->rows_used.p = c->ctrl.p + 4, c->rows_used.cap = 1;
+  c->feat_counter.p = c->ctrl.p + 5, c->feat_counter.cap = 1;
+  c->chol_prog.p = c->ctrl.p + 8, c->chol_prog.cap = 32;
   DevOptions &d = c->dopt;
   d.chi2_multipler = opts->chi2_multipler;
   d.sigma_pix_sq = opts->sigma_pix * opts->sigma_pix; // UpdaterMSCKF.cpp:45
@@ -461,9 +474,11 @@ void ovgpu_destroy(ovgpu_ctx *c) {
   c->init_ctr.release(), c->feat_slot.release(), c->prop_w.release(), c->prop_in.release(), c->prop_ids.release();
   c->trk_count.release(), c->trk_cam.release(), c->trk_slot_in.release(), c->trk_cam_in.release(), c->trk_sel.release(), c->trk_nvalid.release(), c->trk_flag.release();
   c->trk_time.release(), c->trk_clone_times.release(), c->trk_uv.release(), c->trk_uvn.release(), c->trk_uv_in.release(), c->trk_uvn_in.release();
-  c->dx.release(), c->flags.release(), c->given_status.release();
-  c->gram_part.release(), c->gram_G.release(), c->gram_rho.release(), c->Yaug2.release(), c->gram_dropped.release(), c->rows_used.release(), c->Lw.release(), c->feat_counter.release(), c->dbg_cycles.release();
-  c->chol_prog.release(), c->chol_uinv.release();
+  c->dx.release(), c->given_status.release();
+  c->flags.p = nullptr, c->rows_used.p = nullptr, c->feat_counter.p = nullptr, c->chol_prog.p = nullptr; // views into ctrl
+  c->ctrl.release();
+  c->gram_part.release(), c->gram_G.release(), c->gram_rho.release(), c->Yaug2.release(), c->gram_dropped.release(), c->Lw.release(), c->dbg_cycles.release();
+  c->chol_uinv.release();
   c->fs_minfo.release(), c->fs_meas_feat.release(), c->fs_rows.release(), c->fs_V.release(), c->fs_z.release();
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
@@ -480,6 +495,15 @@ void ovgpu_destroy(ovgpu_ctx *c) {
 
 // state dof of a resident landmark: the single-depth representation keeps its bearing as a constant (Landmark.cpp:124-140)
 static int lm_dof(int rep) { return rep == OVGPU_REP_ANCHORED_INVERSE_DEPTH_SINGLE ? 1 : 3; }
+
+// zero one of the control block's views, unless the block-wide memset at the start of this pipeline call already did (ctrl_clean)
+static hipError_t ctrl_zero(ovgpu_ctx *c, unsigned bit, void *ptr, size_t bytes, hipStream_t s) {
+  if (c->ctrl_clean & bit) {
+    c->ctrl_clean &= ~bit;
+    return hipSuccess;
+  }
+  return hipMemsetAsync(ptr, 0, bytes, s);
+}
 
 static int launch_build_tables(ovgpu_ctx *c) {
   const int n = std::max(c->K * c->C, std::max(c->C, c->K));
@@ -628,12 +652,16 @@ int ovgpu_reset_state(ovgpu_ctx *c) {
   if (!c) return set_err(OVGPU_ERR_INVALID, "null ctx");
   c->prior_pending = false; // the covariance changes: a prior-block factorisation started for a sharded update is stale
   if (!c->have_state || c->poses_only) return set_err(OVGPU_ERR_NO_STATE, "ovgpu_set_state was never called");
-  hipStream_t s = c->stream;
-  HIPCHK(hipMemcpyAsync(c->P.p, c->P0.p, sizeof(double) * c->N * c->N, hipMemcpyDeviceToDevice, s));
-  HIPCHK(hipMemcpyAsync(c->clone_qp.p, c->clone_qp0.p, sizeof(double) * 7 * c->C, hipMemcpyDeviceToDevice, s));
-  HIPCHK(hipMemcpyAsync(c->calib_qp.p, c->calib_qp0.p, sizeof(double) * 7 * c->K, hipMemcpyDeviceToDevice, s));
-  HIPCHK(hipMemcpyAsync(c->intr.p, c->intr0.p, sizeof(double) * 8 * c->K, hipMemcpyDeviceToDevice, s));
-  return launch_build_tables(c);
+  HIPCHK(hipSetDevice(c->device));
+  RestoreParams r;
+  r.N2 = c->N * c->N, r.nC = 7 * c->C, r.nK7 = 7 * c->K, r.nK8 = 8 * c->K, r.C = c->C, r.K = c->K;
+  r.P = c->P.p, r.clone_qp = c->clone_qp.p, r.calib_qp = c->calib_qp.p, r.intr = c->intr.p;
+  r.P0 = c->P0.p, r.clone_qp0 = c->clone_qp0.p, r.calib_qp0 = c->calib_qp0.p, r.intr0 = c->intr0.p, r.clone_fej = c->clone_fej.p;
+  r.tab_clone = c->tab_clone.p, r.tab_cam = c->tab_cam.p, r.tab_cc = c->tab_cc.p;
+  const int n = std::max(std::max(r.N2, r.nC), std::max(r.nK8, c->K * c->C));
+  hipLaunchKernelGGL(k_restore_state, dim3((n + 255) / 256), dim3(256), 0, c->stream, r);
+  HIPCHK(hipGetLastError());
+  return OVGPU_OK;
 }
 
 // Sizes the stacked-system buffer and the TSQR leaf layout for c->rows_total rows of c->LD columns:
@@ -872,7 +900,7 @@ static int enqueue_system(ovgpu_ctx *c, int f_one = -1, int init_rep = 0, bool w
   p.rows_used = c->rows_used.p;
   p.Lw = (whiten && f_one < 0) ? c->Lw.p : nullptr;
   int grid = c->sys_grid;
-  if (f_one < 0) HIPCHK(hipMemsetAsync(c->rows_used.p, 0, sizeof(int32_t), c->stream));
+  if (f_one < 0) HIPCHK(ctrl_zero(c, CTRL_ROWS, c->rows_used.p, sizeof(int32_t), c->stream));
   if (f_one >= 0) {
     p.order = nullptr;
     p.rows_used = nullptr;
@@ -884,7 +912,7 @@ static int enqueue_system(ovgpu_ctx *c, int f_one = -1, int init_rep = 0, bool w
   // the MSCKF fast path: whitened output, global representation, one noise level (k_feat.h)
   if (p.Lw && c->feat_variant && !p.slam && !p.feat_sigma && !p.feat_chi2mult) {
     HIPCHK(c->feat_counter.reserve(1));
-    HIPCHK(hipMemsetAsync(c->feat_counter.p, 0, sizeof(int32_t), c->stream));
+    HIPCHK(ctrl_zero(c, CTRL_COUNTER, c->feat_counter.p, sizeof(int32_t), c->stream));
     p.work_counter = c->feat_counter.p;
     static bool attr_done = false;
     if (!attr_done) {
@@ -1140,7 +1168,7 @@ static int enqueue_ekf(ovgpu_ctx *c, const EkfJob &job = EkfJob()) {
   p.dx = job.dx ? job.dx : c->dx.p, p.flags = c->flags.p;
   p.sigma2 = job.sigma2 >= 0.0 ? job.sigma2 : c->dopt.sigma_pix_sq;
   hipStream_t s = c->stream;
-  if (!job.keep_flags) HIPCHK(hipMemsetAsync(c->flags.p, 0, 4 * sizeof(int32_t), s));
+  if (!job.keep_flags) HIPCHK(ctrl_zero(c, CTRL_FLAGS, c->flags.p, 4 * sizeof(int32_t), s));
   const int tm = (p.D + 15) / 16, tn = (p.N + 15) / 16;
   hipLaunchKernelGGL(k_ekf_mt, dim3((tm * tn + 3) / 4), dim3(256), 0, s, p);
   hipLaunchKernelGGL(k_ekf_s, dim3((tm * tm + 3) / 4), dim3(256), 0, s, p);
@@ -1173,7 +1201,7 @@ static int enqueue_chol_carry(ovgpu_ctx *c, const EkfParams &p, hipStream_t s, d
     chol::CholParams q;
     q.D = p.D, q.LA = p.LA, q.A = p.A, q.Y = p.Y, q.Lt = Lt, q.flags = p.flags, q.diag0 = p.diag0, q.pivot_tol = p.pivot_tol, q.pred = p.pred;
     q.prog = c->chol_prog.p + 16 * slot, q.uinv = c->chol_uinv.p + (size_t)slot * 16 * 256, q.err = p.flags + 2, q.dbg = c->dbg_cycles.p;
-    HIPCHK(hipMemsetAsync(q.prog, 0, 16 * sizeof(int32_t), s));
+    HIPCHK(ctrl_zero(c, slot ? CTRL_PROG1 : CTRL_PROG0, q.prog, 16 * sizeof(int32_t), s));
     const int carried = (p.LA - p.D + 15) / 16;
     // the followers run next to the factor workgroup: same stream order is not enough (they would start after it), so they go to
     // the context's helper stream behind an event and join again
@@ -1228,7 +1256,7 @@ static int enqueue_ekf_gram(ovgpu_ctx *c, int part, bool side = false) {
   int rc = OVGPU_OK;
   if (part & 1) {
     if (c->prior_on_side) HIPCHK(hipStreamWaitEvent(s, c->ev_join, 0)); // a factorisation nobody joined still owns the work matrices
-    HIPCHK(hipMemsetAsync(c->flags.p, 0, 4 * sizeof(int32_t), s));
+    HIPCHK(ctrl_zero(c, CTRL_FLAGS, c->flags.p, 4 * sizeof(int32_t), s));
     hipStream_t sp = s;
     c->prior_on_side = false;
     if (side && part == 1) { // everything enqueued so far (the previous update's tail reads these buffers) precedes the side stream's work
@@ -1289,7 +1317,20 @@ static EventPair *next_events(ovgpu_ctx *c, std::vector<EventPair> &v, size_t id
 enum { STAGE_LOCAL = 1, STAGE_EKF = 2 };
 
 // factor_stays: the compressed factor is consumed on the device (EKF update, cross-GPU merge) and never shown to the caller
+static int enqueue_pipeline_body(ovgpu_ctx *c, int stages, bool slam, bool factor_stays, bool gram_only);
 static int enqueue_pipeline(ovgpu_ctx *c, int stages, bool slam = false, bool factor_stays = false, bool gram_only = false) {
+  // one memset for the control block instead of one per flag word (unless side-stream work of an earlier call still owns part of it)
+  c->ctrl_clean = 0;
+  if (c->have_state && !c->prior_on_side && !c->prior_pending && c->ctrl.p) {
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemsetAsync(c->ctrl.p, 0, CTRL_INTS * sizeof(int32_t), c->stream));
+    c->ctrl_clean = CTRL_FLAGS | CTRL_ROWS | CTRL_COUNTER | CTRL_PROG0 | CTRL_PROG1;
+  }
+  const int rc = enqueue_pipeline_body(c, stages, slam, factor_stays, gram_only);
+  c->ctrl_clean = 0;
+  return rc;
+}
+static int enqueue_pipeline_body(ovgpu_ctx *c, int stages, bool slam, bool factor_stays, bool gram_only) {
   if (!c->have_state || c->poses_only) return set_err(OVGPU_ERR_NO_STATE, "ovgpu_set_state was never called");
   if (!c->have_feats) return set_err(OVGPU_ERR_NO_STATE, "ovgpu_set_features was never called (or the state changed since)");
   HIPCHK(hipSetDevice(c->device));
