@@ -504,6 +504,22 @@ __global__ void __launch_bounds__(256) k_tf_bh(TformParams p) {
   if (lane == 0) a[p.D + p.N] = s * p.inv_sigma2;
 }
 
+// Whitened route, k_tf_go + k_tf_a + k_tf_bh in one launch (they were three 6-us launches between the Gram reduction and the second
+// factorisation): one wavefront per row r of A = [I + G / sigma^2 | B | g / sigma^2]; `go` is derived from the first factorisation's
+// flag by every wavefront and published by the first for the kernels that follow.
+__global__ void __launch_bounds__(256) k_tf_abh(TformParams p, const int32_t *flags, int32_t *go_out) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const bool go = flags[0] == 0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) go_out[0] = go ? 1 : 0;
+  if (r >= p.D || !go) return;
+  const double *y = p.Y1 + (size_t)r * p.LA, *gr = p.G + (size_t)r * p.LG;
+  double *a = p.A + (size_t)r * p.LA;
+  for (int c = lane; c < p.D; c += 64) a[c] = gr[c] * p.inv_sigma2 + (r == c ? 1.0 : 0.0);
+  for (int c = lane; c < p.N; c += 64) a[p.D + c] = y[p.D + c];
+  if (lane == 0) a[p.D + p.N] = gr[p.D] * p.inv_sigma2; // the stack was whitened row by row: column D of its Gram matrix is U1 g already
+}
+
 // P' = P - (B^T B - Y2^T Y2)      one wavefront per 16x16 tile of P; both products are symmetric tile by tile
 __device__ __forceinline__ void tf_pupdate_tile(const EkfParams &p, const double *Y1, int tile, int lane) {
   const int tn = (p.N + 15) / 16;

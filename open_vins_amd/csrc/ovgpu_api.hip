@@ -1276,15 +1276,15 @@ static int enqueue_ekf_gram(ovgpu_ctx *c, int part, bool side = false) {
   if (part & 2) {
     if (c->prior_on_side) HIPCHK(hipStreamWaitEvent(s, c->ev_join, 0));
     c->prior_pending = false, c->prior_on_side = false;
-    hipLaunchKernelGGL(k_tf_go, dim3(1), dim3(1), 0, s, (const int32_t *)c->flags.p, c->flags.p + 3);
     p.pred = c->flags.p + 3; // a prior block that is not positive definite: skip, the host falls back (finish_update)
     if (t.whitened) {
-      hipLaunchKernelGGL(k_tf_a, dim3((unsigned)((D * D + 255) / 256)), dim3(256), 0, s, t);
+      hipLaunchKernelGGL(k_tf_abh, dim3((D + 3) / 4), dim3(256), 0, s, t, (const int32_t *)c->flags.p, c->flags.p + 3);
     } else {
+      hipLaunchKernelGGL(k_tf_go, dim3(1), dim3(1), 0, s, (const int32_t *)c->flags.p, c->flags.p + 3);
       hipLaunchKernelGGL(k_tf_w, dim3((tm * tm + 3) / 4), dim3(256), 0, s, t);
       hipLaunchKernelGGL(k_tf_t, dim3((tm * tm + 3) / 4), dim3(256), 0, s, t);
+      hipLaunchKernelGGL(k_tf_bh, dim3((D + 3) / 4), dim3(256), 0, s, t);
     }
-    hipLaunchKernelGGL(k_tf_bh, dim3((D + 3) / 4), dim3(256), 0, s, t);
     p.Y = c->Yaug2.p;
     if ((rc = enqueue_chol_carry(c, p, s, nullptr)) != OVGPU_OK) return rc; // Y2 = [C | C^-T B | C^-T h] in c->Yaug2
     // covariance tiles + (dx -> box-plus -> pose tables) in one launch (k_tail.h; measured on one box: 1.227 -> 1.197 ms at 2000 features,
