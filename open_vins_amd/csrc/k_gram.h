@@ -17,6 +17,8 @@
 //   * 12 wavefronts (8 accumulating with 13-17 tiles each + 4 staging, 168 registers): 0.46 ms — the accumulator tiles of the
 //     eight per-wavefront instantiations no longer fit next to their operands, and spill reloads inside the k-step loop stall the
 //     matrix cores.  This kernel's 27-34 tiles per wavefront need 172 + 256 registers: one wavefront per SIMD, by design.
+//   * 8 wavefronts, two per SIMD, 13-17 tiles each, ONE code path (slot -> tile by run-time offsets, no spills): 0.27 ms — one LDS
+//     operand read per matrix instruction instead of one per two; the second wavefront per SIMD does not make up for it.
 //
 // The default route feeds G straight into the EKF update written in coordinates whitened by the prior (k_ekf.h,
 // "EKF update from the Gram matrix"): no factor of G is ever formed.  Across GPUs Gram matrices simply add (one all-reduce).
