@@ -122,20 +122,36 @@ def main(argv=None):
             dist.barrier()
             torch.cuda.synchronize()
 
+    exchange = {"kind": "none (one GPU)"}
+
     def run(prob_full, feats_of_rank, steps, warmup):
         """Times `steps` updates of prob_full sharded as feats_of_rank(rank); returns (seconds max over ranks, updater, shard)."""
         shard = prob_full if world == 1 else prob_full.subset(feats_of_rank)
         up = UpdaterMSCKF(opts, device=local_rank)
         up.set_problem(shard)  # H2D once; everything below runs on resident data
+        native = True
         if world > 1:
-            up.comm_init(dist, device)
+            # the exchange inside the library (RCCL on the context's stream); if its communicator cannot be set up on this node, every
+            # rank falls back TOGETHER to the host-driven protocol (torch.distributed all-reduce of the Gram buffer, parallel.py)
+            try:
+                up.comm_init(dist, device)
+            except Exception as e:  # noqa: BLE001
+                print(f"[bench rank {rank}] native RCCL exchange unavailable ({e}); host-driven exchange instead", file=sys.stderr, flush=True)
+                native = False
+            ok = torch.tensor([1 if native else 0], dtype=torch.int32, device=device)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            native = bool(ok.item())
+            exchange["kind"] = "ncclAllReduce inside libovgpu (context stream)" if native else "torch.distributed all_reduce (host-driven fallback)"
+        backend = parallel.GpuShardBackend(up)
 
         def step():
             up.reset_state()  # device-side copy of the prior: every step updates the same prior
             if world == 1:
                 up.update_async()
-            else:
+            elif native:
                 up.update_sharded_async()  # local stage -> ncclAllReduce -> update, one stream, no host sync
+            else:
+                parallel.distributed_update(backend, dist, device, want_outputs=False)
 
         for _ in range(warmup):
             step()
@@ -208,7 +224,7 @@ def main(argv=None):
                              f"{' dealt over ' + str(world) + ' GPUs' if world > 1 else ''}, N={prob.N}, D={prob.Dmax}, online cam extrinsic+intrinsic calib, FEJ"),
                 "features_total": prob.F, "features_this_rank": shard.F, "clones": prob.C, "cameras": prob.K, "state_dim": prob.N,
                 "measurements_total": prob.M, "features_used_rank0": int(res["stats"]["n_used"]),
-                "parallelism": f"feature-shard x{world}, one ncclAllReduce of the Gram matrix" if world > 1 else "single GPU",
+                "parallelism": f"feature-shard x{world}, one all-reduce of the Gram matrix: {exchange['kind']}" if world > 1 else "single GPU",
             },
             "roofline": {
                 "kernel": "per-feature stage = k_feat_rows + k_feat_qr + k_feat + k_feat_out (csrc/k_feat.h: Jacobians, chi2 gate with the gate matrix in "
