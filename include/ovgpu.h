@@ -264,6 +264,14 @@ int ovgpu_triangulate(ovgpu_ctx *ctx, double *p_FinA, double *p_FinG,
  * resident) until the next ovgpu_set_state.                                                                      */
 int ovgpu_set_camera_poses(ovgpu_ctx *ctx, int C, int K, const double *R_GtoC, const double *p_CinG);
 
+/* FeatureInitializer::single_gaussnewton ALONE (FeatureInitializer.cpp:197-375): the Levenberg-Marquardt refinement of the
+ * resident features started from the caller's estimates p_FinA_in (3 doubles per feature, in the frame of the anchor
+ * measurement anchor_meas_in[f]) instead of from the library's own linear triangulation — for callers that seed
+ * Feature::p_FinA themselves.  Outputs as ovgpu_triangulate (the anchor is the one passed in).  refine_features of the
+ * context must be set; an anchor outside the feature's measurements fails that feature.                              */
+int ovgpu_refine(ovgpu_ctx *ctx, const double *p_FinA_in, const int32_t *anchor_meas_in, double *p_FinA,
+                 double *p_FinG, int32_t *status);
+
 /* Reads back what the triangulation stage of the LAST pipeline call on the current features left on the device
  * (ovgpu_msckf_compress / _update / ovgpu_slam_delayed_init triangulate internally): p_FinA / p_FinG (3 doubles per
  * feature) and the anchor measurement index, the values the reference stores on the Feature

@@ -187,6 +187,7 @@ def declare(lib):
         "ovgpu_retriangulate": (C.c_int, [ctxp, C.c_int32, C.c_int32, c_int64_p, c_int32_p, c_float_p, c_float_p, C.c_int32, C.c_int32, C.c_int32, c_int32_p,
                                           c_int64_p, c_double_p, c_double_p]),
         "ovgpu_retriangulate_reset": (C.c_int, [ctxp]),
+        "ovgpu_refine": (C.c_int, [ctxp, c_double_p, c_int32_p, c_double_p, c_double_p, c_int32_p]),
         "ovgpu_get_triangulation": (C.c_int, [ctxp, c_double_p, c_double_p, c_int32_p]),
         "ovgpu_set_triangulation": (C.c_int, [ctxp, c_double_p, c_double_p, c_int32_p, c_int32_p]),
         "ovgpu_msckf_update": (C.c_int, [ctxp, c_int32_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p,

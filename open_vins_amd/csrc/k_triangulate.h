@@ -136,13 +136,23 @@ __global__ void __launch_bounds__(256) k_triangulate(TriParams p) {
     }
     anchor = best_last;
   }
+  const bool seeded = p.seed_pA != nullptr; // single_gaussnewton on a caller's estimate: its anchor and position stand
+  if (seeded) {
+    anchor = p.seed_anchor[f];
+    if (anchor < m0 || anchor >= m1) {
+      finish(OVGPU_FEAT_TRI_FAILED, -1, vnan, vnan);
+      return;
+    }
+  }
   const int acode = p.meas_cc[anchor];
   const int acc = (acode >> 10) * p.C + (acode & 1023);
   const M3 R_GtoA = load_m3(lds_cc + 12 * acc);
   const V3 p_AinG = load_v3(lds_cc + 12 * acc + 9);
 
   V3 p_f;
-  if (!p.opt.triangulate_1d) {
+  if (seeded) {
+    p_f = load_v3(p.seed_pA + 3 * f);
+  } else if (!p.opt.triangulate_1d) {
     // ---- single_triangulation: A = sum Bperp^T Bperp, b = sum A_i p_CiinA   (:58-85)
     double A00 = 0, A01 = 0, A02 = 0, A11 = 0, A12 = 0, A22 = 0, b0 = 0, b1 = 0, b2 = 0;
     for (int i = m0 + lane; i < m1; i += 64) {

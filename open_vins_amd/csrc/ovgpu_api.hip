@@ -131,8 +131,8 @@ struct ovgpu_ctx {
   // ovgpu_retriangulate: the running linear systems of the active tracks, two generations (k_retri.h)
   std::unordered_map<int64_t, int32_t> retri_slot_of;
   DevBuf<double> retri_sys[2], retri_pos, retri_uvd;
-  DevBuf<int32_t> retri_int, marg_idx;
-  DevBuf<double> marg_out;
+  DevBuf<int32_t> retri_int, marg_idx, seed_anchor;
+  DevBuf<double> marg_out, seed_pA;
   DevBuf<float> retri_f;
   int retri_gen = 0;
   std::vector<int32_t> trk_free, trk_h_count;
@@ -465,7 +465,7 @@ void ovgpu_destroy(ovgpu_ctx *c) {
   c->clone_cov.release(), c->calib_cov.release(), c->intr_cov.release(), c->clone_col.release(), c->calib_col.release();
   c->intr_col.release(), c->col_cov.release(), c->col_kind.release(), c->col_sub.release(), c->col_var.release();
   c->tab_clone.release(), c->tab_cam.release(), c->tab_cc.release();
-  c->retri_sys[0].release(), c->retri_sys[1].release(), c->retri_pos.release(), c->retri_uvd.release(), c->retri_int.release(), c->retri_f.release(), c->marg_idx.release(), c->marg_out.release();
+  c->retri_sys[0].release(), c->retri_sys[1].release(), c->retri_pos.release(), c->retri_uvd.release(), c->retri_int.release(), c->retri_f.release(), c->marg_idx.release(), c->marg_out.release(), c->seed_anchor.release(), c->seed_pA.release();
   c->meas_offsets.release(), c->meas_cc.release(), c->uv.release(), c->uvn.release(), c->row_off.release();
   c->pA.release(), c->pG.release(), c->chi2.release(), c->chi2_thr.release(), c->anchor.release(), c->status.release(), c->sys_order.release(), c->feat_sigma.release(), c->feat_mult.release();
   c->chi2_table.release(), c->Hbig.release(), c->gate_ws.release(), c->Rws.release(), c->tree_nodes.release(), c->tree_nodes2.release(), c->tree_flags.release(), c->tree_err.release(), c->Mt.release(), c->Aaug.release(), c->Yaug.release();
@@ -857,9 +857,10 @@ int ovgpu_set_features(ovgpu_ctx *c, const ovgpu_features_view *fv) {
 // ---------------------------------------------------------------------------
 // pipeline stages (all asynchronous on ctx->stream)
 // ---------------------------------------------------------------------------
-static int enqueue_triangulate(ovgpu_ctx *c) {
+static int enqueue_triangulate(ovgpu_ctx *c, const double *seed_pA = nullptr, const int32_t *seed_anchor = nullptr) {
   if (c->F == 0) return OVGPU_OK;
   TriParams p;
+  p.seed_pA = seed_pA, p.seed_anchor = seed_anchor;
   p.F = c->F, p.C = c->C, p.K = c->K;
   p.meas_offsets = c->meas_offsets.p, p.meas_cc = c->meas_cc.p, p.uvn = c->uvn.p, p.tab_cc = c->tab_cc.p;
   p.p_FinA = c->pA.p, p.p_FinG = c->pG.p, p.anchor_meas = c->anchor.p, p.status = c->status.p;
@@ -1452,6 +1453,29 @@ int ovgpu_triangulate(ovgpu_ctx *c, double *p_FinA, double *p_FinG, int32_t *anc
     if (p_FinA) HIPCHK(hipMemcpyAsync(p_FinA, c->pA.p, sizeof(double) * 3 * F, hipMemcpyDeviceToHost, s));
     if (p_FinG) HIPCHK(hipMemcpyAsync(p_FinG, c->pG.p, sizeof(double) * 3 * F, hipMemcpyDeviceToHost, s));
     if (anchor_meas) HIPCHK(hipMemcpyAsync(anchor_meas, c->anchor.p, sizeof(int32_t) * F, hipMemcpyDeviceToHost, s));
+    if (status) HIPCHK(hipMemcpyAsync(status, c->status.p, sizeof(int32_t) * F, hipMemcpyDeviceToHost, s));
+  }
+  HIPCHK(hipStreamSynchronize(s));
+  return OVGPU_OK;
+}
+
+int ovgpu_refine(ovgpu_ctx *c, const double *p_FinA_in, const int32_t *anchor_meas_in, double *p_FinA, double *p_FinG, int32_t *status) {
+  if (!c || !p_FinA_in || !anchor_meas_in) return set_err(OVGPU_ERR_INVALID, "null argument");
+  if (!c->have_state || !c->have_feats) return set_err(OVGPU_ERR_NO_STATE, "state / features not set");
+  HIPCHK(hipSetDevice(c->device));
+  const int F = c->F;
+  hipStream_t s = c->stream;
+  HIPCHK(c->seed_pA.reserve((size_t)3 * std::max(F, 1)));
+  HIPCHK(c->seed_anchor.reserve(std::max(F, 1)));
+  if (F > 0) {
+    HIPCHK(upload(c->seed_pA.p, p_FinA_in, sizeof(double) * 3 * F, s));
+    HIPCHK(upload(c->seed_anchor.p, anchor_meas_in, sizeof(int32_t) * F, s));
+  }
+  const int rc = enqueue_triangulate(c, c->seed_pA.p, c->seed_anchor.p);
+  if (rc != OVGPU_OK) return rc;
+  if (F > 0) {
+    if (p_FinA) HIPCHK(hipMemcpyAsync(p_FinA, c->pA.p, sizeof(double) * 3 * F, hipMemcpyDeviceToHost, s));
+    if (p_FinG) HIPCHK(hipMemcpyAsync(p_FinG, c->pG.p, sizeof(double) * 3 * F, hipMemcpyDeviceToHost, s));
     if (status) HIPCHK(hipMemcpyAsync(status, c->status.p, sizeof(int32_t) * F, hipMemcpyDeviceToHost, s));
   }
   HIPCHK(hipStreamSynchronize(s));

@@ -29,6 +29,8 @@ struct TriParams {
   int32_t *anchor_meas;        // [F]
   int32_t *status;             // [F]
   DevOptions opt;
+  const double *seed_pA;       // ovgpu_refine: start the refinement from these positions (anchor frame) ...
+  const int32_t *seed_anchor;  // ... in these anchors, instead of triangulating (FeatureInitializer::single_gaussnewton alone)
 };
 
 // column kinds of the canonical stacked-Jacobian column order

@@ -4,10 +4,9 @@
 // The reference calls these per feature inside loops (UpdaterMSCKF.cpp:117-142, UpdaterSLAM.cpp:113-147,
 // VioManagerHelper.cpp:251-293).  The MSCKF shim does not go through here (it hands the whole batch to the library); this file
 // keeps the class usable for the remaining callers: one feature = a batch of one.  single_triangulation runs the device
-// triangulation WITHOUT the Gauss-Newton refinement (a context with refine_features = 0); single_gaussnewton runs triangulation +
-// refinement in one pass from the same measurements, which reproduces the reference's two-call sequence when — as in every call
-// site of the reference — the refinement follows the triangulation of the same feature (a caller that seeds Feature::p_FinA
-// itself before single_gaussnewton is not supported).  Contexts are keyed by the option values of the calling instance.
+// triangulation WITHOUT the Gauss-Newton refinement (a context with refine_features = 0); single_gaussnewton runs the refinement
+// alone (ovgpu_refine) from the anchor and p_FinA the Feature carries, as the reference does (FeatureInitializer.cpp:199-216).
+// Contexts are keyed by the option values of the calling instance.
 #include "FeatureInitializer.h"
 
 #include <cstring>
@@ -76,7 +75,8 @@ bool flatten(const std::shared_ptr<Feature> &feat, ClonesCam &clonesCAM, OneFeat
   return total >= 2;
 }
 
-bool run(ovgpu_shim::Context &ctx, const std::shared_ptr<Feature> &feat, ClonesCam &clonesCAM) {
+// seeded: single_gaussnewton on the estimate the Feature already carries (its anchor and p_FinA, FeatureInitializer.cpp:199-216)
+bool run(ovgpu_shim::Context &ctx, const std::shared_ptr<Feature> &feat, ClonesCam &clonesCAM, bool seeded = false) {
   OneFeature o;
   if (!flatten(feat, clonesCAM, o)) return false;
   ctx.check(ovgpu_set_camera_poses(ctx.get(), o.C, o.K, o.R.data(), o.p.data()), "ovgpu_set_camera_poses");
@@ -84,7 +84,15 @@ bool run(ovgpu_shim::Context &ctx, const std::shared_ptr<Feature> &feat, ClonesC
   ctx.check(ovgpu_set_features(ctx.get(), &fv), "ovgpu_set_features");
   double pA[3], pG[3];
   int32_t anchor = -1, status = 0;
-  ctx.check(ovgpu_triangulate(ctx.get(), pA, pG, &anchor, &status), "ovgpu_triangulate");
+  if (seeded) {
+    for (size_t i = 0; i < o.ff.cam_idx.size(); i++)
+      if ((int)o.cam_ids[o.ff.cam_idx[i]] == feat->anchor_cam_id && o.ff.meas_time[i] == feat->anchor_clone_timestamp) anchor = (int32_t)i;
+    if (anchor < 0) return false; // the Feature's anchor is not among its measurements in this window
+    const double seed[3] = {feat->p_FinA(0), feat->p_FinA(1), feat->p_FinA(2)};
+    ctx.check(ovgpu_refine(ctx.get(), seed, &anchor, pA, pG, &status), "ovgpu_refine");
+  } else {
+    ctx.check(ovgpu_triangulate(ctx.get(), pA, pG, &anchor, &status), "ovgpu_triangulate");
+  }
   if (anchor >= 0) { // FeatureInitializer.cpp:45-46
     feat->anchor_cam_id = (int)o.cam_ids[o.ff.cam_idx[anchor]];
     feat->anchor_clone_timestamp = o.ff.meas_time[anchor];
@@ -105,5 +113,5 @@ bool FeatureInitializer::single_triangulation_1d(std::shared_ptr<Feature> feat, 
 }
 
 bool FeatureInitializer::single_gaussnewton(std::shared_ptr<Feature> feat, std::unordered_map<size_t, std::unordered_map<double, ClonePose>> &clonesCAM) {
-  return run(context(_options, 1, _options.triangulate_1d ? 1 : 0), feat, clonesCAM);
+  return run(context(_options, 1, _options.triangulate_1d ? 1 : 0), feat, clonesCAM, true);
 }

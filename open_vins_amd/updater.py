@@ -92,6 +92,15 @@ class UpdaterMSCKF:
                    "ovgpu_triangulate")
         return out
 
+    def refine(self, p_FinA, anchor_meas):
+        """FeatureInitializer::single_gaussnewton alone: refinement from the caller's positions / anchors."""
+        F = self.F
+        pa = np.ascontiguousarray(p_FinA, dtype=np.float64)
+        am = np.ascontiguousarray(anchor_meas, dtype=np.int32)
+        out = dict(p_FinA=np.zeros((F, 3)), p_FinG=np.zeros((F, 3)), status=np.zeros(F, np.int32))
+        capi.check(self.lib.ovgpu_refine(self._ctx, _dp(pa), _ip(am), _dp(out["p_FinA"]), _dp(out["p_FinG"]), _ip(out["status"])), "ovgpu_refine")
+        return out
+
     def get_triangulation(self):
         """What the triangulation stage of the last compress / update / delayed_init left on the device (no second pass)."""
         F = self.F

@@ -1333,3 +1333,29 @@ def test_zero_velocity_update_algebra(Updater, oracle):
     assert not again["accepted"] and "dx" not in again
     np.testing.assert_array_equal(up.get_state()["P"], out["P"])
     up.close()
+
+
+def test_refinement_alone_from_a_given_estimate(Updater, oracle):
+    """FeatureInitializer::single_gaussnewton by itself (ovgpu_refine): seeded with the unrefined triangulation it reproduces, bit for
+    bit, what triangulation + refinement in one pass give; seeded with a perturbed estimate it converges to the same point."""
+    prob = synth.make_problem(2, F=90)
+    lin = Updater(capi.default_options(refine_features=0))
+    lin.set_problem(prob)
+    seed = lin.triangulate()
+    lin.close()
+    up = Updater(capi.default_options())
+    up.set_problem(prob)
+    full = up.triangulate()
+    ok = (seed["status"] == 0) & (full["status"] == 0)
+    assert ok.sum() > 70
+    out = up.refine(seed["p_FinA"], seed["anchor_meas"])
+    assert np.array_equal(out["status"][ok], full["status"][ok])
+    np.testing.assert_array_equal(out["p_FinA"][ok], full["p_FinA"][ok])
+    np.testing.assert_array_equal(out["p_FinG"][ok], full["p_FinG"][ok])
+    off = seed["p_FinA"] * (1.0 + 0.02 * np.random.default_rng(5).normal(size=seed["p_FinA"].shape))
+    out2 = up.refine(off, seed["anchor_meas"])
+    good = ok & (out2["status"] == 0)
+    assert good.sum() > 60 and np.abs(out2["p_FinG"][good] - full["p_FinG"][good]).max() < 1e-3
+    ref = oracle.triangulate(capi.default_options(), capi.Views(prob))
+    assert np.abs(out["p_FinG"][ok] - ref["p_FinG"][ok]).max() < TOL_TRI
+    up.close()
