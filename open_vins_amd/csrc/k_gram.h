@@ -26,7 +26,7 @@
 // The default route feeds G straight into the EKF update written in coordinates whitened by the prior (k_ekf.h,
 // "EKF update from the Gram matrix"): no factor of G is ever formed.  Across GPUs Gram matrices simply add (one all-reduce).
 //
-//   k_gram_chol    (OVGPU_COMPRESS=cholqr only) right-looking Cholesky of the (LD x LD) sum inside ONE workgroup, the
+//   k_gram_chol    (compress_route = OVGPU_COMPRESS_CHOLQR only) right-looking Cholesky of the (LD x LD) sum inside ONE workgroup, the
 //                  matrix held in registers (block-cyclic over 32 x 32 threads), one barrier per row; non-positive pivots —
 //                  the stack of an MSCKF update is rank deficient along the unobservable directions — leave a zero row.
 //                  This is the measured NEGATIVE result of DESIGN.md section 4: forming and factoring G squares the

@@ -1093,7 +1093,7 @@ static int enqueue_gram_factor(ovgpu_ctx *c) {
   return OVGPU_OK;
 }
 
-// cholqr: R = chol(Gram) instead of the Householder TSQR (OVGPU_COMPRESS=cholqr, tall stacks)
+// cholqr: R = chol(Gram) instead of the Householder TSQR (compress_route = OVGPU_COMPRESS_CHOLQR, tall stacks)
 static int enqueue_compress(ovgpu_ctx *c, bool cholqr = false) {
   const int D = c->D, LD = c->LD;
   const int NT = (LD + 15) / 16;
