@@ -216,6 +216,7 @@ struct FeatStore {
   double *V;      // [2M][3]  reflectors of H_f, row 2 gm + a
   double *z;      // [F][3][LD]  T^T V^T [H L | r]
   const int32_t *meas_feat; // [M] feature of each measurement
+  double *w;                // [F][3][LD] T^T V^T [H | r] of every feature (k_feat_qr), the left operand of k_feat_z
 };
 
 // ---------------------------------------------------------------------------------------------------
@@ -311,33 +312,52 @@ __global__ void __launch_bounds__(256) k_feat_qr(SysParams p, FeatStore st) {
     wvv[c] = y0, wvv[LD + c] = y1, wvv[2 * LD + c] = y2;
   }
   wsync();
+  // z = T^T (wv L) = (T^T wv) L: the 3 x 3 factor is applied here, the product with L — a (3 F x D) x (D x D) matrix product over ALL
+  // features — is k_feat_z's on the matrix cores (inside this kernel it was a chain of dependent L2 round trips: 86 us of the update's
+  // critical path at 2000 features)
   const double T00 = hq[3], T01 = hq[4], T02 = hq[5], T11 = hq[6], T12 = hq[7], T22 = hq[8];
-  double *zo = st.z + (size_t)f * 3 * LD;
+  double *wo = st.w + (size_t)f * 3 * LD;
   for (int c = lane; c < LD; c += 64) {
-    double y0, y1, y2;
-    if (c == D) {
-      y0 = wvv[D], y1 = wvv[LD + D], y2 = wvv[2 * LD + D];
-    } else { // y = wv L; L is lower triangular: rows s < c of column c are zero
-      const double *Lc = p.Lw + c;
-      double a0 = 0.0, a1 = 0.0, a2 = 0.0, b0 = 0.0, b1 = 0.0, b2 = 0.0;
-      int s = c;
-      for (; s + 7 < D; s += 8) {
-        double l[8];
+    const double y0 = wvv[c], y1 = wvv[LD + c], y2 = wvv[2 * LD + c];
+    wo[c] = T00 * y0, wo[LD + c] = T01 * y0 + T11 * y1, wo[2 * LD + c] = T02 * y0 + T12 * y1 + T22 * y2;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// k_feat_z: Z = W L for all features at once, W = [3 F x LD] (k_feat_qr), L = the prior block's lower-triangular factor; one
+// wavefront per 16 x 16 tile of Z on v_mfma_f64_16x16x4_f64, the sum over s starting at the tile's first column (L[s][c] = 0 for
+// s < c); the residual column D is copied (it is not whitened).  Rows of features that did not reach k_feat_qr hold stale values:
+// nobody reads their z.
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_feat_z(int rows, int D, int LD, const double *__restrict__ W, const double *__restrict__ Lw, double *__restrict__ Z) {
+  const int lane = threadIdx.x & 63;
+  const int tcols = (LD + 15) / 16, trows = (rows + 15) / 16;
+  const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (tile >= trows * tcols) return;
+  const int r0 = (tile / tcols) * 16, c0 = (tile % tcols) * 16;
+  d4 acc = {0.0, 0.0, 0.0, 0.0};
+  const int i = lane & 15, kk = lane >> 4;
+  const int ra = min(r0 + i, rows - 1), cb = min(c0 + i, D - 1);
+  for (int k0 = c0; k0 < D; k0 += 16) { // 4 k-slices per trip, their 8 operand loads issued together
+    double a[4], b[4];
 #pragma unroll
-        for (int u = 0; u < 8; u++) l[u] = Lc[(size_t)(s + u) * D];
-#pragma unroll
-        for (int u = 0; u < 8; u += 2) {
-          a0 = fma(wvv[s + u], l[u], a0), a1 = fma(wvv[LD + s + u], l[u], a1), a2 = fma(wvv[2 * LD + s + u], l[u], a2);
-          b0 = fma(wvv[s + u + 1], l[u + 1], b0), b1 = fma(wvv[LD + s + u + 1], l[u + 1], b1), b2 = fma(wvv[2 * LD + s + u + 1], l[u + 1], b2);
-        }
-      }
-      for (; s < D; s++) {
-        const double l0 = Lc[(size_t)s * D];
-        a0 = fma(wvv[s], l0, a0), a1 = fma(wvv[LD + s], l0, a1), a2 = fma(wvv[2 * LD + s], l0, a2);
-      }
-      y0 = a0 + b0, y1 = a1 + b1, y2 = a2 + b2;
+    for (int u = 0; u < 4; u++) {
+      const int k = k0 + 4 * u + kk;
+      const int kc = min(k, D - 1);
+      a[u] = k < D ? W[(size_t)(ra / 3) * 3 * LD + (size_t)(ra % 3) * LD + kc] : 0.0;
+      b[u] = (k < D && c0 + i < D) ? Lw[(size_t)kc * D + cb] : 0.0;
     }
-    zo[c] = T00 * y0, zo[LD + c] = T01 * y0 + T11 * y1, zo[2 * LD + c] = T02 * y0 + T12 * y1 + T22 * y2; // z = T^T y
+#pragma unroll
+    for (int u = 0; u < 4; u++) FEAT_MFMA(a[u], b[u], acc);
+  }
+  const int col = c0 + (lane & 15);
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const int row = r0 + (lane >> 4) + 4 * q;
+    if (row < rows && col < LD) {
+      const size_t o = (size_t)(row / 3) * 3 * LD + (size_t)(row % 3) * LD + col;
+      Z[o] = col == D ? W[o] : acc[q];
+    }
   }
 }
 

@@ -200,7 +200,7 @@ struct ovgpu_ctx {
   size_t feat_lds = 0;
   bool no_feat_kernel = false;  // options.no_fast_feature_kernel
   DevBuf<int32_t> feat_counter, fs_minfo, fs_meas_feat; // fs_*: the row store of the fast path (feat::FeatStore)
-  DevBuf<double> fs_rows, fs_V, fs_z;
+  DevBuf<double> fs_rows, fs_V, fs_z, fs_w;
   void *comm = nullptr;        // ncclComm_t of this rank (ovgpu_comm_init_rank / ovgpu_multi_create)
   int comm_rank = 0, comm_world = 1;
   DevBuf<double> comm_buf;     // gathered triangles of the Householder exchange
@@ -479,7 +479,7 @@ void ovgpu_destroy(ovgpu_ctx *c) {
   c->ctrl.release();
   c->gram_part.release(), c->gram_G.release(), c->gram_rho.release(), c->Yaug2.release(), c->gram_dropped.release(), c->Lw.release(), c->dbg_cycles.release();
   c->chol_uinv.release();
-  c->fs_minfo.release(), c->fs_meas_feat.release(), c->fs_rows.release(), c->fs_V.release(), c->fs_z.release();
+  c->fs_minfo.release(), c->fs_meas_feat.release(), c->fs_rows.release(), c->fs_V.release(), c->fs_z.release(), c->fs_w.release();
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
@@ -755,6 +755,7 @@ static int set_row_layout(ovgpu_ctx *c, bool slam_rows) {
     HIPCHK(c->fs_minfo.reserve((size_t)M * 8));
     HIPCHK(c->fs_V.reserve((size_t)M * 6));
     HIPCHK(c->fs_z.reserve((size_t)std::max(F, 1) * 3 * c->LD));
+    HIPCHK(c->fs_w.reserve((size_t)std::max(F, 1) * 3 * c->LD));
     HIPCHK(c->fs_meas_feat.reserve(M));
     std::vector<int32_t> mf(M, 0);
     for (int f = 0; f < F; f++)
@@ -924,7 +925,7 @@ static int enqueue_system(ovgpu_ctx *c, int f_one = -1, int init_rep = 0, bool w
     }
     // rows (per measurement) -> gate (needs P only) -> projected whitened rows (need L and z).  The prior block's factorisation and
     // the reflector / z kernel behind it run on the second stream NEXT TO the gate; only the output kernel waits for them.
-    feat::FeatStore st{c->fs_rows.p, c->fs_minfo.p, c->fs_V.p, c->fs_z.p, c->fs_meas_feat.p};
+    feat::FeatStore st{c->fs_rows.p, c->fs_minfo.p, c->fs_V.p, c->fs_z.p, c->fs_meas_feat.p, c->fs_w.p};
     const double *sr = st.rows, *sV = st.V, *sz = st.z;
     const int32_t *sm = st.minfo;
     hipLaunchKernelGGL(feat::k_feat_rows, dim3((c->M + 255) / 256), dim3(256), 0, c->stream, p, st, c->M);
@@ -935,6 +936,10 @@ static int enqueue_system(ovgpu_ctx *c, int f_one = -1, int init_rep = 0, bool w
       sq = c->stream2;
     }
     hipLaunchKernelGGL(feat::k_feat_qr, dim3((c->F + 3) / 4), dim3(256), 4 * feat::feat_qr_lds_per_wave(p.m_max, c->LD, c->K * c->C), sq, p, st);
+    {
+      const int zr = 3 * c->F, ztiles = ((zr + 15) / 16) * ((c->LD + 15) / 16);
+      hipLaunchKernelGGL(feat::k_feat_z, dim3((ztiles + 3) / 4), dim3(256), 0, sq, zr, c->D, c->LD, (const double *)c->fs_w.p, (const double *)c->Lw.p, c->fs_z.p);
+    }
     if (c->prior_on_side) HIPCHK(hipEventRecord(c->ev_join, sq));
     if (c->feat_variant == 1) hipLaunchKernelGGL((feat::k_feat<4, 11, 2>), dim3(c->feat_grid), dim3(256), c->feat_lds, c->stream, p, c->feat_nt_max, sr, sm, sV, sz);
     else hipLaunchKernelGGL((feat::k_feat<8, 17, 2>), dim3(c->feat_grid), dim3(512), c->feat_lds, c->stream, p, c->feat_nt_max, sr, sm, sV, sz);
