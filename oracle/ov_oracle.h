@@ -7,11 +7,17 @@
  * cpu_baseline leg may load it; the product (open_vins_amd/, libovgpu.so)
  * never links, imports or calls anything in oracle/.
  *
- * PARITY UNPINNED: the reference ships no golden vectors / known-answer tests
- * for this path and cannot be compiled here (Eigen, Boost, OpenCV absent), so
- * the oracle is pinned only by (i) line-by-line restatement (each function
- * cites the reference file:line), (ii) independent numpy/scipy invariants in
- * tests/test_oracle_*.py.  See DESIGN.md §3.
+ * PINNING: the reference ships no golden vectors / known-answer tests for this
+ * path and cannot be compiled here (Eigen, Boost, OpenCV absent; no
+ * oracle/_ref), so the pin is manufactured: tools/make_known_answer.py
+ * evaluates the reference's formulas independently of this file (mpmath, 50
+ * digits, the reference's float32 operations emulated) and
+ * tests/test_known_answer.py holds this oracle to those fixtures
+ * (tests/golden/known_answer_msckf_*.json.gz) at float64 round-off:
+ * pixels / residuals bit-exact, chi2 2e-14, dx 1e-13, P' 1e-15.  Beside it:
+ * (i) line-by-line restatement (each function cites the reference
+ * file:line), (ii) numpy/scipy invariants in tests/test_oracle_invariants.py.
+ * The reference's own code has still never executed here.  See DESIGN.md §3.
  *
  * It shares the POD views of include/ovgpu.h so that tests feed identical
  * inputs to both sides.

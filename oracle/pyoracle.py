@@ -1,7 +1,7 @@
 """ctypes loader of oracle/libov_oracle.so.
 
 TEST INFRASTRUCTURE ONLY: may be imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg,
-never by the product package.  PARITY UNPINNED (see ov_oracle.h).
+never by the product package.  Pinned by the known-answer fixtures of tests/test_known_answer.py (see ov_oracle.h).
 """
 from __future__ import annotations
 

@@ -1,8 +1,9 @@
 """CPU tests that pin the oracle (oracle/ov_oracle.cpp).
 
-The reference has no golden vectors for this path ("parity unpinned"), so the oracle is checked
-against independent numpy / scipy computations of the same quantities and against the algebraic invariants the
-reference's own derivations rely on (docs/update-null.dox, docs/update-compress.dox).
+The reference has no golden vectors for this path, so beside the known-answer fixtures of
+tests/test_known_answer.py the oracle is checked against independent numpy / scipy computations of the same
+quantities and against the algebraic invariants the reference's own derivations rely on (docs/update-null.dox,
+docs/update-compress.dox).
 """
 import ctypes as C
 
