@@ -560,10 +560,25 @@ int ovgpu_retriangulate_reset(ovgpu_ctx *ctx);
 /* Number of live tracks. */
 int ovgpu_tracks_count(ovgpu_ctx *ctx, int32_t *n_tracks);
 
+/* Order of the camera groups inside a track of the assembled batch.  It decides the anchor of a feature:
+ * FeatureInitializer.cpp:36-46 iterates Feature::timestamps (a std::unordered_map<size_t, ...>) and keeps the
+ * FIRST camera with strictly the most measurements, and for full stereo tracks the counts tie.  libstdc++
+ * iterates such a map in REVERSE order of first insertion of its keys.
+ *   OVGPU_GROUPS_REFERENCE   (default) exactly that: the store remembers, per track, the order in which cameras
+ *                            first observed it (the order of the entries of ovgpu_tracks_append calls) and walks it
+ *                            backwards.  The front ends insert camera 0 first (TrackKLT.cpp feed_stereo,
+ *                            TrackSIM.cpp:37-63), so this is normally descending camera id and a tie is anchored in
+ *                            the highest id; a track first seen by camera 1 alone and later by camera 0 iterates 0, 1.
+ *   OVGPU_GROUPS_DESCENDING / _ASCENDING   by camera id, whatever the history.
+ * The host-flattened path (shim/ovgpu_flatten.h) walks the map itself and needs no such rule.            */
+enum { OVGPU_GROUPS_REFERENCE = 0, OVGPU_GROUPS_DESCENDING = 1, OVGPU_GROUPS_ASCENDING = 2 };
+int ovgpu_tracks_group_order(ovgpu_ctx *ctx, int32_t order);
+
 /* Builds the resident feature batch from F stored tracks — what ovgpu_set_features would receive
  * after Feature::clean_old_measurements(clone_times) (Feature.cpp:26-53) and the shim's
  * flattening: observations whose time is (exactly) one of clone_times [C] (index = clone index
- * of the resident state), camera groups in ascending camera id, time order inside a group.
+ * of the resident state), camera groups in the order of ovgpu_tracks_group_order (default: the
+ * reference's iteration order of Feature::timestamps), time order inside a group.
  * An unknown id gives an empty track.  The state must be resident (C clones).                */
 int ovgpu_tracks_to_features(ovgpu_ctx *ctx, int32_t F, const int64_t *featid,
                              const double *clone_times);
@@ -707,6 +722,14 @@ int ovgpu_multi_msckf_update(ovgpu_multi *m, int32_t *feat_status, double *chi2,
 /* Which route the last ovgpu_msckf_update / ovgpu_slam_update took: OVGPU_COMPRESS_GRAM, or OVGPU_COMPRESS_TSQR when it was
  * selected or when the prior block failed the pivot test of the Gram route (ovgpu_options::prior_pivot_tol). */
 int ovgpu_last_update_route(ovgpu_ctx *ctx);
+
+/* Developer / test aid (no reference counterpart): reads (old_value, may be NULL) and, with value >= 0, sets a named internal.
+ *   "chol_follow_spin_limit"  wait bound of the single-launch Cholesky's follower workgroups (k_chol.h); 0 makes every follower
+ *                             give up at once, which the tests use to exercise the recovery: the kernels behind the factorisation
+ *                             are switched off on the device, the state stays untouched and the synchronous update calls repeat
+ *                             the update with the step-wise kernels
+ *   "chol_timeouts"           (read only) number of updates repeated that way                                              */
+int ovgpu_debug_option(ovgpu_ctx *ctx, const char *name, int64_t value, int64_t *old_value);
 
 /* Developer aid (no reference counterpart): per-phase cycle counters of workgroup 0 of the per-feature kernel.
  * enable != 0 allocates / clears 512 counters, out512 != NULL reads them back first. */

@@ -21,6 +21,7 @@ FEAT_USED, FEAT_TOO_FEW_MEAS, FEAT_TRI_FAILED, FEAT_GN_FAILED, FEAT_CHI2_REJECTE
 REP_GLOBAL_3D, REP_GLOBAL_FULL_INVERSE_DEPTH, REP_ANCHORED_3D = 0, 1, 2
 REP_ANCHORED_FULL_INVERSE_DEPTH, REP_ANCHORED_MSCKF_INVERSE_DEPTH, REP_ANCHORED_INVERSE_DEPTH_SINGLE = 3, 4, 5
 COMPRESS_GRAM, COMPRESS_TSQR, COMPRESS_CHOLQR = 0, 1, 2
+GROUPS_REFERENCE, GROUPS_DESCENDING, GROUPS_ASCENDING = 0, 1, 2
 
 c_double_p = C.POINTER(C.c_double)
 c_float_p = C.POINTER(C.c_float)
@@ -204,6 +205,7 @@ def declare(lib):
         "ovgpu_tracks_not_containing_newer": (C.c_int, [ctxp, C.c_double, C.c_int32, C.POINTER(C.c_int64), c_int32_p]),
         "ovgpu_tracks_count": (C.c_int, [ctxp, c_int32_p]),
         "ovgpu_tracks_to_features": (C.c_int, [ctxp, C.c_int32, C.POINTER(C.c_int64), c_double_p]),
+        "ovgpu_tracks_group_order": (C.c_int, [ctxp, C.c_int32]),
         "ovgpu_set_feature_options": (C.c_int, [ctxp, c_double_p, c_double_p]),
         "ovgpu_get_features": (C.c_int, [ctxp, c_int32_p, c_int32_p, c_int32_p, c_float_p, c_float_p, c_int32_p, c_int32_p]),
         "ovgpu_slam_change_anchor": (C.c_int, [ctxp, C.c_int32, C.c_int32, C.c_int32]),
@@ -244,6 +246,7 @@ def declare(lib):
         "ovgpu_multi_set_features": (C.c_int, [vp, C.POINTER(FeaturesView)]),
         "ovgpu_multi_msckf_update": (C.c_int, [vp, c_int32_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, C.POINTER(UpdateStats)]),
         "ovgpu_debug_cycles": (C.c_int, [ctxp, C.c_int, C.POINTER(C.c_longlong)]),
+        "ovgpu_debug_option": (C.c_int, [ctxp, C.c_char_p, C.c_int64, C.POINTER(C.c_int64)]),
         "ovgpu_kernel_times": (C.c_int, [ctxp, C.c_int, c_double_p, c_double_p, C.POINTER(C.c_int64)]),
         "ovgpu_system_time": (C.c_int, [ctxp, c_double_p, C.POINTER(C.c_int64)]),
     }

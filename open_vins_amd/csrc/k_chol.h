@@ -42,6 +42,7 @@ struct CholParams {
   int32_t *prog;          // [16] step k published (zeroed before the launch)
   double *uinv;           // [16][256] U_kk^-1 of every step, row-major
   int32_t *err;           // sticky: a follower ran into its wait bound
+  int spin_limit;         // the followers' wait bound per step (polls of ~100 cycles; 1 << 22 ~ 0.2 s)
   long long *dbg;         // optional cycle counters (developer aid)
 };
 
@@ -255,8 +256,17 @@ __global__ void __launch_bounds__(64 * CH_NW, 2) k_chol_follow(CholParams p) {
     int spins = 0;
     while (__hip_atomic_load(p.prog + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < CH_FW + 1) {
       __builtin_amdgcn_s_sleep(2);
-      if (++spins > (1 << 22)) {
-        if (lane == 0) p.err[0] = 1;
+      if (++spins > p.spin_limit) {
+        // The factor workgroup never got scheduled next to us (a shared GPU, a full chip).  The carried columns stay unwritten, so
+        // NOTHING behind this factorisation may run: err is raised for the host, and the update is switched off through the very
+        // words the following kernels are predicated on — the not-SPD flag of a first factorisation (k_tf_abh derives `go` from
+        // it), the `go` word itself for a second one.  The resident state is then untouched and the host repeats the update with
+        // the step-wise kernels (finish_update / update_with_fallbacks).
+        if (lane == 0) {
+          p.err[0] = 1;
+          p.flags[0] = 1;
+          if (p.pred) *const_cast<int32_t *>(p.pred) = 0;
+        }
         return;
       }
     }

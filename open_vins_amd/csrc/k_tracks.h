@@ -46,9 +46,17 @@ __device__ __forceinline__ int clone_index_of(double t, int C, const double *__r
 }
 
 // pass 0: n_valid[f] = observations of track f whose time is a clone time
-// pass 1: the batch — camera groups in ascending camera id, storage (= time) order inside a group
+// pass 1: the batch — camera groups in the order group_order[f][0 .. K-1] (-1 ends the list; the host's record of the order in
+// which the reference would iterate Feature::timestamps, see ovgpu_tracks_group_order), or, without it, in descending (desc != 0)
+// / ascending camera id; storage (= time) order inside a group.
+// The order of the groups is not cosmetic: FeatureInitializer.cpp:36-46 anchors a feature in the FIRST group that has strictly the
+// most measurements while iterating Feature::timestamps, a std::unordered_map<size_t, ...>.  libstdc++ links the node of a new
+// bucket at the FRONT of its element list, so the map iterates in REVERSE order of first insertion: a feature whose cameras were
+// inserted 0, 1, .. (TrackKLT.cpp feed_stereo: left then right; TrackSIM.cpp:37-63: camera ids in order) iterates K-1 .. 0, and
+// a full stereo track — equal counts, the common case — is anchored in the highest camera id.
 __global__ void k_tracks_gather(int F, int K, int C, const int32_t *__restrict__ sel_slot, const double *__restrict__ clone_times, TrackStore ts,
-                                int32_t *n_valid, const int32_t *__restrict__ meas_offsets, float *uv, float *uvn, uint16_t *meas_cc, int pass) {
+                                int32_t *n_valid, const int32_t *__restrict__ meas_offsets, float *uv, float *uvn, uint16_t *meas_cc, int pass, int desc,
+                                const int8_t *__restrict__ group_order) {
   const int f = blockIdx.x * blockDim.x + threadIdx.x;
   if (f >= F) return;
   const int s = sel_slot[f];
@@ -61,7 +69,9 @@ __global__ void k_tracks_gather(int F, int K, int C, const int32_t *__restrict__
     return;
   }
   int w = meas_offsets[f];
-  for (int k = 0; k < K; k++)
+  for (int kk = 0; kk < K; kk++) {
+    const int k = group_order ? group_order[(size_t)f * K + kk] : (desc ? K - 1 - kk : kk);
+    if (k < 0) break;
     for (int j = 0; j < cnt; j++) {
       if (ts.cam[base + j] != k) continue;
       const int ci = clone_index_of(ts.time[base + j], C, clone_times);
@@ -71,6 +81,7 @@ __global__ void k_tracks_gather(int F, int K, int C, const int32_t *__restrict__
       meas_cc[w] = (uint16_t)((k << 10) | ci);
       w++;
     }
+  }
 }
 
 } // namespace ovg

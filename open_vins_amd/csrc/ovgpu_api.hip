@@ -124,6 +124,9 @@ struct ovgpu_ctx {
   bool slam_rows = false; // row layout of the uploaded batch: 2m rows per feature (SLAM update) or 2m - 3 (MSCKF, delayed init)
   // device-resident FeatureDatabase (ovgpu_tracks_*)
   int trk_max = 0, trk_obs = 0;
+  int trk_group_order = OVGPU_GROUPS_REFERENCE; // camera groups of an assembled batch (k_tracks.h, ovgpu_tracks_group_order)
+  std::vector<std::vector<int8_t>> trk_h_cams;  // per slot: the cameras in order of FIRST insertion (what an unordered_map remembers)
+  DevBuf<int8_t> trk_order;
   DevBuf<int32_t> trk_count, trk_cam, trk_slot_in, trk_cam_in, trk_sel, trk_nvalid, trk_flag;
   DevBuf<double> trk_time, trk_clone_times;
   DevBuf<float> trk_uv, trk_uvn, trk_uv_in, trk_uvn_in;
@@ -222,6 +225,9 @@ struct ovgpu_ctx {
   bool async_pending = false;     // ovgpu_msckf_update_async since the last ovgpu_synchronize
   bool last_update_tform = false; // the last EKF stage enqueued was the Gram-form one (finish_update may fall back)
   bool force_tsqr = false;        // one-shot: the next pipeline takes the Householder route
+  int chol_spin_limit = 1 << 22;  // k_chol_follow's wait bound (ovgpu_debug_option "chol_follow_spin_limit" lowers it to provoke the fall-back)
+  int chol_timeouts = 0;          // how often update_with_fallbacks repeated an update with the step-wise kernels
+  bool chol_timed_out = false;    // finish_update: a follower of the single-launch Cholesky gave up waiting; nothing was modified
   bool prior_pending = false; // the sharded update's local stage has started the prior block's factorisation on stream2
   bool prior_overlap = true; // options.no_prior_overlap == 0: the prior block is factored on the second stream
   bool gram_valid = false; // c->Rws holds chol(gram_G): the EKF stage refines dx against gram_G
@@ -749,6 +755,10 @@ static int set_row_layout(ovgpu_ctx *c, bool slam_rows) {
       }
     }
   }
+  // the general kernel's panel routine (gate_chol_panel<8>, k_system.h) holds the 2m + 4 rows of the gate's trapezoid in the eight
+  // registers of a wavefront's lanes: 254 observations per track at most.  Longer tracks are refused, never mis-gated.
+  if (!c->feat_variant && 2 * m_max + 4 > 512)
+    return set_err(OVGPU_ERR_CAPACITY, "track of more than 254 observations: beyond the per-feature kernels (gate of 2m + 4 <= 512 rows)");
   if (c->feat_variant) { // row store of the fast path
     const int M = std::max(c->M, 1);
     HIPCHK(c->fs_rows.reserve((size_t)M * c->row_stride));
@@ -1207,6 +1217,7 @@ static int enqueue_chol_carry(ovgpu_ctx *c, const EkfParams &p, hipStream_t s, d
     chol::CholParams q;
     q.D = p.D, q.LA = p.LA, q.A = p.A, q.Y = p.Y, q.Lt = Lt, q.flags = p.flags, q.diag0 = p.diag0, q.pivot_tol = p.pivot_tol, q.pred = p.pred;
     q.prog = c->chol_prog.p + 16 * slot, q.uinv = c->chol_uinv.p + (size_t)slot * 16 * 256, q.err = p.flags + 2, q.dbg = c->dbg_cycles.p;
+    q.spin_limit = c->chol_spin_limit;
     HIPCHK(ctrl_zero(c, slot ? CTRL_PROG1 : CTRL_PROG0, q.prog, 16 * sizeof(int32_t), s));
     const int carried = (p.LA - p.D + 15) / 16;
     // the followers run next to the factor workgroup: same stream order is not enough (they would start after it), so they go to
@@ -1551,33 +1562,52 @@ static int finish_update(ovgpu_ctx *c, double *dx, double *P_out, ovgpu_update_s
   int status = OVGPU_OK;
   if (flags[0]) status = OVGPU_ERR_NOT_SPD;
   else if (flags[1]) status = OVGPU_ERR_NEGATIVE_DIAGONAL;
-  if (flags[2]) return set_err(OVGPU_ERR_HIP, "single-launch Cholesky: a follower workgroup timed out waiting for the factor workgroup (options.no_single_launch_cholesky = 1 selects the step-wise kernels)");
+  c->chol_timed_out = flags[2] != 0;
+  if (flags[2]) return set_err(OVGPU_ERR_HIP, "single-launch Cholesky: a follower workgroup timed out waiting for the factor workgroup; the state was not modified (options.no_single_launch_cholesky = 1 selects the step-wise kernels)");
   if (stats) stats->status = status;
   fill_times(c, stats);
   if (status != OVGPU_OK) return set_err(status, status == OVGPU_ERR_NOT_SPD ? "innovation covariance not SPD" : "negative covariance diagonal after the update");
   return check_tree_error(c);
 }
 
+// Runs `attempt` (enqueue -> read back -> finish_update) and repeats it when the failure is one that left the resident state untouched:
+//  * OVGPU_ERR_NOT_SPD on the Gram-form update: that form factors the PRIOR block, which a semi-definite prior (e.g. two perfectly
+//    correlated variables) fails; every kernel behind that factorisation was skipped.  Repeat through the Householder route, whose
+//    S = R P R^T + sigma^2 I is positive definite for any valid covariance;
+//  * a follower of the single-launch Cholesky timed out (k_chol.h: the factor workgroup was not co-scheduled; the kernels behind
+//    the factorisation were switched off on the device).  Repeat with the step-wise kernels, which have no cross-workgroup wait.
+extern "C++" {
+template <class Attempt> static int update_with_fallbacks(ovgpu_ctx *c, ovgpu_update_stats *stats, Attempt attempt) {
+  bool tried_householder = false, tried_steps = false;
+  const bool user_no_pipe = c->no_chol_pipe;
+  int rc;
+  for (;;) {
+    c->chol_timed_out = false;
+    rc = attempt();
+    if (rc == OVGPU_ERR_NOT_SPD && c->last_update_tform && !c->chol_timed_out && !tried_householder) {
+      tried_householder = true, c->force_tsqr = true;
+    } else if (c->chol_timed_out && !tried_steps) {
+      tried_steps = true, c->no_chol_pipe = true, c->chol_timeouts++;
+    } else {
+      break;
+    }
+    if (stats) std::memset(stats, 0, sizeof(*stats));
+  }
+  c->no_chol_pipe = user_no_pipe;
+  return rc;
+}
+} // extern "C++"
+
 int ovgpu_msckf_update(ovgpu_ctx *c, int32_t *feat_status, double *chi2, double *chi2_thresh, double *p_FinG, double *dx, double *P_out,
                        ovgpu_update_stats *stats) {
   if (!c) return set_err(OVGPU_ERR_INVALID, "null ctx");
   if (stats) std::memset(stats, 0, sizeof(*stats));
-  int rc = enqueue_pipeline(c, STAGE_LOCAL | STAGE_EKF);
-  if (rc != OVGPU_OK) return rc;
-  rc = read_feature_outputs(c, feat_status, chi2, chi2_thresh, p_FinG, stats);
-  if (rc != OVGPU_OK) return rc;
-  rc = finish_update(c, dx, P_out, stats);
-  if (rc == OVGPU_ERR_NOT_SPD && c->last_update_tform) {
-    // the Gram-form update factors the PRIOR block, which a semi-definite prior (e.g. two perfectly correlated variables) fails;
-    // nothing was modified (every kernel behind that factorisation was skipped): repeat through the Householder route, whose
-    // S = R P R^T + sigma^2 I is positive definite for any valid covariance
-    c->force_tsqr = true;
-    if (stats) std::memset(stats, 0, sizeof(*stats));
-    if ((rc = enqueue_pipeline(c, STAGE_LOCAL | STAGE_EKF)) != OVGPU_OK) return rc;
+  return update_with_fallbacks(c, stats, [&]() {
+    int rc = enqueue_pipeline(c, STAGE_LOCAL | STAGE_EKF);
+    if (rc != OVGPU_OK) return rc;
     if ((rc = read_feature_outputs(c, feat_status, chi2, chi2_thresh, p_FinG, stats)) != OVGPU_OK) return rc;
-    rc = finish_update(c, dx, P_out, stats);
-  }
-  return rc;
+    return finish_update(c, dx, P_out, stats);
+  });
 }
 
 int ovgpu_msckf_update_async(ovgpu_ctx *c) {
@@ -1735,27 +1765,16 @@ int ovgpu_slam_update(ovgpu_ctx *c, const int32_t *lm_index, int32_t *feat_statu
   int rc = slam_prepare(c, lm_index, stats);
   if (rc != OVGPU_OK) return rc;
   hipStream_t s = c->stream;
-  rc = enqueue_pipeline(c, STAGE_LOCAL | STAGE_EKF, true);
-  if (rc != OVGPU_OK) return rc;
-  hipLaunchKernelGGL(k_landmark_update, dim3((3 * c->L + 255) / 256), dim3(256), 0, s, c->L, (const int32_t *)nullptr, lm_dof(c->lm_rep), c->dx.p,
-                     c->lm_cov.p, c->lm_val.p, (const int32_t *)nullptr);
-  HIPCHK(hipGetLastError());
-  rc = read_feature_outputs(c, feat_status, chi2, chi2_thresh, nullptr, stats);
-  if (rc != OVGPU_OK) return rc;
-  if (lm_out) HIPCHK(hipMemcpyAsync(lm_out, c->lm_val.p, sizeof(double) * 3 * c->L, hipMemcpyDeviceToHost, s));
-  rc = finish_update(c, dx, P_out, stats);
-  if (rc == OVGPU_ERR_NOT_SPD && c->last_update_tform) { // semi-definite prior block: see ovgpu_msckf_update
-    c->force_tsqr = true;
-    if (stats) std::memset(stats, 0, sizeof(*stats));
-    if ((rc = enqueue_pipeline(c, STAGE_LOCAL | STAGE_EKF, true)) != OVGPU_OK) return rc;
+  return update_with_fallbacks(c, stats, [&]() {
+    int rc2 = enqueue_pipeline(c, STAGE_LOCAL | STAGE_EKF, true);
+    if (rc2 != OVGPU_OK) return rc2;
     hipLaunchKernelGGL(k_landmark_update, dim3((3 * c->L + 255) / 256), dim3(256), 0, s, c->L, (const int32_t *)nullptr, lm_dof(c->lm_rep), c->dx.p,
                        c->lm_cov.p, c->lm_val.p, (const int32_t *)nullptr);
     HIPCHK(hipGetLastError());
-    if ((rc = read_feature_outputs(c, feat_status, chi2, chi2_thresh, nullptr, stats)) != OVGPU_OK) return rc;
+    if ((rc2 = read_feature_outputs(c, feat_status, chi2, chi2_thresh, nullptr, stats)) != OVGPU_OK) return rc2;
     if (lm_out) HIPCHK(hipMemcpyAsync(lm_out, c->lm_val.p, sizeof(double) * 3 * c->L, hipMemcpyDeviceToHost, s));
-    rc = finish_update(c, dx, P_out, stats);
-  }
-  return rc;
+    return finish_update(c, dx, P_out, stats);
+  });
 }
 
 int ovgpu_slam_compress(ovgpu_ctx *c, const int32_t *lm_index, int32_t *feat_status, double *chi2, double *chi2_thresh, int32_t *D_out,
@@ -1920,7 +1939,8 @@ int ovgpu_slam_delayed_init(ovgpu_ctx *c, int32_t feat_rep, int32_t *feat_status
   int status = OVGPU_OK;
   if (flags[0]) status = OVGPU_ERR_NOT_SPD;
   else if (flags[1]) status = OVGPU_ERR_NEGATIVE_DIAGONAL;
-  if (flags[2]) return set_err(OVGPU_ERR_HIP, "single-launch Cholesky: a follower workgroup timed out waiting for the factor workgroup (options.no_single_launch_cholesky = 1 selects the step-wise kernels)");
+  c->chol_timed_out = flags[2] != 0;
+  if (flags[2]) return set_err(OVGPU_ERR_HIP, "single-launch Cholesky: a follower workgroup timed out waiting for the factor workgroup; the state was not modified (options.no_single_launch_cholesky = 1 selects the step-wise kernels)");
   if (stats) stats->status = status;
   if (status != OVGPU_OK) return set_err(status, status == OVGPU_ERR_NOT_SPD ? "innovation covariance not SPD" : "negative covariance diagonal after the update");
   return OVGPU_OK;
@@ -2262,6 +2282,7 @@ int ovgpu_tracks_create(ovgpu_ctx *c, int32_t max_tracks, int32_t max_obs) {
   c->trk_free.resize(max_tracks);
   for (int i = 0; i < max_tracks; i++) c->trk_free[i] = max_tracks - 1 - i; // slot 0 is handed out first
   c->trk_h_count.assign(max_tracks, 0), c->trk_h_last.assign(max_tracks, 0.0), c->trk_h_id.assign(max_tracks, -1);
+  c->trk_h_cams.assign(max_tracks, std::vector<int8_t>());
   return OVGPU_OK;
 }
 
@@ -2380,8 +2401,13 @@ int ovgpu_tracks_append(ovgpu_ctx *c, double timestamp, int32_t n, const int64_t
       c->trk_free.pop_back();
       c->trk_slot_of.emplace(featid[i], sl);
       c->trk_h_id[sl] = featid[i], c->trk_h_count[sl] = 0;
+      c->trk_h_cams[sl].clear();
     } else {
       sl = it->second;
+    }
+    { // Feature::timestamps[cam_id] (FeatureDatabase.cpp:72, :81): a new key the first time the camera sees the feature
+      std::vector<int8_t> &cams = c->trk_h_cams[sl];
+      if (std::find(cams.begin(), cams.end(), (int8_t)cam_id[i]) == cams.end()) cams.push_back((int8_t)cam_id[i]);
     }
     slot[i] = sl;
     c->trk_h_count[sl]++;
@@ -2435,6 +2461,14 @@ int ovgpu_tracks_not_containing_newer(ovgpu_ctx *c, double timestamp, int32_t ca
   return OVGPU_OK;
 }
 
+int ovgpu_tracks_group_order(ovgpu_ctx *c, int32_t order) {
+  if (!c) return set_err(OVGPU_ERR_INVALID, "null context");
+  if (order != OVGPU_GROUPS_REFERENCE && order != OVGPU_GROUPS_DESCENDING && order != OVGPU_GROUPS_ASCENDING)
+    return set_err(OVGPU_ERR_INVALID, "unknown camera-group order");
+  c->trk_group_order = order;
+  return OVGPU_OK;
+}
+
 int ovgpu_tracks_to_features(ovgpu_ctx *c, int32_t F, const int64_t *featid, const double *clone_times) {
   if (!c) return set_err(OVGPU_ERR_INVALID, "null ctx");
   if (!c->have_state || c->poses_only) return set_err(OVGPU_ERR_NO_STATE, "ovgpu_set_state must precede ovgpu_tracks_to_features");
@@ -2453,10 +2487,27 @@ int ovgpu_tracks_to_features(ovgpu_ctx *c, int32_t F, const int64_t *featid, con
   HIPCHK(c->trk_clone_times.reserve(C));
   HIPCHK(upload(c->trk_sel.p, sel.data(), sizeof(int32_t) * F, s));
   HIPCHK(upload(c->trk_clone_times.p, clone_times, sizeof(double) * C, s));
+  // the order in which the reference would walk each feature's camera groups: reverse order of first insertion (k_tracks.h)
+  const int8_t *order_dev = nullptr;
+  std::vector<int8_t> order_h;
+  if (c->trk_group_order == OVGPU_GROUPS_REFERENCE && F > 0) {
+    order_h.assign((size_t)F * K, (int8_t)-1);
+    for (int f = 0; f < F; f++) {
+      if (sel[f] < 0) continue;
+      const std::vector<int8_t> &cams = c->trk_h_cams[sel[f]];
+      int w = 0;
+      for (int e = (int)cams.size() - 1; e >= 0 && w < K; e--)
+        if (cams[e] < K) order_h[(size_t)f * K + w++] = cams[e];
+    }
+    HIPCHK(c->trk_order.reserve(order_h.size()));
+    HIPCHK(upload(c->trk_order.p, order_h.data(), order_h.size(), s));
+    order_dev = c->trk_order.p;
+  }
+  const int desc = c->trk_group_order != OVGPU_GROUPS_ASCENDING;
   std::vector<int32_t> offs(F + 1, 0);
   if (F > 0) {
     hipLaunchKernelGGL(k_tracks_gather, dim3((F + 127) / 128), dim3(128), 0, s, F, K, C, c->trk_sel.p, c->trk_clone_times.p, track_store(c), c->trk_nvalid.p,
-                       (const int32_t *)nullptr, (float *)nullptr, (float *)nullptr, (uint16_t *)nullptr, 0);
+                       (const int32_t *)nullptr, (float *)nullptr, (float *)nullptr, (uint16_t *)nullptr, 0, desc, order_dev);
     HIPCHK(hipGetLastError());
     std::vector<int32_t> nv(F);
     HIPCHK(hipMemcpyAsync(nv.data(), c->trk_nvalid.p, sizeof(int32_t) * F, hipMemcpyDeviceToHost, s));
@@ -2470,7 +2521,7 @@ int ovgpu_tracks_to_features(ovgpu_ctx *c, int32_t F, const int64_t *featid, con
   if (rc != OVGPU_OK) return rc;
   if (F > 0) {
     hipLaunchKernelGGL(k_tracks_gather, dim3((F + 127) / 128), dim3(128), 0, s, F, K, C, c->trk_sel.p, c->trk_clone_times.p, track_store(c), c->trk_nvalid.p,
-                       (const int32_t *)c->meas_offsets.p, c->uv.p, c->uvn.p, c->meas_cc.p, 1);
+                       (const int32_t *)c->meas_offsets.p, c->uv.p, c->uvn.p, c->meas_cc.p, 1, desc, order_dev);
     HIPCHK(hipGetLastError());
   }
   return end_feature_batch(c);
@@ -2768,10 +2819,25 @@ int ovgpu_synchronize(ovgpu_ctx *c) {
     c->async_pending = false;
     int32_t flags[4] = {0, 0, 0, 0};
     HIPCHK(hipMemcpy(flags, c->flags.p, sizeof(flags), hipMemcpyDeviceToHost));
+    if (flags[2]) return set_err(OVGPU_ERR_HIP, "single-launch Cholesky: a follower workgroup timed out waiting for the factor workgroup; the state was not modified (the synchronous calls repeat the update with the step-wise kernels)");
     if (flags[0]) return set_err(OVGPU_ERR_NOT_SPD, c->last_update_tform ? "prior block of the involved variables not positive definite (state untouched; ovgpu_msckf_update falls back to the Householder route)" : "innovation covariance not SPD");
     if (flags[1]) return set_err(OVGPU_ERR_NEGATIVE_DIAGONAL, "negative covariance diagonal after the update");
   }
   return check_tree_error(c);
+}
+
+int ovgpu_debug_option(ovgpu_ctx *c, const char *name, int64_t value, int64_t *old_value) {
+  if (!c || !name) return set_err(OVGPU_ERR_INVALID, "null argument");
+  const std::string n(name);
+  if (n == "chol_follow_spin_limit") {
+    if (old_value) *old_value = c->chol_spin_limit;
+    if (value >= 0) c->chol_spin_limit = (int)std::min<int64_t>(value, 1 << 30);
+  } else if (n == "chol_timeouts") { // read-only counter: updates repeated with the step-wise Cholesky after a follower timed out
+    if (old_value) *old_value = c->chol_timeouts;
+  } else {
+    return set_err(OVGPU_ERR_INVALID, "unknown debug option");
+  }
+  return OVGPU_OK;
 }
 
 // Developer aid: enable != 0 allocates and clears 512 cycle counters that workgroup 0 of the per-feature kernel accumulates
@@ -2893,7 +2959,7 @@ int nccl_err(int rc, const char *what) {
 
 // the local stage of a sharded update up to (not including) the exchange; gram: which protocol this state uses
 static int sharded_local(ovgpu_ctx *c, bool &gram) {
-  gram = c->compress_gram == 1 && (c->LD + 15) / 16 <= gram::GR_NT_BLK;
+  gram = c->compress_gram == 1 && (c->LD + 15) / 16 <= gram::GR_NT_BLK && !c->force_tsqr;
   const int rc = enqueue_pipeline(c, STAGE_LOCAL, false, true, gram);
   if (rc == OVGPU_OK && gram && c->F == 0) { // an empty shard: nothing was whitened here, but the sum it joins is the other ranks' whitened Gram matrix
     const size_t n = (size_t)256 * ((c->LD + 15) / 16) * ((c->LD + 15) / 16);
@@ -2918,6 +2984,10 @@ static int sharded_exchange(ovgpu_ctx *c, bool gram) {
   }
   const size_t tri = (size_t)c->D * c->LD;
   HIPCHK(c->comm_buf.reserve(tri * G));
+  if (c->F == 0) { // an empty shard's triangle is all zeros (the leaf kernels never ran): say so explicitly before it is gathered
+    HIPCHK(c->Rws.reserve(tri));
+    HIPCHK(hipMemsetAsync(c->Rws.p, 0, sizeof(double) * tri, c->stream));
+  }
   if (G > 1) {
     const int rc = r.AllGather(c->Rws.p, c->comm_buf.p, tri, NCCL_DOUBLE, c->comm, c->stream);
     if (rc != 0) return nccl_err(rc, "ncclAllGather");
@@ -2986,11 +3056,15 @@ int ovgpu_msckf_update_sharded(ovgpu_ctx *c, int32_t *feat_status, double *chi2,
                                ovgpu_update_stats *stats) {
   if (!c) return set_err(OVGPU_ERR_INVALID, "null ctx");
   if (stats) std::memset(stats, 0, sizeof(*stats));
-  int rc = ovgpu_msckf_update_sharded_async(c);
-  if (rc != OVGPU_OK) return rc;
-  c->async_pending = false;
-  if ((rc = read_feature_outputs(c, feat_status, chi2, chi2_thresh, p_FinG, stats)) != OVGPU_OK) return rc;
-  return finish_update(c, dx, P_out, stats);
+  // the fall-backs of the one-GPU update hold here too: the prior is replicated, so every rank sees the same flags and every rank
+  // repeats (the Householder repeat exchanges triangles instead of Gram matrices: the collective stays matched across ranks)
+  return update_with_fallbacks(c, stats, [&]() {
+    int rc = ovgpu_msckf_update_sharded_async(c);
+    if (rc != OVGPU_OK) return rc;
+    c->async_pending = false;
+    if ((rc = read_feature_outputs(c, feat_status, chi2, chi2_thresh, p_FinG, stats)) != OVGPU_OK) return rc;
+    return finish_update(c, dx, P_out, stats);
+  });
 }
 
 } // extern "C"

@@ -34,8 +34,15 @@ void update_pass(UpdaterOptions &opt_slam, UpdaterOptions &opt_aruco, std::share
       it = feature_vec.erase(it);
       continue;
     }
-    if (ovgpu_shim::flatten_track(**it, snap, clones, ff) < 1) { // :289-291
+    // :283-295.  The single-depth representation needs two measurements (its bearing is projected out); a landmark with exactly one
+    // is dropped from THIS update without to_delete, so that FeatureDatabase::cleanup keeps the measurement for the next frame.
+    const int ct_meas = ovgpu_shim::flatten_track(**it, snap, clones, ff);
+    const int required_meas = (landmark->_feat_representation == LandmarkRepresentation::Representation::ANCHORED_INVERSE_DEPTH_SINGLE) ? 2 : 1;
+    if (ct_meas < 1) {
       (*it)->to_delete = true;
+      it = feature_vec.erase(it);
+      continue;
+    } else if (ct_meas < required_meas) {
       it = feature_vec.erase(it);
       continue;
     }

@@ -291,6 +291,11 @@ class UpdaterMSCKF:
         capi.check(self.lib.ovgpu_tracks_count(self._ctx, C.byref(n)), "ovgpu_tracks_count")
         return n.value
 
+    def tracks_group_order(self, order=capi.GROUPS_REFERENCE):
+        """Camera-group order of the assembled batch (include/ovgpu.h): GROUPS_REFERENCE (default) is the reference's iteration
+        order of Feature::timestamps — reverse order of first insertion — which decides the anchor of a track with tied counts."""
+        capi.check(self.lib.ovgpu_tracks_group_order(self._ctx, int(order)), "ovgpu_tracks_group_order")
+
     def tracks_to_features(self, featid, clone_times):
         ids = np.ascontiguousarray(featid, dtype=np.int64)
         ct = np.ascontiguousarray(clone_times, dtype=np.float64)
@@ -501,6 +506,12 @@ class UpdaterMSCKF:
 
     def synchronize(self):
         capi.check(self.lib.ovgpu_synchronize(self._ctx), "ovgpu_synchronize")
+
+    def debug_option(self, name, value=-1):
+        """ovgpu_debug_option: returns the old value; value >= 0 sets it."""
+        old = C.c_int64(0)
+        capi.check(self.lib.ovgpu_debug_option(self._ctx, name.encode(), int(value), C.byref(old)), "ovgpu_debug_option")
+        return old.value
 
     def kernel_times(self, reset=True):
         a, b, n = C.c_double(0), C.c_double(0), C.c_int64(0)

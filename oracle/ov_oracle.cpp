@@ -1361,12 +1361,13 @@ int oracle_msckf_update_given(const ovgpu_options *opts, const ovgpu_state_view 
   }
 
   // 3. triangulate (:117-142)
-  std::vector<int> status(F, OVGPU_FEAT_USED), anchor(F, -1);
+  std::vector<int> status(F, OVGPU_FEAT_USED), anchor(F, -1), forced(F, 0);
   std::vector<V3> pA(F, V3{{NAN, NAN, NAN}}), pG(F, V3{{NAN, NAN, NAN}});
   for (int f = 0; f < F; f++) {
     FeatMeas fm{fv->meas_offsets[f], fv->meas_offsets[f + 1], fv->uvn, fv->uv, fv->clone_idx, fv->cam_idx};
     if (given_p_FinG) { // triangulation supplied by the caller (landmarks already in the state / stage-wise parity tests)
       status[f] = given_status ? given_status[f] : OVGPU_FEAT_USED;
+      if (status[f] < 0) forced[f] = status[f], status[f] = OVGPU_FEAT_USED; // ORACLE_FORCE_ACCEPT / _REJECT: the gate's verdict is the caller's
       anchor[f] = given_anchor ? given_anchor[f] : (fm.m1 - fm.m0 >= 1 ? pick_anchor(fm) : -1);
       for (int i = 0; i < 3; i++) {
         pG[f][i] = given_p_FinG[3 * f + i];
@@ -1485,7 +1486,8 @@ int oracle_msckf_update_given(const ovgpu_options *opts, const ovgpu_state_view 
     double chi2_check = (r < 500) ? chi2_table[r] : chi2_quantile(r, 0.95); // :216-222
     chi2v[f] = chi2;
     thrv[f] = o.chi2_multipler * chi2_check;
-    if (chi2 > o.chi2_multipler * chi2_check) { // :225
+    const bool reject = forced[f] == ORACLE_FORCE_ACCEPT ? false : (forced[f] == ORACLE_FORCE_REJECT ? true : chi2 > o.chi2_multipler * chi2_check); // :225
+    if (reject) {
       status[f] = OVGPU_FEAT_CHI2_REJECTED;
       continue;
     }

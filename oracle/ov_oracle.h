@@ -100,6 +100,12 @@ int oracle_msckf_update(const ovgpu_options *opts, const ovgpu_state_view *st,
                         double *H_comp, double *r_comp, int32_t *rows_comp,
                         ovgpu_update_stats *stats, double *stage_seconds);
 
+/* given_status values that take the gate's verdict from the caller (test infrastructure: a feature whose chi2 sits within
+ * round-off of its threshold may be gated differently by two float64 implementations; the comparison of dx / P' is then repeated
+ * with the decision of the implementation under test imposed on the oracle).  chi2 is still computed and returned. */
+#define ORACLE_FORCE_ACCEPT (-1)
+#define ORACLE_FORCE_REJECT (-2)
+
 /* Same, with the triangulation supplied by the caller (given_p_FinG != NULL): the path
  * UpdaterSLAM::update takes for landmarks that already live in the state, and what the
  * stage-wise parity tests use to compare everything after loop A on identical positions.

@@ -666,3 +666,25 @@ def test_retriangulation_multi_camera_bookkeeping():
     pn1 = [o for o in sc.obs[1][1] if o[0] == fid][0][2]
     np.testing.assert_allclose(at.A[fid], A_old + Ai(1, 1, pn1), atol=1e-15)  # known track: old + camera 1's
     assert at.count[fid] == 2
+
+
+# --------------------------------------------------------------------------- the forced gate verdicts the parity tests fall back on
+def test_forced_gate_verdicts(oracle):
+    """ORACLE_FORCE_ACCEPT / _REJECT (ov_oracle.h): the verdict of a borderline feature can be imposed; chi2 is still reported."""
+    prob, v = _views(2, F=40, outlier_frac=0.3)
+    opts = capi.default_options(chi2_multipler=1.0)
+    tri = oracle.triangulate(opts, v)
+    ref = oracle.msckf_update(opts, v, given=tri)
+    used = np.flatnonzero(ref["feat_status"] == capi.FEAT_USED)
+    rej = np.flatnonzero(ref["feat_status"] == capi.FEAT_CHI2_REJECTED)
+    assert len(used) > 2 and len(rej) > 0
+    st = np.array(tri["status"], dtype=np.int32)
+    st[used[0]], st[rej[0]] = -2, -1
+    out = oracle.msckf_update(opts, v, given=dict(tri, status=st))
+    assert out["feat_status"][used[0]] == capi.FEAT_CHI2_REJECTED and out["feat_status"][rej[0]] == capi.FEAT_USED
+    assert out["stats"]["n_used"] == ref["stats"]["n_used"]
+    np.testing.assert_array_equal(out["chi2"], ref["chi2"])
+    assert not np.allclose(out["dx"], ref["dx"])
+    # untouched verdicts reproduce the plain run bit for bit
+    out2 = oracle.msckf_update(opts, v, given=dict(tri, status=np.array(tri["status"], dtype=np.int32)))
+    np.testing.assert_array_equal(out2["dx"], ref["dx"])

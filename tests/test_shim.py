@@ -123,3 +123,16 @@ def test_shim_drives_an_update_from_cpp():
     subprocess.check_call(["make", "-s", "-C", SHIM, "selftest"])
     out = subprocess.check_output([os.path.join(SHIM, "selftest"), "--gpu"], text=True)
     assert "shim gpu selftest ok" in out, out
+
+
+def test_slam_update_required_meas_rule():
+    """UpdaterSLAM.cpp:283-295: a landmark without measurements is flagged and erased; an ANCHORED_INVERSE_DEPTH_SINGLE landmark
+    with exactly ONE measurement is erased from this update WITHOUT to_delete (FeatureDatabase::cleanup must keep the measurement,
+    the next frame brings the second one).  The shim decides that before the library sees the track."""
+    import re
+    s = _src("UpdaterSLAM_update.cpp")
+    assert "required_meas = (landmark->_feat_representation == LandmarkRepresentation::Representation::ANCHORED_INVERSE_DEPTH_SINGLE) ? 2 : 1" in s
+    m = re.search(r"if \(ct_meas < 1\) \{(.*?)\} else if \(ct_meas < required_meas\) \{(.*?)\}", s, re.S)
+    assert m and "to_delete = true" in m.group(1) and "erase(it)" in m.group(1)
+    assert "to_delete" not in m.group(2) and "erase(it)" in m.group(2)
+    assert s.index("ct_meas < required_meas") < s.index("append_track(")
