@@ -49,6 +49,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the PCIe-inclusive and the secondary (weak / single-GPU reference) measurements")
     ap.add_argument("--route", choices=["gram", "tsqr"], default="gram")
+    ap.add_argument("--legacy-feature-kernel", action="store_true", help="round 2's three-sweep per-feature kernels (k_feat.h) instead of the fused one (k_featy.h)")
     ap.add_argument("--gram-fp32", action="store_true", help="BASELINE configs[4]'s fp32 compression: Gram matrix accumulated on v_mfma_f32_16x16x4_f32")
     return ap.parse_args(argv)
 
@@ -128,6 +129,8 @@ def main(argv=None):
         """Times `steps` updates of prob_full sharded as feats_of_rank(rank); returns (seconds max over ranks, updater, shard)."""
         shard = prob_full if world == 1 else prob_full.subset(feats_of_rank)
         up = UpdaterMSCKF(opts, device=local_rank)
+        if args.legacy_feature_kernel:
+            up.debug_option("legacy_feature_kernel", 1)
         up.set_problem(shard)  # H2D once; everything below runs on resident data
         native = True
         if world > 1:

@@ -728,7 +728,9 @@ int ovgpu_last_update_route(ovgpu_ctx *ctx);
  *                             give up at once, which the tests use to exercise the recovery: the kernels behind the factorisation
  *                             are switched off on the device, the state stays untouched and the synchronous update calls repeat
  *                             the update with the step-wise kernels
- *   "chol_timeouts"           (read only) number of updates repeated that way                                              */
+ *   "chol_timeouts"           (read only) number of updates repeated that way
+ *   "legacy_feature_kernel"   1 selects round 2's three-sweep form of the MSCKF fast path (k_feat.h) instead of the fused
+ *                             kernel of k_featy.h (A / B measurements, parity of both forms)                                 */
 int ovgpu_debug_option(ovgpu_ctx *ctx, const char *name, int64_t value, int64_t *old_value);
 
 /* Developer aid (no reference counterpart): per-phase cycle counters of workgroup 0 of the per-feature kernel.

@@ -1,0 +1,480 @@
+// k_featy.h — the MSCKF fast path, second form (round 3): ONE kernel per feature produces the prior-whitened rows, projects them,
+// writes them to the stack and gates the feature, with the gate matrix built ON THE MATRIX CORES from those same rows.
+//
+//   UpdaterHelper::get_feature_jacobian_full            UpdaterHelper.cpp:192-424   (k_feat_rows: the sparse row store)
+//   UpdaterHelper::nullspace_project_inplace            UpdaterHelper.cpp:426-454   (k_feat_qr: reflectors V, T; here: Q^T [H L | r])
+//   chi2 gate                                           UpdaterMSCKF.cpp:209-234, StateHelper.cpp:226-254
+//   stacking into Hx_big / res_big                      UpdaterMSCKF.cpp:237-255
+//
+// What changed against k_feat.h (whose kernels stay: the legacy form, ovgpu_debug_option "legacy_feature_kernel").  There the gate
+// matrix was S0 = (H P) H^T + s^2 I: a thread-per-column sweep T = H P over the sparse rows (650 KB of P through the vector cache
+// per feature, two multiply-adds per loaded double), S0's tiles as per-lane gathers from the T chunk in LDS, and — in a second
+// kernel, k_feat_out — the sweep Y = H L AGAIN for the rows that go to the stack.  Both sweeps and the gathers were latency
+// bound (54 - 72 % of wave-cycles in s_waitcnt, round-2 PMC passes).  With P_DD = L L^T (the prior block's factor, which the
+// update needs anyway):
+//
+//        S0 = H P H^T + s^2 I = Y Y^T + s^2 I,        Y = H L     (n x D, dense left of each row's last block)
+//
+// so ONE sweep Y = H L per 64-column block feeds (i) the stack — rows 3.. of Q^T [Y | r] = [Y | r] - V z, z = T^T V^T [Y | r]
+// accumulated in the same sweep — and (ii) the gate: S0's 16 x 16 tiles are a SYRK of the block in LDS on v_mfma_f64_16x16x4_f64,
+// accumulated in the registers that the blocked Cholesky then factors in place.  The SYRK executes ~3 x the multiply-adds of the
+// sparse form (1.2 k matrix instructions per 60-observation track after skipping what L's triangle leaves zero) but runs at the
+// matrix rate instead of at the latency of gathers; the T sweep, the S0 gathers, k_feat_out and k_feat_z disappear.
+//
+// Per feature (one workgroup, NW wavefronts):
+//   prologue   right-hand sides [r | H_f] -> LDS, last non-zero column of every tile row, the residual column of the stack
+//   per block of 64 columns (lane = column):
+//     sweep    wavefront w takes measurements w, w + NW, ..: Y[2i .. 2i+1][c] from the 6 (+ 6 + 8) rows of L its blocks select
+//              (scalar-cache operands for the Jacobian values; blocks right of the column block skipped: L is lower triangular),
+//              -> LDS block, and V^T Y accumulated per column                                             | barrier
+//     out      z = T^T V^T Y (per column), rows 3.. of Y - V z -> the stack in HBM (coalesced, 512 B per wavefront and row)
+//     SYRK     every wavefront: its tiles (i, j) += Y_i Y_j^T for the slabs of 8 columns both tile rows reach    | barrier
+//   S0 += s^2 I (identity on the padding), right-hand-side tiles, blocked Cholesky + chi2 exactly as k_feat.h
+//   a rejected feature zeroes the rows it wrote.
+//
+// The row store is kept in CLONE-MAJOR order inside a feature (k_feat_rows_sorted): rows of early clones are zero right of their
+// block, so a column block only concerns a suffix of the rows and whole tile rows drop out of its SYRK.
+#pragma once
+#include "k_feat.h"
+
+namespace ovg {
+namespace feat {
+
+constexpr int FY_CB = 64; // columns per block = lanes of a wavefront
+constexpr int FY_LS = 66; // row stride of the LDS block in doubles: 16-byte aligned rows, conflict-free 16-byte operand reads
+                          // (rows r and r + 1 of a tile are 4 banks apart: 16 lanes x 4 banks = all 64)
+
+struct FeatYLds {
+  size_t yb, rhs, wpart, misc, total;
+};
+// nt_max = tile rows of the longest track; nw = wavefronts per workgroup
+__host__ __device__ inline FeatYLds featy_lds_layout(int nt_max, int nw) {
+  FeatYLds L;
+  size_t o = 0;
+  auto take = [&](size_t bytes) {
+    const size_t at = o;
+    o += (bytes + 15) & ~(size_t)15;
+    return at;
+  };
+  L.yb = take((size_t)16 * nt_max * FY_LS * sizeof(double)); // the block; afterwards the Cholesky's row panel ((nt_max + 1) tiles fit)
+  L.rhs = take((size_t)16 * nt_max * 4 * sizeof(double));
+  const size_t wp = (size_t)nw * 3 * 64 * sizeof(double), stage = 2 * 256 * sizeof(double);
+  L.wpart = take(wp > stage ? wp : stage); // V^T Y partial sums per wavefront; afterwards the Cholesky's diagonal-tile stage
+  L.misc = take(32 * sizeof(double) + (size_t)(nt_max + 16) * sizeof(int)); // V^T r partials per wavefront, then rowlim / sched
+  L.total = o;
+  return L;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// k_feat_rows_sorted: k_feat_rows with the records of a feature stored in clone-major order (clone column, then camera)
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_feat_rows_sorted(SysParams p, FeatStore st, int M) {
+  const int gm = blockIdx.x * 256 + threadIdx.x;
+  if (gm >= M) return;
+  const int f = st.meas_feat[gm];
+  if (p.status[f] != OVGPU_FEAT_USED) return;
+  const int m0 = p.meas_offsets[f], m1 = p.meas_offsets[f + 1];
+  // rank of this measurement inside its feature: (clone column, camera, index)
+  auto key = [&](int i) {
+    const int code = p.meas_cc[i];
+    return (p.clone_col[code & 1023] << 8) | (code >> 10);
+  };
+  const int mykey = key(gm);
+  int rank = 0;
+  for (int i = m0; i < m1; i++) {
+    const int k = key(i);
+    rank += (k < mykey) || (k == mykey && i < gm);
+  }
+  const int pos = m0 + rank;
+  const V3 p_FinG = load_v3(p.p_FinG + 3 * f); // fej == value for MSCKF features (UpdaterMSCKF.cpp:186-194)
+  double hq[21];
+  double *dl = hq + 12;
+  if (p.opt.feat_rep == OVGPU_REP_GLOBAL_FULL_INVERSE_DEPTH) inv_depth_jac(p_FinG, dl); // UpdaterHelper.cpp:46
+  else dl[0] = 1, dl[1] = 0, dl[2] = 0, dl[3] = 0, dl[4] = 1, dl[5] = 0, dl[6] = 0, dl[7] = 0, dl[8] = 1;
+  sys_measurement_rows(p, gm, p_FinG, p_FinG, false, hq, st.minfo + (size_t)8 * pos, st.rows + (size_t)pos * p.row_stride);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// k_feat_vt: one wavefront per feature -> Householder reflectors of H_f: V [2m][3] and the factor T of Q = I - V T V^T (6 doubles)
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_feat_vt(SysParams p, FeatStore st, double *__restrict__ tq) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int f = blockIdx.x * 4 + wv;
+  if (f >= p.F) return;
+  if (p.status[f] != OVGPU_FEAT_USED) return;
+  const int RS = p.row_stride;
+  double *hf = reinterpret_cast<double *>(smem) + (size_t)wv * (12 * p.m_max + 64);
+  double *V = hf + (size_t)6 * p.m_max;
+  double *hq = V + (size_t)6 * p.m_max;
+  const int m0 = p.meas_offsets[f], m = p.meas_offsets[f + 1] - m0, n = 2 * m;
+  const double *rows = st.rows + (size_t)m0 * RS;
+  auto wsync = [] {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+  for (int r = lane; r < n; r += 64) {
+    const double *rd = rows + (size_t)(r >> 1) * RS + RO_HF + 3 * (r & 1);
+    hf[3 * r] = rd[0], hf[3 * r + 1] = rd[1], hf[3 * r + 2] = rd[2];
+  }
+  wsync();
+  sys_hf_householder(hf - RO_HF, 6, V, hq, n, 3, lane);
+  wsync();
+  for (int r = lane; r < n; r += 64) {
+    double *vo = st.V + ((size_t)2 * m0 + r) * 3;
+    vo[0] = V[3 * r], vo[1] = V[3 * r + 1], vo[2] = V[3 * r + 2];
+  }
+  if (lane < 6) tq[(size_t)8 * f + lane] = hq[3 + lane]; // T00 T01 T02 T11 T12 T22
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Blocked Cholesky S0 = U^T U of the gate matrix held as tiles in registers (right-hand sides carried) + the chi2 statistic.
+// Same scheme as k_feat.h (e), (f).  acc / tij: this wavefront's tiles; panel: (NT + 1) tiles of LDS; st0 / st1: 2 x 256 doubles.
+// Returns chi2 in lane 0 of wavefront 0 (other lanes: undefined); ends with the workgroup synchronised.
+// ---------------------------------------------------------------------------------------------------
+template <int NW, int TPW>
+__device__ __forceinline__ double gate_cholesky_chi2(d4 (&acc)[TPW], const int (&tij)[TPW], int NT, int n, double *panel, double *st0, double *st1, double *rhs,
+                                                     int lane, int wv) {
+  const int g = lane >> 4, cl = lane & 15;
+#define TI(s) (tij[s] & 255)
+#define TJ(s) (tij[s] >> 8)
+  for (int k = 0; k < NT; k++) {
+    { // (1) the owner of the diagonal tile factors it and publishes U_kk^-1
+      const int tkk = k * (k + 1) / 2 + k;
+      if (tkk % NW == wv) {
+        const int slot_t = tkk / NW;
+        d4 av = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s = 0; s < TPW; s++)
+          if (s == slot_t) av = acc[s];
+        d4 ev;
+        (void)diag_tile_factor_blk(av, ev, st0, lane, nullptr, 0.0, 16);
+#pragma unroll
+        for (int q = 0; q < 4; q++) st1[cl * 16 + g + 4 * q] = ev[q]; // U^-T in accumulator layout -> U^-1 row-major
+      }
+    }
+    __syncthreads();
+    { // (2) row panel: W_kj = U_kk^-T S_kj, published for the trailing update
+      double ua[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) ua[u] = st1[(4 * u + g) * 16 + cl];
+#pragma unroll
+      for (int s = 0; s < TPW; s++) {
+        if (tij[s] >= 0 && TI(s) == k && TJ(s) > k) {
+          d4 w = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int u = 0; u < 4; u++) FEAT_MFMA(ua[u], acc[s][u], w);
+          acc[s] = w;
+          double *pt = panel + (size_t)TJ(s) * 256;
+#pragma unroll
+          for (int q = 0; q < 4; q++) pt[(g + 4 * q) * 16 + cl] = w[q];
+        }
+      }
+    }
+    __syncthreads();
+    // (3) trailing update S_ij -= W_ki^T W_kj, k < i <= j (j = NT: the right-hand sides)
+#pragma unroll
+    for (int s = 0; s < TPW; s++) {
+      if (tij[s] >= 0 && TI(s) > k) {
+        const double *pi = panel + (size_t)TI(s) * 256, *pj = panel + (size_t)TJ(s) * 256;
+        double a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) a[u] = -pi[(4 * u + g) * 16 + cl], b[u] = pj[(4 * u + g) * 16 + cl];
+#pragma unroll
+        for (int u = 0; u < 4; u++) FEAT_MFMA(a[u], b[u], acc[s]);
+      }
+    }
+    // no barrier here: the next step's factorisation touches st0 / st1 only, and its panel writes come after its first barrier
+  }
+  // chi2 = |y_r|^2 - g^T G^-1 g,  y_r = U^-T r, Y_f = U^-T H_f
+#pragma unroll
+  for (int s = 0; s < TPW; s++) {
+    if (tij[s] >= 0 && TJ(s) == NT && cl < 4) {
+#pragma unroll
+      for (int q = 0; q < 4; q++) rhs[(size_t)(16 * TI(s) + g + 4 * q) * 4 + cl] = acc[s][q];
+    }
+  }
+  __syncthreads();
+  double chi2 = 0.0;
+  if (wv == 0) {
+    double a = 0, G00 = 0, G01 = 0, G02 = 0, G11 = 0, G12 = 0, G22 = 0, g0 = 0, g1 = 0, g2 = 0;
+    for (int j = lane; j < n; j += 64) {
+      const double yr = rhs[4 * j], y0 = rhs[4 * j + 1], y1 = rhs[4 * j + 2], y2 = rhs[4 * j + 3];
+      a = fma(yr, yr, a);
+      G00 = fma(y0, y0, G00), G01 = fma(y0, y1, G01), G02 = fma(y0, y2, G02);
+      G11 = fma(y1, y1, G11), G12 = fma(y1, y2, G12), G22 = fma(y2, y2, G22);
+      g0 = fma(y0, yr, g0), g1 = fma(y1, yr, g1), g2 = fma(y2, yr, g2);
+    }
+    a = wave_sum(a);
+    G00 = wave_sum(G00), G01 = wave_sum(G01), G02 = wave_sum(G02), G11 = wave_sum(G11), G12 = wave_sum(G12), G22 = wave_sum(G22);
+    g0 = wave_sum(g0), g1 = wave_sum(g1), g2 = wave_sum(g2);
+    const M3 Gm{G00, G01, G02, G01, G11, G12, G02, G12, G22};
+    const V3 gv{g0, g1, g2};
+    const V3 x = colpiv_qr_solve3(Gm, gv);
+    chi2 = a - dot(gv, x);
+  }
+#undef TI
+#undef TJ
+  return chi2;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// k_feat_y: one feature per workgroup (see the head of this file).  NW wavefronts, TPW gate tiles per wavefront:
+// NT (NT + 1) / 2 + NT <= NW * TPW for every feature of the batch.  tq: the factors T of k_feat_vt.
+// ---------------------------------------------------------------------------------------------------
+template <int NW, int TPW, int OCC>
+__global__ void __launch_bounds__(64 * NW, OCC)
+    k_feat_y(SysParams p, int nt_max, const double *__restrict__ rowsG, const int32_t *__restrict__ minfoG, const double *__restrict__ VG,
+             const double *__restrict__ tqG) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int NTH = 64 * NW;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, cl = lane & 15;
+  const int D = p.D, LD = p.LD, RS = p.row_stride;
+  const FeatYLds lo = featy_lds_layout(nt_max, NW);
+  double *Yb = reinterpret_cast<double *>(smem + lo.yb);
+  double *panel = Yb; // the Cholesky's row panel takes the block's place once the gate matrix is complete
+  double *rhs = reinterpret_cast<double *>(smem + lo.rhs);
+  double *wpart = reinterpret_cast<double *>(smem + lo.wpart);
+  double *st0 = wpart, *st1 = wpart + 256;
+  double *zres = reinterpret_cast<double *>(smem + lo.misc);                     // [3 NW] V^T r of the residual column, per wavefront
+  int *rowlim = reinterpret_cast<int *>(smem + lo.misc + 32 * sizeof(double));   // [nt_max] last non-zero column of each tile row
+  int *sched = rowlim + nt_max;                                                  // [4]
+  const double sig2 = p.opt.sigma_pix_sq;
+  const int nblk = (D + FY_CB - 1) / FY_CB;
+
+  long long tlast = 0;
+  const bool prof = p.dbg != nullptr && blockIdx.x == 0 && tid == 0;
+  if (prof) tlast = clock64();
+#define FEAT_T(i)                              \
+  if (prof) {                                  \
+    const long long tn = clock64();            \
+    p.dbg[220 + (i)] += tn - tlast, tlast = tn; \
+  }
+
+  for (;;) {
+    __syncthreads(); // the previous feature's LDS is fully consumed
+    if (tid == 0) sched[0] = atomicAdd(p.work_counter, 1);
+    __syncthreads();
+    const int slot = __builtin_amdgcn_readfirstlane(sched[0]);
+    if (slot >= p.F) break;
+    const int f = __builtin_amdgcn_readfirstlane(p.order ? p.order[slot] : slot);
+    const int m0 = __builtin_amdgcn_readfirstlane(p.meas_offsets[f]);
+    const int m = __builtin_amdgcn_readfirstlane(p.meas_offsets[f + 1]) - m0;
+    const int64_t orow0 = p.row_off[f];
+    const int n_out = (int)(p.row_off[f + 1] - orow0); // 2m - 3 (0 when m < 2)
+    double *out = p.Hbig + orow0 * LD;
+    if (p.status[f] != OVGPU_FEAT_USED) { // failed before the gate: its rows of the stack are zero
+      for (int64_t e = tid; e < (int64_t)n_out * LD; e += NTH) out[e] = 0.0;
+      continue;
+    }
+    const int n = 2 * m, NT = (n + 15) >> 4, NTT = NT * (NT + 1) / 2, ntiles = NTT + NT;
+    // this wavefront's tiles: linear index t = s NW + wv over the upper triangle column by column, then the right-hand-side column NT
+    int tij[TPW]; // (j << 8) | i, or -1 for an unused slot
+    d4 acc[TPW];
+#pragma unroll
+    for (int s = 0; s < TPW; s++) {
+      const int t = s * NW + wv;
+      int i = -1, j = 0;
+      if (t < NTT) {
+        while ((j + 1) * (j + 2) / 2 <= t) j++;
+        i = t - j * (j + 1) / 2;
+      } else if (t < ntiles) {
+        j = NT, i = t - NTT;
+      }
+      tij[s] = i < 0 ? -1 : ((j << 8) | i);
+      acc[s] = d4{0.0, 0.0, 0.0, 0.0};
+    }
+#define TI(s) (tij[s] & 255)
+#define TJ(s) (tij[s] >> 8)
+    const double *frow = rowsG + (size_t)m0 * RS;   // this feature's rows in the store (wave-uniform reads -> scalar loads)
+    const int32_t *finfo = minfoG + (size_t)8 * m0;
+    const double *fV = VG + (size_t)6 * m0;         // V[2 i + a][k] = fV[6 i + 3 a + k]
+    const double T00 = tqG[(size_t)8 * f], T01 = tqG[(size_t)8 * f + 1], T02 = tqG[(size_t)8 * f + 2], T11 = tqG[(size_t)8 * f + 3],
+                 T12 = tqG[(size_t)8 * f + 4], T22 = tqG[(size_t)8 * f + 5];
+
+    // ------------------------------------------------------------------ prologue
+    if (tid < nt_max) rowlim[tid] = -1;
+    if (tid < 32) zres[tid] = 0.0;
+    for (int i = tid; i < 8 * NT; i += NTH) { // [r | H_f] of both rows of measurement i (zeros on the padding)
+      double *q0 = rhs + (size_t)8 * i;
+      if (i < m) {
+        const double *rd = frow + (size_t)i * RS;
+        q0[0] = rd[RO_RES], q0[1] = rd[RO_HF], q0[2] = rd[RO_HF + 1], q0[3] = rd[RO_HF + 2];
+        q0[4] = rd[RO_RES + 1], q0[5] = rd[RO_HF + 3], q0[6] = rd[RO_HF + 4], q0[7] = rd[RO_HF + 5];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; e++) q0[e] = 0.0;
+      }
+    }
+    __syncthreads();
+    { // last non-zero column of each tile row; the residual column of the stack: r - V (T^T V^T r)
+      if (tid < m) {
+        const int32_t *mi = finfo + 8 * tid;
+        int lim = mi[2] + 5;
+        if (mi[3] >= 0) lim = max(lim, mi[3] + 5);
+        if (mi[4] >= 0) lim = max(lim, mi[4] + 7);
+        atomicMax(rowlim + (tid >> 3), lim);
+      }
+      double r_a = 0.0, v0 = 0.0, v1 = 0.0, v2 = 0.0;
+      if (tid < n) {
+        r_a = rhs[(size_t)4 * tid];
+        const double *v = fV + (size_t)3 * tid;
+        v0 = v[0], v1 = v[1], v2 = v[2];
+      }
+      const double s0 = wave_sum(v0 * r_a), s1 = wave_sum(v1 * r_a), s2 = wave_sum(v2 * r_a);
+      if (lane == 0) zres[3 * wv] = s0, zres[3 * wv + 1] = s1, zres[3 * wv + 2] = s2; // summed in a fixed order: bit-reproducible
+      __syncthreads();
+      double w0 = 0.0, w1 = 0.0, w2 = 0.0;
+#pragma unroll
+      for (int w = 0; w < NW; w++) w0 += zres[3 * w], w1 += zres[3 * w + 1], w2 += zres[3 * w + 2];
+      const double z0 = T00 * w0, z1 = T01 * w0 + T11 * w1, z2 = T02 * w0 + T12 * w1 + T22 * w2;
+      if (tid >= 3 && tid < n) out[(size_t)(tid - 3) * LD + D] = r_a - (v0 * z0 + v1 * z1 + v2 * z2);
+    }
+    FEAT_T(0)
+
+    // ------------------------------------------------------------------ the column blocks
+    for (int kb = 0; kb < nblk; kb++) {
+      const int c_lo = FY_CB * kb;
+      const int c = c_lo + lane;
+      const bool colok = c < D;
+      const double *Lc = p.Lw + (colok ? c : D - 1);
+      // ---- sweep: Y = H L for this block's columns, V^T Y per column
+      double w0 = 0.0, w1 = 0.0, w2 = 0.0;
+      {
+        double lcp[6] = {0, 0, 0, 0, 0, 0}, lci[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        int cam_l = -1;
+#pragma unroll 1
+        for (int ib = wv; ib < 8 * NT; ib += 2 * NW) { // two measurements per trip: their rows of L are in flight together
+          double lcl[2][6];
+          int ccol[2];
+          bool live[2];
+#pragma unroll
+          for (int ii = 0; ii < 2; ii++) {
+            const int i = ib + NW * ii;
+            ccol[ii] = i < m ? finfo[8 * i + 2] : 0;
+            live[ii] = i < m && ccol[ii] + 5 >= c_lo; // wave-uniform
+            const double *Lr = Lc + (size_t)ccol[ii] * D;
+#pragma unroll
+            for (int s = 0; s < 6; s++) lcl[ii][s] = live[ii] ? Lr[(size_t)s * D] : 0.0;
+          }
+#pragma unroll
+          for (int ii = 0; ii < 2; ii++) {
+            const int i = ib + NW * ii;
+            if (i >= 8 * NT) continue;
+            double t0 = 0.0, t1 = 0.0;
+            if (i < m) {
+              const int32_t *mi = finfo + 8 * i;
+              const double *rd = frow + (size_t)i * RS;
+              const int camv = mi[0], pcol = mi[3], icol = mi[4];
+              if (live[ii]) {
+#pragma unroll
+                for (int s = 0; s < 6; s++) t0 = fma(rd[RO_CLONE + s], lcl[ii][s], t0), t1 = fma(rd[RO_CLONE + 6 + s], lcl[ii][s], t1);
+              }
+              const bool lp = pcol >= 0 && pcol + 5 >= c_lo, li = icol >= 0 && icol + 7 >= c_lo;
+              if (lp || li) {
+                if (camv != cam_l) {
+                  cam_l = camv;
+#pragma unroll
+                  for (int s = 0; s < 6; s++) lcp[s] = lp ? Lc[(size_t)(pcol + s) * D] : 0.0;
+#pragma unroll
+                  for (int s = 0; s < 8; s++) lci[s] = li ? Lc[(size_t)(icol + s) * D] : 0.0;
+                }
+                double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+                for (int s = 0; s < 6; s++) s0 = fma(rd[RO_CPOSE + s], lcp[s], s0), s1 = fma(rd[RO_CPOSE + 6 + s], lcp[s], s1);
+#pragma unroll
+                for (int s = 0; s < 8; s++) s0 = fma(rd[RO_CINTR + s], lci[s], s0), s1 = fma(rd[RO_CINTR + 8 + s], lci[s], s1);
+                t0 += s0, t1 += s1;
+              }
+              if (!colok) t0 = 0.0, t1 = 0.0;
+              const double *v = fV + (size_t)6 * i;
+              w0 = fma(v[0], t0, w0), w1 = fma(v[1], t0, w1), w2 = fma(v[2], t0, w2);
+              w0 = fma(v[3], t1, w0), w1 = fma(v[4], t1, w1), w2 = fma(v[5], t1, w2);
+            }
+            Yb[(size_t)(2 * i) * FY_LS + lane] = t0, Yb[(size_t)(2 * i + 1) * FY_LS + lane] = t1;
+          }
+        }
+      }
+      wpart[(wv * 3 + 0) * 64 + lane] = w0, wpart[(wv * 3 + 1) * 64 + lane] = w1, wpart[(wv * 3 + 2) * 64 + lane] = w2;
+      __syncthreads();
+      FEAT_T(1)
+      // ---- rows 3.. of Q^T Y = Y - V z -> the stack
+      {
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int w = 0; w < NW; w++) s0 += wpart[(w * 3 + 0) * 64 + lane], s1 += wpart[(w * 3 + 1) * 64 + lane], s2 += wpart[(w * 3 + 2) * 64 + lane];
+        const double z0 = T00 * s0, z1 = T01 * s0 + T11 * s1, z2 = T02 * s0 + T12 * s1 + T22 * s2;
+        if (colok) {
+#pragma unroll 4
+          for (int a = 3 + wv; a < n; a += NW) {
+            const double *v = fV + (size_t)3 * a;
+            out[(size_t)(a - 3) * LD + c] = Yb[(size_t)a * FY_LS + lane] - (v[0] * z0 + v[1] * z1 + v[2] * z2);
+          }
+        }
+      }
+      FEAT_T(2)
+      // ---- SYRK: S0 tiles += Y_i Y_j^T over the slabs of 8 columns both tile rows reach
+#pragma unroll
+      for (int s = 0; s < TPW; s++) {
+        if (tij[s] >= 0 && TJ(s) < NT) {
+          const int li = rowlim[TI(s)], lj = rowlim[TJ(s)];
+          const int lim = min(min(li, lj), D - 1);
+          if (lim >= c_lo) {
+            const int nsl = min(FY_CB / 8, (lim - c_lo) / 8 + 1);
+            const double *ya = Yb + (size_t)(16 * TI(s) + cl) * FY_LS + 2 * g, *yb = Yb + (size_t)(16 * TJ(s) + cl) * FY_LS + 2 * g;
+#pragma unroll 2
+            for (int sl = 0; sl < nsl; sl++) {
+              const double2 a = *reinterpret_cast<const double2 *>(ya + 8 * sl), b = *reinterpret_cast<const double2 *>(yb + 8 * sl);
+              FEAT_MFMA(a.x, b.x, acc[s]);
+              FEAT_MFMA(a.y, b.y, acc[s]);
+            }
+          }
+        }
+      }
+      __syncthreads(); // the block is free again
+      FEAT_T(3)
+    }
+
+    // ------------------------------------------------------------------ S0 = Y Y^T + s^2 I (identity on the padding), right-hand sides
+#pragma unroll
+    for (int s = 0; s < TPW; s++) {
+      if (tij[s] < 0) continue;
+      if (TJ(s) == NT) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) acc[s][q] = cl < 4 ? rhs[(size_t)(16 * TI(s) + g + 4 * q) * 4 + cl] : 0.0;
+      } else if (TI(s) == TJ(s)) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const int a = 16 * TI(s) + g + 4 * q;
+          if (g + 4 * q == cl) acc[s][q] = a < n ? acc[s][q] + sig2 : 1.0;
+        }
+      }
+    }
+    __syncthreads(); // wpart becomes the Cholesky's stage, the block its row panel
+    FEAT_T(4)
+    const double chi2 = gate_cholesky_chi2<NW, TPW>(acc, tij, NT, n, panel, st0, st1, rhs, lane, wv);
+    if (wv == 0 && lane == 0) {
+      const double thr = p.opt.chi2_multipler * p.chi2_table[min(n - 3, p.chi2_table_len - 1)]; // UpdaterMSCKF.cpp:216-222
+      p.chi2[f] = chi2;
+      p.chi2_thresh[f] = thr;
+      const bool reject = chi2 > thr; // :225
+      sched[1] = reject ? 1 : 0;
+      if (reject) p.status[f] = OVGPU_FEAT_CHI2_REJECTED;
+      else if (p.rows_used) atomicAdd(p.rows_used, n_out);
+    }
+    __syncthreads();
+    if (sched[1]) { // rejected: its rows leave the stack
+      for (int64_t e = tid; e < (int64_t)n_out * LD; e += NTH) out[e] = 0.0;
+    }
+    FEAT_T(5)
+  }
+#undef FEAT_T
+#undef TI
+#undef TJ
+}
+
+} // namespace feat
+} // namespace ovg

@@ -22,6 +22,7 @@
 #include "k_slam.h"
 #include "k_tsqr_blk.h"
 #include "k_tracks.h"
+#include "k_featy.h"
 #include "k_gram.h"
 #include <unordered_map>
 #include <dlfcn.h>
@@ -201,6 +202,12 @@ struct ovgpu_ctx {
   int feat_variant = 0;         // MSCKF fast path of the per-feature stage (k_feat.h) for this batch: 0 none, 1 <4,11>, 2 <8,17>
   int feat_nt_max = 0, feat_grid = 0;
   size_t feat_lds = 0;
+  // the fused form of the fast path (k_featy.h): rows, projection, stack and gate in one kernel, gate matrix as a SYRK of the whitened rows
+  bool featy_ok = false;         // this batch fits it
+  bool legacy_feat_kernel = false; // ovgpu_debug_option "legacy_feature_kernel": keep k_feat.h's three-sweep form
+  int featy_grid = 0;
+  size_t featy_lds = 0;
+  DevBuf<double> fs_tq;
   bool no_feat_kernel = false;  // options.no_fast_feature_kernel
   DevBuf<int32_t> feat_counter, fs_minfo, fs_meas_feat; // fs_*: the row store of the fast path (feat::FeatStore)
   DevBuf<double> fs_rows, fs_V, fs_z, fs_w;
@@ -485,7 +492,7 @@ void ovgpu_destroy(ovgpu_ctx *c) {
   c->ctrl.release();
   c->gram_part.release(), c->gram_G.release(), c->gram_rho.release(), c->Yaug2.release(), c->gram_dropped.release(), c->Lw.release(), c->dbg_cycles.release();
   c->chol_uinv.release();
-  c->fs_minfo.release(), c->fs_meas_feat.release(), c->fs_rows.release(), c->fs_V.release(), c->fs_z.release(), c->fs_w.release();
+  c->fs_minfo.release(), c->fs_meas_feat.release(), c->fs_rows.release(), c->fs_V.release(), c->fs_z.release(), c->fs_w.release(), c->fs_tq.release();
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
@@ -759,8 +766,20 @@ static int set_row_layout(ovgpu_ctx *c, bool slam_rows) {
   // registers of a wavefront's lanes: 254 observations per track at most.  Longer tracks are refused, never mis-gated.
   if (!c->feat_variant && 2 * m_max + 4 > 512)
     return set_err(OVGPU_ERR_CAPACITY, "track of more than 254 observations: beyond the per-feature kernels (gate of 2m + 4 <= 512 rows)");
+  c->featy_ok = false;
+  if (c->feat_variant) { // the fused form: block of 16 nt x 64 whitened rows in LDS instead of the row copies and the T chunk
+    const int nt = c->feat_nt_max, nw = c->feat_variant == 1 ? 4 : 8;
+    const feat::FeatYLds lo = feat::featy_lds_layout(nt, nw);
+    const size_t vt_lds = (size_t)4 * (12 * std::max(m_max, 1) + 64) * sizeof(double);
+    if (lo.total <= (size_t)c->lds_limit && vt_lds <= (size_t)c->lds_limit && nt * (nt + 1) / 2 + nt <= nw * (nw == 4 ? 11 : 17)) {
+      const int per_cu = nw == 4 ? std::max(1, std::min(2, (int)((size_t)c->lds_limit / lo.total))) : 1;
+      c->featy_ok = true, c->featy_lds = lo.total;
+      c->featy_grid = std::max(1, std::min(F, c->num_cu * per_cu));
+    }
+  }
   if (c->feat_variant) { // row store of the fast path
     const int M = std::max(c->M, 1);
+    HIPCHK(c->fs_tq.reserve((size_t)std::max(F, 1) * 8));
     HIPCHK(c->fs_rows.reserve((size_t)M * c->row_stride));
     HIPCHK(c->fs_minfo.reserve((size_t)M * 8));
     HIPCHK(c->fs_V.reserve((size_t)M * 6));
@@ -938,6 +957,25 @@ static int enqueue_system(ovgpu_ctx *c, int f_one = -1, int init_rep = 0, bool w
     feat::FeatStore st{c->fs_rows.p, c->fs_minfo.p, c->fs_V.p, c->fs_z.p, c->fs_meas_feat.p, c->fs_w.p};
     const double *sr = st.rows, *sV = st.V, *sz = st.z;
     const int32_t *sm = st.minfo;
+    if (c->featy_ok && !c->legacy_feat_kernel) {
+      // the fused form (k_featy.h): rows (clone-major) -> reflectors -> [prior block's factor L joins] -> sweep Y = H L once per feature:
+      // projected rows to the stack, gate matrix as Y Y^T + s^2 I on the matrix cores, Cholesky, chi2
+      static bool attr_y = false;
+      if (!attr_y) {
+        (void)hipFuncSetAttribute((const void *)feat::k_feat_y<4, 11, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_limit);
+        (void)hipFuncSetAttribute((const void *)feat::k_feat_y<8, 17, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_limit);
+        (void)hipFuncSetAttribute((const void *)feat::k_feat_vt, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_limit);
+        attr_y = true;
+      }
+      hipLaunchKernelGGL(feat::k_feat_rows_sorted, dim3((c->M + 255) / 256), dim3(256), 0, c->stream, p, st, c->M);
+      hipLaunchKernelGGL(feat::k_feat_vt, dim3((c->F + 3) / 4), dim3(256), (size_t)4 * (12 * p.m_max + 64) * sizeof(double), c->stream, p, st, c->fs_tq.p);
+      if (c->prior_on_side) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join, 0));
+      const double *stq = c->fs_tq.p;
+      if (c->feat_variant == 1) hipLaunchKernelGGL((feat::k_feat_y<4, 11, 2>), dim3(c->featy_grid), dim3(256), c->featy_lds, c->stream, p, c->feat_nt_max, sr, sm, sV, stq);
+      else hipLaunchKernelGGL((feat::k_feat_y<8, 17, 1>), dim3(c->featy_grid), dim3(512), c->featy_lds, c->stream, p, c->feat_nt_max, sr, sm, sV, stq);
+      HIPCHK(hipGetLastError());
+      return OVGPU_OK;
+    }
     hipLaunchKernelGGL(feat::k_feat_rows, dim3((c->M + 255) / 256), dim3(256), 0, c->stream, p, st, c->M);
     hipStream_t sq = c->stream;
     if (c->prior_on_side) {
@@ -2832,6 +2870,9 @@ int ovgpu_debug_option(ovgpu_ctx *c, const char *name, int64_t value, int64_t *o
   if (n == "chol_follow_spin_limit") {
     if (old_value) *old_value = c->chol_spin_limit;
     if (value >= 0) c->chol_spin_limit = (int)std::min<int64_t>(value, 1 << 30);
+  } else if (n == "legacy_feature_kernel") { // 1: the three-sweep form of the MSCKF fast path (k_feat.h) instead of the fused one (k_featy.h)
+    if (old_value) *old_value = c->legacy_feat_kernel ? 1 : 0;
+    if (value >= 0) c->legacy_feat_kernel = value != 0;
   } else if (n == "chol_timeouts") { // read-only counter: updates repeated with the step-wise Cholesky after a follower timed out
     if (old_value) *old_value = c->chol_timeouts;
   } else {
