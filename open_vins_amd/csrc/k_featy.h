@@ -35,6 +35,8 @@
 // The row store is kept in CLONE-MAJOR order inside a feature (k_feat_rows_sorted): rows of early clones are zero right of their
 // block, so a column block only concerns a suffix of the rows and whole tile rows drop out of its SYRK.
 #pragma once
+#include <type_traits>
+
 #include "k_feat.h"
 
 namespace ovg {
@@ -45,7 +47,7 @@ constexpr int FY_LS = 66; // row stride of the LDS block in doubles: 16-byte ali
                           // (rows r and r + 1 of a tile are 4 banks apart: 16 lanes x 4 banks = all 64)
 
 struct FeatYLds {
-  size_t yb, rhs, wpart, misc, total;
+  size_t yb, vl, wpart, misc, total;
 };
 // nt_max = tile rows of the longest track; nw = wavefronts per workgroup
 __host__ __device__ inline FeatYLds featy_lds_layout(int nt_max, int nw) {
@@ -56,8 +58,9 @@ __host__ __device__ inline FeatYLds featy_lds_layout(int nt_max, int nw) {
     o += (bytes + 15) & ~(size_t)15;
     return at;
   };
-  L.yb = take((size_t)16 * nt_max * FY_LS * sizeof(double)); // the block; afterwards the Cholesky's row panel ((nt_max + 1) tiles fit)
-  L.rhs = take((size_t)16 * nt_max * 4 * sizeof(double));
+  // the block; afterwards the Cholesky's row panel ((nt_max + 1) tiles) and, behind it, the solved right-hand sides (16 nt_max x 4)
+  L.yb = take((size_t)16 * nt_max * FY_LS * sizeof(double));
+  L.vl = take((size_t)16 * nt_max * 3 * sizeof(double));
   const size_t wp = (size_t)nw * 3 * 64 * sizeof(double), stage = 2 * 256 * sizeof(double);
   L.wpart = take(wp > stage ? wp : stage); // V^T Y partial sums per wavefront; afterwards the Cholesky's diagonal-tile stage
   L.misc = take(32 * sizeof(double) + (size_t)(nt_max + 16) * sizeof(int)); // V^T r partials per wavefront, then rowlim / sched
@@ -97,7 +100,10 @@ __global__ void __launch_bounds__(256) k_feat_rows_sorted(SysParams p, FeatStore
 // ---------------------------------------------------------------------------------------------------
 // k_feat_vt: one wavefront per feature -> Householder reflectors of H_f: V [2m][3] and the factor T of Q = I - V T V^T (6 doubles)
 // ---------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_feat_vt(SysParams p, FeatStore st, double *__restrict__ tq) {
+constexpr int FY_INST = 24;           // instances per tile row: <= 8 clones + 8 extrinsic + 8 intrinsic blocks
+constexpr int FY_ISTR = 32;           // ints per tile row in the instance table: [0] count, [1] last non-zero column, [8 ..] instances
+constexpr int FY_IOFF = 8;
+__global__ void __launch_bounds__(256) k_feat_vt(SysParams p, FeatStore st, double *__restrict__ tq, int32_t *__restrict__ inst, int nt_max) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int f = blockIdx.x * 4 + wv;
@@ -126,7 +132,59 @@ __global__ void __launch_bounds__(256) k_feat_vt(SysParams p, FeatStore st, doub
     vo[0] = V[3 * r], vo[1] = V[3 * r + 1], vo[2] = V[3 * r + 2];
   }
   if (lane < 6) tq[(size_t)8 * f + lane] = hq[3 + lane]; // T00 T01 T02 T11 T12 T22
+  // The distinct column blocks ("instances": first column, width) of every tile row of 16 rows, ascending — what the sweep of k_feat_y
+  // loops over.  il[0] = count, il[1] = last non-zero column of the tile row, il[FY_IOFF ..] = (width << 16) | first column.
+  // (built in LDS: the column triples of the measurements are staged by all lanes, the lists grow in the wavefront's scratch)
+  const int NT = (n + 15) >> 4;
+  int *cols3 = reinterpret_cast<int *>(hf);                 // [m][3]: hf is dead (6 m doubles = 12 m ints)
+  int *lists = reinterpret_cast<int *>(V);                  // [NT][FY_ISTR]: V is in HBM by now (6 m doubles >= NT FY_ISTR ints for m >= 3 ... checked below)
+  const bool lds_lists = (size_t)NT * FY_ISTR <= (size_t)12 * m;
+  const int32_t *finfo = st.minfo + (size_t)8 * m0;
+  wsync();
+  for (int i = lane; i < m; i += 64) cols3[3 * i] = finfo[8 * i + 2], cols3[3 * i + 1] = finfo[8 * i + 3], cols3[3 * i + 2] = finfo[8 * i + 4];
+  wsync();
+  if (lane < NT) {
+    int *gl = inst + ((size_t)f * nt_max + lane) * FY_ISTR;
+    int *il = lds_lists ? lists + lane * FY_ISTR : gl;
+    int cnt = 0, lim = -1, prev = -1;
+    int seen_p[8], seen_i[8], np_ = 0, ni_ = 0; // the calibration blocks met so far in this tile row (at most one pair per measurement)
+    const int i1 = min(8 * lane + 8, m);
+    for (int i = 8 * lane; i < i1; i++) {
+      const int c0 = cols3[3 * i], c1 = cols3[3 * i + 1], c2 = cols3[3 * i + 2];
+      if (c0 != prev) il[FY_IOFF + cnt++] = c0 | (6 << 16), prev = c0, lim = max(lim, c0 + 5); // records are clone-major: equal clone columns are neighbours
+      bool sp = c1 < 0, si = c2 < 0;
+#pragma unroll
+      for (int e = 0; e < 8; e++) sp = sp || (e < np_ && seen_p[e] == c1), si = si || (e < ni_ && seen_i[e] == c2);
+      if (!sp) {
+#pragma unroll
+        for (int e = 0; e < 8; e++)
+          if (e == np_) seen_p[e] = c1;
+        np_++, il[FY_IOFF + cnt++] = c1 | (6 << 16), lim = max(lim, c1 + 5);
+      }
+      if (!si) {
+#pragma unroll
+        for (int e = 0; e < 8; e++)
+          if (e == ni_) seen_i[e] = c2;
+        ni_++, il[FY_IOFF + cnt++] = c2 | (8 << 16), lim = max(lim, c2 + 7);
+      }
+    }
+    for (int a = 1; a < cnt; a++) { // ascending first column: a column block's dead instances (left of it) are a prefix of the list
+      const int v = il[FY_IOFF + a];
+      int b = a - 1;
+      while (b >= 0 && (il[FY_IOFF + b] & 0xffff) > (v & 0xffff)) il[FY_IOFF + b + 1] = il[FY_IOFF + b], b--;
+      il[FY_IOFF + b + 1] = v;
+    }
+    il[0] = cnt, il[1] = lim;
+    if (lds_lists) {
+      gl[0] = cnt, gl[1] = lim;
+      for (int e = 0; e < cnt; e++) gl[FY_IOFF + e] = il[FY_IOFF + e];
+    }
+  }
 }
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding GLOBAL access of the wavefront
+// (s_waitcnt vmcnt(0)): behind the output rows' stores that is a drain of ~50 KB to HBM at every barrier of the block loop.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // ---------------------------------------------------------------------------------------------------
 // Blocked Cholesky S0 = U^T U of the gate matrix held as tiles in registers (right-hand sides carried) + the chi2 statistic.
@@ -154,7 +212,7 @@ __device__ __forceinline__ double gate_cholesky_chi2(d4 (&acc)[TPW], const int (
         for (int q = 0; q < 4; q++) st1[cl * 16 + g + 4 * q] = ev[q]; // U^-T in accumulator layout -> U^-1 row-major
       }
     }
-    __syncthreads();
+    lds_barrier();
     { // (2) row panel: W_kj = U_kk^-T S_kj, published for the trailing update
       double ua[4];
 #pragma unroll
@@ -172,7 +230,7 @@ __device__ __forceinline__ double gate_cholesky_chi2(d4 (&acc)[TPW], const int (
         }
       }
     }
-    __syncthreads();
+    lds_barrier();
     // (3) trailing update S_ij -= W_ki^T W_kj, k < i <= j (j = NT: the right-hand sides)
 #pragma unroll
     for (int s = 0; s < TPW; s++) {
@@ -195,7 +253,7 @@ __device__ __forceinline__ double gate_cholesky_chi2(d4 (&acc)[TPW], const int (
       for (int q = 0; q < 4; q++) rhs[(size_t)(16 * TI(s) + g + 4 * q) * 4 + cl] = acc[s][q];
     }
   }
-  __syncthreads();
+  lds_barrier();
   double chi2 = 0.0;
   if (wv == 0) {
     double a = 0, G00 = 0, G01 = 0, G02 = 0, G11 = 0, G12 = 0, G22 = 0, g0 = 0, g1 = 0, g2 = 0;
@@ -222,11 +280,20 @@ __device__ __forceinline__ double gate_cholesky_chi2(d4 (&acc)[TPW], const int (
 // ---------------------------------------------------------------------------------------------------
 // k_feat_y: one feature per workgroup (see the head of this file).  NW wavefronts, TPW gate tiles per wavefront:
 // NT (NT + 1) / 2 + NT <= NW * TPW for every feature of the batch.  tq: the factors T of k_feat_vt.
+//
+// The sweep Y = H L runs on the matrix cores as well.  A tile row (16 rows = 8 measurements) touches a handful of column blocks
+// of H — the clone blocks of its clones, the extrinsic / intrinsic blocks of its cameras ("instances", listed per tile row in the
+// prologue).  For one instance (first column fc, width 6 or 8) and one 16-column tile of the output:
+//        Y_tile += A B,    A[row][k] = H[row][fc + k] (zero for the rows of other clones / cameras),   B[k][col] = L[fc + k][col]
+// two v_mfma_f64_16x16x4_f64 (k = 0..3, 4..7).  Three quarters of A's rows are zero — wasted multiply-adds that cost less than
+// anything else tried: the operands are per-lane loads (A: once per tile row, from the row store; B: 128-byte rows of L), nothing
+// goes through the scalar cache, and the thread-per-column form this replaces (Jacobian values as scalar operands, 100+ scalar
+// registers per measurement, 229 of them spilled) spent 44 % of the kernel in its sweep.
 // ---------------------------------------------------------------------------------------------------
 template <int NW, int TPW, int OCC>
 __global__ void __launch_bounds__(64 * NW, OCC)
     k_feat_y(SysParams p, int nt_max, const double *__restrict__ rowsG, const int32_t *__restrict__ minfoG, const double *__restrict__ VG,
-             const double *__restrict__ tqG) {
+             const double *__restrict__ tqG, const int32_t *__restrict__ instG) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int NTH = 64 * NW;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -235,8 +302,9 @@ __global__ void __launch_bounds__(64 * NW, OCC)
   const int D = p.D, LD = p.LD, RS = p.row_stride;
   const FeatYLds lo = featy_lds_layout(nt_max, NW);
   double *Yb = reinterpret_cast<double *>(smem + lo.yb);
-  double *panel = Yb; // the Cholesky's row panel takes the block's place once the gate matrix is complete
-  double *rhs = reinterpret_cast<double *>(smem + lo.rhs);
+  double *panel = Yb;                                   // the Cholesky's row panel takes the block's place once the gate matrix is complete
+  double *rhs = Yb + (size_t)(nt_max + 1) * 256;        // ... and the solved right-hand sides sit behind it
+  double *Vl = reinterpret_cast<double *>(smem + lo.vl); // [16 nt_max][3] reflectors
   double *wpart = reinterpret_cast<double *>(smem + lo.wpart);
   double *st0 = wpart, *st1 = wpart + 256;
   double *zres = reinterpret_cast<double *>(smem + lo.misc);                     // [3 NW] V^T r of the residual column, per wavefront
@@ -254,11 +322,15 @@ __global__ void __launch_bounds__(64 * NW, OCC)
     p.dbg[220 + (i)] += tn - tlast, tlast = tn; \
   }
 
+  bool first = true;
   for (;;) {
-    __syncthreads(); // the previous feature's LDS is fully consumed
-    if (tid == 0) sched[0] = atomicAdd(p.work_counter, 1);
-    __syncthreads();
-    const int slot = __builtin_amdgcn_readfirstlane(sched[0]);
+    // the next slot was requested while the previous feature was in its Cholesky (sched[2]); the first one here
+    if (first) {
+      if (tid == 0) sched[2] = atomicAdd(p.work_counter, 1);
+      first = false;
+    }
+    lds_barrier(); // the previous feature's LDS is fully consumed; sched[2] is visible
+    const int slot = __builtin_amdgcn_readfirstlane(sched[2]);
     if (slot >= p.F) break;
     const int f = __builtin_amdgcn_readfirstlane(p.order ? p.order[slot] : slot);
     const int m0 = __builtin_amdgcn_readfirstlane(p.meas_offsets[f]);
@@ -268,6 +340,8 @@ __global__ void __launch_bounds__(64 * NW, OCC)
     double *out = p.Hbig + orow0 * LD;
     if (p.status[f] != OVGPU_FEAT_USED) { // failed before the gate: its rows of the stack are zero
       for (int64_t e = tid; e < (int64_t)n_out * LD; e += NTH) out[e] = 0.0;
+      lds_barrier(); // everybody has read sched[2]
+      if (tid == 0) sched[2] = atomicAdd(p.work_counter, 1);
       continue;
     }
     const int n = 2 * m, NT = (n + 15) >> 4, NTT = NT * (NT + 1) / 2, ntiles = NTT + NT;
@@ -289,139 +363,138 @@ __global__ void __launch_bounds__(64 * NW, OCC)
     }
 #define TI(s) (tij[s] & 255)
 #define TJ(s) (tij[s] >> 8)
-    const double *frow = rowsG + (size_t)m0 * RS;   // this feature's rows in the store (wave-uniform reads -> scalar loads)
+    const double *frow = rowsG + (size_t)m0 * RS;   // this feature's records in the row store
     const int32_t *finfo = minfoG + (size_t)8 * m0;
-    const double *fV = VG + (size_t)6 * m0;         // V[2 i + a][k] = fV[6 i + 3 a + k]
+    const double *fV = VG + (size_t)6 * m0;         // V[a][k] = fV[3 a + k]
     const double T00 = tqG[(size_t)8 * f], T01 = tqG[(size_t)8 * f + 1], T02 = tqG[(size_t)8 * f + 2], T11 = tqG[(size_t)8 * f + 3],
                  T12 = tqG[(size_t)8 * f + 4], T22 = tqG[(size_t)8 * f + 5];
 
-    // ------------------------------------------------------------------ prologue
-    if (tid < nt_max) rowlim[tid] = -1;
-    if (tid < 32) zres[tid] = 0.0;
-    for (int i = tid; i < 8 * NT; i += NTH) { // [r | H_f] of both rows of measurement i (zeros on the padding)
-      double *q0 = rhs + (size_t)8 * i;
-      if (i < m) {
-        const double *rd = frow + (size_t)i * RS;
-        q0[0] = rd[RO_RES], q0[1] = rd[RO_HF], q0[2] = rd[RO_HF + 1], q0[3] = rd[RO_HF + 2];
-        q0[4] = rd[RO_RES + 1], q0[5] = rd[RO_HF + 3], q0[6] = rd[RO_HF + 4], q0[7] = rd[RO_HF + 5];
-      } else {
-#pragma unroll
-        for (int e = 0; e < 8; e++) q0[e] = 0.0;
-      }
-    }
-    __syncthreads();
-    { // last non-zero column of each tile row; the residual column of the stack: r - V (T^T V^T r)
-      if (tid < m) {
-        const int32_t *mi = finfo + 8 * tid;
-        int lim = mi[2] + 5;
-        if (mi[3] >= 0) lim = max(lim, mi[3] + 5);
-        if (mi[4] >= 0) lim = max(lim, mi[4] + 7);
-        atomicMax(rowlim + (tid >> 3), lim);
-      }
-      double r_a = 0.0, v0 = 0.0, v1 = 0.0, v2 = 0.0;
+    // ------------------------------------------------------------------ prologue: reflectors -> LDS, instance lists, residual column
+    for (int e = tid; e < 3 * n; e += NTH) Vl[e] = fV[e];
+    const int32_t *finst = instG + (size_t)f * nt_max * FY_ISTR; // per tile row: count, last non-zero column, instances (k_feat_vt)
+    if (tid < NT) rowlim[tid] = finst[(size_t)tid * FY_ISTR + 1];
+    double r_a = 0.0;
+    {
+      double v0 = 0.0, v1 = 0.0, v2 = 0.0;
       if (tid < n) {
-        r_a = rhs[(size_t)4 * tid];
+        r_a = frow[(size_t)(tid >> 1) * RS + RO_RES + (tid & 1)];
         const double *v = fV + (size_t)3 * tid;
         v0 = v[0], v1 = v[1], v2 = v[2];
       }
       const double s0 = wave_sum(v0 * r_a), s1 = wave_sum(v1 * r_a), s2 = wave_sum(v2 * r_a);
       if (lane == 0) zres[3 * wv] = s0, zres[3 * wv + 1] = s1, zres[3 * wv + 2] = s2; // summed in a fixed order: bit-reproducible
-      __syncthreads();
+      lds_barrier();
       double w0 = 0.0, w1 = 0.0, w2 = 0.0;
 #pragma unroll
       for (int w = 0; w < NW; w++) w0 += zres[3 * w], w1 += zres[3 * w + 1], w2 += zres[3 * w + 2];
       const double z0 = T00 * w0, z1 = T01 * w0 + T11 * w1, z2 = T02 * w0 + T12 * w1 + T22 * w2;
-      if (tid >= 3 && tid < n) out[(size_t)(tid - 3) * LD + D] = r_a - (v0 * z0 + v1 * z1 + v2 * z2);
+      if (tid >= 3 && tid < n) out[(size_t)(tid - 3) * LD + D] = r_a - (v0 * z0 + v1 * z1 + v2 * z2); // the residual column is not whitened
     }
     FEAT_T(0)
 
     // ------------------------------------------------------------------ the column blocks
     for (int kb = 0; kb < nblk; kb++) {
       const int c_lo = FY_CB * kb;
-      const int c = c_lo + lane;
-      const bool colok = c < D;
-      const double *Lc = p.Lw + (colok ? c : D - 1);
-      // ---- sweep: Y = H L for this block's columns, V^T Y per column
-      double w0 = 0.0, w1 = 0.0, w2 = 0.0;
-      {
-        double lcp[6] = {0, 0, 0, 0, 0, 0}, lci[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        int cam_l = -1;
-#pragma unroll 1
-        for (int ib = wv; ib < 8 * NT; ib += 2 * NW) { // two measurements per trip: their rows of L are in flight together
-          double lcl[2][6];
-          int ccol[2];
-          bool live[2];
+      // ---- sweep on the matrix cores: this wavefront's tile rows of Y = H L, columns c_lo .. c_lo + 63 -> LDS
+      for (int i = wv; i < NT && !(p.skip & 1); i += NW) {
+        const int r = 16 * i + cl;
+        const bool rv = r < n;
+        const int mr = min(r >> 1, m - 1), par = r & 1;
+        const int32_t *mip = finfo + 8 * mr;
+        const int myc = rv ? mip[2] : -2, myp = rv ? mip[3] : -2, myi = rv ? mip[4] : -2;
+        const double *rd = frow + (size_t)mr * RS;
+        const int g1 = min(4 + g, 5); // (k = 6, 7 of a 6-wide block are masked by the width test below)
+        const double hC0 = rd[RO_CLONE + 6 * par + g], hC1 = rd[RO_CLONE + 6 * par + g1];
+        const double hP0 = rd[RO_CPOSE + 6 * par + g], hP1 = rd[RO_CPOSE + 6 * par + g1];
+        const double hI0 = rd[RO_CINTR + 8 * par + g], hI1 = rd[RO_CINTR + 8 * par + 4 + g];
+        d4 ay[4];
 #pragma unroll
-          for (int ii = 0; ii < 2; ii++) {
-            const int i = ib + NW * ii;
-            ccol[ii] = i < m ? finfo[8 * i + 2] : 0;
-            live[ii] = i < m && ccol[ii] + 5 >= c_lo; // wave-uniform
-            const double *Lr = Lc + (size_t)ccol[ii] * D;
+        for (int ct = 0; ct < 4; ct++) ay[ct] = d4{0.0, 0.0, 0.0, 0.0};
+        const int32_t *il = finst + (size_t)i * FY_ISTR; // wave-uniform: scalar loads
+        const int cnt = il[0];
+        auto code_at = [&](int e) { return il[FY_IOFF + e]; };
+        int e0 = 0; // first instance that reaches this column block ...
+        while (e0 < cnt && (code_at(e0) & 0xffff) + (code_at(e0) >> 16) - 1 < c_lo) e0++;
+        int e1 = e0; // ... and the first that reaches past its first two column tiles
+        while (e1 < cnt && (code_at(e1) & 0xffff) + (code_at(e1) >> 16) - 1 < c_lo + 32) e1++;
+        // The rows of L an instance selects, for the four column tiles of the block.  Straight-line code: every load is issued
+        // unconditionally at a clamped address and masked afterwards (right of an instance L holds explicit zeros, so a column tile
+        // beyond it costs two idle products, not a branch): the loads of the NEXT instance stay in flight behind this one's products.
+        const int colc = min(c_lo + cl, D - 1) - c_lo; // this lane's column of tile 0 (clamped), tiles 1..3: + 16 ct, clamped below
+        const bool okc[4] = {c_lo + cl < D, c_lo + 16 + cl < D, c_lo + 32 + cl < D, c_lo + 48 + cl < D};
+        // instances e_a .. e_b - 1 into the first NCT column tiles of the block
+        auto run = [&](auto nct_tag, int e_a, int e_b) {
+          constexpr int NCT = decltype(nct_tag)::value;
+          if (e_a >= e_b) return;
+          auto load_b = [&](int code, double (&b)[2 * NCT]) {
+            const int fc = code & 0xffff;
+            const double *L0 = p.Lw + (size_t)min(fc + g, D - 1) * D + c_lo, *L1 = p.Lw + (size_t)min(fc + 4 + g, D - 1) * D + c_lo;
 #pragma unroll
-            for (int s = 0; s < 6; s++) lcl[ii][s] = live[ii] ? Lr[(size_t)s * D] : 0.0;
-          }
-#pragma unroll
-          for (int ii = 0; ii < 2; ii++) {
-            const int i = ib + NW * ii;
-            if (i >= 8 * NT) continue;
-            double t0 = 0.0, t1 = 0.0;
-            if (i < m) {
-              const int32_t *mi = finfo + 8 * i;
-              const double *rd = frow + (size_t)i * RS;
-              const int camv = mi[0], pcol = mi[3], icol = mi[4];
-              if (live[ii]) {
-#pragma unroll
-                for (int s = 0; s < 6; s++) t0 = fma(rd[RO_CLONE + s], lcl[ii][s], t0), t1 = fma(rd[RO_CLONE + 6 + s], lcl[ii][s], t1);
-              }
-              const bool lp = pcol >= 0 && pcol + 5 >= c_lo, li = icol >= 0 && icol + 7 >= c_lo;
-              if (lp || li) {
-                if (camv != cam_l) {
-                  cam_l = camv;
-#pragma unroll
-                  for (int s = 0; s < 6; s++) lcp[s] = lp ? Lc[(size_t)(pcol + s) * D] : 0.0;
-#pragma unroll
-                  for (int s = 0; s < 8; s++) lci[s] = li ? Lc[(size_t)(icol + s) * D] : 0.0;
-                }
-                double s0 = 0.0, s1 = 0.0;
-#pragma unroll
-                for (int s = 0; s < 6; s++) s0 = fma(rd[RO_CPOSE + s], lcp[s], s0), s1 = fma(rd[RO_CPOSE + 6 + s], lcp[s], s1);
-#pragma unroll
-                for (int s = 0; s < 8; s++) s0 = fma(rd[RO_CINTR + s], lci[s], s0), s1 = fma(rd[RO_CINTR + 8 + s], lci[s], s1);
-                t0 += s0, t1 += s1;
-              }
-              if (!colok) t0 = 0.0, t1 = 0.0;
-              const double *v = fV + (size_t)6 * i;
-              w0 = fma(v[0], t0, w0), w1 = fma(v[1], t0, w1), w2 = fma(v[2], t0, w2);
-              w0 = fma(v[3], t1, w0), w1 = fma(v[4], t1, w1), w2 = fma(v[5], t1, w2);
+            for (int ct = 0; ct < NCT; ct++) {
+              const int cc = min(colc + 16 * ct, D - 1 - c_lo);
+              b[2 * ct] = L0[cc], b[2 * ct + 1] = L1[cc];
             }
-            Yb[(size_t)(2 * i) * FY_LS + lane] = t0, Yb[(size_t)(2 * i + 1) * FY_LS + lane] = t1;
+          };
+          double bc[2 * NCT], bn[2 * NCT];
+          int code = code_at(e_a), code_n = code_at(min(e_a + 1, e_b - 1));
+          load_b(code, bc);
+#pragma unroll 1
+          for (int e = e_a; e < e_b; e++) {
+            load_b(code_n, bn); // in flight while this instance's products run
+            const int code_nn = code_at(min(e + 2, e_b - 1));
+            const int fc = code & 0xffff, w = code >> 16;
+            const double a0 = myc == fc ? hC0 : (myp == fc ? hP0 : (myi == fc ? hI0 : 0.0));
+            const double a1 = (4 + g < w) ? (myc == fc ? hC1 : (myp == fc ? hP1 : (myi == fc ? hI1 : 0.0))) : 0.0; // k >= w: the next block's rows of L
+#pragma unroll
+            for (int ct = 0; ct < NCT; ct++) {
+              FEAT_MFMA(a0, okc[ct] ? bc[2 * ct] : 0.0, ay[ct]);
+              FEAT_MFMA(a1, okc[ct] ? bc[2 * ct + 1] : 0.0, ay[ct]);
+            }
+#pragma unroll
+            for (int q = 0; q < 2 * NCT; q++) bc[q] = bn[q];
+            code = code_n, code_n = code_nn;
           }
-        }
+        };
+        // instances that end inside the first two column tiles of the block (in block 0: the calibration blocks) skip the other two
+        run(std::integral_constant<int, 2>{}, e0, e1);
+        run(std::integral_constant<int, 4>{}, e1, cnt);
+#pragma unroll
+        for (int ct = 0; ct < 4; ct++)
+#pragma unroll
+          for (int q = 0; q < 4; q++) Yb[(size_t)(16 * i + g + 4 * q) * FY_LS + 16 * ct + cl] = ay[ct][q];
       }
-      wpart[(wv * 3 + 0) * 64 + lane] = w0, wpart[(wv * 3 + 1) * 64 + lane] = w1, wpart[(wv * 3 + 2) * 64 + lane] = w2;
-      __syncthreads();
+      lds_barrier();
       FEAT_T(1)
+      // ---- V^T Y per column (lane = column, the rows dealt to the wavefronts)
+      if (!(p.skip & 2)) {
+        double w0 = 0.0, w1 = 0.0, w2 = 0.0;
+#pragma unroll 8
+        for (int a = wv; a < n; a += NW) {
+          const double y = Yb[(size_t)a * FY_LS + lane];
+          w0 = fma(Vl[3 * a], y, w0), w1 = fma(Vl[3 * a + 1], y, w1), w2 = fma(Vl[3 * a + 2], y, w2);
+        }
+        wpart[(wv * 3 + 0) * 64 + lane] = w0, wpart[(wv * 3 + 1) * 64 + lane] = w1, wpart[(wv * 3 + 2) * 64 + lane] = w2;
+      }
+      lds_barrier();
       // ---- rows 3.. of Q^T Y = Y - V z -> the stack
-      {
+      if (!(p.skip & 2)) {
+        const int c = c_lo + lane;
         double s0 = 0.0, s1 = 0.0, s2 = 0.0;
 #pragma unroll
         for (int w = 0; w < NW; w++) s0 += wpart[(w * 3 + 0) * 64 + lane], s1 += wpart[(w * 3 + 1) * 64 + lane], s2 += wpart[(w * 3 + 2) * 64 + lane];
         const double z0 = T00 * s0, z1 = T01 * s0 + T11 * s1, z2 = T02 * s0 + T12 * s1 + T22 * s2;
-        if (colok) {
-#pragma unroll 4
-          for (int a = 3 + wv; a < n; a += NW) {
-            const double *v = fV + (size_t)3 * a;
-            out[(size_t)(a - 3) * LD + c] = Yb[(size_t)a * FY_LS + lane] - (v[0] * z0 + v[1] * z1 + v[2] * z2);
-          }
+        if (c < D) {
+#pragma unroll 8
+          for (int a = 3 + wv; a < n; a += NW)
+            out[(size_t)(a - 3) * LD + c] = Yb[(size_t)a * FY_LS + lane] - (Vl[3 * a] * z0 + Vl[3 * a + 1] * z1 + Vl[3 * a + 2] * z2);
         }
       }
       FEAT_T(2)
       // ---- SYRK: S0 tiles += Y_i Y_j^T over the slabs of 8 columns both tile rows reach
 #pragma unroll
       for (int s = 0; s < TPW; s++) {
-        if (tij[s] >= 0 && TJ(s) < NT) {
-          const int li = rowlim[TI(s)], lj = rowlim[TJ(s)];
-          const int lim = min(min(li, lj), D - 1);
+        if (tij[s] >= 0 && TJ(s) < NT && !(p.skip & 4)) {
+          const int lim = min(min(rowlim[TI(s)], rowlim[TJ(s)]), D - 1);
           if (lim >= c_lo) {
             const int nsl = min(FY_CB / 8, (lim - c_lo) / 8 + 1);
             const double *ya = Yb + (size_t)(16 * TI(s) + cl) * FY_LS + 2 * g, *yb = Yb + (size_t)(16 * TJ(s) + cl) * FY_LS + 2 * g;
@@ -434,17 +507,25 @@ __global__ void __launch_bounds__(64 * NW, OCC)
           }
         }
       }
-      __syncthreads(); // the block is free again
+      lds_barrier(); // the block is free again
       FEAT_T(3)
     }
 
-    // ------------------------------------------------------------------ S0 = Y Y^T + s^2 I (identity on the padding), right-hand sides
+    // ------------------------------------------------------------------ S0 = Y Y^T + s^2 I (identity on the padding), right-hand sides [r | H_f]
 #pragma unroll
     for (int s = 0; s < TPW; s++) {
       if (tij[s] < 0) continue;
       if (TJ(s) == NT) {
 #pragma unroll
-        for (int q = 0; q < 4; q++) acc[s][q] = cl < 4 ? rhs[(size_t)(16 * TI(s) + g + 4 * q) * 4 + cl] : 0.0;
+        for (int q = 0; q < 4; q++) {
+          const int a = 16 * TI(s) + g + 4 * q;
+          double v = 0.0;
+          if (cl < 4 && a < n) {
+            const double *rd = frow + (size_t)(a >> 1) * RS;
+            v = cl == 0 ? rd[RO_RES + (a & 1)] : rd[RO_HF + 3 * (a & 1) + cl - 1];
+          }
+          acc[s][q] = v;
+        }
       } else if (TI(s) == TJ(s)) {
 #pragma unroll
         for (int q = 0; q < 4; q++) {
@@ -453,9 +534,9 @@ __global__ void __launch_bounds__(64 * NW, OCC)
         }
       }
     }
-    __syncthreads(); // wpart becomes the Cholesky's stage, the block its row panel
     FEAT_T(4)
-    const double chi2 = gate_cholesky_chi2<NW, TPW>(acc, tij, NT, n, panel, st0, st1, rhs, lane, wv);
+    if (tid == 0) sched[2] = atomicAdd(p.work_counter, 1); // the next feature's slot: the atomic's round trip hides behind the Cholesky
+    const double chi2 = (p.skip & 8) ? 0.0 : gate_cholesky_chi2<NW, TPW>(acc, tij, NT, n, panel, st0, st1, rhs, lane, wv);
     if (wv == 0 && lane == 0) {
       const double thr = p.opt.chi2_multipler * p.chi2_table[min(n - 3, p.chi2_table_len - 1)]; // UpdaterMSCKF.cpp:216-222
       p.chi2[f] = chi2;
@@ -465,8 +546,9 @@ __global__ void __launch_bounds__(64 * NW, OCC)
       if (reject) p.status[f] = OVGPU_FEAT_CHI2_REJECTED;
       else if (p.rows_used) atomicAdd(p.rows_used, n_out);
     }
-    __syncthreads();
-    if (sched[1]) { // rejected: its rows leave the stack
+    lds_barrier();
+    if (sched[1]) { // rejected: its rows leave the stack — behind a full barrier: other wavefronts' stores to the same addresses must have landed
+      __syncthreads();
       for (int64_t e = tid; e < (int64_t)n_out * LD; e += NTH) out[e] = 0.0;
     }
     FEAT_T(5)

@@ -204,10 +204,13 @@ struct ovgpu_ctx {
   size_t feat_lds = 0;
   // the fused form of the fast path (k_featy.h): rows, projection, stack and gate in one kernel, gate matrix as a SYRK of the whitened rows
   bool featy_ok = false;         // this batch fits it
+  int featy_shape = 0;             // ovgpu_debug_option "featy_shape": 1 = eight wavefronts x 6 tiles, four wavefronts per SIMD
+  int featy_skip = 0;              // ovgpu_debug_option "featy_skip": ablation bit mask (timing experiments only)
   bool legacy_feat_kernel = false; // ovgpu_debug_option "legacy_feature_kernel": keep k_feat.h's three-sweep form
   int featy_grid = 0;
   size_t featy_lds = 0;
   DevBuf<double> fs_tq;
+  DevBuf<int32_t> fs_inst;
   bool no_feat_kernel = false;  // options.no_fast_feature_kernel
   DevBuf<int32_t> feat_counter, fs_minfo, fs_meas_feat; // fs_*: the row store of the fast path (feat::FeatStore)
   DevBuf<double> fs_rows, fs_V, fs_z, fs_w;
@@ -492,7 +495,7 @@ void ovgpu_destroy(ovgpu_ctx *c) {
   c->ctrl.release();
   c->gram_part.release(), c->gram_G.release(), c->gram_rho.release(), c->Yaug2.release(), c->gram_dropped.release(), c->Lw.release(), c->dbg_cycles.release();
   c->chol_uinv.release();
-  c->fs_minfo.release(), c->fs_meas_feat.release(), c->fs_rows.release(), c->fs_V.release(), c->fs_z.release(), c->fs_w.release(), c->fs_tq.release();
+  c->fs_minfo.release(), c->fs_meas_feat.release(), c->fs_rows.release(), c->fs_V.release(), c->fs_z.release(), c->fs_w.release(), c->fs_tq.release(), c->fs_inst.release();
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
@@ -780,6 +783,7 @@ static int set_row_layout(ovgpu_ctx *c, bool slam_rows) {
   if (c->feat_variant) { // row store of the fast path
     const int M = std::max(c->M, 1);
     HIPCHK(c->fs_tq.reserve((size_t)std::max(F, 1) * 8));
+    HIPCHK(c->fs_inst.reserve((size_t)std::max(F, 1) * std::max(c->feat_nt_max, 1) * feat::FY_ISTR));
     HIPCHK(c->fs_rows.reserve((size_t)M * c->row_stride));
     HIPCHK(c->fs_minfo.reserve((size_t)M * 8));
     HIPCHK(c->fs_V.reserve((size_t)M * 6));
@@ -930,6 +934,7 @@ static int enqueue_system(ovgpu_ctx *c, int f_one = -1, int init_rep = 0, bool w
   HIPCHK(c->rows_used.reserve(1));
   p.rows_used = c->rows_used.p;
   p.Lw = (whiten && f_one < 0) ? c->Lw.p : nullptr;
+  p.skip = c->featy_skip;
   int grid = c->sys_grid;
   if (f_one < 0) HIPCHK(ctrl_zero(c, CTRL_ROWS, c->rows_used.p, sizeof(int32_t), c->stream));
   if (f_one >= 0) {
@@ -964,15 +969,26 @@ static int enqueue_system(ovgpu_ctx *c, int f_one = -1, int init_rep = 0, bool w
       if (!attr_y) {
         (void)hipFuncSetAttribute((const void *)feat::k_feat_y<4, 11, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_limit);
         (void)hipFuncSetAttribute((const void *)feat::k_feat_y<8, 17, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_limit);
+        (void)hipFuncSetAttribute((const void *)feat::k_feat_y<8, 6, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_limit);
+        (void)hipFuncSetAttribute((const void *)feat::k_feat_y<6, 8, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_limit);
         (void)hipFuncSetAttribute((const void *)feat::k_feat_vt, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_limit);
         attr_y = true;
       }
       hipLaunchKernelGGL(feat::k_feat_rows_sorted, dim3((c->M + 255) / 256), dim3(256), 0, c->stream, p, st, c->M);
-      hipLaunchKernelGGL(feat::k_feat_vt, dim3((c->F + 3) / 4), dim3(256), (size_t)4 * (12 * p.m_max + 64) * sizeof(double), c->stream, p, st, c->fs_tq.p);
+      hipLaunchKernelGGL(feat::k_feat_vt, dim3((c->F + 3) / 4), dim3(256), (size_t)4 * (12 * p.m_max + 64) * sizeof(double), c->stream, p, st, c->fs_tq.p, c->fs_inst.p, c->feat_nt_max);
       if (c->prior_on_side) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join, 0));
       const double *stq = c->fs_tq.p;
-      if (c->feat_variant == 1) hipLaunchKernelGGL((feat::k_feat_y<4, 11, 2>), dim3(c->featy_grid), dim3(256), c->featy_lds, c->stream, p, c->feat_nt_max, sr, sm, sV, stq);
-      else hipLaunchKernelGGL((feat::k_feat_y<8, 17, 1>), dim3(c->featy_grid), dim3(512), c->featy_lds, c->stream, p, c->feat_nt_max, sr, sm, sV, stq);
+      const int32_t *sin = c->fs_inst.p;
+      if (c->feat_variant == 1 && c->featy_shape == 1) {
+        const feat::FeatYLds lo8 = feat::featy_lds_layout(c->feat_nt_max, 8);
+        const int per_cu = std::max(1, std::min(2, (int)((size_t)c->lds_limit / lo8.total)));
+        hipLaunchKernelGGL((feat::k_feat_y<8, 6, 4>), dim3(std::max(1, std::min(c->F, c->num_cu * per_cu))), dim3(512), lo8.total, c->stream, p, c->feat_nt_max, sr, sm, sV, stq, sin);
+      } else if (c->feat_variant == 1 && c->featy_shape == 2) {
+        const feat::FeatYLds lo6 = feat::featy_lds_layout(c->feat_nt_max, 6);
+        const int per_cu = std::max(1, std::min(2, (int)((size_t)c->lds_limit / lo6.total)));
+        hipLaunchKernelGGL((feat::k_feat_y<6, 8, 3>), dim3(std::max(1, std::min(c->F, c->num_cu * per_cu))), dim3(384), lo6.total, c->stream, p, c->feat_nt_max, sr, sm, sV, stq, sin);
+      } else if (c->feat_variant == 1) hipLaunchKernelGGL((feat::k_feat_y<4, 11, 2>), dim3(c->featy_grid), dim3(256), c->featy_lds, c->stream, p, c->feat_nt_max, sr, sm, sV, stq, sin);
+      else hipLaunchKernelGGL((feat::k_feat_y<8, 17, 1>), dim3(c->featy_grid), dim3(512), c->featy_lds, c->stream, p, c->feat_nt_max, sr, sm, sV, stq, sin);
       HIPCHK(hipGetLastError());
       return OVGPU_OK;
     }
@@ -2873,6 +2889,12 @@ int ovgpu_debug_option(ovgpu_ctx *c, const char *name, int64_t value, int64_t *o
   } else if (n == "legacy_feature_kernel") { // 1: the three-sweep form of the MSCKF fast path (k_feat.h) instead of the fused one (k_featy.h)
     if (old_value) *old_value = c->legacy_feat_kernel ? 1 : 0;
     if (value >= 0) c->legacy_feat_kernel = value != 0;
+  } else if (n == "featy_shape") {
+    if (old_value) *old_value = c->featy_shape;
+    if (value >= 0) c->featy_shape = (int)value;
+  } else if (n == "featy_skip") { // timing ablation of k_feat_y: 1 sweep, 2 V^T Y + output rows, 4 SYRK, 8 Cholesky (results are garbage)
+    if (old_value) *old_value = c->featy_skip;
+    if (value >= 0) c->featy_skip = (int)value;
   } else if (n == "chol_timeouts") { // read-only counter: updates repeated with the step-wise Cholesky after a follower timed out
     if (old_value) *old_value = c->chol_timeouts;
   } else {

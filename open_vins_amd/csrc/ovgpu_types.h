@@ -88,6 +88,7 @@ struct SysParams {
   const double *Lw;   // [D x D] row-major, lower triangular with explicit zeros above the diagonal: L = U1^T, P_DD = L L^T (k_ekf.h).
                       // Non-null: the rows leave the kernel whitened by the prior, Q^T [H_x L | res] (the Gram route)
   int32_t *work_counter; // k_feat: next feature slot to hand out (zeroed before the launch)
+  int skip;              // developer ablation of k_feat_y's phases (ovgpu_debug_option "featy_skip"; results are garbage when non-zero)
   DevOptions opt;
 };
 

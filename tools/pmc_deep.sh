@@ -24,4 +24,4 @@ SQC_ICACHE_REQ SQC_ICACHE_MISSES SQC_DCACHE_REQ SQC_DCACHE_MISSES
 SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU SQ_INSTS_VALU_MFMA_MOPS_F64
 TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum
 SETS
-ls $OUT; for f in $OUT/p*.txt; do echo "== $f"; grep "k_feat<\|k_feat_out\|k_gram<\|k_chol_factor" $f | head -30; done
+ls $OUT; for f in $OUT/p*.txt; do echo "== $f"; grep "k_feat_y\|k_gram<\|k_chol_factor" $f | head -30; done
