@@ -28,8 +28,9 @@ def _rot(q):
 class Stream:
     """Truth, tracks and noise of one closed-loop run; identical for every updater under test."""
 
-    def __init__(self, C=12, feats_per_frame=50, seed=7, sigma_px=1.0, q_theta=np.deg2rad(0.15), q_p=0.01, T=None):
+    def __init__(self, C=12, feats_per_frame=50, seed=7, sigma_px=1.0, q_theta=np.deg2rad(0.15), q_p=0.01, T=None, K=1):
         rng = np.random.default_rng(seed)
+        self.K = K
         if T is None:
             traj = synth.load_traj_window()
             self.T = traj.shape[0]
@@ -41,6 +42,9 @@ class Stream:
             self.T = T
             self.truth = _analytic_trajectory(T)
         self.C = C
+        if K > 1:
+            self._init_rig(rng, C, K, feats_per_frame, sigma_px, q_theta, q_p)
+            return
         Tm = np.asarray(synth._T_IMU_CAM[0])
         R_CtoI, p_CinI = Tm[:, :3], Tm[:, 3]
         self.calib_true = np.concatenate([synth.rot_2_quat(R_CtoI.T), -R_CtoI.T @ p_CinI])
@@ -81,6 +85,67 @@ class Stream:
                     made += 1
 
 
+def _stream_init_rig(self, rng, C, K, feats_per_frame, sigma_px, q_theta, q_p):
+    """K-camera rig (BASELINE configs[1..3] shape: stereo, 30-clone window, hundreds of features per frame), generated with numpy
+    over all features of a frame at once.  Observations are (frame, un, vn, xu, yu, camera); calib_true / intr_true are [K, .]."""
+    calib, intr = [], []
+    for k in range(K):
+        Tm = np.asarray(synth._T_IMU_CAM[k])
+        R_CtoI, p_CinI = Tm[:, :3], Tm[:, 3]
+        calib.append(np.concatenate([synth.rot_2_quat(R_CtoI.T), -R_CtoI.T @ p_CinI]))
+        intr.append(np.asarray(synth._INTRINSICS[k], dtype=np.float64))
+    self.calib_true, self.intr_true = np.stack(calib), np.stack(intr)
+    self.q_theta, self.q_p = q_theta, q_p
+    self.clone_noise = rng.normal(0, 1, (self.T, 6)) * np.array([q_theta] * 3 + [q_p] * 3)
+    self.init_noise = rng.normal(0, 1, (C, 6)) * np.array([0.01] * 3 + [0.03] * 3)
+    self.calib_noise = np.stack([np.concatenate([rng.normal(0, 0.3 * 0.005, 3), rng.normal(0, 0.3 * 0.015, 3)]) for _ in range(K)])
+    self.intr_noise = np.stack([np.concatenate([rng.normal(0, 0.3, 4), rng.normal(0, 0.3 * 0.0005, 4)]) for _ in range(K)])
+    R_ItoC = np.stack([_rot(c[:4]) for c in self.calib_true])
+    p_IinC = np.stack([c[4:] for c in self.calib_true])
+    Rg = np.stack([_rot(self.truth[i, :4]) for i in range(self.T)])
+    pg = self.truth[:, 4:]
+    self.tracks = {t: [] for t in range(self.T)}
+    for t_use in range(C - 1, self.T):
+        b = t_use - 1
+        lo = max(t_use - (C - 1), 0)
+        made = 0
+        while made < feats_per_frame:
+            nb = 2 * (feats_per_frame - made) + 16
+            a = rng.integers(lo, b - 3, nb)
+            j = rng.integers(a, b + 1)
+            k0 = rng.integers(0, K, nb)
+            u, v = rng.uniform(0, synth.IMG_W, nb), rng.uniform(0, synth.IMG_H, nb)
+            xn, yn = synth.radtan_undistort(self.intr_true[k0].T, u, v)
+            depth = rng.uniform(5.0, 7.0, nb)
+            p_C = depth[:, None] * np.stack([xn, yn, np.ones(nb)], axis=1)
+            p_G = np.einsum("bji,bj->bi", Rg[j], np.einsum("bji,bj->bi", R_ItoC[k0], p_C - p_IinC[k0])) + pg[j]
+            frames = np.arange(lo, b + 1)
+            p_I = np.einsum("fij,bfj->bfi", Rg[frames], p_G[:, None, :] - pg[frames][None, :, :])        # [nb, nf, 3]
+            noise = rng.normal(0, sigma_px, (nb, K, len(frames), 2))
+            per_feat = [[] for _ in range(nb)]
+            for k in range(K):
+                pc = np.einsum("ij,bfj->bfi", R_ItoC[k], p_I) + p_IinC[k]
+                z = pc[..., 2]
+                ok = (z >= 0.1) & (z <= 7.0) & (frames[None, :] >= a[:, None])
+                zs = np.where(ok, z, 1.0)
+                xf = (pc[..., 0] / zs).astype(np.float32).astype(np.float64)
+                yf = (pc[..., 1] / zs).astype(np.float32).astype(np.float64)
+                ud, vd = synth.radtan_distort(self.intr_true[k], xf, yf)
+                ok &= (ud >= 0) & (ud <= synth.IMG_W) & (vd >= 0) & (vd <= synth.IMG_H)
+                un, vn = (ud + noise[:, k, :, 0]).astype(np.float32), (vd + noise[:, k, :, 1]).astype(np.float32)
+                xu, yu = synth.radtan_undistort(self.intr_true[k], un.astype(np.float64), vn.astype(np.float64))
+                xu, yu = xu.astype(np.float32), yu.astype(np.float32)
+                for bi, fi in zip(*np.nonzero(ok)):
+                    per_feat[bi].append((int(frames[fi]), un[bi, fi], vn[bi, fi], xu[bi, fi], yu[bi, fi], k))
+            for obs in per_feat:
+                if len(obs) >= 5 and made < feats_per_frame:
+                    self.tracks[t_use].append(sorted(obs, key=lambda o: (o[0], o[5])))
+                    made += 1
+
+
+Stream._init_rig = _stream_init_rig
+
+
 def _analytic_trajectory(T, dt=0.1):
     """A long smooth trajectory for closed loops beyond the 64-pose fixture: ~1 m/s on a 4 m circle with a vertical wobble, yawing
     with the motion, roll / pitch of a few degrees.  Rows [q_GtoI (JPL), p_IinG] like the fixture."""
@@ -106,37 +171,51 @@ def _compose(last_est, truth_last, truth_new):
 
 
 def _frame_problem(stream, tracks, frames, N, P, clones, fej, calib, intr):
-    """The snapshot handed to the updater at one frame: state + the tracks that ended at the previous frame."""
-    C, K = stream.C, 1
+    """The snapshot handed to the updater at one frame: state + the tracks that ended at the previous frame.  Camera groups of a
+    track in the reference's iteration order of Feature::timestamps (reverse first insertion: normally descending camera id,
+    SURVEY Q13), time order inside a group."""
+    C, K = stream.C, stream.K
     base = 16 + 14 * K
     idx = {f: i for i, f in enumerate(frames)}
-    offs, uv, uvn, ci = [0], [], [], []
-    for obs in tracks:
-        obs = [o for o in obs if o[0] in idx]
-        for (f, un, vn, xu, yu) in obs:
-            uv += [un, vn]
-            uvn += [xu, yu]
-            ci.append(idx[f])
+    offs, uv, uvn, ci, cam = [0], [], [], [], []
+    for obs_all in tracks:
+        # Feature::timestamps is an unordered_map keyed by camera: libstdc++ iterates it in REVERSE order of first insertion, and the
+        # front end delivers a frame camera 0 first (keys of cameras whose observations all left the window stay in the map)
+        first_seen = list(dict.fromkeys((o[5] if len(o) > 5 else 0) for o in sorted(obs_all, key=lambda o: (o[0], o[5] if len(o) > 5 else 0))))
+        obs = [o for o in obs_all if o[0] in idx]
+        for k in reversed(first_seen):
+            for o in obs:
+                if (o[5] if len(o) > 5 else 0) != k:
+                    continue
+                uv += [o[1], o[2]]
+                uvn += [o[3], o[4]]
+                ci.append(idx[o[0]])
+                cam.append(k)
         offs.append(len(ci))
+    calib_true = stream.calib_true if K > 1 else stream.calib_true[None, :]
     return synth.Problem(
         cfg=1, seed=0, N=N, C=C, K=K, P=np.ascontiguousarray(P), clone_q_p=np.ascontiguousarray(clones),
         clone_q_p_fej=np.ascontiguousarray(fej), clone_q_p_true=stream.truth[frames], clone_cov_id=(base + 6 * np.arange(C)).astype(np.int32),
-        calib_q_p=np.ascontiguousarray(calib), calib_q_p_true=stream.calib_true[None, :], intrinsics=np.ascontiguousarray(intr),
-        cam_is_fisheye=np.zeros(K, np.uint8), calib_cov_id=np.array([16], np.int32), intr_cov_id=np.array([22], np.int32),
+        calib_q_p=np.ascontiguousarray(calib), calib_q_p_true=calib_true, intrinsics=np.ascontiguousarray(intr),
+        cam_is_fisheye=np.zeros(K, np.uint8), calib_cov_id=(16 + 14 * np.arange(K)).astype(np.int32), intr_cov_id=(22 + 14 * np.arange(K)).astype(np.int32),
         meas_offsets=np.asarray(offs, np.int32), uv=np.asarray(uv, np.float32), uvn=np.asarray(uvn, np.float32),
-        clone_idx=np.asarray(ci, np.int32), cam_idx=np.zeros(len(ci), np.int32), p_FinG_true=np.zeros((len(tracks), 3)))
+        clone_idx=np.asarray(ci, np.int32), cam_idx=np.asarray(cam, np.int32), p_FinG_true=np.zeros((len(tracks), 3)))
 
 
 def _initial_state(stream):
-    C, K = stream.C, 1
+    C, K = stream.C, stream.K
     base = 16 + 14 * K
     sig = synth.state_sigmas(C, K)
     sig[base:] = np.tile([0.01] * 3 + [0.03] * 3, C)
     N = base + 6 * C
     P = np.diag(sig ** 2)
     clones = np.stack([synth.boxplus_pose(stream.truth[i], stream.init_noise[i]) for i in range(C)])
-    calib = synth.boxplus_pose(stream.calib_true, stream.calib_noise)[None, :]
-    intr = (stream.intr_true + stream.intr_noise)[None, :]
+    if K > 1:
+        calib = np.stack([synth.boxplus_pose(stream.calib_true[k], stream.calib_noise[k]) for k in range(K)])
+        intr = stream.intr_true + stream.intr_noise
+    else:
+        calib = synth.boxplus_pose(stream.calib_true, stream.calib_noise)[None, :]
+        intr = (stream.intr_true + stream.intr_noise)[None, :]
     return base, N, P, clones, calib, intr
 
 
@@ -157,22 +236,23 @@ def run_resident(stream: Stream, up, track_store=False):
     by_frame, ids_at = {}, {}
     if track_store:
         n_tracks = sum(len(v) for v in stream.tracks.values())
-        up.tracks_create(n_tracks + 8, C + 4)
+        up.tracks_create(n_tracks + 8, stream.K * C + 4)
         fid = 0
         for t in sorted(stream.tracks):  # ids in the order the host loop meets the tracks
             if t < C:
                 continue                  # tracks that end before the first update frame are never used by run() either
             for obs in stream.tracks[t]:
-                for (f, un, vn, xu, yu) in obs:
-                    by_frame.setdefault(f, []).append((fid, un, vn, xu, yu))
+                for o in obs:
+                    by_frame.setdefault(o[0], []).append((fid, o[1], o[2], o[3], o[4], o[5] if len(o) > 5 else 0))
                 ids_at.setdefault(t, []).append(fid)
                 fid += 1
 
-        def feed(f):  # the front end's delivery of frame f (one camera)
-            o = by_frame.get(f, [])
-            if o:
-                up.tracks_append(time_of(f), [x[0] for x in o], np.zeros(len(o), np.int32), np.array([[x[1], x[2]] for x in o], np.float32),
-                                 np.array([[x[3], x[4]] for x in o], np.float32))
+        def feed(f):  # the front end's delivery of frame f: camera by camera, camera 0 first
+            for k in range(stream.K):
+                o = [x for x in by_frame.get(f, []) if x[5] == k]
+                if o:
+                    up.tracks_append(time_of(f), [x[0] for x in o], np.full(len(o), k, np.int32), np.array([[x[1], x[2]] for x in o], np.float32),
+                                     np.array([[x[3], x[4]] for x in o], np.float32))
         for f in range(C):
             feed(f)
     for t in range(C, stream.T):
@@ -214,17 +294,10 @@ def run_resident(stream: Stream, up, track_store=False):
 def run(stream: Stream, update_fn=None):
     """Runs the sliding-window filter over the stream.  update_fn(prob) -> dict(P, clone_q_p, calib_q_p, intrinsics,
     feat_status); None = no updates (dead reckoning).  Returns per-frame estimates of the newest clone and the truth."""
-    C, K = stream.C, 1
-    base = 16 + 14 * K
-    sig = synth.state_sigmas(C, K)
-    sig[base:] = np.tile([0.01] * 3 + [0.03] * 3, C)
-    N = base + 6 * C
-    P = np.diag(sig ** 2)
+    C = stream.C
+    base, N, P, clones, calib, intr = _initial_state(stream)
     frames = list(range(C))
-    clones = np.stack([synth.boxplus_pose(stream.truth[i], stream.init_noise[i]) for i in range(C)])
     fej = clones.copy()
-    calib = synth.boxplus_pose(stream.calib_true, stream.calib_noise)[None, :]
-    intr = (stream.intr_true + stream.intr_noise)[None, :]
     est, used = {frames[-1]: clones[-1].copy()}, {}
     for t in range(C, stream.T):
         # ---- clone the new pose (window grows to C + 1) ... then drop the oldest so that the update sees C clones

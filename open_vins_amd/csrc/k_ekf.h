@@ -582,4 +582,37 @@ __global__ void k_boxplus(int C, int K, const double *__restrict__ dx, const int
   boxplus_item(blockIdx.x * blockDim.x + threadIdx.x, C, K, dx, clone_cov, calib_cov, intr_cov, clone_qp, calib_qp, intr);
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// X = R L^-1 for the compressed factor of the WHITENED stack (mode A through the Gram route): the rows left the per-feature stage as
+// [H L | r] with P_DD = L L^T, R is the Cholesky factor of their Gram matrix (k_gram_chol: R^T R = L^T H^T H L), so X^T X = H^T H and
+// (X, c) is a compressed system of the reference's form for the stock StateHelper::EKFUpdate (X dense instead of triangular: nothing
+// in EKFUpdate asks for a triangle).  One workgroup per 16 rows, 16 lanes per row: column j from the right,
+//        x_j = (r_j - sum_{k > j} x_k L[k][j]) / L[j][j],      L[k][j] = U1[j][k] read along a row of Y1 = [U1 | ..] (coalesced).
+// In place on the first D columns of R [D x LD]; the residual column stays.
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_unwhiten(int D, int LD, double *__restrict__ R, const double *__restrict__ Y1, int LA, const int32_t *pred) {
+  __shared__ double X[16][257];
+  if (pred && *pred == 0) return;
+  const int tid = threadIdx.x, r = tid >> 4, l = tid & 15;
+  const int row = blockIdx.x * 16 + r;
+  for (int c = l; c < D; c += 16) X[r][c] = row < D ? R[(size_t)row * LD + c] : 0.0;
+  auto wsync = [] {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+  wsync();
+  for (int j = D - 1; j >= 0; j--) {
+    const double *u = Y1 + (size_t)j * LA;
+    double s = 0.0;
+    for (int k = j + 1 + l; k < D; k += 16) s = fma(X[r][k], u[k], s);
+    s += __shfl_xor(s, 8, 16), s += __shfl_xor(s, 4, 16), s += __shfl_xor(s, 2, 16), s += __shfl_xor(s, 1, 16);
+    if (l == 0) X[r][j] = (X[r][j] - s) / u[j];
+    wsync();
+  }
+  if (row < D)
+    for (int c = l; c < D; c += 16) R[(size_t)row * LD + c] = X[r][c];
+}
+
 } // namespace ovg

@@ -138,6 +138,16 @@ def ekf_update(P, H, res, col_cov_id, sigma2):
     return st, P, dx
 
 
+def apply_dx(opts, views, dx):
+    """Box-plus of the clone / calibration tables with dx (oracle_apply_dx: JPLQuat.h:114-125, PoseJPL.h:74-91, Vec.h:55-58)."""
+    lib = load()
+    Cn, K = views.state.C, views.state.K
+    out = dict(clone_q_p=np.zeros((Cn, 7)), calib_q_p=np.zeros((K, 7)), intrinsics=np.zeros((K, 8)))
+    dx = np.ascontiguousarray(dx, dtype=np.float64)
+    lib.oracle_apply_dx(C.byref(opts), C.byref(views.state), _p(dx), _p(out["clone_q_p"]), _p(out["calib_q_p"]), _p(out["intrinsics"]))
+    return out
+
+
 def msckf_update(opts, views, want_compressed=False, given=None):
     """Runs the complete reference-order update on the CPU; returns a dict of outputs.
 

@@ -111,3 +111,94 @@ def test_long_loop_with_imu_level_process_noise():
     assert np.abs(gpu["est"] - ref["est"]).max() < 1e-4            # after a differing gate decision: same filter, one measurement apart
     a_g, a_o = closed_loop.ate(gpu), closed_loop.ate(ref)
     assert abs(a_g[0] - a_o[0]) < 1e-4 and abs(a_g[1] - a_o[1]) < 1e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("route", ["default", "cholqr"])
+def test_mode_a_closed_loop(stream, oracle_run, route):
+    """Mode A as the shim ships it: ovgpu_msckf_compress hands (H, r) to the STOCK EKFUpdate — here the oracle's restatement of
+    StateHelper::EKFUpdate and of the box-plus — 52 frames with the posterior fed back.
+    default = the Householder TSQR's triangle: the oracle-driven trajectory to round-off.
+    cholqr  = the Cholesky factor of the whitened stack's Gram matrix, un-whitened (Gram-route cost, 2.3 x faster host to host).
+    VERDICT round 2 asked whether that can replace the QR: it cannot.  The whitened Gram matrix is numerically singular (gauge
+    directions, weakly observed calibration), the factor reproduces H^T r to eps cond(Y)^2 instead of eps cond(Y) (one step: dx off
+    by up to 6e-9 at cond(P_DD) = 5e5), and the closed loop drifts 1e-5 — the same defect round 1 measured for the Cholesky factor of
+    the RAW Gram matrix (6e-6).  The test keeps the number honest: it FAILS if the drift ever disappears (then the default may change)."""
+    from open_vins_amd.updater import UpdaterMSCKF
+    opts = capi.default_options(compress_route=capi.COMPRESS_CHOLQR if route == "cholqr" else capi.COMPRESS_GRAM, **OPTS)
+    up = UpdaterMSCKF(opts)
+    routes = []
+
+    def mode_a_update(prob):
+        up.set_problem(prob)
+        cmp = up.compress()
+        routes.append(up.lib.ovgpu_last_update_route(up._ctx))
+        v = capi.Views(prob)
+        st, P1, dx = pyoracle.ekf_update(prob.P, cmp["H"], cmp["r"], cmp["col_cov_id"], opts.sigma_pix ** 2)
+        assert st == 0
+        out = pyoracle.apply_dx(opts, v, dx)
+        out.update(P=P1, feat_status=cmp["feat_status"])
+        return out
+
+    res = closed_loop.run(stream, mode_a_update)
+    up.close()
+    assert all(r == (capi.COMPRESS_CHOLQR if route == "cholqr" else capi.COMPRESS_TSQR) for r in routes)
+    assert res["used"] == oracle_run["used"]
+    dev = np.abs(res["est"] - oracle_run["est"]).max()
+    print(f"mode A ({route}), 52 frames: max deviation from the oracle-driven loop {dev:.1e}")
+    if route == "default":
+        assert dev < 1e-9
+    else:
+        assert 1e-8 < dev < 1e-3
+
+
+@pytest.mark.gpu
+def test_headline_closed_loop_stereo_30_clone_window():
+    """north_star's 'ATE parity on rpng_sim' at the HEADLINE shape: stereo rig, 30 clones + the new one, 800 MSCKF features per
+    frame (BASELINE configs[1]), 33 consecutive frames with the posterior fed back (the loop of VioManager.cpp:518-526; ATE as
+    ov_eval/src/calc/ResultTrajectory.cpp:82-110).
+
+    (1) Step by step ALONG the oracle-driven loop: every frame's prior goes through the GPU as well (fused per-feature kernel, Gram
+        route, single-launch Cholesky) — identical accept sets in all 33 frames (26 400 gate decisions), posterior poses within 1e-9.
+    (2) Free running, covariance AND feature tracks resident on the device (window bookkeeping, track store): the trajectory is the
+        oracle-driven one up to what the loop itself amplifies.  At 800 features x ~29 observations per frame the reference's
+        float32 residual path (FeatureInitializer.cpp:273-281) quantises half a million values per frame; a 1e-14 difference between
+        two float64 implementations flips a few of those roundings, each flip moves a feature by ~1e-8 m, and the filter feeds that
+        back: two CORRECT implementations drift apart by ~1e-7 within four frames and meet a differing gate decision after ~10
+        (measured; the 50-feature mono loop above stays at 1e-13).  So: ATE parity to 1e-4 m / 1e-2 deg, accept counts within 3."""
+    from open_vins_amd.updater import UpdaterMSCKF
+    stream = closed_loop.Stream(C=31, feats_per_frame=800, seed=3, K=2)
+    opts = capi.default_options(**OPTS)
+    up = UpdaterMSCKF(opts)
+    worst = dict(pose=0.0, P=0.0, dx=0.0)
+
+    def oracle_and_gpu(prob):
+        ref = pyoracle.msckf_update(opts, capi.Views(prob))
+        up.set_problem(prob)
+        out = up.update()
+        assert out["route"] == capi.COMPRESS_GRAM
+        assert np.array_equal(out["feat_status"], ref["feat_status"])
+        worst["pose"] = max(worst["pose"], np.abs(out["clone_q_p"] - ref["clone_q_p"]).max())
+        worst["P"] = max(worst["P"], np.linalg.norm(out["P"] - ref["P"]) / np.linalg.norm(ref["P"]))
+        worst["dx"] = max(worst["dx"], np.linalg.norm(out["dx"] - ref["dx"]) / np.linalg.norm(ref["dx"]))
+        return ref
+
+    ref = closed_loop.run(stream, oracle_and_gpu)
+    up.close()
+    assert len(ref["used"]) == stream.T - stream.C >= 30 and min(ref["used"].values()) > 600
+    assert worst["pose"] < 1e-9 and worst["P"] < 1e-9 and worst["dx"] < 1e-8, worst
+    up = UpdaterMSCKF(opts)
+    res = closed_loop.run_resident(stream, up, track_store=True)
+    up.close()
+    frames = sorted(ref["used"])
+    first_diff = next((i for i, t in enumerate(frames) if res["used"][t] != ref["used"][t]), len(frames))
+    dev = np.abs(res["est"] - ref["est"]).max(axis=1)
+    a_g, a_o, a_d = closed_loop.ate(res), closed_loop.ate(ref), closed_loop.ate(closed_loop.run(stream, None))
+    print(f"headline closed loop: step-by-step worst pose {worst['pose']:.1e}, P {worst['P']:.1e}, dx {worst['dx']:.1e}; free running: first differing "
+          f"accept set at frame {first_diff} of {len(frames)}, deviation {dev[:4].max():.1e} (4 frames) / {dev.max():.1e} (all); ATE GPU {a_g[0]:.4f} deg / "
+          f"{a_g[1]:.5f} m, oracle {a_o[0]:.4f} deg / {a_o[1]:.5f} m, dead reckoning {a_d[0]:.4f} deg / {a_d[1]:.5f} m")
+    assert first_diff >= 3 and dev[:3].max() < 1e-6
+    assert max(abs(res["used"][t] - ref["used"][t]) for t in frames) <= 3
+    assert dev.max() < 1e-3
+    assert abs(a_g[0] - a_o[0]) < 1e-2 and abs(a_g[1] - a_o[1]) < 1e-4
+    assert a_o[0] < 0.6 * a_d[0]
