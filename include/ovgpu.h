@@ -311,7 +311,8 @@ int ovgpu_set_triangulation(ovgpu_ctx *ctx, const double *p_FinA, const double *
  * successive updater calls do (VioManager.cpp:525-547).
  * The device does not factor the stack on this call: it accumulates [H | r]^T [H | r] on the matrix cores
  * and applies the update in coordinates whitened by the prior (same dx, P' as compress -> EKFUpdate;
- * DESIGN.md section 4).  Environment OVGPU_COMPRESS=tsqr keeps the reference's order.     */
+ * DESIGN.md section 4).  ovgpu_options::compress_route = OVGPU_COMPRESS_TSQR keeps the reference's order
+ * (nothing in the library reads the environment).                                           */
 int ovgpu_msckf_update(ovgpu_ctx *ctx, int32_t *feat_status, double *chi2,
                        double *chi2_thresh, double *p_FinG, double *dx,
                        double *P_out, ovgpu_update_stats *stats);

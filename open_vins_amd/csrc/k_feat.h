@@ -18,10 +18,10 @@
 //    and U_kk^-1 comes out of the diagonal tile's factorisation for free: 16 extra lanes carry the identity through the same
 //    instruction stream (row k scaled, rows below updated with the broadcast multipliers), which turns it into U_kk^-T.
 //    LDS per workgroup drops from 117 KB to ~60 KB (two workgroups per CU at 30 clones x 2 cameras).
-//  * T = H P (for the gate) and the whitened, projected rows Q^T [H L | r] (for the Gram accumulation) are produced in ONE sweep
-//    over the measurements, thread per column; the projected rows leave the kernel while the gate is still being evaluated and
-//    are zeroed afterwards in the rare case that the feature is rejected.  V^T (H L) = (V^T H) L is formed before the sweep from
-//    a sparse gather (a (camera, clone) -> measurement table replaces the scan over all rows).
+//  * T = H P is swept chunk by chunk INSIDE this kernel (thread per column, two columns per lane); the whitened, projected rows
+//    Q^T [H L | r] for the Gram accumulation are a SECOND sweep in k_feat_out (round 2 moved them out: the gate needs only P, so the
+//    prior block's factorisation and k_feat_qr / k_feat_z run beside it on the second stream).  Round 3's k_featy.h replaces both
+//    sweeps by one on the matrix cores; these kernels remain as the legacy form (ovgpu_debug_option "legacy_feature_kernel").
 //  * The Jacobian rows come from a thread-per-measurement pre-kernel (k_feat_rows) and the reflectors of H_f with z = T^T V^T [H L | r]
 //    from a wavefront-per-feature pre-kernel (k_feat_qr): both are tiny, but inlined into the per-feature kernel they cost it a
 //    third of its time (60 busy threads of 256, sin / cos / sqrt code, dependent L2 round trips of the dense product with L).

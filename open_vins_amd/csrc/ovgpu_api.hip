@@ -92,6 +92,7 @@ struct EventPair {
 
 enum { CTRL_FLAGS = 1, CTRL_ROWS = 2, CTRL_COUNTER = 4, CTRL_PROG0 = 8, CTRL_PROG1 = 16, CTRL_INTS = 64 };
 
+struct LoopComm;
 struct ovgpu_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -215,6 +216,7 @@ struct ovgpu_ctx {
   DevBuf<int32_t> feat_counter, fs_minfo, fs_meas_feat; // fs_*: the row store of the fast path (feat::FeatStore)
   DevBuf<double> fs_rows, fs_V, fs_z, fs_w;
   void *comm = nullptr;        // ncclComm_t of this rank (ovgpu_comm_init_rank / ovgpu_multi_create)
+  struct LoopComm *loop = nullptr; // several ranks on ONE device (ovgpu_multi_create with a repeated device): the collective is emulated
   int comm_rank = 0, comm_world = 1;
   DevBuf<double> comm_buf;     // gathered triangles of the Householder exchange
   DevBuf<int32_t> chol_prog;   // [2][16] per-step flags of the single-launch Cholesky (k_chol.h), one set per factorisation in flight
@@ -432,7 +434,7 @@ int ovgpu_create(const ovgpu_options *opts, int device, ovgpu_ctx **out) {
   // allow the large dynamic LDS carve of the per-feature kernel
   // library switches are options of the context, not of the environment (include/ovgpu.h)
   if (opts->compress_route < 0 || opts->compress_route > OVGPU_COMPRESS_CHOLQR || opts->tsqr_overlap < 0 || opts->tsqr_overlap > 2 || opts->tsqr_workers < 0) {
-    delete c;
+    ovgpu_destroy(c); // (the stream and the control block exist already: a bare delete would leak them)
     return set_err(OVGPU_ERR_INVALID, "bad library switch in ovgpu_options");
   }
   c->tree_pipelined = opts->tsqr_no_pipeline == 0;
@@ -3053,6 +3055,65 @@ int nccl_err(int rc, const char *what) {
 }
 } // namespace
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Loop-back collective: G ranks that share ONE device (ovgpu_multi_create with a repeated device id).  RCCL refuses such a
+// communicator, and this machine pool leases one GPU at a time — so without it the G > 1 branches of the sharded update (the
+// empty shard's zero contribution, the triangle all-gather + merge tree of the Householder protocol, the Gram all-reduce feeding
+// G identical updates) would never execute on hardware before the first multi-GPU run.  Semantics of the real thing: every rank
+// marks its buffer ready on its own stream; when all have, the sum (rank order: bit-identical on every rank) / the concatenation is
+// delivered to every rank's stream.  A test double of the TRANSPORT only: everything before and after it is the production path.
+// ---------------------------------------------------------------------------------------------------------------------
+struct LoopComm {
+  int G = 0;
+  std::vector<ovgpu_ctx *> ranks;
+  std::vector<hipEvent_t> ready;
+  hipEvent_t done = nullptr;
+  DevBuf<double> sum;
+};
+struct LoopPtrs {
+  const double *p[8];
+};
+__global__ void k_loop_sum(int64_t n, int G, LoopPtrs in, double *out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double s = in.p[0][i];
+  for (int g = 1; g < G; g++) s += in.p[g][i];
+  out[i] = s;
+}
+// called once per exchange, after every rank has been through sharded_exchange (its buffer is final on its stream)
+static int loop_finish(LoopComm *L, bool gram) {
+  const int G = L->G;
+  for (int g = 0; g < G; g++) HIPCHK(hipEventRecord(L->ready[g], L->ranks[g]->stream));
+  ovgpu_ctx *c0 = L->ranks[0];
+  if (gram) {
+    const size_t n = (size_t)256 * ((c0->LD + 15) / 16) * ((c0->LD + 15) / 16);
+    HIPCHK(L->sum.reserve(n));
+    LoopPtrs in;
+    for (int g = 0; g < 8; g++) in.p[g] = L->ranks[g < G ? g : 0]->gram_G.p;
+    for (int g = 0; g < G; g++) HIPCHK(hipStreamWaitEvent(c0->stream, L->ready[g], 0));
+    hipLaunchKernelGGL(k_loop_sum, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c0->stream, (int64_t)n, G, in, L->sum.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(L->done, c0->stream));
+    for (int g = 0; g < G; g++) {
+      HIPCHK(hipStreamWaitEvent(L->ranks[g]->stream, L->done, 0));
+      HIPCHK(hipMemcpyAsync(L->ranks[g]->gram_G.p, L->sum.p, sizeof(double) * n, hipMemcpyDeviceToDevice, L->ranks[g]->stream));
+    }
+    return OVGPU_OK;
+  }
+  const size_t tri = (size_t)c0->D * c0->LD;
+  for (int g = 0; g < G; g++) {
+    ovgpu_ctx *c = L->ranks[g];
+    for (int h = 0; h < G; h++) HIPCHK(hipStreamWaitEvent(c->stream, L->ready[h], 0));
+    for (int h = 0; h < G; h++)
+      HIPCHK(hipMemcpyAsync(c->comm_buf.p + (size_t)h * tri, L->ranks[h]->Rws.p, sizeof(double) * tri, hipMemcpyDeviceToDevice, c->stream));
+  }
+  // nobody may overwrite its triangle (the merge tree works in Rws) before every rank has copied it
+  for (int g = 0; g < G; g++) HIPCHK(hipEventRecord(L->ready[g], L->ranks[g]->stream));
+  for (int g = 0; g < G; g++)
+    for (int h = 0; h < G; h++) HIPCHK(hipStreamWaitEvent(L->ranks[g]->stream, L->ready[h], 0));
+  return OVGPU_OK;
+}
+
 // the local stage of a sharded update up to (not including) the exchange; gram: which protocol this state uses
 static int sharded_local(ovgpu_ctx *c, bool &gram) {
   gram = c->compress_gram == 1 && (c->LD + 15) / 16 <= gram::GR_NT_BLK && !c->force_tsqr;
@@ -3072,6 +3133,7 @@ static int sharded_exchange(ovgpu_ctx *c, bool gram) {
   if (gram) {
     const size_t n = (size_t)256 * ((c->LD + 15) / 16) * ((c->LD + 15) / 16);
     if (c->F == 0) HIPCHK(hipMemsetAsync(c->gram_G.p, 0, sizeof(double) * n, c->stream)); // an empty shard contributes nothing
+    if (c->loop) return OVGPU_OK; // (loop_finish delivers the sum once every rank is here)
     if (G > 1) {
       const int rc = r.AllReduce(c->gram_G.p, c->gram_G.p, n, NCCL_DOUBLE, NCCL_SUM, c->comm, c->stream);
       if (rc != 0) return nccl_err(rc, "ncclAllReduce");
@@ -3084,6 +3146,7 @@ static int sharded_exchange(ovgpu_ctx *c, bool gram) {
     HIPCHK(c->Rws.reserve(tri));
     HIPCHK(hipMemsetAsync(c->Rws.p, 0, sizeof(double) * tri, c->stream));
   }
+  if (c->loop) return OVGPU_OK;
   if (G > 1) {
     const int rc = r.AllGather(c->Rws.p, c->comm_buf.p, tri, NCCL_DOUBLE, c->comm, c->stream);
     if (rc != 0) return nccl_err(rc, "ncclAllGather");
@@ -3139,6 +3202,7 @@ int ovgpu_comm_destroy(ovgpu_ctx *c) {
 
 int ovgpu_msckf_update_sharded_async(ovgpu_ctx *c) {
   if (!c) return set_err(OVGPU_ERR_INVALID, "null ctx");
+  if (c->loop) return set_err(OVGPU_ERR_INVALID, "ranks that share a device are driven through ovgpu_multi_msckf_update");
   if (c->comm_world > 1 && !c->comm) return set_err(OVGPU_ERR_NO_STATE, "ovgpu_comm_init_rank was never called");
   bool gram = false;
   int rc = sharded_local(c, gram);
@@ -3171,6 +3235,7 @@ int ovgpu_msckf_update_sharded(ovgpu_ctx *c, int32_t *feat_status, double *chi2,
 // ---------------------------------------------------------------------------------------------------------------------
 struct ovgpu_multi {
   std::vector<ovgpu_ctx *> ctx;
+  LoopComm *loop = nullptr; // a device appears more than once: loop-back collective instead of RCCL
   std::vector<std::vector<int32_t>> feat_of; // per device: global feature index of each local feature
   int F = 0;
 };
@@ -3181,10 +3246,14 @@ int ovgpu_multi_create(const ovgpu_options *opts, int n, const int *devices, ovg
   if (!opts || !out || n < 1) return set_err(OVGPU_ERR_INVALID, "bad argument");
   *out = nullptr;
   Rccl &r = rccl();
-  if (n > 1 && !r.ok) return set_err(OVGPU_ERR_HIP, "RCCL (librccl.so.1) is not available in this process");
-  ovgpu_multi *m = new ovgpu_multi();
   std::vector<int> devs(n);
   for (int i = 0; i < n; i++) devs[i] = devices ? devices[i] : i;
+  bool repeated = false;
+  for (int i = 0; i < n; i++)
+    for (int j = 0; j < i; j++) repeated = repeated || devs[i] == devs[j];
+  if (repeated && n > 8) return set_err(OVGPU_ERR_CAPACITY, "at most 8 ranks on one device");
+  if (n > 1 && !repeated && !r.ok) return set_err(OVGPU_ERR_HIP, "RCCL (librccl.so.1) is not available in this process");
+  ovgpu_multi *m = new ovgpu_multi();
   for (int i = 0; i < n; i++) {
     ovgpu_ctx *c = nullptr;
     const int rc = ovgpu_create(opts, devs[i], &c);
@@ -3195,7 +3264,20 @@ int ovgpu_multi_create(const ovgpu_options *opts, int n, const int *devices, ovg
     }
     m->ctx.push_back(c);
   }
-  if (n > 1) {
+  if (n > 1 && repeated) { // several ranks on one device: the loop-back collective (see LoopComm)
+    LoopComm *L = new LoopComm();
+    L->G = n, L->ranks = m->ctx, L->ready.resize(n, nullptr);
+    bool ok = hipEventCreateWithFlags(&L->done, hipEventDisableTiming) == hipSuccess;
+    for (int i = 0; i < n; i++) ok = ok && hipEventCreateWithFlags(&L->ready[i], hipEventDisableTiming) == hipSuccess;
+    if (!ok) {
+      for (auto *x : m->ctx) ovgpu_destroy(x);
+      delete L;
+      delete m;
+      return set_err(OVGPU_ERR_HIP, "event creation failed");
+    }
+    m->loop = L;
+    for (int i = 0; i < n; i++) m->ctx[i]->loop = L, m->ctx[i]->comm_rank = i, m->ctx[i]->comm_world = n;
+  } else if (n > 1) {
     std::vector<void *> comms(n, nullptr);
     const int rc = r.CommInitAll(comms.data(), n, devs.data());
     if (rc != 0) {
@@ -3214,7 +3296,14 @@ void ovgpu_multi_destroy(ovgpu_multi *m) {
   if (!m) return;
   for (auto *c : m->ctx) {
     (void)ovgpu_comm_destroy(c);
+    c->loop = nullptr;
     ovgpu_destroy(c);
+  }
+  if (m->loop) {
+    for (auto e : m->loop->ready)
+      if (e) (void)hipEventDestroy(e);
+    if (m->loop->done) (void)hipEventDestroy(m->loop->done);
+    delete m->loop;
   }
   delete m;
 }
@@ -3278,15 +3367,17 @@ int ovgpu_multi_msckf_update(ovgpu_multi *m, int32_t *feat_status, double *chi2,
     if ((rc = sharded_local(m->ctx[g], gr)) != OVGPU_OK) return rc;
     gram[g] = gr;
   }
-  if (G > 1) (void)r.GroupStart();
+  const bool rccl_group = G > 1 && !m->loop;
+  if (rccl_group) (void)r.GroupStart();
   for (int g = 0; g < G; g++) {
     HIPCHK(hipSetDevice(m->ctx[g]->device));
     if ((rc = sharded_exchange(m->ctx[g], gram[g])) != OVGPU_OK) break;
   }
-  if (G > 1) {
+  if (rccl_group) {
     const int rg = r.GroupEnd();
     if (rc == OVGPU_OK && rg != 0) rc = nccl_err(rg, "ncclGroupEnd");
   }
+  if (rc == OVGPU_OK && m->loop) rc = loop_finish(m->loop, gram[0] != 0);
   if (rc != OVGPU_OK) return rc;
   for (int g = 0; g < G; g++) {
     HIPCHK(hipSetDevice(m->ctx[g]->device));

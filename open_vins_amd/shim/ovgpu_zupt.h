@@ -1,12 +1,17 @@
 // ovgpu_zupt.h — the linear algebra of ov_msckf::UpdaterZeroVelocity::try_update (ov_msckf/src/update/UpdaterZeroVelocity.cpp,
 // rpng/open_vins v2.7) on the device, for a mode-B build (ovgpu_state_access.h): the function keeps selecting IMU readings,
-// filling H / res (:100-181) and taking its disparity / velocity decision (:210-247); the four calls in between are replaced:
+// filling H / res (:100-181), compressing them (:183 — see below) and taking its disparity / velocity decision (:210-247); the
+// calls on the covariance are replaced:
 //
-//   :183  UpdaterHelper::measurement_compress_inplace(H, res)        ->  ovgpu_shim::zupt_compress_and_chi2(...)
-//   :193-198  get_marginal_covariance + Q_bias, S, chi2                   (same call; returns chi2, H / res come back compressed)
+//   :183  UpdaterHelper::measurement_compress_inplace(H, res)            STAYS the reference's own call
+//   :193-198  get_marginal_covariance + Q_bias, S, chi2               ->  ovgpu_shim::zupt_chi2(...)
 //   :268-274  StateHelper::EKFPropagation(state, Phi_order, ...)      ->  ovgpu_shim::zupt_apply(...)
 //   :277  StateHelper::EKFUpdate(state, Hx_order, H, res, R)              (same call)
 //
+// Why the compression stays on the host: the stacked ZUPT Jacobian has rank 6 (every IMU sample contributes the same 6 x 9 block),
+// so three rows of the 9 x 9 compressed system depend on the ELIMINATION ORDER; the chi2 of :198 sums their squares.  The reference's
+// Givens sweep on a 9-column system costs microseconds; running it keeps the accept / reject decision of :241 bit-compatible, which
+// the device's Householder compression (round 2) did not.
 // INTEGRATION.md shows the patch.  No Eigen decomposition is used here: the 9 x 9 (or 12 x 12) chi2 solve is a plain Cholesky.
 #pragma once
 #include "ovgpu_shim_common.h"
@@ -14,44 +19,35 @@
 
 namespace ovgpu_shim {
 
-struct ZuptPending { // what zupt_apply needs from zupt_compress_and_chi2 of the same call
+struct ZuptPending { // what zupt_apply needs from zupt_chi2 of the same call
   Context *ctx = nullptr;
   std::vector<int32_t> cols;    // covariance index of every column of H
   std::vector<double> H, r;     // compressed system, row-major rows x cols
   int rows = 0, N = 0;
 };
 
-// H [m x h] over the variables of Hx_order, res [m]; Q_bias: 6 x 6 added to the (bg, ba) block of the marginal covariance when
-// model_time_varying_bias (variables 1 and 2 of Hx_order).  On return H, res hold the compressed system (as after :183) and the
-// result is res^T (H P_marg H^T + noise_multiplier I)^-1 res (:197-198).
+// H [rows x h] over the variables of Hx_order, res [rows]: the system AFTER the reference's measurement_compress_inplace (:183);
+// Q_bias: 6 x 6 added to the (bg, ba) block of the marginal covariance when model_time_varying_bias (variables 1 and 2 of
+// Hx_order).  Returns res^T (H P_marg H^T + noise_multiplier I)^-1 res (:197-198) with P_marg read from the device-resident state.
 template <class UpdaterOptionsT>
-inline double zupt_compress_and_chi2(const std::shared_ptr<ov_msckf::State> &state, const std::vector<std::shared_ptr<ov_type::Type>> &Hx_order,
-                                     Eigen::MatrixXd &H, Eigen::VectorXd &res, const Eigen::MatrixXd &Q_bias, bool model_time_varying_bias,
-                                     double noise_multiplier, const UpdaterOptionsT &options, ZuptPending &pend) {
+inline double zupt_chi2(const std::shared_ptr<ov_msckf::State> &state, const std::vector<std::shared_ptr<ov_type::Type>> &Hx_order,
+                        const Eigen::MatrixXd &H, const Eigen::VectorXd &res, const Eigen::MatrixXd &Q_bias, bool model_time_varying_bias,
+                        double noise_multiplier, const UpdaterOptionsT &options, ZuptPending &pend) {
   const StateSnapshot snap(state);
   ov_core::FeatureInitializerOptions fo;
   Context &cx = context_for(make_options(options, fo, state->_options, OVGPU_REP_GLOBAL_3D));
   const ovgpu_state_view sv = snap.fs.view();
   cx.check(ovgpu_set_state(cx.get(), &sv), "ovgpu_set_state");
-  const int m = (int)H.rows(), h = (int)H.cols();
+  const int rows = (int)H.rows(), h = (int)H.cols();
   pend.ctx = &cx, pend.N = sv.N, pend.cols.clear();
   for (const auto &v : Hx_order)
     for (int i = 0; i < v->size(); i++) pend.cols.push_back(v->id() + i);
-  std::vector<double> Hin((size_t)m * h), rin(m);
-  for (int i = 0; i < m; i++) {
-    rin[i] = res(i);
-    for (int j = 0; j < h; j++) Hin[(size_t)i * h + j] = H(i, j);
-  }
-  const int nmax = std::min(m, h);
-  pend.H.assign((size_t)std::max(nmax, 1) * h, 0.0), pend.r.assign(std::max(nmax, 1), 0.0);
-  int32_t rows = 0;
-  cx.check(ovgpu_measurement_compress(cx.get(), m, h, Hin.data(), rin.data(), pend.H.data(), pend.r.data(), &rows), "ovgpu_measurement_compress");
-  pend.rows = rows;
-  H.resize(rows, h), res.resize(rows);
+  pend.H.assign((size_t)std::max(rows, 1) * h, 0.0), pend.r.assign(std::max(rows, 1), 0.0);
   for (int i = 0; i < rows; i++) {
-    res(i) = pend.r[i];
-    for (int j = 0; j < h; j++) H(i, j) = pend.H[(size_t)i * h + j];
+    pend.r[i] = res(i);
+    for (int j = 0; j < h; j++) pend.H[(size_t)i * h + j] = H(i, j);
   }
+  pend.rows = rows;
   if (rows < 1) return 0.0; // :184-186
   std::vector<double> Pm((size_t)h * h);
   cx.check(ovgpu_state_marginal_covariance(cx.get(), h, pend.cols.data(), Pm.data()), "ovgpu_state_marginal_covariance");

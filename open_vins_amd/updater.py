@@ -523,7 +523,8 @@ class UpdaterMSCKF:
 
 class MultiUpdater:
     """ovgpu_multi_*: ONE host process driving several GPUs (the reference's host is one C++ process); devices = list of HIP device
-    indices (the same index may not appear twice: RCCL refuses two ranks on one GPU)."""
+    indices.  A repeated index puts several ranks on one GPU with the library's loop-back collective instead of RCCL (which refuses
+    two ranks on one GPU): how the G > 1 code paths are exercised on a one-GPU box."""
 
     def __init__(self, options=None, devices=(0,)):
         self.lib = capi.load()

@@ -6,7 +6,7 @@
 double probe(std::shared_ptr<ov_msckf::State> state, std::vector<std::shared_ptr<ov_type::Type>> order, Eigen::MatrixXd &H, Eigen::VectorXd &res, ov_msckf::UpdaterOptions &o) {
   Eigen::MatrixXd Q = Eigen::MatrixXd::Identity(6, 6);
   ovgpu_shim::ZuptPending pend;
-  const double chi2 = ovgpu_shim::zupt_compress_and_chi2(state, order, H, res, Q, true, 10.0, o, pend);
+  const double chi2 = ovgpu_shim::zupt_chi2(state, order, H, res, Q, true, 10.0, o, pend);
   ovgpu_shim::zupt_apply(state, order[1], Q, true, 10.0, pend);
   std::map<size_t, std::vector<std::pair<float, float>>> obs;
   std::map<size_t, std::vector<size_t>> ids;
