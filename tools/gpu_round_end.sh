@@ -11,7 +11,8 @@ if [ "${SKIP_TESTS:-0}" != 1 ]; then
   timeout 120 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.txt 2>&1
 fi
 timeout 300 python -m pytest tests/test_gpu_fullsize.py -q -s -p no:cacheprovider -k "conditioning_sweep or round1_route" 2>&1 | grep "cond(P_DD)\|gram then\|passed\|failed" > $OUT/conditioning_sweep.txt
-timeout 300 python bench.py > $OUT/bench.json 2> $OUT/bench.err
+timeout 400 python bench.py > $OUT/bench.json 2> $OUT/bench.err
+timeout 120 python bench.py --legacy-feature-kernel --steps 30 --warmup 5 --no-cpu-baseline --no-extras > $OUT/bench_legacy_feature_kernels.json 2>> $OUT/bench.err
 timeout 120 python bench.py --cfg 2 --steps 50 --warmup 5 --no-cpu-baseline --no-extras > $OUT/bench_cfg2.json 2>> $OUT/bench.err
 timeout 120 python bench.py --cfg 2 --features 10000 --steps 10 --warmup 2 --no-cpu-baseline --no-extras > $OUT/bench_stereo_10k.json 2>> $OUT/bench.err
 timeout 120 python bench.py --cfg 4 --steps 10 --warmup 2 --no-cpu-baseline --no-extras > $OUT/bench_cfg4_one_gpu.json 2>> $OUT/bench.err
@@ -22,12 +23,13 @@ cd /tmp && export TMPDIR=/tmp
 B="python /root/repo/bench.py --no-cpu-baseline --no-extras"
 timeout 180 rocprofv3 --kernel-trace --stats -d $OUT/prof_stats -o s -- $B --steps 20 --warmup 5 > /dev/null 2>&1
 timeout 180 rocprofv3 --kernel-trace --stats -d $OUT/prof_stats2 -o s -- $B --cfg 2 --steps 20 --warmup 5 > /dev/null 2>&1
+timeout 180 rocprofv3 --kernel-trace --stats -d $OUT/prof_stats3 -o s -- $B --cfg 4 --steps 6 --warmup 2 > /dev/null 2>&1
 timeout 180 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/prof_fetch -o f -- $B --steps 5 --warmup 2 > /dev/null 2>&1
 timeout 180 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/prof_write -o w -- $B --steps 5 --warmup 2 > /dev/null 2>&1
 timeout 180 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY -d $OUT/prof_sq1 -o q -- $B --steps 5 --warmup 2 > /dev/null 2>&1
 timeout 180 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS -d $OUT/prof_sq2 -o q -- $B --steps 5 --warmup 2 > /dev/null 2>&1
 cd /root/repo
-for d in prof_stats prof_stats2; do f=$(find $OUT/$d -name "*.db" | head -1); [ -n "$f" ] && python tools/prof_summary.py $f $d > $OUT/${d}.txt; done
+for d in prof_stats prof_stats2 prof_stats3; do f=$(find $OUT/$d -name "*.db" | head -1); [ -n "$f" ] && python tools/prof_summary.py $f $d > $OUT/${d}.txt; done
 for d in prof_fetch prof_write prof_sq1 prof_sq2; do f=$(find $OUT/$d -name "*.db" | head -1); [ -n "$f" ] && python tools/pmc_summary.py $f $d > $OUT/${d}.txt; done
-rm -rf $OUT/prof_stats $OUT/prof_stats2 $OUT/prof_fetch $OUT/prof_write $OUT/prof_sq1 $OUT/prof_sq2
+rm -rf $OUT/prof_stats $OUT/prof_stats2 $OUT/prof_stats3 $OUT/prof_fetch $OUT/prof_write $OUT/prof_sq1 $OUT/prof_sq2
 cat $OUT/pytest_gpu.txt 2>/dev/null; tail -2 $OUT/smoke.txt 2>/dev/null; cut -c1-400 $OUT/bench.json; echo; for f in bench_cfg2 bench_stereo_10k bench_cfg4_one_gpu bench_tsqr; do cut -c1-200 $OUT/$f.json; echo; done; for f in bench_cfg5_share_f64 bench_cfg5_share_fp32_gram; do cut -c1-200 $OUT/$f.json; echo; done; cat $OUT/conditioning_sweep.txt | cut -c1-200; head -24 $OUT/prof_stats.txt | cut -c1-60,72-128
