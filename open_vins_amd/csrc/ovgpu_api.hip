@@ -23,6 +23,7 @@
 #include "k_tsqr_blk.h"
 #include "k_tracks.h"
 #include "k_featy.h"
+#include "k_featy_big.h"
 #include "k_gram.h"
 #include <unordered_map>
 #include <dlfcn.h>
@@ -212,6 +213,9 @@ struct ovgpu_ctx {
   size_t featy_lds = 0;
   DevBuf<double> fs_tq;
   DevBuf<int32_t> fs_inst;
+  DevBuf<double> featyb_ws;        // k_featy_big.h: row panels of the earlier passes, per workgroup
+  int featy_big = 0;               // ovgpu_debug_option "featy_big": 1 = the multi-pass kernel also for tracks the one-pass kernels hold,
+                                   // 2 = with 5 tiles per wavefront (several passes on short tracks: tests)
   bool no_feat_kernel = false;  // options.no_fast_feature_kernel
   DevBuf<int32_t> feat_counter, fs_minfo, fs_meas_feat; // fs_*: the row store of the fast path (feat::FeatStore)
   DevBuf<double> fs_rows, fs_V, fs_z, fs_w;
@@ -499,7 +503,7 @@ void ovgpu_destroy(ovgpu_ctx *c) {
   c->ctrl.release();
   c->gram_part.release(), c->gram_G.release(), c->gram_rho.release(), c->Yaug2.release(), c->gram_dropped.release(), c->Lw.release(), c->dbg_cycles.release();
   c->chol_uinv.release();
-  c->fs_minfo.release(), c->fs_meas_feat.release(), c->fs_rows.release(), c->fs_V.release(), c->fs_z.release(), c->fs_w.release(), c->fs_tq.release(), c->fs_inst.release();
+  c->fs_minfo.release(), c->fs_meas_feat.release(), c->fs_rows.release(), c->fs_V.release(), c->fs_z.release(), c->fs_w.release(), c->fs_tq.release(), c->fs_inst.release(), c->featyb_ws.release();
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
@@ -767,6 +771,9 @@ static int set_row_layout(ovgpu_ctx *c, bool slam_rows) {
         c->feat_grid = std::max(1, std::min(F, c->num_cu * per_cu));
         if (feat::feat_qr_lds_per_wave(m_max, c->LD, c->K * c->C) * 4 > (size_t)c->lds_limit) c->feat_variant = 0;
       }
+    } else if (nt <= 29 && c->feat_shape == 0 && feat::featyb_lds_layout(nt, 8).total <= (size_t)c->lds_limit) {
+      // 3: the gate matrix does not fit the registers of a compute unit: block row by block row (k_featy_big.h; no legacy form)
+      c->feat_variant = 3, c->feat_nt_max = nt;
     }
   }
   // the general kernel's panel routine (gate_chol_panel<8>, k_system.h) holds the 2m + 4 rows of the gate's trapezoid in the eight
@@ -778,7 +785,16 @@ static int set_row_layout(ovgpu_ctx *c, bool slam_rows) {
     const int nt = c->feat_nt_max, nw = c->feat_variant == 1 ? 4 : 8;
     const feat::FeatYLds lo = feat::featy_lds_layout(nt, nw);
     const size_t vt_lds = (size_t)4 * (12 * std::max(m_max, 1) + 64) * sizeof(double);
-    if (lo.total <= (size_t)c->lds_limit && vt_lds <= (size_t)c->lds_limit && nt * (nt + 1) / 2 + nt <= nw * (nw == 4 ? 11 : 17)) {
+    if (c->feat_variant == 3) {
+      if (vt_lds <= (size_t)c->lds_limit) {
+        c->featy_ok = true, c->featy_lds = feat::featyb_lds_layout(nt, 8).total;
+        c->featy_grid = std::max(1, std::min(F, c->num_cu));
+        HIPCHK(c->featyb_ws.reserve((size_t)c->featy_grid * feat::featyb_ws_doubles(nt)));
+      } else {
+        c->feat_variant = 0;
+        if (2 * m_max + 4 > 512) return set_err(OVGPU_ERR_CAPACITY, "track of more than 254 observations: beyond the per-feature kernels (gate of 2m + 4 <= 512 rows)");
+      }
+    } else if (lo.total <= (size_t)c->lds_limit && vt_lds <= (size_t)c->lds_limit && nt * (nt + 1) / 2 + nt <= nw * (nw == 4 ? 11 : 17)) {
       const int per_cu = nw == 4 ? std::max(1, std::min(2, (int)((size_t)c->lds_limit / lo.total))) : 1;
       c->featy_ok = true, c->featy_lds = lo.total;
       c->featy_grid = std::max(1, std::min(F, c->num_cu * per_cu));
@@ -966,7 +982,7 @@ static int enqueue_system(ovgpu_ctx *c, int f_one = -1, int init_rep = 0, bool w
     feat::FeatStore st{c->fs_rows.p, c->fs_minfo.p, c->fs_V.p, c->fs_z.p, c->fs_meas_feat.p, c->fs_w.p};
     const double *sr = st.rows, *sV = st.V, *sz = st.z;
     const int32_t *sm = st.minfo;
-    if (c->featy_ok && !c->legacy_feat_kernel) {
+    if (c->featy_ok && (!c->legacy_feat_kernel || c->feat_variant == 3)) {
       // the fused form (k_featy.h): rows (clone-major) -> reflectors -> [prior block's factor L joins] -> sweep Y = H L once per feature:
       // projected rows to the stack, gate matrix as Y Y^T + s^2 I on the matrix cores, Cholesky, chi2
       static bool attr_y = false;
@@ -983,7 +999,20 @@ static int enqueue_system(ovgpu_ctx *c, int f_one = -1, int init_rep = 0, bool w
       if (c->prior_on_side) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join, 0));
       const double *stq = c->fs_tq.p;
       const int32_t *sin = c->fs_inst.p;
-      if (c->feat_variant == 1 && c->featy_shape == 1) {
+      if (c->feat_variant == 3 || c->featy_big) { // block row by block row (k_featy_big.h)
+        static bool attr_b = false;
+        if (!attr_b) {
+          (void)hipFuncSetAttribute((const void *)feat::k_feat_y_big<8, 17>, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_limit);
+          (void)hipFuncSetAttribute((const void *)feat::k_feat_y_big<8, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_limit);
+          attr_b = true;
+        }
+        const int nt = c->feat_nt_max, gridb = std::max(1, std::min(c->F, c->num_cu));
+        const size_t ldsb = feat::featyb_lds_layout(nt, 8).total;
+        if (ldsb > (size_t)c->lds_limit || nt > 29) return set_err(OVGPU_ERR_CAPACITY, "k_feat_y_big: track too long for its LDS block");
+        HIPCHK(c->featyb_ws.reserve((size_t)gridb * feat::featyb_ws_doubles(nt)));
+        if (c->featy_big == 2) hipLaunchKernelGGL((feat::k_feat_y_big<8, 5>), dim3(gridb), dim3(512), ldsb, c->stream, p, nt, sr, sm, sV, stq, sin, c->featyb_ws.p);
+        else hipLaunchKernelGGL((feat::k_feat_y_big<8, 17>), dim3(gridb), dim3(512), ldsb, c->stream, p, nt, sr, sm, sV, stq, sin, c->featyb_ws.p);
+      } else if (c->feat_variant == 1 && c->featy_shape == 1) {
         const feat::FeatYLds lo8 = feat::featy_lds_layout(c->feat_nt_max, 8);
         const int per_cu = std::max(1, std::min(2, (int)((size_t)c->lds_limit / lo8.total)));
         hipLaunchKernelGGL((feat::k_feat_y<8, 6, 4>), dim3(std::max(1, std::min(c->F, c->num_cu * per_cu))), dim3(512), lo8.total, c->stream, p, c->feat_nt_max, sr, sm, sV, stq, sin);
@@ -2924,6 +2953,9 @@ int ovgpu_debug_option(ovgpu_ctx *c, const char *name, int64_t value, int64_t *o
   } else if (n == "legacy_feature_kernel") { // 1: the three-sweep form of the MSCKF fast path (k_feat.h) instead of the fused one (k_featy.h)
     if (old_value) *old_value = c->legacy_feat_kernel ? 1 : 0;
     if (value >= 0) c->legacy_feat_kernel = value != 0;
+  } else if (n == "featy_big") { // the multi-pass per-feature kernel on batches the one-pass kernels hold (tests)
+    if (old_value) *old_value = c->featy_big;
+    if (value >= 0) c->featy_big = (int)value;
   } else if (n == "featy_shape") {
     if (old_value) *old_value = c->featy_shape;
     if (value >= 0) c->featy_shape = (int)value;
