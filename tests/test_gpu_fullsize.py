@@ -31,10 +31,18 @@ def _rel(a, b):
     return float(np.linalg.norm(np.asarray(a - b, dtype=np.float64)) / max(np.linalg.norm(np.asarray(b, dtype=np.float64)), 1e-300))
 
 
-def _parity(Updater, oracle, prob, opts, tol_dx=1e-8, tol_p=1e-9, **fields):
+_ORACLE_RUNS = {}  # key -> (triangulation, update) of the oracle: the large batches are used by more than one test
+
+
+def _parity(Updater, oracle, prob, opts, tol_dx=1e-8, tol_p=1e-9, key=None, **fields):
     v = capi.Views(prob)
-    tri = oracle.triangulate(opts, v)
-    ref = oracle.msckf_update(opts, v, given=tri)
+    if key is not None and key in _ORACLE_RUNS:
+        tri, ref = _ORACLE_RUNS[key]
+    else:
+        tri = oracle.triangulate(opts, v)
+        ref = oracle.msckf_update(opts, v, given=tri)
+        if key is not None:
+            _ORACLE_RUNS[key] = (tri, ref)
     up = Updater(opts)
     up.set_problem(prob)
     up.set_triangulation(tri["p_FinG"], tri["p_FinA"], tri["anchor_meas"], tri["status"])
@@ -73,25 +81,28 @@ def test_10k_features_against_oracle(Updater, oracle):
     _parity(Updater, oracle, prob, capi.default_options(chi2_multipler=1.0))
 
 
-def test_cfg5_geometry_against_oracle(Updater, oracle):
-    """BASELINE configs[4] geometry: 50 clones, 4 cameras, N = 372, D = 356 columns (23 column tiles), tracks of up to 200."""
-    prob = synth.make_problem(5, F=240)
-    assert prob.C == 50 and prob.K == 4 and prob.N == 372
-    out, _ = _parity(Updater, oracle, prob, capi.default_options(chi2_multipler=1.0))
+@pytest.mark.parametrize("F", [240, 2500])
+def test_cfg5_geometry_against_oracle(Updater, oracle, F):
+    """BASELINE configs[4] geometry: 50 clones, 4 cameras, N = 372, D = 356 columns (23 column tiles), tracks of up to 200
+    observations (gate matrices of 25 tile rows: k_featy_big.h); F = 2500 is one rank's real share of the 20 000-feature job."""
+    prob = synth.make_problem(5, F=F)
+    assert prob.C == 50 and prob.K == 4 and prob.N == 372 and np.diff(prob.meas_offsets).max() == 200
+    out, _ = _parity(Updater, oracle, prob, capi.default_options(chi2_multipler=1.0), key=("cfg5", F))
     assert out["route"] == capi.COMPRESS_GRAM  # 23 tile columns: the block variant of the Gram kernel (k_gram_blk), f64
 
 
-@pytest.mark.parametrize("cfg,F", [(5, 500), (2, 300)])
+@pytest.mark.parametrize("cfg,F", [(5, 500), (5, 2500), (2, 300)])
 def test_fp32_gram_variant(Updater, oracle, cfg, F):
     """BASELINE configs[4]'s "fp32 compressed-QR": options.gram_fp32 accumulates the Gram matrix of the prior-whitened stack on
     v_mfma_f32_16x16x4_f32.  Everything else stays f64 (gate, whitening, both factorisations), so the accept sets and chi2 are those
     of the f64 path; dx within 1e-4 and P within 1e-3 of the f64 oracle (measured: see the printed line)."""
     prob = synth.make_problem(cfg, F=F)
     opts = capi.default_options(chi2_multipler=1.0, gram_fp32=1)
-    out, ref = _parity(Updater, oracle, prob, opts, tol_dx=1e-4, tol_p=1e-3)
+    key = (f"cfg{cfg}", F)  # the oracle's result does not depend on gram_fp32
+    out, ref = _parity(Updater, oracle, prob, opts, tol_dx=1e-4, tol_p=1e-3, key=key)
     assert out["route"] == capi.COMPRESS_GRAM
     print(f"fp32 Gram, cfg {cfg}, {F} features: |ddx|/|dx| {_rel(out['dx'], ref['dx']):.1e}, |dP|/|P| {_rel(out['P'], ref['P']):.1e}")
-    f64 = _parity(Updater, oracle, prob, capi.default_options(chi2_multipler=1.0))[0]
+    f64 = _parity(Updater, oracle, prob, capi.default_options(chi2_multipler=1.0), key=key)[0]
     assert _rel(out["P"], f64["P"]) > 1e-12  # it really is another arithmetic
 
 

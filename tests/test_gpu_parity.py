@@ -157,12 +157,40 @@ def test_update_parity_state_options(Updater, oracle, flags):
     _check_given(Updater, oracle, prob, capi.default_options(**{"chi2_multipler": 1.0, **flags}))
 
 
-def test_update_parity_long_tracks_use_global_gate_workspace(Updater, oracle):
-    """cfg-5 geometry (50 clones x 4 cameras, up to 200 measurements per feature): the gate matrix no longer
-    fits LDS and goes through the HBM workspace."""
+@pytest.mark.parametrize("general", [0, 1])
+def test_update_parity_long_tracks(Updater, oracle, general):
+    """cfg-5 geometry (50 clones x 4 cameras, up to 200 measurements per feature).  Default: the gate matrix (25 tile rows) is
+    factored block row by block row (k_featy_big.h); no_fast_feature_kernel: the general kernel, whose gate matrix no longer fits
+    LDS and goes through the HBM workspace."""
     prob = synth.make_problem(5, F=12)
     assert np.diff(prob.meas_offsets).max() > 120
-    _check_given(Updater, oracle, prob, capi.default_options(chi2_multipler=1.0))
+    _check_given(Updater, oracle, prob, capi.default_options(chi2_multipler=1.0, no_fast_feature_kernel=general))
+
+
+@pytest.mark.parametrize("kw", [dict(F=300), dict(F=200, track="ragged", outlier_frac=0.3), dict(cfg=4, F=100), dict(F=150, C=11, K=1)])
+def test_block_row_gate_equals_the_one_pass_gate(Updater, kw):
+    """k_feat_y_big (k_featy_big.h) on batches the one-pass kernel holds: with the same tile budget (one pass) and with 5 tiles per
+    wavefront (2 .. 5 passes over 8 .. 15 tile rows).  A tile of the gate matrix receives the same updates in the same order
+    whatever the pass structure, so chi2 is BIT-identical; the stacked rows differ in the summation order of V^T Y only."""
+    kw = dict(kw)
+    prob = synth.make_problem(kw.pop("cfg", 2), **kw)
+    opts = capi.default_options(chi2_multipler=1.0)
+    outs = []
+    for big in (0, 1, 2):
+        up = Updater(opts)
+        assert up.debug_option("featy_big", big) == 0
+        up.set_problem(prob)
+        outs.append(up.update())
+        up.close()
+    ref = outs[0]
+    gate = np.isfinite(ref["chi2"])
+    assert gate.sum() > 0.5 * prob.F
+    for out in outs[1:]:
+        assert np.array_equal(out["feat_status"], ref["feat_status"])
+        assert np.array_equal(out["chi2"][gate], ref["chi2"][gate])
+        assert out["stats"]["n_rows"] == ref["stats"]["n_rows"]
+        assert _rel(out["dx"], ref["dx"]) < 1e-10
+        assert _rel(out["P"], ref["P"]) < 1e-11
 
 
 def test_short_and_empty_tracks(Updater, oracle):
