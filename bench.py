@@ -49,6 +49,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the PCIe-inclusive and the secondary (weak / single-GPU reference) measurements")
     ap.add_argument("--route", choices=["gram", "tsqr"], default="gram")
+    ap.add_argument("--stage-events-every", type=int, default=4, help="the library's per-stage HIP events (roofline durations) on every n-th update of the timed region")
     ap.add_argument("--legacy-feature-kernel", action="store_true", help="round 2's three-sweep per-feature kernels (k_feat.h) instead of the fused one (k_featy.h)")
     ap.add_argument("--gram-fp32", action="store_true", help="BASELINE configs[4]'s fp32 compression: Gram matrix accumulated on v_mfma_f32_16x16x4_f32")
     return ap.parse_args(argv)
@@ -134,6 +135,10 @@ def main(argv=None):
         up = UpdaterMSCKF(opts, device=local_rank)
         if args.legacy_feature_kernel:
             up.debug_option("legacy_feature_kernel", 1)
+        # the library's stage events (the roofline's kernel durations) are marker packets the next kernel waits for: ~5 us apiece, six per
+        # update (measured: 0.982 -> 0.961 ms at every 4th update, 0.948 with none).  They are recorded on every n-th update of the timed
+        # region; the reported durations are averages over those updates.
+        up.debug_option("stage_timing_period", args.stage_events_every)
         up.set_problem(shard)  # H2D once; everything below runs on resident data
         native = True
         if world > 1 and not local_only:
@@ -264,7 +269,8 @@ def main(argv=None):
                 "kernel": ("per-feature stage = k_feat_rows + k_feat_qr + k_feat + k_feat_out (csrc/k_feat.h, round 2's three-sweep form)" if args.legacy_feature_kernel else
                            "per-feature stage = k_feat_rows_sorted + k_feat_vt + k_feat_y (csrc/k_featy.h: Jacobian records, reflectors, then ONE kernel per "
                            "feature: whitened rows Y = H L as block products on the f64 matrix cores, projection and stacking, gate matrix Y Y^T + s^2 I as a "
-                           "SYRK in accumulator registers, blocked Cholesky, chi2)") + ", timed with HIP events on the context's stream (the wait for the prior "
+                           "SYRK in accumulator registers, blocked Cholesky, chi2; gate matrices beyond 136 tiles (configs[4]): k_feat_y_big, csrc/k_featy_big.h, block row "
+                           "by block row)") + ", timed with HIP events on the context's stream (the wait for the prior "
                           "block's factor on the second stream included)" + (" (rank 0's shard)" if world > 1 else ""),
                 "bound": "mfma",
                 "achieved": achieved,
@@ -282,6 +288,7 @@ def main(argv=None):
                     "traffic": traffic.get("compression") if (traffic and gram) else None,
                 },
                 "update_ms_device": kt["ms_update"],
+                "stage_events": f"HIP events around the stages on every {args.stage_events_every}th update of the timed region ({kt['launches']} updates sampled)",
             },
         }
         out.update(extras)

@@ -44,14 +44,40 @@ struct CholParams {
   int32_t *err;           // sticky: a follower ran into its wait bound
   int spin_limit;         // the followers' wait bound per step (polls of ~100 cycles; 1 << 22 ~ 0.2 s)
   long long *dbg;         // optional cycle counters (developer aid)
+  // Where [A | C] comes from.  The two factorisations of the Gram-form update each had a small kernel in front that only assembled
+  // the work matrix (k_tf_gather, k_tf_abh: a launch and a stream hand-over on the critical path each); the factorisation reads
+  // every input element exactly once, so it can as well read it from where it lives:
+  //   CH_SRC_MATRIX   A as stored
+  //   CH_SRC_PRIOR    [P_DD | P(D, :) | 0] gathered from the covariance through col_cov (k_tf_gather)
+  //   CH_SRC_WHITENED [I + G / s^2 | B | g / s^2]: G the Gram matrix of the whitened stack, B the carried columns of Y1 (k_tf_abh)
+  int src = 0;
+  int N = 0;                          // carried covariance columns (LA = D + N + 1)
+  const int32_t *col_cov = nullptr;   // CH_SRC_PRIOR
+  const double *P = nullptr;          // CH_SRC_PRIOR: [N x N]
+  const double *G = nullptr;          // CH_SRC_WHITENED: [LG x LG]
+  int LG = 0;
+  double inv_sigma2 = 0.0;
+  const double *Y1 = nullptr;         // CH_SRC_WHITENED: [D x LA], the first factorisation's result
+  const int32_t *pred_not = nullptr;  // optional: nothing happens when *pred_not != 0 (the not-SPD / time-out flag of an earlier factorisation)
 };
+enum { CH_SRC_MATRIX = 0, CH_SRC_PRIOR = 1, CH_SRC_WHITENED = 2 };
 
 constexpr int CH_TMAX = 16;  // tile rows: D <= 256
 constexpr int CH_NW = 8;     // wavefronts per workgroup
 
 __device__ __forceinline__ double ld_a(const CholParams &p, int r, int c) { // element (r, c) of the padded matrix part
-  return (r < p.D && c < p.D) ? p.A[(size_t)r * p.LA + c] : (r == c ? 1.0 : 0.0);
+  if (!(r < p.D && c < p.D)) return r == c ? 1.0 : 0.0;
+  if (p.src == CH_SRC_PRIOR) return p.P[(size_t)p.col_cov[r] * p.N + p.col_cov[c]];
+  if (p.src == CH_SRC_WHITENED) return p.G[(size_t)r * p.LG + c] * p.inv_sigma2 + (r == c ? 1.0 : 0.0);
+  return p.A[(size_t)r * p.LA + c];
 }
+__device__ __forceinline__ double ld_c(const CholParams &p, int r, int col) { // carried column col (D <= col < LA) of row r < D
+  const int cc = col - p.D;
+  if (p.src == CH_SRC_PRIOR) return cc < p.N ? p.P[(size_t)p.col_cov[r] * p.N + cc] : 0.0;
+  if (p.src == CH_SRC_WHITENED) return cc < p.N ? p.Y1[(size_t)r * p.LA + col] : p.G[(size_t)r * p.LG + p.D] * p.inv_sigma2;
+  return p.A[(size_t)r * p.LA + col];
+}
+__device__ __forceinline__ bool chol_skipped(const CholParams &p) { return (p.pred && *p.pred == 0) || (p.pred_not && *p.pred_not != 0); }
 
 constexpr int CH_FW = 15;  // tile wavefronts of the factor workgroup (wavefront 15 runs the diagonal chain and holds no tiles)
 constexpr int CH_FT = 10;  // tiles per wavefront: 16 * 17 / 2 = 136 <= 15 * 10
@@ -60,12 +86,15 @@ __global__ void __launch_bounds__(64 * (CH_FW + 1), 4) k_chol_factor(CholParams 
   __shared__ __attribute__((aligned(16))) double panel[CH_TMAX][256];
   __shared__ __attribute__((aligned(16))) double st[2][256];
   __shared__ int diag_ready; // number of diagonal tiles handed to the chain wavefront so far (look-ahead hand-over, see below)
-  if (p.pred && *p.pred == 0) return;
+  __shared__ double d0s[16 * CH_TMAX]; // CH_SRC_PRIOR: the diagonal of the matrix before the factorisation (pivot test)
+  if (chol_skipped(p)) return;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, cl = lane & 15;
   const int D = p.D, LA = p.LA, TM = (D + 15) >> 4, NTT = TM * (TM + 1) / 2;
   if (tid == 0) diag_ready = 0;
+  if (p.src == CH_SRC_PRIOR && tid < 16 * CH_TMAX) d0s[tid] = tid < D ? p.P[(size_t)p.col_cov[tid] * p.N + p.col_cov[tid]] : 1.0;
+  const double *diag0 = p.src == CH_SRC_PRIOR ? d0s : p.diag0;
   __syncthreads();
   // Barriers of the chain order LDS traffic only; memory traffic is fire-and-forget.  Data for the followers leaves with
   // write-through stores (sc1), and a wavefront adds itself to prog[k - 1] one step LATER, when those stores have long completed
@@ -92,8 +121,8 @@ __global__ void __launch_bounds__(64 * (CH_FW + 1), 4) k_chol_factor(CholParams 
 #pragma unroll
       for (int q = 0; q < 4; q++) sv[q] = st[0][(g + 4 * q) * 16 + cl];
       __builtin_amdgcn_wave_barrier(); // st[0] becomes the factorisation's scratch
-      const bool bad = feat::diag_tile_factor_blk(sv, ev, st[0], lane, p.diag0 ? p.diag0 + 16 * k : nullptr, p.pivot_tol, D - 16 * k);
-      if (bad && lane == 0) p.flags[0] = 1;
+      const bool bad = feat::diag_tile_factor_blk(sv, ev, st[0], lane, diag0 ? diag0 + 16 * k : nullptr, p.pivot_tol, D - 16 * k);
+      if (bad && lane == 0) __hip_atomic_store(p.flags, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // written through: a consumer may start before this kernel ends
 #pragma unroll
       for (int q = 0; q < 4; q++) st[1][cl * 16 + g + 4 * q] = ev[q]; // U^-T in accumulator layout -> U^-1 row-major
       t_diag += clock64() - t_d0;
@@ -225,7 +254,7 @@ __global__ void __launch_bounds__(64 * (CH_FW + 1), 4) k_chol_factor(CholParams 
 
 // followers: one wavefront per 16 carried columns (launched on a second stream next to k_chol_factor)
 __global__ void __launch_bounds__(64 * CH_NW, 2) k_chol_follow(CholParams p) {
-  if (p.pred && *p.pred == 0) return;
+  if (chol_skipped(p)) return;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, cl = lane & 15;
@@ -243,7 +272,7 @@ __global__ void __launch_bounds__(64 * CH_NW, 2) k_chol_follow(CholParams p) {
 #pragma unroll
       for (int q = 0; q < 4; q++) {
         const int r = 16 * i + g + 4 * q;
-        v[q] = (r < D && colok) ? p.A[(size_t)r * LA + col] : 0.0;
+        v[q] = (r < D && colok) ? ld_c(p, r, col) : 0.0;
       }
     }
     acc[i] = v;

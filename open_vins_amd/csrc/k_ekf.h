@@ -59,7 +59,9 @@ struct EkfParams {
   const double *diag0 = nullptr; // optional [D]: the matrix's own diagonal before the factorisation; a pivot below pivot_tol of it
                                  // counts as not SPD (numerically singular prior block of the Gram-form update)
   double pivot_tol = 1e-13;
+  const int32_t *pred_not = nullptr; // optional: the whole update is skipped when *pred_not != 0 (flags[0] of an earlier factorisation)
 };
+__device__ __forceinline__ bool ekf_skipped(const EkfParams &p) { return (p.pred && *p.pred == 0) || (p.pred_not && *p.pred_not != 0); }
 
 // Mt = R * P(cols, :)     grid: tiles(D/16) x tiles(N/16) wavefronts, 4 per block
 __global__ void __launch_bounds__(256) k_ekf_mt(EkfParams p) {
@@ -241,7 +243,7 @@ __global__ void __launch_bounds__(256) k_ekf_pupdate(EkfParams p) {
 // dx = Y^T y     (one thread per state dof)
 __device__ __forceinline__ void ekf_dx_item(const EkfParams &p, int i) {
   if (i >= p.N) return;
-  if (p.pred && *p.pred == 0) { // no update: the correction is zero
+  if (ekf_skipped(p)) { // no update: the correction is zero
     p.dx[i] = 0.0;
     return;
   }
@@ -523,7 +525,7 @@ __global__ void __launch_bounds__(256) k_tf_abh(TformParams p, const int32_t *fl
 // P' = P - (B^T B - Y2^T Y2)      one wavefront per 16x16 tile of P; both products are symmetric tile by tile
 __device__ __forceinline__ void tf_pupdate_tile(const EkfParams &p, const double *Y1, int tile, int lane) {
   const int tn = (p.N + 15) / 16;
-  if (tile >= tn * tn || (p.pred && *p.pred == 0)) return;
+  if (tile >= tn * tn || ekf_skipped(p)) return;
   const int r0 = (tile / tn) * 16, c0 = (tile % tn) * 16;
   const double *B = Y1 + p.D, *Y = p.Y + p.D;
   auto fa1 = [&](int i, int k) { const int r = r0 + i; return (r < p.N) ? B[(size_t)k * p.LA + r] : 0.0; };

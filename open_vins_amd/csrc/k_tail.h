@@ -24,7 +24,7 @@ __global__ void __launch_bounds__(256) k_tf_tail(EkfParams p, const double *Y1, 
   for (int i = threadIdx.x; i < p.N; i += 256) ekf_dx_item(p, i);
   __syncthreads(); // dx is complete (global writes of this workgroup are visible to it after the barrier)
   const int n1 = t.C > t.K ? t.C : t.K;
-  if (!(p.pred && *p.pred == 0))
+  if (!ekf_skipped(p))
     for (int i = threadIdx.x; i < n1; i += 256) boxplus_item(i, t.C, t.K, p.dx, t.clone_cov, t.calib_cov, t.intr_cov, t.clone_qp, t.calib_qp, t.intr);
   __syncthreads();
   const int n2 = t.K * t.C > n1 ? t.K * t.C : n1;

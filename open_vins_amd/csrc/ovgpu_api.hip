@@ -181,6 +181,10 @@ struct ovgpu_ctx {
   // leaf / tree overlap: the merge tree runs on a second stream next to the leaf kernel's last append
   hipStream_t stream2 = nullptr, stream3 = nullptr; // stream3: followers of the single-launch Cholesky
   hipEvent_t ev_cf = nullptr, ev_cj = nullptr, ev_rows = nullptr;
+  hipEvent_t ev_lt = nullptr;       // the prior block's FACTOR kernel is done (L complete): the per-feature kernel waits for this, not for the carried columns
+  bool lt_on_side = false;          // ev_lt is pending on the side stream
+  bool cj_deferred = false;         // the factor kernel of a follow-on-main factorisation has not been joined yet (ev_cj)
+  bool fuse_chol_inputs = true;     // ovgpu_debug_option "fuse_chol_inputs": the factorisations read their inputs at the source (no k_tf_gather / k_tf_abh)
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   DevBuf<int32_t> leaf_flags; // [W] panels of the last append finished by each leaf node
   int tree_overlap = -1; // -1: only when leaves and merge nodes all get a CU of their own; 0 / 1 force it (OVGPU_TSQR_OVERLAP)
@@ -260,6 +264,8 @@ struct ovgpu_ctx {
   std::vector<EventPair> ev_compress, ev_update, ev_system;
   size_t ev_used = 0;
   bool timing = true;
+  int timing_period = 1;        // ovgpu_debug_option "stage_timing_period": the stage events go into every n-th update only (each is a
+  uint64_t timing_seq = 0;      // marker packet the next kernel waits for: ~3 us apiece, six per update)
 };
 
 // removes element `idx` of a device array of `n` records of `w` doubles / ints (through a scratch copy: the ranges overlap)
@@ -457,6 +463,7 @@ int ovgpu_create(const ovgpu_options *opts, int device, ovgpu_ctx **out) {
       hipEventCreateWithFlags(&c->ev_cj, hipEventDisableTiming) != hipSuccess)
     c->no_chol_pipe = true;
   if (hipEventCreateWithFlags(&c->ev_rows, hipEventDisableTiming) != hipSuccess) c->no_feat_kernel = true;
+  if (hipEventCreateWithFlags(&c->ev_lt, hipEventDisableTiming) != hipSuccess) c->ev_lt = nullptr;
   if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess)
     c->tree_overlap = 0;
@@ -512,6 +519,7 @@ void ovgpu_destroy(ovgpu_ctx *c) {
   if (c->ev_cf) (void)hipEventDestroy(c->ev_cf);
   if (c->ev_cj) (void)hipEventDestroy(c->ev_cj);
   if (c->ev_rows) (void)hipEventDestroy(c->ev_rows);
+  if (c->ev_lt) (void)hipEventDestroy(c->ev_lt);
   c->leaf_flags.release();
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -996,7 +1004,7 @@ static int enqueue_system(ovgpu_ctx *c, int f_one = -1, int init_rep = 0, bool w
       }
       hipLaunchKernelGGL(feat::k_feat_rows_sorted, dim3((c->M + 255) / 256), dim3(256), 0, c->stream, p, st, c->M);
       hipLaunchKernelGGL(feat::k_feat_vt, dim3((c->F + 3) / 4), dim3(256), (size_t)4 * (12 * p.m_max + 64) * sizeof(double), c->stream, p, st, c->fs_tq.p, c->fs_inst.p, c->feat_nt_max);
-      if (c->prior_on_side) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join, 0));
+      if (c->prior_on_side) HIPCHK(hipStreamWaitEvent(c->stream, c->lt_on_side ? c->ev_lt : c->ev_join, 0)); // L only: the carried columns join before the update
       const double *stq = c->fs_tq.p;
       const int32_t *sin = c->fs_inst.p;
       if (c->feat_variant == 3 || c->featy_big) { // block row by block row (k_featy_big.h)
@@ -1259,7 +1267,13 @@ struct EkfJob {
   bool keep_flags = false;            // do not clear the sticky error flags (a chain of updates)
 };
 
-static int enqueue_chol_carry(ovgpu_ctx *c, const EkfParams &p, hipStream_t s, double *Lt);
+struct CholSource { // where the factorisation reads [A | C] (k_chol.h CH_SRC_*); MATRIX: p.A
+  int src = chol::CH_SRC_MATRIX;
+  const TformParams *t = nullptr;
+  bool follow_first = false; // the carried columns' kernel on the caller's stream, the factor kernel on the helper stream; the caller joins
+                             // the helper stream LATER (ovgpu_ctx::cj_deferred): what follows on `s` may only need the carried columns
+};
+static int enqueue_chol_carry(ovgpu_ctx *c, const EkfParams &p, hipStream_t s, double *Lt, const CholSource &from = CholSource());
 
 static int enqueue_ekf(ovgpu_ctx *c, const EkfJob &job = EkfJob()) {
   c->prior_pending = false;
@@ -1295,8 +1309,9 @@ static int enqueue_ekf(ovgpu_ctx *c, const EkfJob &job = EkfJob()) {
 
 // EKF update straight from the Gram matrix in c->gram_G (k_ekf.h, "whitened by the prior"): two Cholesky-with-carry passes
 // through k_ekf_chol_step — P_DD carrying P(D, :), then T = I + U1 G U1^T / sigma^2 carrying [B | U1 g / sigma^2]
-static int enqueue_chol_carry(ovgpu_ctx *c, const EkfParams &p, hipStream_t s, double *Lt) {
-  if (!c->no_chol_pipe && p.D <= 16 * chol::CH_TMAX && p.D >= 1) {
+static bool chol_pipe_usable(const ovgpu_ctx *c, int D) { return !c->no_chol_pipe && D <= 16 * chol::CH_TMAX && D >= 1; }
+static int enqueue_chol_carry(ovgpu_ctx *c, const EkfParams &p, hipStream_t s, double *Lt, const CholSource &from) {
+  if (chol_pipe_usable(c, p.D)) {
     // one launch: the factor workgroup's chain stays inside a compute unit, the carried columns follow through flags (k_chol.h)
     HIPCHK(c->chol_prog.reserve(2 * 16));
     HIPCHK(c->chol_uinv.reserve((size_t)2 * 16 * 256));
@@ -1305,20 +1320,44 @@ static int enqueue_chol_carry(ovgpu_ctx *c, const EkfParams &p, hipStream_t s, d
     q.D = p.D, q.LA = p.LA, q.A = p.A, q.Y = p.Y, q.Lt = Lt, q.flags = p.flags, q.diag0 = p.diag0, q.pivot_tol = p.pivot_tol, q.pred = p.pred;
     q.prog = c->chol_prog.p + 16 * slot, q.uinv = c->chol_uinv.p + (size_t)slot * 16 * 256, q.err = p.flags + 2, q.dbg = c->dbg_cycles.p;
     q.spin_limit = c->chol_spin_limit;
+    q.src = from.src, q.N = p.N, q.pred_not = p.pred_not;
+    if (from.src != chol::CH_SRC_MATRIX) {
+      const TformParams &t = *from.t;
+      q.col_cov = t.col_cov, q.P = t.P, q.G = t.G, q.LG = t.LG, q.inv_sigma2 = t.inv_sigma2, q.Y1 = t.Y1;
+    }
     HIPCHK(ctrl_zero(c, slot ? CTRL_PROG1 : CTRL_PROG0, q.prog, 16 * sizeof(int32_t), s));
     const int carried = (p.LA - p.D + 15) / 16;
-    // the followers run next to the factor workgroup: same stream order is not enough (they would start after it), so they go to
-    // the context's helper stream behind an event and join again
+    // the followers run next to the factor workgroup: same stream order is not enough (they would start after it), so one of the two
+    // kernels goes to the context's helper stream behind an event
     hipStream_t sf = c->stream3;
+    if (c->cj_deferred) {
+      HIPCHK(hipStreamWaitEvent(s, c->ev_cj, 0));
+      c->cj_deferred = false;
+    }
     HIPCHK(hipEventRecord(c->ev_cf, s));
     HIPCHK(hipStreamWaitEvent(sf, c->ev_cf, 0));
-    hipLaunchKernelGGL(chol::k_chol_factor, dim3(1), dim3(64 * (chol::CH_FW + 1)), 0, s, q);
-    if (carried > 0) hipLaunchKernelGGL(chol::k_chol_follow, dim3((carried + chol::CH_NW - 1) / chol::CH_NW), dim3(64 * chol::CH_NW), 0, sf, q);
-    HIPCHK(hipEventRecord(c->ev_cj, sf));
-    HIPCHK(hipStreamWaitEvent(s, c->ev_cj, 0));
+    const dim3 gf((carried + chol::CH_NW - 1) / chol::CH_NW);
+    if (from.follow_first && carried > 0) {
+      // the followers spin until the factor workgroup (one event hand-over later) publishes its first step; what follows them on `s`
+      // starts when THEY are done, without a second hand-over
+      hipLaunchKernelGGL(chol::k_chol_follow, gf, dim3(64 * chol::CH_NW), 0, s, q);
+      hipLaunchKernelGGL(chol::k_chol_factor, dim3(1), dim3(64 * (chol::CH_FW + 1)), 0, sf, q);
+      HIPCHK(hipEventRecord(c->ev_cj, sf));
+      c->cj_deferred = true;
+    } else {
+      hipLaunchKernelGGL(chol::k_chol_factor, dim3(1), dim3(64 * (chol::CH_FW + 1)), 0, s, q);
+      if (Lt && c->ev_lt && c->prior_on_side) {
+        HIPCHK(hipEventRecord(c->ev_lt, s));
+        c->lt_on_side = true;
+      }
+      if (carried > 0) hipLaunchKernelGGL(chol::k_chol_follow, gf, dim3(64 * chol::CH_NW), 0, sf, q);
+      HIPCHK(hipEventRecord(c->ev_cj, sf));
+      HIPCHK(hipStreamWaitEvent(s, c->ev_cj, 0));
+    }
     HIPCHK(hipGetLastError());
     return OVGPU_OK;
   }
+  if (from.src != chol::CH_SRC_MATRIX) return set_err(OVGPU_ERR_INVALID, "the step-wise factorisation needs its work matrix assembled");
   const int TM = (p.D + 15) / 16, TL = (p.LA + 15) / 16;
   for (int kb = 0; kb < p.D; kb += 16) {
     const int tb = kb / 16;
@@ -1362,7 +1401,7 @@ static int enqueue_ekf_gram(ovgpu_ctx *c, int part, bool side = false) {
     if (c->prior_on_side) HIPCHK(hipStreamWaitEvent(s, c->ev_join, 0)); // a factorisation nobody joined still owns the work matrices
     HIPCHK(ctrl_zero(c, CTRL_FLAGS, c->flags.p, 4 * sizeof(int32_t), s));
     hipStream_t sp = s;
-    c->prior_on_side = false;
+    c->prior_on_side = false, c->lt_on_side = false;
     if (side && part == 1) { // everything enqueued so far (the previous update's tail reads these buffers) precedes the side stream's work
       HIPCHK(hipEventRecord(c->ev_fork, s));
       HIPCHK(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
@@ -1370,18 +1409,27 @@ static int enqueue_ekf_gram(ovgpu_ctx *c, int part, bool side = false) {
       c->prior_on_side = true;
     }
     const int64_t elems = (int64_t)D * LA;
-    hipLaunchKernelGGL(k_tf_gather, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, sp, t);
+    const bool at_source = c->fuse_chol_inputs && chol_pipe_usable(c, D); // the factorisation gathers [P_DD | P(D, :) | 0] itself
+    if (!at_source) hipLaunchKernelGGL(k_tf_gather, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, sp, t);
     p.diag0 = c->gram_rho.p, p.pivot_tol = c->prior_pivot_tol;
-    if ((rc = enqueue_chol_carry(c, p, sp, c->Lw.p)) != OVGPU_OK) return rc; // Y1 = [U1 | B | 0] in c->Yaug, L = U1^T in c->Lw
+    CholSource from;
+    if (at_source) from.src = chol::CH_SRC_PRIOR, from.t = &t;
+    if ((rc = enqueue_chol_carry(c, p, sp, c->Lw.p, from)) != OVGPU_OK) return rc; // Y1 = [U1 | B | 0] in c->Yaug, L = U1^T in c->Lw
     p.diag0 = nullptr;
     if (c->prior_on_side) HIPCHK(hipEventRecord(c->ev_join, sp));
     c->prior_pending = true;
   }
   if (part & 2) {
     if (c->prior_on_side) HIPCHK(hipStreamWaitEvent(s, c->ev_join, 0));
-    c->prior_pending = false, c->prior_on_side = false;
+    c->prior_pending = false, c->prior_on_side = false, c->lt_on_side = false;
     p.pred = c->flags.p + 3; // a prior block that is not positive definite: skip, the host falls back (finish_update)
-    if (t.whitened) {
+    CholSource from;
+    if (t.whitened && c->fuse_chol_inputs && chol_pipe_usable(c, D)) {
+      // [I + G / s^2 | B | g / s^2] is read at the source by the factorisation (no k_tf_abh), everything from here on is predicated on
+      // the first factorisation's flag itself, and the tail follows the carried columns' kernel on this stream
+      from.src = chol::CH_SRC_WHITENED, from.t = &t, from.follow_first = true;
+      p.pred = nullptr, p.pred_not = c->flags.p;
+    } else if (t.whitened) {
       hipLaunchKernelGGL(k_tf_abh, dim3((D + 3) / 4), dim3(256), 0, s, t, (const int32_t *)c->flags.p, c->flags.p + 3);
     } else {
       hipLaunchKernelGGL(k_tf_go, dim3(1), dim3(1), 0, s, (const int32_t *)c->flags.p, c->flags.p + 3);
@@ -1390,7 +1438,7 @@ static int enqueue_ekf_gram(ovgpu_ctx *c, int part, bool side = false) {
       hipLaunchKernelGGL(k_tf_bh, dim3((D + 3) / 4), dim3(256), 0, s, t);
     }
     p.Y = c->Yaug2.p;
-    if ((rc = enqueue_chol_carry(c, p, s, nullptr)) != OVGPU_OK) return rc; // Y2 = [C | C^-T B | C^-T h] in c->Yaug2
+    if ((rc = enqueue_chol_carry(c, p, s, nullptr, from)) != OVGPU_OK) return rc; // Y2 = [C | C^-T B | C^-T h] in c->Yaug2
     // covariance tiles + (dx -> box-plus -> pose tables) in one launch (k_tail.h; measured on one box: 1.227 -> 1.197 ms at 2000 features,
     // 0.737 -> 0.704 ms at 800, against the four separate launches)
     TailTables tt;
@@ -1399,6 +1447,10 @@ static int enqueue_ekf_gram(ovgpu_ctx *c, int part, bool side = false) {
     tt.tab_clone = c->tab_clone.p, tt.tab_cam = c->tab_cam.p, tt.tab_cc = c->tab_cc.p;
     const int nb = (tn * tn + 3) / 4;
     hipLaunchKernelGGL(k_tf_tail, dim3(nb + 1), dim3(256), 0, s, p, (const double *)c->Yaug.p, tt, nb);
+    if (c->cj_deferred) { // the factor kernel on the helper stream (off the critical path)
+      HIPCHK(hipStreamWaitEvent(s, c->ev_cj, 0));
+      c->cj_deferred = false;
+    }
     HIPCHK(hipGetLastError());
     c->last_update_tform = true;
     return OVGPU_OK;
@@ -1444,7 +1496,7 @@ static int enqueue_pipeline_body(ovgpu_ctx *c, int stages, bool slam, bool facto
   }
   EventPair *eu = nullptr, *ec = nullptr, *es = nullptr;
   bool tform = false;
-  if (c->timing) {
+  if (c->timing && (c->timing_period <= 1 || c->timing_seq++ % c->timing_period == 0)) {
     eu = next_events(c, c->ev_update, c->ev_used);
     ec = next_events(c, c->ev_compress, c->ev_used);
     es = next_events(c, c->ev_system, c->ev_used);
@@ -1499,7 +1551,7 @@ static int enqueue_pipeline_body(ovgpu_ctx *c, int stages, bool slam, bool facto
       c->gram_valid = false;               // (not the cholqr route's refinement state)
       if (rc == OVGPU_OK) {
         if (c->prior_on_side) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join, 0));
-        c->prior_pending = false, c->prior_on_side = false;
+        c->prior_pending = false, c->prior_on_side = false, c->lt_on_side = false;
         hipLaunchKernelGGL(k_tf_go, dim3(1), dim3(1), 0, c->stream, (const int32_t *)c->flags.p, c->flags.p + 3); // go = the prior block's factorisation succeeded
         hipLaunchKernelGGL(k_unwhiten, dim3((c->D + 15) / 16), dim3(256), 0, c->stream, c->D, c->LD, c->Rws.p, (const double *)c->Yaug.p, c->D + c->N + 1,
                            (const int32_t *)(c->flags.p + 3));
@@ -2953,6 +3005,12 @@ int ovgpu_debug_option(ovgpu_ctx *c, const char *name, int64_t value, int64_t *o
   } else if (n == "legacy_feature_kernel") { // 1: the three-sweep form of the MSCKF fast path (k_feat.h) instead of the fused one (k_featy.h)
     if (old_value) *old_value = c->legacy_feat_kernel ? 1 : 0;
     if (value >= 0) c->legacy_feat_kernel = value != 0;
+  } else if (n == "stage_timing_period") {
+    if (old_value) *old_value = c->timing_period;
+    if (value >= 1) c->timing_period = (int)value, c->timing_seq = 0;
+  } else if (n == "fuse_chol_inputs") { // 0: k_tf_gather / k_tf_abh assemble the factorisations' work matrices (round 2's form)
+    if (old_value) *old_value = c->fuse_chol_inputs ? 1 : 0;
+    if (value >= 0) c->fuse_chol_inputs = value != 0;
   } else if (n == "featy_big") { // the multi-pass per-feature kernel on batches the one-pass kernels hold (tests)
     if (old_value) *old_value = c->featy_big;
     if (value >= 0) c->featy_big = (int)value;
