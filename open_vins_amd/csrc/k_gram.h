@@ -189,6 +189,226 @@ template <int NTC> __global__ void __launch_bounds__(256) k_gram(GramParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// 17 .. 23 tile columns in TWO passes over the stack instead of the block variant's three (BASELINE configs[4]: D = 356, NT = 23,
+// 276 tiles of the triangle against the ~224 a workgroup of four one-per-SIMD wavefronts can hold).  With WS = NT - 16:
+//   k_gram_wide_win  tile rows WS .. NT-1: a 16 x 16 tile triangle over the column window [16 WS, 16 NT) — k_gram's own schedule
+//                    (gram_stage<W, 16>) on a window of the rows (2 KB of every 2.9 KB row);
+//   k_gram_wide_top  tile rows 0 .. WS-1 against all NT tile columns: the columns dealt to the four wavefronts in runs of equal tile
+//                    count (WS = 7: columns 0-7 / 8-12 / 13-17 / 18-22, 35 tiles each); a k-step reads the WS row operands + the
+//                    wavefront's own columns (12 - 15 LDS reads for 35 matrix instructions); full rows staged, 16 per stage.
+// Both write partial tiles in k_gram's format; k_gram_reduce sums them.  gridDim.x workgroups of each kind share the rows.
+// ---------------------------------------------------------------------------------------------------
+constexpr int GW_ROWS = 16;  // rows per LDS stage of the top kind (full rows: 2 x 16 x 376 doubles = 94 KB)
+constexpr int GW_LS = 376;   // LDS row stride of the top kind (23 tile columns + 8)
+template <int WS> struct WideCols {
+  static constexpr int NT = GR_NT + WS;
+  static constexpr int col_tiles(int j) { return j + 1 < WS ? j + 1 : WS; } // tiles of column j in tile rows 0 .. WS-1
+  static constexpr int tiles_upto(int j) {
+    int t = 0;
+    for (int q = 0; q < j; q++) t += col_tiles(q);
+    return t;
+  }
+  static constexpr int total = tiles_upto(NT);
+  static constexpr int cut(int w) { // first column of wavefront w (4: one past the last)
+    if (w <= 0) return 0;
+    if (w >= 4) return NT;
+    int j = 0;
+    while (j < NT && 4 * tiles_upto(j) < w * total) j++;
+    return j;
+  }
+  static constexpr int share(int w) { return tiles_upto(cut(w + 1)) - tiles_upto(cut(w)); }
+  static constexpr int acc_max() {
+    int m = 0;
+    for (int w = 0; w < 4; w++) m = share(w) > m ? share(w) : m;
+    return m;
+  }
+};
+inline size_t gram_wide_top_lds_bytes() { return (size_t)2 * GW_ROWS * GW_LS * sizeof(double); }
+
+template <int WS, int W, int ACC> __device__ __forceinline__ void gram_stage_top(const double *cur, int lane, d4 (&acc)[ACC]) {
+  using WC = WideCols<WS>;
+  constexpr int J0 = WC::cut(W), J1 = WC::cut(W + 1);
+  const int g = lane >> 4, cl = lane & 15;
+#pragma unroll 2
+  for (int k0 = 0; k0 < GW_ROWS; k0 += 4) {
+    const double *rowp = cur + (k0 + g) * GW_LS + cl;
+    double a[WS], b[J1 - J0];
+#pragma unroll
+    for (int i = 0; i < WS; i++) a[i] = rowp[16 * i];
+#pragma unroll
+    for (int j = J0; j < J1; j++) b[j - J0] = j < WS ? a[j < WS ? j : 0] : rowp[16 * j];
+    int idx = 0;
+#pragma unroll
+    for (int j = J0; j < J1; j++) {
+#pragma unroll
+      for (int i = 0; i < WS; i++) {
+        if (i <= j) {
+          GRAM_MFMA(a[i], b[j - J0], acc[idx]);
+          idx++;
+        }
+      }
+    }
+  }
+}
+template <int WS, int W, int ACC> __device__ __forceinline__ void gram_put_top(double *out, int lane, const d4 (&acc)[ACC]) {
+  using WC = WideCols<WS>;
+  constexpr int J0 = WC::cut(W), J1 = WC::cut(W + 1);
+  int idx = 0;
+#pragma unroll
+  for (int j = J0; j < J1; j++) {
+#pragma unroll
+    for (int i = 0; i < WS; i++) {
+      if (i <= j) {
+        double2 *o = reinterpret_cast<double2 *>(out + (size_t)pair_index(WC::NT, i, j) * 256) + lane;
+        o[0] = double2{acc[idx][0], acc[idx][1]}, o[64] = double2{acc[idx][2], acc[idx][3]};
+        idx++;
+      }
+    }
+  }
+}
+// window kind: k_gram's tiles (ti, tj) are tiles (ti + WS, tj + WS) of the wide grid
+template <int W> __device__ __forceinline__ void gram_put_window(double *out, int NT, int WS, int lane, const d4 (&acc)[GR_ACC]) {
+  using WR = WaveRows<W>;
+  auto put = [&](int ti, int tj, const d4 &a) {
+    double2 *o = reinterpret_cast<double2 *>(out + (size_t)pair_index(NT, ti + WS, tj + WS) * 256) + lane;
+    o[0] = double2{a[0], a[1]}, o[64] = double2{a[2], a[3]};
+  };
+#pragma unroll
+  for (int j = WR::R0; j < GR_NT; j++) put(WR::R0, j, acc[WR::O0 + j - WR::R0]);
+#pragma unroll
+  for (int j = WR::R1; j < GR_NT; j++) put(WR::R1, j, acc[WR::O1 + j - WR::R1]);
+#pragma unroll
+  for (int j = WR::R2; j < GR_NT; j++) put(WR::R2, j, acc[WR::O2 + j - WR::R2]);
+#pragma unroll
+  for (int j = WR::R3; j < GR_NT; j++) put(WR::R3, j, acc[WR::O3 + j - WR::R3]);
+}
+
+template <int WS> __global__ void __launch_bounds__(256) k_gram_wide_top(GramParams p) {
+  extern __shared__ double gram_lds[];
+  using WC = WideCols<WS>;
+  constexpr int NT = WC::NT, NP = NT * (NT + 1) / 2;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int LD = p.LD;
+  double *out = p.part + (size_t)blockIdx.x * NP * 256;
+  {
+    // ------------------------------------------------------------------ tile rows 0 .. WS-1, all columns
+    constexpr int ACC = WC::acc_max();
+    for (int i = tid; i < 2 * GW_ROWS * GW_LS; i += 256) gram_lds[i] = 0.0; // columns LD .. are never written
+    __syncthreads();
+    const int64_t nchunks = (p.rows_total + GW_ROWS - 1) / GW_ROWS;
+    const int chunk_begin = (int)((nchunks * blockIdx.x) / gridDim.x), chunk_end = (int)((nchunks * (blockIdx.x + 1)) / gridDim.x);
+    d4 acc[ACC];
+#pragma unroll
+    for (int i = 0; i < ACC; i++) acc[i] = d4{0, 0, 0, 0};
+    constexpr int NQ = (GW_ROWS * 16 * NT + 255) / 256; // >= ceil(GW_ROWS * LD / 256), compile-time: the loads stay in one basic block
+    const int row0 = tid / LD, col0 = tid - row0 * LD, step_r = 256 / LD, step_c = 256 - step_r * LD;
+    constexpr int SCRATCH = GW_LS - 1;
+    double v[NQ];
+    int left = 0;
+    auto fetch = [&](int chunk) {
+      const int64_t first = (int64_t)chunk * GW_ROWS;
+      const int64_t left64 = (p.rows_total - first) * LD;
+      left = (int)(left64 < (int64_t)GW_ROWS * LD ? left64 : (int64_t)GW_ROWS * LD);
+      const double *src = p.H + first * LD;
+#pragma unroll
+      for (int q = 0; q < NQ; q++) {
+        const int e = tid + 256 * q;
+        v[q] = src[e < left ? e : left - 1];
+      }
+    };
+    auto stash = [&](double *buf) {
+      int r = row0, cc = col0;
+#pragma unroll
+      for (int q = 0; q < NQ; q++) {
+        buf[r < GW_ROWS ? r * GW_LS + cc : SCRATCH] = (tid + 256 * q) < left ? v[q] : 0.0;
+        r += step_r, cc += step_c;
+        if (cc >= LD) cc -= LD, r++;
+      }
+    };
+    if (chunk_begin < chunk_end) {
+      fetch(chunk_begin);
+      stash(gram_lds);
+    }
+    __syncthreads();
+    for (int chunk = chunk_begin; chunk < chunk_end; chunk++) {
+      const double *cur = gram_lds + (size_t)((chunk - chunk_begin) & 1) * GW_ROWS * GW_LS;
+      double *nxt = gram_lds + (size_t)((chunk - chunk_begin + 1) & 1) * GW_ROWS * GW_LS;
+      const bool more = chunk + 1 < chunk_end;
+      if (more) fetch(chunk + 1);
+      switch (wave) {
+      case 0: gram_stage_top<WS, 0, ACC>(cur, lane, acc); break;
+      case 1: gram_stage_top<WS, 1, ACC>(cur, lane, acc); break;
+      case 2: gram_stage_top<WS, 2, ACC>(cur, lane, acc); break;
+      default: gram_stage_top<WS, 3, ACC>(cur, lane, acc); break;
+      }
+      if (more) stash(nxt);
+      __syncthreads();
+    }
+    switch (wave) {
+    case 0: gram_put_top<WS, 0, ACC>(out, lane, acc); break;
+    case 1: gram_put_top<WS, 1, ACC>(out, lane, acc); break;
+    case 2: gram_put_top<WS, 2, ACC>(out, lane, acc); break;
+    default: gram_put_top<WS, 3, ACC>(out, lane, acc); break;
+    }
+  }
+}
+
+// tile rows WS .. NT-1 over the column window [16 WS, 16 NT): thread = window column
+template <int WS> __global__ void __launch_bounds__(256) k_gram_wide_win(GramParams p) {
+  extern __shared__ double gram_lds[];
+  constexpr int NT = GR_NT + WS, NP = NT * (NT + 1) / 2;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int LD = p.LD;
+  double *out = p.part + (size_t)blockIdx.x * NP * 256;
+  const int64_t nchunks = (p.rows_total + GR_ROWS - 1) / GR_ROWS;
+  const int chunk_begin = (int)((nchunks * blockIdx.x) / gridDim.x), chunk_end = (int)((nchunks * (blockIdx.x + 1)) / gridDim.x);
+  d4 acc[GR_ACC];
+#pragma unroll
+  for (int i = 0; i < GR_ACC; i++) acc[i] = d4{0, 0, 0, 0};
+  const int wcol = 16 * WS + tid;
+  const bool colok = wcol < LD;
+  const int wcolc = colok ? wcol : LD - 1;
+  double v[GR_ROWS];
+  int64_t rows_left = 0;
+  auto fetch = [&](int chunk) {
+    const int64_t first = (int64_t)chunk * GR_ROWS;
+    rows_left = p.rows_total - first; // >= 1
+    const double *src = p.H + first * LD + wcolc;
+#pragma unroll
+    for (int q = 0; q < GR_ROWS; q++) v[q] = src[(size_t)(q < rows_left ? q : rows_left - 1) * LD];
+  };
+  auto stash = [&](double *buf) {
+#pragma unroll
+    for (int q = 0; q < GR_ROWS; q++) buf[q * GR_LS + tid] = (colok && q < rows_left) ? v[q] : 0.0;
+  };
+  if (chunk_begin < chunk_end) {
+    fetch(chunk_begin);
+    stash(gram_lds);
+  }
+  __syncthreads();
+  for (int chunk = chunk_begin; chunk < chunk_end; chunk++) {
+    const double *cur = gram_lds + (size_t)((chunk - chunk_begin) & 1) * GR_ROWS * GR_LS;
+    double *nxt = gram_lds + (size_t)((chunk - chunk_begin + 1) & 1) * GR_ROWS * GR_LS;
+    const bool more = chunk + 1 < chunk_end;
+    if (more) fetch(chunk + 1);
+    switch (wave) {
+    case 0: gram_stage<0, GR_NT>(cur, lane, acc); break;
+    case 1: gram_stage<1, GR_NT>(cur, lane, acc); break;
+    case 2: gram_stage<2, GR_NT>(cur, lane, acc); break;
+    default: gram_stage<3, GR_NT>(cur, lane, acc); break;
+    }
+    if (more) stash(nxt);
+    __syncthreads();
+  }
+  switch (wave) {
+  case 0: gram_put_window<0>(out, NT, WS, lane, acc); break;
+  case 1: gram_put_window<1>(out, NT, WS, lane, acc); break;
+  case 2: gram_put_window<2>(out, NT, WS, lane, acc); break;
+  default: gram_put_window<3>(out, NT, WS, lane, acc); break;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // More than 16 tile columns (BASELINE configs[4]: 50 clones, D = 356, 23 tile columns): the tile grid no longer fits the
 // accumulator registers of one workgroup, so it is cut into 8 x 8-tile blocks (column windows of 128) and blockIdx.y picks
 // the block pair (a <= b): every workgroup streams its rows once per pair, stages the two column windows in LDS and keeps the

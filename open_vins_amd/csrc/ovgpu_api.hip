@@ -184,6 +184,7 @@ struct ovgpu_ctx {
   hipEvent_t ev_lt = nullptr;       // the prior block's FACTOR kernel is done (L complete): the per-feature kernel waits for this, not for the carried columns
   bool lt_on_side = false;          // ev_lt is pending on the side stream
   bool cj_deferred = false;         // the factor kernel of a follow-on-main factorisation has not been joined yet (ev_cj)
+  bool gram_blocks_only = false;    // ovgpu_debug_option "gram_blocks_only": the block variant (k_gram_blk) also where k_gram_wide applies
   bool fuse_chol_inputs = true;     // ovgpu_debug_option "fuse_chol_inputs": the factorisations read their inputs at the source (no k_tf_gather / k_tf_abh)
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   DevBuf<int32_t> leaf_flags; // [W] panels of the last append finished by each leaf node
@@ -1153,6 +1154,20 @@ static int enqueue_compress_gram(ovgpu_ctx *c, bool factor = true) {
   HIPCHK(c->gram_G.reserve((size_t)LG * LG));
   gram::GramParams g;
   g.LD = LD, g.NT = NT, g.rows_total = c->rows_total, g.H = c->Hbig.p, g.part = c->gram_part.p;
+  if (NT == gram::GR_NT + 7 && !c->gram_fp32 && !c->gram_blocks_only) { // configs[4]'s 23 tile columns: two passes over the stack (k_gram_wide)
+    static bool attr_w = false;
+    if (!attr_w) {
+      (void)hipFuncSetAttribute((const void *)gram::k_gram_wide_top<7>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute((const void *)gram::k_gram_wide_win<7>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr_w = true;
+    }
+    const int Gw = G; // (every workgroup of either kernel writes its own tiles of partial blockIdx.x)
+    hipLaunchKernelGGL(gram::k_gram_wide_top<7>, dim3(Gw), dim3(256), gram::gram_wide_top_lds_bytes(), c->stream, g);
+    hipLaunchKernelGGL(gram::k_gram_wide_win<7>, dim3(Gw), dim3(256), gram::gram_lds_bytes(), c->stream, g);
+    hipLaunchKernelGGL(gram::k_gram_reduce, dim3(NP), dim3(256), 0, c->stream, NT, Gw, c->gram_part.p, c->gram_G.p);
+    HIPCHK(hipGetLastError());
+    return factor ? set_err(OVGPU_ERR_CAPACITY, "the Cholesky-QR variant holds at most 255 Jacobian columns") : OVGPU_OK;
+  }
   if (NT > gram::GR_NT || c->gram_fp32) { // more than 255 columns (configs[4]), or its fp32 variant: 8 x 8-tile blocks of the grid, one block pair per blockIdx.y
     const int NB = (NT + gram::GB_T - 1) / gram::GB_T, pairs = NB * (NB + 1) / 2;
     HIPCHK(c->gram_part.reserve((size_t)pairs * G * gram::GB_T * gram::GB_T * 256));
@@ -3005,6 +3020,9 @@ int ovgpu_debug_option(ovgpu_ctx *c, const char *name, int64_t value, int64_t *o
   } else if (n == "legacy_feature_kernel") { // 1: the three-sweep form of the MSCKF fast path (k_feat.h) instead of the fused one (k_featy.h)
     if (old_value) *old_value = c->legacy_feat_kernel ? 1 : 0;
     if (value >= 0) c->legacy_feat_kernel = value != 0;
+  } else if (n == "gram_blocks_only") {
+    if (old_value) *old_value = c->gram_blocks_only ? 1 : 0;
+    if (value >= 0) c->gram_blocks_only = value != 0;
   } else if (n == "stage_timing_period") {
     if (old_value) *old_value = c->timing_period;
     if (value >= 1) c->timing_period = (int)value, c->timing_seq = 0;
