@@ -59,6 +59,7 @@ struct CholParams {
   double inv_sigma2 = 0.0;
   const double *Y1 = nullptr;         // CH_SRC_WHITENED: [D x LA], the first factorisation's result
   const int32_t *pred_not = nullptr;  // optional: nothing happens when *pred_not != 0 (the not-SPD / time-out flag of an earlier factorisation)
+  int n_arrive = 0;                   // wavefronts of the factor workgroup that count themselves into prog[k] (set by the host: k_chol_factor 16, k_chol_factor2 15)
 };
 enum { CH_SRC_MATRIX = 0, CH_SRC_PRIOR = 1, CH_SRC_WHITENED = 2 };
 
@@ -252,6 +253,275 @@ __global__ void __launch_bounds__(64 * (CH_FW + 1), 4) k_chol_factor(CholParams 
 #undef CTJ
 }
 
+// ---------------------------------------------------------------------------------------------------
+// k_chol_factor2: the same factorisation WITHOUT workgroup barriers in the step loop.
+//
+// In k_chol_factor every step costs the chain wavefront ~16 kcycles for a 6-kcycle tile factorisation: it takes part in the
+// three s_barriers of the step, so it waits for the SLOWEST tile wavefront's panel solve (and that wavefront's stores) before it
+// may even look for the next diagonal tile.  Here the wavefronts synchronise through LDS words only:
+//   uinv_ready   chain -> tile wavefronts: U_kk^-1 of step k is in st1[k & 1]
+//   diag_ready   owner -> chain: diagonal tile k + 1 is in st0
+//   panel_cnt[k] tile wavefronts among themselves: row panel k is complete in panel[k & 1] (a counting barrier of the 15)
+// and the tiles are dealt so that ONE wavefront owns (k, k+1) and (k+1, k+1) (wavefront k: slots 0 and 1).  Right after
+// U_kk^-1 appears, that wavefront solves W_k,k+1, applies it to its diagonal tile straight from registers (the accumulator layout
+// of W IS the operand layout of W^T W), and hands the tile over: the chain wavefront factors tile k + 1 while the other fourteen are
+// still solving / storing / updating step k.  Double buffers (st1, panel) keep a fast wavefront's step k + 1 off a slow
+// wavefront's step k: a wavefront enters the panel solve of step k + 2 only after every wavefront has counted itself into
+// panel_cnt[k + 1], i.e. has finished reading panel[k & 1] and st1[k & 1].
+// Every wait is bounded (a wavefront that runs into the bound raises err / flags[0] like a follower does and leaves).
+// ---------------------------------------------------------------------------------------------------
+constexpr int CH_F2_SLOTS = 10; // 0: (w, w+1); 1: (w+1, w+1); 2 .. 8: the far tiles (j - i >= 2) dealt round-robin; 9: (0, 0) on wavefront 0
+inline size_t chol_factor2_lds_bytes() { return (size_t)(2 * CH_TMAX * 256 + 7 * 256 + 16 * CH_TMAX + 64) * sizeof(double); }
+
+__global__ void __launch_bounds__(64 * (CH_FW + 1), 4) k_chol_factor2(CholParams p) {
+  extern __shared__ __attribute__((aligned(16))) double f2_lds[];
+  double *panel = f2_lds;                       // [2][CH_TMAX][256]
+  double *st0 = panel + 2 * CH_TMAX * 256;      // [256] diagonal tile hand-over / the factorisation's scratch
+  double *st1 = st0 + 256;                      // [3][256] U_kk^-1, row-major
+  double *su = st1 + 3 * 256;                   // [3][256] U_kk, row-major (for the wavefront that writes it to memory)
+  double *d0s = su + 3 * 256;                   // [16 CH_TMAX] CH_SRC_PRIOR: the diagonal before the factorisation
+  int *sync = reinterpret_cast<int *>(d0s + 16 * CH_TMAX); // [0] diag_ready, [1] uinv_ready, [2] abort, [16 + k] tiles of row panel k in LDS,
+                                                           // [32 + k] tile wavefronts that are done with step k (its buffers may be reused)
+  if (chol_skipped(p)) return;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, cl = lane & 15;
+  const int D = p.D, LA = p.LA, TM = (D + 15) >> 4;
+  if (tid < 64) sync[tid] = 0;
+  if (p.src == CH_SRC_PRIOR && tid < 16 * CH_TMAX) d0s[tid] = tid < D ? p.P[(size_t)p.col_cov[tid] * p.N + p.col_cov[tid]] : 1.0;
+  const double *diag0 = p.src == CH_SRC_PRIOR ? d0s : p.diag0;
+  __syncthreads();
+  auto st_dev = [](double *ptr, double v) { __hip_atomic_store(ptr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+  auto arrive = [&](int k) { // this wavefront's stores of row k are complete
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) (void)__hip_atomic_fetch_add(p.prog + k, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  auto lds_ld = [&](int i) { return __hip_atomic_load(sync + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+  // waits until sync[i] >= want; false: the bound was hit (or another wavefront gave up)
+  auto wait_for = [&](int i, int want, bool relaxed = false) { // relaxed: nobody waits for this wavefront's reaction — poll less often
+    int spins = 0;
+    while (lds_ld(i) < want) {
+      if (relaxed) __builtin_amdgcn_s_sleep(4);
+      else __builtin_amdgcn_s_sleep(1);
+      if (++spins > (1 << 21) || lds_ld(2) != 0) {
+        if (lane == 0) {
+          __hip_atomic_store(sync + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          p.err[0] = 1;
+          __hip_atomic_store(p.flags, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (p.pred) *const_cast<int32_t *>(p.pred) = 0;
+        }
+        return false;
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    return true;
+  };
+  auto publish = [&](int i, int v) { // this wavefront's LDS writes first
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_store(sync + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  };
+
+  if (wv == CH_FW) {
+    // ------------------------------------------------------------------ the diagonal chain: LDS in, LDS out, nothing else
+    __builtin_amdgcn_s_setprio(3); // ahead of the three tile wavefronts on this SIMD whenever it has an instruction ready
+    long long c_wait = 0, c_fact = 0;
+    const long long c_begin = clock64();
+    for (int k = 0; k < TM; k++) {
+      const long long c0 = clock64();
+      if (!wait_for(0, k + 1)) return;
+      const long long c1 = clock64();
+      c_wait += c1 - c0;
+      d4 sv, ev;
+#pragma unroll
+      for (int q = 0; q < 4; q++) sv[q] = st0[(g + 4 * q) * 16 + cl];
+      __builtin_amdgcn_wave_barrier(); // st0 becomes the factorisation's scratch
+      const bool bad = feat::diag_tile_factor_blk(sv, ev, st0, lane, diag0 ? diag0 + 16 * k : nullptr, p.pivot_tol, D - 16 * k);
+      c_fact += clock64() - c1;
+      if (bad && lane == 0) __hip_atomic_store(p.flags, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (k >= 3 && !wait_for(32 + k - 3, CH_FW)) return; // (long satisfied: the buffers of step k - 3 are free)
+      double *s1 = st1 + (k % 3) * 256, *sk = su + (k % 3) * 256;
+#pragma unroll
+      for (int q = 0; q < 4; q++) s1[cl * 16 + g + 4 * q] = ev[q], sk[(g + 4 * q) * 16 + cl] = sv[q]; // U^-T in accumulator layout -> U^-1 row-major; U_kk
+      publish(1, k + 1);
+      // (a store instruction holds its wavefront for ~600 cycles, and this is the chain: tile wavefronts write U_kk and U_kk^-1 out)
+    }
+    if (p.dbg && lane == 0) p.dbg[310] += clock64() - c_begin, p.dbg[311] += c_wait, p.dbg[312] += c_fact, p.dbg[313] += 1;
+    return;
+  }
+
+  // -------------------------------------------------------------------- tile wavefronts
+  int tij[CH_F2_SLOTS]; // (j << 8) | i, or -1
+  d4 acc[CH_F2_SLOTS];
+#pragma unroll
+  for (int s = 0; s < CH_F2_SLOTS; s++) {
+    int i = -1, j = 0;
+    if (s == 0) {
+      if (wv + 1 < TM) i = wv, j = wv + 1;
+    } else if (s == 1) {
+      if (wv + 1 < TM) i = wv + 1, j = wv + 1;
+    } else if (s == 9) {
+      if (wv == 0) i = 0, j = 0;
+    } else { // far tile number f = (s - 2) CH_FW + wv, column by column: column j >= 2 holds rows 0 .. j-2
+      int f = (s - 2) * CH_FW + wv;
+      j = 2;
+      while (j < TM && f >= j - 1) f -= j - 1, j++;
+      if (j < TM) i = f;
+    }
+    tij[s] = i < 0 ? -1 : ((j << 8) | i);
+    d4 v = {0.0, 0.0, 0.0, 0.0};
+    if (i >= 0) {
+#pragma unroll
+      for (int q = 0; q < 4; q++) v[q] = ld_a(p, 16 * i + g + 4 * q, 16 * j + cl);
+    }
+    acc[s] = v;
+  }
+#define CTI(s) (tij[s] & 255)
+#define CTJ(s) (tij[s] >> 8)
+  if (wv == 0) { // tile (0, 0) to the chain wavefront
+#pragma unroll
+    for (int q = 0; q < 4; q++) st0[(g + 4 * q) * 16 + cl] = acc[9][q];
+    publish(0, 1);
+  }
+  // Tile (k, j) of U, row-major in LDS at `tile` -> memory: Y (write-through for the followers when to_followers) and, transposed,
+  // L = U^T: four consecutive doubles of a column per lane (the per-lane transposed stores of the accumulator layout touch 64
+  // cache lines per instruction).
+  auto store_row_tile = [&](int k, int j, const double *tile, bool to_followers) {
+    const bool whole = 16 * k + 16 <= D && 16 * j + 16 <= D;
+    double w[4], t[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) w[q] = tile[(g + 4 * q) * 16 + cl];
+    const int cc = lane >> 2, r0 = 4 * (lane & 3);
+    if (p.Lt && whole) {
+#pragma unroll
+      for (int q = 0; q < 4; q++) t[q] = tile[(r0 + q) * 16 + cc];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int r = 16 * k + g + 4 * q, c = 16 * j + cl;
+      if (r < D && c < D) {
+        if (to_followers) st_dev(p.Y + (size_t)r * LA + c, w[q]);
+        else p.Y[(size_t)r * LA + c] = w[q];
+        if (p.Lt && !whole) p.Lt[(size_t)c * D + r] = w[q];
+      }
+    }
+    if (p.Lt && whole) {
+      double *dst = p.Lt + (size_t)(16 * j + cc) * D + 16 * k + r0;
+      if ((D & 1) == 0) {
+        reinterpret_cast<double2 *>(dst)[0] = double2{t[0], t[1]};
+        reinterpret_cast<double2 *>(dst)[1] = double2{t[2], t[3]};
+      } else {
+        dst[0] = t[0], dst[1] = t[1], dst[2] = t[2], dst[3] = t[3];
+      }
+    }
+  };
+  // row kk of U, U_kk and U_kk^-1 -> memory, by their LDS copies; then this wavefront is done with step kk's buffers
+  auto row_to_memory = [&](int kk) {
+    const double *pn = panel + (size_t)(kk & 1) * CH_TMAX * 256;
+    if (kk > 0) arrive(kk - 1); // the stores of row kk - 1 were issued a step ago
+    if (wv == kk && kk + 1 < TM) store_row_tile(kk, kk + 1, pn + (size_t)(kk + 1) * 256, true);
+#pragma unroll
+    for (int s = 2; s < 9; s++)
+      if (tij[s] >= 0 && CTI(s) == kk) store_row_tile(kk, CTJ(s), pn + (size_t)CTJ(s) * 256, true);
+    if (wv == (kk + 5) % CH_FW) store_row_tile(kk, kk, su + (kk % 3) * 256, false); // U_kk -> Y and L
+    if (wv == (kk + 10) % CH_FW) {                                                 // U_kk^-1 -> memory for the followers
+      const double *s1 = st1 + (kk % 3) * 256;
+      double e4[4];
+#pragma unroll
+      for (int t = 0; t < 4; t++) e4[t] = s1[lane + 64 * t];
+#pragma unroll
+      for (int t = 0; t < 4; t++) st_dev(p.uinv + (size_t)kk * 256 + lane + 64 * t, e4[t]);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane == 0) (void)__hip_atomic_fetch_add(sync + 32 + kk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  };
+  long long t_uinv = 0, t_st = 0, t_panel = 0, t_cnt = 0, t_trail = 0;
+  const long long t_begin = clock64();
+  for (int k = 0; k < TM; k++) {
+    const long long t0 = clock64();
+    if (!wait_for(1, k + 1, wv != k)) return; // (wavefront k is the one the chain waits for)
+    const long long t1 = clock64();
+    t_uinv += t1 - t0;
+    double *pan = panel + (size_t)(k & 1) * CH_TMAX * 256;
+    int wrote = 0;
+    double ua[4];
+    {
+      const double *s1 = st1 + (k % 3) * 256;
+#pragma unroll
+      for (int u = 0; u < 4; u++) ua[u] = s1[(4 * u + g) * 16 + cl];
+    }
+    // (a) the pair first: W_k,k+1, the next diagonal tile, hand-over
+    if (wv == k && k + 1 < TM) {
+      __builtin_amdgcn_s_setprio(2); // the chain waits for this
+      d4 w = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int u = 0; u < 4; u++) FEAT_MFMA(ua[u], acc[0][u], w);
+      d4 av = acc[1];
+#pragma unroll
+      for (int u = 0; u < 4; u++) FEAT_MFMA(-w[u], w[u], av); // S_k+1,k+1 -= W^T W: lane (g, cl) holds W[4u + g][cl] in w[u]
+#pragma unroll
+      for (int q = 0; q < 4; q++) st0[(g + 4 * q) * 16 + cl] = av[q];
+      publish(0, k + 2);
+      __builtin_amdgcn_s_setprio(0);
+      if (p.dbg && lane == 0) p.dbg[340] += clock64() - t1, p.dbg[341] += t1 - t0, p.dbg[342] += 1;
+      acc[1] = av;
+      if (k >= 2 && !wait_for(32 + k - 2, CH_FW)) return; // every wavefront is done with row panel k - 2 (long satisfied): its buffer is free
+      double *pt = pan + (size_t)(k + 1) * 256;
+#pragma unroll
+      for (int q = 0; q < 4; q++) pt[(g + 4 * q) * 16 + cl] = w[q];
+      wrote++;
+    }
+    // (b) the other tiles of row k
+    if (!(wv == k && k + 1 < TM) && k >= 2 && !wait_for(32 + k - 2, CH_FW)) return;
+#pragma unroll
+    for (int s = 2; s < 9; s++) {
+      if (tij[s] >= 0 && CTI(s) == k) {
+        d4 w = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int u = 0; u < 4; u++) FEAT_MFMA(ua[u], acc[s][u], w);
+        double *pt = pan + (size_t)CTJ(s) * 256;
+#pragma unroll
+        for (int q = 0; q < 4; q++) pt[(g + 4 * q) * 16 + cl] = w[q];
+        wrote++;
+      }
+    }
+    // row panel k is complete in LDS when its TM - 1 - k tiles are written: only their OWNERS are waited for — a wavefront that is
+    // still busy with the previous row's stores and owns nothing in this row holds nobody up
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const long long t3 = clock64();
+    t_panel += t3 - t1;
+    if (lane == 0 && wrote > 0) (void)__hip_atomic_fetch_add(sync + 16 + k, wrote, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (!wait_for(16 + k, TM - 1 - k)) return;
+    const long long t4 = clock64();
+    t_cnt += t4 - t3;
+    // (c) trailing update S_ij -= W_ki^T W_kj of this wavefront's tiles below row k (its next diagonal tile is done)
+#pragma unroll
+    for (int s = 0; s < 9; s++) {
+      if (tij[s] >= 0 && CTI(s) > k && !(s == 1 && wv == k)) {
+        const double *pi = pan + (size_t)CTI(s) * 256, *pj = pan + (size_t)CTJ(s) * 256;
+        double a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) a[u] = -pi[(4 * u + g) * 16 + cl], b[u] = pj[(4 * u + g) * 16 + cl];
+#pragma unroll
+        for (int u = 0; u < 4; u++) FEAT_MFMA(a[u], b[u], acc[s]);
+      }
+    }
+    const long long t5 = clock64();
+    t_trail += t5 - t4;
+    // (d) row k leaves for memory LAST: nothing in this workgroup waits for it (the followers do, one step behind).  Everything is
+    //     read back from LDS: the row panel (valid until step k + 2 overwrites its buffer — behind the counting barrier of step k + 1,
+    //     which this wavefront only joins after this point), U_kk / U_kk^-1 (three buffers, same argument one step further).
+    row_to_memory(k);
+    t_st += clock64() - t5;
+  }
+  arrive(TM - 1);
+  if (p.dbg && lane == 0 && (wv == 1 || wv == 7)) {
+    long long *d = p.dbg + (wv == 1 ? 320 : 330);
+    d[0] += clock64() - t_begin, d[1] += t_uinv, d[2] += t_st, d[3] += t_panel, d[4] += t_cnt, d[5] += t_trail, d[6] += 1;
+  }
+#undef CTI
+#undef CTJ
+}
+
 // followers: one wavefront per 16 carried columns (launched on a second stream next to k_chol_factor)
 __global__ void __launch_bounds__(64 * CH_NW, 2) k_chol_follow(CholParams p) {
   if (chol_skipped(p)) return;
@@ -283,7 +553,7 @@ __global__ void __launch_bounds__(64 * CH_NW, 2) k_chol_follow(CholParams p) {
     // wait for step k of the factor workgroup
     const long long f_w0 = clock64();
     int spins = 0;
-    while (__hip_atomic_load(p.prog + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < CH_FW + 1) {
+    while (__hip_atomic_load(p.prog + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < p.n_arrive) {
       __builtin_amdgcn_s_sleep(2);
       if (++spins > p.spin_limit) {
         // The factor workgroup never got scheduled next to us (a shared GPU, a full chip).  The carried columns stay unwritten, so

@@ -185,6 +185,7 @@ struct ovgpu_ctx {
   bool lt_on_side = false;          // ev_lt is pending on the side stream
   bool cj_deferred = false;         // the factor kernel of a follow-on-main factorisation has not been joined yet (ev_cj)
   bool gram_blocks_only = false;    // ovgpu_debug_option "gram_blocks_only": the block variant (k_gram_blk) also where k_gram_wide applies
+  bool chol_flag_sync = true;       // ovgpu_debug_option "chol_flag_sync": k_chol_factor2 (LDS flags instead of workgroup barriers in the step loop)
   bool fuse_chol_inputs = true;     // ovgpu_debug_option "fuse_chol_inputs": the factorisations read their inputs at the source (no k_tf_gather / k_tf_abh)
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   DevBuf<int32_t> leaf_flags; // [W] panels of the last append finished by each leaf node
@@ -1335,6 +1336,7 @@ static int enqueue_chol_carry(ovgpu_ctx *c, const EkfParams &p, hipStream_t s, d
     q.D = p.D, q.LA = p.LA, q.A = p.A, q.Y = p.Y, q.Lt = Lt, q.flags = p.flags, q.diag0 = p.diag0, q.pivot_tol = p.pivot_tol, q.pred = p.pred;
     q.prog = c->chol_prog.p + 16 * slot, q.uinv = c->chol_uinv.p + (size_t)slot * 16 * 256, q.err = p.flags + 2, q.dbg = c->dbg_cycles.p;
     q.spin_limit = c->chol_spin_limit;
+    q.n_arrive = c->chol_flag_sync ? chol::CH_FW : chol::CH_FW + 1;
     q.src = from.src, q.N = p.N, q.pred_not = p.pred_not;
     if (from.src != chol::CH_SRC_MATRIX) {
       const TformParams &t = *from.t;
@@ -1352,15 +1354,24 @@ static int enqueue_chol_carry(ovgpu_ctx *c, const EkfParams &p, hipStream_t s, d
     HIPCHK(hipEventRecord(c->ev_cf, s));
     HIPCHK(hipStreamWaitEvent(sf, c->ev_cf, 0));
     const dim3 gf((carried + chol::CH_NW - 1) / chol::CH_NW);
+    static bool attr_f2 = false;
+    if (!attr_f2) {
+      (void)hipFuncSetAttribute((const void *)chol::k_chol_factor2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)chol::chol_factor2_lds_bytes());
+      attr_f2 = true;
+    }
+    auto launch_factor = [&](hipStream_t on) {
+      if (c->chol_flag_sync) hipLaunchKernelGGL(chol::k_chol_factor2, dim3(1), dim3(64 * (chol::CH_FW + 1)), chol::chol_factor2_lds_bytes(), on, q);
+      else hipLaunchKernelGGL(chol::k_chol_factor, dim3(1), dim3(64 * (chol::CH_FW + 1)), 0, on, q);
+    };
     if (from.follow_first && carried > 0) {
       // the followers spin until the factor workgroup (one event hand-over later) publishes its first step; what follows them on `s`
       // starts when THEY are done, without a second hand-over
       hipLaunchKernelGGL(chol::k_chol_follow, gf, dim3(64 * chol::CH_NW), 0, s, q);
-      hipLaunchKernelGGL(chol::k_chol_factor, dim3(1), dim3(64 * (chol::CH_FW + 1)), 0, sf, q);
+      launch_factor(sf);
       HIPCHK(hipEventRecord(c->ev_cj, sf));
       c->cj_deferred = true;
     } else {
-      hipLaunchKernelGGL(chol::k_chol_factor, dim3(1), dim3(64 * (chol::CH_FW + 1)), 0, s, q);
+      launch_factor(s);
       if (Lt && c->ev_lt && c->prior_on_side) {
         HIPCHK(hipEventRecord(c->ev_lt, s));
         c->lt_on_side = true;
@@ -3020,6 +3031,9 @@ int ovgpu_debug_option(ovgpu_ctx *c, const char *name, int64_t value, int64_t *o
   } else if (n == "legacy_feature_kernel") { // 1: the three-sweep form of the MSCKF fast path (k_feat.h) instead of the fused one (k_featy.h)
     if (old_value) *old_value = c->legacy_feat_kernel ? 1 : 0;
     if (value >= 0) c->legacy_feat_kernel = value != 0;
+  } else if (n == "chol_flag_sync") {
+    if (old_value) *old_value = c->chol_flag_sync ? 1 : 0;
+    if (value >= 0) c->chol_flag_sync = value != 0;
   } else if (n == "gram_blocks_only") {
     if (old_value) *old_value = c->gram_blocks_only ? 1 : 0;
     if (value >= 0) c->gram_blocks_only = value != 0;
