@@ -549,23 +549,35 @@ __global__ void __launch_bounds__(256) k_gram_blk_reduce(int NB, int NT, int npa
 
 // Sum of the partials, workgroup order; one workgroup per tile pair writes the tile and its mirror image into the dense
 // symmetric G [LG x LG], LG = 16 NT.
-__global__ void __launch_bounds__(256) k_gram_reduce(int NT, int nparts, const double *part, double *G) {
+// 1024 threads: four groups of 256 take a quarter of the partials each (contiguous ranges, four running sums per thread), their
+// totals are added in group order through LDS.  (One group of 256 per tile pair left 91 workgroups x 4 wavefronts on 256 CUs with
+// four loads in flight per thread: 24 us for 48 MB, latency bound.)
+__global__ void __launch_bounds__(1024) k_gram_reduce(int NT, int nparts, const double *part, double *G) {
+  __shared__ double tot[4][256];
   const int NP = NT * (NT + 1) / 2, LG = 16 * NT;
-  const int idx = blockIdx.x, t = threadIdx.x;
+  const int idx = blockIdx.x, t = threadIdx.x & 255, grp = threadIdx.x >> 8;
   int ti = 0, rem = idx;
   while (rem >= NT - ti) rem -= NT - ti, ti++;
   const int tj = ti + rem;
   const double *src = part + (size_t)idx * 256 + t;
-  double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-  int w = 0;
-  for (; w + 4 <= nparts; w += 4) {
+  const int w_lo = (int)(((int64_t)nparts * grp) / 4), w_hi = (int)(((int64_t)nparts * (grp + 1)) / 4);
+  double s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0, s6 = 0, s7 = 0;
+  int w = w_lo;
+  for (; w + 8 <= w_hi; w += 8) {
     s0 += src[(size_t)(w + 0) * NP * 256];
     s1 += src[(size_t)(w + 1) * NP * 256];
     s2 += src[(size_t)(w + 2) * NP * 256];
     s3 += src[(size_t)(w + 3) * NP * 256];
+    s4 += src[(size_t)(w + 4) * NP * 256];
+    s5 += src[(size_t)(w + 5) * NP * 256];
+    s6 += src[(size_t)(w + 6) * NP * 256];
+    s7 += src[(size_t)(w + 7) * NP * 256];
   }
-  for (; w < nparts; w++) s0 += src[(size_t)w * NP * 256];
-  const double s = (s0 + s1) + (s2 + s3);
+  for (; w < w_hi; w++) s0 += src[(size_t)w * NP * 256];
+  tot[grp][t] = ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7));
+  __syncthreads();
+  if (grp != 0) return;
+  const double s = (tot[0][t] + tot[1][t]) + (tot[2][t] + tot[3][t]);
   const int q = 2 * (t >> 7) + (t & 1), lane = (t >> 1) & 63; // slot t = h * 128 + 2 * lane + e holds register q = 2 h + e
   const int i = 16 * ti + 4 * q + (lane >> 4), j = 16 * tj + (lane & 15);
   G[(size_t)i * LG + j] = s;

@@ -1165,7 +1165,7 @@ static int enqueue_compress_gram(ovgpu_ctx *c, bool factor = true) {
     const int Gw = G; // (every workgroup of either kernel writes its own tiles of partial blockIdx.x)
     hipLaunchKernelGGL(gram::k_gram_wide_top<7>, dim3(Gw), dim3(256), gram::gram_wide_top_lds_bytes(), c->stream, g);
     hipLaunchKernelGGL(gram::k_gram_wide_win<7>, dim3(Gw), dim3(256), gram::gram_lds_bytes(), c->stream, g);
-    hipLaunchKernelGGL(gram::k_gram_reduce, dim3(NP), dim3(256), 0, c->stream, NT, Gw, c->gram_part.p, c->gram_G.p);
+    hipLaunchKernelGGL(gram::k_gram_reduce, dim3(NP), dim3(1024), 0, c->stream, NT, Gw, c->gram_part.p, c->gram_G.p);
     HIPCHK(hipGetLastError());
     return factor ? set_err(OVGPU_ERR_CAPACITY, "the Cholesky-QR variant holds at most 255 Jacobian columns") : OVGPU_OK;
   }
@@ -1195,7 +1195,7 @@ static int enqueue_compress_gram(ovgpu_ctx *c, bool factor = true) {
   case 7: launch_gram<14>(G, g, c->stream); break;
   default: launch_gram<16>(G, g, c->stream); break;
   }
-  hipLaunchKernelGGL(gram::k_gram_reduce, dim3(NP), dim3(256), 0, c->stream, NT, G, c->gram_part.p, c->gram_G.p);
+  hipLaunchKernelGGL(gram::k_gram_reduce, dim3(NP), dim3(1024), 0, c->stream, NT, G, c->gram_part.p, c->gram_G.p);
   HIPCHK(hipGetLastError());
   return factor ? enqueue_gram_factor(c) : OVGPU_OK;
 }
