@@ -21,6 +21,7 @@ Rank 0 prints ONE JSON line with the contract fields plus
                      SURVEY.md 8(d) of the features that reach the gate / its HIP-event time on the context's stream, against
                      the FP64 peak; `compression` = the same for the Gram accumulation on the matrix cores
   pcie_inclusive_ms  host buffers -> HBM -> update -> results back in host memory (never `value`)
+  mode_a             ovgpu_msckf_compress host to host (the shims' unpatched mode): default route and Householder TSQR
   cpu_baseline       the oracle (float64 restatement of the reference's serial Eigen path) on this host: 1 thread, and all cores
                      for the per-feature loops; bounded sample, 5 repetitions after a warm-up, median.
 """
@@ -294,6 +295,7 @@ def main(argv=None):
         out.update(extras)
         if world == 1 and not args.no_extras:
             out["pcie_inclusive_ms"] = pcie_inclusive_ms(prob, opts, local_rank)
+            out["mode_a"] = mode_a_ms(prob, opts, local_rank, capi)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(prob, opts)
         print(json.dumps(out), flush=True)
@@ -320,6 +322,29 @@ def pcie_inclusive_ms(prob, opts, device):
         ts.append(time.perf_counter() - t)
     up.close()
     return 1e3 * sorted(ts)[len(ts) // 2]
+
+
+def mode_a_ms(prob, opts, device, capi):
+    """Mode A — what the shims do WITHOUT the friend patch: ovgpu_msckf_compress returns the compressed (H, r) to the host for the stock
+    StateHelper::EKFUpdate.  Host to host with the snapshot resident (the call itself: kernels + read-back of status, chi2, p_FinG,
+    H, r), median of 9, default route (pivoted Cholesky factor of the whitened Gram matrix) and the Householder TSQR."""
+    import copy
+    from open_vins_amd.updater import UpdaterMSCKF
+    res = {}
+    for name, route in (("default_pivoted_gram_factor", capi.COMPRESS_GRAM), ("householder_tsqr", capi.COMPRESS_TSQR)):
+        o = copy.copy(opts)
+        o.compress_route = route
+        up = UpdaterMSCKF(o, device=device)
+        up.set_problem(prob)
+        up.compress()
+        ts = []
+        for _ in range(9):
+            t = time.perf_counter()
+            c = up.compress()
+            ts.append(time.perf_counter() - t)
+        res[name] = {"ms_host_to_host": 1e3 * sorted(ts)[len(ts) // 2], "rows": int(c["rows"]), "route_reported": int(up.lib.ovgpu_last_update_route(up._ctx))}
+        up.close()
+    return res
 
 
 def pmc_traffic_bytes(cfg):

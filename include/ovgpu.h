@@ -134,13 +134,20 @@ typedef struct {
                              /* f64 result (tests/test_gpu_fullsize.py)        */
 } ovgpu_options;
 
-/* Measurement compression (UpdaterHelper.cpp:456-487) of ovgpu_msckf_update / ovgpu_slam_update:           */
+/* Measurement compression (UpdaterHelper.cpp:456-487) of ovgpu_msckf_update / ovgpu_slam_update (mode B) and  */
+/* of ovgpu_msckf_compress (mode A: the compressed system leaves the device):                                */
 typedef enum {
-  OVGPU_COMPRESS_GRAM = 0,   /* Gram matrix of the prior-whitened stack on the matrix cores + the update in */
-                             /* whitened coordinates (default; D <= 255 columns)                            */
-  OVGPU_COMPRESS_TSQR = 1,   /* Householder TSQR + the reference-shaped update (always used when the factor */
-                             /* itself is returned: ovgpu_msckf_compress, ovgpu_measurement_compress)       */
-  OVGPU_COMPRESS_CHOLQR = 2  /* R = chol(Gram): kept as the measured negative result of DESIGN.md section 4  */
+  OVGPU_COMPRESS_GRAM = 0,   /* default.  Mode B: Gram matrix of the prior-whitened stack on the matrix cores + */
+                             /* the update in whitened coordinates (D <= 383 columns).  Mode A: the DIAGONALLY  */
+                             /* PIVOTED Cholesky factor of that Gram matrix, un-whitened — a dense rank x D     */
+                             /* system with H^T H, H^T r of the stack (D <= 255; Householder beyond, for SLAM   */
+                             /* stacks and when the prior block's factorisation fails)                          */
+  OVGPU_COMPRESS_TSQR = 1,   /* Householder TSQR: the reference's upper-triangular factor (mode A) + the        */
+                             /* reference-shaped update (mode B); always used by ovgpu_measurement_compress     */
+  OVGPU_COMPRESS_CHOLQR = 2, /* R = chol(Gram), UNPIVOTED: kept as the measured negative result of DESIGN.md    */
+                             /* section 4 (closed-loop drift 6e-6)                                              */
+  OVGPU_COMPRESS_PCHOLQR = 3 /* what ovgpu_last_update_route reports after a mode A call that took the pivoted  */
+                             /* factor; as an option it is an alias of OVGPU_COMPRESS_GRAM                      */
 } ovgpu_compress_route;
 
 /* Fills *o with the reference defaults. */
@@ -323,10 +330,18 @@ int ovgpu_msckf_update(ovgpu_ctx *ctx, int32_t *feat_status, double *chi2,
  * StateHelper::EKFUpdate.
  *   D_out          number of columns
  *   col_cov_id [D] covariance index of every column of H (canonical order)
- *   H   [rows*D]   compressed Jacobian (upper-triangular when rows == D)
+ *   H   [rows*D]   compressed Jacobian
  *   r   [rows]     compressed residual
- *   rows_out       min(ct_meas, D)
- * H, r, col_cov_id must hold Dmax = 6*C + 14*K columns / rows.               */
+ *   rows_out       <= D
+ * H, r, col_cov_id must hold Dmax = 6*C + 14*K columns / rows.
+ * What EKFUpdate needs from (H, r) is H^T H and H^T r (StateHelper.cpp:131-160 uses H only through H P H^T, P H^T
+ * and H^T-weighted residuals), and both forms below carry the stack's:
+ *   default (OVGPU_COMPRESS_GRAM)  the diagonally pivoted Cholesky factor of the prior-whitened stack's Gram
+ *                                  matrix, un-whitened: DENSE, rows = its numerical rank (the stack of an MSCKF
+ *                                  update has a null space: gauge directions) — 1.8 ms host to host at 2000 features
+ *   OVGPU_COMPRESS_TSQR            the reference's form, the upper-triangular Householder factor, rows = D
+ *                                  (4.0 ms); also taken beyond 255 columns and when the prior block's
+ *                                  factorisation fails.  ovgpu_last_update_route tells which one came back. */
 int ovgpu_msckf_compress(ovgpu_ctx *ctx, int32_t *feat_status, double *chi2,
                          double *chi2_thresh, double *p_FinG, int32_t *D_out,
                          int32_t *rows_out, int32_t *col_cov_id, double *H,

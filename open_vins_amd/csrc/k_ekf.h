@@ -615,20 +615,41 @@ __global__ void __launch_bounds__(256) k_unwhiten(int D, int LD, double *__restr
   if (pred && *pred == 0) return;
   const int tid = threadIdx.x, r = tid >> 4, l = tid & 15;
   const int row = blockIdx.x * 16 + r;
-  for (int c = l; c < D; c += 16) X[r][c] = row < D ? R[(size_t)row * LD + c] : 0.0;
+  for (int c = l; c < 256; c += 16) X[r][c] = (row < D && c < D) ? R[(size_t)row * LD + c] : 0.0;
   auto wsync = [] {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   };
+  // Row j of U1 for step j is fetched during step j + 1 (a lane's sixteen entries k = l + 16 q, clamped, and the diagonal entry):
+  // the chain of D column steps then runs on LDS and lane shuffles only (fetched inside the step it was 2 us of memory latency per
+  // column, 0.45 ms at D = 208 — more than the Gram matrix and its factorisation together).
+  auto fetch = [&](int j, double (&u)[16], double &ujj) {
+    const double *src = Y1 + (size_t)(j < 0 ? 0 : j) * LA;
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+      const int k = l + 16 * q;
+      u[q] = src[k < D ? k : D - 1];
+    }
+    ujj = src[j < 0 ? 0 : j];
+  };
+  double uc[16], un[16], dc, dn;
+  fetch(D - 1, uc, dc);
   wsync();
   for (int j = D - 1; j >= 0; j--) {
-    const double *u = Y1 + (size_t)j * LA;
+    fetch(j - 1, un, dn);
     double s = 0.0;
-    for (int k = j + 1 + l; k < D; k += 16) s = fma(X[r][k], u[k], s);
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+      const int k = l + 16 * q;
+      s = fma(X[r][k], (k > j && k < D) ? uc[q] : 0.0, s);
+    }
     s += __shfl_xor(s, 8, 16), s += __shfl_xor(s, 4, 16), s += __shfl_xor(s, 2, 16), s += __shfl_xor(s, 1, 16);
-    if (l == 0) X[r][j] = (X[r][j] - s) / u[j];
+    if (l == 0) X[r][j] = (X[r][j] - s) / dc;
     wsync();
+#pragma unroll
+    for (int q = 0; q < 16; q++) uc[q] = un[q];
+    dc = dn;
   }
   if (row < D)
     for (int c = l; c < D; c += 16) R[(size_t)row * LD + c] = X[r][c];

@@ -687,5 +687,162 @@ __global__ void __launch_bounds__(1024) k_gram_chol(int D, int LD, int LG, const
   if (tid == 0 && n_dropped) *n_dropped = drops;
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// Diagonally PIVOTED Cholesky of the whitened stack's Gram matrix: mode A (ovgpu_msckf_compress) at the cost of the Gram route.
+//
+// The whitened Gram matrix G_w = L^T H^T H L is positive SEMI-definite (gauge directions, weakly observed calibration), and the
+// unpivoted factorisation above is not backward stable there: a pivot that is pure rounding noise divides the rest of its row, and
+// the closed loop drifts 7e-6 in 52 frames.  With diagonal pivoting the computed factor satisfies
+// R^T R = G_w + O(eps |G_w|) whatever the rank (Higham, Accuracy and Stability of Numerical Algorithms, thm 10.14), which is the
+// error the Gram matrix carries anyway — measured: the same loop stays at 1e-13, the level of the Householder triangle
+// (tools/dev_mode_a_numerics.py on the CPU, tests/test_closed_loop.py::test_mode_a_closed_loop on the device).
+//
+// No row or column is ever moved: step k eliminates the live column p_k with the largest remaining diagonal entry and writes
+// row k of R in the ORIGINAL column order (zeros in the columns eliminated before), i.e. R = (triangular) x (permutation)^T — still
+// R^T R = G_w, and the un-whitened X = R L^-1 is dense either way.  The matrix sits in registers as in k_gram_chol (upper block
+// triangle, thread (ti, tj) holds (ti + 32 bi, tj + 32 bj), bj >= bi, diagonal blocks in full); row p of the symmetric matrix is
+// then a[bp][bj >= bp] of the 32 threads ti = p & 31 plus a[bi < bp][bp] of the 32 threads tj = p & 31.  Wavefront 0 keeps a copy of
+// the diagonal (four entries per lane, updated with the same fma as the matrix: bit-identical) and picks the next pivot while the
+// others apply the rank-one update; two workgroup barriers per step.  The factorisation stops at the first pivot that is not above
+// tol x the largest diagonal entry (the rest of the Schur complement is rounding noise of the Gram sum): the remaining rows are zero.
+// ---------------------------------------------------------------------------------------------------
+template <int NB>
+__global__ void __launch_bounds__(1024) k_gram_pchol(int D, int LD, int LG, const double *G, double *out, int32_t *n_dropped, double tol) {
+  extern __shared__ double rstore[]; // [2][CH_FLUSH][LD] finished rows on their way to memory
+  __shared__ __attribute__((aligned(16))) double rowbuf[2][32 * CH_NB];
+  __shared__ double alive[32 * CH_NB]; // 1 = column not eliminated yet (the carried column LD - 1 stays 1)
+  __shared__ double pivinv[2];         // 1 / sqrt(pivot) of the step
+  __shared__ int piv[2];               // its column, -1 = stop
+  const int tid = threadIdx.x, ti = tid >> 5, tj = tid & 31, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  double a[NB][NB];
+#pragma unroll
+  for (int bi = 0; bi < NB; bi++)
+#pragma unroll
+    for (int bj = 0; bj < NB; bj++) {
+      a[bi][bj] = 0.0;
+      if (bj >= bi) {
+        const int i = ti + 32 * bi, j = tj + 32 * bj;
+        if (i < LD && j < LD) a[bi][bj] = G[(size_t)i * LG + j];
+      }
+    }
+  if (tid < 32 * CH_NB) alive[tid] = tid < LD ? 1.0 : 0.0, rowbuf[0][tid] = 0.0, rowbuf[1][tid] = 0.0;
+  // wavefront 0: the diagonal of the live columns, entry j = lane + 64 q in dg[q]; eliminated or never eligible: DEAD
+  constexpr double DEAD = -1.0e300;
+  double dg[4] = {DEAD, DEAD, DEAD, DEAD}, dmax0 = 0.0;
+  // the live column with the largest diagonal entry (ties: the lowest column).  The comparison key is the entry's bit pattern with
+  // the column in its low byte — a pivot CHOICE may ignore the last 8 mantissa bits, the pivot's VALUE is then read exactly.
+  auto next_pivot = [&](int slot, bool first) {
+    long long key = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const long long kq = dg[q] > 0.0 ? ((__double_as_longlong(dg[q]) & ~0xFFll) | (long long)(255 - (lane + 64 * q))) : 0ll;
+      key = kq > key ? kq : key;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      const long long o = __shfl_xor(key, off, 64);
+      key = o > key ? o : key;
+    }
+    const int j = 255 - (int)(key & 0xFF);
+    double d = 0.0;
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+      if (q == (j >> 6)) d = dg[q];
+    d = __shfl(d, j & 63, 64);
+    if (first) dmax0 = d;
+    const bool go = key != 0 && d > tol * dmax0 && d > 0.0;
+    if (go) {
+#pragma unroll
+      for (int q = 0; q < 4; q++)
+        if (lane + 64 * q == j) dg[q] = DEAD;
+    }
+    if (lane == 0) piv[slot] = go ? j : -1, pivinv[slot] = go ? rsqrt_f64(d) : 0.0;
+  };
+  if (wv == 0) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int j = lane + 64 * q;
+      if (j < D) dg[q] = G[(size_t)j * LG + j];
+    }
+    next_pivot(0, true);
+  }
+  __syncthreads();
+  int rank = D;
+  for (int k = 0; k < D; k++) {
+    const int p = __builtin_amdgcn_readfirstlane(piv[k & 1]);
+    if (p < 0) {
+      rank = k;
+      break;
+    }
+    const int bp = p >> 5, pl = p & 31;
+    const double inv = pivinv[k & 1];
+    double *rb = rowbuf[k & 1];
+    if (ti == pl || tj == pl) {
+#pragma unroll
+      for (int b = 0; b < NB; b++)
+        if (b == bp) {
+          if (ti == pl) { // columns of the blocks from the pivot's block on: the stored part of row p
+#pragma unroll
+            for (int bj = b; bj < NB; bj++) rb[((bj >> 1) * 32 + tj) * 2 + (bj & 1)] = a[b][bj] * inv * alive[tj + 32 * bj];
+          }
+          if (tj == pl) { // columns of the blocks left of it: column p of the stored block rows above (the matrix is symmetric)
+#pragma unroll
+            for (int bi = 0; bi < b; bi++) rb[((bi >> 1) * 32 + ti) * 2 + (bi & 1)] = a[bi][b] * inv * alive[ti + 32 * bi];
+          }
+        }
+    }
+    __syncthreads();
+    if (wv == 0) { // the diagonal copy, then the next pivot (its column leaves the live set now: row k + 1 gets a zero there)
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const double r = rb[(q * 32 + (lane & 31)) * 2 + (lane >> 5)]; // column lane + 64 q = block 2 q + (lane >> 5), offset lane & 31
+        if (dg[q] != DEAD) dg[q] = fma(-r, r, dg[q]);
+      }
+      if (lane == 0) alive[p] = 0.0;
+      next_pivot((k + 1) & 1, false);
+    } else if (wv <= 4) { // row k of R, original column order, into the burst buffer
+      const int j = tid - 64;
+      if (j < LD) rstore[((size_t)((k / CH_FLUSH) & 1) * CH_FLUSH + (k % CH_FLUSH)) * LD + j] = rb[(((j >> 5) >> 1) * 32 + (j & 31)) * 2 + ((j >> 5) & 1)];
+    }
+    {
+      constexpr int NP = (NB + 1) / 2;
+      double rj[2 * NP];
+#pragma unroll
+      for (int m = 0; m < NP; m++) {
+        const double2 vj = *reinterpret_cast<const double2 *>(rb + (m * 32 + tj) * 2);
+        rj[2 * m] = vj.x, rj[2 * m + 1] = vj.y;
+      }
+#pragma unroll
+      for (int m = 0; m < NP; m++) { // the row factors pair by pair (all sixteen at once no longer fit next to 36 blocks: spills)
+        const double2 vi = *reinterpret_cast<const double2 *>(rb + (m * 32 + ti) * 2);
+#pragma unroll
+        for (int bj = 2 * m; bj < NB; bj++) a[2 * m][bj] = fma(-vi.x, rj[bj], a[2 * m][bj]);
+        if (2 * m + 1 < NB) {
+#pragma unroll
+          for (int bj = 2 * m + 1; bj < NB; bj++) a[2 * m + 1][bj] = fma(-vi.y, rj[bj], a[2 * m + 1][bj]);
+        }
+      }
+    }
+    __syncthreads();
+    if ((k % CH_FLUSH) == CH_FLUSH - 1 || k == D - 1) {
+      const int k0 = (k / CH_FLUSH) * CH_FLUSH, n = (k - k0 + 1) * LD;
+      const double *src = rstore + (size_t)((k / CH_FLUSH) & 1) * CH_FLUSH * LD;
+      double *dst = out + (size_t)k0 * LD;
+      for (int e = tid; e < n; e += 1024) dst[e] = src[e];
+    }
+  }
+  if (rank < D) { // stopped early: the burst in flight, then zero rows
+    const int k0 = (rank / CH_FLUSH) * CH_FLUSH, n = (rank - k0) * LD;
+    const double *src = rstore + (size_t)((rank / CH_FLUSH) & 1) * CH_FLUSH * LD;
+    double *dst = out + (size_t)k0 * LD;
+    for (int e = tid; e < n; e += 1024) dst[e] = src[e];
+    dst = out + (size_t)rank * LD;
+    for (int e = tid; e < (D - rank) * LD; e += 1024) dst[e] = 0.0;
+  }
+  if (tid == 0 && n_dropped) *n_dropped = D - rank;
+}
+
 } // namespace gram
 } // namespace ovg

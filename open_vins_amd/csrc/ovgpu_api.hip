@@ -249,6 +249,7 @@ struct ovgpu_ctx {
   bool force_tsqr = false;        // one-shot: the next pipeline takes the Householder route
   int chol_spin_limit = 1 << 22;  // k_chol_follow's wait bound (ovgpu_debug_option "chol_follow_spin_limit" lowers it to provoke the fall-back)
   int chol_timeouts = 0;          // how often update_with_fallbacks repeated an update with the step-wise kernels
+  int mode_a_factor = 0;          // where mode A's compressed factor comes from: 0 Householder TSQR, 1 chol(whitened Gram) (CHOLQR, negative result), 2 its diagonally pivoted form (PCHOLQR)
   bool factor_from_gram = false;  // one-shot (compress_impl): the compressed factor of mode A comes from the Gram matrix of the whitened stack
   bool last_factor_from_gram = false;
   bool chol_timed_out = false;    // finish_update: a follower of the single-launch Cholesky gave up waiting; nothing was modified
@@ -390,6 +391,15 @@ template <int NB> static void launch_gram_chol(hipStream_t s, int D, int LD, int
   hipLaunchKernelGGL(gram::k_gram_chol<NB>, dim3(1), dim3(1024), gram::chol_lds_bytes(LD), s, D, LD, LG, G, out, dropped);
 }
 
+template <int NB> static void launch_gram_pchol(hipStream_t s, int D, int LD, int LG, const double *G, double *out, int32_t *dropped, double tol) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void *)gram::k_gram_pchol<NB>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(gram::k_gram_pchol<NB>, dim3(1), dim3(1024), gram::chol_lds_bytes(LD), s, D, LD, LG, G, out, dropped, tol);
+}
+
 extern "C" {
 
 const char *ovgpu_last_error(void) { return g_err.c_str(); }
@@ -445,13 +455,14 @@ int ovgpu_create(const ovgpu_options *opts, int device, ovgpu_ctx **out) {
   c->row_stride = (d.feat_rep >= OVGPU_REP_ANCHORED_3D) ? 72 : 48;
   // allow the large dynamic LDS carve of the per-feature kernel
   // library switches are options of the context, not of the environment (include/ovgpu.h)
-  if (opts->compress_route < 0 || opts->compress_route > OVGPU_COMPRESS_CHOLQR || opts->tsqr_overlap < 0 || opts->tsqr_overlap > 2 || opts->tsqr_workers < 0) {
+  if (opts->compress_route < 0 || opts->compress_route > OVGPU_COMPRESS_PCHOLQR || opts->tsqr_overlap < 0 || opts->tsqr_overlap > 2 || opts->tsqr_workers < 0) {
     ovgpu_destroy(c); // (the stream and the control block exist already: a bare delete would leak them)
     return set_err(OVGPU_ERR_INVALID, "bad library switch in ovgpu_options");
   }
   c->tree_pipelined = opts->tsqr_no_pipeline == 0;
   c->prior_overlap = opts->no_prior_overlap == 0;
   c->compress_gram = opts->compress_route == OVGPU_COMPRESS_TSQR ? 0 : (opts->compress_route == OVGPU_COMPRESS_CHOLQR ? 2 : 1);
+  c->mode_a_factor = opts->compress_route == OVGPU_COMPRESS_CHOLQR ? 1 : (opts->compress_route == OVGPU_COMPRESS_TSQR ? 0 : 2);
   c->tree_overlap = opts->tsqr_overlap == 0 ? -1 : (opts->tsqr_overlap == 1 ? 1 : 0);
   c->whiten = opts->gram_no_whiten == 0;
   c->prior_pivot_tol = opts->prior_pivot_tol > 0.0 ? opts->prior_pivot_tol : 1e-13;
@@ -1204,6 +1215,22 @@ static int enqueue_compress_gram(ovgpu_ctx *c, bool factor = true) {
 static int enqueue_gram_factor(ovgpu_ctx *c) {
   const int D = c->D, LD = c->LD, LG = 16 * ((LD + 15) / 16);
   HIPCHK(c->gram_dropped.reserve(1));
+  if (c->mode_a_factor == 2) { // diagonally pivoted (k_gram_pchol): the stable factor of a semi-definite matrix
+    const double tol = 1e-15;
+    switch ((LD + 31) / 32) {
+    case 1: launch_gram_pchol<1>(c->stream, D, LD, LG, c->gram_G.p, c->Rws.p, c->gram_dropped.p, tol); break;
+    case 2: launch_gram_pchol<2>(c->stream, D, LD, LG, c->gram_G.p, c->Rws.p, c->gram_dropped.p, tol); break;
+    case 3: launch_gram_pchol<3>(c->stream, D, LD, LG, c->gram_G.p, c->Rws.p, c->gram_dropped.p, tol); break;
+    case 4: launch_gram_pchol<4>(c->stream, D, LD, LG, c->gram_G.p, c->Rws.p, c->gram_dropped.p, tol); break;
+    case 5: launch_gram_pchol<5>(c->stream, D, LD, LG, c->gram_G.p, c->Rws.p, c->gram_dropped.p, tol); break;
+    case 6: launch_gram_pchol<6>(c->stream, D, LD, LG, c->gram_G.p, c->Rws.p, c->gram_dropped.p, tol); break;
+    case 7: launch_gram_pchol<7>(c->stream, D, LD, LG, c->gram_G.p, c->Rws.p, c->gram_dropped.p, tol); break;
+    default: launch_gram_pchol<8>(c->stream, D, LD, LG, c->gram_G.p, c->Rws.p, c->gram_dropped.p, tol); break;
+    }
+    HIPCHK(hipGetLastError());
+    c->gram_valid = true;
+    return OVGPU_OK;
+  }
   switch ((LD + 31) / 32) {
   case 1: launch_gram_chol<1>(c->stream, D, LD, LG, c->gram_G.p, c->Rws.p, c->gram_dropped.p); break;
   case 2: launch_gram_chol<2>(c->stream, D, LD, LG, c->gram_G.p, c->Rws.p, c->gram_dropped.p); break;
@@ -1533,13 +1560,18 @@ static int enqueue_pipeline_body(ovgpu_ctx *c, int stages, bool slam, bool facto
   int rc = OVGPU_OK;
   const bool fits = (c->LD + 15) / 16 <= gram::GR_NT_BLK && c->F > 0;
   tform = !gram_only && c->compress_gram == 1 && !c->force_tsqr && fits && (stages & STAGE_EKF) != 0 && (stages & STAGE_LOCAL) != 0;
-  // mode A through the Gram matrix (compress_route = OVGPU_COMPRESS_CHOLQR only): whitened rows -> Gram matrix -> its Cholesky factor ->
-  // un-whitened (k_unwhiten): a compressed (H, r) of the reference's form at the cost of the Gram route (1.8 ms host to host against
-  // 4.0 ms through the Householder TSQR at 2000 features).  Round 3's measured NEGATIVE result, kept selectable: the whitened Gram
-  // matrix is numerically singular (gauge directions, weakly observed calibration), its factor reproduces H^T r only to
-  // eps cond(Y)^2 (1e-11 .. 2e-8 along the rpng_sim loop, Householder: 1e-14), and 52 frames of mode A drift 7.7e-6 from the
-  // oracle-driven loop (Householder: 1e-13) — tests/test_closed_loop.py.  The default mode A therefore stays Householder.
-  const bool factor_gram = c->factor_from_gram && !gram_only && c->compress_gram == 2 && !c->force_tsqr && c->F > 0 && (c->LD + 15) / 16 <= gram::GR_NT &&
+  // Mode A through the Gram matrix: whitened rows -> Gram matrix -> its Cholesky factor -> un-whitened (k_unwhiten): a compressed (H, r)
+  // of the reference's form at the cost of the Gram route instead of the Householder TSQR's (4.0 ms host to host at 2000 features).
+  // The whitened Gram matrix is positive SEMI-definite (gauge directions, weakly observed calibration), so the factorisation decides:
+  //   unpivoted (k_gram_chol, compress_route = OVGPU_COMPRESS_CHOLQR): round 3's measured NEGATIVE result, kept selectable — pivots
+  //     that are rounding noise divide their rows, one step loses 1e-8 of dx, and 52 frames of mode A drift 6e-6 from the
+  //     oracle-driven loop (Householder: 1e-13);
+  //   diagonally pivoted (k_gram_pchol, the DEFAULT and OVGPU_COMPRESS_PCHOLQR): backward stable whatever the rank — the same loop
+  //     stays at 1e-13, snapshots at dx 1e-12 / P 1e-12 (tests/test_closed_loop.py::test_mode_a_closed_loop,
+  //     tests/test_gpu_parity.py::test_mode_a_pivoted_factor_shapes).
+  // compress_route = OVGPU_COMPRESS_TSQR keeps the Householder triangle; so do SLAM stacks, more than 255 columns, the fp32 Gram
+  // variant, an un-whitened stack and a prior block whose own factorisation fails (compress_impl repeats the call then).
+  const bool factor_gram = c->factor_from_gram && !gram_only && c->mode_a_factor != 0 && !c->force_tsqr && c->F > 0 && (c->LD + 15) / 16 <= gram::GR_NT &&
                            (stages & STAGE_EKF) == 0 && (stages & STAGE_LOCAL) != 0 && c->whiten && !c->gram_fp32 && !slam; // (the SLAM stack is short: its mode A stays Householder)
   c->factor_from_gram = false, c->last_factor_from_gram = factor_gram;
   c->force_tsqr = false;
@@ -1808,7 +1840,7 @@ static int compress_impl(ovgpu_ctx *c, bool slam, int32_t *feat_status, double *
   ovgpu_update_stats local;
   int rc;
   for (int attempt = 0;; attempt++) {
-    c->factor_from_gram = attempt == 0; // the whitened Gram matrix's factor when compress_route = OVGPU_COMPRESS_CHOLQR asks for it; Householder TSQR otherwise
+    c->factor_from_gram = attempt == 0; // the whitened Gram matrix's factor (pivoted by default) where it applies; Householder TSQR otherwise
     if ((rc = enqueue_pipeline(c, STAGE_LOCAL, slam)) != OVGPU_OK) return rc;
     std::memset(&local, 0, sizeof(local));
     if ((rc = read_feature_outputs(c, feat_status, chi2, chi2_thresh, p_FinG, &local)) != OVGPU_OK) return rc;
@@ -1824,7 +1856,12 @@ static int compress_impl(ovgpu_ctx *c, bool slam, int32_t *feat_status, double *
   const int D = c->D, LD = c->LD;
   std::vector<double> tri((size_t)D * LD);
   HIPCHK(hipMemcpy(tri.data(), c->Rws.p, sizeof(double) * D * LD, hipMemcpyDeviceToHost));
-  const int rows = local.n_rows > 0 ? D : 0;
+  int rows = local.n_rows > 0 ? D : 0;
+  if (rows > 0 && c->last_factor_from_gram && c->mode_a_factor == 2) { // the pivoted factor stops at the numerical rank: its zero rows stay behind
+    int32_t dropped = 0;
+    HIPCHK(hipMemcpy(&dropped, c->gram_dropped.p, sizeof(int32_t), hipMemcpyDeviceToHost));
+    rows = std::max(0, D - dropped);
+  }
   if (H)
     for (int i = 0; i < rows; i++) std::memcpy(H + (size_t)i * D, tri.data() + (size_t)i * LD, sizeof(double) * D);
   if (r)
@@ -1832,7 +1869,7 @@ static int compress_impl(ovgpu_ctx *c, bool slam, int32_t *feat_status, double *
   if (col_cov_id) std::memcpy(col_cov_id, c->h_col_cov.data(), sizeof(int32_t) * D);
   if (D_out) *D_out = D;
   if (rows_out) *rows_out = rows;
-  c->last_route = c->last_factor_from_gram ? OVGPU_COMPRESS_CHOLQR : OVGPU_COMPRESS_TSQR;
+  c->last_route = c->last_factor_from_gram ? (c->mode_a_factor == 2 ? OVGPU_COMPRESS_PCHOLQR : OVGPU_COMPRESS_CHOLQR) : OVGPU_COMPRESS_TSQR;
   fill_times(c, &local);
   if (stats) *stats = local;
   return check_tree_error(c);

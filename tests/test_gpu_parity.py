@@ -261,16 +261,17 @@ def test_end_to_end_update(Updater, oracle):
     up.close()
 
 
-@pytest.mark.parametrize("route", ["default", "cholqr"])
+@pytest.mark.parametrize("route", ["default", "tsqr", "cholqr"])
 def test_mode_a_compressed_system(Updater, oracle, route):
     """ovgpu_msckf_compress hands back (H, r) for the stock StateHelper::EKFUpdate: H^T H and H^T r equal the reference's compressed
     system's, and feeding it to the oracle's EKFUpdate reproduces the oracle's posterior.
-    default: the triangle of the Householder TSQR (R itself is only unique up to row signs, SURVEY section 7), H^T H to 1e-11;
-    cholqr (opt-in, round 3's negative result): the Cholesky factor of the WHITENED stack's Gram matrix, un-whitened — a dense
-    D x D system at the Gram route's cost, good on a snapshot like this one and NOT good enough in the closed loop
-    (tests/test_closed_loop.py::test_mode_a_closed_loop)."""
+    default: the diagonally PIVOTED Cholesky factor of the whitened stack's Gram matrix, un-whitened (k_gram_pchol) — dense, rows =
+             its numerical rank, at the Gram route's cost; the closed loop holds it to the Householder level (test_closed_loop.py);
+    tsqr:    the triangle of the Householder TSQR, the reference's own form (R is unique up to row signs, SURVEY section 7);
+    cholqr:  (opt-in, round 3's negative result) the UNPIVOTED factor: good on a snapshot like this one, drifts in the closed loop."""
     prob = synth.make_problem(2, F=100)
-    opts = capi.default_options(chi2_multipler=1.0, compress_route=capi.COMPRESS_CHOLQR if route == "cholqr" else capi.COMPRESS_GRAM)
+    code = dict(default=capi.COMPRESS_GRAM, cholqr=capi.COMPRESS_CHOLQR, tsqr=capi.COMPRESS_TSQR)[route]
+    opts = capi.default_options(chi2_multipler=1.0, compress_route=code)
     v = capi.Views(prob)
     tri = oracle.triangulate(opts, v)
     ref = oracle.msckf_update(opts, v, want_compressed=True, given=tri)
@@ -278,16 +279,17 @@ def test_mode_a_compressed_system(Updater, oracle, route):
     up.set_problem(prob)
     up.set_triangulation(tri["p_FinG"], tri["p_FinA"], tri["anchor_meas"], tri["status"])
     cmp = up.compress()
-    assert cmp["D"] == ref["D"] and cmp["rows"] == cmp["D"]
+    assert cmp["D"] == ref["D"] and (cmp["rows"] == cmp["D"] if route != "default" else 0 < cmp["rows"] <= cmp["D"])
     assert np.array_equal(cmp["col_cov_id"], oracle.column_map(opts, v))
-    assert up.lib.ovgpu_last_update_route(up._ctx) == (capi.COMPRESS_CHOLQR if route == "cholqr" else capi.COMPRESS_TSQR)
+    assert up.lib.ovgpu_last_update_route(up._ctx) == (capi.COMPRESS_PCHOLQR if route == "default" else code)
     H, r = cmp["H"], cmp["r"]
     G = ref["H_comp"].T @ ref["H_comp"]
     g = ref["H_comp"].T @ ref["r_comp"]
     eG, eg = np.linalg.norm(H.T @ H - G) / np.linalg.norm(G), np.linalg.norm(H.T @ r - g) / np.linalg.norm(g)
     print(f"mode A, {route}: |H^T H - G| / |G| = {eG:.1e}, |H^T r - g| / |g| = {eg:.1e}")
-    if route == "default":
+    if route == "tsqr":
         assert np.abs(np.tril(H, -1)).max() == 0.0
+    if route != "cholqr":
         assert eG < 1e-11 and eg < 1e-10
     else:
         assert eG < 1e-9 and eg < 1e-9
@@ -296,6 +298,41 @@ def test_mode_a_compressed_system(Updater, oracle, route):
     assert _rel(P1, ref["P"]) < TOL_P and _rel(dx1, ref["dx"]) < TOL_DX
     # the resident state was not touched by mode A
     np.testing.assert_array_equal(up.get_state()["P"], prob.P)
+    up.close()
+
+
+@pytest.mark.parametrize("cfg,F,track", [(1, 3, "full"), (1, 12, "ragged"), (2, 40, "full"), (2, 400, "ragged"), (3, 600, "full"), (4, 300, "full")])
+def test_mode_a_pivoted_factor_shapes(Updater, oracle, cfg, F, track):
+    """Mode A's default — the diagonally pivoted Cholesky factor of the whitened stack's Gram matrix (k_gram_pchol), un-whitened —
+    on short, ragged and tall stacks, mono / stereo / four cameras: the stack of an MSCKF update is rank deficient (gauge directions;
+    a 3-feature update leaves most columns unobserved), the factor stops at the numerical rank and its remaining rows are zero.
+    (H, r) through the stock EKFUpdate (the oracle's restatement) reproduces the oracle's posterior at the update's own tolerances."""
+    prob = synth.make_problem(cfg, F=F, track=track)
+    opts = capi.default_options(chi2_multipler=1.0)
+    v = capi.Views(prob)
+    tri = oracle.triangulate(opts, v)
+    ref = oracle.msckf_update(opts, v, want_compressed=True, given=tri)
+    up = Updater(opts)
+    up.set_problem(prob)
+    up.set_triangulation(tri["p_FinG"], tri["p_FinA"], tri["anchor_meas"], tri["status"])
+    cmp = up.compress()
+    assert up.lib.ovgpu_last_update_route(up._ctx) == capi.COMPRESS_PCHOLQR  # the default of mode A
+    assert np.array_equal(cmp["feat_status"], ref["feat_status"])
+    H, r = cmp["H"], cmp["r"]
+    rank = cmp["rows"]
+    assert H.shape == (rank, ref["D"]) and 0 < rank <= ref["D"] and np.isfinite(H).all() and np.isfinite(r).all()
+    assert (np.abs(H).sum(axis=1) > 0).all()  # the rows beyond the numerical rank stayed on the device
+    G, g = ref["H_comp"].T @ ref["H_comp"], ref["H_comp"].T @ ref["r_comp"]
+    st, P1, dx1 = oracle.ekf_update(prob.P, H, r, cmp["col_cov_id"], 1.0)
+    assert st == 0
+    eP, edx = _rel(P1, ref["P"]), _rel(dx1, ref["dx"])
+    print(f"mode A, pivoted, cfg {cfg} F {F} {track}: rank {rank} of {ref['D']} ({ref['rows_comp']} rows), |H^T H - G| / |G| = "
+          f"{np.linalg.norm(H.T @ H - G) / np.linalg.norm(G):.1e}, |H^T r - g| / |g| = {np.linalg.norm(H.T @ r - g) / np.linalg.norm(g):.1e}, P {eP:.1e}, dx {edx:.1e}")
+    assert eP < TOL_P and edx < TOL_DX
+    # the mode B update of the same context is the Gram route's, untouched by the option
+    out = up.update()
+    assert up.lib.ovgpu_last_update_route(up._ctx) == capi.COMPRESS_GRAM
+    assert _rel(out["P"], ref["P"]) < TOL_P and _rel(out["dx"], ref["dx"]) < TOL_DX
     up.close()
 
 
@@ -570,6 +607,7 @@ def test_compression_is_independent_of_the_tree_shape(Updater, oracle, kw):
     prob = synth.make_problem(kw.pop("cfg", 2), **kw)
     opts = capi.default_options(chi2_multipler=1.0)
     tri = oracle.triangulate(opts, capi.Views(prob))
+    opts.compress_route = capi.COMPRESS_TSQR
     base = _compress_with(Updater, prob, opts, tri, tsqr_workers=1)
     G0, g0 = base["H"].T @ base["H"], base["H"].T @ base["r"]
     for env in (dict(tsqr_workers=2), dict(tsqr_workers=5), dict(tsqr_workers=64), dict(tsqr_workers=64, tsqr_no_pipeline=1),
@@ -590,7 +628,7 @@ def test_cfg4_full_size_properties(Updater):
     up = Updater(opts)
     up.set_problem(prob)
     cmp = up.compress()
-    assert cmp["D"] == 236 and np.abs(np.tril(cmp["H"], -1)).max() == 0.0
+    assert cmp["D"] == 236 and up.lib.ovgpu_last_update_route(up._ctx) == capi.COMPRESS_PCHOLQR and 200 < cmp["rows"] <= 236
     up.reset_state()
     out = up.update()
     P1 = out["P"]
