@@ -610,49 +610,106 @@ __global__ void k_boxplus(int C, int K, const double *__restrict__ dx, const int
 //        x_j = (r_j - sum_{k > j} x_k L[k][j]) / L[j][j],      L[k][j] = U1[j][k] read along a row of Y1 = [U1 | ..] (coalesced).
 // In place on the first D columns of R [D x LD]; the residual column stays.
 // ---------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_unwhiten(int D, int LD, double *__restrict__ R, const double *__restrict__ Y1, int LA, const int32_t *pred) {
-  __shared__ double X[16][257];
+// Blocked form on the matrix cores, one wavefront per 16 rows of X: for tile column tj from the right
+//   S = R(:, J) - X(:, > J) L(> J, J)     v_mfma_f64_16x16x4_f64, A = X from LDS, B = rows of U1 read in place (L(k, j) = U1(j, k))
+//   X(:, J) = S L(J, J)^-1                16 substitution steps inside the tile: lane (g, cl) holds rows 4 q + g of column cl (the
+//                                         accumulator layout), column j's finished values reach the lanes left of it by a 16-lane shuffle
+// Everything tile column tj - 1 needs from memory (its strip of U1, its diagonal tile, its tile of R) is requested while tile column
+// tj is being computed: U1 was written on another XCD a moment ago, a read costs ~1.5 us, and the chain of NT columns would
+// otherwise pay it once per trip of the product loop (measured: 164 us at D = 208 that way; the column-at-a-time form before it ran
+// D dependent steps of LDS round trip + shuffle reduction, 162 us, and with its fetches inside the step 0.45 ms).
+struct UnwhitenStrip {
+  double b[60]; // B operands of up to 15 tiles right of the column (D <= 256): b[4 t + u] = U1[col][16 (tj + 1 + t) + 4 u + g]
+  double ud[16]; // row cl of the diagonal tile from the diagonal on, identity beyond D
+  double rr[4];  // R(rows 4 q + g, col)
+};
+__global__ void __launch_bounds__(64) k_unwhiten(int D, int LD, double *__restrict__ R, const double *__restrict__ Y1, int LA, const int32_t *pred) {
+  constexpr int XS = 260; // LDS row stride: the A-operand read X[cl][k0 + g] touches 64 different banks
+  __shared__ double X[16 * XS];
   if (pred && *pred == 0) return;
-  const int tid = threadIdx.x, r = tid >> 4, l = tid & 15;
-  const int row = blockIdx.x * 16 + r;
-  for (int c = l; c < 256; c += 16) X[r][c] = (row < D && c < D) ? R[(size_t)row * LD + c] : 0.0;
+  const int lane = threadIdx.x, g = lane >> 4, cl = lane & 15;
+  const int r0 = blockIdx.x * 16, NT = (D + 15) >> 4;
+  for (int e = lane; e < 16 * XS; e += 64) X[e] = 0.0;
   auto wsync = [] {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   };
-  // Row j of U1 for step j is fetched during step j + 1 (a lane's sixteen entries k = l + 16 q, clamped, and the diagonal entry):
-  // the chain of D column steps then runs on LDS and lane shuffles only (fetched inside the step it was 2 us of memory latency per
-  // column, 0.45 ms at D = 208 — more than the Gram matrix and its factorisation together).
-  auto fetch = [&](int j, double (&u)[16], double &ujj) {
-    const double *src = Y1 + (size_t)(j < 0 ? 0 : j) * LA;
+  auto fetch = [&](int tj, UnwhitenStrip &s) { // clamped addresses, masked afterwards: one basic block of loads
+    const int c0 = 16 * tj, col = c0 + cl;
+    const bool cok = col < D;
+    const double *urow = Y1 + (size_t)(cok ? col : D - 1) * LA; // row `col` of U1 = column `col` of L
 #pragma unroll
-    for (int q = 0; q < 16; q++) {
-      const int k = l + 16 * q;
-      u[q] = src[k < D ? k : D - 1];
+    for (int i = 0; i < 60; i++) {
+      const int k = c0 + 16 + 16 * (i >> 2) + 4 * (i & 3) + g;
+      s.b[i] = urow[k < D ? k : D - 1];
     }
-    ujj = src[j < 0 ? 0 : j];
+#pragma unroll
+    for (int j = 0; j < 16; j++) s.ud[j] = urow[c0 + j < D ? c0 + j : D - 1];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int row = r0 + 4 * q + g;
+      s.rr[q] = R[(size_t)(row < D ? row : D - 1) * LD + (cok ? col : 0)];
+    }
+#pragma unroll
+    for (int i = 0; i < 60; i++) {
+      const int k = c0 + 16 + 16 * (i >> 2) + 4 * (i & 3) + g;
+      if (!(cok && k < D)) s.b[i] = 0.0;
+    }
+#pragma unroll
+    for (int j = 0; j < 16; j++)
+      if (!(cok && c0 + j < D && j >= cl)) s.ud[j] = j == cl ? 1.0 : 0.0;
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+      if (!(r0 + 4 * q + g < D && cok)) s.rr[q] = 0.0;
   };
-  double uc[16], un[16], dc, dn;
-  fetch(D - 1, uc, dc);
-  wsync();
-  for (int j = D - 1; j >= 0; j--) {
-    fetch(j - 1, un, dn);
-    double s = 0.0;
+  auto column = [&](int tj, const UnwhitenStrip &s) {
+    const int c0 = 16 * tj, col = c0 + cl;
+    const bool cok = col < D;
+    double4_t acc = {s.rr[0], s.rr[1], s.rr[2], s.rr[3]}, acc2 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int q = 0; q < 16; q++) {
-      const int k = l + 16 * q;
-      s = fma(X[r][k], (k > j && k < D) ? uc[q] : 0.0, s);
+    for (int t = 0; t < 15; t++) {
+      const int k0 = c0 + 16 + 16 * t;
+      if (k0 < 16 * NT) { // (wave-uniform)
+        const double *xa = X + cl * XS + k0 + g;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-xa[0], s.b[4 * t + 0], acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(-xa[4], s.b[4 * t + 1], acc2, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-xa[8], s.b[4 * t + 2], acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(-xa[12], s.b[4 * t + 3], acc2, 0, 0, 0);
+      }
     }
-    s += __shfl_xor(s, 8, 16), s += __shfl_xor(s, 4, 16), s += __shfl_xor(s, 2, 16), s += __shfl_xor(s, 1, 16);
-    if (l == 0) X[r][j] = (X[r][j] - s) / dc;
-    wsync();
+    acc += acc2;
+    double dinv = 1.0;
 #pragma unroll
-    for (int q = 0; q < 16; q++) uc[q] = un[q];
-    dc = dn;
+    for (int j = 0; j < 16; j++)
+      if (j == cl) dinv = 1.0 / s.ud[j];
+#pragma unroll
+    for (int j = 15; j >= 0; j--) {
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const double xq = acc[q] * dinv;           // meaningful in the lanes of column j
+        const double xj = __shfl(xq, j, 16);       // ... and from there to the whole 16-lane group (same rows 4 q + g)
+        acc[q] = cl == j ? xq : (cl < j ? fma(-xj, s.ud[j], acc[q]) : acc[q]);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int row = r0 + 4 * q + g;
+      X[(4 * q + g) * XS + col] = cok ? acc[q] : 0.0;
+      if (row < D && cok) R[(size_t)row * LD + col] = acc[q];
+    }
+    wsync();
+  };
+  UnwhitenStrip s0, s1;
+  fetch(NT - 1, s0);
+  wsync();
+  for (int tj = NT - 1; tj >= 0; tj -= 2) {
+    if (tj >= 1) fetch(tj - 1, s1);
+    column(tj, s0);
+    if (tj < 1) break;
+    if (tj >= 2) fetch(tj - 2, s0);
+    column(tj - 1, s1);
   }
-  if (row < D)
-    for (int c = l; c < D; c += 16) R[(size_t)row * LD + c] = X[r][c];
 }
 
 } // namespace ovg

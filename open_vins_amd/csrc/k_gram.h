@@ -728,45 +728,44 @@ __global__ void __launch_bounds__(1024) k_gram_pchol(int D, int LD, int LG, cons
       }
     }
   if (tid < 32 * CH_NB) alive[tid] = tid < LD ? 1.0 : 0.0, rowbuf[0][tid] = 0.0, rowbuf[1][tid] = 0.0;
-  // wavefront 0: the diagonal of the live columns, entry j = lane + 64 q in dg[q]; eliminated or never eligible: DEAD
+  // wavefront 0: the diagonal of the live columns, entry j = lane + 64 q in dg<q>; eliminated or never eligible: DEAD
+  // (four named registers, not an array: the pivot's value is selected by a run-time q, and an indexed array would live in scratch —
+  // on the critical path of every step)
   constexpr double DEAD = -1.0e300;
-  double dg[4] = {DEAD, DEAD, DEAD, DEAD}, dmax0 = 0.0;
-  // the live column with the largest diagonal entry (ties: the lowest column).  The comparison key is the entry's bit pattern with
-  // the column in its low byte — a pivot CHOICE may ignore the last 8 mantissa bits, the pivot's VALUE is then read exactly.
-  auto next_pivot = [&](int slot, bool first) {
-    long long key = 0;
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-      const long long kq = dg[q] > 0.0 ? ((__double_as_longlong(dg[q]) & ~0xFFll) | (long long)(255 - (lane + 64 * q))) : 0ll;
-      key = kq > key ? kq : key;
-    }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-      const long long o = __shfl_xor(key, off, 64);
-      key = o > key ? o : key;
-    }
-    const int j = 255 - (int)(key & 0xFF);
-    double d = 0.0;
-#pragma unroll
-    for (int q = 0; q < 4; q++)
-      if (q == (j >> 6)) d = dg[q];
-    d = __shfl(d, j & 63, 64);
-    if (first) dmax0 = d;
-    const bool go = key != 0 && d > tol * dmax0 && d > 0.0;
-    if (go) {
-#pragma unroll
-      for (int q = 0; q < 4; q++)
-        if (lane + 64 * q == j) dg[q] = DEAD;
-    }
-    if (lane == 0) piv[slot] = go ? j : -1, pivinv[slot] = go ? rsqrt_f64(d) : 0.0;
-  };
+  double dg0 = DEAD, dg1 = DEAD, dg2 = DEAD, dg3 = DEAD, dmax0 = 0.0;
+  // The live column with the largest diagonal entry (ties: the lowest column).  The comparison key is 32 bits: exponent and twelve
+  // mantissa bits of the entry with the column in the low byte — a pivot CHOICE within 2^-12 of the maximum is as good as the maximum,
+  // the pivot's VALUE is then read exactly.  Wavefront maximum on the DPP network (four row shifts, one readlane per row) instead of
+  // six rounds of 64-bit ds_bpermute: this reduction is on the critical path of every step.
+  // (a macro, not a lambda: captured by reference the four registers become a closure in memory, and the selects below turn into
+  // indexed scratch accesses)
+#define OVG_PCHOL_KEY(v, q) ((v) > 0.0 ? ((__double2hiint(v) & ~0xFF) | (255 - (lane + 64 * (q)))) : 0)
+#define OVG_PCHOL_NEXT_PIVOT(slot, first)                                                                                              \
+  {                                                                                                                                    \
+    int key = max(max(OVG_PCHOL_KEY(dg0, 0), OVG_PCHOL_KEY(dg1, 1)), max(OVG_PCHOL_KEY(dg2, 2), OVG_PCHOL_KEY(dg3, 3)));               \
+    key = max(key, __builtin_amdgcn_update_dpp(0, key, 0x111, 0xF, 0xF, false)); /* row_shr:1 .. 8: lane 15 of a row = the row's max */ \
+    key = max(key, __builtin_amdgcn_update_dpp(0, key, 0x112, 0xF, 0xF, false));                                                       \
+    key = max(key, __builtin_amdgcn_update_dpp(0, key, 0x114, 0xF, 0xF, false));                                                       \
+    key = max(key, __builtin_amdgcn_update_dpp(0, key, 0x118, 0xF, 0xF, false));                                                       \
+    const int k01 = max(__builtin_amdgcn_readlane(key, 15), __builtin_amdgcn_readlane(key, 31));                                       \
+    const int k23 = max(__builtin_amdgcn_readlane(key, 47), __builtin_amdgcn_readlane(key, 63));                                       \
+    const int kmax = max(k01, k23); /* wave-uniform (scalar registers) */                                                              \
+    const int j = 255 - (kmax & 0xFF), jq = j >> 6, jl = j & 63;                                                                       \
+    const double dsel = jq == 0 ? dg0 : (jq == 1 ? dg1 : (jq == 2 ? dg2 : dg3));                                                       \
+    const double d = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(dsel), jl), __builtin_amdgcn_readlane(__double2loint(dsel), jl)); \
+    if (first) dmax0 = d;                                                                                                              \
+    const bool go = kmax != 0 && d > tol * dmax0 && d > 0.0;                                                                           \
+    const bool mine = go && lane == jl;                                                                                                \
+    dg0 = (mine && jq == 0) ? DEAD : dg0, dg1 = (mine && jq == 1) ? DEAD : dg1;                                                        \
+    dg2 = (mine && jq == 2) ? DEAD : dg2, dg3 = (mine && jq == 3) ? DEAD : dg3;                                                        \
+    if (lane == 0) piv[slot] = go ? j : -1, pivinv[slot] = go ? rsqrt_f64(d) : 0.0;                                                    \
+  }
   if (wv == 0) {
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-      const int j = lane + 64 * q;
-      if (j < D) dg[q] = G[(size_t)j * LG + j];
-    }
-    next_pivot(0, true);
+    if (lane < D) dg0 = G[(size_t)lane * LG + lane];
+    if (lane + 64 < D) dg1 = G[(size_t)(lane + 64) * LG + lane + 64];
+    if (lane + 128 < D) dg2 = G[(size_t)(lane + 128) * LG + lane + 128];
+    if (lane + 192 < D) dg3 = G[(size_t)(lane + 192) * LG + lane + 192];
+    OVG_PCHOL_NEXT_PIVOT(0, true)
   }
   __syncthreads();
   int rank = D;
@@ -795,13 +794,14 @@ __global__ void __launch_bounds__(1024) k_gram_pchol(int D, int LD, int LG, cons
     }
     __syncthreads();
     if (wv == 0) { // the diagonal copy, then the next pivot (its column leaves the live set now: row k + 1 gets a zero there)
-#pragma unroll
-      for (int q = 0; q < 4; q++) {
-        const double r = rb[(q * 32 + (lane & 31)) * 2 + (lane >> 5)]; // column lane + 64 q = block 2 q + (lane >> 5), offset lane & 31
-        if (dg[q] != DEAD) dg[q] = fma(-r, r, dg[q]);
+      { // column lane + 64 q = block 2 q + (lane >> 5), offset lane & 31
+        const double *rq = rb + (lane & 31) * 2 + (lane >> 5);
+        const double r0 = rq[0], r1 = rq[64], r2 = rq[128], r3 = rq[192];
+        dg0 = dg0 != DEAD ? fma(-r0, r0, dg0) : dg0, dg1 = dg1 != DEAD ? fma(-r1, r1, dg1) : dg1;
+        dg2 = dg2 != DEAD ? fma(-r2, r2, dg2) : dg2, dg3 = dg3 != DEAD ? fma(-r3, r3, dg3) : dg3;
       }
       if (lane == 0) alive[p] = 0.0;
-      next_pivot((k + 1) & 1, false);
+      OVG_PCHOL_NEXT_PIVOT((k + 1) & 1, false)
     } else if (wv <= 4) { // row k of R, original column order, into the burst buffer
       const int j = tid - 64;
       if (j < LD) rstore[((size_t)((k / CH_FLUSH) & 1) * CH_FLUSH + (k % CH_FLUSH)) * LD + j] = rb[(((j >> 5) >> 1) * 32 + (j & 31)) * 2 + ((j >> 5) & 1)];
@@ -843,6 +843,8 @@ __global__ void __launch_bounds__(1024) k_gram_pchol(int D, int LD, int LG, cons
   }
   if (tid == 0 && n_dropped) *n_dropped = D - rank;
 }
+#undef OVG_PCHOL_NEXT_PIVOT
+#undef OVG_PCHOL_KEY
 
 } // namespace gram
 } // namespace ovg

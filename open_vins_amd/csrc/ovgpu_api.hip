@@ -1611,7 +1611,7 @@ static int enqueue_pipeline_body(ovgpu_ctx *c, int stages, bool slam, bool facto
         if (c->prior_on_side) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join, 0));
         c->prior_pending = false, c->prior_on_side = false, c->lt_on_side = false;
         hipLaunchKernelGGL(k_tf_go, dim3(1), dim3(1), 0, c->stream, (const int32_t *)c->flags.p, c->flags.p + 3); // go = the prior block's factorisation succeeded
-        hipLaunchKernelGGL(k_unwhiten, dim3((c->D + 15) / 16), dim3(256), 0, c->stream, c->D, c->LD, c->Rws.p, (const double *)c->Yaug.p, c->D + c->N + 1,
+        hipLaunchKernelGGL(k_unwhiten, dim3((c->D + 15) / 16), dim3(64), 0, c->stream, c->D, c->LD, c->Rws.p, (const double *)c->Yaug.p, c->D + c->N + 1,
                            (const int32_t *)(c->flags.p + 3));
         HIPCHK(hipGetLastError());
       }

@@ -596,6 +596,16 @@ def test_semi_definite_prior_takes_the_householder_route(Updater, oracle):
     assert out["stats"]["status"] == 0 and np.array_equal(out["feat_status"], ref["feat_status"])
     assert _rel(out["dx"], ref["dx"]) < 1e-7 and _rel(out["P"], ref["P"]) < 1e-8
     assert np.abs(out["clone_q_p"] - ref["clone_q_p"]).max() < 1e-9
+    # mode A on the same singular prior: the whitened Gram matrix has nothing to stand on (its whitening IS the prior's factor), the
+    # call repeats through the Householder TSQR of the raw rows and says so
+    up.set_problem(prob)
+    up.set_triangulation(tri["p_FinG"], tri["p_FinA"], tri["anchor_meas"], tri["status"])
+    cmp = up.compress()
+    assert up.lib.ovgpu_last_update_route(up._ctx) == capi.COMPRESS_TSQR and cmp["rows"] == cmp["D"]
+    assert np.abs(np.tril(cmp["H"], -1)).max() == 0.0
+    st, P1, dx1 = oracle.ekf_update(prob.P, cmp["H"], cmp["r"], cmp["col_cov_id"], 1.0)
+    assert st == 0 and _rel(dx1, ref["dx"]) < 1e-7 and _rel(P1, ref["P"]) < 1e-8
+    np.testing.assert_array_equal(up.get_state()["P"], prob.P)
     up.close()
 
 
