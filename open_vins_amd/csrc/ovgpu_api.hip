@@ -54,6 +54,26 @@ static int set_err(int code, const std::string &msg) {
 
 namespace {
 
+// page-locked host staging (read-backs that complete with the stream's next synchronisation instead of one blocking copy each)
+template <class T>
+struct PinBuf {
+  T *p = nullptr;
+  size_t cap = 0; // elements
+  hipError_t reserve(size_t n) {
+    if (n <= cap) return hipSuccess;
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+    hipError_t e = hipHostMalloc((void **)&p, std::max<size_t>(n, 1) * sizeof(T), hipHostMallocDefault);
+    if (e == hipSuccess) cap = n;
+    return e;
+  }
+  void release() {
+    if (p) (void)hipHostFree(p);
+    p = nullptr, cap = 0;
+  }
+};
+
 template <class T>
 struct DevBuf {
   T *p = nullptr;
@@ -236,6 +256,7 @@ struct ovgpu_ctx {
   DevBuf<int32_t> ctrl;
   unsigned ctrl_clean = 0;
   DevBuf<double> chol_uinv;    // [2][16][256]
+  PinBuf<double> h_tri;        // mode A: the compressed system on its way to the caller ([D x LD] + one word of flags per double behind it)
   int chol_slot = 0;
   bool no_chol_pipe = false;   // options.no_single_launch_cholesky
   int feat_shape = 0;          // options.feature_kernel_shape
@@ -523,6 +544,7 @@ void ovgpu_destroy(ovgpu_ctx *c) {
   c->ctrl.release();
   c->gram_part.release(), c->gram_G.release(), c->gram_rho.release(), c->Yaug2.release(), c->gram_dropped.release(), c->Lw.release(), c->dbg_cycles.release();
   c->chol_uinv.release();
+  c->h_tri.release();
   c->fs_minfo.release(), c->fs_meas_feat.release(), c->fs_rows.release(), c->fs_V.release(), c->fs_z.release(), c->fs_w.release(), c->fs_tq.release(), c->fs_inst.release(), c->featyb_ws.release();
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
@@ -1839,37 +1861,44 @@ static int compress_impl(ovgpu_ctx *c, bool slam, int32_t *feat_status, double *
   if (stats) std::memset(stats, 0, sizeof(*stats));
   ovgpu_update_stats local;
   int rc;
+  const double *tri = nullptr;
+  int32_t dropped = 0;
   for (int attempt = 0;; attempt++) {
     c->factor_from_gram = attempt == 0; // the whitened Gram matrix's factor (pivoted by default) where it applies; Householder TSQR otherwise
     if ((rc = enqueue_pipeline(c, STAGE_LOCAL, slam)) != OVGPU_OK) return rc;
+    // The compressed system, the factorisation flags and the pivoted factor's rank follow the pipeline on its stream into page-locked
+    // staging and arrive with the synchronisation of read_feature_outputs (three blocking copies from pageable memory cost 60 us).
+    const size_t n_tri = (size_t)c->D * c->LD;
+    HIPCHK(c->h_tri.reserve(n_tri + 4));
+    int32_t *h_words = reinterpret_cast<int32_t *>(c->h_tri.p + n_tri); // [0..3] flags, [4] dropped rows
+    std::memset(h_words, 0, 8 * sizeof(int32_t));
+    if (n_tri > 0) HIPCHK(hipMemcpyAsync(c->h_tri.p, c->Rws.p, sizeof(double) * n_tri, hipMemcpyDeviceToHost, c->stream));
+    if (c->last_factor_from_gram) {
+      HIPCHK(hipMemcpyAsync(h_words, c->flags.p, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+      if (c->mode_a_factor == 2) HIPCHK(hipMemcpyAsync(h_words + 4, c->gram_dropped.p, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    }
     std::memset(&local, 0, sizeof(local));
     if ((rc = read_feature_outputs(c, feat_status, chi2, chi2_thresh, p_FinG, &local)) != OVGPU_OK) return rc;
+    tri = c->h_tri.p, dropped = h_words[4];
     if (!c->last_factor_from_gram) break;
-    int32_t flags[4] = {0, 0, 0, 0};
-    HIPCHK(hipMemcpy(flags, c->flags.p, sizeof(flags), hipMemcpyDeviceToHost));
-    if (!flags[0] && !flags[2]) break;
+    if (!h_words[0] && !h_words[2]) break;
     // the prior block is not (numerically) positive definite, or its single-launch factorisation was not co-scheduled: the whitened
     // route has nothing to offer; repeat through the Householder TSQR on the raw rows (which needs no factor of the prior)
     c->force_tsqr = true;
     if (attempt > 0) return set_err(OVGPU_ERR_NOT_SPD, "prior block of the involved variables not positive definite");
   }
   const int D = c->D, LD = c->LD;
-  std::vector<double> tri((size_t)D * LD);
-  HIPCHK(hipMemcpy(tri.data(), c->Rws.p, sizeof(double) * D * LD, hipMemcpyDeviceToHost));
   int rows = local.n_rows > 0 ? D : 0;
-  if (rows > 0 && c->last_factor_from_gram && c->mode_a_factor == 2) { // the pivoted factor stops at the numerical rank: its zero rows stay behind
-    int32_t dropped = 0;
-    HIPCHK(hipMemcpy(&dropped, c->gram_dropped.p, sizeof(int32_t), hipMemcpyDeviceToHost));
-    rows = std::max(0, D - dropped);
-  }
+  if (rows > 0 && c->last_factor_from_gram && c->mode_a_factor == 2) rows = std::max(0, D - dropped); // the pivoted factor stops at the numerical rank: its zero rows stay behind
   if (H)
-    for (int i = 0; i < rows; i++) std::memcpy(H + (size_t)i * D, tri.data() + (size_t)i * LD, sizeof(double) * D);
+    for (int i = 0; i < rows; i++) std::memcpy(H + (size_t)i * D, tri + (size_t)i * LD, sizeof(double) * D);
   if (r)
     for (int i = 0; i < rows; i++) r[i] = tri[(size_t)i * LD + D];
   if (col_cov_id) std::memcpy(col_cov_id, c->h_col_cov.data(), sizeof(int32_t) * D);
   if (D_out) *D_out = D;
   if (rows_out) *rows_out = rows;
   c->last_route = c->last_factor_from_gram ? (c->mode_a_factor == 2 ? OVGPU_COMPRESS_PCHOLQR : OVGPU_COMPRESS_CHOLQR) : OVGPU_COMPRESS_TSQR;
+  local.n_rows_comp = rows;
   fill_times(c, &local);
   if (stats) *stats = local;
   return check_tree_error(c);

@@ -111,6 +111,32 @@ def test_long_loop_with_imu_level_process_noise():
     assert np.abs(gpu["est"] - ref["est"]).max() < 1e-4            # after a differing gate decision: same filter, one measurement apart
     a_g, a_o = closed_loop.ate(gpu), closed_loop.ate(ref)
     assert abs(a_g[0] - a_o[0]) < 1e-4 and abs(a_g[1] - a_o[1]) < 1e-3
+    # The same 500 frames in MODE A (the shims' unpatched mode): ovgpu_msckf_compress -> the stock EKFUpdate (oracle restatement).  The
+    # default factor — diagonally pivoted Cholesky of the whitened Gram matrix, un-whitened by the prior's own factor — has to hold
+    # at cond(P_DD) = 2-4e10 what it holds on the short loop.
+    up = UpdaterMSCKF(opts)
+    routes = []
+
+    def mode_a_update(prob):
+        up.set_problem(prob)
+        cmp = up.compress()
+        routes.append(up.lib.ovgpu_last_update_route(up._ctx))
+        st, P1, dx = pyoracle.ekf_update(prob.P, cmp["H"], cmp["r"], cmp["col_cov_id"], opts.sigma_pix ** 2)
+        assert st == 0
+        out = pyoracle.apply_dx(opts, capi.Views(prob), dx)
+        out.update(P=P1, feat_status=cmp["feat_status"])
+        return out
+
+    ma = closed_loop.run(stream, mode_a_update)
+    up.close()
+    assert all(r == capi.COMPRESS_PCHOLQR for r in routes)
+    same = [ma["used"][t] == ref["used"][t] for t in frames]
+    first_diff = same.index(False) if False in same else len(frames)
+    k = first_diff + (stream.C - 1)
+    dev = np.abs(ma["est"][:k] - ref["est"][:k]).max()
+    print(f"mode A (pivoted Gram factor), IMU-level process noise: {first_diff} frames with identical accept sets, max deviation {dev:.1e}")
+    assert first_diff >= 100 and dev < 1e-8
+    assert np.abs(ma["est"] - ref["est"]).max() < 1e-4
 
 
 @pytest.mark.gpu

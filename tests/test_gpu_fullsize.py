@@ -181,6 +181,17 @@ def test_prior_conditioning_sweep(Updater, oracle, kw):
         up = Updater(capi.default_options(chi2_multipler=GATE_OPEN, prior_pivot_tol=1e-300 if forced else 0.0))
         up.set_problem(prob)
         up.set_triangulation(tri["p_FinG"], tri["p_FinA"], tri["anchor_meas"], tri["status"])
+        # mode A first (it leaves the resident state alone): the pivoted factor of the whitened Gram matrix, un-whitened, through the
+        # STOCK EKFUpdate — held to the same bounds as the update on the device; where the prior's pivot test fails it is the
+        # Householder triangle that comes back
+        cmp = up.compress()
+        route_a = up.lib.ovgpu_last_update_route(up._ctx)
+        st, Pa, dxa = oracle.ekf_update(prob.P, cmp["H"], cmp["r"], cmp["col_cov_id"], opts.sigma_pix ** 2)
+        e_a = (_rel(Pa.astype(LD), P_true), _rel(dxa.astype(LD), dx_true))
+        print(f"cond(P_DD) {cond:.1e} mode A route {'pivoted gram factor' if route_a == capi.COMPRESS_PCHOLQR else 'tsqr'}{' (forced)' if forced else ''}, "
+              f"{cmp['rows']} rows: |dP|/|P| {e_a[0]:.1e} (Householder triangle through the same EKFUpdate {e_ref[0]:.1e}); |ddx|/|dx| {e_a[1]:.1e} ({e_ref[1]:.1e})")
+        assert st == 0 and (route_a == capi.COMPRESS_PCHOLQR or not forced)
+        assert e_a[0] < max(1e-9, 5 * e_ref[0]) and e_a[1] < max(1e-8, 10 * e_ref[1]), (cond, forced, e_a, e_ref)
         out = up.update()
         up.close()
         assert out["stats"]["status"] == 0

@@ -73,15 +73,16 @@ def variant(name):
         return out
     return upd
 
-errs = {}
-TALL = int(os.environ.get("TALL", "0"))
-rng = np.random.default_rng(5)
-K = int(os.environ.get("K", "1"))
-C, F = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (12, 50)
-stream = closed_loop.Stream(C=C, feats_per_frame=F, seed=7, K=K, T=int(os.environ.get("T", "0")) or None)
-base = closed_loop.run(stream, lambda prob: pyoracle.msckf_update(opts, capi.Views(prob)))
-for name in ("householder", "chol0", "pchol0", "pchol1e-15", "pchol1e-13", "eigh"):
-    res = closed_loop.run(stream, variant(name))
-    dev = np.abs(res["est"] - base["est"]).max()
-    e = np.array(errs[name])
-    print(f"{name:12s} closed-loop deviation {dev:.1e}   one-step dx max {e[:,0].max():.1e} P max {e[:,1].max():.1e}", flush=True)
+if __name__ == "__main__":
+    errs = {}
+    TALL = int(os.environ.get("TALL", "0"))
+    rng = np.random.default_rng(5)
+    K = int(os.environ.get("K", "1"))
+    C, F = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (12, 50)
+    stream = closed_loop.Stream(C=C, feats_per_frame=F, seed=7, K=K, T=int(os.environ.get("T", "0")) or None)
+    base = closed_loop.run(stream, lambda prob: pyoracle.msckf_update(opts, capi.Views(prob)))
+    for name in ("householder", "chol0", "pchol0", "pchol1e-15", "pchol1e-13", "eigh"):
+        res = closed_loop.run(stream, variant(name))
+        dev = np.abs(res["est"] - base["est"]).max()
+        e = np.array(errs[name])
+        print(f"{name:12s} closed-loop deviation {dev:.1e}   one-step dx max {e[:,0].max():.1e} P max {e[:,1].max():.1e}", flush=True)
