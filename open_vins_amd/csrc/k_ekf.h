@@ -623,10 +623,11 @@ struct UnwhitenStrip {
   double ud[16]; // row cl of the diagonal tile from the diagonal on, identity beyond D
   double rr[4];  // R(rows 4 q + g, col)
 };
-__global__ void __launch_bounds__(64) k_unwhiten(int D, int LD, double *__restrict__ R, const double *__restrict__ Y1, int LA, const int32_t *pred) {
+__global__ void __launch_bounds__(64) k_unwhiten(int D, int LD, double *__restrict__ R, const double *__restrict__ Y1, int LA, const int32_t *pred,
+                                                 const int32_t *pred_not) {
   constexpr int XS = 260; // LDS row stride: the A-operand read X[cl][k0 + g] touches 64 different banks
   __shared__ double X[16 * XS];
-  if (pred && *pred == 0) return;
+  if ((pred && *pred == 0) || (pred_not && *pred_not != 0)) return; // (pred_not: the not-SPD flag of the prior block's factorisation)
   const int lane = threadIdx.x, g = lane >> 4, cl = lane & 15;
   const int r0 = blockIdx.x * 16, NT = (D + 15) >> 4;
   for (int e = lane; e < 16 * XS; e += 64) X[e] = 0.0;

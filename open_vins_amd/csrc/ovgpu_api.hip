@@ -1632,9 +1632,9 @@ static int enqueue_pipeline_body(ovgpu_ctx *c, int stages, bool slam, bool facto
       if (rc == OVGPU_OK) {
         if (c->prior_on_side) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join, 0));
         c->prior_pending = false, c->prior_on_side = false, c->lt_on_side = false;
-        hipLaunchKernelGGL(k_tf_go, dim3(1), dim3(1), 0, c->stream, (const int32_t *)c->flags.p, c->flags.p + 3); // go = the prior block's factorisation succeeded
+        // (nothing happens when the prior block's factorisation failed: flags[0]; the call is repeated through the Householder route then)
         hipLaunchKernelGGL(k_unwhiten, dim3((c->D + 15) / 16), dim3(64), 0, c->stream, c->D, c->LD, c->Rws.p, (const double *)c->Yaug.p, c->D + c->N + 1,
-                           (const int32_t *)(c->flags.p + 3));
+                           (const int32_t *)nullptr, (const int32_t *)c->flags.p);
         HIPCHK(hipGetLastError());
       }
     } else {

@@ -23,7 +23,7 @@ for name, code in (("tsqr (Householder)", capi.COMPRESS_TSQR), ("cholqr (unpivot
         ts.append((time.perf_counter() - t) * 1e3)
     st = out["stats"]
     res[name] = out
-    print(f"{name:20s} route {up.lib.ovgpu_last_update_route(up._ctx)}  host to host median {np.median(ts):.3f} ms  min {min(ts):.3f}   stats {({k: round(v, 4) for k, v in st.items() if k.startswith('ms')})}", flush=True)
+    print(f"cfg {cfg} F {prob.F} | {name:20s} route {up.lib.ovgpu_last_update_route(up._ctx)}  host to host median {np.median(ts):.3f} ms  min {min(ts):.3f}   stats {({k: round(v, 4) for k, v in st.items() if k.startswith('ms')})}", flush=True)
     up.close()
 a, b = res["tsqr (Householder)"], res["pcholqr (pivoted)"]
 Ga, Gb = a["H"].T @ a["H"], b["H"].T @ b["H"]
