@@ -57,6 +57,21 @@ def test_struct_layouts_match_header(tmp_path):
     assert C.sizeof(capi.Options) == 2 * 8 + 4 * 4 + 9 * 8 + 4 * 4 + 10 * 4 + 8 + 2 * 4
 
 
+def test_enum_values_match_header(tmp_path):
+    """The route / status / representation codes of the ctypes mirror are the header's enumerators as gcc evaluates them."""
+    import subprocess
+    names = {"OVGPU_COMPRESS_GRAM": capi.COMPRESS_GRAM, "OVGPU_COMPRESS_TSQR": capi.COMPRESS_TSQR, "OVGPU_COMPRESS_CHOLQR": capi.COMPRESS_CHOLQR,
+             "OVGPU_COMPRESS_PCHOLQR": capi.COMPRESS_PCHOLQR, "OVGPU_FEAT_USED": capi.FEAT_USED, "OVGPU_FEAT_CHI2_REJECTED": capi.FEAT_CHI2_REJECTED}
+    lines = ['#include <stdio.h>', '#include "ovgpu.h"', 'int main(void) {'] + [f'  printf("{n} %d\\n", (int){n});' for n in names] + ['  return 0;', '}']
+    src = tmp_path / "enums.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "enums"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = dict(l.split() for l in subprocess.check_output([str(exe)], text=True).splitlines())
+    for n, v in names.items():
+        assert int(got[n]) == v, n
+
+
 def test_default_options_are_the_reference_defaults():
     lib = capi.load()
     o = capi.Options()
