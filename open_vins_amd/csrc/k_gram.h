@@ -189,6 +189,133 @@ template <int NTC> __global__ void __launch_bounds__(256) k_gram(GramParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// k_gram_il: k_gram with the staging INSIDE the matrix-instruction stream.
+//
+// k_gram's stage is [28 global loads] [8 k-steps of 27-34 v_mfma, 64 cycles each] [28 LDS writes, each behind its own s_waitcnt]
+// [barrier]: the ~330 staging instructions of a stage issue while the matrix pipe has nothing queued — with one wavefront per SIMD
+// nobody else fills the gap (ISA of k_gram<14>: 150 + 180 instructions around 272 matrix instructions, ~10 % of the stage).  A matrix
+// instruction occupies the pipe for 64 cycles and the issue port for 4-8, so the same instructions are free when they sit BETWEEN
+// matrix instructions.  Here every k-step carries NTC / 2 staging slots, one behind the products of a tile column:
+//   k-steps 0-3   LDS writes of stage s + 1 (in registers since the previous stage) into the other buffer
+//   k-steps 4-7   global loads of stage s + 2 into the registers just freed (four k-steps = ~8 k cycles until their first use)
+// and the stage ends with an LDS-only barrier (s_waitcnt lgkmcnt(0); s_barrier): the loads in flight cross it.
+// Element offsets in LDS are computed once (register array) instead of incrementally per stage.  Same products in the same order:
+// the partial tiles are bit-identical to k_gram's.
+// ---------------------------------------------------------------------------------------------------
+// One wavefront's whole pass over its share of the stack (W = its row set).  The chunk loop lives INSIDE the per-wavefront
+// instantiation: with a switch (wave) around each stage the four cases end in identical staging instructions, which the compiler
+// sinks into the common successor — behind all matrix instructions again.  Inside, __builtin_amdgcn_sched_barrier(0) pins the order
+// [products of a tile column] [one staging slot] [products of the next column] ..; without it the scheduler gathers the slots into
+// runs (ISA of the first attempt: 90 address instructions up front, 7 LDS writes in a row behind every k-step).
+template <int W, int NTC> __device__ __forceinline__ void gram_il_loop(const GramParams &p, double *gram_lds, int tid, int lane, int chunk_begin, int chunk_end,
+                                                                     d4 (&acc)[GR_ACC]) {
+  using WR = WaveRows<W>;
+  const int LD = p.LD;
+  const int g = lane >> 4, cl = lane & 15;
+  constexpr int JLO = WR::R0 < NTC ? WR::R0 : NTC;
+  constexpr int SL = NTC / 2; // staging slots per k-step
+  constexpr int NQ = 2 * NTC;
+  constexpr int SCRATCH = GR_LS - 1;
+  double v[NQ];
+  // src_f / left_f, left_v: the stage whose elements are requested next / sit in v — source pointer and number of valid doubles (a
+  // chunk index past the workgroup's range is clamped to its last chunk: redundant loads and LDS writes nobody reads, instead of
+  // branches in the slots)
+  const double *src_f = p.H;
+  int left_f = 1, left_v = 1;
+  // element e = tid + 256 q of a stage sits in row e / LD, column e % LD (past the stage: the scratch slot): walked incrementally,
+  // the slots of a stage run in ascending q
+  const int row0 = tid / LD, col0 = tid - row0 * LD, step_r = 256 / LD, step_c = 256 - step_r * LD;
+  int wr = row0, wc = col0;
+  auto put = [&](double *buf, int q) {
+    buf[wr < GR_ROWS ? wr * GR_LS + wc : SCRATCH] = (tid + 256 * q) < left_v ? v[q] : 0.0;
+    wr += step_r, wc += step_c;
+    if (wc >= LD) wc -= LD, wr++;
+  };
+  auto aim = [&](int chunk) {
+    const int c = chunk < chunk_end ? chunk : chunk_end - 1;
+    const int64_t first = (int64_t)c * GR_ROWS;
+    const int64_t left64 = (p.rows_total - first) * LD;
+    left_f = (int)(left64 < (int64_t)GR_ROWS * LD ? left64 : (int64_t)GR_ROWS * LD);
+    src_f = p.H + first * LD;
+  };
+  auto fetch1 = [&](int q) {
+    const int e = tid + 256 * q;
+    v[q] = src_f[e < left_f ? e : left_f - 1];
+  };
+  if (chunk_begin < chunk_end) {
+    aim(chunk_begin);
+#pragma unroll
+    for (int q = 0; q < NQ; q++) fetch1(q);
+    left_v = left_f;
+#pragma unroll
+    for (int q = 0; q < NQ; q++) put(gram_lds, q);
+    aim(chunk_begin + 1);
+#pragma unroll
+    for (int q = 0; q < NQ; q++) fetch1(q);
+    left_v = left_f;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  for (int chunk = chunk_begin; chunk < chunk_end; chunk++) {
+    const double *cur = gram_lds + (size_t)((chunk - chunk_begin) & 1) * GR_ROWS * GR_LS;
+    double *nxt = gram_lds + (size_t)((chunk - chunk_begin + 1) & 1) * GR_ROWS * GR_LS; // last read two stages ago
+    wr = row0, wc = col0;
+#pragma unroll
+    for (int ks = 0; ks < 8; ks++) {
+      if (ks == 4) aim(chunk + 2);
+      const double *rowp = cur + (4 * ks + g) * GR_LS + cl;
+      double b[GR_NT];
+#pragma unroll
+      for (int j = JLO; j < NTC; j++) b[j] = rowp[16 * j];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = JLO; j < NTC; j++) {
+        if (j >= WR::R0 && WR::R0 < NTC) GRAM_MFMA(b[WR::R0 < NTC ? WR::R0 : 0], b[j], acc[j >= WR::R0 ? WR::O0 + j - WR::R0 : 0]);
+        if (j >= WR::R1 && WR::R1 < NTC) GRAM_MFMA(b[WR::R1 < NTC ? WR::R1 : 0], b[j], acc[j >= WR::R1 ? WR::O1 + j - WR::R1 : 0]);
+        if (j >= WR::R2 && WR::R2 < NTC) GRAM_MFMA(b[WR::R2 < NTC ? WR::R2 : 0], b[j], acc[j >= WR::R2 ? WR::O2 + j - WR::R2 : 0]);
+        if (j >= WR::R3 && WR::R3 < NTC) GRAM_MFMA(b[WR::R3 < NTC ? WR::R3 : 0], b[j], acc[j >= WR::R3 ? WR::O3 + j - WR::R3 : 0]);
+        if (j - JLO < SL) {
+          __builtin_amdgcn_sched_barrier(0);
+          const int q = (ks & 3) * SL + (j - JLO);
+          if (ks < 4) put(nxt, q); // k-steps 0-3: stage s + 1 from the registers into the other buffer
+          else fetch1(q);          // k-steps 4-7: stage s + 2 into the registers just freed
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+#pragma unroll
+      for (int sl = NTC - JLO; sl < SL; sl++) { // wavefronts with fewer tile columns than slots
+        const int q = (ks & 3) * SL + sl;
+        if (ks < 4) put(nxt, q);
+        else fetch1(q);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    left_v = left_f;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  }
+}
+
+template <int NTC> __global__ void __launch_bounds__(256) k_gram_il(GramParams p) {
+  extern __shared__ double gram_lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int NT = p.NT;
+  for (int i = tid; i < 2 * GR_ROWS * GR_LS; i += 256) gram_lds[i] = 0.0;
+  __syncthreads();
+  const int64_t nchunks = (p.rows_total + GR_ROWS - 1) / GR_ROWS;
+  const int chunk_begin = (int)((nchunks * blockIdx.x) / gridDim.x), chunk_end = (int)((nchunks * (blockIdx.x + 1)) / gridDim.x);
+  d4 acc[GR_ACC];
+#pragma unroll
+  for (int i = 0; i < GR_ACC; i++) acc[i] = d4{0, 0, 0, 0};
+  const int NP = NT * (NT + 1) / 2;
+  double *out = p.part + (size_t)blockIdx.x * NP * 256;
+  switch (wave) { // every wavefront runs its own instantiation: accumulator indices are compile-time
+  case 0: gram_il_loop<0, NTC>(p, gram_lds, tid, lane, chunk_begin, chunk_end, acc), gram_put<0>(out, NT, lane, acc); break;
+  case 1: gram_il_loop<1, NTC>(p, gram_lds, tid, lane, chunk_begin, chunk_end, acc), gram_put<1>(out, NT, lane, acc); break;
+  case 2: gram_il_loop<2, NTC>(p, gram_lds, tid, lane, chunk_begin, chunk_end, acc), gram_put<2>(out, NT, lane, acc); break;
+  default: gram_il_loop<3, NTC>(p, gram_lds, tid, lane, chunk_begin, chunk_end, acc), gram_put<3>(out, NT, lane, acc); break;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // 17 .. 23 tile columns in TWO passes over the stack instead of the block variant's three (BASELINE configs[4]: D = 356, NT = 23,
 // 276 tiles of the triangle against the ~224 a workgroup of four one-per-SIMD wavefronts can hold).  With WS = NT - 16:
 //   k_gram_wide_win  tile rows WS .. NT-1: a 16 x 16 tile triangle over the column window [16 WS, 16 NT) — k_gram's own schedule

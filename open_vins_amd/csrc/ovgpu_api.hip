@@ -204,6 +204,7 @@ struct ovgpu_ctx {
   hipEvent_t ev_lt = nullptr;       // the prior block's FACTOR kernel is done (L complete): the per-feature kernel waits for this, not for the carried columns
   bool lt_on_side = false;          // ev_lt is pending on the side stream
   bool cj_deferred = false;         // the factor kernel of a follow-on-main factorisation has not been joined yet (ev_cj)
+  bool gram_il = true;              // ovgpu_debug_option "gram_interleaved": k_gram_il (staging between the matrix instructions) instead of k_gram
   bool gram_blocks_only = false;    // ovgpu_debug_option "gram_blocks_only": the block variant (k_gram_blk) also where k_gram_wide applies
   bool chol_flag_sync = true;       // ovgpu_debug_option "chol_flag_sync": k_chol_factor2 (LDS flags instead of workgroup barriers in the step loop)
   bool fuse_chol_inputs = true;     // ovgpu_debug_option "fuse_chol_inputs": the factorisations read their inputs at the source (no k_tf_gather / k_tf_abh)
@@ -394,11 +395,20 @@ static int launch_qr_tree(ovgpu_ctx *c, int nodes, const QrTreeParams &q, hipStr
   return OVGPU_OK;
 }
 
-template <int NTC> static void launch_gram(int G, const gram::GramParams &g, hipStream_t s) {
+template <int NTC> static void launch_gram(int G, const gram::GramParams &g, hipStream_t s, bool interleaved) {
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute((const void *)gram::k_gram<NTC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if constexpr (NTC <= 14) (void)hipFuncSetAttribute((const void *)gram::k_gram_il<NTC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
+  }
+  // staging inside the matrix-instruction stream (k_gram_il) up to 14 tile columns; with 16 its 34 accumulator tiles + staged elements +
+  // hoisted LDS operands exceed the 512 registers of a wavefront (1.1 KB of scratch per lane) and k_gram stays
+  if constexpr (NTC <= 14) {
+    if (interleaved) {
+      hipLaunchKernelGGL(gram::k_gram_il<NTC>, dim3(G), dim3(256), gram::gram_lds_bytes(), s, g);
+      return;
+    }
   }
   hipLaunchKernelGGL(gram::k_gram<NTC>, dim3(G), dim3(256), gram::gram_lds_bytes(), s, g);
 }
@@ -1219,14 +1229,14 @@ static int enqueue_compress_gram(ovgpu_ctx *c, bool factor = true) {
     return factor ? set_err(OVGPU_ERR_CAPACITY, "the Cholesky-QR variant holds at most 255 Jacobian columns") : OVGPU_OK;
   }
   switch ((NT + 1) / 2) {
-  case 1: launch_gram<2>(G, g, c->stream); break;
-  case 2: launch_gram<4>(G, g, c->stream); break;
-  case 3: launch_gram<6>(G, g, c->stream); break;
-  case 4: launch_gram<8>(G, g, c->stream); break;
-  case 5: launch_gram<10>(G, g, c->stream); break;
-  case 6: launch_gram<12>(G, g, c->stream); break;
-  case 7: launch_gram<14>(G, g, c->stream); break;
-  default: launch_gram<16>(G, g, c->stream); break;
+  case 1: launch_gram<2>(G, g, c->stream, c->gram_il); break;
+  case 2: launch_gram<4>(G, g, c->stream, c->gram_il); break;
+  case 3: launch_gram<6>(G, g, c->stream, c->gram_il); break;
+  case 4: launch_gram<8>(G, g, c->stream, c->gram_il); break;
+  case 5: launch_gram<10>(G, g, c->stream, c->gram_il); break;
+  case 6: launch_gram<12>(G, g, c->stream, c->gram_il); break;
+  case 7: launch_gram<14>(G, g, c->stream, c->gram_il); break;
+  default: launch_gram<16>(G, g, c->stream, c->gram_il); break;
   }
   hipLaunchKernelGGL(gram::k_gram_reduce, dim3(NP), dim3(1024), 0, c->stream, NT, G, c->gram_part.p, c->gram_G.p);
   HIPCHK(hipGetLastError());
@@ -3100,6 +3110,9 @@ int ovgpu_debug_option(ovgpu_ctx *c, const char *name, int64_t value, int64_t *o
   } else if (n == "chol_flag_sync") {
     if (old_value) *old_value = c->chol_flag_sync ? 1 : 0;
     if (value >= 0) c->chol_flag_sync = value != 0;
+  } else if (n == "gram_interleaved") {
+    if (old_value) *old_value = c->gram_il ? 1 : 0;
+    if (value >= 0) c->gram_il = value != 0;
   } else if (n == "gram_blocks_only") {
     if (old_value) *old_value = c->gram_blocks_only ? 1 : 0;
     if (value >= 0) c->gram_blocks_only = value != 0;
