@@ -261,6 +261,26 @@ def test_end_to_end_update(Updater, oracle):
     up.close()
 
 
+@pytest.mark.parametrize("kw", [dict(no_single_launch_cholesky=1), dict(no_prior_overlap=1), dict(no_single_launch_cholesky=1, no_prior_overlap=1),
+                                dict(no_timing=1), dict(feature_kernel_shape=2), dict(no_fast_feature_kernel=1)])
+def test_mode_a_default_under_the_library_switches(Updater, oracle, kw):
+    """Mode A's default (pivoted factor of the whitened Gram matrix, un-whitened with the prior block's factor) takes that factor from
+    whichever factorisation ran — the single-launch Cholesky or the step-wise one, on the side stream or on the main one — and the
+    whitened rows from whichever per-feature kernel produced them: same compressed system (Gram matrices 1e-11) and posterior."""
+    prob = synth.make_problem(2, F=150)
+    v = capi.Views(prob)
+    base = capi.default_options(chi2_multipler=1.0)
+    tri = oracle.triangulate(base, v)
+    ref = oracle.msckf_update(base, v, want_compressed=True, given=tri)
+    G, g = ref["H_comp"].T @ ref["H_comp"], ref["H_comp"].T @ ref["r_comp"]
+    cmp = _compress_with(Updater, prob, base, tri, **kw)
+    H, r = cmp["H"], cmp["r"]
+    assert 0 < cmp["rows"] <= cmp["D"] == ref["D"] and np.array_equal(cmp["feat_status"], ref["feat_status"])
+    assert np.linalg.norm(H.T @ H - G) / np.linalg.norm(G) < 1e-11 and np.linalg.norm(H.T @ r - g) / np.linalg.norm(g) < 1e-10
+    st, P1, dx1 = oracle.ekf_update(prob.P, H, r, cmp["col_cov_id"], 1.0)
+    assert st == 0 and _rel(P1, ref["P"]) < TOL_P and _rel(dx1, ref["dx"]) < TOL_DX
+
+
 @pytest.mark.parametrize("route", ["default", "tsqr", "cholqr"])
 def test_mode_a_compressed_system(Updater, oracle, route):
     """ovgpu_msckf_compress hands back (H, r) for the stock StateHelper::EKFUpdate: H^T H and H^T r equal the reference's compressed
