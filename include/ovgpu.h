@@ -338,7 +338,7 @@ int ovgpu_msckf_update(ovgpu_ctx *ctx, int32_t *feat_status, double *chi2,
  * and H^T-weighted residuals), and both forms below carry the stack's:
  *   default (OVGPU_COMPRESS_GRAM)  the diagonally pivoted Cholesky factor of the prior-whitened stack's Gram
  *                                  matrix, un-whitened: DENSE, rows = its numerical rank (the stack of an MSCKF
- *                                  update has a null space: gauge directions) — 1.8 ms host to host at 2000 features
+ *                                  update has a null space: gauge directions) — 1.2 ms host to host at 2000 features
  *   OVGPU_COMPRESS_TSQR            the reference's form, the upper-triangular Householder factor, rows = D
  *                                  (4.0 ms); also taken beyond 255 columns and when the prior block's
  *                                  factorisation fails.  ovgpu_last_update_route tells which one came back. */

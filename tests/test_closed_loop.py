@@ -145,7 +145,7 @@ def test_mode_a_closed_loop(stream, oracle_run, route):
     """Mode A as the shim ships it: ovgpu_msckf_compress hands (H, r) to the STOCK EKFUpdate — here the oracle's restatement of
     StateHelper::EKFUpdate and of the box-plus — 52 frames with the posterior fed back.
     default = the diagonally PIVOTED Cholesky factor of the whitened stack's Gram matrix, un-whitened (k_gram_pchol; Gram-route cost,
-              2.2 x faster host to host than the Householder route): the oracle-driven trajectory to round-off;
+              3.2 x faster host to host than the Householder route): the oracle-driven trajectory to round-off;
     tsqr    = the Householder TSQR's triangle, the reference's own form: likewise;
     cholqr  = the UNPIVOTED factor, round 3's negative result: the whitened Gram matrix is numerically singular (gauge directions,
               weakly observed calibration), a pivot that is rounding noise divides its row, one step loses 1e-8 of dx and the loop
