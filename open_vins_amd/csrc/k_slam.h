@@ -190,7 +190,10 @@ __global__ void k_anchor_change(AnchorParams p) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   const int l = p.l;
   const int old_cam = p.lm.anchor[l] >> 10, old_clone = p.lm.anchor[l] & 1023;
-  const V3 pA_old = lm_to_xyz(p.rep, p.lm.value + 3 * l), pA_old_fej = lm_to_xyz(p.rep, p.lm.fej + 3 * l);
+  // Landmark::get_xyz(true) ignores its flag for ANCHORED_MSCKF_INVERSE_DEPTH and the single depth (Landmark.cpp:47-59 read value() /
+  // uv_norm_zero in both cases): for these two the "first estimate" that moves to the new anchor is the CURRENT estimate
+  const bool fej_reads_value = p.rep == OVGPU_REP_ANCHORED_MSCKF_INVERSE_DEPTH || p.rep == OVGPU_REP_ANCHORED_INVERSE_DEPTH_SINGLE;
+  const V3 pA_old = lm_to_xyz(p.rep, p.lm.value + 3 * l), pA_old_fej = lm_to_xyz(p.rep, (fej_reads_value ? p.lm.value : p.lm.fej) + 3 * l);
   double Hf_old[9], Ha_old[18], Hc_old[18], Hf_new[9], Ha_new[18], Hc_new[18];
   // the single-depth landmark uses the Jacobians of the MSCKF inverse depth (its third column is d p / d rho)
   const int jrep = p.rep == OVGPU_REP_ANCHORED_INVERSE_DEPTH_SINGLE ? OVGPU_REP_ANCHORED_MSCKF_INVERSE_DEPTH : p.rep;

@@ -256,12 +256,15 @@ def load_traj_window():
     return np.loadtxt(TRAJ_FIXTURE, comments="#")
 
 
-def state_sigmas(C, K):
-    """Per-dof prior sigma in covariance order: IMU 15, dt 1, K x (extrinsic 6, intrinsic 8), C x clone 6.
+def state_sigmas(C, K, imu_intrinsics=False):
+    """Per-dof prior sigma in covariance order: IMU 15, [IMU intrinsics 24: dw 6, da 6, tg 9, R_GYROtoIMU 3 -- State.cpp:65-88,
+    priors :137-150], dt 1, K x (extrinsic 6, intrinsic 8), C x clone 6.
 
     IMU block: ov_msckf/src/core/VioManagerHelper.cpp:49-52; calibration: ov_msckf/src/state/State.cpp:150-164;
     clones: SURVEY.md §8d (0.01 rad, 0.05 m)."""
     s = [0.017] * 3 + [0.05] * 3 + [0.01] * 3 + [0.02] * 3 + [0.02] * 3  # q p v bg ba
+    if imu_intrinsics:
+        s += [0.005] * 6 + [0.008] * 6 + [0.005] * 9 + [0.005] * 3
     s += [0.01]  # dt
     for _ in range(K):
         s += [0.005] * 3 + [0.015] * 3 + [1.0] * 4 + [0.005] * 4
@@ -271,13 +274,15 @@ def state_sigmas(C, K):
 
 
 def make_problem(cfg=2, rep=0, *, C=None, K=None, F=None, track="full", fisheye=False,
-                 min_obs=5, pose_noise=1.0, seed=None, shard=0, outlier_frac=0.0) -> Problem:
+                 min_obs=5, pose_noise=1.0, seed=None, shard=0, outlier_frac=0.0, imu_intrinsics=False) -> Problem:
     """Builds the snapshot of BASELINE.json config `cfg`; C/K/F override its sizes.
 
     track = "full": every visible observation is kept; "ragged": a contiguous sub-window of clones of
     length ~U[5, C] per feature.  The state (clones, calibration, prior P) depends only on (cfg, rep / seed,
     C, K); `shard` selects an independent feature stream on the same state (feature-sharded multi-GPU runs).
-    outlier_frac: fraction of features whose pixels get a gross 15 px offset (exercises the chi2 gate)."""
+    outlier_frac: fraction of features whose pixels get a gross 15 px offset (exercises the chi2 gate).
+    imu_intrinsics: the state also calibrates the IMU intrinsics (BASELINE configs[2] "online cam/IMU calib": 24 more rows of P behind
+    the IMU block, N = 248 at 30 clones x 2 cameras); they never get Jacobian columns, only correlations."""
     base = CONFIGS[cfg]
     C = C or base["C"]
     K = K or base["K"]
@@ -415,17 +420,18 @@ def make_problem(cfg=2, rep=0, *, C=None, K=None, F=None, track="full", fisheye=
     pf_l = np.concatenate(pf_l, axis=0)
 
     # --- prior covariance ---------------------------------------------------
-    N = 16 + 14 * K + 6 * C
-    sig = state_sigmas(C, K)
+    base = 16 + (24 if imu_intrinsics else 0)
+    N = base + 14 * K + 6 * C
+    sig = state_sigmas(C, K, imu_intrinsics)
     assert sig.shape[0] == N
     G = np.tril(rng_P.normal(0, 1.0 / np.sqrt(N), (N, N)), -1)
     L = sig[:, None] * (np.eye(N) + 0.1 * G)
     P = L @ L.T
     P = 0.5 * (P + P.T)
 
-    calib_cov_id = np.array([16 + 14 * k for k in range(K)], dtype=np.int32)
-    intr_cov_id = np.array([16 + 14 * k + 6 for k in range(K)], dtype=np.int32)
-    clone_cov_id = np.array([16 + 14 * K + 6 * c for c in range(C)], dtype=np.int32)
+    calib_cov_id = np.array([base + 14 * k for k in range(K)], dtype=np.int32)
+    intr_cov_id = np.array([base + 14 * k + 6 for k in range(K)], dtype=np.int32)
+    clone_cov_id = np.array([base + 14 * K + 6 * c for c in range(C)], dtype=np.int32)
 
     return Problem(
         cfg=cfg, seed=seed, N=N, C=C, K=K, P=np.ascontiguousarray(P),

@@ -2036,7 +2036,11 @@ int oracle_anchor_change(const ovgpu_options *opts, const ovgpu_state_view *st, 
   const int sz = single ? 1 : 3, j0 = 3 - sz;
   const int old_cam = lm->anchor_cam[l], old_clone = lm->anchor_clone[l];
   const V3 nanv{{NAN, NAN, NAN}};
-  V3 pA_old = landmark_get_xyz(rep, lm->p_value + 3 * l), pA_old_fej = landmark_get_xyz(rep, lm->p_fej + 3 * l); // :517-518
+  // :517-518.  Landmark::get_xyz(true) (Landmark.cpp:47-59) IGNORES its flag for ANCHORED_MSCKF_INVERSE_DEPTH and for the single depth:
+  // both branches read value() / uv_norm_zero, so the "first estimate" carried into the new anchor is the CURRENT estimate for these
+  // two representations (found by running the reference's own code, oracle/_ref; ANCHORED_3D / _FULL_INVERSE_DEPTH honour the flag).
+  const bool fej_reads_value = rep == OVGPU_REP_ANCHORED_MSCKF_INVERSE_DEPTH || rep == OVGPU_REP_ANCHORED_INVERSE_DEPTH_SINGLE;
+  V3 pA_old = landmark_get_xyz(rep, lm->p_value + 3 * l), pA_old_fej = landmark_get_xyz(rep, (fej_reads_value ? lm->p_value : lm->p_fej) + 3 * l);
   RepJac jo = feature_jacobian_representation(o, T, jrep, nanv, nanv, pA_old, old_cam, old_clone);              // :523-526
   // transform between the old anchor and the new one, current (:536-551) and first estimates (:556-571)
   V3 pA_new, pA_new_fej;
