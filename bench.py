@@ -36,6 +36,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP64_TFLOPS = 78.6  # MI355X FP64 vector = matrix peak (spec), 256 CU x 128 flop/clk x 2.4 GHz
+PEAK_FP32_TFLOPS = 157.3  # MI355X FP32 matrix (v_mfma_f32_32x32x2_f32) = vector peak, 256 CU x 256 flop/clk x 2.4 GHz (MI355X_MICROARCH.md)
 CFG_SINGLE, CFG_MULTI = 3, 4  # synth.CONFIGS keys = BASELINE.json configs index + 1
 WEAK_FEATURES_PER_GPU = 1250
 
@@ -43,8 +44,8 @@ WEAK_FEATURES_PER_GPU = 1250
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=1200, help="updates per timed loop (default: ~1 s of device time per loop at the N = 1 workload)")
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--cfg", type=int, default=None, help="BASELINE.json config index + 1 (default: 3 at one GPU, 4 beyond)")
     ap.add_argument("--features", type=int, default=None, help="override the TOTAL number of features of the update")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -89,6 +90,12 @@ def gated_flops(prob, status, capi, synth):
         if used[f]:
             fc += 2 * r * D * D
     return fs, fc
+
+
+def ekf_flops(prob):
+    """once per update, the EKF term 4 N D^2 + 2.33 D^3 + N^2 D."""
+    N, D = prob.N, prob.Dmax
+    return 4.0 * N * D * D + 2.33 * D ** 3 + float(N) * N * D
 
 
 def main(argv=None):
@@ -257,7 +264,8 @@ def main(argv=None):
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "f64 (Gram accumulation: f32 products, f64 totals per 32 rows)" if args.gram_fp32 else "f64",
+            "dtype": ("f64 per-feature stage and update; compression (configs[4]'s fp32 variant): f32 stack, f32 products on v_mfma_f32_32x32x2_f32, "
+                      "two-level f32 sums per <= 1536 rows, f64 beyond") if args.gram_fp32 else "f64",
             "data": "synthetic",
             "config": {
                 "workload": (f"BASELINE.json configs[{cfg - 1}]: {prob.K}-camera radtan rig, {prob.C}-clone window, {prob.F} MSCKF features/update"
@@ -279,16 +287,25 @@ def main(argv=None):
                 "unit": "TFLOP/s",
                 "frac": achieved / PEAK_FP64_TFLOPS,
                 "traffic": traffic.get("per_feature") if traffic else None,
+                "traffic_source": (traffic.get("source") if traffic else None),  # NOT measured in this run: the committed rocprofv3 --pmc passes
                 "algorithmic_flops_per_launch": flops_system,
                 "avg_ms_per_launch": ms_s,
                 "compression": {
-                    "kernel": ("k_gram<NT> (v_mfma_f64_16x16x4_f64 rank-k update of the whitened stack) + k_gram_reduce, timed together" if gram else
+                    "kernel": (("k_gram_f32 (v_mfma_f32_32x32x2_f32 rank-k update from the FP32 whitened stack, csrc/k_gram32.h) + k_gram_f32_reduce (f64), timed together"
+                                if args.gram_fp32 else "k_gram<NT> (v_mfma_f64_16x16x4_f64 rank-k update of the whitened stack) + k_gram_reduce, timed together") if gram else
                                "Householder TSQR leaf + merge tree"),
-                    "achieved": exec_c, "frac": exec_c / PEAK_FP64_TFLOPS, "algorithmic_tflops": achieved_c,
+                    "dtype": "f32" if (gram and args.gram_fp32) else "f64",
+                    "peak": PEAK_FP32_TFLOPS if (gram and args.gram_fp32) else PEAK_FP64_TFLOPS,
+                    "achieved": exec_c, "frac": exec_c / (PEAK_FP32_TFLOPS if (gram and args.gram_fp32) else PEAK_FP64_TFLOPS), "algorithmic_tflops": achieved_c,
                     "algorithmic_flops_per_launch": flops_compress, "avg_ms_per_launch": ms_c,
                     "traffic": traffic.get("compression") if (traffic and gram) else None,
                 },
                 "update_ms_device": kt["ms_update"],
+                # the whole update (every kernel between the two barriers) against the same peak: SURVEY 8(d)'s algorithmic FLOPs of the
+                # per-feature stages + the compression (Householder-equivalent count) + the EKF term, over ms_per_step
+                "whole_update": {"algorithmic_flops": flops_system + flops_compress + ekf_flops(prob),
+                                 "achieved": (flops_system + flops_compress + ekf_flops(prob)) / (ms_per_step * 1e-3) / 1e12,
+                                 "frac": (flops_system + flops_compress + ekf_flops(prob)) / (ms_per_step * 1e-3) / 1e12 / PEAK_FP64_TFLOPS},
                 "stage_events": f"HIP events around the stages on every {args.stage_events_every}th update of the timed region ({kt['launches']} updates sampled)",
             },
         }
@@ -366,7 +383,7 @@ def pmc_traffic_bytes(cfg):
         if not names:
             return None
         return sum(1024.0 * (2.0 * k[n]["FETCH_SIZE_KiB"] + k[n]["WRITE_SIZE_KiB"]) for n in names)
-    return {"per_feature": tot(["k_feat"]), "compression": tot(["k_gram"])}
+    return {"per_feature": tot(["k_feat"]), "compression": tot(["k_gram"]), "source": os.path.relpath(path, ROOT)}
 
 
 def _oracle_chunk(job):

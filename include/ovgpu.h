@@ -32,6 +32,23 @@ extern "C" {
 #endif
 
 /* ------------------------------------------------------------------------- */
+/* ABI version.  Bumped whenever an entry point changes what it returns.      */
+/*   3  (round 3) ovgpu_msckf_compress: the DEFAULT compressed system is the  */
+/*      dense, rank x D pivoted-Cholesky factor of the whitened Gram matrix   */
+/*      (rows < D possible, not triangular); the reference's upper-triangular */
+/*      D x D Householder factor needs compress_route = OVGPU_COMPRESS_TSQR.  */
+/*      A caller that assumes rows == D or a triangle must set that route.    */
+/*   4  (round 4) perform_anchor_change: the first estimate of an             */
+/*      ANCHORED_MSCKF_INVERSE_DEPTH / single-depth landmark moves as the     */
+/*      reference moves it (Landmark::get_xyz(true) reads the current value); */
+/*      multi-rank updates return OVGPU_ERR_HIP on a follower time-out        */
+/*      instead of repeating locally; ovgpu_update_stats::ms_* are 0 for an   */
+/*      update that recorded no stage events.                                 */
+/* ------------------------------------------------------------------------- */
+#define OVGPU_ABI_VERSION 4
+int ovgpu_abi_version(void);
+
+/* ------------------------------------------------------------------------- */
 /* status codes                                                              */
 /* ------------------------------------------------------------------------- */
 typedef enum {
@@ -717,7 +734,12 @@ int ovgpu_comm_destroy(ovgpu_ctx *ctx);
 
 /* UpdaterMSCKF::update of THIS rank's shard (uploaded with ovgpu_set_features on the replicated state): local stage, exchange and
  * update are enqueued back to back on the context's stream, no host synchronisation in between.  Per-feature outputs are the
- * shard's; dx / P_out are identical on every rank.  _async returns after enqueueing (status through ovgpu_synchronize). */
+ * shard's; dx / P_out are identical on every rank.  _async returns after enqueueing (status through ovgpu_synchronize).
+ * Errors: OVGPU_ERR_NOT_SPD conditions of the (replicated) prior are repeated through the Householder route on every rank alike.
+ * A follower time-out of the single-launch Cholesky (a scheduling event of ONE rank, possible only when the device is shared) is NOT
+ * repeated in a world of more than one rank -- a local repeat would issue a collective the peers never match: OVGPU_ERR_HIP is
+ * returned, this rank's state is untouched while the peers have applied the update, and the caller uploads the state again on every
+ * rank (ovgpu_multi_msckf_update: the same, detected for the whole set).  options.no_single_launch_cholesky = 1 rules it out. */
 int ovgpu_msckf_update_sharded(ovgpu_ctx *ctx, int32_t *feat_status, double *chi2, double *chi2_thresh, double *p_FinG, double *dx, double *P_out,
                                ovgpu_update_stats *stats);
 int ovgpu_msckf_update_sharded_async(ovgpu_ctx *ctx);

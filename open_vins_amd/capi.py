@@ -180,6 +180,7 @@ def declare(lib):
         "ovgpu_destroy": (None, [ctxp]),
         "ovgpu_last_error": (C.c_char_p, []),
         "ovgpu_chi2_quantile_95": (C.c_double, [C.c_int]),
+        "ovgpu_abi_version": (C.c_int, []),
         "ovgpu_set_state": (C.c_int, [ctxp, C.POINTER(StateView)]),
         "ovgpu_set_camera_poses": (C.c_int, [ctxp, C.c_int, C.c_int, c_double_p, c_double_p]),
         "ovgpu_set_features": (C.c_int, [ctxp, C.POINTER(FeaturesView)]),

@@ -290,7 +290,7 @@ __device__ __forceinline__ double gate_cholesky_chi2(d4 (&acc)[TPW], const int (
 // goes through the scalar cache, and the thread-per-column form this replaces (Jacobian values as scalar operands, 100+ scalar
 // registers per measurement, 229 of them spilled) spent 44 % of the kernel in its sweep.
 // ---------------------------------------------------------------------------------------------------
-template <int NW, int TPW, int OCC>
+template <int NW, int TPW, int OCC, bool F32OUT = false>
 __global__ void __launch_bounds__(64 * NW, OCC)
     k_feat_y(SysParams p, int nt_max, const double *__restrict__ rowsG, const int32_t *__restrict__ minfoG, const double *__restrict__ VG,
              const double *__restrict__ tqG, const int32_t *__restrict__ instG) {
@@ -337,9 +337,9 @@ __global__ void __launch_bounds__(64 * NW, OCC)
     const int m = __builtin_amdgcn_readfirstlane(p.meas_offsets[f + 1]) - m0;
     const int64_t orow0 = p.row_off[f];
     const int n_out = (int)(p.row_off[f + 1] - orow0); // 2m - 3 (0 when m < 2)
-    double *out = p.Hbig + orow0 * LD;
+    const StackRows<F32OUT> out(p, orow0);
     if (p.status[f] != OVGPU_FEAT_USED) { // failed before the gate: its rows of the stack are zero
-      for (int64_t e = tid; e < (int64_t)n_out * LD; e += NTH) out[e] = 0.0;
+      for (int64_t e = tid; e < (int64_t)n_out * out.ld; e += NTH) out.zero(e);
       lds_barrier(); // everybody has read sched[2]
       if (tid == 0) sched[2] = atomicAdd(p.work_counter, 1);
       continue;
@@ -388,7 +388,8 @@ __global__ void __launch_bounds__(64 * NW, OCC)
 #pragma unroll
       for (int w = 0; w < NW; w++) w0 += zres[3 * w], w1 += zres[3 * w + 1], w2 += zres[3 * w + 2];
       const double z0 = T00 * w0, z1 = T01 * w0 + T11 * w1, z2 = T02 * w0 + T12 * w1 + T22 * w2;
-      if (tid >= 3 && tid < n) out[(size_t)(tid - 3) * LD + D] = r_a - (v0 * z0 + v1 * z1 + v2 * z2); // the residual column is not whitened
+      if (tid >= 3 && tid < n) out.put(tid - 3, D, r_a - (v0 * z0 + v1 * z1 + v2 * z2)); // the residual column is not whitened
+      out.pad(tid, NTH, n_out, LD);
     }
     FEAT_T(0)
 
@@ -486,7 +487,7 @@ __global__ void __launch_bounds__(64 * NW, OCC)
         if (c < D) {
 #pragma unroll 8
           for (int a = 3 + wv; a < n; a += NW)
-            out[(size_t)(a - 3) * LD + c] = Yb[(size_t)a * FY_LS + lane] - (Vl[3 * a] * z0 + Vl[3 * a + 1] * z1 + Vl[3 * a + 2] * z2);
+            out.put(a - 3, c, Yb[(size_t)a * FY_LS + lane] - (Vl[3 * a] * z0 + Vl[3 * a + 1] * z1 + Vl[3 * a + 2] * z2));
         }
       }
       FEAT_T(2)
@@ -549,7 +550,7 @@ __global__ void __launch_bounds__(64 * NW, OCC)
     lds_barrier();
     if (sched[1]) { // rejected: its rows leave the stack — behind a full barrier: other wavefronts' stores to the same addresses must have landed
       __syncthreads();
-      for (int64_t e = tid; e < (int64_t)n_out * LD; e += NTH) out[e] = 0.0;
+      for (int64_t e = tid; e < (int64_t)n_out * out.ld; e += NTH) out.zero(e);
     }
     FEAT_T(5)
   }

@@ -53,7 +53,7 @@ __host__ __device__ inline FeatYBigLds featyb_lds_layout(int nt_max, int nw) {
 // scratch per workgroup: row panels W_kj, tile (k, j) at (k (nt_max + 1) + j) * 256
 __host__ __device__ inline size_t featyb_ws_doubles(int nt_max) { return (size_t)nt_max * (nt_max + 1) * 256; }
 
-template <int NW, int TPW>
+template <int NW, int TPW, bool F32OUT = false>
 __global__ void __launch_bounds__(64 * NW, 1)
     k_feat_y_big(SysParams p, int nt_max, const double *__restrict__ rowsG, const int32_t *__restrict__ minfoG, const double *__restrict__ VG,
                  const double *__restrict__ tqG, const int32_t *__restrict__ instG, double *wsG) {
@@ -95,9 +95,9 @@ __global__ void __launch_bounds__(64 * NW, 1)
     const int m = __builtin_amdgcn_readfirstlane(p.meas_offsets[f + 1]) - m0;
     const int64_t orow0 = p.row_off[f];
     const int n_out = (int)(p.row_off[f + 1] - orow0);
-    double *out = p.Hbig + orow0 * LD;
+    const StackRows<F32OUT> out(p, orow0);
     if (p.status[f] != OVGPU_FEAT_USED) {
-      for (int64_t e = tid; e < (int64_t)n_out * LD; e += NTH) out[e] = 0.0;
+      for (int64_t e = tid; e < (int64_t)n_out * out.ld; e += NTH) out.zero(e);
       lds_barrier();
       if (tid == 0) sched[2] = atomicAdd(p.work_counter, 1);
       continue;
@@ -127,7 +127,8 @@ __global__ void __launch_bounds__(64 * NW, 1)
 #pragma unroll
       for (int w = 0; w < NW; w++) w0 += zres[3 * w], w1 += zres[3 * w + 1], w2 += zres[3 * w + 2];
       const double z0 = T00 * w0, z1 = T01 * w0 + T11 * w1, z2 = T02 * w0 + T12 * w1 + T22 * w2;
-      if (tid >= 3 && tid < n) out[(size_t)(tid - 3) * LD + D] = r_a - (v0 * z0 + v1 * z1 + v2 * z2);
+      if (tid >= 3 && tid < n) out.put(tid - 3, D, r_a - (v0 * z0 + v1 * z1 + v2 * z2));
+      out.pad(tid, NTH, n_out, LD);
     }
     if (tid == 0) sched[2] = atomicAdd(p.work_counter, 1); // every wavefront has read the current slot (barrier above)
 
@@ -237,7 +238,7 @@ __global__ void __launch_bounds__(64 * NW, 1)
           if (c < D) {
 #pragma unroll 4
             for (int r = 3 + 2 * wv + hp; r < n; r += 2 * NW)
-              out[(size_t)(r - 3) * LD + c] = Yb[(size_t)r * FB_LS + col32] - (Vl[3 * r] * z0 + Vl[3 * r + 1] * z1 + Vl[3 * r + 2] * z2);
+              out.put(r - 3, c, Yb[(size_t)r * FB_LS + col32] - (Vl[3 * r] * z0 + Vl[3 * r + 1] * z1 + Vl[3 * r + 2] * z2));
           }
         }
         // SYRK: this pass's tiles += Y_i Y_j^T over the slabs of 8 columns both tile rows reach
@@ -423,7 +424,7 @@ __global__ void __launch_bounds__(64 * NW, 1)
     }
     lds_barrier();
     if (sched[1]) { // rejected: its rows leave the stack (the pass loop ended with a full barrier: the rows' stores have landed)
-      for (int64_t e = tid; e < (int64_t)n_out * LD; e += NTH) out[e] = 0.0;
+      for (int64_t e = tid; e < (int64_t)n_out * out.ld; e += NTH) out.zero(e);
     }
   }
 }

@@ -25,6 +25,7 @@
 #include "k_featy.h"
 #include "k_featy_big.h"
 #include "k_gram.h"
+#include "k_gram32.h"
 #include <unordered_map>
 #include <dlfcn.h>
 #include "k_system.h"
@@ -262,6 +263,12 @@ struct ovgpu_ctx {
   bool no_chol_pipe = false;   // options.no_single_launch_cholesky
   int feat_shape = 0;          // options.feature_kernel_shape
   bool gram_fp32 = false;      // options.gram_fp32
+  bool want_stack_f32 = false; // this pipeline: gram_fp32 on the prior-whitened Gram route -> the fused per-feature kernels may store floats
+  bool stack_is_f32 = false;   // ... and did: the stack is c->Hbig32 [rows_total][stack_ldf] (k_gram32.h reads it)
+  int stack_ldf = 0;
+  DevBuf<float> Hbig32, gram32_part;
+  DevBuf<int32_t> gram32_tiles;
+  int gram32_ntm = 0, gram32_P = 0; // the tile table on the device is for this macro grid
   int Lw_D = -1;               // column count c->Lw was zeroed for (its upper triangle stays zero)
   DevBuf<long long> dbg_cycles; // ovgpu_debug_cycles: per-phase cycle counters of workgroup 0 of the per-feature kernel
   int tsqr_workers = 0;         // options.tsqr_workers
@@ -288,6 +295,7 @@ struct ovgpu_ctx {
   // ---- timing
   std::vector<EventPair> ev_compress, ev_update, ev_system;
   size_t ev_used = 0;
+  bool timed_this_update = false; // the last enqueued pipeline recorded its stage events (stage_timing_period skips most)
   bool timing = true;
   int timing_period = 1;        // ovgpu_debug_option "stage_timing_period": the stage events go into every n-th update only (each is a
   uint64_t timing_seq = 0;      // marker packet the next kernel waits for: ~3 us apiece, six per update)
@@ -447,6 +455,7 @@ void ovgpu_default_options(ovgpu_options *o) {
 }
 
 double ovgpu_chi2_quantile_95(int dof) { return chi2_quantile_95(dof); }
+int ovgpu_abi_version(void) { return OVGPU_ABI_VERSION; }
 
 int ovgpu_create(const ovgpu_options *opts, int device, ovgpu_ctx **out) {
   if (!opts || !out) return set_err(OVGPU_ERR_INVALID, "null argument");
@@ -543,6 +552,7 @@ void ovgpu_destroy(ovgpu_ctx *c) {
   c->retri_sys[0].release(), c->retri_sys[1].release(), c->retri_pos.release(), c->retri_uvd.release(), c->retri_int.release(), c->retri_f.release(), c->marg_idx.release(), c->marg_out.release(), c->seed_anchor.release(), c->seed_pA.release();
   c->meas_offsets.release(), c->meas_cc.release(), c->uv.release(), c->uvn.release(), c->row_off.release();
   c->pA.release(), c->pG.release(), c->chi2.release(), c->chi2_thr.release(), c->anchor.release(), c->status.release(), c->sys_order.release(), c->feat_sigma.release(), c->feat_mult.release();
+  c->Hbig32.release(), c->gram32_part.release(), c->gram32_tiles.release();
   c->chi2_table.release(), c->Hbig.release(), c->gate_ws.release(), c->Rws.release(), c->tree_nodes.release(), c->tree_nodes2.release(), c->tree_flags.release(), c->tree_err.release(), c->Mt.release(), c->Aaug.release(), c->Yaug.release();
   c->pFej.release(), c->lm_val.release(), c->lm_fej.release(), c->feat_lm.release(), c->feat_lmcol.release(), c->feat_lmcov.release(), c->lm_cov.release();
   c->feat_anchor.release(), c->lm_col.release(), c->lm_anchor.release(), c->lm_index.release(), c->Ppad.release(), c->init_ws.release(), c->dx_seq.release();
@@ -992,6 +1002,8 @@ static int enqueue_system(ovgpu_ctx *c, int f_one = -1, int init_rep = 0, bool w
   p.status = c->status.p, p.chi2 = c->chi2.p, p.chi2_thresh = c->chi2_thr.p;
   p.chi2_table = c->chi2_table.p, p.chi2_table_len = c->chi2_table_len;
   p.row_off = c->row_off.p, p.Hbig = c->Hbig.p, p.ws = c->gate_ws.p, p.ws_stride = c->gate_ws_stride;
+  p.Hbig32 = nullptr, p.LDF = 0;
+  c->stack_is_f32 = false;
   p.m_lds_max = c->m_lds_max, p.m_max = std::max(c->m_max, 1), p.row_stride = c->row_stride;
   p.opt = c->dopt;
   p.dbg = c->dbg_cycles.p ? c->dbg_cycles.p : qr_dbg_buffer();
@@ -1042,10 +1054,21 @@ static int enqueue_system(ovgpu_ctx *c, int f_one = -1, int init_rep = 0, bool w
       if (!attr_y) {
         (void)hipFuncSetAttribute((const void *)feat::k_feat_y<4, 11, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_limit);
         (void)hipFuncSetAttribute((const void *)feat::k_feat_y<8, 17, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_limit);
+        (void)hipFuncSetAttribute((const void *)feat::k_feat_y<4, 11, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_limit);
+        (void)hipFuncSetAttribute((const void *)feat::k_feat_y<8, 17, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_limit);
         (void)hipFuncSetAttribute((const void *)feat::k_feat_y<8, 6, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_limit);
         (void)hipFuncSetAttribute((const void *)feat::k_feat_y<6, 8, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_limit);
         (void)hipFuncSetAttribute((const void *)feat::k_feat_vt, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_limit);
         attr_y = true;
+      }
+      const bool f32_twin = (c->feat_variant == 3 || c->featy_big) ? c->featy_big != 2 : !(c->feat_variant == 1 && (c->featy_shape == 1 || c->featy_shape == 2));
+      if (c->want_stack_f32 && f_one < 0 && f32_twin) { // options.gram_fp32: the rows leave as floats, stride 32 ceil(LD / 32) (k_gram32.h)
+        c->stack_ldf = ((c->LD + 31) / 32) * 32;
+        HIPCHK(c->Hbig32.reserve((size_t)(std::max<int64_t>(c->rows_total, 1) + 32) * c->stack_ldf));
+        // k_gram_f32 copies whole 32-row stages: the rows behind the last feature's must read as zeros
+        HIPCHK(hipMemsetAsync(c->Hbig32.p + (size_t)c->rows_total * c->stack_ldf, 0, sizeof(float) * 32 * c->stack_ldf, c->stream));
+        p.Hbig32 = c->Hbig32.p, p.LDF = c->stack_ldf;
+        c->stack_is_f32 = true;
       }
       hipLaunchKernelGGL(feat::k_feat_rows_sorted, dim3((c->M + 255) / 256), dim3(256), 0, c->stream, p, st, c->M);
       hipLaunchKernelGGL(feat::k_feat_vt, dim3((c->F + 3) / 4), dim3(256), (size_t)4 * (12 * p.m_max + 64) * sizeof(double), c->stream, p, st, c->fs_tq.p, c->fs_inst.p, c->feat_nt_max);
@@ -1056,6 +1079,7 @@ static int enqueue_system(ovgpu_ctx *c, int f_one = -1, int init_rep = 0, bool w
         static bool attr_b = false;
         if (!attr_b) {
           (void)hipFuncSetAttribute((const void *)feat::k_feat_y_big<8, 17>, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_limit);
+          (void)hipFuncSetAttribute((const void *)feat::k_feat_y_big<8, 17, true>, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_limit);
           (void)hipFuncSetAttribute((const void *)feat::k_feat_y_big<8, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_limit);
           attr_b = true;
         }
@@ -1064,6 +1088,7 @@ static int enqueue_system(ovgpu_ctx *c, int f_one = -1, int init_rep = 0, bool w
         if (ldsb > (size_t)c->lds_limit || nt > 29) return set_err(OVGPU_ERR_CAPACITY, "k_feat_y_big: track too long for its LDS block");
         HIPCHK(c->featyb_ws.reserve((size_t)gridb * feat::featyb_ws_doubles(nt)));
         if (c->featy_big == 2) hipLaunchKernelGGL((feat::k_feat_y_big<8, 5>), dim3(gridb), dim3(512), ldsb, c->stream, p, nt, sr, sm, sV, stq, sin, c->featyb_ws.p);
+        else if (p.Hbig32) hipLaunchKernelGGL((feat::k_feat_y_big<8, 17, true>), dim3(gridb), dim3(512), ldsb, c->stream, p, nt, sr, sm, sV, stq, sin, c->featyb_ws.p);
         else hipLaunchKernelGGL((feat::k_feat_y_big<8, 17>), dim3(gridb), dim3(512), ldsb, c->stream, p, nt, sr, sm, sV, stq, sin, c->featyb_ws.p);
       } else if (c->feat_variant == 1 && c->featy_shape == 1) {
         const feat::FeatYLds lo8 = feat::featy_lds_layout(c->feat_nt_max, 8);
@@ -1073,7 +1098,9 @@ static int enqueue_system(ovgpu_ctx *c, int f_one = -1, int init_rep = 0, bool w
         const feat::FeatYLds lo6 = feat::featy_lds_layout(c->feat_nt_max, 6);
         const int per_cu = std::max(1, std::min(2, (int)((size_t)c->lds_limit / lo6.total)));
         hipLaunchKernelGGL((feat::k_feat_y<6, 8, 3>), dim3(std::max(1, std::min(c->F, c->num_cu * per_cu))), dim3(384), lo6.total, c->stream, p, c->feat_nt_max, sr, sm, sV, stq, sin);
-      } else if (c->feat_variant == 1) hipLaunchKernelGGL((feat::k_feat_y<4, 11, 2>), dim3(c->featy_grid), dim3(256), c->featy_lds, c->stream, p, c->feat_nt_max, sr, sm, sV, stq, sin);
+      } else if (c->feat_variant == 1 && p.Hbig32) hipLaunchKernelGGL((feat::k_feat_y<4, 11, 2, true>), dim3(c->featy_grid), dim3(256), c->featy_lds, c->stream, p, c->feat_nt_max, sr, sm, sV, stq, sin);
+      else if (c->feat_variant == 1) hipLaunchKernelGGL((feat::k_feat_y<4, 11, 2>), dim3(c->featy_grid), dim3(256), c->featy_lds, c->stream, p, c->feat_nt_max, sr, sm, sV, stq, sin);
+      else if (p.Hbig32) hipLaunchKernelGGL((feat::k_feat_y<8, 17, 1, true>), dim3(c->featy_grid), dim3(512), c->featy_lds, c->stream, p, c->feat_nt_max, sr, sm, sV, stq, sin);
       else hipLaunchKernelGGL((feat::k_feat_y<8, 17, 1>), dim3(c->featy_grid), dim3(512), c->featy_lds, c->stream, p, c->feat_nt_max, sr, sm, sV, stq, sin);
       HIPCHK(hipGetLastError());
       return OVGPU_OK;
@@ -1196,6 +1223,34 @@ static int enqueue_compress_gram(ovgpu_ctx *c, bool factor = true) {
   const int G = (int)std::max<int64_t>(1, std::min<int64_t>(c->num_cu, nchunks));
   HIPCHK(c->gram_part.reserve((size_t)G * NP * 256));
   HIPCHK(c->gram_G.reserve((size_t)LG * LG));
+  if (c->stack_is_f32) { // the fp32 stack of options.gram_fp32: one pass per part of the macro-tile triangle (k_gram32.h)
+    const int LDF = c->stack_ldf, NTM = LDF / 32, P = gram32::gram32_parts(NTM), slots = P * gram32::G32_NW * gram32::G32_MAXT;
+    if (c->gram32_ntm != NTM || c->gram32_P != P) {
+      std::vector<int32_t> tab((size_t)slots);
+      gram32::gram32_tile_table(NTM, P, tab.data());
+      HIPCHK(c->gram32_tiles.reserve((size_t)slots));
+      HIPCHK(hipMemcpyAsync(c->gram32_tiles.p, tab.data(), sizeof(int32_t) * slots, hipMemcpyHostToDevice, c->stream));
+      HIPCHK(hipStreamSynchronize(c->stream)); // (the staging vector goes; once per column count)
+      c->gram32_ntm = NTM, c->gram32_P = P;
+    }
+    // workgroups per part: no more than G32_ROWS_WG rows each; on a short stack as many as keep every compute unit busy (>= 4 stages each)
+    const int64_t by_rows = (c->rows_total + gram32::G32_ROWS_WG - 1) / gram32::G32_ROWS_WG;
+    const int64_t by_cus = std::min<int64_t>((2 * c->num_cu + P - 1) / P, (c->rows_total + 127) / 128);
+    const int Gw = (int)std::max<int64_t>(1, std::max(by_rows, by_cus));
+    HIPCHK(c->gram32_part.reserve((size_t)P * Gw * gram32::G32_NW * gram32::G32_MAXT * 1024));
+    static bool attr32 = false;
+    if (!attr32) {
+      (void)hipFuncSetAttribute((const void *)gram32::k_gram_f32, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr32 = true;
+    }
+    gram32::Gram32Params q;
+    q.H = c->Hbig32.p, q.part = c->gram32_part.p, q.tiles = c->gram32_tiles.p, q.rows_total = c->rows_total, q.LDF = LDF, q.LD = LD;
+    hipLaunchKernelGGL(gram32::k_gram_f32, dim3(Gw, P), dim3(gram32::G32_NTH), gram32::gram32_lds_bytes(LDF), c->stream, q);
+    hipLaunchKernelGGL(gram32::k_gram_f32_reduce, dim3(slots, 4), dim3(256), 0, c->stream, (const int32_t *)c->gram32_tiles.p, Gw,
+                       (const float *)c->gram32_part.p, c->gram_G.p, LG);
+    HIPCHK(hipGetLastError());
+    return factor ? set_err(OVGPU_ERR_CAPACITY, "the fp32 Gram variant feeds the on-device update only") : OVGPU_OK;
+  }
   gram::GramParams g;
   g.LD = LD, g.NT = NT, g.rows_total = c->rows_total, g.H = c->Hbig.p, g.part = c->gram_part.p;
   if (NT == gram::GR_NT + 7 && !c->gram_fp32 && !c->gram_blocks_only) { // configs[4]'s 23 tile columns: two passes over the stack (k_gram_wide)
@@ -1588,6 +1643,7 @@ static int enqueue_pipeline_body(ovgpu_ctx *c, int stages, bool slam, bool facto
     if (eu && ec && es) c->ev_used++;
     else eu = ec = es = nullptr;
   }
+  c->timed_this_update = eu != nullptr; // fill_times: an update that recorded no events reports no stage times (not an earlier update's)
   if (eu) HIPCHK(hipEventRecord(eu->a, c->stream));
   int rc = OVGPU_OK;
   const bool fits = (c->LD + 15) / 16 <= gram::GR_NT_BLK && c->F > 0;
@@ -1620,7 +1676,10 @@ static int enqueue_pipeline_body(ovgpu_ctx *c, int stages, bool slam, bool facto
       if (c->F > 0) HIPCHK(hipMemcpyAsync(c->status.p, c->given_status.p, sizeof(int32_t) * c->F, hipMemcpyDeviceToDevice, c->stream));
     } else if ((rc = enqueue_triangulate(c)) != OVGPU_OK) return rc;
     if (es) HIPCHK(hipEventRecord(es->a, c->stream));
-    if ((rc = enqueue_system(c, -1, 0, whiten)) != OVGPU_OK) return rc;
+    c->want_stack_f32 = c->gram_fp32 && whiten && (gram_only || tform) && (c->LD + 31) / 32 <= 12;
+    rc = enqueue_system(c, -1, 0, whiten);
+    c->want_stack_f32 = false;
+    if (rc != OVGPU_OK) return rc;
     if (es) HIPCHK(hipEventRecord(es->b, c->stream));
     if (need_prior) c->gram_is_whitened = whiten;
     // which compression (see ovgpu_ctx::compress_gram)
@@ -1696,7 +1755,7 @@ static int read_feature_outputs(ovgpu_ctx *c, int32_t *feat_status, double *chi2
 }
 
 static void fill_times(ovgpu_ctx *c, ovgpu_update_stats *stats) {
-  if (!stats || !c->timing || c->ev_used == 0) return;
+  if (!stats || !c->timing || c->ev_used == 0 || !c->timed_this_update) return; // stats->ms_* stay 0
   float ms = 0.f;
   EventPair &eu = c->ev_update[c->ev_used - 1];
   EventPair &ec = c->ev_compress[c->ev_used - 1];
@@ -1826,8 +1885,10 @@ static int finish_update(ovgpu_ctx *c, double *dx, double *P_out, ovgpu_update_s
 //  * a follower of the single-launch Cholesky timed out (k_chol.h: the factor workgroup was not co-scheduled; the kernels behind
 //    the factorisation were switched off on the device).  Repeat with the step-wise kernels, which have no cross-workgroup wait.
 extern "C++" {
-template <class Attempt> static int update_with_fallbacks(ovgpu_ctx *c, ovgpu_update_stats *stats, Attempt attempt) {
-  bool tried_householder = false, tried_steps = false;
+// retry_timeout = false (a rank of a multi-rank update): the time-out is a scheduling event LOCAL to one rank, so a local repeat
+// would issue a collective the peers never match; the error is returned instead and the caller repeats collectively.
+template <class Attempt> static int update_with_fallbacks(ovgpu_ctx *c, ovgpu_update_stats *stats, Attempt attempt, bool retry_timeout = true) {
+  bool tried_householder = false, tried_steps = !retry_timeout;
   const bool user_no_pipe = c->no_chol_pipe;
   int rc;
   for (;;) {
@@ -3131,6 +3192,8 @@ int ovgpu_debug_option(ovgpu_ctx *c, const char *name, int64_t value, int64_t *o
   } else if (n == "featy_skip") { // timing ablation of k_feat_y: 1 sweep, 2 V^T Y + output rows, 4 SYRK, 8 Cholesky (results are garbage)
     if (old_value) *old_value = c->featy_skip;
     if (value >= 0) c->featy_skip = (int)value;
+  } else if (n == "stack_is_f32") { // read-only: the last pipeline stored the stack as floats and ran k_gram_f32 (options.gram_fp32)
+    if (old_value) *old_value = c->stack_is_f32 ? 1 : 0;
   } else if (n == "chol_timeouts") { // read-only counter: updates repeated with the step-wise Cholesky after a follower timed out
     if (old_value) *old_value = c->chol_timeouts;
   } else {
@@ -3417,15 +3480,19 @@ int ovgpu_msckf_update_sharded(ovgpu_ctx *c, int32_t *feat_status, double *chi2,
                                ovgpu_update_stats *stats) {
   if (!c) return set_err(OVGPU_ERR_INVALID, "null ctx");
   if (stats) std::memset(stats, 0, sizeof(*stats));
-  // the fall-backs of the one-GPU update hold here too: the prior is replicated, so every rank sees the same flags and every rank
-  // repeats (the Householder repeat exchanges triangles instead of Gram matrices: the collective stays matched across ranks)
+  // Of the one-GPU update's fall-backs only the REPLICATED condition repeats here: the prior is the same on every rank, so every
+  // rank sees OVGPU_ERR_NOT_SPD together and every rank repeats (the Householder repeat exchanges triangles instead of Gram
+  // matrices: the collective stays matched).  The single-launch Cholesky's follower time-out is a scheduling event of ONE rank: a
+  // local repeat would issue a collective its peers never match.  In a world of more than one rank it is therefore returned as
+  // OVGPU_ERR_HIP: THIS rank's state is untouched while its peers have applied the update, so the caller uploads the state again on
+  // every rank (options.no_single_launch_cholesky = 1 rules the time-out out); a world of one keeps the local repeat.
   return update_with_fallbacks(c, stats, [&]() {
     int rc = ovgpu_msckf_update_sharded_async(c);
     if (rc != OVGPU_OK) return rc;
     c->async_pending = false;
     if ((rc = read_feature_outputs(c, feat_status, chi2, chi2_thresh, p_FinG, stats)) != OVGPU_OK) return rc;
     return finish_update(c, dx, P_out, stats);
-  });
+  }, c->comm_world <= 1);
 }
 
 } // extern "C"
@@ -3583,6 +3650,23 @@ int ovgpu_multi_msckf_update(ovgpu_multi *m, int32_t *feat_status, double *chi2,
   for (int g = 0; g < G; g++) {
     HIPCHK(hipSetDevice(m->ctx[g]->device));
     if ((rc = sharded_update(m->ctx[g], gram[g])) != OVGPU_OK) return rc;
+  }
+  // Every rank's factorisation flags BEFORE any result is taken.  A follower time-out of the single-launch Cholesky is local to one
+  // rank (the factor workgroup was not co-scheduled there): that rank skipped its update while the others applied theirs, so the
+  // replicas have diverged.  There is no local repeat that keeps the exchange matched (the one-GPU entry points repeat with the
+  // step-wise kernels; here the peers have already moved on): the error is returned for the whole set and the caller uploads the
+  // state again on every rank (ovgpu_multi_set_state) before the next update.
+  for (int g = 0; g < G; g++) {
+    ovgpu_ctx *c = m->ctx[g];
+    HIPCHK(hipSetDevice(c->device));
+    int32_t flags[4] = {0, 0, 0, 0};
+    HIPCHK(hipMemcpyAsync(flags, c->flags.p, sizeof(flags), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (flags[2]) {
+      c->chol_timeouts++;
+      return set_err(OVGPU_ERR_HIP, "multi-device update: the single-launch Cholesky of one rank timed out; the ranks' states differ now -- "
+                                    "upload the state again on every rank (options.no_single_launch_cholesky = 1 rules the time-out out)");
+    }
   }
   // outputs: per-feature results from the shard that owns the feature, (dx, P') from device 0 (identical on all)
   ovgpu_update_stats total;

@@ -59,6 +59,8 @@ struct SysParams {
   int chi2_table_len;
   const int64_t *row_off;   // [F+1] first output row of each feature
   double *Hbig;             // [rows_total * LD]
+  float *Hbig32;            // options.gram_fp32 on the MSCKF fast path: the stack leaves as FLOATS instead, [rows_total * LDF] (k_gram32.h)
+  int LDF;                  // its row stride, 32 ceil(LD / 32)
   double *ws;               // global workspace for the gate matrix when it does not fit LDS
   int64_t ws_stride;        // doubles per workgroup
   int m_lds_max;            // largest track length whose gate matrix is LDS-resident
@@ -90,6 +92,30 @@ struct SysParams {
   int32_t *work_counter; // k_feat: next feature slot to hand out (zeroed before the launch)
   int skip;              // developer ablation of k_feat_y's phases (ovgpu_debug_option "featy_skip"; results are garbage when non-zero)
   DevOptions opt;
+};
+
+// A feature's rows of the stack: float64 with stride LD, or (F32: the instantiations options.gram_fp32 launches) float32 with stride
+// LDF (SysParams::Hbig32).  A compile-time choice: the float64 kernels carry nothing of the variant.
+template <bool F32> struct StackRows;
+template <> struct StackRows<false> {
+  double *d;
+  int ld;
+  __device__ __forceinline__ StackRows(const SysParams &p, int64_t row0) : d(p.Hbig + row0 * p.LD), ld(p.LD) {}
+  __device__ __forceinline__ void put(int64_t r, int c, double v) const { d[r * ld + c] = v; }
+  __device__ __forceinline__ void zero(int64_t e) const { d[e] = 0.0; }
+  __device__ __forceinline__ void pad(int, int, int, int) const {}
+};
+template <> struct StackRows<true> {
+  float *f;
+  int ld;
+  __device__ __forceinline__ StackRows(const SysParams &p, int64_t row0) : f(p.Hbig32 + row0 * p.LDF), ld(p.LDF) {}
+  __device__ __forceinline__ void put(int64_t r, int c, double v) const { f[r * ld + c] = (float)v; }
+  __device__ __forceinline__ void zero(int64_t e) const { f[e] = 0.f; }
+  // columns LD .. LDF-1 of the feature's n rows: k_gram_f32 copies whole rows into LDS and multiplies what it finds there
+  __device__ __forceinline__ void pad(int tid, int nth, int n, int LD) const {
+    const int w = ld - LD;
+    for (int e = tid; e < n * w; e += nth) f[(int64_t)(e / w) * ld + LD + e % w] = 0.f;
+  }
 };
 
 struct CompressParams {

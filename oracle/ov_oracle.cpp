@@ -1,15 +1,13 @@
 /*
  * ov_oracle.cpp — float64 CPU restatement of the open_vins MSCKF update path.
  *
- * TEST INFRASTRUCTURE ONLY (see ov_oracle.h).  The reference has no golden
- * vectors for this path and cannot be built here; every function below
- * restates the cited reference lines (paths relative to the open_vins
- * checkout) and the Eigen / Boost routines they call, algorithm for algorithm:
- * same loop order, same float casts, same thresholds.  PINNED by the
- * independent known-answer fixtures of tests/test_known_answer.py
- * (tools/make_known_answer.py; MSCKF path: triangulation through the EKF
- * update); the SLAM / delayed-initialisation / anchor-change entry points
- * share those building blocks but have no fixture of their own yet.
+ * TEST INFRASTRUCTURE ONLY (see ov_oracle.h).  Every function below restates the cited reference lines (paths relative
+ * to the open_vins checkout) and the Eigen / Boost routines they call, algorithm for algorithm: same loop order, same
+ * float casts, same thresholds.  PINNED by the reference's own code: oracle/_ref (the reference's update-path sources
+ * compiled from /root/reference against stand-in Eigen / Boost / OpenCV headers) runs every entry point restated here
+ * -- MSCKF update, SLAM update, delayed initialisation, anchor change, window bookkeeping -- on the same inputs
+ * (tests/test_ref_build.py, live; tests/test_ref_fixtures.py, from the fixtures it generated), and by the independent
+ * known-answer fixtures of tests/test_known_answer.py (tools/make_known_answer.py).
  *
  * Build: see oracle/Makefile (g++ -O3, no FMA contraction so that the float
  * casts round exactly like the reference's x86-64 build).

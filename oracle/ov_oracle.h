@@ -7,17 +7,18 @@
  * cpu_baseline leg may load it; the product (open_vins_amd/, libovgpu.so)
  * never links, imports or calls anything in oracle/.
  *
- * PINNING: the reference ships no golden vectors / known-answer tests for this
- * path and cannot be compiled here (Eigen, Boost, OpenCV absent; no
- * oracle/_ref), so the pin is manufactured: tools/make_known_answer.py
- * evaluates the reference's formulas independently of this file (mpmath, 50
- * digits, the reference's float32 operations emulated) and
- * tests/test_known_answer.py holds this oracle to those fixtures
- * (tests/golden/known_answer_msckf_*.json.gz) at float64 round-off:
- * pixels / residuals bit-exact, chi2 2e-14, dx 1e-13, P' 1e-15.  Beside it:
- * (i) line-by-line restatement (each function cites the reference
- * file:line), (ii) numpy/scipy invariants in tests/test_oracle_invariants.py.
- * The reference's own code has still never executed here.  See DESIGN.md §3.
+ * PINNING (round 4): the reference's OWN update-path sources are compiled here, where they lie under /root/reference, into
+ * oracle/_ref/libov_ref.so (oracle/ref/Makefile; Eigen / Boost.Math / OpenCV, which this machine does not have, are the
+ * stand-in headers of oracle/ref/standin that restate the library calls the reference makes), and
+ * tests/test_ref_build.py holds EVERY entry point of this oracle to what the reference's classes compute on the same
+ * inputs: triangulation (verdicts, anchors, positions 1e-10), Jacobians, nullspace projection / compression (bit-exact),
+ * the complete UpdaterMSCKF::update over 40 random shapes (identical accept sets, dx 1e-11, P' 1e-12), UpdaterSLAM::update
+ * (six representations, ArUco options), delayed_init chains, perform_anchor_change / change_anchors, marginalize / clone /
+ * EKFPropagation / EKFUpdate.  The fixtures that library generated (tests/golden/ref_*.npz, tools/make_ref_fixtures.py)
+ * hold the oracle AND the GPU where /root/reference does not exist (tests/test_ref_fixtures.py).  Beside it, from round 3:
+ * the independent 50-digit evaluation of two MSCKF snapshots (tools/make_known_answer.py, tests/test_known_answer.py)
+ * and the numpy / scipy invariants of tests/test_oracle_invariants.py.  What is still not the reference: real Eigen's
+ * summation order inside products and decompositions (the stand-ins use the plain sequential order).  See DESIGN.md §3.
  *
  * It shares the POD views of include/ovgpu.h so that tests feed identical
  * inputs to both sides.

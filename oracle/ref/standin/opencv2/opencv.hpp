@@ -7,6 +7,8 @@
 #define OV_REF_STANDIN_OPENCV_HPP
 #include <cassert>
 #include <cmath>
+#include <string>
+#include <unistd.h> // (real OpenCV headers drag it in; Simulator.cpp calls sleep())
 #include <vector>
 #define CV_32F 5
 #define CV_8UC1 0
@@ -26,6 +28,11 @@ struct Point2f {
   float x = 0, y = 0;
   Point2f() {}
   Point2f(float x_, float y_) : x(x_), y(y_) {}
+};
+struct KeyPoint {
+  Point2f pt;
+  float size = 0, angle = -1, response = 0;
+  int octave = 0, class_id = -1;
 };
 struct Size {
   int width = 0, height = 0;
@@ -50,7 +57,10 @@ public:
   bool empty() const { return d.empty(); }
   Mat clone() const { return *this; }
   static Mat zeros(int r, int c, int t) { return Mat(r, c, t); }
+  static Mat zeros(Size, int) { return Mat(); } // (the simulated front end keeps blank "images": nothing reads them)
 };
+enum { IMREAD_GRAYSCALE = 0 };
+inline Mat imread(const std::string &, int = 0) { return Mat(); }
 // x_d = x (1 + k1 r2 + k2 r4) + 2 p1 x y + p2 (r2 + 2 x2); inverse by OpenCV's fixed-point iteration (5 passes, no tolerance)
 inline void undistortPoints(const Mat &src, Mat &dst, const Matx33d &K, const Vec4d &D) {
   Mat out = src;

@@ -5,6 +5,8 @@
 #ifndef OPENCV_YAML_PARSER_H
 #define OPENCV_YAML_PARSER_H
 #include <Eigen/Eigen>
+#include <boost/filesystem.hpp>
+#include <opencv2/opencv.hpp>
 #include <memory>
 #include <string>
 #include <vector>

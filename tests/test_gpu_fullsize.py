@@ -47,6 +47,7 @@ def _parity(Updater, oracle, prob, opts, tol_dx=1e-8, tol_p=1e-9, key=None, **fi
     up.set_problem(prob)
     up.set_triangulation(tri["p_FinG"], tri["p_FinA"], tri["anchor_meas"], tri["status"])
     out = up.update()
+    out["stack_f32"] = up.debug_option("stack_is_f32")
     up.close()
     ref = oracle_with_the_same_gate_verdicts(oracle, opts, v, tri, ref, out)
     gate = np.isfinite(ref["chi2"])
@@ -93,14 +94,16 @@ def test_cfg5_geometry_against_oracle(Updater, oracle, F):
 
 @pytest.mark.parametrize("cfg,F", [(5, 500), (5, 2500), (2, 300)])
 def test_fp32_gram_variant(Updater, oracle, cfg, F):
-    """BASELINE configs[4]'s "fp32 compressed-QR": options.gram_fp32 accumulates the Gram matrix of the prior-whitened stack on
-    v_mfma_f32_16x16x4_f32.  Everything else stays f64 (gate, whitening, both factorisations), so the accept sets and chi2 are those
+    """BASELINE configs[4]'s "fp32 compressed-QR": with options.gram_fp32 the prior-whitened stack leaves the per-feature kernel as
+    FLOATS and its Gram matrix is accumulated on v_mfma_f32_32x32x2_f32 (csrc/k_gram32.h: two-level f32 sums inside a workgroup's
+    <= 1536 rows, f64 across workgroups).  Everything else stays f64 (gate, whitening, both factorisations), so the accept sets and chi2 are those
     of the f64 path; dx within 1e-4 and P within 1e-3 of the f64 oracle (measured: see the printed line)."""
     prob = synth.make_problem(cfg, F=F)
     opts = capi.default_options(chi2_multipler=1.0, gram_fp32=1)
     key = (f"cfg{cfg}", F)  # the oracle's result does not depend on gram_fp32
     out, ref = _parity(Updater, oracle, prob, opts, tol_dx=1e-4, tol_p=1e-3, key=key)
     assert out["route"] == capi.COMPRESS_GRAM
+    assert out["stack_f32"] == 1  # the per-feature kernel stored floats and k_gram_f32 (csrc/k_gram32.h) read them
     print(f"fp32 Gram, cfg {cfg}, {F} features: |ddx|/|dx| {_rel(out['dx'], ref['dx']):.1e}, |dP|/|P| {_rel(out['P'], ref['P']):.1e}")
     f64 = _parity(Updater, oracle, prob, capi.default_options(chi2_multipler=1.0), key=key)[0]
     assert _rel(out["P"], f64["P"]) > 1e-12  # it really is another arithmetic
