@@ -57,7 +57,8 @@ def _parity(Updater, oracle, prob, opts, tol_dx=1e-8, tol_p=1e-9, key=None, **fi
     assert _rel(out["dx"], ref["dx"]) < tol_dx, _rel(out["dx"], ref["dx"])
     assert _rel(out["P"], ref["P"]) < tol_p, _rel(out["P"], ref["P"])
     assert np.array_equal(out["P"], out["P"].T)
-    assert np.abs(out["clone_q_p"] - ref["clone_q_p"]).max() < (1e-9 if tol_dx <= 1e-8 else 1e-5)
+    # the posterior clone table: dx's tolerance times the size of the correction (|dx| ~ 0.1 - 0.3 on these snapshots)
+    assert np.abs(out["clone_q_p"] - ref["clone_q_p"]).max() < (1e-9 if tol_dx <= 1e-8 else 0.3 * tol_dx)
     return out, ref
 
 
