@@ -114,27 +114,39 @@ def main(argv=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
+    # Test seam (tests/test_bench_multirank.py): OVGPU_BENCH_TEST_HOOK names a module that supplies a host stand-in for the updater, so
+    # that the N-rank CONTROL FLOW of this file -- spawn, communicator set-up, the fall-back to the host-driven exchange, the timed
+    # loops, the JSON line -- runs on a machine without GPUs over gloo.  The line it prints says so ("test_hook") and is no measurement.
+    hook = None
+    if os.environ.get("OVGPU_BENCH_TEST_HOOK"):
+        import importlib
+        hook = importlib.import_module(os.environ["OVGPU_BENCH_TEST_HOOK"])
+        UpdaterMSCKF = hook.Updater
+    if hook is None and not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the update path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    if hook is None:
+        torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank) if hook is None else torch.device("cpu")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)  # RCCL over xGMI
+        dist.init_process_group("nccl" if hook is None else "gloo", rank=rank, world_size=world)  # "nccl" = RCCL over xGMI
 
     cfg = args.cfg if args.cfg is not None else (CFG_SINGLE if world == 1 else CFG_MULTI)
     route = capi.COMPRESS_GRAM if args.route == "gram" else capi.COMPRESS_TSQR
     opts = capi.default_options(chi2_multipler=1.0, compress_route=route, gram_fp32=1 if args.gram_fp32 else 0)  # config/rpng_sim/estimator_config.yaml:100-101
 
     def fence():
-        torch.cuda.synchronize()
+        if hook is None:
+            torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
-            torch.cuda.synchronize()
+            if hook is None:
+                torch.cuda.synchronize()
 
     exchange = {"kind": "none (one GPU)"}
 
     timed_loops = []  # seconds of every timed loop of the last run()
+    rank_loops = []   # the last timed loop of the last run(): every rank's own seconds (before the max over ranks)
 
     def run(prob_full, feats_of_rank, steps, warmup, local_only=False, repeats=1):
         """Times `steps` updates of prob_full sharded as feats_of_rank(rank); returns (seconds max over ranks, updater, shard).
@@ -161,7 +173,7 @@ def main(argv=None):
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
             native = bool(ok.item())
             exchange["kind"] = "ncclAllReduce inside libovgpu (context stream)" if native else "torch.distributed all_reduce (host-driven fallback)"
-        backend = parallel.GpuShardBackend(up)
+        backend = parallel.GpuShardBackend(up) if hook is None else hook.backend(up)
 
         def step():
             up.reset_state()  # device-side copy of the prior: every step updates the same prior
@@ -187,6 +199,10 @@ def main(argv=None):
             dt = time.perf_counter() - t0
             if world > 1:
                 t = torch.tensor([dt], dtype=torch.float64, device=device)
+                every = [torch.zeros(1, dtype=torch.float64, device=device) for _ in range(world)]
+                dist.all_gather(every, t)
+                rank_loops.clear()
+                rank_loops.extend(float(x.item()) for x in every)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 dt = float(t.item())
             dts.append(dt)
@@ -199,6 +215,7 @@ def main(argv=None):
     mine = parallel.shard_features(prob.meas_offsets, rank, world)
     dt, up, shard = run(prob, mine, args.steps, args.warmup, repeats=3)  # the MEDIAN of three timed loops of K steps is the line's value
     headline_loops = [1e3 * x / args.steps for x in timed_loops]
+    headline_rank_ms = [1e3 * x / args.steps for x in rank_loops]
     kt = up.kernel_times(reset=True)
     ms_per_step = 1e3 * dt / args.steps
     value = prob.F / (dt / args.steps)
@@ -207,7 +224,7 @@ def main(argv=None):
     extras = {}
     if not args.no_extras:
         if world > 1:  # weak figure: the same per-GPU load whatever N
-            wprob = synth.make_problem(cfg, F=WEAK_FEATURES_PER_GPU * world)
+            wprob = synth.make_problem(cfg, F=(WEAK_FEATURES_PER_GPU if hook is None else hook.WEAK_FEATURES_PER_GPU) * world)
             wdt, wup, _ = run(wprob, parallel.shard_features(wprob.meas_offsets, rank, world), max(5, args.steps // 2), 2)
             wup.close()
             extras["weak"] = {"features_per_gpu": WEAK_FEATURES_PER_GPU, "features_total": wprob.F, "ms_per_step": 1e3 * wdt / max(5, args.steps // 2),
@@ -309,6 +326,12 @@ def main(argv=None):
                 "stage_events": f"HIP events around the stages on every {args.stage_events_every}th update of the timed region ({kt['launches']} updates sampled)",
             },
         }
+        if world > 1:
+            # what the first real multi-GPU line is read against (no N > 1 run has been measured: DESIGN.md section 5)
+            out["exchange"] = dict(exchange)
+            out["per_rank_ms_per_step"] = headline_rank_ms  # last timed loop, every rank's own clock
+        if hook is not None:
+            out["test_hook"] = os.environ["OVGPU_BENCH_TEST_HOOK"] + ": host stand-in for the updater over gloo -- control flow only, NOT a measurement"
         out.update(extras)
         if world == 1 and not args.no_extras:
             out["pcie_inclusive_ms"] = pcie_inclusive_ms(prob, opts, local_rank)
