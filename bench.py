@@ -336,6 +336,7 @@ def main(argv=None):
         if world == 1 and not args.no_extras:
             out["pcie_inclusive_ms"] = pcie_inclusive_ms(prob, opts, local_rank)
             out["mode_a"] = mode_a_ms(prob, opts, local_rank, capi)
+            out["shim"] = shim_dropin_ms(prob.F)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(prob, opts)
         print(json.dumps(out), flush=True)
@@ -362,6 +363,21 @@ def pcie_inclusive_ms(prob, opts, device):
         ts.append(time.perf_counter() - t)
     up.close()
     return 1e3 * sorted(ts)[len(ts) // 2]
+
+
+def shim_dropin_ms(F):
+    """The drop-in path as a C++ host drives it (open_vins_amd/shim/selftest --time): F tracks in the reference's container shape
+    (unordered_map of vectors of heap-allocated 2-float vectors) -> flatten -> ovgpu_set_state + ovgpu_set_features -> mode A
+    (ovgpu_msckf_compress) resp. mode B (ovgpu_msckf_update), host to host, median of 9.  None when the binary is missing."""
+    exe = os.path.join(ROOT, "open_vins_amd", "shim", "selftest")
+    if not os.path.exists(exe):
+        return None
+    try:
+        p = subprocess.run([exe, "--time", str(int(F)), "9"], capture_output=True, text=True, timeout=300)
+        line = [l for l in p.stdout.splitlines() if l.startswith("{")]
+        return json.loads(line[-1]) if line else {"error": (p.stdout + p.stderr)[-300:]}
+    except Exception as e:  # noqa: BLE001
+        return {"error": str(e)}
 
 
 def mode_a_ms(prob, opts, device, capi):

@@ -262,6 +262,11 @@ struct ovgpu_ctx {
   int chol_slot = 0;
   bool no_chol_pipe = false;   // options.no_single_launch_cholesky
   int feat_shape = 0;          // options.feature_kernel_shape
+  PinBuf<unsigned char> up_arena; // page-locked upload arena of ovgpu_set_state / ovgpu_set_features (upload_staged)
+  PinBuf<unsigned char> down_arena; // page-locked landing zone of the results (status, chi2, p_FinG, dx, P'): asynchronous copies, one synchronisation, memcpy to the caller
+  size_t up_off = 0, up_want = 8u << 20;
+  bool up_dirty = false;    // copies out of the arena may be in flight
+  bool up_fallback = false; // an upload since the last synchronisation bypassed the arena (its host source must outlive the copy)
   bool gram_fp32 = false;      // options.gram_fp32
   bool want_stack_f32 = false; // this pipeline: gram_fp32 on the prior-whitened Gram route -> the fused per-feature kernels may store floats
   bool stack_is_f32 = false;   // ... and did: the stack is c->Hbig32 [rows_total][stack_ldf] (k_gram32.h reads it)
@@ -316,6 +321,48 @@ static hipError_t remove_record(DevBuf<T> &a, DevBuf<T> &tmp, int n, int w, int 
 static hipError_t upload(void *dst, const void *src, size_t bytes, hipStream_t s) {
   if (bytes == 0) return hipSuccess;
   return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s);
+}
+
+// The uploads of a state / feature batch (25 arrays per update of the drop-in path): a copy from PAGEABLE memory is staged by the
+// runtime one call at a time (~20 us apiece, the caller blocked); here the CPU packs the bytes into one page-locked arena and the
+// copies leave asynchronously, so packing the next array overlaps the DMA of the previous one.  upload_begin() at the top of
+// ovgpu_set_state / ovgpu_set_features (both end with a stream synchronisation: the arena is free again when they return).
+static hipError_t upload_begin(ovgpu_ctx *c) {
+  // copies out of the arena may still be in flight (ovgpu_set_state returns without a synchronisation): keep appending behind them;
+  // the offset goes back to 0 once a synchronisation of the stream has been seen (upload_sync / upload_fence)
+  if (!c->up_dirty) c->up_off = 0;
+  if (c->up_want > c->up_arena.cap) {
+    if (c->up_dirty) {
+      hipError_t e = hipStreamSynchronize(c->stream);
+      if (e != hipSuccess) return e;
+      c->up_dirty = false, c->up_fallback = false, c->up_off = 0;
+    }
+    return c->up_arena.reserve(c->up_want);
+  }
+  return hipSuccess;
+}
+static hipError_t upload_staged(ovgpu_ctx *c, void *dst, const void *src, size_t bytes, hipStream_t s) {
+  if (bytes == 0) return hipSuccess;
+  const size_t off = (c->up_off + 63) & ~(size_t)63;
+  if (s != c->stream || off + bytes > c->up_arena.cap) { // no room this time: the runtime's own staging; the arena grows at the next upload_begin
+    if (s == c->stream) c->up_want = std::max(c->up_want, 2 * (off + bytes));
+    c->up_fallback = true;
+    return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s);
+  }
+  std::memcpy(c->up_arena.p + off, src, bytes);
+  c->up_off = off + bytes, c->up_dirty = true;
+  return hipMemcpyAsync(dst, c->up_arena.p + off, bytes, hipMemcpyHostToDevice, s);
+}
+// "the host staging vectors go out of scope": needed only for uploads that bypassed the arena
+static hipError_t upload_fence(ovgpu_ctx *c, hipStream_t s) {
+  if (!c->up_fallback) return hipSuccess;
+  c->up_fallback = false, c->up_dirty = false;
+  return hipStreamSynchronize(s);
+}
+// a synchronisation of the context's stream that the caller needs anyway
+static hipError_t upload_sync(ovgpu_ctx *c, hipStream_t s) {
+  c->up_fallback = false, c->up_dirty = false;
+  return hipStreamSynchronize(s);
 }
 
 // profiling builds (-DQR_PROFILE): 128 cycle counters written by node 0 of the last leaf / merge launch
@@ -553,6 +600,7 @@ void ovgpu_destroy(ovgpu_ctx *c) {
   c->meas_offsets.release(), c->meas_cc.release(), c->uv.release(), c->uvn.release(), c->row_off.release();
   c->pA.release(), c->pG.release(), c->chi2.release(), c->chi2_thr.release(), c->anchor.release(), c->status.release(), c->sys_order.release(), c->feat_sigma.release(), c->feat_mult.release();
   c->Hbig32.release(), c->gram32_part.release(), c->gram32_tiles.release();
+  c->up_arena.release(), c->down_arena.release();
   c->chi2_table.release(), c->Hbig.release(), c->gate_ws.release(), c->Rws.release(), c->tree_nodes.release(), c->tree_nodes2.release(), c->tree_flags.release(), c->tree_err.release(), c->Mt.release(), c->Aaug.release(), c->Yaug.release();
   c->pFej.release(), c->lm_val.release(), c->lm_fej.release(), c->feat_lm.release(), c->feat_lmcol.release(), c->feat_lmcov.release(), c->lm_cov.release();
   c->feat_anchor.release(), c->lm_col.release(), c->lm_anchor.release(), c->lm_index.release(), c->Ppad.release(), c->init_ws.release(), c->dx_seq.release();
@@ -638,14 +686,14 @@ static int build_columns(ovgpu_ctx *c) {
   HIPCHK(c->Aaug.reserve((size_t)D * (D + N + 1)));
   HIPCHK(c->Yaug.reserve((size_t)D * (D + N + 1)));
   hipStream_t s = c->stream;
-  HIPCHK(upload(c->clone_col.p, clone_col.data(), sizeof(int32_t) * C, s));
-  HIPCHK(upload(c->calib_col.p, calib_col.data(), sizeof(int32_t) * K, s));
-  HIPCHK(upload(c->intr_col.p, intr_col.data(), sizeof(int32_t) * K, s));
-  HIPCHK(upload(c->col_cov.p, col_cov.data(), sizeof(int32_t) * D, s));
-  HIPCHK(upload(c->col_kind.p, col_kind.data(), D, s));
-  HIPCHK(upload(c->col_sub.p, col_sub.data(), D, s));
-  HIPCHK(upload(c->col_var.p, col_var.data(), sizeof(uint16_t) * D, s));
-  if (c->L > 0) HIPCHK(upload(c->lm_col.p, c->h_lm_col.data(), sizeof(int32_t) * c->L, s));
+  HIPCHK(upload_staged(c, c->clone_col.p, clone_col.data(), sizeof(int32_t) * C, s));
+  HIPCHK(upload_staged(c, c->calib_col.p, calib_col.data(), sizeof(int32_t) * K, s));
+  HIPCHK(upload_staged(c, c->intr_col.p, intr_col.data(), sizeof(int32_t) * K, s));
+  HIPCHK(upload_staged(c, c->col_cov.p, col_cov.data(), sizeof(int32_t) * D, s));
+  HIPCHK(upload_staged(c, c->col_kind.p, col_kind.data(), D, s));
+  HIPCHK(upload_staged(c, c->col_sub.p, col_sub.data(), D, s));
+  HIPCHK(upload_staged(c, c->col_var.p, col_var.data(), sizeof(uint16_t) * D, s));
+  if (c->L > 0) HIPCHK(upload_staged(c, c->lm_col.p, c->h_lm_col.data(), sizeof(int32_t) * c->L, s));
   HIPCHK(hipStreamSynchronize(s)); // host staging vectors go out of scope
   c->have_feats = false;           // workspaces depend on D
   return OVGPU_OK;
@@ -660,6 +708,7 @@ int ovgpu_set_state(ovgpu_ctx *c, const ovgpu_state_view *st) {
       !st->calib_cov_id || !st->intr_cov_id)
     return set_err(OVGPU_ERR_INVALID, "null state array");
   HIPCHK(hipSetDevice(c->device));
+  HIPCHK(upload_begin(c));
   const int N = st->N, C = st->C, K = st->K;
 
   // ---- canonical column order: calibrated camera variables and clones sorted by covariance id
@@ -712,17 +761,17 @@ int ovgpu_set_state(ovgpu_ctx *c, const ovgpu_state_view *st) {
   }
   c->h_clone_cov.assign(st->clone_cov_id, st->clone_cov_id + C);
   c->h_calib_cov = calib_cov, c->h_intr_cov = intr_cov;
-  HIPCHK(upload(c->P.p, st->P, sizeof(double) * N * N, s));
-  HIPCHK(upload(c->clone_qp.p, st->clone_q_p, sizeof(double) * 7 * C, s));
-  HIPCHK(upload(c->clone_fej.p, st->clone_q_p_fej, sizeof(double) * 7 * C, s));
-  HIPCHK(upload(c->calib_qp.p, st->calib_q_p, sizeof(double) * 7 * K, s));
-  HIPCHK(upload(c->intr.p, st->intrinsics, sizeof(double) * 8 * K, s));
-  HIPCHK(upload(c->fisheye.p, st->cam_is_fisheye, K, s));
-  HIPCHK(upload(c->clone_cov.p, st->clone_cov_id, sizeof(int32_t) * C, s));
-  HIPCHK(upload(c->calib_cov.p, calib_cov.data(), sizeof(int32_t) * K, s));
-  HIPCHK(upload(c->intr_cov.p, intr_cov.data(), sizeof(int32_t) * K, s));
-  // the pageable-host copies above must complete before the caller's buffers may change
-  HIPCHK(hipStreamSynchronize(s));
+  HIPCHK(upload_staged(c, c->P.p, st->P, sizeof(double) * N * N, s));
+  HIPCHK(upload_staged(c, c->clone_qp.p, st->clone_q_p, sizeof(double) * 7 * C, s));
+  HIPCHK(upload_staged(c, c->clone_fej.p, st->clone_q_p_fej, sizeof(double) * 7 * C, s));
+  HIPCHK(upload_staged(c, c->calib_qp.p, st->calib_q_p, sizeof(double) * 7 * K, s));
+  HIPCHK(upload_staged(c, c->intr.p, st->intrinsics, sizeof(double) * 8 * K, s));
+  HIPCHK(upload_staged(c, c->fisheye.p, st->cam_is_fisheye, K, s));
+  HIPCHK(upload_staged(c, c->clone_cov.p, st->clone_cov_id, sizeof(int32_t) * C, s));
+  HIPCHK(upload_staged(c, c->calib_cov.p, calib_cov.data(), sizeof(int32_t) * K, s));
+  HIPCHK(upload_staged(c, c->intr_cov.p, intr_cov.data(), sizeof(int32_t) * K, s));
+  // the caller's buffers may change when this returns: the bytes sit in the page-locked arena (a synchronisation only for what bypassed it)
+  HIPCHK(upload_fence(c, s));
   // device-side copy of the prior for ovgpu_reset_state
   HIPCHK(hipMemcpyAsync(c->P0.p, c->P.p, sizeof(double) * N * N, hipMemcpyDeviceToDevice, s));
   HIPCHK(hipMemcpyAsync(c->clone_qp0.p, c->clone_qp.p, sizeof(double) * 7 * C, hipMemcpyDeviceToDevice, s));
@@ -876,15 +925,15 @@ static int set_row_layout(ovgpu_ctx *c, bool slam_rows) {
     std::vector<int32_t> mf(M, 0);
     for (int f = 0; f < F; f++)
       for (int i = c->h_offsets[f]; i < c->h_offsets[f + 1]; i++) mf[i] = f;
-    HIPCHK(upload(c->fs_meas_feat.p, mf.data(), sizeof(int32_t) * c->M, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(upload_staged(c, c->fs_meas_feat.p, mf.data(), sizeof(int32_t) * c->M, c->stream));
+    HIPCHK(upload_fence(c, c->stream));
   }
   // ---- stacked system and TSQR accumulators
   const int rct = configure_tsqr(c);
   if (rct != OVGPU_OK) return rct;
   HIPCHK(c->row_off.reserve(F + 1));
-  HIPCHK(upload(c->row_off.p, row_off.data(), sizeof(int64_t) * (F + 1), c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(upload_staged(c, c->row_off.p, row_off.data(), sizeof(int64_t) * (F + 1), c->stream));
+  HIPCHK(upload_fence(c, c->stream));
   return OVGPU_OK;
 }
 
@@ -928,10 +977,10 @@ static int begin_feature_batch(ovgpu_ctx *c, int F, int M, const int32_t *offset
   for (int f = 0; f < F; f++) order[f] = f;
   std::stable_sort(order.begin(), order.begin() + F, [&](int32_t a, int32_t b) { return offsets[a + 1] - offsets[a] > offsets[b + 1] - offsets[b]; });
   HIPCHK(c->sys_order.reserve(std::max(F, 1)));
-  HIPCHK(upload(c->sys_order.p, order.data(), sizeof(int32_t) * F, s));
-  HIPCHK(upload(c->meas_offsets.p, c->h_offsets.data(), sizeof(int32_t) * (F + 1), s));
-  HIPCHK(upload(c->chi2_table.p, c->h_chi2_table.data(), sizeof(double) * c->chi2_table_len, s));
-  HIPCHK(hipStreamSynchronize(s)); // host staging vectors go out of scope
+  HIPCHK(upload_staged(c, c->sys_order.p, order.data(), sizeof(int32_t) * F, s));
+  HIPCHK(upload_staged(c, c->meas_offsets.p, c->h_offsets.data(), sizeof(int32_t) * (F + 1), s));
+  HIPCHK(upload_staged(c, c->chi2_table.p, c->h_chi2_table.data(), sizeof(double) * c->chi2_table_len, s));
+  HIPCHK(upload_fence(c, s)); // host staging vectors go out of scope (the arena keeps its copies)
   return OVGPU_OK;
 }
 
@@ -952,6 +1001,7 @@ int ovgpu_set_features(ovgpu_ctx *c, const ovgpu_features_view *fv) {
   if (fv->F > 0 && (!fv->meas_offsets)) return set_err(OVGPU_ERR_INVALID, "null feature arrays");
   if (fv->M > 0 && (!fv->uv || !fv->uvn || !fv->clone_idx || !fv->cam_idx)) return set_err(OVGPU_ERR_INVALID, "null measurement arrays");
   HIPCHK(hipSetDevice(c->device));
+  HIPCHK(upload_begin(c));
   const int F = fv->F, M = fv->M;
   if (F > 0 && (fv->meas_offsets[0] != 0 || fv->meas_offsets[F] != M)) return set_err(OVGPU_ERR_INVALID, "meas_offsets must span [0, M]");
   std::vector<uint16_t> cc(std::max(M, 1));
@@ -964,11 +1014,14 @@ int ovgpu_set_features(ovgpu_ctx *c, const ovgpu_features_view *fv) {
   int rc = begin_feature_batch(c, F, M, F > 0 ? fv->meas_offsets : &zero);
   if (rc != OVGPU_OK) return rc;
   hipStream_t s = c->stream;
-  HIPCHK(upload(c->meas_cc.p, cc.data(), sizeof(uint16_t) * M, s));
-  HIPCHK(upload(c->uv.p, fv->uv, sizeof(float) * 2 * M, s));
-  HIPCHK(upload(c->uvn.p, fv->uvn, sizeof(float) * 2 * M, s));
-  HIPCHK(hipStreamSynchronize(s)); // host staging vectors go out of scope
-  return end_feature_batch(c);
+  HIPCHK(upload_staged(c, c->meas_cc.p, cc.data(), sizeof(uint16_t) * M, s));
+  HIPCHK(upload_staged(c, c->uv.p, fv->uv, sizeof(float) * 2 * M, s));
+  HIPCHK(upload_staged(c, c->uvn.p, fv->uvn, sizeof(float) * 2 * M, s));
+  HIPCHK(upload_fence(c, s)); // host staging vectors go out of scope (the arena keeps its copies)
+  const int rce = end_feature_batch(c);
+  if (rce != OVGPU_OK) return rce;
+  HIPCHK(upload_sync(c, s)); // ONE synchronisation per batch: everything above left the page-locked arena asynchronously
+  return OVGPU_OK;
 }
 
 // ---------------------------------------------------------------------------
@@ -1724,11 +1777,22 @@ static int read_feature_outputs(ovgpu_ctx *c, int32_t *feat_status, double *chi2
   const int F = c->F;
   hipStream_t s = c->stream;
   std::vector<int32_t> st(F);
-  if (F > 0) HIPCHK(hipMemcpyAsync(st.data(), c->status.p, sizeof(int32_t) * F, hipMemcpyDeviceToHost, s));
-  if (chi2 && F > 0) HIPCHK(hipMemcpyAsync(chi2, c->chi2.p, sizeof(double) * F, hipMemcpyDeviceToHost, s));
-  if (chi2_thresh && F > 0) HIPCHK(hipMemcpyAsync(chi2_thresh, c->chi2_thr.p, sizeof(double) * F, hipMemcpyDeviceToHost, s));
-  if (p_FinG && F > 0) HIPCHK(hipMemcpyAsync(p_FinG, c->pG.p, sizeof(double) * 3 * F, hipMemcpyDeviceToHost, s));
-  HIPCHK(hipStreamSynchronize(s));
+  if (F > 0) { // through the page-locked landing zone: a device-to-PAGEABLE copy is staged by the runtime, one blocking call per array
+    const size_t o_st = 0, o_c2 = (sizeof(int32_t) * F + 63) & ~(size_t)63, o_th = o_c2 + sizeof(double) * F, o_pg = o_th + sizeof(double) * F;
+    HIPCHK(c->down_arena.reserve(o_pg + sizeof(double) * 3 * F));
+    unsigned char *h = c->down_arena.p;
+    HIPCHK(hipMemcpyAsync(h + o_st, c->status.p, sizeof(int32_t) * F, hipMemcpyDeviceToHost, s));
+    if (chi2) HIPCHK(hipMemcpyAsync(h + o_c2, c->chi2.p, sizeof(double) * F, hipMemcpyDeviceToHost, s));
+    if (chi2_thresh) HIPCHK(hipMemcpyAsync(h + o_th, c->chi2_thr.p, sizeof(double) * F, hipMemcpyDeviceToHost, s));
+    if (p_FinG) HIPCHK(hipMemcpyAsync(h + o_pg, c->pG.p, sizeof(double) * 3 * F, hipMemcpyDeviceToHost, s));
+    HIPCHK(upload_sync(c, s));
+    std::memcpy(st.data(), h + o_st, sizeof(int32_t) * F);
+    if (chi2) std::memcpy(chi2, h + o_c2, sizeof(double) * F);
+    if (chi2_thresh) std::memcpy(chi2_thresh, h + o_th, sizeof(double) * F);
+    if (p_FinG) std::memcpy(p_FinG, h + o_pg, sizeof(double) * 3 * F);
+  } else {
+    HIPCHK(upload_sync(c, s));
+  }
   const double qnan = std::nan("");
   int n_used = 0;
   int64_t rows = 0;
@@ -1863,10 +1927,18 @@ static int check_tree_error(ovgpu_ctx *c) {
 static int finish_update(ovgpu_ctx *c, double *dx, double *P_out, ovgpu_update_stats *stats) {
   hipStream_t s = c->stream;
   int32_t flags[4] = {0, 0, 0, 0};
-  HIPCHK(hipMemcpyAsync(flags, c->flags.p, sizeof(flags), hipMemcpyDeviceToHost, s));
-  if (dx) HIPCHK(hipMemcpyAsync(dx, c->dx.p, sizeof(double) * c->N, hipMemcpyDeviceToHost, s));
-  if (P_out) HIPCHK(hipMemcpyAsync(P_out, c->P.p, sizeof(double) * c->N * c->N, hipMemcpyDeviceToHost, s));
-  HIPCHK(hipStreamSynchronize(s));
+  {
+    const size_t N = (size_t)c->N, o_dx = 64, o_P = o_dx + ((sizeof(double) * N + 63) & ~(size_t)63);
+    HIPCHK(c->down_arena.reserve(o_P + sizeof(double) * N * N));
+    unsigned char *h = c->down_arena.p;
+    HIPCHK(hipMemcpyAsync(h, c->flags.p, sizeof(flags), hipMemcpyDeviceToHost, s));
+    if (dx) HIPCHK(hipMemcpyAsync(h + o_dx, c->dx.p, sizeof(double) * N, hipMemcpyDeviceToHost, s));
+    if (P_out) HIPCHK(hipMemcpyAsync(h + o_P, c->P.p, sizeof(double) * N * N, hipMemcpyDeviceToHost, s));
+    HIPCHK(upload_sync(c, s));
+    std::memcpy(flags, h, sizeof(flags));
+    if (dx) std::memcpy(dx, h + o_dx, sizeof(double) * N);
+    if (P_out) std::memcpy(P_out, h + o_P, sizeof(double) * N * N);
+  }
   int status = OVGPU_OK;
   if (flags[0]) status = OVGPU_ERR_NOT_SPD;
   else if (flags[1]) status = OVGPU_ERR_NEGATIVE_DIAGONAL;

@@ -7,7 +7,11 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <algorithm>
+#include <cstdlib>
 #include <random>
+#include <string>
+#include <vector>
 
 #include "ovgpu_flatten.h"
 
@@ -82,7 +86,133 @@ static int gpu_update() {
   return (used >= F / 2 && tr1 < 0.9 * tr0 && std::sqrt(dxn) > 1e-4 && std::sqrt(dxn) < 0.5 && st.status == OVGPU_OK) ? 0 : 1;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// `selftest --time [F] [reps]`: what the DROP-IN path costs per update, host to host, from C++.  F tracks in the
+// reference's own container shape -- per camera an unordered_map entry holding a vector of HEAP-ALLOCATED 2-float vectors
+// (ov_core::Feature::uvs / uvs_norm are std::unordered_map<size_t, std::vector<Eigen::VectorXf>>, Feature.h:49-55) and a vector of
+// timestamps -- on a 30-clone stereo window (N = 224, D = 208).  Per update, exactly as shim/UpdaterMSCKF.cpp sequences it:
+//   flatten      the tracks -> the flat views (clean_old_measurements by exact timestamp match included)
+//   upload       ovgpu_set_state + ovgpu_set_features
+//   mode A       ovgpu_msckf_compress (+ ovgpu_get_triangulation): kernels + read-back of status, p_FinG, (H, r)
+//   mode B       ovgpu_msckf_update: kernels + read-back of status, p_FinG, dx, P'
+// One JSON line; bench.py puts it into its own line (`shim`).
+// ---------------------------------------------------------------------------------------------------------------------
+#include <chrono>
+#include <memory>
+#include <unordered_map>
+struct HeapVec2 { // stands in for Eigen::VectorXf of size 2: its own heap block
+  std::unique_ptr<float[]> d;
+  HeapVec2(float a, float b) : d(new float[2]) { d[0] = a, d[1] = b; }
+};
+struct RefShapedFeature {
+  std::unordered_map<size_t, std::vector<HeapVec2>> uvs, uvs_norm;
+  std::unordered_map<size_t, std::vector<double>> timestamps;
+};
+static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+static double median(std::vector<double> v) {
+  std::sort(v.begin(), v.end());
+  return v[v.size() / 2];
+}
+
+static int time_dropin(int F, int reps) {
+  FlatState fs;
+  const double q[4] = {0, 0, 0, 1}, zero[3] = {0, 0, 0}, intr[8] = {458, 457, 367, 248, 0, 0, 0, 0};
+  const double p_cam1[3] = {-0.11, 0, 0}; // p_IinC of the second camera: 11 cm baseline
+  const int C = 30, K = 2, base = 16 + 14 * K;
+  std::mt19937 rng(11);
+  std::normal_distribution<double> nz(0.0, 1.0);
+  std::vector<double> ptrue(3 * C);
+  for (int i = 0; i < C; i++) {
+    const double pt[3] = {0.10 * i, 0.004 * i * i, 0.02 * std::sin(0.4 * i)};
+    std::memcpy(&ptrue[3 * i], pt, sizeof(pt));
+    const double pe[3] = {pt[0] + 0.005 * nz(rng), pt[1] + 0.005 * nz(rng), pt[2] + 0.005 * nz(rng)};
+    fs.add_clone(20.0 + 0.1 * i, q, pe, q, pe, base + 6 * i);
+  }
+  fs.add_camera(q, zero, intr, false, 16, 22);
+  fs.add_camera(q, p_cam1, intr, false, 30, 36);
+  fs.N = base + 6 * C;
+  fs.P.assign((size_t)fs.N * fs.N, 0.0);
+  for (int i = 0; i < fs.N; i++) fs.P[(size_t)i * fs.N + i] = i < base ? 1e-6 : (((i - base) % 6) < 3 ? 1e-4 : 4e-4);
+  // the tracks, in the reference's container shape; one stale observation per track that clean_old_measurements must drop
+  std::uniform_real_distribution<double> ux(-1.0, 4.0), uy(-1.5, 1.5), uz(5.0, 7.0);
+  std::vector<RefShapedFeature> feats((size_t)F);
+  size_t n_obs = 0;
+  for (int f = 0; f < F; f++) {
+    const double pf[3] = {ux(rng), uy(rng), uz(rng)};
+    RefShapedFeature &t = feats[f];
+    for (int k = 0; k < K; k++) {
+      const double cx = k == 0 ? 0.0 : 0.11; // camera centre in the IMU frame (identity rotations)
+      t.timestamps[k].push_back(19.9), t.uvs[k].emplace_back(1.f, 1.f), t.uvs_norm[k].emplace_back(0.f, 0.f);
+      for (int i = 0; i < C; i++) {
+        const double dz = pf[2] - ptrue[3 * i + 2];
+        const double xn = (pf[0] - ptrue[3 * i] - cx) / dz, yn = (pf[1] - ptrue[3 * i + 1]) / dz;
+        const float u = (float)(intr[0] * xn + intr[2] + 0.5 * nz(rng)), v = (float)(intr[1] * yn + intr[3] + 0.5 * nz(rng));
+        if (u < 0 || u > 752 || v < 0 || v > 480) continue;
+        t.timestamps[k].push_back(fs.clone_times[i]);
+        t.uvs[k].emplace_back(u, v);
+        t.uvs_norm[k].emplace_back((float)((u - intr[2]) / intr[0]), (float)((v - intr[3]) / intr[1]));
+        n_obs++;
+      }
+    }
+  }
+  ovgpu_options o;
+  ovgpu_default_options(&o);
+  o.chi2_multipler = 1.0, o.sigma_pix = 1.0;
+  Context ctx(o);
+  const CloneIndex clones(fs.clone_times);
+  const int Dmax = 6 * C + 14 * K;
+  std::vector<int32_t> status(F), anchor(F), col_cov(Dmax);
+  std::vector<double> pA(3 * (size_t)F), pG(3 * (size_t)F), H((size_t)Dmax * Dmax), r(Dmax), dx(fs.N), P1((size_t)fs.N * fs.N);
+  std::vector<double> t_flat, t_up, t_a, t_b, t_dev;
+  int used = 0, rows = 0, M = 0;
+  for (int it = 0; it < reps + 2; it++) {
+    const double t0 = now_ms();
+    FlatFeatures ff;
+    for (const RefShapedFeature &t : feats) {
+      for (const auto &pair : t.timestamps) {
+        const auto &uv = t.uvs.at(pair.first), &un = t.uvs_norm.at(pair.first);
+        ff.add_camera((int)pair.first, pair.second, [&](size_t i, float &x, float &y) { x = uv[i].d[0], y = uv[i].d[1]; },
+                      [&](size_t i, float &x, float &y) { x = un[i].d[0], y = un[i].d[1]; }, clones);
+      }
+      ff.end_feature();
+    }
+    const ovgpu_state_view sv = fs.view();
+    const ovgpu_features_view fv = ff.view();
+    M = fv.M;
+    const double t1 = now_ms();
+    ctx.check(ovgpu_set_state(ctx.get(), &sv), "ovgpu_set_state");
+    ctx.check(ovgpu_set_features(ctx.get(), &fv), "ovgpu_set_features");
+    const double t2 = now_ms();
+    int32_t D = 0, rr = 0;
+    ovgpu_update_stats st;
+    ctx.check(ovgpu_msckf_compress(ctx.get(), status.data(), nullptr, nullptr, pG.data(), &D, &rr, col_cov.data(), H.data(), r.data(), &st), "ovgpu_msckf_compress");
+    ctx.check(ovgpu_get_triangulation(ctx.get(), pA.data(), nullptr, anchor.data()), "ovgpu_get_triangulation");
+    const double t3 = now_ms();
+    // mode B on the same upload (the state is untouched by mode A)
+    ctx.check(ovgpu_msckf_update(ctx.get(), status.data(), nullptr, nullptr, pG.data(), dx.data(), P1.data(), &st), "ovgpu_msckf_update");
+    const double t4 = now_ms();
+    if (it >= 2) t_flat.push_back(t1 - t0), t_up.push_back(t2 - t1), t_a.push_back(t3 - t2), t_b.push_back(t4 - t3), t_dev.push_back(st.ms_total);
+    rows = rr, used = 0;
+    for (int f = 0; f < F; f++) used += status[f] == OVGPU_FEAT_USED;
+  }
+  const double fl = median(t_flat), up = median(t_up), a = median(t_a), b = median(t_b);
+  std::printf("{\"what\": \"drop-in path from C++, host to host, reference-shaped Feature containers\", \"features\": %d, \"measurements\": %d, "
+              "\"observations_incl_stale\": %zu, \"clones\": %d, \"cameras\": %d, \"features_used\": %d, \"rows_mode_a\": %d, \"reps\": %d, "
+              "\"flatten_ms\": %.4f, \"upload_ms\": %.4f, \"mode_a_call_ms\": %.4f, \"mode_b_call_ms\": %.4f, \"device_update_ms\": %.4f, "
+              "\"shim_mode_a_ms\": %.4f, \"shim_mode_b_ms\": %.4f}\n",
+              F, M, n_obs + (size_t)F * K, C, K, used, rows, reps, fl, up, a, b, median(t_dev), fl + up + a, fl + up + b);
+  return used > F / 2 ? 0 : 1;
+}
+
 int main(int argc, char **argv) {
+  if (argc > 1 && std::strcmp(argv[1], "--time") == 0) {
+    try {
+      return time_dropin(argc > 2 ? std::atoi(argv[2]) : 2000, argc > 3 ? std::atoi(argv[3]) : 9);
+    } catch (const std::exception &e) {
+      std::printf("shim timing FAILED: %s\n", e.what());
+      return 3;
+    }
+  }
   if (argc > 1 && std::strcmp(argv[1], "--gpu") == 0) {
     try {
       const int rc = gpu_update();

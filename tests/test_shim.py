@@ -136,3 +136,20 @@ def test_slam_update_required_meas_rule():
     assert m and "to_delete = true" in m.group(1) and "erase(it)" in m.group(1)
     assert "to_delete" not in m.group(2) and "erase(it)" in m.group(2)
     assert s.index("ct_meas < required_meas") < s.index("append_track(")
+
+
+@pytest.mark.gpu
+def test_shim_timing_mode_reports_the_drop_in_cost():
+    """`selftest --time`: reference-shaped tracks -> flatten -> upload -> mode A / mode B, host to host, as one JSON line (what bench.py
+    embeds as `shim`)."""
+    import json
+    import subprocess
+    exe = os.path.join(ROOT, "open_vins_amd", "shim", "selftest")
+    p = subprocess.run([exe, "--time", "300", "3"], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["features"] == 300 and d["clones"] == 30 and d["cameras"] == 2 and d["features_used"] > 200
+    assert d["measurements"] < d["observations_incl_stale"]  # the stale observation of every track was cleaned away
+    for k in ("flatten_ms", "upload_ms", "mode_a_call_ms", "mode_b_call_ms", "shim_mode_a_ms", "shim_mode_b_ms"):
+        assert d[k] > 0
+    assert abs(d["shim_mode_a_ms"] - (d["flatten_ms"] + d["upload_ms"] + d["mode_a_call_ms"])) < 1e-3
