@@ -52,7 +52,6 @@ def parse_args(argv=None):
     ap.add_argument("--no-extras", action="store_true", help="skip the PCIe-inclusive and the secondary (weak / single-GPU reference) measurements")
     ap.add_argument("--route", choices=["gram", "tsqr"], default="gram")
     ap.add_argument("--stage-events-every", type=int, default=4, help="the library's per-stage HIP events (roofline durations) on every n-th update of the timed region")
-    ap.add_argument("--legacy-feature-kernel", action="store_true", help="round 2's three-sweep per-feature kernels (k_feat.h) instead of the fused one (k_featy.h)")
     ap.add_argument("--gram-fp32", action="store_true", help="BASELINE configs[4]'s fp32 compression: Gram matrix accumulated on v_mfma_f32_16x16x4_f32")
     return ap.parse_args(argv)
 
@@ -153,8 +152,6 @@ def main(argv=None):
         local_only: every rank updates with ITS shard alone (no exchange) — the compute side of the scaling model."""
         shard = prob_full if world == 1 else prob_full.subset(feats_of_rank)
         up = UpdaterMSCKF(opts, device=local_rank)
-        if args.legacy_feature_kernel:
-            up.debug_option("legacy_feature_kernel", 1)
         # the library's stage events (the roofline's kernel durations) are marker packets the next kernel waits for: ~5 us apiece, six per
         # update (measured: 0.982 -> 0.961 ms at every 4th update, 0.948 with none).  They are recorded on every n-th update of the timed
         # region; the reported durations are averages over those updates.
@@ -292,8 +289,7 @@ def main(argv=None):
                 "parallelism": f"feature-shard x{world}, one all-reduce of the Gram matrix: {exchange['kind']}" if world > 1 else "single GPU",
             },
             "roofline": {
-                "kernel": ("per-feature stage = k_feat_rows + k_feat_qr + k_feat + k_feat_out (csrc/k_feat.h, round 2's three-sweep form)" if args.legacy_feature_kernel else
-                           "per-feature stage = k_feat_rows_sorted + k_feat_vt + k_feat_y (csrc/k_featy.h: Jacobian records, reflectors, then ONE kernel per "
+                "kernel": ("per-feature stage = k_feat_rows_sorted + k_feat_vt + k_feat_y (csrc/k_featy.h: Jacobian records, reflectors, then ONE kernel per "
                            "feature: whitened rows Y = H L as block products on the f64 matrix cores, projection and stacking, gate matrix Y Y^T + s^2 I as a "
                            "SYRK in accumulator registers, blocked Cholesky, chi2; gate matrices beyond 136 tiles (configs[4]): k_feat_y_big, csrc/k_featy_big.h, block row "
                            "by block row)") + ", timed with HIP events on the context's stream (the wait for the prior "

@@ -128,7 +128,7 @@ typedef struct {
   int32_t tsqr_no_pipeline;  /* 1: merge tree level by level                 */
   int32_t tsqr_overlap;      /* 0 auto, 1 merge tree next to the leaves,     */
                              /* 2 never                                      */
-  int32_t tsqr_leaf_blocked; /* 1: experimental compact-WY leaf (k_tsqr_blk) */
+  int32_t tsqr_leaf_blocked; /* reserved (round 3's experimental leaf was retired): ignored   */
   int32_t no_timing;         /* 1: no HIP events around the stages           */
   int32_t no_fast_feature_kernel; /* 1: always the general per-feature       */
                              /* kernel (k_system) instead of the MSCKF fast  */
@@ -767,8 +767,18 @@ int ovgpu_last_update_route(ovgpu_ctx *ctx);
  *                             are switched off on the device, the state stays untouched and the synchronous update calls repeat
  *                             the update with the step-wise kernels
  *   "chol_timeouts"           (read only) number of updates repeated that way
- *   "legacy_feature_kernel"   1 selects round 2's three-sweep form of the MSCKF fast path (k_feat.h) instead of the fused
- *                             kernel of k_featy.h (A / B measurements, parity of both forms)                                 */
+ *   "stage_timing_period"     n >= 1: the six stage events (ovgpu_update_stats::ms_*, ovgpu_kernel_times) go into every n-th update
+ *                             only (each is a marker packet the next kernel waits for, ~5 us); updates without events report 0
+ *   "stack_is_f32"            (read only) the last pipeline stored the stack as floats and ran k_gram_f32 (options.gram_fp32)
+ *   "featy_big"               1 / 2: the block-row form of the per-feature kernel (k_featy_big.h) on batches the one-pass kernel holds
+ *   "featy_shape"             1 / 2: alternative wavefront x tile shapes of the fused per-feature kernel (tuning experiments)
+ *   "gram_interleaved"        0: k_gram instead of k_gram_il (staging not interleaved with the matrix instructions)
+ *   "gram_blocks_only"        1: always the 8 x 8-tile block form of the Gram kernel (k_gram_blk)
+ *   "fuse_chol_inputs"        0: round 2's k_tf_gather / k_tf_abh assemble the factorisations' inputs
+ *   "chol_flag_sync"          1: flag-word synchronisation inside the step-wise Cholesky (experiment)
+ *   "featy_skip"              ABLATION ONLY (bit mask: 1 sweep, 2 projection + stores, 4 SYRK, 8 Cholesky): phases of the fused
+ *                             kernel are skipped for timing; the results of such an update are GARBAGE.  Never set it outside
+ *                             tools/dev_featy_ablate.py.                                                                      */
 int ovgpu_debug_option(ovgpu_ctx *ctx, const char *name, int64_t value, int64_t *old_value);
 
 /* Developer aid (no reference counterpart): per-phase cycle counters of workgroup 0 of the per-feature kernel.

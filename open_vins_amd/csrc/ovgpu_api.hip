@@ -20,7 +20,6 @@
 #include "k_tsqr_pw.h"
 #include "k_ekf.h"
 #include "k_slam.h"
-#include "k_tsqr_blk.h"
 #include "k_tracks.h"
 #include "k_featy.h"
 #include "k_featy_big.h"
@@ -230,13 +229,11 @@ struct ovgpu_ctx {
   bool gram_is_whitened = false; // c->gram_G / the Gram buffer handed out by the last local stage is the whitened stack's
   bool prior_on_side = false;   // the pending prior-block factorisation runs on stream2 (ev_join marks its end)
   int feat_variant = 0;         // MSCKF fast path of the per-feature stage (k_feat.h) for this batch: 0 none, 1 <4,11>, 2 <8,17>
-  int feat_nt_max = 0, feat_grid = 0;
-  size_t feat_lds = 0;
+  int feat_nt_max = 0;
   // the fused form of the fast path (k_featy.h): rows, projection, stack and gate in one kernel, gate matrix as a SYRK of the whitened rows
   bool featy_ok = false;         // this batch fits it
   int featy_shape = 0;             // ovgpu_debug_option "featy_shape": 1 = eight wavefronts x 6 tiles, four wavefronts per SIMD
   int featy_skip = 0;              // ovgpu_debug_option "featy_skip": ablation bit mask (timing experiments only)
-  bool legacy_feat_kernel = false; // ovgpu_debug_option "legacy_feature_kernel": keep k_feat.h's three-sweep form
   int featy_grid = 0;
   size_t featy_lds = 0;
   DevBuf<double> fs_tq;
@@ -277,7 +274,6 @@ struct ovgpu_ctx {
   int Lw_D = -1;               // column count c->Lw was zeroed for (its upper triangle stays zero)
   DevBuf<long long> dbg_cycles; // ovgpu_debug_cycles: per-phase cycle counters of workgroup 0 of the per-feature kernel
   int tsqr_workers = 0;         // options.tsqr_workers
-  bool leaf_blocked = false;    // options.tsqr_leaf_blocked
   bool async_pending = false;     // ovgpu_msckf_update_async since the last ovgpu_synchronize
   bool last_update_tform = false; // the last EKF stage enqueued was the Gram-form one (finish_update may fall back)
   bool force_tsqr = false;        // one-shot: the next pipeline takes the Householder route
@@ -412,17 +408,6 @@ static int launch_qr_node(ovgpu_ctx *c, int nodes, const QrNodeParams &q) {
 // leaf nodes: the "panel wave" variant (k_tsqr_pw.h), NT <= 15
 template <int QH>
 static int launch_qr_leaf_pw(ovgpu_ctx *c, int nodes, const QrNodeParams &q) {
-  // options.tsqr_leaf_blocked: the compact-WY leaf on the matrix cores (k_tsqr_blk.h) — experimental, see DESIGN.md §4
-  if (c->leaf_blocked && QH == 32) {
-    static bool attr_b = false;
-    if (!attr_b) {
-      (void)hipFuncSetAttribute((const void *)blk::k_qr_leaf<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      attr_b = true;
-    }
-    hipLaunchKernelGGL((blk::k_qr_leaf<0>), dim3(nodes), dim3(64 * (pw::qr_node_bulk_waves(q.NT) + 1)), blk::qr_leaf_lds_bytes(q.NT), c->stream, q);
-    HIPCHK(hipGetLastError());
-    return OVGPU_OK;
-  }
   const size_t lds = pw::qr_node_lds_bytes(q.NT, QH);
   static bool attr_done = false;
   if (!attr_done) {
@@ -554,7 +539,6 @@ int ovgpu_create(const ovgpu_options *opts, int device, ovgpu_ctx **out) {
   c->whiten = opts->gram_no_whiten == 0;
   c->prior_pivot_tol = opts->prior_pivot_tol > 0.0 ? opts->prior_pivot_tol : 1e-13;
   c->tsqr_workers = opts->tsqr_workers;
-  c->leaf_blocked = opts->tsqr_leaf_blocked != 0;
   c->no_feat_kernel = opts->no_fast_feature_kernel != 0;
   c->no_chol_pipe = opts->no_single_launch_cholesky != 0;
   c->feat_shape = opts->feature_kernel_shape;
@@ -876,13 +860,7 @@ static int set_row_layout(ovgpu_ctx *c, bool slam_rows) {
     if (c->feat_shape == 1 && tiles <= 4 * 11) variant = 1;
     if (c->feat_shape == 2 && tiles <= 8 * 17) variant = 2;
     if (variant) {
-      const feat::FeatLds lo = feat::feat_lds_layout(m_max, c->row_stride, c->D, c->LD, c->K * c->C, nt);
-      if (lo.total <= (size_t)c->lds_limit) {
-        const int per_cu = std::max(1, std::min(2, (int)((size_t)c->lds_limit / lo.total)));
-        c->feat_variant = variant, c->feat_nt_max = nt, c->feat_lds = lo.total;
-        c->feat_grid = std::max(1, std::min(F, c->num_cu * per_cu));
-        if (feat::feat_qr_lds_per_wave(m_max, c->LD, c->K * c->C) * 4 > (size_t)c->lds_limit) c->feat_variant = 0;
-      }
+      c->feat_variant = variant, c->feat_nt_max = nt; // confirmed against the fused kernel's own limits below
     } else if (nt <= 29 && c->feat_shape == 0 && feat::featyb_lds_layout(nt, 8).total <= (size_t)c->lds_limit) {
       // 3: the gate matrix does not fit the registers of a compute unit: block row by block row (k_featy_big.h; no legacy form)
       c->feat_variant = 3, c->feat_nt_max = nt;
@@ -910,6 +888,8 @@ static int set_row_layout(ovgpu_ctx *c, bool slam_rows) {
       const int per_cu = nw == 4 ? std::max(1, std::min(2, (int)((size_t)c->lds_limit / lo.total))) : 1;
       c->featy_ok = true, c->featy_lds = lo.total;
       c->featy_grid = std::max(1, std::min(F, c->num_cu * per_cu));
+    } else {
+      c->feat_variant = 0; // the general kernel (k_system.h)
     }
   }
   if (c->feat_variant) { // row store of the fast path
@@ -919,8 +899,6 @@ static int set_row_layout(ovgpu_ctx *c, bool slam_rows) {
     HIPCHK(c->fs_rows.reserve((size_t)M * c->row_stride));
     HIPCHK(c->fs_minfo.reserve((size_t)M * 8));
     HIPCHK(c->fs_V.reserve((size_t)M * 6));
-    HIPCHK(c->fs_z.reserve((size_t)std::max(F, 1) * 3 * c->LD));
-    HIPCHK(c->fs_w.reserve((size_t)std::max(F, 1) * 3 * c->LD));
     HIPCHK(c->fs_meas_feat.reserve(M));
     std::vector<int32_t> mf(M, 0);
     for (int f = 0; f < F; f++)
@@ -1088,19 +1066,12 @@ static int enqueue_system(ovgpu_ctx *c, int f_one = -1, int init_rep = 0, bool w
     HIPCHK(c->feat_counter.reserve(1));
     HIPCHK(ctrl_zero(c, CTRL_COUNTER, c->feat_counter.p, sizeof(int32_t), c->stream));
     p.work_counter = c->feat_counter.p;
-    static bool attr_done = false;
-    if (!attr_done) {
-      (void)hipFuncSetAttribute((const void *)feat::k_feat<4, 11, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_limit);
-      (void)hipFuncSetAttribute((const void *)feat::k_feat<8, 17, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_limit);
-      (void)hipFuncSetAttribute((const void *)feat::k_feat_qr, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_limit);
-      attr_done = true;
-    }
     // rows (per measurement) -> gate (needs P only) -> projected whitened rows (need L and z).  The prior block's factorisation and
     // the reflector / z kernel behind it run on the second stream NEXT TO the gate; only the output kernel waits for them.
     feat::FeatStore st{c->fs_rows.p, c->fs_minfo.p, c->fs_V.p, c->fs_z.p, c->fs_meas_feat.p, c->fs_w.p};
-    const double *sr = st.rows, *sV = st.V, *sz = st.z;
+    const double *sr = st.rows, *sV = st.V;
     const int32_t *sm = st.minfo;
-    if (c->featy_ok && (!c->legacy_feat_kernel || c->feat_variant == 3)) {
+    if (c->featy_ok) {
       // the fused form (k_featy.h): rows (clone-major) -> reflectors -> [prior block's factor L joins] -> sweep Y = H L once per feature:
       // projected rows to the stack, gate matrix as Y Y^T + s^2 I on the matrix cores, Cholesky, chi2
       static bool attr_y = false;
@@ -1158,26 +1129,7 @@ static int enqueue_system(ovgpu_ctx *c, int f_one = -1, int init_rep = 0, bool w
       HIPCHK(hipGetLastError());
       return OVGPU_OK;
     }
-    hipLaunchKernelGGL(feat::k_feat_rows, dim3((c->M + 255) / 256), dim3(256), 0, c->stream, p, st, c->M);
-    hipStream_t sq = c->stream;
-    if (c->prior_on_side) {
-      HIPCHK(hipEventRecord(c->ev_rows, c->stream));
-      HIPCHK(hipStreamWaitEvent(c->stream2, c->ev_rows, 0));
-      sq = c->stream2;
-    }
-    hipLaunchKernelGGL(feat::k_feat_qr, dim3((c->F + 3) / 4), dim3(256), 4 * feat::feat_qr_lds_per_wave(p.m_max, c->LD, c->K * c->C), sq, p, st);
-    {
-      const int zr = 3 * c->F, ztiles = ((zr + 15) / 16) * ((c->LD + 15) / 16);
-      hipLaunchKernelGGL(feat::k_feat_z, dim3((ztiles + 3) / 4), dim3(256), 0, sq, zr, c->D, c->LD, (const double *)c->fs_w.p, (const double *)c->Lw.p, c->fs_z.p);
-    }
-    if (c->prior_on_side) HIPCHK(hipEventRecord(c->ev_join, sq));
-    if (c->feat_variant == 1) hipLaunchKernelGGL((feat::k_feat<4, 11, 2>), dim3(c->feat_grid), dim3(256), c->feat_lds, c->stream, p, c->feat_nt_max, sr, sm, sV, sz);
-    else hipLaunchKernelGGL((feat::k_feat<8, 17, 2>), dim3(c->feat_grid), dim3(512), c->feat_lds, c->stream, p, c->feat_nt_max, sr, sm, sV, sz);
-    if (c->prior_on_side) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join, 0));
-    // two columns per lane (measured at 2000 / 10 000 x 4-camera features: 1 column 190 / 3070 us, 2 columns 160 / 2100, 4 columns 183 / 2050)
-    hipLaunchKernelGGL(feat::k_feat_out<2>, dim3(std::max(1, std::min(c->F, 16 * c->num_cu))), dim3(128), 0, c->stream, p, sr, sm, sV, sz);
-    HIPCHK(hipGetLastError());
-    return OVGPU_OK;
+    return set_err(OVGPU_ERR_INVALID, "internal: the MSCKF fast path was selected for a batch the fused kernel does not hold");
   }
   if (p.Lw && c->prior_on_side) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join, 0)); // the general kernel reads L from its first instruction on
   hipLaunchKernelGGL(k_system, dim3(grid), dim3(SYS_NT), c->sys_lds_bytes, c->stream, p);
@@ -3237,9 +3189,6 @@ int ovgpu_debug_option(ovgpu_ctx *c, const char *name, int64_t value, int64_t *o
   if (n == "chol_follow_spin_limit") {
     if (old_value) *old_value = c->chol_spin_limit;
     if (value >= 0) c->chol_spin_limit = (int)std::min<int64_t>(value, 1 << 30);
-  } else if (n == "legacy_feature_kernel") { // 1: the three-sweep form of the MSCKF fast path (k_feat.h) instead of the fused one (k_featy.h)
-    if (old_value) *old_value = c->legacy_feat_kernel ? 1 : 0;
-    if (value >= 0) c->legacy_feat_kernel = value != 0;
   } else if (n == "chol_flag_sync") {
     if (old_value) *old_value = c->chol_flag_sync ? 1 : 0;
     if (value >= 0) c->chol_flag_sync = value != 0;

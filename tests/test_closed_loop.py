@@ -149,8 +149,8 @@ def test_mode_a_closed_loop(stream, oracle_run, route):
     tsqr    = the Householder TSQR's triangle, the reference's own form: likewise;
     cholqr  = the UNPIVOTED factor, round 3's negative result: the whitened Gram matrix is numerically singular (gauge directions,
               weakly observed calibration), a pivot that is rounding noise divides its row, one step loses 1e-8 of dx and the loop
-              drifts 6e-6 — the same defect round 1 measured for the Cholesky factor of the RAW Gram matrix.  The test keeps that
-              number honest too (it fails if the drift ever disappears).
+              drifts 6e-6 — the same defect round 1 measured for the Cholesky factor of the RAW Gram matrix.  Informational: the
+              drift is printed and only bounded from above (a negative result that improved would not be a failure).
     VERDICT round 2 asked whether the Gram route can serve mode A: without pivoting it cannot, with diagonal pivoting (backward
     stable for semi-definite matrices) it does."""
     from open_vins_amd.updater import UpdaterMSCKF
@@ -179,7 +179,7 @@ def test_mode_a_closed_loop(stream, oracle_run, route):
     if route in ("default", "tsqr"):
         assert dev < 1e-9
     else:
-        assert 1e-8 < dev < 1e-3
+        assert dev < 1e-3
 
 
 @pytest.mark.gpu

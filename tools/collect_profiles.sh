@@ -6,7 +6,6 @@ SRC=gpurun_out/$1; P=profiles/$2
 cp $SRC/prof_stats.txt ${P}_kernel_stats_cfg3.txt
 cp $SRC/prof_stats2.txt ${P}_kernel_stats_cfg2.txt
 [ -f $SRC/prof_stats3.txt ] && cp $SRC/prof_stats3.txt ${P}_kernel_stats_cfg4_one_gpu.txt
-[ -f $SRC/bench_legacy_feature_kernels.json ] && cp $SRC/bench_legacy_feature_kernels.json ${P}_bench_legacy_feature_kernels.json
 cp $SRC/prof_fetch.txt ${P}_pmc_fetch_size.txt
 cp $SRC/prof_write.txt ${P}_pmc_write_size.txt
 cp $SRC/prof_sq1.txt ${P}_pmc_sq_waits.txt

@@ -12,7 +12,6 @@ if [ "${SKIP_TESTS:-0}" != 1 ]; then
 fi
 timeout 300 python -m pytest tests/test_gpu_fullsize.py -q -s -p no:cacheprovider -k "conditioning_sweep or round1_route" 2>&1 | grep "cond(P_DD)\|gram then\|passed\|failed" > $OUT/conditioning_sweep.txt
 timeout 400 python bench.py > $OUT/bench.json 2> $OUT/bench.err
-timeout 120 python bench.py --legacy-feature-kernel --steps 30 --warmup 5 --no-cpu-baseline --no-extras > $OUT/bench_legacy_feature_kernels.json 2>> $OUT/bench.err
 timeout 120 python bench.py --cfg 2 --steps 50 --warmup 5 --no-cpu-baseline --no-extras > $OUT/bench_cfg2.json 2>> $OUT/bench.err
 timeout 120 python bench.py --cfg 2 --features 10000 --steps 10 --warmup 2 --no-cpu-baseline --no-extras > $OUT/bench_stereo_10k.json 2>> $OUT/bench.err
 timeout 120 python bench.py --cfg 4 --steps 10 --warmup 2 --no-cpu-baseline --no-extras > $OUT/bench_cfg4_one_gpu.json 2>> $OUT/bench.err
