@@ -603,7 +603,11 @@ int ovgpu_tracks_count(ovgpu_ctx *ctx, int32_t *n_tracks);
  *                            TrackSIM.cpp:37-63), so this is normally descending camera id and a tie is anchored in
  *                            the highest id; a track first seen by camera 1 alone and later by camera 0 iterates 0, 1.
  *   OVGPU_GROUPS_DESCENDING / _ASCENDING   by camera id, whatever the history.
- * The host-flattened path (shim/ovgpu_flatten.h) walks the map itself and needs no such rule.            */
+ * The host-flattened path (shim/ovgpu_flatten.h) walks the map itself and needs no such rule.
+ * ASSUMPTION of OVGPU_GROUPS_REFERENCE: the reference is built against libstdc++ and a track's map never
+ * rehashes (at most 13 distinct camera keys: the first bucket count).  libc++ / MSVC iterate differently,
+ * and a rehash reverses the list again; a host in that situation flattens on its side (it iterates its
+ * own map) or passes OVGPU_GROUPS_DESCENDING / _ASCENDING explicitly.                                         */
 enum { OVGPU_GROUPS_REFERENCE = 0, OVGPU_GROUPS_DESCENDING = 1, OVGPU_GROUPS_ASCENDING = 2 };
 int ovgpu_tracks_group_order(ovgpu_ctx *ctx, int32_t order);
 

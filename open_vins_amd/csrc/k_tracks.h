@@ -63,8 +63,22 @@ __global__ void k_tracks_gather(int F, int K, int C, const int32_t *__restrict__
   const int cnt = s >= 0 ? ts.count[s] : 0;
   const size_t base = (size_t)max(s, 0) * ts.max_obs;
   if (pass == 0) {
+    // the SAME filter as pass 1: the observation's camera must be one the group order lists (an order that stops early, -1, or a
+    // camera id >= K leaves observations out), and its time a clone time — otherwise the offsets and the written rows disagree
     int n = 0;
-    for (int j = 0; j < cnt; j++) n += clone_index_of(ts.time[base + j], C, clone_times) >= 0;
+    for (int j = 0; j < cnt; j++) {
+      const int cam = ts.cam[base + j];
+      bool listed = cam >= 0 && cam < K;
+      if (listed && group_order) {
+        listed = false;
+        for (int kk = 0; kk < K; kk++) {
+          const int k = group_order[(size_t)f * K + kk];
+          if (k < 0) break;
+          listed = listed || k == cam;
+        }
+      }
+      n += listed && clone_index_of(ts.time[base + j], C, clone_times) >= 0;
+    }
     n_valid[f] = n;
     return;
   }
