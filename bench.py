@@ -52,6 +52,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-extras", action="store_true", help="skip the PCIe-inclusive and the secondary (weak / single-GPU reference) measurements")
     ap.add_argument("--route", choices=["gram", "tsqr"], default="gram")
     ap.add_argument("--stage-events-every", type=int, default=4, help="the library's per-stage HIP events (roofline durations) on every n-th update of the timed region")
+    ap.add_argument("--gate-always-factor", action="store_true", help="ovgpu_options::gate_always_factor = 1: form and factor every feature's gate matrix "
+                    "(default: features whose residual bound is under the chi2 threshold are accepted without it)")
     ap.add_argument("--gram-fp32", action="store_true", help="BASELINE configs[4]'s fp32 compression: Gram matrix accumulated on v_mfma_f32_16x16x4_f32")
     return ap.parse_args(argv)
 
@@ -132,7 +134,8 @@ def main(argv=None):
 
     cfg = args.cfg if args.cfg is not None else (CFG_SINGLE if world == 1 else CFG_MULTI)
     route = capi.COMPRESS_GRAM if args.route == "gram" else capi.COMPRESS_TSQR
-    opts = capi.default_options(chi2_multipler=1.0, compress_route=route, gram_fp32=1 if args.gram_fp32 else 0)  # config/rpng_sim/estimator_config.yaml:100-101
+    opts = capi.default_options(chi2_multipler=1.0, compress_route=route, gram_fp32=1 if args.gram_fp32 else 0,
+                                gate_always_factor=1 if args.gate_always_factor else 0)  # config/rpng_sim/estimator_config.yaml:100-101
 
     def fence():
         if hook is None:
@@ -147,7 +150,7 @@ def main(argv=None):
     timed_loops = []  # seconds of every timed loop of the last run()
     rank_loops = []   # the last timed loop of the last run(): every rank's own seconds (before the max over ranks)
 
-    def run(prob_full, feats_of_rank, steps, warmup, local_only=False, repeats=1):
+    def run(prob_full, feats_of_rank, steps, warmup, local_only=False, repeats=1, opts=opts):
         """Times `steps` updates of prob_full sharded as feats_of_rank(rank); returns (seconds max over ranks, updater, shard).
         local_only: every rank updates with ITS shard alone (no exchange) — the compute side of the scaling model."""
         shard = prob_full if world == 1 else prob_full.subset(feats_of_rank)
@@ -233,6 +236,43 @@ def main(argv=None):
             t_ar = 2 * (world - 1) * 8e-3 + 2.0 * (world - 1) / world * gram_bytes / 40e9 * 1e3
             extras["predicted_ms"] = 1e3 * ldt / max(5, args.steps // 2) + t_ar
             extras["predicted_ms_model"] = "slowest rank's share as a stand-alone update (measured now) + ring all-reduce of the Gram matrix modelled as 2 (N - 1) x 8 us + bytes at 40 GB/s"
+        if world == 1 and not args.gate_always_factor:
+            # the same workload with every gate matrix formed and factored (gate_always_factor = 1): what the residual bound saves
+            fopts = capi.default_options(chi2_multipler=1.0, compress_route=route, gram_fp32=1 if args.gram_fp32 else 0, gate_always_factor=1)
+            gsteps = max(5, args.steps // 4)
+            keep_loops = list(timed_loops)
+            gdt, gup, _ = run(prob, mine, gsteps, 5, opts=fopts)
+            gup.close()
+            timed_loops[:] = keep_loops
+            extras["gate_always_factor_ms_per_step"] = 1e3 * gdt / gsteps
+        if world == 1 and not args.gate_always_factor and args.route == "gram":
+            # The same batch on a window as tight as a RUNNING filter's.  SURVEY 8(d)'s snapshot gives every clone an independent 0.57 deg /
+            # 5 cm of prior uncertainty (10 - 50 px of predicted-pixel uncertainty: no residual bound can decide such a gate); in the
+            # rpng_sim closed loop (tests/test_rpng_sim_loop.py) the window's relative uncertainty is a fraction of a pixel and 99.8 % of the
+            # accepted features pass by the bound.  Here: clone errors and the clone block of P scaled by 0.05 (0.03 deg / 2.5 mm).
+            s_c = 0.05
+            tprob = synth.make_problem(cfg, F=args.features, pose_noise=s_c)
+            sc = np.ones(tprob.N)
+            for cid in tprob.clone_cov_id:
+                sc[int(cid):int(cid) + 6] = s_c
+            tprob.P = np.ascontiguousarray(sc[:, None] * tprob.P * sc[None, :])
+            tsteps = max(5, args.steps // 4)
+            keep_loops = list(timed_loops)
+            tdt, tup, _ = run(tprob, None, tsteps, 5)
+            tup.reset_state()
+            tres = tup.update()
+            tup.close()
+            fopts = capi.default_options(chi2_multipler=1.0, compress_route=route, gram_fp32=1 if args.gram_fp32 else 0, gate_always_factor=1)
+            fdt, fup, _ = run(tprob, None, tsteps, 5, opts=fopts)
+            fup.close()
+            timed_loops[:] = keep_loops
+            extras["tight_window"] = {
+                "what": "the headline batch on a window with 0.05 x the clone uncertainty of SURVEY 8(d)'s snapshot (a running filter's relative "
+                        "uncertainty: the regime of the rpng_sim closed loop), where the gate's residual bound decides most features; NOT the headline",
+                "ms_per_step": 1e3 * tdt / tsteps, "ms_per_step_with_every_gate_factored": 1e3 * fdt / tsteps,
+                "features_used": int(tres["stats"]["n_used"]), "features_passed_by_the_bound": int(tres["stats"]["n_gate_bound"])}
+        if world > 1:
+            pass
         elif cfg != CFG_MULTI:  # the strong-scaling job of N > 1 on this one GPU: the reference point of the scaling curve
             sprob = synth.make_problem(CFG_MULTI)
             ksteps = max(5, args.steps // 5)
@@ -255,7 +295,8 @@ def main(argv=None):
                                        "model": "measured stand-alone update of rank 0's share (F / N features, this GPU) + modelled ring all-reduce of the "
                                                 f"{gram_bytes / 1e6:.2f} MB Gram matrix (2 (N - 1) steps x 8 us + bytes at 40 GB/s); not a measurement of N GPUs"}
     if rank == 0:
-        res = up.update()  # one synchronous update for the accept set (outside the timed region)
+        up.reset_state()   # (the timed loop left the posterior of its last update resident)
+        res = up.update()  # one synchronous update of the prior for the accept set (outside the timed region)
         up.reset_state()
         flops_system, flops_compress = gated_flops(shard, res["feat_status"], capi, synth)
         ms_c, ms_s = kt["ms_compress"], kt["ms_system"]
@@ -314,6 +355,13 @@ def main(argv=None):
                     "traffic": traffic.get("compression") if (traffic and gram) else None,
                 },
                 "update_ms_device": kt["ms_update"],
+                # The gate's residual bound (ovgpu_options::gate_always_factor = 0, the library's default): a feature with |r'|^2 / sigma^2
+                # under its chi2 threshold is accepted without its gate matrix (SYRK + Cholesky) -- the same accept set, dx and P'.
+                # `algorithmic_flops_per_launch` above is SURVEY 8(d)'s count for EVERY feature that reaches the gate, whether its gate
+                # matrix was formed or not: for those features the fraction is earned by not doing the work, not by the matrix pipes.
+                "gate": {"residual_bound": not args.gate_always_factor, "features_reaching_the_gate": int(((res["feat_status"] == capi.FEAT_USED) | (res["feat_status"] == capi.FEAT_CHI2_REJECTED)).sum()),
+                         "features_passed_by_the_bound": int(res["stats"].get("n_gate_bound", 0)),
+                         "ms_per_step_with_every_gate_factored": extras.get("gate_always_factor_ms_per_step")},
                 # the whole update (every kernel between the two barriers) against the same peak: SURVEY 8(d)'s algorithmic FLOPs of the
                 # per-feature stages + the compression (Householder-equivalent count) + the EKF term, over ms_per_step
                 "whole_update": {"algorithmic_flops": flops_system + flops_compress + ekf_flops(prob),

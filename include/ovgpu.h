@@ -128,7 +128,14 @@ typedef struct {
   int32_t tsqr_no_pipeline;  /* 1: merge tree level by level                 */
   int32_t tsqr_overlap;      /* 0 auto, 1 merge tree next to the leaves,     */
                              /* 2 never                                      */
-  int32_t tsqr_leaf_blocked; /* reserved (round 3's experimental leaf was retired): ignored   */
+  int32_t gate_always_factor; /* MSCKF gate (round 4; the slot of round 3's retired tsqr_leaf_blocked).  0 (default): a feature whose  */
+                             /* RESIDUAL BOUND |r'|^2 / sigma^2 (r' = the nullspace-projected residual) is under its threshold  */
+                             /* is accepted without forming or factoring its gate matrix: S = H P H^T + sigma^2 I >= sigma^2 I,  */
+                             /* hence chi2 = r'^T S^-1 r' <= the bound, and the reference's test (UpdaterMSCKF.cpp:216-225)      */
+                             /* cannot reject it.  Accept / reject sets, dx and P' are those of the full gate; the chi2 output   */
+                             /* of such a feature is the BOUND (>= the reference's statistic, <= chi2_thresh);                   */
+                             /* ovgpu_update_stats::n_gate_bound counts them.  1: every gate matrix is formed and factored and   */
+                             /* every chi2 output is the reference's statistic                                                 */
   int32_t no_timing;         /* 1: no HIP events around the stages           */
   int32_t no_fast_feature_kernel; /* 1: always the general per-feature       */
                              /* kernel (k_system) instead of the MSCKF fast  */
@@ -220,7 +227,7 @@ typedef struct {
   int32_t D;           /* columns of the stacked Jacobian (canonical order) */
   int32_t n_rows_comp; /* rows after measurement compression                */
   int32_t status;      /* ovgpu_status of the EKF step                      */
-  int32_t _pad0;
+  int32_t n_gate_bound; /* features the gate's residual bound accepted (ovgpu_options::gate_always_factor = 0; was _pad0) */
   /* device-side stage times in ms (same five stages the reference prints,
    * UpdaterMSCKF.cpp:289-294), 0 when timing is disabled                   */
   float ms_triangulate;

@@ -41,7 +41,7 @@ class Options(C.Structure):
         ("do_fej", C.c_int32), ("do_calib_camera_pose", C.c_int32), ("do_calib_camera_intrinsics", C.c_int32),
         ("feat_rep_msckf", C.c_int32),
         ("compress_route", C.c_int32), ("gram_no_whiten", C.c_int32), ("no_prior_overlap", C.c_int32), ("tsqr_workers", C.c_int32),
-        ("tsqr_no_pipeline", C.c_int32), ("tsqr_overlap", C.c_int32), ("tsqr_leaf_blocked", C.c_int32), ("no_timing", C.c_int32),
+        ("tsqr_no_pipeline", C.c_int32), ("tsqr_overlap", C.c_int32), ("gate_always_factor", C.c_int32), ("no_timing", C.c_int32),
         ("no_fast_feature_kernel", C.c_int32), ("no_single_launch_cholesky", C.c_int32), ("prior_pivot_tol", C.c_double),
         ("feature_kernel_shape", C.c_int32), ("gram_fp32", C.c_int32),
     ]
@@ -91,7 +91,7 @@ class UpdateStats(C.Structure):
     """ovgpu_update_stats"""
     _fields_ = [
         ("n_used", C.c_int32), ("n_rows", C.c_int32), ("D", C.c_int32), ("n_rows_comp", C.c_int32),
-        ("status", C.c_int32), ("_pad0", C.c_int32),
+        ("status", C.c_int32), ("n_gate_bound", C.c_int32),
         ("ms_triangulate", C.c_float), ("ms_system", C.c_float), ("ms_compress", C.c_float), ("ms_update", C.c_float),
         ("ms_total", C.c_float), ("_pad1", C.c_float),
     ]

@@ -373,7 +373,7 @@ __global__ void __launch_bounds__(64 * NW, OCC)
     for (int e = tid; e < 3 * n; e += NTH) Vl[e] = fV[e];
     const int32_t *finst = instG + (size_t)f * nt_max * FY_ISTR; // per tile row: count, last non-zero column, instances (k_feat_vt)
     if (tid < NT) rowlim[tid] = finst[(size_t)tid * FY_ISTR + 1];
-    double r_a = 0.0;
+    double r_a = 0.0, bound = 0.0;
     {
       double v0 = 0.0, v1 = 0.0, v2 = 0.0;
       if (tid < n) {
@@ -388,9 +388,29 @@ __global__ void __launch_bounds__(64 * NW, OCC)
 #pragma unroll
       for (int w = 0; w < NW; w++) w0 += zres[3 * w], w1 += zres[3 * w + 1], w2 += zres[3 * w + 2];
       const double z0 = T00 * w0, z1 = T01 * w0 + T11 * w1, z2 = T02 * w0 + T12 * w1 + T22 * w2;
-      if (tid >= 3 && tid < n) out.put(tid - 3, D, r_a - (v0 * z0 + v1 * z1 + v2 * z2)); // the residual column is not whitened
+      double rp = 0.0;
+      if (tid >= 3 && tid < n) {
+        rp = r_a - (v0 * z0 + v1 * z1 + v2 * z2);
+        out.put(tid - 3, D, rp); // the residual column is not whitened
+      }
       out.pad(tid, NTH, n_out, LD);
+      // The residual bound of the gate (round 4).  S = Y Y^T + s^2 I >= s^2 I, so chi2 = r'^T S^-1 r' <= |r'|^2 / s^2 with r' the
+      // projected residual just written: a feature whose BOUND is under the threshold passes the reference's test
+      // (UpdaterMSCKF.cpp:216-225) whatever its gate matrix holds, and neither the SYRK nor the Cholesky below is needed to know it.
+      if (!p.opt.gate_always_factor) {
+        const double sq = wave_sum(rp * rp);
+        if (lane == 0) zres[24 + wv] = sq;
+        lds_barrier();
+        double tot = 0.0;
+#pragma unroll
+        for (int w = 0; w < NW; w++) tot += zres[24 + w];
+        bound = tot / sig2;
+      }
     }
+    const double thr = p.opt.chi2_multipler * p.chi2_table[min(n - 3, p.chi2_table_len - 1)]; // UpdaterMSCKF.cpp:216-222
+    // (1 - 1e-9): the bound is a float64 sum of ~100 squares and the reference's own chi2 carries ~1e-12 of rounding: a feature
+    // this close to the threshold takes the full gate
+    const bool skip_gate = __builtin_amdgcn_readfirstlane((int)(!p.opt.gate_always_factor && bound <= thr * (1.0 - 1e-9))) != 0;
     FEAT_T(0)
 
     // ------------------------------------------------------------------ the column blocks
@@ -494,7 +514,7 @@ __global__ void __launch_bounds__(64 * NW, OCC)
       // ---- SYRK: S0 tiles += Y_i Y_j^T over the slabs of 8 columns both tile rows reach
 #pragma unroll
       for (int s = 0; s < TPW; s++) {
-        if (tij[s] >= 0 && TJ(s) < NT && !(p.skip & 4)) {
+        if (tij[s] >= 0 && TJ(s) < NT && !skip_gate && !(p.skip & 4)) {
           const int lim = min(min(rowlim[TI(s)], rowlim[TJ(s)]), D - 1);
           if (lim >= c_lo) {
             const int nsl = min(FY_CB / 8, (lim - c_lo) / 8 + 1);
@@ -515,7 +535,7 @@ __global__ void __launch_bounds__(64 * NW, OCC)
     // ------------------------------------------------------------------ S0 = Y Y^T + s^2 I (identity on the padding), right-hand sides [r | H_f]
 #pragma unroll
     for (int s = 0; s < TPW; s++) {
-      if (tij[s] < 0) continue;
+      if (tij[s] < 0 || skip_gate) continue;
       if (TJ(s) == NT) {
 #pragma unroll
         for (int q = 0; q < 4; q++) {
@@ -537,9 +557,10 @@ __global__ void __launch_bounds__(64 * NW, OCC)
     }
     FEAT_T(4)
     if (tid == 0) sched[2] = atomicAdd(p.work_counter, 1); // the next feature's slot: the atomic's round trip hides behind the Cholesky
-    const double chi2 = (p.skip & 8) ? 0.0 : gate_cholesky_chi2<NW, TPW>(acc, tij, NT, n, panel, st0, st1, rhs, lane, wv);
+    // a feature passed by the bound reports the BOUND as its statistic (>= the reference's chi2, <= the threshold; include/ovgpu.h)
+    const double chi2 = skip_gate ? bound : ((p.skip & 8) ? 0.0 : gate_cholesky_chi2<NW, TPW>(acc, tij, NT, n, panel, st0, st1, rhs, lane, wv));
     if (wv == 0 && lane == 0) {
-      const double thr = p.opt.chi2_multipler * p.chi2_table[min(n - 3, p.chi2_table_len - 1)]; // UpdaterMSCKF.cpp:216-222
+      if (skip_gate && p.rows_used) atomicAdd(p.rows_used + 1, 1);
       p.chi2[f] = chi2;
       p.chi2_thresh[f] = thr;
       const bool reject = chi2 > thr; // :225

@@ -110,6 +110,7 @@ __global__ void __launch_bounds__(64 * NW, 1)
                  T12 = tqG[(size_t)8 * f + 4], T22 = tqG[(size_t)8 * f + 5];
 
     // ------------------------------------------------------------------ prologue (k_feat_y's)
+    double bound = 0.0;
     for (int e = tid; e < 3 * n; e += NTH) Vl[e] = fV[e];
     const int32_t *finst = instG + (size_t)f * nt_max * FY_ISTR;
     if (tid < NT) rowlim[tid] = finst[(size_t)tid * FY_ISTR + 1];
@@ -127,9 +128,24 @@ __global__ void __launch_bounds__(64 * NW, 1)
 #pragma unroll
       for (int w = 0; w < NW; w++) w0 += zres[3 * w], w1 += zres[3 * w + 1], w2 += zres[3 * w + 2];
       const double z0 = T00 * w0, z1 = T01 * w0 + T11 * w1, z2 = T02 * w0 + T12 * w1 + T22 * w2;
-      if (tid >= 3 && tid < n) out.put(tid - 3, D, r_a - (v0 * z0 + v1 * z1 + v2 * z2));
+      double rp = 0.0;
+      if (tid >= 3 && tid < n) {
+        rp = r_a - (v0 * z0 + v1 * z1 + v2 * z2);
+        out.put(tid - 3, D, rp);
+      }
       out.pad(tid, NTH, n_out, LD);
+      if (!p.opt.gate_always_factor) { // the residual bound of the gate (k_featy.h): chi2 <= |r'|^2 / s^2
+        const double sq = wave_sum(rp * rp);
+        if (lane == 0) zres[24 + wv] = sq;
+        lds_barrier();
+        double tot = 0.0;
+#pragma unroll
+        for (int w = 0; w < NW; w++) tot += zres[24 + w];
+        bound = tot / sig2;
+      }
     }
+    const double thr = p.opt.chi2_multipler * p.chi2_table[min(n - 3, p.chi2_table_len - 1)]; // UpdaterMSCKF.cpp:216-222
+    const bool skip_gate = __builtin_amdgcn_readfirstlane((int)(!p.opt.gate_always_factor && bound <= thr * (1.0 - 1e-9))) != 0;
     if (tid == 0) sched[2] = atomicAdd(p.work_counter, 1); // every wavefront has read the current slot (barrier above)
 
     // ------------------------------------------------------------------ the passes over block rows [a, b)
@@ -137,6 +153,7 @@ __global__ void __launch_bounds__(64 * NW, 1)
     while (a < NT) {
       int b = a, cnt = 0;
       while (b < NT && cnt + (NT + 1 - b) <= NW * TPW) cnt += NT + 1 - b, b++;
+      if (skip_gate) b = NT, cnt = 0; // passed by the bound: ONE pass that sweeps, projects and stacks, no gate tiles
       // this wavefront's tiles: t = s NW + wv over the rows a .. b-1, each from its diagonal tile to the right-hand-side column NT
       int tij[TPW]; // (j << 8) | i, or -1
       d4 acc[TPW];
@@ -330,7 +347,7 @@ __global__ void __launch_bounds__(64 * NW, 1)
       }
 
       // ---------------------------------------------------------------- (C) tile rows a .. b-1
-      for (int k = a; k < b; k++) {
+      for (int k = a; k < b && !skip_gate; k++) {
         {
           const int tkk = (k - a) * (NT + 1) - (k * (k - 1) - a * (a - 1)) / 2; // tiles of the rows a .. k-1 come first
           if (tkk % NW == wv) {
@@ -396,7 +413,13 @@ __global__ void __launch_bounds__(64 * NW, 1)
     }
 
     // ------------------------------------------------------------------ chi2 = |y_r|^2 - g^T G^-1 g,  y_r = U^-T r, Y_f = U^-T H_f
-    if (wv == 0) {
+    if (skip_gate) {
+      if (wv == 0 && lane == 0) { // the BOUND is reported as the statistic (include/ovgpu.h)
+        p.chi2[f] = bound, p.chi2_thresh[f] = thr;
+        sched[1] = 0;
+        if (p.rows_used) atomicAdd(p.rows_used, n_out), atomicAdd(p.rows_used + 1, 1);
+      }
+    } else if (wv == 0) {
       double sa = 0, G00 = 0, G01 = 0, G02 = 0, G11 = 0, G12 = 0, G22 = 0, g0 = 0, g1 = 0, g2 = 0;
       for (int j = lane; j < n; j += 64) {
         const double yr = rhs[4 * j], y0 = rhs[4 * j + 1], y1 = rhs[4 * j + 2], y2 = rhs[4 * j + 3];
@@ -413,7 +436,6 @@ __global__ void __launch_bounds__(64 * NW, 1)
       const V3 x = colpiv_qr_solve3(Gm, gv);
       const double chi2 = sa - dot(gv, x);
       if (lane == 0) {
-        const double thr = p.opt.chi2_multipler * p.chi2_table[min(n - 3, p.chi2_table_len - 1)]; // UpdaterMSCKF.cpp:216-222
         p.chi2[f] = chi2;
         p.chi2_thresh[f] = thr;
         const bool reject = chi2 > thr; // :225

@@ -13,6 +13,7 @@ struct DevOptions {
   double min_dist, max_dist, max_baseline, max_cond_number;
   int triangulate_1d, refine_features, max_runs;
   int do_fej, do_calib_pose, do_calib_intr, feat_rep;
+  int gate_always_factor; // options.gate_always_factor: no residual bound in the MSCKF gate (k_featy.h)
 };
 
 // packed (camera, clone) code of one measurement: cam << 10 | clone
@@ -86,7 +87,7 @@ struct SysParams {
   int init;
   double *init_out;
   int32_t *init_flag; // [0] = 1 when the feature passed the gate
-  int32_t *rows_used; // optional counter: rows of the stack that belong to accepted features
+  int32_t *rows_used; // optional counters: [0] rows of the stack that belong to accepted features, [1] features the gate's residual bound passed
   const double *Lw;   // [D x D] row-major, lower triangular with explicit zeros above the diagonal: L = U1^T, P_DD = L L^T (k_ekf.h).
                       // Non-null: the rows leave the kernel whitened by the prior, Q^T [H_x L | res] (the Gram route)
   int32_t *work_counter; // k_feat: next feature slot to hand out (zeroed before the launch)

@@ -32,7 +32,8 @@ void UpdaterMSCKF::update(std::shared_ptr<State> state, std::vector<std::shared_
   const ovgpu_shim::CloneIndex clones(snap.fs.clone_times);
 
   // ---- 1. clean + flatten the tracks (UpdaterMSCKF.cpp:71-93)
-  ovgpu_shim::FlatFeatures ff;
+  static thread_local ovgpu_shim::FlatFeatures ff; // reused from update to update: a fresh 3.5 MB of buffers per call costs more in page faults than the flattening itself
+  ff.clear();
   for (auto it = feature_vec.begin(); it != feature_vec.end();) {
     if (ovgpu_shim::flatten_track(**it, snap, clones, ff) < 2) {
       (*it)->to_delete = true;

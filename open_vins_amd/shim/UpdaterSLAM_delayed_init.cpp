@@ -33,7 +33,8 @@ void UpdaterSLAM::delayed_init(std::shared_ptr<State> state, std::vector<std::sh
     if (kv.second->_feat_representation == rep) old.add(kv.second, snap, clones); // the others are corrected below through dx_seq
 
   // ---- 1. clean the tracks (:75-96) and flatten them
-  ovgpu_shim::FlatFeatures ff;
+  static thread_local ovgpu_shim::FlatFeatures ff; // reused from update to update: a fresh 3.5 MB of buffers per call costs more in page faults than the flattening itself
+  ff.clear();
   std::vector<double> f_sigma, f_mult; // ArUco corners use _options_aruco (:226-232)
   bool any_aruco = false;
   for (auto it = feature_vec.begin(); it != feature_vec.end();) {

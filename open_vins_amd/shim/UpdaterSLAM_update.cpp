@@ -21,7 +21,8 @@ void update_pass(UpdaterOptions &opt_slam, UpdaterOptions &opt_aruco, std::share
                  LandmarkRepresentation::Representation rep, std::vector<std::shared_ptr<Feature>> &later) {
   const ovgpu_shim::StateSnapshot snap(state);
   const ovgpu_shim::CloneIndex clones(snap.fs.clone_times);
-  ovgpu_shim::FlatFeatures ff;
+  static thread_local ovgpu_shim::FlatFeatures ff; // reused from update to update: a fresh 3.5 MB of buffers per call costs more in page faults than the flattening itself
+  ff.clear();
   ovgpu_shim::FlatLandmarks fl;
   std::vector<int32_t> lm_index;
   std::vector<double> f_sigma, f_mult; // per-feature options: ArUco corners use _options_aruco (:392-394, :408-409)

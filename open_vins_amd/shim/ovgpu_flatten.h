@@ -9,8 +9,13 @@
 //   ov_core::Feature                (ov_core/src/feat/Feature.h:39-98)     -> FlatFeatures
 //   ov_msckf::State (subset)        (ov_msckf/src/state/State.h:137-192)   -> FlatState
 #pragma once
+#include <algorithm>
+#include <climits>
 #include <cstddef>
 #include <cstdint>
+#include <cstdlib>
+#include <initializer_list>
+#include <new>
 #include <stdexcept>
 #include <string>
 #include <unordered_map>
@@ -25,22 +30,71 @@ namespace ovgpu_shim {
 class CloneIndex {
 public:
   explicit CloneIndex(const std::vector<double> &clone_times) {
-    for (size_t i = 0; i < clone_times.size(); i++) index_[clone_times[i]] = (int32_t)i;
+    for (size_t i = 0; i < clone_times.size(); i++) sorted_.push_back({clone_times[i], (int32_t)i});
+    std::sort(sorted_.begin(), sorted_.end());
   }
   int32_t find(double t) const {
-    auto it = index_.find(t);
-    return it == index_.end() ? -1 : it->second;
+    const auto it = std::lower_bound(sorted_.begin(), sorted_.end(), std::pair<double, int32_t>(t, INT32_MIN));
+    return (it != sorted_.end() && it->first == t) ? it->second : -1;
+  }
+  // A track's timestamps ascend (observations are appended frame by frame), and so do the clone times: walking both lists once
+  // replaces a look-up per observation.  `cursor` survives from one call to the next of the same list; a timestamp that steps back
+  // restarts it by binary search, so the result never depends on the ordering assumption.
+  int32_t find_next(double t, size_t &cursor) const {
+    const size_t n = sorted_.size();
+    if (cursor > 0 && (cursor > n || sorted_[cursor - 1].first >= t)) // (stepped back, or equal to the previous match: search again)
+      cursor = (size_t)(std::lower_bound(sorted_.begin(), sorted_.end(), std::pair<double, int32_t>(t, INT32_MIN)) - sorted_.begin());
+    while (cursor < n && sorted_[cursor].first < t) cursor++;
+    return (cursor < n && sorted_[cursor].first == t) ? sorted_[cursor].second : -1;
   }
 
 private:
-  std::unordered_map<double, int32_t> index_;
+  std::vector<std::pair<double, int32_t>> sorted_; // (clone time, clone index), ascending
+};
+
+// Growable array of plain data that does NOT value-initialise what it grows by (std::vector::resize zero-fills; at 100 k
+// observations per update that is a second pass over 3.5 MB).
+template <class T> class PodBuf {
+public:
+  PodBuf() = default;
+  explicit PodBuf(std::initializer_list<T> init) {
+    for (const T &v : init) push_back(v);
+  }
+  ~PodBuf() { std::free(p_); }
+  PodBuf(const PodBuf &) = delete;
+  PodBuf &operator=(const PodBuf &) = delete;
+  PodBuf(PodBuf &&o) noexcept : p_(o.p_), n_(o.n_), cap_(o.cap_) { o.p_ = nullptr, o.n_ = o.cap_ = 0; }
+  PodBuf &operator=(PodBuf &&o) noexcept {
+    if (this != &o) std::free(p_), p_ = o.p_, n_ = o.n_, cap_ = o.cap_, o.p_ = nullptr, o.n_ = o.cap_ = 0;
+    return *this;
+  }
+  void reserve(size_t c) {
+    if (c <= cap_) return;
+    T *q = static_cast<T *>(std::realloc(p_, c * sizeof(T)));
+    if (!q) throw std::bad_alloc();
+    p_ = q, cap_ = c;
+  }
+  T *room(size_t k) { // space for k more elements behind the current end (uninitialised); commit() what was written
+    if (n_ + k > cap_) reserve(std::max(2 * cap_, n_ + k));
+    return p_ + n_;
+  }
+  void commit(size_t k) { n_ += k; }
+  void clear() { n_ = 0; } // keeps the allocation: a buffer reused from update to update touches no fresh pages
+  void push_back(const T &v) { *room(1) = v, n_++; }
+  size_t size() const { return n_; }
+  const T *data() const { return p_; }
+  const T &operator[](size_t i) const { return p_[i]; }
+
+private:
+  T *p_ = nullptr;
+  size_t n_ = 0, cap_ = 0;
 };
 
 struct FlatFeatures {
-  std::vector<int32_t> meas_offsets{0};
-  std::vector<float> uv, uvn;
-  std::vector<int32_t> clone_idx, cam_idx;
-  std::vector<double> meas_time; // kept on the host: Feature::anchor_clone_timestamp is read back from it
+  PodBuf<int32_t> meas_offsets{0};
+  PodBuf<float> uv, uvn;
+  PodBuf<int32_t> clone_idx, cam_idx;
+  PodBuf<double> meas_time; // kept on the host: Feature::anchor_clone_timestamp is read back from it
 
   int32_t F() const { return (int32_t)meas_offsets.size() - 1; }
   int32_t M() const { return (int32_t)clone_idx.size(); }
@@ -51,21 +105,32 @@ struct FlatFeatures {
   // Feature::timestamps — the anchor rule of FeatureInitializer.cpp:36-46 is evaluated on that order.
   template <class GetUV, class GetUVN>
   int add_camera(int cam, const std::vector<double> &times, GetUV get_uv, GetUVN get_uvn, const CloneIndex &clones) {
-    int kept = 0;
-    for (size_t i = 0; i < times.size(); i++) {
-      const int32_t ci = clones.find(times[i]);
+    const size_t n = times.size();
+    float *puv = uv.room(2 * n), *pun = uvn.room(2 * n);
+    int32_t *pc = clone_idx.room(n), *pk = cam_idx.room(n);
+    double *pt = meas_time.room(n);
+    size_t kept = 0, cursor = 0;
+    for (size_t i = 0; i < n; i++) {
+      const int32_t ci = clones.find_next(times[i], cursor);
       if (ci < 0) continue;
-      float a, b;
-      get_uv(i, a, b);
-      uv.push_back(a), uv.push_back(b);
-      get_uvn(i, a, b);
-      uvn.push_back(a), uvn.push_back(b);
-      clone_idx.push_back(ci), cam_idx.push_back(cam), meas_time.push_back(times[i]);
+      get_uv(i, puv[2 * kept], puv[2 * kept + 1]);
+      get_uvn(i, pun[2 * kept], pun[2 * kept + 1]);
+      pc[kept] = ci, pk[kept] = cam, pt[kept] = times[i];
       kept++;
     }
-    return kept;
+    uv.commit(2 * kept), uvn.commit(2 * kept), clone_idx.commit(kept), cam_idx.commit(kept), meas_time.commit(kept);
+    return (int)kept;
+  }
+  // capacity for F features and M observations up front (the buffers double on demand without it)
+  void reserve(size_t F, size_t M) {
+    meas_offsets.reserve(F + 1);
+    uv.reserve(2 * M), uvn.reserve(2 * M), clone_idx.reserve(M), cam_idx.reserve(M), meas_time.reserve(M);
   }
   void end_feature() { meas_offsets.push_back(M()); }
+  void clear() { // start the next batch in the same allocations
+    meas_offsets.clear(), meas_offsets.push_back(0);
+    uv.clear(), uvn.clear(), clone_idx.clear(), cam_idx.clear(), meas_time.clear();
+  }
 
   ovgpu_features_view view() const {
     ovgpu_features_view v;

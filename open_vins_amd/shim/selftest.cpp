@@ -114,7 +114,28 @@ static double median(std::vector<double> v) {
   return v[v.size() / 2];
 }
 
-static int time_dropin(int F, int reps) {
+// what shim/ovgpu_shim_common.h: append_track does, on the stand-in containers
+static void flatten_tracks(const std::vector<RefShapedFeature> &feats, const CloneIndex &clones, FlatFeatures &ff) {
+  size_t n = 0;
+  for (const RefShapedFeature &t : feats)
+    for (const auto &pair : t.timestamps) n += pair.second.size();
+  ff.reserve(feats.size(), n);
+  for (const RefShapedFeature &t : feats) {
+    for (const auto &pair : t.timestamps) {
+      const auto &uv = t.uvs.at(pair.first), &un = t.uvs_norm.at(pair.first);
+      const size_t cnt = uv.size();
+      ff.add_camera((int)pair.first, pair.second,
+                    [&](size_t i, float &x, float &y) {
+                      if (i + 8 < cnt) __builtin_prefetch(uv[i + 8].d.get()), __builtin_prefetch(un[i + 8].d.get());
+                      x = uv[i].d[0], y = uv[i].d[1];
+                    },
+                    [&](size_t i, float &x, float &y) { x = un[i].d[0], y = un[i].d[1]; }, clones);
+    }
+    ff.end_feature();
+  }
+}
+
+static int time_dropin(int F, int reps, bool gpu = true) {
   FlatState fs;
   const double q[4] = {0, 0, 0, 1}, zero[3] = {0, 0, 0}, intr[8] = {458, 457, 367, 248, 0, 0, 0, 0};
   const double p_cam1[3] = {-0.11, 0, 0}; // p_IinC of the second camera: 11 cm baseline
@@ -155,11 +176,26 @@ static int time_dropin(int F, int reps) {
       }
     }
   }
+  const CloneIndex clones(fs.clone_times);
+  if (!gpu) { // `--time-host`: the flattening alone (no device needed)
+    std::vector<double> t_flat;
+    int M = 0;
+    for (int it = 0; it < reps + 2; it++) {
+      const double t0 = now_ms();
+      static FlatFeatures ff; // persistent, as in the shims
+      ff.clear();
+      flatten_tracks(feats, clones, ff);
+      M = ff.M();
+      if (it >= 2) t_flat.push_back(now_ms() - t0);
+    }
+    std::printf("{\"features\": %d, \"measurements\": %d, \"flatten_ms\": %.4f, \"ns_per_observation\": %.2f}\n", F, M, median(t_flat),
+                1e6 * median(t_flat) / (double)(n_obs + (size_t)F * K));
+    return 0;
+  }
   ovgpu_options o;
   ovgpu_default_options(&o);
   o.chi2_multipler = 1.0, o.sigma_pix = 1.0;
   Context ctx(o);
-  const CloneIndex clones(fs.clone_times);
   const int Dmax = 6 * C + 14 * K;
   std::vector<int32_t> status(F), anchor(F), col_cov(Dmax);
   std::vector<double> pA(3 * (size_t)F), pG(3 * (size_t)F), H((size_t)Dmax * Dmax), r(Dmax), dx(fs.N), P1((size_t)fs.N * fs.N);
@@ -167,15 +203,9 @@ static int time_dropin(int F, int reps) {
   int used = 0, rows = 0, M = 0;
   for (int it = 0; it < reps + 2; it++) {
     const double t0 = now_ms();
-    FlatFeatures ff;
-    for (const RefShapedFeature &t : feats) {
-      for (const auto &pair : t.timestamps) {
-        const auto &uv = t.uvs.at(pair.first), &un = t.uvs_norm.at(pair.first);
-        ff.add_camera((int)pair.first, pair.second, [&](size_t i, float &x, float &y) { x = uv[i].d[0], y = uv[i].d[1]; },
-                      [&](size_t i, float &x, float &y) { x = un[i].d[0], y = un[i].d[1]; }, clones);
-      }
-      ff.end_feature();
-    }
+    static FlatFeatures ff; // persistent, as in the shims
+    ff.clear();
+    flatten_tracks(feats, clones, ff);
     const ovgpu_state_view sv = fs.view();
     const ovgpu_features_view fv = ff.view();
     M = fv.M;
@@ -205,9 +235,9 @@ static int time_dropin(int F, int reps) {
 }
 
 int main(int argc, char **argv) {
-  if (argc > 1 && std::strcmp(argv[1], "--time") == 0) {
+  if (argc > 1 && (std::strcmp(argv[1], "--time") == 0 || std::strcmp(argv[1], "--time-host") == 0)) {
     try {
-      return time_dropin(argc > 2 ? std::atoi(argv[2]) : 2000, argc > 3 ? std::atoi(argv[3]) : 9);
+      return time_dropin(argc > 2 ? std::atoi(argv[2]) : 2000, argc > 3 ? std::atoi(argv[3]) : 9, std::strcmp(argv[1], "--time") == 0);
     } catch (const std::exception &e) {
       std::printf("shim timing FAILED: %s\n", e.what());
       return 3;

@@ -81,7 +81,7 @@ def test_default_options_are_the_reference_defaults():
     assert (o.init_lamda, o.max_lamda, o.min_dx, o.min_dcost, o.lam_mult) == (1e-3, 1e10, 1e-6, 1e-6, 10.0)
     assert (o.min_dist, o.max_dist, o.max_baseline, o.max_cond_number) == (0.10, 60.0, 40.0, 10000.0)
     # library switches: zero = default route (whitened Gram matrix, prior block factored on the side stream, timing on)
-    assert (o.compress_route, o.gram_no_whiten, o.no_prior_overlap, o.tsqr_workers, o.tsqr_no_pipeline, o.tsqr_overlap, o.tsqr_leaf_blocked, o.no_timing) == (0,) * 8
+    assert (o.compress_route, o.gram_no_whiten, o.no_prior_overlap, o.tsqr_workers, o.tsqr_no_pipeline, o.tsqr_overlap, o.gate_always_factor, o.no_timing) == (0,) * 8
 
 
 def test_chi2_quantile_host_helper():

@@ -15,7 +15,7 @@ import numpy as np
 import pytest
 
 from open_vins_amd import capi, synth
-from parity_util import oracle_with_the_same_gate_verdicts
+from parity_util import assert_chi2, oracle_with_the_same_gate_verdicts
 
 pytestmark = pytest.mark.gpu
 
@@ -62,7 +62,7 @@ def _check_given(Updater, oracle, prob, opts, tol_dx=TOL_DX, tol_p=TOL_P, requir
         assert len(diff) == 0 and not out["dx"].any() and np.array_equal(out["P"], prob.P)
         up.close()
         return out, ref
-    np.testing.assert_allclose(out["chi2"][gate], ref["chi2"][gate], rtol=TOL_CHI2)
+    assert_chi2(out, ref, TOL_CHI2, strict=bool(opts.gate_always_factor))
     np.testing.assert_allclose(out["chi2_thresh"][gate], ref["chi2_thresh"][gate], rtol=1e-12)
     if len(diff) == 0:
         assert out["stats"]["n_used"] == ref["stats"]["n_used"]
@@ -74,6 +74,20 @@ def _check_given(Updater, oracle, prob, opts, tol_dx=TOL_DX, tol_p=TOL_P, requir
         assert np.abs(out["intrinsics"] - ref["intrinsics"]).max() < 1e-8
         assert np.array_equal(out["P"], out["P"].T)
     up.close()
+    if not opts.gate_always_factor:
+        # ... and once more with every gate matrix formed and factored: every chi2 is then the reference's statistic, and the
+        # update is the one the residual bound's shortcut gave (same accept sets; the stack differs by nothing)
+        full = capi.default_options(**{k: getattr(opts, k) for k, _ in opts._fields_ if not k.startswith("_")})
+        full.gate_always_factor = 1
+        up = Updater(full)
+        up.set_problem(prob)
+        up.set_triangulation(tri["p_FinG"], tri["p_FinA"], tri["anchor_meas"], tri["status"])
+        out1 = up.update()
+        up.close()
+        assert_chi2(out1, ref, TOL_CHI2, strict=True)
+        # (features that take the full gate run the same code in both modes; a bound only ever accepts 1e-9 under the threshold)
+        assert np.array_equal(out1["feat_status"], out["feat_status"])
+        assert _rel(out1["dx"], out["dx"]) < 1e-12 and _rel(out1["P"], out["P"]) < 1e-12
     return out, ref
 
 
@@ -174,7 +188,7 @@ def test_block_row_gate_equals_the_one_pass_gate(Updater, kw):
     whatever the pass structure, so chi2 is BIT-identical; the stacked rows differ in the summation order of V^T Y only."""
     kw = dict(kw)
     prob = synth.make_problem(kw.pop("cfg", 2), **kw)
-    opts = capi.default_options(chi2_multipler=1.0)
+    opts = capi.default_options(chi2_multipler=1.0, gate_always_factor=1)  # the test is about the gate's pass structure
     outs = []
     for big in (0, 1, 2):
         up = Updater(opts)

@@ -190,6 +190,7 @@ def test_gpu_against_the_known_answer(name, route):
     from open_vins_amd.updater import UpdaterMSCKF
     doc, prob, opts = load_case(name)
     opts.compress_route = capi.COMPRESS_TSQR if route == "tsqr" else capi.COMPRESS_GRAM
+    opts.gate_always_factor = 1  # every chi2 is the reference's statistic (the default's residual bound: the leg at the end)
     ans = doc["answer"]
     up = UpdaterMSCKF(opts)
     up.set_problem(prob)
@@ -213,3 +214,18 @@ def test_gpu_against_the_known_answer(name, route):
     assert list(comp["col_cov_id"]) == ans["col_cov_id"]
     assert _rel(Hc.T @ Hc, G) < 1e-9 and _rel(Hc.T @ rc, g) < 1e-9
     up.close()
+    # the library's default: features whose residual bound is under the threshold skip their gate matrix — same verdicts, same
+    # update, and a reported statistic between the known answer's chi2 and the threshold
+    opts.gate_always_factor = 0
+    up = UpdaterMSCKF(opts)
+    up.set_problem(prob)
+    out0 = up.update()
+    up.close()
+    assert np.array_equal(out0["feat_status"], out["feat_status"])
+    assert _rel(out0["dx"], out["dx"]) < 1e-12 and _rel(out0["P"], out["P"]) < 1e-12
+    n_bound = 0
+    for f, af in enumerate(ans["features"]):
+        if "chi2" in af and out0["chi2"][f] != out["chi2"][f]:
+            n_bound += 1
+            assert float(af["chi2"]) * (1 - 1e-9) <= out0["chi2"][f] <= out0["chi2_thresh"][f] and out0["feat_status"][f] == capi.FEAT_USED
+    assert n_bound <= out0["stats"]["n_gate_bound"]

@@ -563,7 +563,11 @@ def test_anchor_change_keeps_the_landmark_where_it_is(rep):
 
     old_clone = int(prob.lm_anchor_clone[l])
     np.testing.assert_allclose(to_global(o["value"], new_clone, prob.clone_q_p), to_global(prob.lm_value[l], old_clone, prob.clone_q_p), rtol=0, atol=1e-11)
-    np.testing.assert_allclose(to_global(o["fej"], new_clone, prob.clone_q_p_fej), to_global(prob.lm_fej[l], old_clone, prob.clone_q_p_fej), rtol=0, atol=1e-11)
+    # the first estimate: carried through the FEJ poses — except that Landmark::get_xyz(true) reads the CURRENT value for the MSCKF
+    # inverse depth (Landmark.cpp:47-59 ignores its flag there; found with oracle/_ref in round 4), so that representation's new
+    # first estimate is its current value seen through the FEJ poses
+    src_fej = prob.lm_value[l] if rep == capi.REP_ANCHORED_MSCKF_INVERSE_DEPTH else prob.lm_fej[l]
+    np.testing.assert_allclose(to_global(o["fej"], new_clone, prob.clone_q_p_fej), to_global(src_fej, old_clone, prob.clone_q_p_fej), rtol=0, atol=1e-11)
     idx = int(prob.lm_cov_id[l]) + np.arange(3)
     rest = np.setdiff1d(np.arange(prob.N), idx)
     np.testing.assert_array_equal(o["P"][np.ix_(rest, rest)], prob.P[np.ix_(rest, rest)])
