@@ -250,12 +250,7 @@ def main(argv=None):
             # 5 cm of prior uncertainty (10 - 50 px of predicted-pixel uncertainty: no residual bound can decide such a gate); in the
             # rpng_sim closed loop (tests/test_rpng_sim_loop.py) the window's relative uncertainty is a fraction of a pixel and 99.8 % of the
             # accepted features pass by the bound.  Here: clone errors and the clone block of P scaled by 0.05 (0.03 deg / 2.5 mm).
-            s_c = 0.05
-            tprob = synth.make_problem(cfg, F=args.features, pose_noise=s_c)
-            sc = np.ones(tprob.N)
-            for cid in tprob.clone_cov_id:
-                sc[int(cid):int(cid) + 6] = s_c
-            tprob.P = np.ascontiguousarray(sc[:, None] * tprob.P * sc[None, :])
+            tprob = synth.tight_window_problem(cfg, 0.05, F=args.features)
             tsteps = max(5, args.steps // 4)
             keep_loops = list(timed_loops)
             tdt, tup, _ = run(tprob, None, tsteps, 5)

@@ -44,8 +44,16 @@ extern "C" {
 /*      multi-rank updates return OVGPU_ERR_HIP on a follower time-out        */
 /*      instead of repeating locally; ovgpu_update_stats::ms_* are 0 for an   */
 /*      update that recorded no stage events.                                 */
+/*   5  (round 4) the MSCKF gate accepts a feature whose residual bound is    */
+/*      under its threshold without factoring its gate matrix                 */
+/*      (ovgpu_options::gate_always_factor, in the slot of the retired        */
+/*      tsqr_leaf_blocked; 0 = default).  Verdicts, dx, P' unchanged; the     */
+/*      chi2 OUTPUT of such a feature is the bound, an upper bound of the      */
+/*      reference's statistic.  ovgpu_update_stats::_pad0 became n_gate_bound. */
+/*      A caller that logs or thresholds the chi2 values itself sets           */
+/*      gate_always_factor = 1.                                                */
 /* ------------------------------------------------------------------------- */
-#define OVGPU_ABI_VERSION 4
+#define OVGPU_ABI_VERSION 5
 int ovgpu_abi_version(void);
 
 /* ------------------------------------------------------------------------- */

@@ -60,7 +60,7 @@ __host__ __device__ inline FeatYLds featy_lds_layout(int nt_max, int nw) {
   };
   // the block; afterwards the Cholesky's row panel ((nt_max + 1) tiles) and, behind it, the solved right-hand sides (16 nt_max x 4)
   L.yb = take((size_t)16 * nt_max * FY_LS * sizeof(double));
-  L.vl = take((size_t)16 * nt_max * 3 * sizeof(double));
+  L.vl = take((((size_t)16 * nt_max * 3 * sizeof(double)) + 1023) & ~(size_t)1023); // whole 1 KiB chunks: filled by the LDS DMA path
   const size_t wp = (size_t)nw * 3 * 64 * sizeof(double), stage = 2 * 256 * sizeof(double);
   L.wpart = take(wp > stage ? wp : stage); // V^T Y partial sums per wavefront; afterwards the Cholesky's diagonal-tile stage
   L.misc = take(32 * sizeof(double) + (size_t)(nt_max + 16) * sizeof(int)); // V^T r partials per wavefront, then rowlim / sched
@@ -103,16 +103,33 @@ __global__ void __launch_bounds__(256) k_feat_rows_sorted(SysParams p, FeatStore
 constexpr int FY_INST = 24;           // instances per tile row: <= 8 clones + 8 extrinsic + 8 intrinsic blocks
 constexpr int FY_ISTR = 32;           // ints per tile row in the instance table: [0] count, [1] last non-zero column, [8 ..] instances
 constexpr int FY_IOFF = 8;
-__global__ void __launch_bounds__(256) k_feat_vt(SysParams p, FeatStore st, double *__restrict__ tq, int32_t *__restrict__ inst, int nt_max) {
+// Round 4: the wavefront also finishes what needs nothing but the reflectors — the RESIDUAL column of the feature's stacked rows
+// (rows 3.. of Q^T r; never whitened) and the residual bound of the gate, |Q2^T r|^2 / s^2 (tq[8 f + 6]) — and leaves, per tile row
+// and column block of `cb` columns, the first instance that reaches the block and the first that reaches past its first half
+// (il[2 ..], three blocks of 10 bits per int): k_feat_y's prologue and its sweep were chains of dependent look-ups for these.
+template <bool F32OUT>
+__device__ __forceinline__ void vt_residual_column(const SysParams &p, int64_t orow0, const double *V, const double *res, int n, int lane, double z0, double z1,
+                                                    double z2, double &sumsq) {
+  const StackRows<F32OUT> out(p, orow0);
+  double sq = 0.0;
+  for (int r = 3 + lane; r < n; r += 64) {
+    const double rp = res[r] - (V[3 * r] * z0 + V[3 * r + 1] * z1 + V[3 * r + 2] * z2);
+    out.put(r - 3, p.D, rp);
+    sq = fma(rp, rp, sq);
+  }
+  sumsq = wave_sum(sq);
+}
+__global__ void __launch_bounds__(256) k_feat_vt(SysParams p, FeatStore st, double *__restrict__ tq, int32_t *__restrict__ inst, int nt_max, int cb) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int f = blockIdx.x * 4 + wv;
   if (f >= p.F) return;
   if (p.status[f] != OVGPU_FEAT_USED) return;
   const int RS = p.row_stride;
-  double *hf = reinterpret_cast<double *>(smem) + (size_t)wv * (12 * p.m_max + 64);
+  double *hf = reinterpret_cast<double *>(smem) + (size_t)wv * (14 * p.m_max + 64);
   double *V = hf + (size_t)6 * p.m_max;
   double *hq = V + (size_t)6 * p.m_max;
+  double *res = hq + 64; // [2 m] the residuals
   const int m0 = p.meas_offsets[f], m = p.meas_offsets[f + 1] - m0, n = 2 * m;
   const double *rows = st.rows + (size_t)m0 * RS;
   auto wsync = [] {
@@ -123,6 +140,7 @@ __global__ void __launch_bounds__(256) k_feat_vt(SysParams p, FeatStore st, doub
   for (int r = lane; r < n; r += 64) {
     const double *rd = rows + (size_t)(r >> 1) * RS + RO_HF + 3 * (r & 1);
     hf[3 * r] = rd[0], hf[3 * r + 1] = rd[1], hf[3 * r + 2] = rd[2];
+    res[r] = rows[(size_t)(r >> 1) * RS + RO_RES + (r & 1)];
   }
   wsync();
   sys_hf_householder(hf - RO_HF, 6, V, hq, n, 3, lane);
@@ -132,6 +150,22 @@ __global__ void __launch_bounds__(256) k_feat_vt(SysParams p, FeatStore st, doub
     vo[0] = V[3 * r], vo[1] = V[3 * r + 1], vo[2] = V[3 * r + 2];
   }
   if (lane < 6) tq[(size_t)8 * f + lane] = hq[3 + lane]; // T00 T01 T02 T11 T12 T22
+  { // the residual column: z = T^T V^T r, rows 3.. of r - V z -> column D of the feature's rows of the stack; the gate's bound
+    double w0 = 0.0, w1 = 0.0, w2 = 0.0;
+    for (int r = lane; r < n; r += 64) {
+      const double x = res[r];
+      w0 = fma(V[3 * r], x, w0), w1 = fma(V[3 * r + 1], x, w1), w2 = fma(V[3 * r + 2], x, w2);
+    }
+    w0 = wave_sum(w0), w1 = wave_sum(w1), w2 = wave_sum(w2);
+    const double T00 = hq[3], T01 = hq[4], T02 = hq[5], T11 = hq[6], T12 = hq[7], T22 = hq[8];
+    const double z0 = T00 * w0, z1 = T01 * w0 + T11 * w1, z2 = T02 * w0 + T12 * w1 + T22 * w2;
+    double sumsq;
+    if (p.Hbig32) vt_residual_column<true>(p, p.row_off[f], V, res, n, lane, z0, z1, z2, sumsq);
+    else vt_residual_column<false>(p, p.row_off[f], V, res, n, lane, z0, z1, z2, sumsq);
+    // S = Y Y^T + s^2 I >= s^2 I, so chi2 = r'^T S^-1 r' <= |r'|^2 / s^2: a feature whose BOUND is under its threshold passes the
+    // reference's test (UpdaterMSCKF.cpp:216-225) whatever its gate matrix holds
+    if (lane == 0) tq[(size_t)8 * f + 6] = sumsq / p.opt.sigma_pix_sq;
+  }
   // The distinct column blocks ("instances": first column, width) of every tile row of 16 rows, ascending — what the sweep of k_feat_y
   // loops over.  il[0] = count, il[1] = last non-zero column of the tile row, il[FY_IOFF ..] = (width << 16) | first column.
   // (built in LDS: the column triples of the measurements are staged by all lanes, the lists grow in the wavefront's scratch)
@@ -175,6 +209,20 @@ __global__ void __launch_bounds__(256) k_feat_vt(SysParams p, FeatStore st, doub
       il[FY_IOFF + b + 1] = v;
     }
     il[0] = cnt, il[1] = lim;
+    // per column block of cb columns: e0 = the first instance that reaches the block, e1 = the first that reaches past its first half
+    const int nblk = (p.D + cb - 1) / cb;
+    int packed[4] = {0, 0, 0, 0};
+    for (int kb = 0; kb < nblk && kb < 12; kb++) {
+      const int c_lo = cb * kb;
+      int e0 = 0;
+      while (e0 < cnt && (il[FY_IOFF + e0] & 0xffff) + (il[FY_IOFF + e0] >> 16) - 1 < c_lo) e0++;
+      int e1 = e0;
+      while (e1 < cnt && (il[FY_IOFF + e1] & 0xffff) + (il[FY_IOFF + e1] >> 16) - 1 < c_lo + cb / 2) e1++;
+#pragma unroll
+      for (int w = 0; w < 4; w++)
+        if (w == kb / 3) packed[w] |= (e0 | (e1 << 5)) << (10 * (kb % 3));
+    }
+    gl[2] = packed[0], gl[3] = packed[1], gl[4] = packed[2], gl[5] = packed[3];
     if (lds_lists) {
       gl[0] = cnt, gl[1] = lim;
       for (int e = 0; e < cnt; e++) gl[FY_IOFF + e] = il[FY_IOFF + e];
@@ -293,7 +341,7 @@ __device__ __forceinline__ double gate_cholesky_chi2(d4 (&acc)[TPW], const int (
 template <int NW, int TPW, int OCC, bool F32OUT = false>
 __global__ void __launch_bounds__(64 * NW, OCC)
     k_feat_y(SysParams p, int nt_max, const double *__restrict__ rowsG, const int32_t *__restrict__ minfoG, const double *__restrict__ VG,
-             const double *__restrict__ tqG, const int32_t *__restrict__ instG) {
+             const double *__restrict__ tqG, const int32_t *__restrict__ instG, const int32_t *__restrict__ slotsG) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int NTH = 64 * NW;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -322,26 +370,21 @@ __global__ void __launch_bounds__(64 * NW, OCC)
     p.dbg[220 + (i)] += tn - tlast, tlast = tn; \
   }
 
-  bool first = true;
-  for (;;) {
-    // the next slot was requested while the previous feature was in its Cholesky (sched[2]); the first one here
-    if (first) {
-      if (tid == 0) sched[2] = atomicAdd(p.work_counter, 1);
-      first = false;
-    }
-    lds_barrier(); // the previous feature's LDS is fully consumed; sched[2] is visible
-    const int slot = __builtin_amdgcn_readfirstlane(sched[2]);
-    if (slot >= p.F) break;
-    const int f = __builtin_amdgcn_readfirstlane(p.order ? p.order[slot] : slot);
-    const int m0 = __builtin_amdgcn_readfirstlane(p.meas_offsets[f]);
-    const int m = __builtin_amdgcn_readfirstlane(p.meas_offsets[f + 1]) - m0;
-    const int64_t orow0 = p.row_off[f];
-    const int n_out = (int)(p.row_off[f + 1] - orow0); // 2m - 3 (0 when m < 2)
+  // Static schedule (round 4): slot = blockIdx.x, + gridDim.x, ..  over the features sorted by descending track length — the
+  // workgroups' shares differ by one short track at most — and everything a feature's prologue used to look up in a chain (slot ->
+  // feature -> offsets -> rows) is ONE 32-byte record per slot (FeatSlot, written by the host with the batch).  No atomic, no
+  // dependent scalar loads between two features.
+  for (int slot = blockIdx.x; slot < p.F; slot += gridDim.x) {
+    lds_barrier(); // the previous feature's LDS is fully consumed
+    const int32_t *rec = slotsG + (size_t)8 * slot;
+    const int f = __builtin_amdgcn_readfirstlane(rec[0]);
+    const int m0 = __builtin_amdgcn_readfirstlane(rec[1]);
+    const int m = __builtin_amdgcn_readfirstlane(rec[2]);
+    const int n_out = __builtin_amdgcn_readfirstlane(rec[3]); // 2m - 3 (0 when m < 2)
+    const int64_t orow0 = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(rec[5]) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane(rec[4]));
     const StackRows<F32OUT> out(p, orow0);
     if (p.status[f] != OVGPU_FEAT_USED) { // failed before the gate: its rows of the stack are zero
       for (int64_t e = tid; e < (int64_t)n_out * out.ld; e += NTH) out.zero(e);
-      lds_barrier(); // everybody has read sched[2]
-      if (tid == 0) sched[2] = atomicAdd(p.work_counter, 1);
       continue;
     }
     const int n = 2 * m, NT = (n + 15) >> 4, NTT = NT * (NT + 1) / 2, ntiles = NTT + NT;
@@ -369,44 +412,22 @@ __global__ void __launch_bounds__(64 * NW, OCC)
     const double T00 = tqG[(size_t)8 * f], T01 = tqG[(size_t)8 * f + 1], T02 = tqG[(size_t)8 * f + 2], T11 = tqG[(size_t)8 * f + 3],
                  T12 = tqG[(size_t)8 * f + 4], T22 = tqG[(size_t)8 * f + 5];
 
-    // ------------------------------------------------------------------ prologue: reflectors -> LDS, instance lists, residual column
-    for (int e = tid; e < 3 * n; e += NTH) Vl[e] = fV[e];
-    const int32_t *finst = instG + (size_t)f * nt_max * FY_ISTR; // per tile row: count, last non-zero column, instances (k_feat_vt)
-    if (tid < NT) rowlim[tid] = finst[(size_t)tid * FY_ISTR + 1];
-    double r_a = 0.0, bound = 0.0;
+    // ------------------------------------------------------------------ prologue: reflectors -> LDS (DMA path: no registers, and
+    // nothing waits for them before the first sweep is done), the tile rows' last columns; the residual column of the stack and the
+    // gate's bound were left by k_feat_vt
     {
-      double v0 = 0.0, v1 = 0.0, v2 = 0.0;
-      if (tid < n) {
-        r_a = frow[(size_t)(tid >> 1) * RS + RO_RES + (tid & 1)];
-        const double *v = fV + (size_t)3 * tid;
-        v0 = v[0], v1 = v[1], v2 = v[2];
-      }
-      const double s0 = wave_sum(v0 * r_a), s1 = wave_sum(v1 * r_a), s2 = wave_sum(v2 * r_a);
-      if (lane == 0) zres[3 * wv] = s0, zres[3 * wv + 1] = s1, zres[3 * wv + 2] = s2; // summed in a fixed order: bit-reproducible
-      lds_barrier();
-      double w0 = 0.0, w1 = 0.0, w2 = 0.0;
-#pragma unroll
-      for (int w = 0; w < NW; w++) w0 += zres[3 * w], w1 += zres[3 * w + 1], w2 += zres[3 * w + 2];
-      const double z0 = T00 * w0, z1 = T01 * w0 + T11 * w1, z2 = T02 * w0 + T12 * w1 + T22 * w2;
-      double rp = 0.0;
-      if (tid >= 3 && tid < n) {
-        rp = r_a - (v0 * z0 + v1 * z1 + v2 * z2);
-        out.put(tid - 3, D, rp); // the residual column is not whitened
-      }
-      out.pad(tid, NTH, n_out, LD);
-      // The residual bound of the gate (round 4).  S = Y Y^T + s^2 I >= s^2 I, so chi2 = r'^T S^-1 r' <= |r'|^2 / s^2 with r' the
-      // projected residual just written: a feature whose BOUND is under the threshold passes the reference's test
-      // (UpdaterMSCKF.cpp:216-225) whatever its gate matrix holds, and neither the SYRK nor the Cholesky below is needed to know it.
-      if (!p.opt.gate_always_factor) {
-        const double sq = wave_sum(rp * rp);
-        if (lane == 0) zres[24 + wv] = sq;
-        lds_barrier();
-        double tot = 0.0;
-#pragma unroll
-        for (int w = 0; w < NW; w++) tot += zres[24 + w];
-        bound = tot / sig2;
+      const int nchunk = (24 * n + 1023) >> 10; // 1 KiB per wavefront and instruction; a lane past the end re-reads the last 16 bytes
+      const char *src = reinterpret_cast<const char *>(fV);
+      for (int ch = wv; ch < nchunk; ch += NW) {
+        const int off = min(1024 * ch + 16 * lane, 24 * n - 16);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + off),
+                                         (__attribute__((address_space(3))) void *)(reinterpret_cast<char *>(Vl) + 1024 * ch), 16, 0, 0);
       }
     }
+    const int32_t *finst = instG + (size_t)f * nt_max * FY_ISTR; // per tile row: count, last non-zero column, block starts, instances (k_feat_vt)
+    if (tid < NT) rowlim[tid] = finst[(size_t)tid * FY_ISTR + 1];
+    out.pad(tid, NTH, n_out, LD);
+    const double bound = tqG[(size_t)8 * f + 6];
     const double thr = p.opt.chi2_multipler * p.chi2_table[min(n - 3, p.chi2_table_len - 1)]; // UpdaterMSCKF.cpp:216-222
     // (1 - 1e-9): the bound is a float64 sum of ~100 squares and the reference's own chi2 carries ~1e-12 of rounding: a feature
     // this close to the threshold takes the full gate
@@ -434,10 +455,9 @@ __global__ void __launch_bounds__(64 * NW, OCC)
         const int32_t *il = finst + (size_t)i * FY_ISTR; // wave-uniform: scalar loads
         const int cnt = il[0];
         auto code_at = [&](int e) { return il[FY_IOFF + e]; };
-        int e0 = 0; // first instance that reaches this column block ...
-        while (e0 < cnt && (code_at(e0) & 0xffff) + (code_at(e0) >> 16) - 1 < c_lo) e0++;
-        int e1 = e0; // ... and the first that reaches past its first two column tiles
-        while (e1 < cnt && (code_at(e1) & 0xffff) + (code_at(e1) >> 16) - 1 < c_lo + 32) e1++;
+        // first instance that reaches this column block, and the first that reaches past its first two column tiles (k_feat_vt)
+        const int pk = il[2 + kb / 3] >> (10 * (kb % 3));
+        const int e0 = pk & 31, e1 = (pk >> 5) & 31;
         // The rows of L an instance selects, for the four column tiles of the block.  Straight-line code: every load is issued
         // unconditionally at a clamped address and masked afterwards (right of an instance L holds explicit zeros, so a column tile
         // beyond it costs two idle products, not a branch): the loads of the NEXT instance stay in flight behind this one's products.
@@ -484,6 +504,7 @@ __global__ void __launch_bounds__(64 * NW, OCC)
 #pragma unroll
           for (int q = 0; q < 4; q++) Yb[(size_t)(16 * i + g + 4 * q) * FY_LS + 16 * ct + cl] = ay[ct][q];
       }
+      if (kb == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the reflectors' DMA (issued in the prologue) has landed
       lds_barrier();
       FEAT_T(1)
       // ---- V^T Y per column (lane = column, the rows dealt to the wavefronts)
@@ -556,7 +577,6 @@ __global__ void __launch_bounds__(64 * NW, OCC)
       }
     }
     FEAT_T(4)
-    if (tid == 0) sched[2] = atomicAdd(p.work_counter, 1); // the next feature's slot: the atomic's round trip hides behind the Cholesky
     // a feature passed by the bound reports the BOUND as its statistic (>= the reference's chi2, <= the threshold; include/ovgpu.h)
     const double chi2 = skip_gate ? bound : ((p.skip & 8) ? 0.0 : gate_cholesky_chi2<NW, TPW>(acc, tij, NT, n, panel, st0, st1, rhs, lane, wv));
     if (wv == 0 && lane == 0) {

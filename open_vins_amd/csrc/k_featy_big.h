@@ -42,7 +42,7 @@ __host__ __device__ inline FeatYBigLds featyb_lds_layout(int nt_max, int nw) {
   };
   const size_t blk = (size_t)16 * nt_max * FB_LS * sizeof(double), pan = (size_t)2 * (nt_max + 1) * 256 * sizeof(double);
   L.yb = take(blk > pan ? blk : pan); // the block; in phases (B), (C) two row panels of (nt_max + 1) tiles
-  L.vl = take((size_t)16 * nt_max * 3 * sizeof(double));
+  L.vl = take((((size_t)16 * nt_max * 3 * sizeof(double)) + 1023) & ~(size_t)1023); // whole 1 KiB chunks (LDS DMA)
   const size_t wp = (size_t)nw * 3 * FB_CB * sizeof(double), stage = 2 * 256 * sizeof(double);
   L.wpart = take(wp > stage ? wp : stage);
   L.rhs = take((size_t)16 * nt_max * 4 * sizeof(double)); // solved right-hand sides: they live across the passes
@@ -56,7 +56,7 @@ __host__ __device__ inline size_t featyb_ws_doubles(int nt_max) { return (size_t
 template <int NW, int TPW, bool F32OUT = false>
 __global__ void __launch_bounds__(64 * NW, 1)
     k_feat_y_big(SysParams p, int nt_max, const double *__restrict__ rowsG, const int32_t *__restrict__ minfoG, const double *__restrict__ VG,
-                 const double *__restrict__ tqG, const int32_t *__restrict__ instG, double *wsG) {
+                 const double *__restrict__ tqG, const int32_t *__restrict__ instG, const int32_t *__restrict__ slotsG, double *wsG) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int NTH = 64 * NW;
   static_assert(FB_PF * NTH >= 30 * 256, "a fetched row panel must fit the prefetch registers");
@@ -81,25 +81,17 @@ __global__ void __launch_bounds__(64 * NW, 1)
   // the scratch is read back by other wavefronts of this workgroup: past the vector cache (it may hold the previous track's panels)
   auto ld_l2 = [](const double *ptr) { return __hip_atomic_load(ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
 
-  bool first = true;
-  for (;;) {
-    if (first) {
-      if (tid == 0) sched[2] = atomicAdd(p.work_counter, 1);
-      first = false;
-    }
+  for (int slot = blockIdx.x; slot < p.F; slot += gridDim.x) { // static schedule over the slot records (k_featy.h)
     lds_barrier();
-    const int slot = __builtin_amdgcn_readfirstlane(sched[2]);
-    if (slot >= p.F) break;
-    const int f = __builtin_amdgcn_readfirstlane(p.order ? p.order[slot] : slot);
-    const int m0 = __builtin_amdgcn_readfirstlane(p.meas_offsets[f]);
-    const int m = __builtin_amdgcn_readfirstlane(p.meas_offsets[f + 1]) - m0;
-    const int64_t orow0 = p.row_off[f];
-    const int n_out = (int)(p.row_off[f + 1] - orow0);
+    const int32_t *rec = slotsG + (size_t)8 * slot;
+    const int f = __builtin_amdgcn_readfirstlane(rec[0]);
+    const int m0 = __builtin_amdgcn_readfirstlane(rec[1]);
+    const int m = __builtin_amdgcn_readfirstlane(rec[2]);
+    const int n_out = __builtin_amdgcn_readfirstlane(rec[3]);
+    const int64_t orow0 = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(rec[5]) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane(rec[4]));
     const StackRows<F32OUT> out(p, orow0);
     if (p.status[f] != OVGPU_FEAT_USED) {
       for (int64_t e = tid; e < (int64_t)n_out * out.ld; e += NTH) out.zero(e);
-      lds_barrier();
-      if (tid == 0) sched[2] = atomicAdd(p.work_counter, 1);
       continue;
     }
     const int n = 2 * m, NT = (n + 15) >> 4;
@@ -109,44 +101,23 @@ __global__ void __launch_bounds__(64 * NW, 1)
     const double T00 = tqG[(size_t)8 * f], T01 = tqG[(size_t)8 * f + 1], T02 = tqG[(size_t)8 * f + 2], T11 = tqG[(size_t)8 * f + 3],
                  T12 = tqG[(size_t)8 * f + 4], T22 = tqG[(size_t)8 * f + 5];
 
-    // ------------------------------------------------------------------ prologue (k_feat_y's)
-    double bound = 0.0;
-    for (int e = tid; e < 3 * n; e += NTH) Vl[e] = fV[e];
-    const int32_t *finst = instG + (size_t)f * nt_max * FY_ISTR;
-    if (tid < NT) rowlim[tid] = finst[(size_t)tid * FY_ISTR + 1];
+    // ------------------------------------------------------------------ prologue (k_feat_y's): reflectors by the LDS DMA path; the
+    // residual column of the stack and the gate's bound were left by k_feat_vt
     {
-      double r_a = 0.0, v0 = 0.0, v1 = 0.0, v2 = 0.0;
-      if (tid < n) {
-        r_a = frow[(size_t)(tid >> 1) * RS + RO_RES + (tid & 1)];
-        const double *v = fV + (size_t)3 * tid;
-        v0 = v[0], v1 = v[1], v2 = v[2];
-      }
-      const double s0 = wave_sum(v0 * r_a), s1 = wave_sum(v1 * r_a), s2 = wave_sum(v2 * r_a);
-      if (lane == 0) zres[3 * wv] = s0, zres[3 * wv + 1] = s1, zres[3 * wv + 2] = s2;
-      lds_barrier();
-      double w0 = 0.0, w1 = 0.0, w2 = 0.0;
-#pragma unroll
-      for (int w = 0; w < NW; w++) w0 += zres[3 * w], w1 += zres[3 * w + 1], w2 += zres[3 * w + 2];
-      const double z0 = T00 * w0, z1 = T01 * w0 + T11 * w1, z2 = T02 * w0 + T12 * w1 + T22 * w2;
-      double rp = 0.0;
-      if (tid >= 3 && tid < n) {
-        rp = r_a - (v0 * z0 + v1 * z1 + v2 * z2);
-        out.put(tid - 3, D, rp);
-      }
-      out.pad(tid, NTH, n_out, LD);
-      if (!p.opt.gate_always_factor) { // the residual bound of the gate (k_featy.h): chi2 <= |r'|^2 / s^2
-        const double sq = wave_sum(rp * rp);
-        if (lane == 0) zres[24 + wv] = sq;
-        lds_barrier();
-        double tot = 0.0;
-#pragma unroll
-        for (int w = 0; w < NW; w++) tot += zres[24 + w];
-        bound = tot / sig2;
+      const int nchunk = (24 * n + 1023) >> 10;
+      const char *src = reinterpret_cast<const char *>(fV);
+      for (int ch = wv; ch < nchunk; ch += NW) {
+        const int off = min(1024 * ch + 16 * lane, 24 * n - 16);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + off),
+                                         (__attribute__((address_space(3))) void *)(reinterpret_cast<char *>(Vl) + 1024 * ch), 16, 0, 0);
       }
     }
+    const int32_t *finst = instG + (size_t)f * nt_max * FY_ISTR;
+    if (tid < NT) rowlim[tid] = finst[(size_t)tid * FY_ISTR + 1];
+    out.pad(tid, NTH, n_out, LD);
+    const double bound = tqG[(size_t)8 * f + 6];
     const double thr = p.opt.chi2_multipler * p.chi2_table[min(n - 3, p.chi2_table_len - 1)]; // UpdaterMSCKF.cpp:216-222
     const bool skip_gate = __builtin_amdgcn_readfirstlane((int)(!p.opt.gate_always_factor && bound <= thr * (1.0 - 1e-9))) != 0;
-    if (tid == 0) sched[2] = atomicAdd(p.work_counter, 1); // every wavefront has read the current slot (barrier above)
 
     // ------------------------------------------------------------------ the passes over block rows [a, b)
     int a = 0;
@@ -191,10 +162,9 @@ __global__ void __launch_bounds__(64 * NW, 1)
           const int32_t *il = finst + (size_t)i * FY_ISTR;
           const int ni = il[0];
           auto code_at = [&](int e) { return il[FY_IOFF + e]; };
-          int e0 = 0; // first instance that reaches this column block ...
-          while (e0 < ni && (code_at(e0) & 0xffff) + (code_at(e0) >> 16) - 1 < c_lo) e0++;
-          int e1 = e0; // ... and the first that reaches past its first column tile
-          while (e1 < ni && (code_at(e1) & 0xffff) + (code_at(e1) >> 16) - 1 < c_lo + 16) e1++;
+          // first instance that reaches this column block, and the first that reaches past its first column tile (k_feat_vt)
+          const int pk = il[2 + kb / 3] >> (10 * (kb % 3));
+          const int e0 = pk & 31, e1 = (pk >> 5) & 31;
           const int colc = min(c_lo + cl, D - 1) - c_lo;
           const bool okc[2] = {c_lo + cl < D, c_lo + 16 + cl < D};
           auto run = [&](auto nct_tag, int e_a, int e_b) {
@@ -236,6 +206,7 @@ __global__ void __launch_bounds__(64 * NW, 1)
 #pragma unroll
             for (int q = 0; q < 4; q++) Yb[(size_t)(16 * i + g + 4 * q) * FB_LS + 16 * ct + cl] = ay[ct][q];
         }
+        if (a == 0 && kb == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the reflectors' DMA has landed
         lds_barrier();
         if (a == 0) { // first pass: rows 3.. of Q^T Y = Y - V z -> the stack (half a wavefront per row: lane & 31 = column)
           double w0 = 0.0, w1 = 0.0, w2 = 0.0;

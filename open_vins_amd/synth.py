@@ -449,6 +449,19 @@ def make_problem(cfg=2, rep=0, *, C=None, K=None, F=None, track="full", fisheye=
     )
 
 
+def tight_window_problem(cfg=2, scale=0.05, **kw) -> Problem:
+    """make_problem's snapshot with the clone window `scale` times as uncertain — clone errors AND the clone rows / columns of the prior
+    scaled alike, so the snapshot stays consistent.  SURVEY 8(d)'s snapshot gives every clone an independent 0.57 deg / 5 cm (tens of
+    pixels of predicted-pixel uncertainty); a running filter's window is tight relative to its newest clone — the regime in which the
+    gate's residual bound (ovgpu_options::gate_always_factor = 0) decides most features (tests/test_rpng_sim_loop.py: 99.8 %)."""
+    prob = make_problem(cfg, pose_noise=scale, **kw)
+    sc = np.ones(prob.N)
+    for cid in prob.clone_cov_id:
+        sc[int(cid):int(cid) + 6] = scale
+    prob.P = np.ascontiguousarray(sc[:, None] * prob.P * sc[None, :])
+    return prob
+
+
 def realistic_prior(prob: Problem, sigma_g_p=1.0, sigma_g_th=0.05, q_th=5e-5, q_p=1e-5, seed=0):
     """A prior covariance shaped like a live sliding window instead of make_problem's generic SPD matrix.
 
