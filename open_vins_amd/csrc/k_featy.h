@@ -42,6 +42,9 @@
 namespace ovg {
 namespace feat {
 
+#ifndef FY_SYRK_UNROLL
+#define FY_SYRK_UNROLL 2
+#endif
 constexpr int FY_CB = 64; // columns per block = lanes of a wavefront
 constexpr int FY_LS = 66; // row stride of the LDS block in doubles: 16-byte aligned rows, conflict-free 16-byte operand reads
                           // (rows r and r + 1 of a tile are 4 banks apart: 16 lanes x 4 banks = all 64)
@@ -361,6 +364,9 @@ __global__ void __launch_bounds__(64 * NW, OCC)
   const double sig2 = p.opt.sigma_pix_sq;
   const int nblk = (D + FY_CB - 1) / FY_CB;
 
+  // phase counters of workgroup 0 (tools/dev_featy_phases.py): a developer build only (-DOVG_FEAT_PROF) — the six read-modify-writes per
+  // feature cost that workgroup a third of its time, and the bookkeeping costs every wavefront registers
+#ifdef OVG_FEAT_PROF
   long long tlast = 0;
   const bool prof = p.dbg != nullptr && blockIdx.x == 0 && tid == 0;
   if (prof) tlast = clock64();
@@ -369,6 +375,9 @@ __global__ void __launch_bounds__(64 * NW, OCC)
     const long long tn = clock64();            \
     p.dbg[220 + (i)] += tn - tlast, tlast = tn; \
   }
+#else
+#define FEAT_T(i)
+#endif
 
   // Static schedule (round 4): slot = blockIdx.x, + gridDim.x, ..  over the features sorted by descending track length — the
   // workgroups' shares differ by one short track at most — and everything a feature's prologue used to look up in a chain (slot ->
@@ -540,7 +549,7 @@ __global__ void __launch_bounds__(64 * NW, OCC)
           if (lim >= c_lo) {
             const int nsl = min(FY_CB / 8, (lim - c_lo) / 8 + 1);
             const double *ya = Yb + (size_t)(16 * TI(s) + cl) * FY_LS + 2 * g, *yb = Yb + (size_t)(16 * TJ(s) + cl) * FY_LS + 2 * g;
-#pragma unroll 2
+#pragma unroll FY_SYRK_UNROLL
             for (int sl = 0; sl < nsl; sl++) {
               const double2 a = *reinterpret_cast<const double2 *>(ya + 8 * sl), b = *reinterpret_cast<const double2 *>(yb + 8 * sl);
               FEAT_MFMA(a.x, b.x, acc[s]);
