@@ -274,7 +274,7 @@ def state_sigmas(C, K, imu_intrinsics=False):
 
 
 def make_problem(cfg=2, rep=0, *, C=None, K=None, F=None, track="full", fisheye=False,
-                 min_obs=5, pose_noise=1.0, seed=None, shard=0, outlier_frac=0.0, imu_intrinsics=False) -> Problem:
+                 min_obs=5, pose_noise=1.0, seed=None, shard=0, outlier_frac=0.0, imu_intrinsics=False, calib_noise=1.0) -> Problem:
     """Builds the snapshot of BASELINE.json config `cfg`; C/K/F override its sizes.
 
     track = "full": every visible observation is kept; "ragged": a contiguous sub-window of clones of
@@ -329,10 +329,10 @@ def make_problem(cfg=2, rep=0, *, C=None, K=None, F=None, track="full", fisheye=
     calib_est = np.empty_like(calib_true)
     intr_est = intr_true.copy()
     for k in range(K):
-        d = np.concatenate([rng.normal(0, 0.3 * 0.005, 3), rng.normal(0, 0.3 * 0.015, 3)])
+        d = np.concatenate([rng.normal(0, 0.3 * 0.005, 3), rng.normal(0, 0.3 * 0.015, 3)]) * calib_noise
         calib_est[k] = boxplus_pose(calib_true[k], d)
-        intr_est[k, :4] += rng.normal(0, 0.3 * 1.0, 4)
-        intr_est[k, 4:] += rng.normal(0, 0.3 * 0.005 * 0.1, 4)
+        intr_est[k, :4] += rng.normal(0, 0.3 * 1.0, 4) * calib_noise
+        intr_est[k, 4:] += rng.normal(0, 0.3 * 0.005 * 0.1, 4) * calib_noise
 
     R_GtoI = [quat_2_rot(clone_true[i, :4]) for i in range(C)]
 
@@ -450,15 +450,13 @@ def make_problem(cfg=2, rep=0, *, C=None, K=None, F=None, track="full", fisheye=
 
 
 def tight_window_problem(cfg=2, scale=0.05, **kw) -> Problem:
-    """make_problem's snapshot with the clone window `scale` times as uncertain — clone errors AND the clone rows / columns of the prior
-    scaled alike, so the snapshot stays consistent.  SURVEY 8(d)'s snapshot gives every clone an independent 0.57 deg / 5 cm (tens of
-    pixels of predicted-pixel uncertainty); a running filter's window is tight relative to its newest clone — the regime in which the
-    gate's residual bound (ovgpu_options::gate_always_factor = 0) decides most features (tests/test_rpng_sim_loop.py: 99.8 %)."""
-    prob = make_problem(cfg, pose_noise=scale, **kw)
-    sc = np.ones(prob.N)
-    for cid in prob.clone_cov_id:
-        sc[int(cid):int(cid) + 6] = scale
-    prob.P = np.ascontiguousarray(sc[:, None] * prob.P * sc[None, :])
+    """make_problem's snapshot `scale` times as uncertain — clone and calibration errors AND the prior covariance scaled alike, so the
+    snapshot stays consistent.  SURVEY 8(d)'s snapshot gives every clone an independent 0.57 deg / 5 cm and the calibration its
+    start-up priors (tens of pixels of predicted-pixel uncertainty); a running filter's window is tight relative to its newest clone and
+    its calibration has converged — the regime in which the gate's residual bound (ovgpu_options::gate_always_factor = 0) decides
+    most features (tests/test_rpng_sim_loop.py: 99.8 %)."""
+    prob = make_problem(cfg, pose_noise=scale, calib_noise=scale, **kw)
+    prob.P = np.ascontiguousarray(prob.P * (scale * scale))
     return prob
 
 
