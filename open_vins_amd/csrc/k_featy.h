@@ -42,6 +42,12 @@
 namespace ovg {
 namespace feat {
 
+// developer ablation of the fused kernel's phases (tools/dev_featy_ablate.py; the results are garbage): a developer build only
+#ifdef OVG_FEAT_ABLATE
+#define FY_SKIP(p) ((p).skip)
+#else
+#define FY_SKIP(p) 0
+#endif
 #ifndef FY_SYRK_UNROLL
 #define FY_SYRK_UNROLL 2
 #endif
@@ -449,7 +455,7 @@ __global__ void __launch_bounds__(64 * NW, OCC)
     for (int kb = 0; kb < nblk; kb++) {
       const int c_lo = FY_CB * kb;
       // ---- sweep on the matrix cores: this wavefront's tile rows of Y = H L, columns c_lo .. c_lo + 63 -> LDS
-      for (int i = wv; i < NT && !(p.skip & 1); i += NW) {
+      for (int i = wv; i < NT && !(FY_SKIP(p) & 1); i += NW) {
         const int r = 16 * i + cl;
         const bool rv = r < n;
         const int mr = min(r >> 1, m - 1), par = r & 1;
@@ -519,7 +525,7 @@ __global__ void __launch_bounds__(64 * NW, OCC)
       lds_barrier();
       FEAT_T(1)
       // ---- V^T Y per column (lane = column, the rows dealt to the wavefronts)
-      if (!(p.skip & 2)) {
+      if (!(FY_SKIP(p) & 2)) {
         double w0 = 0.0, w1 = 0.0, w2 = 0.0;
 #pragma unroll 8
         for (int a = wv; a < n; a += NW) {
@@ -530,7 +536,7 @@ __global__ void __launch_bounds__(64 * NW, OCC)
       }
       lds_barrier();
       // ---- rows 3.. of Q^T Y = Y - V z -> the stack
-      if (!(p.skip & 2)) {
+      if (!(FY_SKIP(p) & 2)) {
         const int c = c_lo + lane;
         double s0 = 0.0, s1 = 0.0, s2 = 0.0;
 #pragma unroll
@@ -546,7 +552,7 @@ __global__ void __launch_bounds__(64 * NW, OCC)
       // ---- SYRK: S0 tiles += Y_i Y_j^T over the slabs of 8 columns both tile rows reach
 #pragma unroll
       for (int s = 0; s < TPW; s++) {
-        if (tij[s] >= 0 && TJ(s) < NT && !skip_gate && !(p.skip & 4)) {
+        if (tij[s] >= 0 && TJ(s) < NT && !skip_gate && !(FY_SKIP(p) & 4)) {
           const int lim = min(min(rowlim[TI(s)], rowlim[TJ(s)]), D - 1);
           if (lim >= c_lo) {
             const int nsl = min(FY_CB / 8, (lim - c_lo) / 8 + 1);
@@ -589,7 +595,7 @@ __global__ void __launch_bounds__(64 * NW, OCC)
     }
     FEAT_T(4)
     // a feature passed by the bound reports the BOUND as its statistic (>= the reference's chi2, <= the threshold; include/ovgpu.h)
-    const double chi2 = skip_gate ? bound : ((p.skip & 8) ? 0.0 : gate_cholesky_chi2<NW, TPW>(acc, tij, NT, n, panel, st0, st1, rhs, lane, wv));
+    const double chi2 = skip_gate ? bound : ((FY_SKIP(p) & 8) ? 0.0 : gate_cholesky_chi2<NW, TPW>(acc, tij, NT, n, panel, st0, st1, rhs, lane, wv));
     if (wv == 0 && lane == 0) {
       if (skip_gate && p.rows_used) atomicAdd(p.rows_used + 1, 1);
       p.chi2[f] = chi2;

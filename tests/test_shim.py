@@ -125,17 +125,26 @@ def test_shim_drives_an_update_from_cpp():
     assert "shim gpu selftest ok" in out, out
 
 
-def test_slam_update_required_meas_rule():
+def test_slam_update_required_meas_rule(tmp_path):
     """UpdaterSLAM.cpp:283-295: a landmark without measurements is flagged and erased; an ANCHORED_INVERSE_DEPTH_SINGLE landmark
     with exactly ONE measurement is erased from this update WITHOUT to_delete (FeatureDatabase::cleanup must keep the measurement,
-    the next frame brings the second one).  The shim decides that before the library sees the track."""
-    import re
-    s = _src("UpdaterSLAM_update.cpp")
-    assert "required_meas = (landmark->_feat_representation == LandmarkRepresentation::Representation::ANCHORED_INVERSE_DEPTH_SINGLE) ? 2 : 1" in s
-    m = re.search(r"if \(ct_meas < 1\) \{(.*?)\} else if \(ct_meas < required_meas\) \{(.*?)\}", s, re.S)
-    assert m and "to_delete = true" in m.group(1) and "erase(it)" in m.group(1)
-    assert "to_delete" not in m.group(2) and "erase(it)" in m.group(2)
-    assert s.index("ct_meas < required_meas") < s.index("append_track(")
+    the next frame brings the second one).  The shim decides that before the library sees the track — so the drop-in translation
+    unit can be RUN against the stand-in headers (tests/shim_mock/run_required_meas.cpp): three such tracks, two passes (the
+    second representation), and the library is never reached."""
+    exe = str(tmp_path / "run_required_meas")
+    cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-Werror", f"-I{MOCK}", f"-I{MOCK}/update", f"-I{MOCK}/feat", f"-I{ROOT}/include", f"-I{SHIM}",
+           os.path.join(MOCK, "run_required_meas.cpp"), os.path.join(SHIM, "UpdaterSLAM_update.cpp"), "-o", exe,
+           f"-L{ROOT}/open_vins_amd/csrc", "-lovgpu", f"-Wl,-rpath,{ROOT}/open_vins_amd/csrc"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+    assert p.returncode == 0, p.stdout + p.stderr
+    lines = p.stdout.split("\n")
+    assert "left in feature_vec: 0" in lines                      # all three left the update ...
+    assert "feature 10 to_delete 1" in lines                      # ... no measurement: flagged
+    assert "feature 11 to_delete 0" in lines                      # ... single depth with ONE measurement: kept for the next frame
+    assert "feature 12 to_delete 1" in lines                      # ... the second pass (another representation) applies the same rule
+    assert "EKFUpdate reached" not in p.stdout
 
 
 @pytest.mark.gpu
