@@ -18,6 +18,9 @@ cp $SRC/bench_cfg4_one_gpu.json ${P}_bench_cfg4_one_gpu.json
 cp $SRC/bench_tsqr.json ${P}_bench_tsqr_route.json
 cp $SRC/bench_cfg5_share_f64.json ${P}_bench_cfg5_one_gpu_share.json
 cp $SRC/bench_cfg5_share_fp32_gram.json ${P}_bench_cfg5_one_gpu_share_fp32_gram.json
+[ -f $SRC/rpng_sim_loop.txt ] && cp $SRC/rpng_sim_loop.txt ${P}_rpng_sim_closed_loop.txt
+[ -f $SRC/shim_time.json ] && cp $SRC/shim_time.json ${P}_shim_dropin_times.json
+[ -f $SRC/pytest_gpu.txt ] && cp $SRC/pytest_gpu.txt ${P}_pytest_gpu.txt
 [ -f $SRC/mode_a_times.txt ] && cp $SRC/mode_a_times.txt ${P}_mode_a_times.txt
 [ -f $SRC/prof_modea.txt ] && cp $SRC/prof_modea.txt ${P}_kernel_stats_mode_a.txt
 python tools/make_pmc_json.py $SRC/prof_fetch.txt $SRC/prof_write.txt 3 ${P}_pmc.json

@@ -7,9 +7,12 @@ OUT=/root/repo/gpurun_out/$TAG
 mkdir -p $OUT
 cd /root/repo
 if [ "${SKIP_TESTS:-0}" != 1 ]; then
-  timeout 900 python -m pytest tests -q -m gpu -p no:cacheprovider 2>&1 | tail -12 > $OUT/pytest_gpu.txt
+  timeout 1200 python -m pytest tests -q -m gpu -p no:cacheprovider 2>&1 | tail -12 > $OUT/pytest_gpu.txt
   timeout 120 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.txt 2>&1
 fi
+timeout 300 python -m pytest tests/test_rpng_sim_loop.py -m gpu -q -s -p no:cacheprovider 2>&1 | grep "GPU- vs reference\|passed\|failed" > $OUT/rpng_sim_loop.txt
+timeout 120 open_vins_amd/shim/selftest --time 2000 9 > $OUT/shim_time.json 2>/dev/null
+timeout 120 open_vins_amd/shim/selftest --time 800 9 >> $OUT/shim_time.json 2>/dev/null
 timeout 300 python -m pytest tests/test_gpu_fullsize.py -q -s -p no:cacheprovider -k "conditioning_sweep or round1_route" 2>&1 | grep "cond(P_DD)\|gram then\|passed\|failed" > $OUT/conditioning_sweep.txt
 timeout 400 python bench.py > $OUT/bench.json 2> $OUT/bench.err
 timeout 120 python bench.py --cfg 2 --steps 50 --warmup 5 --no-cpu-baseline --no-extras > $OUT/bench_cfg2.json 2>> $OUT/bench.err
