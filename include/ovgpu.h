@@ -372,8 +372,8 @@ int ovgpu_msckf_update(ovgpu_ctx *ctx, int32_t *feat_status, double *chi2,
  *                                  matrix, un-whitened: DENSE, rows = its numerical rank (the stack of an MSCKF
  *                                  update has a null space: gauge directions) — 1.2 ms host to host at 2000 features
  *   OVGPU_COMPRESS_TSQR            the reference's form, the upper-triangular Householder factor, rows = D
- *                                  (4.0 ms); also taken beyond 255 columns and when the prior block's
- *                                  factorisation fails.  ovgpu_last_update_route tells which one came back. */
+ *                                  (4.0 ms); also taken beyond 383 columns (255 before ABI 5) and when the
+ *                                  prior block's factorisation fails.  ovgpu_last_update_route tells which one came back. */
 int ovgpu_msckf_compress(ovgpu_ctx *ctx, int32_t *feat_status, double *chi2,
                          double *chi2_thresh, double *p_FinG, int32_t *D_out,
                          int32_t *rows_out, int32_t *col_cov_id, double *H,

@@ -618,14 +618,18 @@ __global__ void k_boxplus(int C, int K, const double *__restrict__ dx, const int
 // tj is being computed: U1 was written on another XCD a moment ago, a read costs ~1.5 us, and the chain of NT columns would
 // otherwise pay it once per trip of the product loop (measured: 164 us at D = 208 that way; the column-at-a-time form before it ran
 // D dependent steps of LDS round trip + shuffle reduction, 162 us, and with its fetches inside the step 0.45 ms).
-struct UnwhitenStrip {
-  double b[60]; // B operands of up to 15 tiles right of the column (D <= 256): b[4 t + u] = U1[col][16 (tj + 1 + t) + 4 u + g]
+// NTM = tile columns at most: 16 (D <= 256, the next column's strip prefetched) or 24 (D <= 384: one strip — two would not fit the
+// registers of a wavefront — fetched and used in turn; configs[4]'s mode A, round 4)
+template <int NTM> struct UnwhitenStrip {
+  double b[4 * (NTM - 1)]; // B operands of up to NTM - 1 tiles right of the column: b[4 t + u] = U1[col][16 (tj + 1 + t) + 4 u + g]
   double ud[16]; // row cl of the diagonal tile from the diagonal on, identity beyond D
   double rr[4];  // R(rows 4 q + g, col)
 };
+template <int NTM>
 __global__ void __launch_bounds__(64) k_unwhiten(int D, int LD, double *__restrict__ R, const double *__restrict__ Y1, int LA, const int32_t *pred,
                                                  const int32_t *pred_not) {
-  constexpr int XS = 260; // LDS row stride: the A-operand read X[cl][k0 + g] touches 64 different banks
+  constexpr int XS = 16 * NTM + 4; // LDS row stride: the A-operand read X[cl][k0 + g] touches 64 different banks
+  using Strip = UnwhitenStrip<NTM>;
   __shared__ double X[16 * XS];
   if ((pred && *pred == 0) || (pred_not && *pred_not != 0)) return; // (pred_not: the not-SPD flag of the prior block's factorisation)
   const int lane = threadIdx.x, g = lane >> 4, cl = lane & 15;
@@ -636,12 +640,12 @@ __global__ void __launch_bounds__(64) k_unwhiten(int D, int LD, double *__restri
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   };
-  auto fetch = [&](int tj, UnwhitenStrip &s) { // clamped addresses, masked afterwards: one basic block of loads
+  auto fetch = [&](int tj, Strip &s) { // clamped addresses, masked afterwards: one basic block of loads
     const int c0 = 16 * tj, col = c0 + cl;
     const bool cok = col < D;
     const double *urow = Y1 + (size_t)(cok ? col : D - 1) * LA; // row `col` of U1 = column `col` of L
 #pragma unroll
-    for (int i = 0; i < 60; i++) {
+    for (int i = 0; i < 4 * (NTM - 1); i++) {
       const int k = c0 + 16 + 16 * (i >> 2) + 4 * (i & 3) + g;
       s.b[i] = urow[k < D ? k : D - 1];
     }
@@ -653,7 +657,7 @@ __global__ void __launch_bounds__(64) k_unwhiten(int D, int LD, double *__restri
       s.rr[q] = R[(size_t)(row < D ? row : D - 1) * LD + (cok ? col : 0)];
     }
 #pragma unroll
-    for (int i = 0; i < 60; i++) {
+    for (int i = 0; i < 4 * (NTM - 1); i++) {
       const int k = c0 + 16 + 16 * (i >> 2) + 4 * (i & 3) + g;
       if (!(cok && k < D)) s.b[i] = 0.0;
     }
@@ -664,12 +668,12 @@ __global__ void __launch_bounds__(64) k_unwhiten(int D, int LD, double *__restri
     for (int q = 0; q < 4; q++)
       if (!(r0 + 4 * q + g < D && cok)) s.rr[q] = 0.0;
   };
-  auto column = [&](int tj, const UnwhitenStrip &s) {
+  auto column = [&](int tj, const Strip &s) {
     const int c0 = 16 * tj, col = c0 + cl;
     const bool cok = col < D;
     double4_t acc = {s.rr[0], s.rr[1], s.rr[2], s.rr[3]}, acc2 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int t = 0; t < 15; t++) {
+    for (int t = 0; t < NTM - 1; t++) {
       const int k0 = c0 + 16 + 16 * t;
       if (k0 < 16 * NT) { // (wave-uniform)
         const double *xa = X + cl * XS + k0 + g;
@@ -701,15 +705,24 @@ __global__ void __launch_bounds__(64) k_unwhiten(int D, int LD, double *__restri
     }
     wsync();
   };
-  UnwhitenStrip s0, s1;
-  fetch(NT - 1, s0);
-  wsync();
-  for (int tj = NT - 1; tj >= 0; tj -= 2) {
-    if (tj >= 1) fetch(tj - 1, s1);
-    column(tj, s0);
-    if (tj < 1) break;
-    if (tj >= 2) fetch(tj - 2, s0);
-    column(tj - 1, s1);
+  if constexpr (NTM <= 16) {
+    Strip s0, s1;
+    fetch(NT - 1, s0);
+    wsync();
+    for (int tj = NT - 1; tj >= 0; tj -= 2) {
+      if (tj >= 1) fetch(tj - 1, s1);
+      column(tj, s0);
+      if (tj < 1) break;
+      if (tj >= 2) fetch(tj - 2, s0);
+      column(tj - 1, s1);
+    }
+  } else {
+    Strip s0;
+    wsync();
+    for (int tj = NT - 1; tj >= 0; tj--) {
+      fetch(tj, s0);
+      column(tj, s0);
+    }
   }
 }
 

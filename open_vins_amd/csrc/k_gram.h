@@ -719,9 +719,10 @@ __global__ void __launch_bounds__(1024) k_gram_reduce(int NT, int nparts, const 
 // below k.  The publish buffers alternate, so step k + 1 never overwrites what a slow wavefront still reads.  Finished rows
 // collect in LDS and leave in bursts of 16 rows written by all 16 wavefronts: a global store costs the issuing wavefront
 // ~600 cycles, which on the owner's critical path was most of the step (measured: 2.0 us per row, 0.4 ms per factorisation).
-constexpr int CH_NB = 8; // blocks per dimension: LD <= 256; the kernel is instantiated per block count (a run-time count puts every
+constexpr int CH_NB = 8; // blocks per dimension of k_gram_chol: LD <= 256; the kernels are instantiated per block count (a run-time count puts every
                          // multiply-add behind its own scalar branch)
 constexpr int CH_FLUSH = 16;
+constexpr int PCH_NB = 12; // k_gram_pchol: LD <= 384 (beyond 9 blocks the register blocks of a thread no longer fit 128 registers and spill: slower per step, correct)
 __device__ __forceinline__ double rsqrt_f64(double d) {
   double y = __builtin_amdgcn_rsq(d);
   const double h = 0.5 * d;
@@ -837,8 +838,8 @@ __global__ void __launch_bounds__(1024) k_gram_chol(int D, int LD, int LG, const
 template <int NB>
 __global__ void __launch_bounds__(1024) k_gram_pchol(int D, int LD, int LG, const double *G, double *out, int32_t *n_dropped, double tol) {
   extern __shared__ double rstore[]; // [2][CH_FLUSH][LD] finished rows on their way to memory
-  __shared__ __attribute__((aligned(16))) double rowbuf[2][32 * CH_NB];
-  __shared__ double alive[32 * CH_NB]; // 1 = column not eliminated yet (the carried column LD - 1 stays 1)
+  __shared__ __attribute__((aligned(16))) double rowbuf[2][32 * PCH_NB];
+  __shared__ double alive[32 * PCH_NB]; // 1 = column not eliminated yet (the carried column LD - 1 stays 1)
   __shared__ double pivinv[2];         // 1 / sqrt(pivot) of the step
   __shared__ int piv[2];               // its column, -1 = stop
   const int tid = threadIdx.x, ti = tid >> 5, tj = tid & 31, lane = tid & 63;
@@ -854,22 +855,23 @@ __global__ void __launch_bounds__(1024) k_gram_pchol(int D, int LD, int LG, cons
         if (i < LD && j < LD) a[bi][bj] = G[(size_t)i * LG + j];
       }
     }
-  if (tid < 32 * CH_NB) alive[tid] = tid < LD ? 1.0 : 0.0, rowbuf[0][tid] = 0.0, rowbuf[1][tid] = 0.0;
+  if (tid < 32 * PCH_NB) alive[tid] = tid < LD ? 1.0 : 0.0, rowbuf[0][tid] = 0.0, rowbuf[1][tid] = 0.0;
   // wavefront 0: the diagonal of the live columns, entry j = lane + 64 q in dg<q>; eliminated or never eligible: DEAD
-  // (four named registers, not an array: the pivot's value is selected by a run-time q, and an indexed array would live in scratch —
-  // on the critical path of every step)
+  // (named registers, not an array: the pivot's value is selected by a run-time q, and an indexed array would live in scratch —
+  // on the critical path of every step; dg4 / dg5 serve columns 256 .. 383 and stay DEAD in the instantiations of up to 8 blocks)
   constexpr double DEAD = -1.0e300;
-  double dg0 = DEAD, dg1 = DEAD, dg2 = DEAD, dg3 = DEAD, dmax0 = 0.0;
-  // The live column with the largest diagonal entry (ties: the lowest column).  The comparison key is 32 bits: exponent and twelve
-  // mantissa bits of the entry with the column in the low byte — a pivot CHOICE within 2^-12 of the maximum is as good as the maximum,
+  double dg0 = DEAD, dg1 = DEAD, dg2 = DEAD, dg3 = DEAD, dg4 = DEAD, dg5 = DEAD, dmax0 = 0.0;
+  // The live column with the largest diagonal entry (ties: the lowest column).  The comparison key is 32 bits: exponent and eleven
+  // mantissa bits of the entry with the column in the low nine bits — a pivot CHOICE within 2^-12 of the maximum is as good as the maximum,
   // the pivot's VALUE is then read exactly.  Wavefront maximum on the DPP network (four row shifts, one readlane per row) instead of
   // six rounds of 64-bit ds_bpermute: this reduction is on the critical path of every step.
   // (a macro, not a lambda: captured by reference the four registers become a closure in memory, and the selects below turn into
   // indexed scratch accesses)
-#define OVG_PCHOL_KEY(v, q) ((v) > 0.0 ? ((__double2hiint(v) & ~0xFF) | (255 - (lane + 64 * (q)))) : 0)
+#define OVG_PCHOL_KEY(v, q) ((v) > 0.0 ? ((__double2hiint(v) & ~0x1FF) | (511 - (lane + 64 * (q)))) : 0)
 #define OVG_PCHOL_NEXT_PIVOT(slot, first)                                                                                              \
   {                                                                                                                                    \
     int key = max(max(OVG_PCHOL_KEY(dg0, 0), OVG_PCHOL_KEY(dg1, 1)), max(OVG_PCHOL_KEY(dg2, 2), OVG_PCHOL_KEY(dg3, 3)));               \
+    if (NB > 8) key = max(key, max(OVG_PCHOL_KEY(dg4, 4), OVG_PCHOL_KEY(dg5, 5)));                                                     \
     key = max(key, __builtin_amdgcn_update_dpp(0, key, 0x111, 0xF, 0xF, false)); /* row_shr:1 .. 8: lane 15 of a row = the row's max */ \
     key = max(key, __builtin_amdgcn_update_dpp(0, key, 0x112, 0xF, 0xF, false));                                                       \
     key = max(key, __builtin_amdgcn_update_dpp(0, key, 0x114, 0xF, 0xF, false));                                                       \
@@ -877,14 +879,15 @@ __global__ void __launch_bounds__(1024) k_gram_pchol(int D, int LD, int LG, cons
     const int k01 = max(__builtin_amdgcn_readlane(key, 15), __builtin_amdgcn_readlane(key, 31));                                       \
     const int k23 = max(__builtin_amdgcn_readlane(key, 47), __builtin_amdgcn_readlane(key, 63));                                       \
     const int kmax = max(k01, k23); /* wave-uniform (scalar registers) */                                                              \
-    const int j = 255 - (kmax & 0xFF), jq = j >> 6, jl = j & 63;                                                                       \
-    const double dsel = jq == 0 ? dg0 : (jq == 1 ? dg1 : (jq == 2 ? dg2 : dg3));                                                       \
+    const int j = 511 - (kmax & 0x1FF), jq = j >> 6, jl = j & 63;                                                                      \
+    const double dsel = jq == 0 ? dg0 : (jq == 1 ? dg1 : (jq == 2 ? dg2 : (jq == 3 ? dg3 : (jq == 4 ? dg4 : dg5))));                   \
     const double d = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(dsel), jl), __builtin_amdgcn_readlane(__double2loint(dsel), jl)); \
     if (first) dmax0 = d;                                                                                                              \
     const bool go = kmax != 0 && d > tol * dmax0 && d > 0.0;                                                                           \
     const bool mine = go && lane == jl;                                                                                                \
     dg0 = (mine && jq == 0) ? DEAD : dg0, dg1 = (mine && jq == 1) ? DEAD : dg1;                                                        \
     dg2 = (mine && jq == 2) ? DEAD : dg2, dg3 = (mine && jq == 3) ? DEAD : dg3;                                                        \
+    dg4 = (mine && jq == 4) ? DEAD : dg4, dg5 = (mine && jq == 5) ? DEAD : dg5;                                                        \
     if (lane == 0) piv[slot] = go ? j : -1, pivinv[slot] = go ? rsqrt_f64(d) : 0.0;                                                    \
   }
   if (wv == 0) {
@@ -892,6 +895,8 @@ __global__ void __launch_bounds__(1024) k_gram_pchol(int D, int LD, int LG, cons
     if (lane + 64 < D) dg1 = G[(size_t)(lane + 64) * LG + lane + 64];
     if (lane + 128 < D) dg2 = G[(size_t)(lane + 128) * LG + lane + 128];
     if (lane + 192 < D) dg3 = G[(size_t)(lane + 192) * LG + lane + 192];
+    if (NB > 8 && lane + 256 < D) dg4 = G[(size_t)(lane + 256) * LG + lane + 256];
+    if (NB > 8 && lane + 320 < D) dg5 = G[(size_t)(lane + 320) * LG + lane + 320];
     OVG_PCHOL_NEXT_PIVOT(0, true)
   }
   __syncthreads();
@@ -926,10 +931,14 @@ __global__ void __launch_bounds__(1024) k_gram_pchol(int D, int LD, int LG, cons
         const double r0 = rq[0], r1 = rq[64], r2 = rq[128], r3 = rq[192];
         dg0 = dg0 != DEAD ? fma(-r0, r0, dg0) : dg0, dg1 = dg1 != DEAD ? fma(-r1, r1, dg1) : dg1;
         dg2 = dg2 != DEAD ? fma(-r2, r2, dg2) : dg2, dg3 = dg3 != DEAD ? fma(-r3, r3, dg3) : dg3;
+        if (NB > 8) {
+          const double r4 = rq[256], r5 = rq[320];
+          dg4 = dg4 != DEAD ? fma(-r4, r4, dg4) : dg4, dg5 = dg5 != DEAD ? fma(-r5, r5, dg5) : dg5;
+        }
       }
       if (lane == 0) alive[p] = 0.0;
       OVG_PCHOL_NEXT_PIVOT((k + 1) & 1, false)
-    } else if (wv <= 4) { // row k of R, original column order, into the burst buffer
+    } else if (tid - 64 < LD) { // row k of R, original column order, into the burst buffer
       const int j = tid - 64;
       if (j < LD) rstore[((size_t)((k / CH_FLUSH) & 1) * CH_FLUSH + (k % CH_FLUSH)) * LD + j] = rb[(((j >> 5) >> 1) * 32 + (j & 31)) * 2 + ((j >> 5) & 1)];
     }

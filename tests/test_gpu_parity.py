@@ -335,7 +335,8 @@ def test_mode_a_compressed_system(Updater, oracle, route):
     up.close()
 
 
-@pytest.mark.parametrize("cfg,F,track", [(1, 3, "full"), (1, 12, "ragged"), (2, 40, "full"), (2, 400, "ragged"), (3, 600, "full"), (4, 300, "full")])
+@pytest.mark.parametrize("cfg,F,track", [(1, 3, "full"), (1, 12, "ragged"), (2, 40, "full"), (2, 400, "ragged"), (3, 600, "full"), (4, 300, "full"),
+                                         (5, 60, "full"), (5, 3, "ragged")])  # configs[4]'s geometry: D = 356 columns (round 4: k_gram_pchol<12>, k_unwhiten<24>)
 def test_mode_a_pivoted_factor_shapes(Updater, oracle, cfg, F, track):
     """Mode A's default — the diagonally pivoted Cholesky factor of the whitened stack's Gram matrix (k_gram_pchol), un-whitened —
     on short, ragged and tall stacks, mono / stereo / four cameras: the stack of an MSCKF update is rank deficient (gauge directions;
