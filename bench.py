@@ -414,7 +414,12 @@ def shim_dropin_ms(F):
     try:
         p = subprocess.run([exe, "--time", str(int(F)), "9"], capture_output=True, text=True, timeout=300)
         line = [l for l in p.stdout.splitlines() if l.startswith("{")]
-        return json.loads(line[-1]) if line else {"error": (p.stdout + p.stderr)[-300:]}
+        res = json.loads(line[-1]) if line else {"error": (p.stdout + p.stderr)[-300:]}
+        # the same update with tracks and state RESIDENT on the device (ovgpu_tracks_*): only the newest frame's observations go in
+        p = subprocess.run([exe, "--time-resident", str(int(F)), "5"], capture_output=True, text=True, timeout=300)
+        line = [l for l in p.stdout.splitlines() if l.startswith("{")]
+        res["resident"] = json.loads(line[-1]) if line else {"error": (p.stdout + p.stderr)[-300:]}
+        return res
     except Exception as e:  # noqa: BLE001
         return {"error": str(e)}
 

@@ -114,6 +114,15 @@ static double median(std::vector<double> v) {
   return v[v.size() / 2];
 }
 
+// `selftest --time-resident [F] [reps]`: the same update with the tracks RESIDENT on the device (ovgpu_tracks_*: the role of
+// ov_core::FeatureDatabase) and the state resident (ovgpu_set_state once; a live caller keeps it current with
+// ovgpu_state_augment_clone / _marginalize / _propagate).  Per camera frame the host sends only that frame's observations (20 bytes each);
+// per update it names the tracks, the device assembles the batch (clean_old_measurements by exact clone time included), updates, and
+// returns dx / P'.  Timed per update: append of the newest frame + ovgpu_tracks_to_features + ovgpu_msckf_update (mode B).
+struct ResidentTimes {
+  double append_ms, gather_ms, update_ms;
+};
+
 // what shim/ovgpu_shim_common.h: append_track does, on the stand-in containers
 static void flatten_tracks(const std::vector<RefShapedFeature> &feats, const CloneIndex &clones, FlatFeatures &ff) {
   size_t n = 0;
@@ -135,7 +144,7 @@ static void flatten_tracks(const std::vector<RefShapedFeature> &feats, const Clo
   }
 }
 
-static int time_dropin(int F, int reps, bool gpu = true) {
+static int time_dropin(int F, int reps, bool gpu = true, bool resident = false) {
   FlatState fs;
   const double q[4] = {0, 0, 0, 1}, zero[3] = {0, 0, 0}, intr[8] = {458, 457, 367, 248, 0, 0, 0, 0};
   const double p_cam1[3] = {-0.11, 0, 0}; // p_IinC of the second camera: 11 cm baseline
@@ -177,6 +186,72 @@ static int time_dropin(int F, int reps, bool gpu = true) {
     }
   }
   const CloneIndex clones(fs.clone_times);
+  if (resident) {
+    ovgpu_options o;
+    ovgpu_default_options(&o);
+    o.chi2_multipler = 1.0, o.sigma_pix = 1.0;
+    Context ctx(o);
+    const ovgpu_state_view sv = fs.view();
+    ctx.check(ovgpu_set_state(ctx.get(), &sv), "ovgpu_set_state");
+    // the observations of every camera frame, as a front end would hand them over (one call per clone time and camera)
+    struct Frame {
+      std::vector<int64_t> id;
+      std::vector<int32_t> cam;
+      std::vector<float> uv, uvn;
+    };
+    std::vector<Frame> frames((size_t)C * K);
+    std::vector<int64_t> ids((size_t)F);
+    for (int f = 0; f < F; f++) {
+      ids[f] = 1000 + f;
+      for (const auto &pair : feats[f].timestamps) {
+        const auto &uv = feats[f].uvs.at(pair.first), &un = feats[f].uvs_norm.at(pair.first);
+        for (size_t i = 0; i < pair.second.size(); i++) {
+          const int32_t ci = clones.find(pair.second[i]);
+          if (ci < 0) continue; // (the stale observation: it would only be filtered again)
+          Frame &fr = frames[(size_t)ci * K + pair.first];
+          fr.id.push_back(ids[f]), fr.cam.push_back((int32_t)pair.first);
+          fr.uv.push_back(uv[i].d[0]), fr.uv.push_back(uv[i].d[1]), fr.uvn.push_back(un[i].d[0]), fr.uvn.push_back(un[i].d[1]);
+        }
+      }
+    }
+    std::vector<int32_t> status(F);
+    std::vector<double> pG(3 * (size_t)F), dx(fs.N), P1((size_t)fs.N * fs.N);
+    std::vector<double> t_app, t_gat, t_upd;
+    int used = 0;
+    size_t n_last = 0;
+    for (int it = 0; it < reps + 1; it++) {
+      ctx.check(ovgpu_tracks_create(ctx.get(), F + 16, 2 * C + 4), "ovgpu_tracks_create");
+      for (int ci = 0; ci + 1 < C; ci++)
+        for (int k = 0; k < K; k++) {
+          const Frame &fr = frames[(size_t)ci * K + k];
+          if (!fr.id.empty()) ctx.check(ovgpu_tracks_append(ctx.get(), fs.clone_times[ci], (int32_t)fr.id.size(), fr.id.data(), fr.cam.data(), fr.uv.data(), fr.uvn.data()), "ovgpu_tracks_append");
+        }
+      ctx.check(ovgpu_reset_state(ctx.get()), "ovgpu_reset_state");
+      ctx.check(ovgpu_synchronize(ctx.get()), "ovgpu_synchronize");
+      const double t0 = now_ms();
+      n_last = 0;
+      for (int k = 0; k < K; k++) { // the newest camera frame
+        const Frame &fr = frames[(size_t)(C - 1) * K + k];
+        n_last += fr.id.size();
+        if (!fr.id.empty()) ctx.check(ovgpu_tracks_append(ctx.get(), fs.clone_times[C - 1], (int32_t)fr.id.size(), fr.id.data(), fr.cam.data(), fr.uv.data(), fr.uvn.data()), "ovgpu_tracks_append");
+      }
+      const double t1 = now_ms();
+      ctx.check(ovgpu_tracks_to_features(ctx.get(), F, ids.data(), fs.clone_times.data()), "ovgpu_tracks_to_features");
+      const double t2 = now_ms();
+      ovgpu_update_stats st;
+      ctx.check(ovgpu_msckf_update(ctx.get(), status.data(), nullptr, nullptr, pG.data(), dx.data(), P1.data(), &st), "ovgpu_msckf_update");
+      const double t3 = now_ms();
+      if (it >= 1) t_app.push_back(t1 - t0), t_gat.push_back(t2 - t1), t_upd.push_back(t3 - t2);
+      used = 0;
+      for (int f = 0; f < F; f++) used += status[f] == OVGPU_FEAT_USED;
+    }
+    const double a = median(t_app), g = median(t_gat), u = median(t_upd);
+    std::printf("{\"what\": \"resident path from C++: tracks and state on the device, per update the newest frame's observations in, dx / P' out\", "
+                "\"features\": %d, \"observations_newest_frame\": %zu, \"features_used\": %d, \"reps\": %d, \"append_ms\": %.4f, "
+                "\"tracks_to_features_ms\": %.4f, \"mode_b_call_ms\": %.4f, \"resident_mode_b_ms\": %.4f}\n",
+                F, n_last, used, reps, a, g, u, a + g + u);
+    return used > F / 2 ? 0 : 1;
+  }
   if (!gpu) { // `--time-host`: the flattening alone (no device needed)
     std::vector<double> t_flat;
     int M = 0;
@@ -235,9 +310,10 @@ static int time_dropin(int F, int reps, bool gpu = true) {
 }
 
 int main(int argc, char **argv) {
-  if (argc > 1 && (std::strcmp(argv[1], "--time") == 0 || std::strcmp(argv[1], "--time-host") == 0)) {
+  if (argc > 1 && (std::strcmp(argv[1], "--time") == 0 || std::strcmp(argv[1], "--time-host") == 0 || std::strcmp(argv[1], "--time-resident") == 0)) {
     try {
-      return time_dropin(argc > 2 ? std::atoi(argv[2]) : 2000, argc > 3 ? std::atoi(argv[3]) : 9, std::strcmp(argv[1], "--time") == 0);
+      return time_dropin(argc > 2 ? std::atoi(argv[2]) : 2000, argc > 3 ? std::atoi(argv[3]) : 9, std::strcmp(argv[1], "--time-host") != 0,
+                         std::strcmp(argv[1], "--time-resident") == 0);
     } catch (const std::exception &e) {
       std::printf("shim timing FAILED: %s\n", e.what());
       return 3;

@@ -162,3 +162,9 @@ def test_shim_timing_mode_reports_the_drop_in_cost():
     for k in ("flatten_ms", "upload_ms", "mode_a_call_ms", "mode_b_call_ms", "shim_mode_a_ms", "shim_mode_b_ms"):
         assert d[k] > 0
     assert abs(d["shim_mode_a_ms"] - (d["flatten_ms"] + d["upload_ms"] + d["mode_a_call_ms"])) < 1e-3
+    # ... and the resident form: tracks appended frame by frame, the batch assembled on the device
+    p = subprocess.run([exe, "--time-resident", "300", "2"], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    r = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert r["features"] == 300 and r["features_used"] == d["features_used"]  # the device-assembled batch gates like the flattened one
+    assert r["observations_newest_frame"] > 300 and r["resident_mode_b_ms"] > 0

@@ -5,8 +5,8 @@ TAG=${1:-io}
 OUT=/root/repo/gpurun_out/$TAG
 mkdir -p $OUT
 cd /root/repo
-timeout 600 python -m pytest tests -q -m gpu -x -p no:cacheprovider -k "not cfg5_geometry and not headline_closed_loop and not 10k_features and not fp32_gram_variant and not cfg4_shard and not long_loop and not rpng_sim" 2>&1 | tail -6 > $OUT/pytest_gpu.txt
-timeout 300 python bench.py --no-cpu-baseline --steps 200 --warmup 10 > $OUT/bench.json 2> $OUT/bench.err
+timeout 600 python -m pytest tests/test_shim.py tests/test_gpu_parity.py -q -m gpu -x -p no:cacheprovider -k "shim or track" 2>&1 | tail -6 > $OUT/pytest_gpu.txt
+timeout 300 python bench.py --no-cpu-baseline --steps 200 --warmup 10 --no-extras > $OUT/bench.json 2> $OUT/bench.err
 timeout 120 open_vins_amd/shim/selftest --time 2000 9 > $OUT/shim_time.json 2>> $OUT/bench.err
 timeout 120 open_vins_amd/shim/selftest --time 800 9 >> $OUT/shim_time.json 2>> $OUT/bench.err
 cat $OUT/pytest_gpu.txt
@@ -19,3 +19,5 @@ print("shim", d.get("shim"))
 print("configs3_single_gpu", d.get("configs3_single_gpu",{}).get("ms_per_step"), "scaling_model", d.get("scaling_model",{}).get("predicted_ms"))
 PY
 cat $OUT/shim_time.json; tail -3 $OUT/bench.err
+timeout 120 open_vins_amd/shim/selftest --time-resident 2000 5 2>> $OUT/bench.err | tee -a $OUT/shim_time.json
+timeout 120 open_vins_amd/shim/selftest --time-resident 800 5 2>> $OUT/bench.err | tee -a $OUT/shim_time.json
