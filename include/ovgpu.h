@@ -143,7 +143,9 @@ typedef struct {
                              /* cannot reject it.  Accept / reject sets, dx and P' are those of the full gate; the chi2 output   */
                              /* of such a feature is the BOUND (>= the reference's statistic, <= chi2_thresh);                   */
                              /* ovgpu_update_stats::n_gate_bound counts them.  1: every gate matrix is formed and factored and   */
-                             /* every chi2 output is the reference's statistic                                                 */
+                             /* every chi2 output is the reference's statistic.  The bound is used by the fused per-feature    */
+                             /* kernels (MSCKF features in a global representation, tracks of up to 232 observations); the      */
+                             /* general kernel (anchored representations, SLAM, delayed initialisation) always factors          */
   int32_t no_timing;         /* 1: no HIP events around the stages           */
   int32_t no_fast_feature_kernel; /* 1: always the general per-feature       */
                              /* kernel (k_system) instead of the MSCKF fast  */
