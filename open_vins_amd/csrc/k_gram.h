@@ -835,6 +835,7 @@ __global__ void __launch_bounds__(1024) k_gram_chol(int D, int LD, int LG, const
 // others apply the rank-one update; two workgroup barriers per step.  The factorisation stops at the first pivot that is not above
 // tol x the largest diagonal entry (the rest of the Schur complement is rounding noise of the Gram sum): the remaining rows are zero.
 // ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void pchol_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 template <int NB>
 __global__ void __launch_bounds__(1024) k_gram_pchol(int D, int LD, int LG, const double *G, double *out, int32_t *n_dropped, double tol) {
   extern __shared__ double rstore[]; // [2][CH_FLUSH][LD] finished rows on their way to memory
@@ -924,7 +925,7 @@ __global__ void __launch_bounds__(1024) k_gram_pchol(int D, int LD, int LG, cons
           }
         }
     }
-    __syncthreads();
+    pchol_lds_barrier(); // LDS traffic only: __syncthreads() would also drain the burst's global stores (vmcnt(0)) once every 16 steps
     if (wv == 0) { // the diagonal copy, then the next pivot (its column leaves the live set now: row k + 1 gets a zero there)
       { // column lane + 64 q = block 2 q + (lane >> 5), offset lane & 31
         const double *rq = rb + (lane & 31) * 2 + (lane >> 5);
@@ -961,7 +962,7 @@ __global__ void __launch_bounds__(1024) k_gram_pchol(int D, int LD, int LG, cons
         }
       }
     }
-    __syncthreads();
+    pchol_lds_barrier(); // LDS traffic only: __syncthreads() would also drain the burst's global stores (vmcnt(0)) once every 16 steps
     if ((k % CH_FLUSH) == CH_FLUSH - 1 || k == D - 1) {
       const int k0 = (k / CH_FLUSH) * CH_FLUSH, n = (k - k0 + 1) * LD;
       const double *src = rstore + (size_t)((k / CH_FLUSH) & 1) * CH_FLUSH * LD;
