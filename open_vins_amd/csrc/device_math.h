@@ -84,17 +84,45 @@ __device__ __forceinline__ void store_m3(double *p, const M3 &m) {
 __device__ __forceinline__ void store_v3(double *p, const V3 &v) { p[0] = v.x, p[1] = v.y, p[2] = v.z; }
 
 // ---------------------------------------------------------------------------
-// wavefront (64 lanes) all-reduce by xor butterfly: every lane ends with the sum
+// wavefront (64 lanes) all-reduce: every lane ends with the sum.
+// Round 4: on the DPP network instead of an xor butterfly of __shfl_xor.  A shuffle of a double is two ds_bpermute_b32 — the LDS
+// path, ~100 cycles of latency each level, six dependent levels: ~1.4 k cycles per reduction, and the wavefront-per-feature kernels
+// (k_triangulate: 23 reductions per Gauss-Newton pass structure, k_feat_vt, the chi2 tail of the gate) are chains of them.  DPP
+// moves are plain vector instructions: pairs (quad_perm), quads, half rows (row_half_mirror), rows (row_mirror), then row_bcast15 /
+// row_bcast31 carry the row sums upwards; lane 63 holds the total and two v_readlane make it wave-uniform.  The order of the
+// additions is fixed (pairs, quads, eights, rows, row pairs, halves): bit-reproducible, and different from the butterfly's.
 // ---------------------------------------------------------------------------
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ double dpp_mov_f64(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_bcast63(double v) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
+  v += dpp_mov_f64<0xB1, 0xF>(v);  // quad_perm [1, 0, 3, 2]
+  v += dpp_mov_f64<0x4E, 0xF>(v);  // quad_perm [2, 3, 0, 1]
+  v += dpp_mov_f64<0x141, 0xF>(v); // row_half_mirror
+  v += dpp_mov_f64<0x140, 0xF>(v); // row_mirror: every lane of a row holds the row's sum
+  v += dpp_mov_f64<0x142, 0xA>(v); // row_bcast15 into rows 1 and 3 (the other rows add 0)
+  v += dpp_mov_f64<0x143, 0xC>(v); // row_bcast31 into rows 2 and 3: lane 63 = the total
+  return wave_bcast63(v);
+}
+// (the same network; the rows a broadcast does not reach keep their value: fmax(v, v))
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ double dpp_mov_keep_f64(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(__double2loint(v), __double2loint(v), CTRL, ROW_MASK, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), CTRL, ROW_MASK, 0xF, false);
+  return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
-  return v;
+  v = fmax(v, dpp_mov_f64<0xB1, 0xF>(v));
+  v = fmax(v, dpp_mov_f64<0x4E, 0xF>(v));
+  v = fmax(v, dpp_mov_f64<0x141, 0xF>(v));
+  v = fmax(v, dpp_mov_f64<0x140, 0xF>(v));
+  v = fmax(v, dpp_mov_keep_f64<0x142, 0xA>(v));
+  v = fmax(v, dpp_mov_keep_f64<0x143, 0xC>(v));
+  return wave_bcast63(v);
 }
 
 // ---------------------------------------------------------------------------
