@@ -25,6 +25,17 @@
 #pragma once
 #include "k_feat.h"
 
+// Cycle counters of the factor / follower wavefronts (p.dbg, tools/dev_tail_ab.py): a developer build only (-DOVG_CHOL_PROF).  clock64() is
+// s_memtime — a scalar memory instruction on the same counter as the LDS hand-overs of the chain — and its 64-bit temporaries cost
+// registers in kernels that are already out of them.
+#ifdef OVG_CHOL_PROF
+#define OVG_CHOL_CLOCK() clock64()
+#define OVG_CHOL_DBG(p) ((p).dbg)
+#else
+#define OVG_CHOL_CLOCK() 0LL
+#define OVG_CHOL_DBG(p) ((long long *)nullptr)
+#endif
+
 namespace ovg {
 namespace chol {
 
@@ -109,7 +120,7 @@ __global__ void __launch_bounds__(64 * (CH_FW + 1), 4) k_chol_factor(CholParams 
 
   if (wv == CH_FW) {
     // ------------------------------------------------------------------ the diagonal chain: one wavefront, no tiles of its own
-    const long long t_begin = clock64();
+    const long long t_begin = OVG_CHOL_CLOCK();
     long long t_diag = 0;
     for (int k = 0; k < TM; k++) {
       // Look-ahead: the owner of tile (k, k) brings it up to date FIRST in the trailing update of step k - 1, parks it in st[0] and
@@ -117,7 +128,7 @@ __global__ void __launch_bounds__(64 * (CH_FW + 1), 4) k_chol_factor(CholParams 
       // then: the panel solve of step k - 1 read st[1] before barrier B2, which this wavefront has passed.)
       while (__hip_atomic_load(&diag_ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= k) __builtin_amdgcn_s_sleep(1);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      const long long t_d0 = clock64();
+      const long long t_d0 = OVG_CHOL_CLOCK();
       d4 sv, ev;
 #pragma unroll
       for (int q = 0; q < 4; q++) sv[q] = st[0][(g + 4 * q) * 16 + cl];
@@ -126,7 +137,7 @@ __global__ void __launch_bounds__(64 * (CH_FW + 1), 4) k_chol_factor(CholParams 
       if (bad && lane == 0) __hip_atomic_store(p.flags, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // written through: a consumer may start before this kernel ends
 #pragma unroll
       for (int q = 0; q < 4; q++) st[1][cl * 16 + g + 4 * q] = ev[q]; // U^-T in accumulator layout -> U^-1 row-major
-      t_diag += clock64() - t_d0;
+      t_diag += OVG_CHOL_CLOCK() - t_d0;
       lds_barrier(); // B0 (kept so that every wavefront counts the same barriers)
       lds_barrier(); // B1: U_kk^-1 is in st[1]
       if (k > 0) arrive(k - 1);
@@ -143,7 +154,7 @@ __global__ void __launch_bounds__(64 * (CH_FW + 1), 4) k_chol_factor(CholParams 
       lds_barrier(); // B2
     }
     arrive(TM - 1);
-    if (p.dbg && lane == 0) p.dbg[300] += clock64() - t_begin, p.dbg[301] += t_diag, p.dbg[302] += 1;
+    if (OVG_CHOL_DBG(p) && lane == 0) p.dbg[300] += OVG_CHOL_CLOCK() - t_begin, p.dbg[301] += t_diag, p.dbg[302] += 1;
     return;
   }
 
@@ -325,18 +336,18 @@ __global__ void __launch_bounds__(64 * (CH_FW + 1), 4) k_chol_factor2(CholParams
     // ------------------------------------------------------------------ the diagonal chain: LDS in, LDS out, nothing else
     __builtin_amdgcn_s_setprio(3); // ahead of the three tile wavefronts on this SIMD whenever it has an instruction ready
     long long c_wait = 0, c_fact = 0;
-    const long long c_begin = clock64();
+    const long long c_begin = OVG_CHOL_CLOCK();
     for (int k = 0; k < TM; k++) {
-      const long long c0 = clock64();
+      const long long c0 = OVG_CHOL_CLOCK();
       if (!wait_for(0, k + 1)) return;
-      const long long c1 = clock64();
+      const long long c1 = OVG_CHOL_CLOCK();
       c_wait += c1 - c0;
       d4 sv, ev;
 #pragma unroll
       for (int q = 0; q < 4; q++) sv[q] = st0[(g + 4 * q) * 16 + cl];
       __builtin_amdgcn_wave_barrier(); // st0 becomes the factorisation's scratch
       const bool bad = feat::diag_tile_factor_blk(sv, ev, st0, lane, diag0 ? diag0 + 16 * k : nullptr, p.pivot_tol, D - 16 * k);
-      c_fact += clock64() - c1;
+      c_fact += OVG_CHOL_CLOCK() - c1;
       if (bad && lane == 0) __hip_atomic_store(p.flags, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (k >= 3 && !wait_for(32 + k - 3, CH_FW)) return; // (long satisfied: the buffers of step k - 3 are free)
       double *s1 = st1 + (k % 3) * 256, *sk = su + (k % 3) * 256;
@@ -345,7 +356,7 @@ __global__ void __launch_bounds__(64 * (CH_FW + 1), 4) k_chol_factor2(CholParams
       publish(1, k + 1);
       // (a store instruction holds its wavefront for ~600 cycles, and this is the chain: tile wavefronts write U_kk and U_kk^-1 out)
     }
-    if (p.dbg && lane == 0) p.dbg[310] += clock64() - c_begin, p.dbg[311] += c_wait, p.dbg[312] += c_fact, p.dbg[313] += 1;
+    if (OVG_CHOL_DBG(p) && lane == 0) p.dbg[310] += OVG_CHOL_CLOCK() - c_begin, p.dbg[311] += c_wait, p.dbg[312] += c_fact, p.dbg[313] += 1;
     return;
   }
 
@@ -388,7 +399,13 @@ __global__ void __launch_bounds__(64 * (CH_FW + 1), 4) k_chol_factor2(CholParams
   auto store_row_tile = [&](int k, int j, const double *tile, bool to_followers) {
     const bool whole = 16 * k + 16 <= D && 16 * j + 16 <= D;
     double w[4], t[4];
-    const int cc = lane >> 2, r0 = 4 * (lane & 3);
+    // The lane's part of every address below is recomputed here, from a value the compiler cannot see through: hoisted out of the step
+    // loop, the ten per-lane base pointers of this function were spilled, and a scratch reload in front of a store is an
+    // s_waitcnt vmcnt(0) — a wait for the previous fire-and-forget stores, on the path that must never wait for them.
+    int lane_o = lane;
+    asm volatile("" : "+v"(lane_o));
+    const int g = lane_o >> 4, cl = lane_o & 15;
+    const int cc = lane_o >> 2, r0 = 4 * (lane_o & 3);
     if (whole) { // a quarter row per lane: two 16-byte stores instead of four 8-byte ones (a store costs its wavefront ~400 cycles whatever its width)
       typedef double dd2 __attribute__((ext_vector_type(2)));
       const dd2 lo = *reinterpret_cast<const dd2 *>(tile + cc * 16 + r0), hi = *reinterpret_cast<const dd2 *>(tile + cc * 16 + r0 + 2);
@@ -430,9 +447,14 @@ __global__ void __launch_bounds__(64 * (CH_FW + 1), 4) k_chol_factor2(CholParams
     const double *pn = panel + (size_t)(kk & 1) * CH_TMAX * 256;
     if (kk > 0) arrive(kk - 1); // the stores of row kk - 1 were issued a step ago
     if (wv == kk && kk + 1 < TM) store_row_tile(kk, kk + 1, pn + (size_t)(kk + 1) * 256, true);
-#pragma unroll
-    for (int s = 2; s < 9; s++)
-      if (tij[s] >= 0 && CTI(s) == kk) store_row_tile(kk, CTJ(s), pn + (size_t)CTJ(s) * 256, true);
+    // this wavefront's far tiles of row kk, found by arithmetic instead of by walking its (unrolled) slots: ONE copy of the store code
+    // and no hoisted address per slot (unrolled seven times the addresses of all copies were computed up front and spilled — 244 bytes
+    // of scratch whose reloads wait on vmcnt(0), i.e. on the very stores this path must never wait for)
+#pragma unroll 1
+    for (int j = kk + 2; j < TM; j++) {
+      const int f = (j - 1) * (j - 2) / 2 + kk; // far tile number of (kk, j): column j >= 2 holds rows 0 .. j-2
+      if (f % CH_FW == wv) store_row_tile(kk, j, pn + (size_t)j * 256, true);
+    }
     if (wv == (kk + 5) % CH_FW) store_row_tile(kk, kk, su + (kk % 3) * 256, false); // U_kk -> Y and L
     if (wv == (kk + 10) % CH_FW) {                                                 // U_kk^-1 -> memory for the followers
       const double *s1 = st1 + (kk % 3) * 256;
@@ -446,11 +468,11 @@ __global__ void __launch_bounds__(64 * (CH_FW + 1), 4) k_chol_factor2(CholParams
     if (lane == 0) (void)__hip_atomic_fetch_add(sync + 32 + kk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   };
   long long t_uinv = 0, t_st = 0, t_panel = 0, t_cnt = 0, t_trail = 0;
-  const long long t_begin = clock64();
+  const long long t_begin = OVG_CHOL_CLOCK();
   for (int k = 0; k < TM; k++) {
-    const long long t0 = clock64();
+    const long long t0 = OVG_CHOL_CLOCK();
     if (!wait_for(1, k + 1, wv != k)) return; // (wavefront k is the one the chain waits for)
-    const long long t1 = clock64();
+    const long long t1 = OVG_CHOL_CLOCK();
     t_uinv += t1 - t0;
     double *pan = panel + (size_t)(k & 1) * CH_TMAX * 256;
     int wrote = 0;
@@ -473,7 +495,7 @@ __global__ void __launch_bounds__(64 * (CH_FW + 1), 4) k_chol_factor2(CholParams
       for (int q = 0; q < 4; q++) st0[(g + 4 * q) * 16 + cl] = av[q];
       publish(0, k + 2);
       __builtin_amdgcn_s_setprio(0);
-      if (p.dbg && lane == 0) p.dbg[340] += clock64() - t1, p.dbg[341] += t1 - t0, p.dbg[342] += 1;
+      if (OVG_CHOL_DBG(p) && lane == 0) p.dbg[340] += OVG_CHOL_CLOCK() - t1, p.dbg[341] += t1 - t0, p.dbg[342] += 1;
       acc[1] = av;
       if (k >= 2 && !wait_for(32 + k - 2, CH_FW)) return; // every wavefront is done with row panel k - 2 (long satisfied): its buffer is free
       double *pt = pan + (size_t)(k + 1) * 256;
@@ -498,11 +520,11 @@ __global__ void __launch_bounds__(64 * (CH_FW + 1), 4) k_chol_factor2(CholParams
     // row panel k is complete in LDS when its TM - 1 - k tiles are written: only their OWNERS are waited for — a wavefront that is
     // still busy with the previous row's stores and owns nothing in this row holds nobody up
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    const long long t3 = clock64();
+    const long long t3 = OVG_CHOL_CLOCK();
     t_panel += t3 - t1;
     if (lane == 0 && wrote > 0) (void)__hip_atomic_fetch_add(sync + 16 + k, wrote, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     if (!wait_for(16 + k, TM - 1 - k)) return;
-    const long long t4 = clock64();
+    const long long t4 = OVG_CHOL_CLOCK();
     t_cnt += t4 - t3;
     // (c) trailing update S_ij -= W_ki^T W_kj of this wavefront's tiles below row k (its next diagonal tile is done)
 #pragma unroll
@@ -516,18 +538,18 @@ __global__ void __launch_bounds__(64 * (CH_FW + 1), 4) k_chol_factor2(CholParams
         for (int u = 0; u < 4; u++) FEAT_MFMA(a[u], b[u], acc[s]);
       }
     }
-    const long long t5 = clock64();
+    const long long t5 = OVG_CHOL_CLOCK();
     t_trail += t5 - t4;
     // (d) row k leaves for memory LAST: nothing in this workgroup waits for it (the followers do, one step behind).  Everything is
     //     read back from LDS: the row panel (valid until step k + 2 overwrites its buffer — behind the counting barrier of step k + 1,
     //     which this wavefront only joins after this point), U_kk / U_kk^-1 (three buffers, same argument one step further).
     row_to_memory(k);
-    t_st += clock64() - t5;
+    t_st += OVG_CHOL_CLOCK() - t5;
   }
   arrive(TM - 1);
-  if (p.dbg && lane == 0 && (wv == 1 || wv == 7)) {
+  if (OVG_CHOL_DBG(p) && lane == 0 && (wv == 1 || wv == 7)) {
     long long *d = p.dbg + (wv == 1 ? 320 : 330);
-    d[0] += clock64() - t_begin, d[1] += t_uinv, d[2] += t_st, d[3] += t_panel, d[4] += t_cnt, d[5] += t_trail, d[6] += 1;
+    d[0] += OVG_CHOL_CLOCK() - t_begin, d[1] += t_uinv, d[2] += t_st, d[3] += t_panel, d[4] += t_cnt, d[5] += t_trail, d[6] += 1;
   }
 #undef CTI
 #undef CTJ
@@ -558,11 +580,11 @@ __global__ void __launch_bounds__(64 * CH_NW, 2) k_chol_follow(CholParams p) {
     }
     acc[i] = v;
   }
-  const long long f_begin = clock64();
+  const long long f_begin = OVG_CHOL_CLOCK();
   long long f_wait = 0;
   for (int k = 0; k < TM; k++) {
     // wait for step k of the factor workgroup
-    const long long f_w0 = clock64();
+    const long long f_w0 = OVG_CHOL_CLOCK();
     int spins = 0;
     while (__hip_atomic_load(p.prog + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < p.n_arrive) {
       __builtin_amdgcn_s_sleep(2);
@@ -580,7 +602,7 @@ __global__ void __launch_bounds__(64 * CH_NW, 2) k_chol_follow(CholParams p) {
         return;
       }
     }
-    f_wait += clock64() - f_w0;
+    f_wait += OVG_CHOL_CLOCK() - f_w0;
     // the factor workgroup's data was written through (sc1 stores): sc1 loads read it past this CU's L1
     auto ld_sys = [](const double *ptr) { return __hip_atomic_load(ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
     double ua[4];
@@ -623,7 +645,7 @@ __global__ void __launch_bounds__(64 * CH_NW, 2) k_chol_follow(CholParams p) {
       }
     }
   }
-  if (p.dbg && blockIdx.x == 0 && tid == 0) p.dbg[303] += clock64() - f_begin, p.dbg[304] += f_wait;
+  if (OVG_CHOL_DBG(p) && blockIdx.x == 0 && tid == 0) p.dbg[303] += OVG_CHOL_CLOCK() - f_begin, p.dbg[304] += f_wait;
 }
 
 } // namespace chol
