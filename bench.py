@@ -365,6 +365,16 @@ def main(argv=None):
                 "stage_events": f"HIP events around the stages on every {args.stage_events_every}th update of the timed region ({kt['launches']} updates sampled)",
             },
         }
+        if hook is None:
+            # the shader clock this box sustains for a busy wavefront (ovgpu_debug_clock_mhz): boxes of one pool differ by 20+ %, and a
+            # pipeline of short latency-bound kernels scales with it -- two bench lines are comparable only next to this number
+            try:
+                import ctypes as _C
+                mhz = _C.c_double(0.0)
+                if up.lib.ovgpu_debug_clock_mhz(up._ctx, _C.byref(mhz)) == 0:
+                    out["device_clock_mhz_probe"] = round(mhz.value, 1)
+            except Exception as e:  # noqa: BLE001
+                out["device_clock_mhz_probe"] = None
         if world > 1:
             # what the first real multi-GPU line is read against (no N > 1 run has been measured: DESIGN.md section 5)
             out["exchange"] = dict(exchange)

@@ -806,6 +806,12 @@ int ovgpu_debug_option(ovgpu_ctx *ctx, const char *name, int64_t value, int64_t 
  * enable != 0 allocates / clears 512 counters, out512 != NULL reads them back first. */
 int ovgpu_debug_cycles(ovgpu_ctx *ctx, int enable, long long *out512);
 
+/* Measurement aid (no reference counterpart): the shader clock this device sustains for one busy wavefront, in MHz — shader
+ * cycles (s_memtime) over the constant 100 MHz reference (s_memrealtime) across a ~0.3 ms dependent-arithmetic loop.  The boxes of
+ * a pool differ (1.7 ... 2.4 GHz measured), and a pipeline of short latency-bound kernels scales with it: bench.py reports the
+ * value next to its line so that two runs can be compared.                                                       */
+int ovgpu_debug_clock_mhz(ovgpu_ctx *ctx, double *mhz_out);
+
 /* Time in ms of the measurement compression (all its launches) and of the
  * whole update, averaged over the launches since the last call with
  * reset != 0; measured with HIP events on the context's stream.              */
