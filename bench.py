@@ -366,15 +366,19 @@ def main(argv=None):
             },
         }
         if hook is None:
-            # the shader clock this box sustains for a busy wavefront (ovgpu_debug_clock_mhz): boxes of one pool differ by 20+ %, and a
-            # pipeline of short latency-bound kernels scales with it -- two bench lines are comparable only next to this number
+            # What kind of box this is (ovgpu_debug_box_probe: shader clock idle and under matrix load, dependent-load latencies, launch
+            # and dispatch rates).  Boxes of one pool run this binary 20 % apart (0.85 and 1.02 ms per update within minutes of each
+            # other); the one slow box these probes were taken on showed the SAME values as the fast ones -- so the spread is not clock,
+            # not memory latency, not the command processor -- and the probe is reported so that a reader can rule those out, too.
             try:
                 import ctypes as _C
-                mhz = _C.c_double(0.0)
-                if up.lib.ovgpu_debug_clock_mhz(up._ctx, _C.byref(mhz)) == 0:
-                    out["device_clock_mhz_probe"] = round(mhz.value, 1)
+                pr = (_C.c_double * 6)()
+                if up.lib.ovgpu_debug_box_probe(up._ctx, pr) == 0:
+                    out["box_probe"] = {"shader_clock_mhz": round(pr[0], 1), "l2_hit_latency_ns": round(pr[1], 1), "beyond_l2_latency_ns": round(pr[2], 1),
+                                        "shader_clock_mhz_all_simds_on_fp64_mfma": round(pr[3], 1),
+                                        "us_per_dependent_empty_launch": round(pr[4], 2), "ns_per_empty_workgroup": round(pr[5], 2)}
             except Exception as e:  # noqa: BLE001
-                out["device_clock_mhz_probe"] = None
+                out["box_probe"] = None
         if world > 1:
             # what the first real multi-GPU line is read against (no N > 1 run has been measured: DESIGN.md section 5)
             out["exchange"] = dict(exchange)

@@ -806,11 +806,18 @@ int ovgpu_debug_option(ovgpu_ctx *ctx, const char *name, int64_t value, int64_t 
  * enable != 0 allocates / clears 512 counters, out512 != NULL reads them back first. */
 int ovgpu_debug_cycles(ovgpu_ctx *ctx, int enable, long long *out512);
 
-/* Measurement aid (no reference counterpart): the shader clock this device sustains for one busy wavefront, in MHz — shader
- * cycles (s_memtime) over the constant 100 MHz reference (s_memrealtime) across a ~0.3 ms dependent-arithmetic loop.  The boxes of
- * a pool differ (1.7 ... 2.4 GHz measured), and a pipeline of short latency-bound kernels scales with it: bench.py reports the
- * value next to its line so that two runs can be compared.                                                       */
-int ovgpu_debug_clock_mhz(ovgpu_ctx *ctx, double *mhz_out);
+/* Measurement aid (no reference counterpart): what kind of box this is, from six short probes (out3 holds SIX doubles).
+ *   out3[0]  shader clock in MHz: shader cycles (s_memtime) over the constant 100 MHz reference (s_memrealtime) across a
+ *            dependent-arithmetic loop
+ *   out3[1]  latency of a dependent load that hits L2, in ns (pointer chase over 1 MB)
+ *   out3[2]  latency of a dependent load beyond L2, in ns (pointer chase over 256 MB, one load per 4 KB page)
+ *   out3[3]  shader clock in MHz with every SIMD busy on the FP64 matrix pipe for ~1 ms (what the power limit leaves under load)
+ *   out3[4]  microseconds per launch of 200 dependent empty kernels on one stream (command processor + host)
+ *   out3[5]  nanoseconds per workgroup of one launch of 65 536 empty workgroups (dispatch rate)
+ * The boxes of a pool run the same binary 20 % apart (0.85 and 1.02 ms per update measured within minutes of each other);
+ * bench.py reports these numbers next to its line.  (On the one slow box probed they equalled the fast boxes': whatever
+ * separates the boxes, it is none of the six.)                                                                        */
+int ovgpu_debug_box_probe(ovgpu_ctx *ctx, double *out3);
 
 /* Time in ms of the measurement compression (all its launches) and of the
  * whole update, averaged over the launches since the last call with

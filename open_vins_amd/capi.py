@@ -247,7 +247,7 @@ def declare(lib):
         "ovgpu_multi_set_features": (C.c_int, [vp, C.POINTER(FeaturesView)]),
         "ovgpu_multi_msckf_update": (C.c_int, [vp, c_int32_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, C.POINTER(UpdateStats)]),
         "ovgpu_debug_cycles": (C.c_int, [ctxp, C.c_int, C.POINTER(C.c_longlong)]),
-        "ovgpu_debug_clock_mhz": (C.c_int, [ctxp, c_double_p]),
+        "ovgpu_debug_box_probe": (C.c_int, [ctxp, c_double_p]),
         "ovgpu_debug_option": (C.c_int, [ctxp, C.c_char_p, C.c_int64, C.POINTER(C.c_int64)]),
         "ovgpu_kernel_times": (C.c_int, [ctxp, C.c_int, c_double_p, c_double_p, C.POINTER(C.c_int64)]),
         "ovgpu_system_time": (C.c_int, [ctxp, c_double_p, C.POINTER(C.c_int64)]),
