@@ -796,7 +796,6 @@ int ovgpu_last_update_route(ovgpu_ctx *ctx);
  *   "gram_interleaved"        0: k_gram instead of k_gram_il (staging not interleaved with the matrix instructions)
  *   "gram_blocks_only"        1: always the 8 x 8-tile block form of the Gram kernel (k_gram_blk)
  *   "fuse_chol_inputs"        0: round 2's k_tf_gather / k_tf_abh assemble the factorisations' inputs
- *   "chol_flag_sync"          1: flag-word synchronisation inside the step-wise Cholesky (experiment)
  *   "featy_skip"              DEVELOPER BUILD ONLY (-DOVG_FEAT_ABLATE; the shipped library answers OVGPU_ERR_INVALID): bit mask
  *                             (1 sweep, 2 projection + stores, 4 SYRK, 8 Cholesky) of phases of the fused kernel skipped for
  *                             timing (tools/dev_featy_ablate.py); the results of such an update are GARBAGE.                    */

@@ -4,7 +4,7 @@
 // [B | h]) used to be 13 launches of k_ekf_chol_step each — a chain of 16-row steps in which every launch boundary, and every
 // wavefront refactoring the diagonal block for itself, sat on the critical path (26 launches = 0.29 ms of a 1.15 ms update).
 //
-//   k_chol_factor            ONE workgroup: 15 wavefronts hold the upper triangle of A as 16 x 16 tiles in REGISTERS (accumulator
+//   k_chol_factor2           ONE workgroup (round 2's k_chol_factor described here; round 3's barrier-free form of it is what remains, see below): 15 wavefronts hold the upper triangle of A as 16 x 16 tiles in REGISTERS (accumulator
 //                            layout of v_mfma_f64_16x16x4_f64; tiles dealt round-robin, 10 per wavefront), a 16th runs the
 //                            chain of diagonal tiles and holds nothing else (the factorisation of a tile needs ~90 registers: in
 //                            a wavefront that also holds tiles they end up in scratch, and scratch latency on the chain).  Step k:
@@ -92,182 +92,12 @@ __device__ __forceinline__ double ld_c(const CholParams &p, int r, int col) { //
 __device__ __forceinline__ bool chol_skipped(const CholParams &p) { return (p.pred && *p.pred == 0) || (p.pred_not && *p.pred_not != 0); }
 
 constexpr int CH_FW = 15;  // tile wavefronts of the factor workgroup (wavefront 15 runs the diagonal chain and holds no tiles)
-constexpr int CH_FT = 10;  // tiles per wavefront: 16 * 17 / 2 = 136 <= 15 * 10
-
-__global__ void __launch_bounds__(64 * (CH_FW + 1), 4) k_chol_factor(CholParams p) {
-  __shared__ __attribute__((aligned(16))) double panel[CH_TMAX][256];
-  __shared__ __attribute__((aligned(16))) double st[2][256];
-  __shared__ int diag_ready; // number of diagonal tiles handed to the chain wavefront so far (look-ahead hand-over, see below)
-  __shared__ double d0s[16 * CH_TMAX]; // CH_SRC_PRIOR: the diagonal of the matrix before the factorisation (pivot test)
-  if (chol_skipped(p)) return;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int g = lane >> 4, cl = lane & 15;
-  const int D = p.D, LA = p.LA, TM = (D + 15) >> 4, NTT = TM * (TM + 1) / 2;
-  if (tid == 0) diag_ready = 0;
-  if (p.src == CH_SRC_PRIOR && tid < 16 * CH_TMAX) d0s[tid] = tid < D ? p.P[(size_t)p.col_cov[tid] * p.N + p.col_cov[tid]] : 1.0;
-  const double *diag0 = p.src == CH_SRC_PRIOR ? d0s : p.diag0;
-  __syncthreads();
-  // Barriers of the chain order LDS traffic only; memory traffic is fire-and-forget.  Data for the followers leaves with
-  // write-through stores (sc1), and a wavefront adds itself to prog[k - 1] one step LATER, when those stores have long completed
-  // (a release fence or a vmcnt(0) wait right behind the stores would sit on the chain: 2-6 us per step).
-  auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
-  auto st_dev = [](double *ptr, double v) { __hip_atomic_store(ptr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
-  auto arrive = [&](int k) { // this wavefront's stores of step k are complete
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (lane == 0) (void)__hip_atomic_fetch_add(p.prog + k, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  };
-
-  if (wv == CH_FW) {
-    // ------------------------------------------------------------------ the diagonal chain: one wavefront, no tiles of its own
-    const long long t_begin = OVG_CHOL_CLOCK();
-    long long t_diag = 0;
-    for (int k = 0; k < TM; k++) {
-      // Look-ahead: the owner of tile (k, k) brings it up to date FIRST in the trailing update of step k - 1, parks it in st[0] and
-      // raises diag_ready; this wavefront factors it while the others are still in that trailing update.  (st[0] / st[1] are free
-      // then: the panel solve of step k - 1 read st[1] before barrier B2, which this wavefront has passed.)
-      while (__hip_atomic_load(&diag_ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= k) __builtin_amdgcn_s_sleep(1);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      const long long t_d0 = OVG_CHOL_CLOCK();
-      d4 sv, ev;
-#pragma unroll
-      for (int q = 0; q < 4; q++) sv[q] = st[0][(g + 4 * q) * 16 + cl];
-      __builtin_amdgcn_wave_barrier(); // st[0] becomes the factorisation's scratch
-      const bool bad = feat::diag_tile_factor_blk(sv, ev, st[0], lane, diag0 ? diag0 + 16 * k : nullptr, p.pivot_tol, D - 16 * k);
-      if (bad && lane == 0) __hip_atomic_store(p.flags, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // written through: a consumer may start before this kernel ends
-#pragma unroll
-      for (int q = 0; q < 4; q++) st[1][cl * 16 + g + 4 * q] = ev[q]; // U^-T in accumulator layout -> U^-1 row-major
-      t_diag += OVG_CHOL_CLOCK() - t_d0;
-      lds_barrier(); // B0 (kept so that every wavefront counts the same barriers)
-      lds_barrier(); // B1: U_kk^-1 is in st[1]
-      if (k > 0) arrive(k - 1);
-#pragma unroll
-      for (int q = 0; q < 4; q++) { // U_kk -> Y and L; U_kk^-1 -> memory for the followers
-        const int r = 16 * k + g + 4 * q, c = 16 * k + cl;
-        if (r < D && c < D) {
-          p.Y[(size_t)r * LA + c] = sv[q];
-          if (p.Lt) p.Lt[(size_t)c * D + r] = sv[q];
-        }
-        st_dev(p.uinv + (size_t)k * 256 + cl * 16 + g + 4 * q, ev[q]);
-      }
-      // (Y left of the diagonal tile is never read: the consumers of U take k >= row only)
-      lds_barrier(); // B2
-    }
-    arrive(TM - 1);
-    if (OVG_CHOL_DBG(p) && lane == 0) p.dbg[300] += OVG_CHOL_CLOCK() - t_begin, p.dbg[301] += t_diag, p.dbg[302] += 1;
-    return;
-  }
-
-  // -------------------------------------------------------------------- tile wavefronts: linear tile index t = s CH_FW + wv over the upper triangle, column by column
-  int tij[CH_FT]; // (j << 8) | i, or -1
-  d4 acc[CH_FT];
-#pragma unroll
-  for (int s = 0; s < CH_FT; s++) {
-    const int t = s * CH_FW + wv;
-    int i = -1, j = 0;
-    if (t < NTT) {
-      while ((j + 1) * (j + 2) / 2 <= t) j++;
-      i = t - j * (j + 1) / 2;
-    }
-    tij[s] = i < 0 ? -1 : ((j << 8) | i);
-    d4 v = {0.0, 0.0, 0.0, 0.0};
-    if (i >= 0) {
-#pragma unroll
-      for (int q = 0; q < 4; q++) v[q] = ld_a(p, 16 * i + g + 4 * q, 16 * j + cl);
-    }
-    acc[s] = v;
-  }
-#define CTI(s) (tij[s] & 255)
-#define CTJ(s) (tij[s] >> 8)
-  // hands diagonal tile kd (already up to date in this wavefront's registers) to the chain wavefront
-  auto hand_over = [&](int kd) {
-    const int slot = (kd * (kd + 1) / 2 + kd) / CH_FW;
-    d4 av = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int s = 0; s < CH_FT; s++)
-      if (s == slot) av = acc[s];
-#pragma unroll
-    for (int q = 0; q < 4; q++) st[0][(g + 4 * q) * 16 + cl] = av[q];
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (lane == 0) __hip_atomic_store(&diag_ready, kd + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  };
-  if (wv == 0) hand_over(0); // tile (0, 0): t = 0 belongs to wavefront 0
-  for (int k = 0; k < TM; k++) {
-    // (1) the diagonal tile is already with the chain wavefront (hand_over in the previous trailing update)
-    lds_barrier(); // B0
-    lds_barrier(); // B1
-    // (2) row panel W_kj = U_kk^-T S_kj -> LDS (for the trailing update) and memory (final: the tile is not needed here again).
-    //     One copy of the code, the register slot is selected at run time; the stores are fire-and-forget.
-    if (k > 0) arrive(k - 1); // the previous row's stores were issued a step ago
-    {
-      double ua[4];
-#pragma unroll
-      for (int u = 0; u < 4; u++) ua[u] = st[1][(4 * u + g) * 16 + cl];
-      for (int j = k + 1; j < TM; j++) {
-        const int t = j * (j + 1) / 2 + k;
-        if (t % CH_FW != wv) continue;
-        const int slot = t / CH_FW;
-        d4 sv = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int s = 0; s < CH_FT; s++)
-          if (s == slot) sv = acc[s];
-        d4 w = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int u = 0; u < 4; u++) FEAT_MFMA(ua[u], sv[u], w);
-        double *pt = panel[j];
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-          pt[(g + 4 * q) * 16 + cl] = w[q];
-          const int r = 16 * k + g + 4 * q, c = 16 * j + cl;
-          if (r < D && c < D) {
-            st_dev(p.Y + (size_t)r * LA + c, w[q]);
-            if (p.Lt) p.Lt[(size_t)c * D + r] = w[q];
-          }
-        }
-      }
-    }
-    lds_barrier(); // B2
-    // (3) trailing update S_ij -= W_ki^T W_kj; the next diagonal tile first, and straight to the chain wavefront
-    const int tnext = (k + 1) * (k + 2) / 2 + k + 1;
-    const bool own_next = k + 1 < TM && tnext % CH_FW == wv;
-    const int slot_next = own_next ? tnext / CH_FW : -1;
-    if (own_next) {
-      const double *pi = panel[k + 1];
-      double a[4], b[4];
-#pragma unroll
-      for (int u = 0; u < 4; u++) b[u] = pi[(4 * u + g) * 16 + cl], a[u] = -b[u];
-      d4 av = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int s = 0; s < CH_FT; s++)
-        if (s == slot_next) av = acc[s];
-#pragma unroll
-      for (int u = 0; u < 4; u++) FEAT_MFMA(a[u], b[u], av);
-#pragma unroll
-      for (int s = 0; s < CH_FT; s++)
-        if (s == slot_next) acc[s] = av;
-      hand_over(k + 1);
-    }
-#pragma unroll
-    for (int s = 0; s < CH_FT; s++) {
-      if (tij[s] >= 0 && CTI(s) > k && s != slot_next) {
-        const double *pi = panel[CTI(s)], *pj = panel[CTJ(s)];
-        double a[4], b[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) a[u] = -pi[(4 * u + g) * 16 + cl], b[u] = pj[(4 * u + g) * 16 + cl];
-#pragma unroll
-        for (int u = 0; u < 4; u++) FEAT_MFMA(a[u], b[u], acc[s]);
-      }
-    }
-  }
-  arrive(TM - 1);
-#undef CTI
-#undef CTJ
-}
 
 // ---------------------------------------------------------------------------------------------------
-// k_chol_factor2: the same factorisation WITHOUT workgroup barriers in the step loop.
+// k_chol_factor2: the factorisation WITHOUT workgroup barriers in the step loop.  (k_chol_factor, its round-2 form with three
+// s_barriers per step, was deleted in round 4: nothing but a debug switch reached it.)
 //
-// In k_chol_factor every step costs the chain wavefront ~16 kcycles for a 6-kcycle tile factorisation: it takes part in the
+// In k_chol_factor every step cost the chain wavefront ~16 kcycles for a 6-kcycle tile factorisation: it takes part in the
 // three s_barriers of the step, so it waits for the SLOWEST tile wavefront's panel solve (and that wavefront's stores) before it
 // may even look for the next diagonal tile.  Here the wavefronts synchronise through LDS words only:
 //   uinv_ready   chain -> tile wavefronts: U_kk^-1 of step k is in st1[k & 1]
@@ -555,7 +385,7 @@ __global__ void __launch_bounds__(64 * (CH_FW + 1), 4) k_chol_factor2(CholParams
 #undef CTJ
 }
 
-// followers: one wavefront per 16 carried columns (launched on a second stream next to k_chol_factor)
+// followers: one wavefront per 16 carried columns (launched on a second stream next to k_chol_factor2)
 __global__ void __launch_bounds__(64 * CH_NW, 2) k_chol_follow(CholParams p) {
   if (chol_skipped(p)) return;
   const int tid = threadIdx.x, lane = tid & 63;
