@@ -792,7 +792,6 @@ int ovgpu_last_update_route(ovgpu_ctx *ctx);
  *                             only (each is a marker packet the next kernel waits for, ~5 us); updates without events report 0
  *   "stack_is_f32"            (read only) the last pipeline stored the stack as floats and ran k_gram_f32 (options.gram_fp32)
  *   "featy_big"               1 / 2: the block-row form of the per-feature kernel (k_featy_big.h) on batches the one-pass kernel holds
- *   "featy_shape"             1 / 2: alternative wavefront x tile shapes of the fused per-feature kernel (tuning experiments)
  *   "gram_interleaved"        0: k_gram instead of k_gram_il (staging not interleaved with the matrix instructions)
  *   "gram_blocks_only"        1: always the 8 x 8-tile block form of the Gram kernel (k_gram_blk)
  *   "fuse_chol_inputs"        0: round 2's k_tf_gather / k_tf_abh assemble the factorisations' inputs
