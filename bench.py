@@ -365,7 +365,7 @@ def main(argv=None):
                 "stage_events": f"HIP events around the stages on every {args.stage_events_every}th update of the timed region ({kt['launches']} updates sampled)",
             },
         }
-        if hook is None:
+        if hook is None and not args.no_extras:
             # What kind of box this is (ovgpu_debug_box_probe: shader clock idle and under matrix load, dependent-load latencies, launch
             # and dispatch rates).  Boxes of one pool run this binary 20 % apart (0.85 and 1.02 ms per update within minutes of each
             # other); the one slow box these probes were taken on showed the SAME values as the fast ones -- so the spread is not clock,
