@@ -357,6 +357,23 @@ int main(int argc, char **argv) {
   assert(fv.meas_offsets[1] == 3 && fv.meas_offsets[2] == 4);
   assert(fv.clone_idx[0] == 0 && fv.clone_idx[2] == 2 && fv.clone_idx[3] == 2);
   assert(fv.uv[0] == 2.f && fv.uvn[6] == .7f && ff.meas_time[3] == 10.2);
+  { // the merge walk over the sorted clone times does not DEPEND on ascending timestamps: a track whose observations step back in time
+    // (never produced by the reference's front end, but nothing in Feature forbids it), repeat a time, or lie between / outside the
+    // clone times flattens like the look-up per observation would; a buffer reused after clear() starts from scratch
+    ToyFeature c;
+    c.timestamps[0] = {10.2, 10.0, 10.05, 10.0, 11.0, 10.1, 9.0};
+    c.uvs[0] = {{1, 0}, {2, 0}, {3, 0}, {4, 0}, {5, 0}, {6, 0}, {7, 0}}, c.uvs_norm[0] = c.uvs[0];
+    ff.clear();
+    assert(ff.F() == 0 && ff.M() == 0);
+    const auto &uv = c.uvs.at(0);
+    const int kept = ff.add_camera(0, c.timestamps.at(0), [&](size_t i, float &x, float &y) { x = uv[i].first, y = uv[i].second; },
+                                   [&](size_t i, float &x, float &y) { x = uv[i].first, y = uv[i].second; }, clones);
+    ff.end_feature();
+    assert(kept == 4 && ff.M() == 4 && ff.F() == 1);
+    const int want_clone[4] = {2, 0, 0, 1};
+    const float want_u[4] = {1.f, 2.f, 4.f, 6.f};
+    for (int i = 0; i < 4; i++) assert(ff.clone_idx[i] == want_clone[i] && ff.uv[2 * i] == want_u[i] && clones.find(ff.meas_time[i]) == want_clone[i]);
+  }
   ovgpu_options o;
   ovgpu_default_options(&o);
   assert(o.chi2_multipler == 5.0 && o.max_runs == 5);
