@@ -692,3 +692,26 @@ def test_forced_gate_verdicts(oracle):
     # untouched verdicts reproduce the plain run bit for bit
     out2 = oracle.msckf_update(opts, v, given=dict(tri, status=np.array(tri["status"], dtype=np.int32)))
     np.testing.assert_array_equal(out2["dx"], ref["dx"])
+
+
+def test_tight_window_snapshot_is_consistent():
+    """synth.tight_window_problem (bench.py's `tight_window`, the GPU test of the gate's residual bound): errors and prior scaled alike,
+    so the gate accepts as it does on the unscaled snapshot — and the accepted statistics sit where chi2(2m - 3) puts them (mean ~ dof),
+    which is what lets the bound |r'|^2 / sigma^2 decide most features there."""
+    from oracle import pyoracle
+    opts = capi.default_options(chi2_multipler=1.0)
+    frac, ratio = {}, {}
+    for name, prob in (("survey", synth.make_problem(3, F=200)), ("tight", synth.tight_window_problem(3, 0.05, F=200))):
+        o = pyoracle.msckf_update(opts, capi.Views(prob))
+        reached = np.isfinite(o["chi2"])
+        used = o["feat_status"] == capi.FEAT_USED
+        assert reached.sum() > 150
+        frac[name] = used.sum() / reached.sum()
+        dof = 2 * np.diff(prob.meas_offsets)[used] - 3
+        ratio[name] = float(np.mean(o["chi2"][used] / dof))
+    assert frac["tight"] > 0.9 and frac["survey"] > 0.9
+    assert 0.7 < ratio["tight"] < 1.2 and 0.7 < ratio["survey"] < 1.2, ratio
+    # the tight window really is tighter: its prior's clone block is 0.05^2 of the survey snapshot's
+    a, b = synth.make_problem(3, F=10), synth.tight_window_problem(3, 0.05, F=10)
+    i = int(a.clone_cov_id[0])
+    np.testing.assert_allclose(b.P[i:i + 6, i:i + 6], 0.0025 * a.P[i:i + 6, i:i + 6], rtol=1e-12)
