@@ -575,13 +575,18 @@ __global__ void __launch_bounds__(64 * NW, OCC)
     for (int s = 0; s < TPW; s++) {
       if (tij[s] < 0 || skip_gate) continue;
       if (TJ(s) == NT) {
+        // (the lane's part of the address is recomputed behind an opaque value: hoisted out of the feature loop it was spilled in the
+        // 8 x 17 shape, and reloaded from scratch 2 x 68 times per feature, each reload a wait on memory)
+        int lane_o = lane;
+        asm volatile("" : "+v"(lane_o));
+        const int go = lane_o >> 4, clo = lane_o & 15;
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-          const int a = 16 * TI(s) + g + 4 * q;
+          const int a = 16 * TI(s) + go + 4 * q;
           double v = 0.0;
-          if (cl < 4 && a < n) {
+          if (clo < 4 && a < n) {
             const double *rd = frow + (size_t)(a >> 1) * RS;
-            v = cl == 0 ? rd[RO_RES + (a & 1)] : rd[RO_HF + 3 * (a & 1) + cl - 1];
+            v = clo == 0 ? rd[RO_RES + (a & 1)] : rd[RO_HF + 3 * (a & 1) + clo - 1];
           }
           acc[s][q] = v;
         }

@@ -254,13 +254,16 @@ __global__ void __launch_bounds__(64 * NW, 1)
       for (int s = 0; s < TPW; s++) {
         if (tij[s] < 0) continue;
         if (TJ(s) == NT) {
+          int lane_o = lane; // (opaque: the lane's part of the address is not hoisted out of the loops and spilled, see k_featy.h)
+          asm volatile("" : "+v"(lane_o));
+          const int go = lane_o >> 4, clo = lane_o & 15;
 #pragma unroll
           for (int q = 0; q < 4; q++) {
-            const int r = 16 * TI(s) + g + 4 * q;
+            const int r = 16 * TI(s) + go + 4 * q;
             double v = 0.0;
-            if (cl < 4 && r < n) {
+            if (clo < 4 && r < n) {
               const double *rd = frow + (size_t)(r >> 1) * RS;
-              v = cl == 0 ? rd[RO_RES + (r & 1)] : rd[RO_HF + 3 * (r & 1) + cl - 1];
+              v = clo == 0 ? rd[RO_RES + (r & 1)] : rd[RO_HF + 3 * (r & 1) + clo - 1];
             }
             acc[s][q] = v;
           }
