@@ -577,8 +577,8 @@ __global__ void __launch_bounds__(64 * NW, OCC)
       if (TJ(s) == NT) {
         // (the lane's part of the address is recomputed behind an opaque value: hoisted out of the feature loop it was spilled in the
         // 8 x 17 shape, and reloaded from scratch 2 x 68 times per feature, each reload a wait on memory)
-        int lane_o = lane;
-        asm volatile("" : "+v"(lane_o));
+        int lane_o; // the lane id from the hardware, inside the asm: `lane` itself — and a hoisted mbcnt — were spilled and reloaded here
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_o));
         const int go = lane_o >> 4, clo = lane_o & 15;
 #pragma unroll
         for (int q = 0; q < 4; q++) {

@@ -254,8 +254,8 @@ __global__ void __launch_bounds__(64 * NW, 1)
       for (int s = 0; s < TPW; s++) {
         if (tij[s] < 0) continue;
         if (TJ(s) == NT) {
-          int lane_o = lane; // (opaque: the lane's part of the address is not hoisted out of the loops and spilled, see k_featy.h)
-          asm volatile("" : "+v"(lane_o));
+          int lane_o; // (opaque, and from the hardware: see k_featy.h)
+          asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_o));
           const int go = lane_o >> 4, clo = lane_o & 15;
 #pragma unroll
           for (int q = 0; q < 4; q++) {
