@@ -266,6 +266,25 @@ def main(argv=None):
                         "uncertainty: the regime of the rpng_sim closed loop), where the gate's residual bound decides most features; NOT the headline",
                 "ms_per_step": 1e3 * tdt / tsteps, "ms_per_step_with_every_gate_factored": 1e3 * fdt / tsteps,
                 "features_used": int(tres["stats"]["n_used"]), "features_passed_by_the_bound": int(tres["stats"]["n_gate_bound"])}
+        if world == 1 and args.cfg is None and args.features is None:
+            # BASELINE configs[2] reads "online cam/IMU calib": with StateOptions::do_calib_imu_intrinsics the state carries 24 more
+            # rows of P behind the IMU block (State.cpp:65-88: N = 248) that never get Jacobian columns -- the per-feature
+            # stage and the compression are the headline's, the update's N x N products grow.  The same batch on that state, beside the
+            # headline (whose N = 224 is SURVEY 8(d)'s cfg-3 figure); an extra must never take the line down with it.
+            try:
+                iprob = synth.make_problem(cfg, imu_intrinsics=True)
+                isteps = max(5, args.steps // 4)
+                keep_loops = list(timed_loops)
+                idt, iup, _ = run(iprob, None, isteps, 5)
+                iup.reset_state()
+                ires = iup.update()
+                iup.close()
+                timed_loops[:] = keep_loops
+                extras["imu_intrinsics_state"] = {"workload": f"the headline batch on a state that also calibrates the IMU intrinsics: N={iprob.N}, D={iprob.Dmax}",
+                                                  "ms_per_step": 1e3 * idt / isteps, "value": iprob.F / (idt / isteps), "unit": "features/s",
+                                                  "features_used": int(ires["stats"]["n_used"])}
+            except Exception as e:  # noqa: BLE001
+                extras["imu_intrinsics_state"] = {"error": repr(e)}
         if world > 1:
             pass
         elif cfg != CFG_MULTI:  # the strong-scaling job of N > 1 on this one GPU: the reference point of the scaling curve
