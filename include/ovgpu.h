@@ -52,8 +52,14 @@ extern "C" {
 /*      reference's statistic.  ovgpu_update_stats::_pad0 became n_gate_bound. */
 /*      A caller that logs or thresholds the chi2 values itself sets           */
 /*      gate_always_factor = 1.                                                */
+/*   6  (round 4) the device track store answers the rest of FeatureDatabase:  */
+/*      ovgpu_tracks_containing / _containing_older / _oldest_timestamp /      */
+/*      _cleanup_measurements / _cleanup_measurements_exact / _get_feature.    */
+/*      ovgpu_tracks_not_containing_newer reads the stored observations (per   */
+/*      camera the LAST one, as the reference does) instead of the host's      */
+/*      record of the last append: same answer for times appended in order.    */
 /* ------------------------------------------------------------------------- */
-#define OVGPU_ABI_VERSION 5
+#define OVGPU_ABI_VERSION 6
 int ovgpu_abi_version(void);
 
 /* ------------------------------------------------------------------------- */
@@ -586,6 +592,38 @@ int ovgpu_tracks_erase(ovgpu_ctx *ctx, int32_t n, const int64_t *featid);
  * MSCKF features, VioManager.cpp:366-378).  ids [capacity], n_out = how many there are.       */
 int ovgpu_tracks_not_containing_newer(ovgpu_ctx *ctx, double timestamp, int32_t capacity,
                                       int64_t *ids, int32_t *n_out);
+
+/* FeatureDatabase::features_containing_older(timestamp) (FeatureDatabase.cpp:128-167): tracks with a camera
+ * whose FIRST stored observation is older than `timestamp`; FeatureDatabase::features_containing(timestamp)
+ * (FeatureDatabase.cpp:169-209): tracks with an observation AT `timestamp` (exact ==) — with the oldest clone's
+ * time, the tracks VioManager marginalises into MSCKF features (VioManager.cpp:376-378).  Same conventions as
+ * ovgpu_tracks_not_containing_newer: ids [capacity] ascending, n_out = how many there are (call with
+ * capacity 0 to size the array); nothing is removed (the reference's `remove` = false; ovgpu_tracks_erase does
+ * that) and there is no to_delete flag on the device (`skip_deleted`: erase what was used).                  */
+int ovgpu_tracks_containing_older(ovgpu_ctx *ctx, double timestamp, int32_t capacity,
+                                  int64_t *ids, int32_t *n_out);
+int ovgpu_tracks_containing(ovgpu_ctx *ctx, double timestamp, int32_t capacity, int64_t *ids,
+                            int32_t *n_out);
+
+/* FeatureDatabase::get_oldest_timestamp (FeatureDatabase.cpp:265-276): the smallest FIRST observation time
+ * over all tracks and cameras, -1 when the store holds no observation.                                       */
+int ovgpu_tracks_oldest_timestamp(ovgpu_ctx *ctx, double *t_out);
+
+/* FeatureDatabase::cleanup_measurements(timestamp) (FeatureDatabase.cpp:226-243, Feature.cpp:84-110): every
+ * observation with time <= timestamp leaves (VioManager.cpp:589-591 calls it once per frame with the time of
+ * the clone about to be marginalised: this is what keeps a long-lived track inside max_obs); _exact
+ * (FeatureDatabase.cpp:245-263, Feature.cpp:55-82; UpdaterZeroVelocity.cpp:257): every observation with time ==
+ * timestamp leaves.  A track left without observations is dropped (:236-238).  n_erased (may be NULL): how
+ * many tracks were dropped.  The survivors keep their order.                                                  */
+int ovgpu_tracks_cleanup_measurements(ovgpu_ctx *ctx, double timestamp, int32_t *n_erased);
+int ovgpu_tracks_cleanup_measurements_exact(ovgpu_ctx *ctx, double timestamp, int32_t *n_erased);
+
+/* FeatureDatabase::get_feature_clone (FeatureDatabase.cpp:41-57): the stored observations of one track in the
+ * order they were appended (per camera = the order of Feature::timestamps[cam]).  n_out = their number (0 for
+ * an unknown id); the first min(n_out, capacity) are written to timestamps [capacity], cam_id [capacity],
+ * uv / uvn [2 * capacity] (any of them may be NULL).                                                          */
+int ovgpu_tracks_get_feature(ovgpu_ctx *ctx, int64_t featid, int32_t capacity, int32_t *n_out,
+                             double *timestamps, int32_t *cam_id, float *uv, float *uvn);
 
 /* ---- VioManager::retriangulate_active_tracks (VioManagerHelper.cpp:190-387), SURVEY.md row N4 -------------
  * The running linear triangulation of the tracks alive in the newest frame.  Per call = per camera frame:

@@ -204,6 +204,12 @@ def declare(lib):
         "ovgpu_tracks_append": (C.c_int, [ctxp, C.c_double, C.c_int32, C.POINTER(C.c_int64), c_int32_p, c_float_p, c_float_p]),
         "ovgpu_tracks_erase": (C.c_int, [ctxp, C.c_int32, C.POINTER(C.c_int64)]),
         "ovgpu_tracks_not_containing_newer": (C.c_int, [ctxp, C.c_double, C.c_int32, C.POINTER(C.c_int64), c_int32_p]),
+        "ovgpu_tracks_containing_older": (C.c_int, [ctxp, C.c_double, C.c_int32, C.POINTER(C.c_int64), c_int32_p]),
+        "ovgpu_tracks_containing": (C.c_int, [ctxp, C.c_double, C.c_int32, C.POINTER(C.c_int64), c_int32_p]),
+        "ovgpu_tracks_oldest_timestamp": (C.c_int, [ctxp, c_double_p]),
+        "ovgpu_tracks_cleanup_measurements": (C.c_int, [ctxp, C.c_double, c_int32_p]),
+        "ovgpu_tracks_cleanup_measurements_exact": (C.c_int, [ctxp, C.c_double, c_int32_p]),
+        "ovgpu_tracks_get_feature": (C.c_int, [ctxp, C.c_int64, C.c_int32, c_int32_p, c_double_p, c_int32_p, c_float_p, c_float_p]),
         "ovgpu_tracks_count": (C.c_int, [ctxp, c_int32_p]),
         "ovgpu_tracks_to_features": (C.c_int, [ctxp, C.c_int32, C.POINTER(C.c_int64), c_double_p]),
         "ovgpu_tracks_group_order": (C.c_int, [ctxp, C.c_int32]),

@@ -98,4 +98,81 @@ __global__ void k_tracks_gather(int F, int K, int C, const int32_t *__restrict__
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// FeatureDatabase's queries and clean-ups over the stored tracks (round 4): one thread per LIVE track (slots[t]), a track's
+// observations walked in storage order = the order of the appends, i.e. per camera the order of Feature::timestamps[cam].
+//
+//   features_not_containing_newer   FeatureDatabase.cpp:87-126    no camera whose LAST observation is >= timestamp  (:103-108)
+//   features_containing_older       FeatureDatabase.cpp:128-167   a camera whose FIRST observation is < timestamp   (:144-149)
+//   features_containing             FeatureDatabase.cpp:169-209   an observation whose time == timestamp            (:186-191)
+//   get_oldest_timestamp            FeatureDatabase.cpp:265-276   min over the cameras' FIRST observations          (:268-273)
+//   cleanup_measurements            FeatureDatabase.cpp:226-243 + Feature::clean_older_measurements, Feature.cpp:84-110: time <= timestamp goes
+//   cleanup_measurements_exact      FeatureDatabase.cpp:245-263 + Feature::clean_invalid_measurements, Feature.cpp:55-82: time == timestamp goes
+//
+// "First" / "last" are positions in the camera's vector, not the smallest / largest time: the reference reads at(0) and
+// at(size - 1) — the same thing for the ascending times a front end appends, and reproduced as written for any other order.
+// Pure index / byte work, bit-exact by construction.
+// ---------------------------------------------------------------------------------------------------
+enum { TRK_Q_NOT_NEWER = 0, TRK_Q_CONTAINING_OLDER = 1, TRK_Q_CONTAINING = 2, TRK_Q_OLDEST = 3 };
+
+// flag[t] = the track answers the query; aux[t] (TRK_Q_OLDEST): the smallest FIRST observation time of its cameras, +inf without observations
+__global__ void k_tracks_query(int T, const int32_t *__restrict__ slots, int mode, double timestamp, TrackStore ts, int32_t *__restrict__ flag,
+                               double *__restrict__ aux) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= T) return;
+  const int s = slots[t];
+  const int cnt = ts.count[s];
+  const size_t base = (size_t)s * ts.max_obs;
+  unsigned long long seen = 0; // cameras met so far (camera ids < 64: OVG_MAX_CAMS)
+  int hit = 0;
+  double oldest = __builtin_huge_val();
+  if (mode == TRK_Q_NOT_NEWER) {
+    bool newer = false;
+    for (int j = cnt - 1; j >= 0; j--) { // from the end: the first entry of a camera met this way is its LAST observation
+      const unsigned long long bit = 1ull << (ts.cam[base + j] & 63);
+      if (seen & bit) continue;
+      seen |= bit;
+      newer = newer || ts.time[base + j] >= timestamp;
+    }
+    hit = newer ? 0 : 1;
+  } else {
+    for (int j = 0; j < cnt; j++) {
+      const double tm = ts.time[base + j];
+      const unsigned long long bit = 1ull << (ts.cam[base + j] & 63);
+      const bool first = !(seen & bit);
+      seen |= bit;
+      if (mode == TRK_Q_CONTAINING) hit |= tm == timestamp ? 1 : 0;
+      else if (mode == TRK_Q_CONTAINING_OLDER) hit |= (first && tm < timestamp) ? 1 : 0;
+      else if (first && tm < oldest) oldest = tm;
+    }
+  }
+  flag[t] = hit;
+  if (aux) aux[t] = oldest;
+}
+
+// In-place compaction of every live track: observations with time <= timestamp (exact == 0) resp. == timestamp (exact != 0) leave,
+// the others keep their order (a survivor only ever moves towards the front).  newcount[t] = what is left (also in ts.count).
+__global__ void k_tracks_cleanup(int T, const int32_t *__restrict__ slots, int exact, double timestamp, TrackStore ts, int32_t *__restrict__ newcount) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= T) return;
+  const int s = slots[t];
+  const int cnt = ts.count[s];
+  const size_t base = (size_t)s * ts.max_obs;
+  int w = 0;
+  for (int j = 0; j < cnt; j++) {
+    const double tm = ts.time[base + j];
+    const bool drop = exact ? (tm == timestamp) : (tm <= timestamp);
+    if (drop) continue;
+    if (w != j) {
+      const size_t a = base + w, b = base + j;
+      ts.time[a] = tm, ts.cam[a] = ts.cam[b];
+      ts.uv[2 * a] = ts.uv[2 * b], ts.uv[2 * a + 1] = ts.uv[2 * b + 1];
+      ts.uvn[2 * a] = ts.uvn[2 * b], ts.uvn[2 * a + 1] = ts.uvn[2 * b + 1];
+    }
+    w++;
+  }
+  ts.count[s] = w;
+  newcount[t] = w;
+}
+
 } // namespace ovg

@@ -278,13 +278,52 @@ class UpdaterMSCKF:
         ids = np.ascontiguousarray(featid, dtype=np.int64)
         capi.check(self.lib.ovgpu_tracks_erase(self._ctx, len(ids), ids.ctypes.data_as(C.POINTER(C.c_int64))), "ovgpu_tracks_erase")
 
-    def tracks_not_containing_newer(self, timestamp):
+    def _tracks_ids(self, fn, name, timestamp):
         n = C.c_int32(0)
-        capi.check(self.lib.ovgpu_tracks_not_containing_newer(self._ctx, float(timestamp), 0, None, C.byref(n)), "ovgpu_tracks_not_containing_newer")
+        capi.check(fn(self._ctx, float(timestamp), 0, None, C.byref(n)), name)
         ids = np.zeros(max(n.value, 1), np.int64)
-        capi.check(self.lib.ovgpu_tracks_not_containing_newer(self._ctx, float(timestamp), n.value, ids.ctypes.data_as(C.POINTER(C.c_int64)), C.byref(n)),
-                   "ovgpu_tracks_not_containing_newer")
+        capi.check(fn(self._ctx, float(timestamp), n.value, ids.ctypes.data_as(C.POINTER(C.c_int64)), C.byref(n)), name)
         return ids[: n.value]
+
+    def tracks_not_containing_newer(self, timestamp):
+        """FeatureDatabase::features_not_containing_newer (FeatureDatabase.cpp:87-126): ids, ascending."""
+        return self._tracks_ids(self.lib.ovgpu_tracks_not_containing_newer, "ovgpu_tracks_not_containing_newer", timestamp)
+
+    def tracks_containing_older(self, timestamp):
+        """FeatureDatabase::features_containing_older (FeatureDatabase.cpp:128-167)."""
+        return self._tracks_ids(self.lib.ovgpu_tracks_containing_older, "ovgpu_tracks_containing_older", timestamp)
+
+    def tracks_containing(self, timestamp):
+        """FeatureDatabase::features_containing (FeatureDatabase.cpp:169-209)."""
+        return self._tracks_ids(self.lib.ovgpu_tracks_containing, "ovgpu_tracks_containing", timestamp)
+
+    def tracks_oldest_timestamp(self):
+        """FeatureDatabase::get_oldest_timestamp (FeatureDatabase.cpp:265-276): -1 for an empty store."""
+        t = C.c_double(0.0)
+        capi.check(self.lib.ovgpu_tracks_oldest_timestamp(self._ctx, C.byref(t)), "ovgpu_tracks_oldest_timestamp")
+        return t.value
+
+    def tracks_cleanup_measurements(self, timestamp, exact=False):
+        """FeatureDatabase::cleanup_measurements / cleanup_measurements_exact (FeatureDatabase.cpp:226-263): returns how many tracks
+        were left without observations and dropped."""
+        n = C.c_int32(0)
+        fn = self.lib.ovgpu_tracks_cleanup_measurements_exact if exact else self.lib.ovgpu_tracks_cleanup_measurements
+        capi.check(fn(self._ctx, float(timestamp), C.byref(n)), "ovgpu_tracks_cleanup_measurements")
+        return n.value
+
+    def tracks_get_feature(self, featid):
+        """FeatureDatabase::get_feature_clone (FeatureDatabase.cpp:41-57): the stored observations of one track in append order, or
+        None for an unknown id."""
+        n = C.c_int32(0)
+        capi.check(self.lib.ovgpu_tracks_get_feature(self._ctx, int(featid), 0, C.byref(n), None, None, None, None), "ovgpu_tracks_get_feature")
+        k = n.value
+        if k == 0:
+            return None
+        out = dict(timestamps=np.zeros(k), cam_id=np.zeros(k, np.int32), uv=np.zeros((k, 2), np.float32), uvn=np.zeros((k, 2), np.float32))
+        capi.check(self.lib.ovgpu_tracks_get_feature(self._ctx, int(featid), k, C.byref(n), _dp(out["timestamps"]), _ip(out["cam_id"]),
+                                                     out["uv"].ctypes.data_as(capi.c_float_p), out["uvn"].ctypes.data_as(capi.c_float_p)),
+                   "ovgpu_tracks_get_feature")
+        return out
 
     def tracks_count(self):
         n = C.c_int32(0)
