@@ -80,6 +80,7 @@ __host__ __device__ inline FeatYLds featy_lds_layout(int nt_max, int nw) {
 // ---------------------------------------------------------------------------------------------------
 // k_feat_rows_sorted: k_feat_rows with the records of a feature stored in clone-major order (clone column, then camera)
 // ---------------------------------------------------------------------------------------------------
+#ifndef OVG_TU_FEATY // (non-template kernels: defined in the library's main translation unit only, see ovgpu_featy_tu.hip)
 __global__ void __launch_bounds__(256) k_feat_rows_sorted(SysParams p, FeatStore st, int M) {
   const int gm = blockIdx.x * 256 + threadIdx.x;
   if (gm >= M) return;
@@ -105,6 +106,7 @@ __global__ void __launch_bounds__(256) k_feat_rows_sorted(SysParams p, FeatStore
   else dl[0] = 1, dl[1] = 0, dl[2] = 0, dl[3] = 0, dl[4] = 1, dl[5] = 0, dl[6] = 0, dl[7] = 0, dl[8] = 1;
   sys_measurement_rows(p, gm, p_FinG, p_FinG, false, hq, st.minfo + (size_t)8 * pos, st.rows + (size_t)pos * p.row_stride);
 }
+#endif // OVG_TU_FEATY
 
 // ---------------------------------------------------------------------------------------------------
 // k_feat_vt: one wavefront per feature -> Householder reflectors of H_f: V [2m][3] and the factor T of Q = I - V T V^T (6 doubles)
@@ -128,6 +130,7 @@ __device__ __forceinline__ void vt_residual_column(const SysParams &p, int64_t o
   }
   sumsq = wave_sum(sq);
 }
+#ifndef OVG_TU_FEATY
 __global__ void __launch_bounds__(256) k_feat_vt(SysParams p, FeatStore st, double *__restrict__ tq, int32_t *__restrict__ inst, int nt_max, int cb) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -238,6 +241,7 @@ __global__ void __launch_bounds__(256) k_feat_vt(SysParams p, FeatStore st, doub
     }
   }
 }
+#endif // OVG_TU_FEATY
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding GLOBAL access of the wavefront
 // (s_waitcnt vmcnt(0)): behind the output rows' stores that is a drain of ~50 KB to HBM at every barrier of the block loop.

@@ -322,6 +322,7 @@ __device__ __forceinline__ void sys_hf_householder(double *rows, int RS, double 
   }
 }
 
+#ifndef OVG_TU_FEATY // (a non-template kernel: defined in the library's main translation unit only, see ovgpu_featy_tu.hip)
 __global__ void __launch_bounds__(SYS_NT) k_system(SysParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
@@ -863,5 +864,6 @@ __global__ void __launch_bounds__(SYS_NT) k_system(SysParams p) {
     for (int i = 0; i < 10; i++) p.dbg[100 + i] = sys_tacc[i];
 #endif
 }
+#endif // OVG_TU_FEATY
 
 } // namespace ovg

@@ -37,6 +37,17 @@
 #include "k_retri.h"
 #include "ovgpu_types.h"
 
+// The headline shape of the fused per-feature kernel lives in the second translation unit (ovgpu_featy_tu.hip: its own scheduler
+// strategy); here it is only declared, so that its launches below bind to that definition.
+namespace ovg {
+namespace feat {
+extern template __global__ void k_feat_y<4, 11, 2, false>(SysParams, int, const double *__restrict__, const int32_t *__restrict__, const double *__restrict__,
+                                                          const double *__restrict__, const int32_t *__restrict__, const int32_t *__restrict__);
+extern template __global__ void k_feat_y<4, 11, 2, true>(SysParams, int, const double *__restrict__, const int32_t *__restrict__, const double *__restrict__,
+                                                         const double *__restrict__, const int32_t *__restrict__, const int32_t *__restrict__);
+} // namespace feat
+} // namespace ovg
+
 #include "api_context.inc"
 
 extern "C" {
