@@ -37,14 +37,24 @@
 #include "k_retri.h"
 #include "ovgpu_types.h"
 
-// The headline shape of the fused per-feature kernel lives in the second translation unit (ovgpu_featy_tu.hip: its own scheduler
-// strategy); here it is only declared, so that its launches below bind to that definition.
+// The fused per-feature kernels live in the second translation unit (ovgpu_featy_tu.hip: its own scheduler strategy); here they are
+// only declared, so that their launches below bind to those definitions.
 namespace ovg {
 namespace feat {
 extern template __global__ void k_feat_y<4, 11, 2, false>(SysParams, int, const double *__restrict__, const int32_t *__restrict__, const double *__restrict__,
                                                           const double *__restrict__, const int32_t *__restrict__, const int32_t *__restrict__);
 extern template __global__ void k_feat_y<4, 11, 2, true>(SysParams, int, const double *__restrict__, const int32_t *__restrict__, const double *__restrict__,
                                                          const double *__restrict__, const int32_t *__restrict__, const int32_t *__restrict__);
+extern template __global__ void k_feat_y<8, 17, 1, false>(SysParams, int, const double *__restrict__, const int32_t *__restrict__, const double *__restrict__,
+    const double *__restrict__, const int32_t *__restrict__, const int32_t *__restrict__);
+extern template __global__ void k_feat_y<8, 17, 1, true>(SysParams, int, const double *__restrict__, const int32_t *__restrict__, const double *__restrict__,
+    const double *__restrict__, const int32_t *__restrict__, const int32_t *__restrict__);
+extern template __global__ void k_feat_y_big<8, 17, false>(SysParams, int, const double *__restrict__, const int32_t *__restrict__, const double *__restrict__,
+    const double *__restrict__, const int32_t *__restrict__, const int32_t *__restrict__, double *);
+extern template __global__ void k_feat_y_big<8, 17, true>(SysParams, int, const double *__restrict__, const int32_t *__restrict__, const double *__restrict__,
+    const double *__restrict__, const int32_t *__restrict__, const int32_t *__restrict__, double *);
+extern template __global__ void k_feat_y_big<8, 5, false>(SysParams, int, const double *__restrict__, const int32_t *__restrict__, const double *__restrict__,
+    const double *__restrict__, const int32_t *__restrict__, const int32_t *__restrict__, double *);
 } // namespace feat
 } // namespace ovg
 
