@@ -268,9 +268,15 @@ __device__ __forceinline__ double gate_cholesky_chi2(d4 (&acc)[TPW], const int (
         for (int s = 0; s < TPW; s++)
           if (s == slot_t) av = acc[s];
         d4 ev;
+        // the step's critical path: three wavefronts of this workgroup wait at the barrier below, the wavefront of the CU's OTHER workgroup
+        // on this SIMD does not — the chain goes first whenever it has an instruction ready
+        // (measured, same box: 4-wavefront shape, two workgroups per CU: stage 0.4189 -> 0.4141 ms at configs[2]; the 8-wavefront shapes
+        // have the CU to themselves and do not move, 6.480 / 6.493 ms at configs[3]: not applied there)
+        if (NW == 4) __builtin_amdgcn_s_setprio(3);
         (void)diag_tile_factor_blk(av, ev, st0, lane, nullptr, 0.0, 16);
 #pragma unroll
         for (int q = 0; q < 4; q++) st1[cl * 16 + g + 4 * q] = ev[q]; // U^-T in accumulator layout -> U^-1 row-major
+        if (NW == 4) __builtin_amdgcn_s_setprio(0);
       }
     }
     lds_barrier();
