@@ -9,6 +9,8 @@
 // Contexts are keyed by the option values of the calling instance.
 #include "FeatureInitializer.h"
 
+#include "Feature.h" // (FeatureInitializer.h only forward-declares the class: FeatureInitializer.cpp:24 includes it, too)
+
 #include <cstring>
 #include <memory>
 #include <stdexcept>

@@ -35,17 +35,56 @@ def available():
     return os.path.exists(LIB_PATH) or can_build()
 
 
+def _open(path):
+    lib = C.CDLL(path)
+    lib.ref_chi2_quantile_95.restype = C.c_double
+    lib.ref_chi2_quantile_95.argtypes = [C.c_int]
+    return lib
+
+
 def load():
     global _lib
     if _lib is not None:
         return _lib
     if can_build():
         build()  # make: no-op when up to date
-    lib = C.CDLL(LIB_PATH)
-    lib.ref_chi2_quantile_95.restype = C.c_double
-    lib.ref_chi2_quantile_95.argtypes = [C.c_int]
-    _lib = lib
-    return lib
+    _lib = _open(LIB_PATH)
+    return _lib
+
+
+# ---- the DROP-IN build: open_vins_amd/shim's translation units compiled against the reference's own headers and linked with the
+# reference's own State / StateHelper / types objects + libovgpu behind the SAME C driver (oracle/ref/Makefile: `dropin`).  Mode "a":
+# the stock StateHelper::EKFUpdate applies the compressed system; "b": -DOVGPU_SHIM_MODE_B.  Every function of this module runs through
+# that library inside `with pyref.using(pyref.dropin_path("a")):` -- the updates then need a GPU (the shims have no CPU fallback).
+def dropin_path(mode):
+    return os.path.join(_HERE, "_ref", f"libov_dropin_{mode}.so")
+
+
+def build_dropin():
+    subprocess.check_call(["make", "-s", "-j8", "-C", os.path.join(_HERE, "ref"), "dropin"])
+
+
+def dropin_available(mode="a"):
+    return os.path.exists(dropin_path(mode)) or can_build()
+
+
+class using:
+    """Context manager: the wrappers of this module call into another build of the driver (a drop-in library)."""
+
+    def __init__(self, path):
+        self.path = path
+
+    def __enter__(self):
+        global _lib
+        capi.load()  # libovgpu (and torch's HIP runtime before it) first: the drop-in library links against it
+        self.saved = _lib
+        _lib = _open(self.path)
+        return _lib
+
+    def __exit__(self, *exc):
+        global _lib
+        _lib = self.saved
+        return False
 
 
 def _p(a):

@@ -1,0 +1,89 @@
+"""Run by tests/test_dropin_build.py in a SUBPROCESS (a C++ exception of the shim crossing the C driver would take the caller down):
+`python dropin_probe.py <a|b>` runs the reference's VioManager-side calls — UpdaterMSCKF::update, UpdaterSLAM::update / delayed_init /
+change_anchors on a reference `State` built by oracle/ref/ref_driver.cpp — once through oracle/_ref/libov_ref.so (the reference's own
+updaters) and once through oracle/_ref/libov_dropin_<mode>.so (the SAME driver and reference classes with open_vins_amd/shim's
+translation units in place of the reference's updaters, on the GPU through libovgpu), and prints one JSON line per case with the
+deviations.  TEST INFRASTRUCTURE."""
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+
+from open_vins_amd import capi, synth  # noqa: E402
+from oracle import pyref  # noqa: E402
+
+
+def rel(a, b):
+    m = np.isfinite(a) & np.isfinite(b)
+    return float(np.linalg.norm(a[m] - b[m]) / max(np.linalg.norm(b[m]), 1e-300)) if m.any() else 0.0
+
+
+def emit(case, **kw):
+    print(json.dumps(dict(case=case, **kw)), flush=True)
+
+
+def state_dev(a, b):
+    return float(max(np.abs(a[k] - b[k]).max() for k in ("clone_q_p", "calib_q_p", "intrinsics")))
+
+
+def msckf(mode, seed):
+    from test_ref_build import _msckf_case
+    prob, opts = _msckf_case(seed)
+    v = capi.Views(prob)
+    ref = pyref.msckf_update(opts, v)
+    with pyref.using(pyref.dropin_path(mode)):
+        got = pyref.msckf_update(opts, capi.Views(prob))
+    tri = (ref["feat_status"] == capi.FEAT_USED) | (ref["feat_status"] == capi.FEAT_CHI2_REJECTED)
+    used = int((ref["feat_status"] == capi.FEAT_USED).sum())
+    emit(f"msckf:{seed}", F=int(prob.F), C=int(prob.C), K=int(prob.K), rep=int(opts.feat_rep_msckf), used=used,
+         status_equal=bool(np.array_equal(got["feat_status"], ref["feat_status"])),
+         pos=float(np.abs(got["p_FinG"] - ref["p_FinG"])[tri].max()) if tri.any() else 0.0,
+         dx=rel(got["dx"], ref["dx"]) if used else 0.0, P=rel(got["P"], ref["P"]), state=state_dev(got, ref))
+
+
+def slam(mode, rep):
+    prob = synth.make_slam_problem(2, L=10, lm_rep=rep)
+    opts = capi.default_options(chi2_multipler=1.0)
+    ref = pyref.slam_update(opts, capi.Views(prob))
+    with pyref.using(pyref.dropin_path(mode)):
+        got = pyref.slam_update(opts, capi.Views(prob))
+    emit(f"slam:{rep}", used=int((ref["feat_status"] == capi.FEAT_USED).sum()), status_equal=bool(np.array_equal(got["feat_status"], ref["feat_status"])),
+         dx=rel(got["dx"], ref["dx"]), P=rel(got["P"], ref["P"]), landmarks=float(np.abs(got["landmarks"] - ref["landmarks"]).max()), state=state_dev(got, ref))
+
+
+def delayed(mode, rep):
+    prob = synth.make_problem(2, F=16, outlier_frac=0.2)
+    opts = capi.default_options(chi2_multipler=1.0)
+    ref = pyref.slam_delayed_init(opts, capi.Views(prob), feat_rep=rep)
+    with pyref.using(pyref.dropin_path(mode)):
+        got = pyref.slam_delayed_init(opts, capi.Views(prob), feat_rep=rep)
+    acc = ref["lm_cov_id"] >= 0
+    same = bool(np.array_equal(got["feat_status"], ref["feat_status"]) and got["N"] == ref["N"] and np.array_equal(got["lm_cov_id"], ref["lm_cov_id"]))
+    emit(f"delayed:{rep}", accepted=int(acc.sum()), status_equal=same,
+         value=float(np.abs(got["lm_value"][acc] - ref["lm_value"][acc]).max()) if same and acc.any() else -1.0,
+         P=rel(got["P"], ref["P"]) if same else -1.0, state=state_dev(got, ref))
+
+
+def anchors(mode, rep):
+    prob = synth.make_slam_problem(2, L=10, lm_rep=rep)
+    opts = capi.default_options(chi2_multipler=1.0)
+    ref = pyref.change_anchors(opts, capi.Views(prob))
+    with pyref.using(pyref.dropin_path(mode)):
+        got = pyref.change_anchors(opts, capi.Views(prob))
+    emit(f"anchors:{rep}", moved=int((prob.lm_anchor_clone == 0).sum()), status_equal=bool(np.array_equal(got["anchor_clone"], ref["anchor_clone"])),
+         P=rel(got["P"], ref["P"]), value=float(np.abs(got["value"] - ref["value"]).max()), fej=float(np.abs(got["fej"] - ref["fej"]).max()))
+
+
+CASES = [("msckf", 0), ("msckf", 3), ("msckf", 7), ("msckf", 11), ("msckf", 19), ("slam", 0), ("slam", 4), ("delayed", 0), ("delayed", 4), ("anchors", 2), ("anchors", 4)]
+
+if __name__ == "__main__":
+    mode = sys.argv[1]
+    pyref.load()
+    for kind, arg in CASES:
+        globals()[kind](mode, arg)
+    emit("done")

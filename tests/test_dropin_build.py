@@ -1,0 +1,152 @@
+"""The drop-in translation units of open_vins_amd/shim INSIDE the reference tree (round 4; VERDICT r3 row (b): "real-tree build
+unverified").
+
+Eigen, Boost and OpenCV are not on this machine, but oracle/ref/standin restates what the reference's update path needs of them — enough to
+compile the reference's OWN sources (oracle/_ref/libov_ref.so, tests/test_ref_build.py).  The same stand-ins let the shim units be
+compiled against the reference's own HEADERS (not the hand-written stand-ins of tests/shim_mock) and LINKED with the reference's own
+State / StateHelper / Propagator / types objects in place of ov_msckf/src/update/UpdaterMSCKF.cpp, ov_core/src/feat/FeatureInitializer.cpp
+and the three member functions of UpdaterSLAM.cpp the shim redefines: oracle/_ref/libov_dropin_a.so (mode A) and _b.so (mode B), behind
+the SAME C driver as the reference build.
+
+CPU legs: every unit compiles in the tree in both modes (the first such build found a real defect: shim/FeatureInitializer.cpp used
+ov_core::Feature through FeatureInitializer.h's forward declaration only); the two mode-B-only units need the friend line; the libraries
+link, load, bind the C-ABI entry points of their mode, carry the SHIM's definitions of the replaced functions, and run the reference's
+driver up to the shim's own early returns.  GPU legs (tests/dropin_probe.py in a subprocess): UpdaterMSCKF::update, UpdaterSLAM::update /
+delayed_init / change_anchors through the drop-in library against the reference's own updaters on identical reference `State`s."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from open_vins_amd import capi, synth
+from oracle import pyref
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SHIM = os.path.join(ROOT, "open_vins_amd", "shim")
+REF = pyref.REFERENCE
+UNITS = {"UpdaterMSCKF": ("A", "B"), "UpdaterSLAM_update": ("A", "B"), "FeatureInitializer": ("A", "B"), "UpdaterSLAM_delayed_init": ("B",),
+         "UpdaterSLAM_change_anchors": ("B",)}
+in_tree = pytest.mark.skipif(not pyref.can_build(), reason="/root/reference is not on this machine")
+
+
+def _compile(unit, mode, friend):
+    cmd = ["g++", "-std=c++17", "-fsyntax-only", "-w", f"-I{ROOT}/oracle/ref/standin", f"-I{REF}/ov_core/src", f"-I{REF}/ov_msckf/src",
+           f"-I{REF}/ov_msckf/src/update", f"-I{REF}/ov_core/src/feat", f"-I{ROOT}/include", f"-I{SHIM}", os.path.join(SHIM, unit + ".cpp")]
+    if mode == "B":
+        cmd.insert(1, "-DOVGPU_SHIM_MODE_B")
+    if friend:  # INTEGRATION.md's `friend class ovgpu_shim::StateAccess;` in State.h, emulated: the tree is not ours to patch
+        cmd[1:1] = ["-Dprivate=public", "-Dprotected=public"]
+    return subprocess.run(cmd, capture_output=True, text=True)
+
+
+@in_tree
+@pytest.mark.parametrize("unit,mode", [(u, m) for u, ms in UNITS.items() for m in ms])
+def test_unit_compiles_against_the_reference_headers(unit, mode):
+    r = _compile(unit, mode, friend=(mode == "B"))
+    assert r.returncode == 0, r.stderr[-3000:]
+
+
+@in_tree
+@pytest.mark.parametrize("unit", [u for u, ms in UNITS.items() if "A" not in ms])
+def test_mode_b_only_units_need_the_friend_line_in_the_real_state_h(unit):
+    r = _compile(unit, "B", friend=False)
+    assert r.returncode != 0 and "private within this context" in r.stderr and "_Cov" in r.stderr
+
+
+@in_tree
+def test_helper_headers_compile_against_the_reference_headers():
+    """ovgpu_zupt.h / ovgpu_retri.h (called FROM UpdaterZeroVelocity::try_update / VioManager::retriangulate_active_tracks), instantiated
+    by tests/shim_mock/probe_helpers.cpp the way those callers would — here against the reference's own State / Type / options headers."""
+    cmd = ["g++", "-std=c++17", "-fsyntax-only", "-w", "-DOVGPU_SHIM_MODE_B", "-Dprivate=public", "-Dprotected=public", f"-I{ROOT}/oracle/ref/standin",
+           f"-I{REF}/ov_core/src", f"-I{REF}/ov_msckf/src", f"-I{REF}/ov_msckf/src/update", f"-I{REF}/ov_core/src/feat", f"-I{ROOT}/include", f"-I{SHIM}",
+           os.path.join(ROOT, "tests", "shim_mock", "probe_helpers.cpp")]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+
+
+def _nm(path, *flags):
+    return subprocess.check_output(["nm", "-C", *flags, path], text=True)
+
+
+@pytest.fixture(scope="module")
+def dropin_libs():
+    if pyref.can_build():
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "open_vins_amd", "csrc")])
+        pyref.build()
+        pyref.build_dropin()
+    paths = {m: pyref.dropin_path(m) for m in ("a", "b")}
+    if not all(os.path.exists(p) for p in paths.values()):
+        pytest.skip("oracle/_ref/libov_dropin_*.so are not here and cannot be built (no /root/reference)")
+    return paths
+
+
+def test_dropin_libraries_link_the_shim_into_the_reference_objects(dropin_libs):
+    for mode, path in dropin_libs.items():
+        und = _nm(path, "-D", "--undefined-only")
+        want = ("ovgpu_msckf_compress", "ovgpu_slam_compress") if mode == "a" else ("ovgpu_msckf_update", "ovgpu_slam_update")
+        other = ("ovgpu_msckf_update", "ovgpu_slam_update") if mode == "a" else ("ovgpu_msckf_compress", "ovgpu_slam_compress")
+        for s in want + ("ovgpu_set_state", "ovgpu_set_features", "ovgpu_get_triangulation", "ovgpu_slam_delayed_init", "ovgpu_slam_change_anchors"):
+            assert f"U {s}\n" in und, (mode, s)
+        for s in other:
+            assert f"U {s}\n" not in und, (mode, s)
+        syms = _nm(path)
+        # the replaced member functions are the SHIM's (its persistent flattening buffer is a function-local static of update()) ...
+        assert "guard variable for ov_msckf::UpdaterMSCKF::update(" in syms or "ov_msckf::UpdaterMSCKF::update(std::shared_ptr<ov_msckf::State>, std::vector<std::shared_ptr<ov_core::Feature>" in syms
+        assert "ovgpu_shim::" in syms
+        # ... and the reference's own classes around them are still there
+        for s in ("ov_msckf::StateHelper::EKFUpdate(", "ov_msckf::StateHelper::marginalize(", "ov_msckf::UpdaterSLAM::perform_anchor_change(",
+                  "ov_msckf::UpdaterSLAM::UpdaterSLAM(", "ov_msckf::Propagator::", "ov_core::FeatureDatabase::update_feature("):
+            assert s in syms, (mode, s)
+    ref_syms = _nm(pyref.LIB_PATH)
+    assert "ovgpu_shim::" not in ref_syms and "ovgpu_" not in _nm(pyref.LIB_PATH, "-D", "--undefined-only")
+
+
+def test_dropin_library_runs_the_reference_driver_up_to_the_shims_early_return(dropin_libs):
+    """No GPU here: a batch whose tracks all fall under two observations never reaches the library (UpdaterMSCKF.cpp:88-92, the shim's
+    clean + flatten loop erases them and returns), so the reference's State construction, the shim's State snapshot, its track flattening
+    and its side effects on the Feature objects run on the CPU — and must leave the state exactly as the reference's own updater leaves it."""
+    prob = synth.make_problem(2, F=6, C=8)
+    keep = np.zeros(prob.M, bool)
+    keep[prob.meas_offsets[:-1]] = True  # ONE observation per track
+    short = prob.subset(np.arange(prob.F))
+    offs = np.arange(prob.F + 1, dtype=np.int32)
+    short.meas_offsets = offs
+    short.uv, short.uvn = prob.uv.reshape(-1, 2)[keep].reshape(-1).copy(), prob.uvn.reshape(-1, 2)[keep].reshape(-1).copy()
+    short.clone_idx, short.cam_idx = prob.clone_idx[keep].copy(), prob.cam_idx[keep].copy()
+    opts = capi.default_options(chi2_multipler=1.0)
+    ref = pyref.msckf_update(opts, capi.Views(short))
+    for mode, path in dropin_libs.items():
+        with pyref.using(path):
+            got = pyref.msckf_update(opts, capi.Views(short))
+        assert np.array_equal(got["feat_status"], ref["feat_status"]) and (got["feat_status"] != capi.FEAT_USED).all(), mode
+        assert np.array_equal(got["P"], ref["P"]) and np.array_equal(got["clone_q_p"], ref["clone_q_p"]) and np.array_equal(got["dx"], ref["dx"]), mode
+
+
+# what the drop-in library has to reproduce of the reference's own updaters (tests/dropin_probe.py's keys): the tolerances of the
+# GPU-against-reference fixtures (tests/test_ref_fixtures.py)
+LIMITS = {"msckf": dict(pos=1e-8, dx=1e-7, P=1e-8, state=1e-9), "slam": dict(dx=1e-7, P=1e-8, landmarks=1e-9, state=1e-9),
+          "delayed": dict(value=1e-8, P=1e-7, state=1e-9), "anchors": dict(P=1e-11, value=1e-11, fej=1e-11)}
+
+
+@pytest.mark.gpu
+@pytest.mark.xfail(strict=False, reason="written after the round's GPU budget was spent: its first run on hardware is the driver's round-end suite "
+                                        "(a failure here is a finding about the shims in the real tree, not about the library)")
+@pytest.mark.parametrize("mode", ["a", "b"])
+def test_dropin_library_equals_the_reference_updaters_on_the_gpu(dropin_libs, mode):
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "dropin_probe.py"), mode], capture_output=True, text=True, timeout=600)
+    lines = [json.loads(l) for l in p.stdout.splitlines() if l.startswith("{")]
+    seen = [l["case"] for l in lines]
+    assert p.returncode == 0 and seen and seen[-1] == "done", (p.returncode, seen, p.stderr[-2000:])
+    bad = []
+    for l in lines[:-1]:
+        kind = l["case"].split(":")[0]
+        if not l["status_equal"]:
+            bad.append((l["case"], "accept / reject sets differ"))
+        for k, lim in LIMITS[kind].items():
+            if not (0.0 <= l[k] < lim):
+                bad.append((l["case"], k, l[k], lim))
+    assert not bad, bad
+    assert sum(l.get("used", 0) for l in lines[:-1]) > 50 and any(l["case"].startswith("delayed") and l["accepted"] >= 4 for l in lines[:-1])
