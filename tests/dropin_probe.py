@@ -79,7 +79,27 @@ def anchors(mode, rep):
          P=rel(got["P"], ref["P"]), value=float(np.abs(got["value"] - ref["value"]).max()), fej=float(np.abs(got["fej"] - ref["fej"]).max()))
 
 
-CASES = [("msckf", 0), ("msckf", 3), ("msckf", 7), ("msckf", 11), ("msckf", 19), ("slam", 0), ("slam", 4), ("delayed", 0), ("delayed", 4), ("anchors", 2), ("anchors", 4)]
+def loop(mode, seconds):
+    """The rpng_sim closed loop (BASELINE configs[0]; tests/test_rpng_sim_loop.py) with the DROP-IN as the filter's updater: the reference's
+    Simulator, Propagator, FeatureDatabase and State around open_vins_amd/shim/UpdaterMSCKF.cpp, against the same loop around the reference's
+    UpdaterMSCKF.cpp; the control = two runs of the reference 1e-13 m apart at the start."""
+    from test_rpng_sim_loop import _ate, run_filter, separation
+    ref = run_filter("reference", seconds=seconds)
+    ctl = run_filter("reference", seconds=seconds, perturb=1e-13)
+    with pyref.using(pyref.dropin_path(mode)):
+        got = run_filter("reference", seconds=seconds)  # ("reference" = the library's own UpdaterMSCKF::update: here the shim's)
+    n = min(len(got["used"]), len(ref["used"]))
+    same_first = all(np.array_equal(got["used"][k], ref["used"][k]) for k in range(min(n, 100)))
+    n_dec = sum(len(u) for u in ref["used"][:n])
+    n_diff = sum(int((u != v).sum()) if len(u) == len(v) else len(v) for u, v in zip(got["used"][:n], ref["used"][:n]))
+    d = separation(got, ref)
+    a, b = _ate(got), _ate(ref)
+    emit(f"loop:{seconds}", updates=len(got["used"]), updates_reference=len(ref["used"]), status_equal=bool(same_first and len(got["used"]) == len(ref["used"])),
+         decisions=int(n_dec), differing=int(n_diff), sep_first_ten=float(d[:10].max()), sep=float(d.max()), control=float(separation(ctl, ref).max()),
+         ate_deg=a[0], ate_m=a[1], ate_deg_reference=b[0], ate_m_reference=b[1])
+
+
+CASES = [("msckf", 0), ("msckf", 3), ("msckf", 7), ("msckf", 11), ("msckf", 19), ("slam", 0), ("slam", 4), ("delayed", 0), ("delayed", 4), ("anchors", 2), ("anchors", 4), ("loop", 60.0)]
 
 if __name__ == "__main__":
     mode = sys.argv[1]
