@@ -7,7 +7,7 @@
 // are latency bound at two wavefronts per SIMD (256 registers), so a schedule built for instruction-level parallelism instead of
 // occupancy hides more of their operand latency; k_gram_il, at one wavefront per SIMD with 367 registers, loses under it (151 -> 215
 // vector registers, 0.211 -> 0.217 ms), and the chain kernels (triangulation, the factorisations, the tail) do not move.  Same box,
-// alternating bench lines (tools/gpu_ab3.sh, tools/gpu_bitcompare.sh, tools/gpu_bitcompare2.sh; profiles/r04_late_*):
+// alternating bench lines (tools/gpu_ab3.sh, tools/gpu_bitcompare.sh; profiles/r04_late_*):
 //   configs[2]  per-feature stage 0.512 -> 0.495 ms, update 1.033 -> 1.008 (a box of the slower kind; 0.437 -> 0.418 on a fast one)
 //   configs[1]  0.269 -> 0.260, update 0.615 -> 0.609
 //   configs[3] on one GPU (k_feat_y<8, 17, 1>)  6.62 -> 6.47, update 9.76 -> 9.60

@@ -1,8 +1,14 @@
 #!/bin/bash
-# The tree's libovgpu.so against ab_old/base.so on ONE box: outputs bit for bit over tools/dev_bitcompare.py's shapes (with the base
-# build against itself as the determinism control), then alternating bench lines at configs[2] and one at configs[3] on one GPU.
+# The tree's libovgpu.so against ab_old/base.so on ONE box: every output of tools/dev_bitcompare.py's 17 shapes bit for bit, then alternating
+# bench lines.  Usage: gpu_bitcompare.sh TAG [control] [cfg3] [cfg2] [cfg4] [cfg5]
+#   control   also the base build against itself (the determinism control)
+#   cfgN      bench lines to alternate: cfg3 = configs[2] (the headline), cfg2 = configs[1], cfg4 = configs[3] on one GPU, cfg5 = one rank's share of configs[4]
+# ab_old/problems.pkl: the problems, generated here on the CPU (`python tools/dev_bitcompare.py prepare ab_old/problems.pkl`).
+# Late round 4 this was run as: `bitcmp control cfg3 cfg2` (the 4-wavefront kernel in its own translation unit), `bitcmp2 cfg4 cfg5` (the 8-wavefront and
+# block-row kernels), `prio cfg4 cfg3` (the gate chain's wave priority): profiles/r04_late_*.
 set -u
 TAG=${1:-bitcmp}
+shift || true
 OUT=/root/repo/gpurun_out/$TAG
 mkdir -p $OUT
 cd /root/repo
@@ -11,15 +17,17 @@ cp $CUR /tmp/new.so
 P=ab_old/problems.pkl
 cp ab_old/base.so $CUR
 timeout 60 python tools/dev_bitcompare.py dump /tmp/base_a.npz $P > $OUT/dump_base_a.txt 2>&1
-timeout 60 python tools/dev_bitcompare.py dump /tmp/base_b.npz $P > $OUT/dump_base_b.txt 2>&1
+case " $* " in *" control "*)
+  timeout 60 python tools/dev_bitcompare.py dump /tmp/base_b.npz $P > $OUT/dump_base_b.txt 2>&1
+  echo "== base against itself (determinism control)" | tee $OUT/compare.txt
+  python tools/dev_bitcompare.py compare /tmp/base_a.npz /tmp/base_b.npz 2>&1 | tee -a $OUT/compare.txt;;
+esac
 cp /tmp/new.so $CUR
 timeout 60 python tools/dev_bitcompare.py dump /tmp/new.npz $P > $OUT/dump_new.txt 2>&1
-tail -3 $OUT/dump_new.txt
-echo "== base against itself (determinism control)" | tee $OUT/compare.txt
-python tools/dev_bitcompare.py compare /tmp/base_a.npz /tmp/base_b.npz 2>&1 | tee -a $OUT/compare.txt
+tail -2 $OUT/dump_new.txt
 echo "== new build against base" | tee -a $OUT/compare.txt
 python tools/dev_bitcompare.py compare /tmp/base_a.npz /tmp/new.npz 2>&1 | tee -a $OUT/compare.txt
-B="python bench.py --no-cpu-baseline --no-extras --warmup 10"
+B="python bench.py --no-cpu-baseline --no-extras"
 run() { # name, args
   timeout 60 $B $2 > $OUT/$1.json 2>> $OUT/err
   python - $OUT/$1.json <<'PY'
@@ -32,10 +40,16 @@ except Exception as e:
     print(sys.argv[1], "ERR", e)
 PY
 }
-for rep in 1; do
-  cp /tmp/new.so $CUR; run new_cfg3_$rep "--steps 300"
-  cp ab_old/base.so $CUR; run base_cfg3_$rep "--steps 300"
+for w in "$@"; do
+  case $w in
+    cfg3) A="--steps 300 --warmup 10";;
+    cfg2) A="--cfg 2 --steps 300 --warmup 10";;
+    cfg4) A="--cfg 4 --steps 30 --warmup 3";;
+    cfg5) A="--cfg 5 --features 2500 --steps 15 --warmup 2";;
+    *) continue;;
+  esac
+  cp /tmp/new.so $CUR; run new_$w "$A"
+  cp ab_old/base.so $CUR; run base_$w "$A"
 done
-cp /tmp/new.so $CUR; run new_cfg2 "--cfg 2 --steps 300"
-cp ab_old/base.so $CUR; run base_cfg2 "--cfg 2 --steps 300"
 cp /tmp/new.so $CUR
+tail -2 $OUT/err
