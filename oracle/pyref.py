@@ -60,8 +60,11 @@ def dropin_path(mode):
     return os.path.join(_HERE, "_ref", f"libov_dropin_{mode}.so")
 
 
-def build_dropin():
-    subprocess.check_call(["make", "-s", "-j8", "-C", os.path.join(_HERE, "ref"), "dropin"])
+def build_dropin(target="dropin"):
+    """target: "dropin" (links libovgpu) or "dropin_cpu" (links the oracle-backed test double tests/fake_ovgpu: mode names "a_cpu" / "b_cpu")."""
+    if target == "dropin_cpu":
+        subprocess.check_call(["make", "-s", "-C", _HERE])  # oracle/libov_oracle.so
+    subprocess.check_call(["make", "-s", "-j8", "-C", os.path.join(_HERE, "ref"), target])
 
 
 def dropin_available(mode="a"):
@@ -76,7 +79,8 @@ class using:
 
     def __enter__(self):
         global _lib
-        capi.load()  # libovgpu (and torch's HIP runtime before it) first: the drop-in library links against it
+        if not self.path.endswith("_cpu.so"):  # (the *_cpu builds link tests/fake_ovgpu, the oracle-backed double of the C ABI, instead)
+            capi.load()  # libovgpu (and torch's HIP runtime before it) first: the drop-in library links against it
         self.saved = _lib
         _lib = _open(self.path)
         return _lib

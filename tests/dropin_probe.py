@@ -3,7 +3,8 @@
 change_anchors on a reference `State` built by oracle/ref/ref_driver.cpp — once through oracle/_ref/libov_ref.so (the reference's own
 updaters) and once through oracle/_ref/libov_dropin_<mode>.so (the SAME driver and reference classes with open_vins_amd/shim's
 translation units in place of the reference's updaters, on the GPU through libovgpu), and prints one JSON line per case with the
-deviations.  TEST INFRASTRUCTURE."""
+deviations.  Modes a_cpu / b_cpu run the same drop-in build linked against tests/fake_ovgpu (the C ABI served by the CPU oracle): the shim's
+C++ end to end without a GPU.  TEST INFRASTRUCTURE."""
 import json
 import os
 import sys
@@ -102,10 +103,11 @@ def loop(mode, seconds):
 CASES = [("msckf", 0), ("msckf", 3), ("msckf", 7), ("msckf", 11), ("msckf", 19), ("slam", 0), ("slam", 4), ("delayed", 0), ("delayed", 4), ("anchors", 2), ("anchors", 4), ("loop", 60.0)]
 
 if __name__ == "__main__":
-    mode = sys.argv[1]
+    mode = sys.argv[1]  # a | b (libovgpu: needs the GPU) or a_cpu | b_cpu (tests/fake_ovgpu, the oracle-backed double of the C ABI: runs anywhere)
+    seconds = float(sys.argv[2]) if len(sys.argv) > 2 else 60.0
     pyref.load()
     for kind, arg in CASES:
-        globals()[kind](mode, arg)
+        globals()[kind](mode, seconds if kind == "loop" else arg)
     emit("done")
     sys.stdout.flush()
     os._exit(0)  # (the shims keep their contexts in a function-local static: nothing to learn from the order of static destructors at exit)
