@@ -57,17 +57,41 @@ def slam(mode, rep):
          dx=rel(got["dx"], ref["dx"]), P=rel(got["P"], ref["P"]), landmarks=float(np.abs(got["landmarks"] - ref["landmarks"]).max()), state=state_dev(got, ref))
 
 
-def delayed(mode, rep):
+def _aruco(F):
+    """UpdaterSLAM's second option set (UpdaterSLAM.cpp:226-232, :392-409): 40 % of the features are ArUco corners with their own sigma / multiplier."""
+    tag = np.random.default_rng(5).random(F) < 0.4
+    return np.where(tag, 2.5, 1.0), np.where(tag, 3.0, 1.0)
+
+
+def slam_aruco(mode, rep):
+    if mode == "a_cpu":  # (tests/fake_ovgpu does not model the row scaling of ovgpu_slam_compress under per-feature sigma)
+        return
+    prob = synth.make_slam_problem(2, L=10, lm_rep=rep)
+    opts = capi.default_options(chi2_multipler=1.0)
+    sig, mult = _aruco(prob.F)
+    ref = pyref.slam_update(opts, capi.Views(prob), feat_sigma=sig, feat_chi2mult=mult)
+    with pyref.using(pyref.dropin_path(mode)):
+        got = pyref.slam_update(opts, capi.Views(prob), feat_sigma=sig, feat_chi2mult=mult)
+    emit(f"slam:aruco{rep}", used=int((ref["feat_status"] == capi.FEAT_USED).sum()), status_equal=bool(np.array_equal(got["feat_status"], ref["feat_status"])),
+         dx=rel(got["dx"], ref["dx"]), P=rel(got["P"], ref["P"]), landmarks=float(np.abs(got["landmarks"] - ref["landmarks"]).max()), state=state_dev(got, ref))
+
+
+def delayed(mode, rep, aruco=False):
     prob = synth.make_problem(2, F=16, outlier_frac=0.2)
     opts = capi.default_options(chi2_multipler=1.0)
-    ref = pyref.slam_delayed_init(opts, capi.Views(prob), feat_rep=rep)
+    kw = dict(zip(("feat_sigma", "feat_chi2mult"), _aruco(16))) if aruco else {}
+    ref = pyref.slam_delayed_init(opts, capi.Views(prob), feat_rep=rep, **kw)
     with pyref.using(pyref.dropin_path(mode)):
-        got = pyref.slam_delayed_init(opts, capi.Views(prob), feat_rep=rep)
+        got = pyref.slam_delayed_init(opts, capi.Views(prob), feat_rep=rep, **kw)
     acc = ref["lm_cov_id"] >= 0
     same = bool(np.array_equal(got["feat_status"], ref["feat_status"]) and got["N"] == ref["N"] and np.array_equal(got["lm_cov_id"], ref["lm_cov_id"]))
-    emit(f"delayed:{rep}", accepted=int(acc.sum()), status_equal=same,
+    emit(f"delayed:{'aruco' if aruco else ''}{rep}", accepted=int(acc.sum()), status_equal=same,
          value=float(np.abs(got["lm_value"][acc] - ref["lm_value"][acc]).max()) if same and acc.any() else -1.0,
          P=rel(got["P"], ref["P"]) if same else -1.0, state=state_dev(got, ref))
+
+
+def delayed_aruco(mode, rep):
+    delayed(mode, rep, aruco=True)
 
 
 def anchors(mode, rep):
@@ -100,7 +124,7 @@ def loop(mode, seconds):
          ate_deg=a[0], ate_m=a[1], ate_deg_reference=b[0], ate_m_reference=b[1])
 
 
-CASES = [("msckf", 0), ("msckf", 3), ("msckf", 7), ("msckf", 11), ("msckf", 19), ("slam", 0), ("slam", 4), ("delayed", 0), ("delayed", 4), ("anchors", 2), ("anchors", 4), ("loop", 60.0)]
+CASES = [("msckf", 0), ("msckf", 3), ("msckf", 7), ("msckf", 11), ("msckf", 19), ("slam", 0), ("slam", 4), ("slam_aruco", 0), ("slam_aruco", 5), ("delayed", 0), ("delayed", 4), ("delayed", 5), ("delayed_aruco", 0), ("anchors", 2), ("anchors", 4), ("loop", 60.0)]
 
 if __name__ == "__main__":
     mode = sys.argv[1]  # a | b (libovgpu: needs the GPU) or a_cpu | b_cpu (tests/fake_ovgpu, the oracle-backed double of the C ABI: runs anywhere)
