@@ -15,6 +15,9 @@
 #ifdef OVGPU_SHIM_MODE_B
 #include "ovgpu_state_access.h"
 #endif
+#ifdef OVGPU_SHIM_RESIDENT_TRACKS
+#include "ovgpu_track_mirror.h" // opt-in: the observations live in the library's track store, an update names its tracks
+#endif
 
 using namespace ov_core;
 using namespace ov_type;
@@ -32,6 +35,28 @@ void UpdaterMSCKF::update(std::shared_ptr<State> state, std::vector<std::shared_
   const ovgpu_shim::CloneIndex clones(snap.fs.clone_times);
 
   // ---- 1. clean + flatten the tracks (UpdaterMSCKF.cpp:71-93)
+#ifdef OVGPU_SHIM_RESIDENT_TRACKS
+  // resident tracks (ovgpu_track_mirror.h): the Feature objects are cleaned as the reference cleans them (the database's own objects,
+  // :74), but nothing is copied out of them — the device holds every observation since the frame it was made
+  ovgpu_shim::TrackMirror &mirror = ovgpu_shim::TrackMirror::instance();
+  std::vector<int64_t> ids, seen_ids; // the batch; every track handed in (all of them leave the database after this update)
+  std::vector<int32_t> offs(1, 0);
+  for (auto it = feature_vec.begin(); it != feature_vec.end();) {
+    seen_ids.push_back((int64_t)(*it)->featid);
+    const int ct = ovgpu_shim::clean_track(**it, snap);
+    if (ct < 2) {
+      (*it)->to_delete = true;
+      it = feature_vec.erase(it);
+      continue;
+    }
+    ids.push_back((int64_t)(*it)->featid), offs.push_back(offs.back() + ct);
+    ++it;
+  }
+  if (feature_vec.empty()) {
+    if (mirror.attached()) mirror.erase(seen_ids);
+    return;
+  }
+#else
   static thread_local ovgpu_shim::FlatFeatures ff; // reused from update to update: a fresh 3.5 MB of buffers per call costs more in page faults than the flattening itself
   ff.clear();
   for (auto it = feature_vec.begin(); it != feature_vec.end();) {
@@ -44,16 +69,31 @@ void UpdaterMSCKF::update(std::shared_ptr<State> state, std::vector<std::shared_
     ++it;
   }
   if (feature_vec.empty()) return;
+#endif
 
   // ---- 2..5 on the GPU: triangulate, Jacobians, nullspace, chi2 gate, stack, compress (options re-read on every call)
   LandmarkRepresentation::Representation rep = state->_options.feat_rep_msckf; // :180-183: the single depth maps to the MSCKF inverse depth
   if (rep == LandmarkRepresentation::Representation::ANCHORED_INVERSE_DEPTH_SINGLE) rep = LandmarkRepresentation::Representation::ANCHORED_MSCKF_INVERSE_DEPTH;
   ovgpu_shim::Context &ctx = ovgpu_shim::context_for(ovgpu_shim::make_options(_options, initializer_feat->config(), state->_options, (int)rep));
   const ovgpu_state_view sv = snap.fs.view();
-  const ovgpu_features_view fv = ff.view();
   ctx.check(ovgpu_set_state(ctx.get(), &sv), "ovgpu_set_state");
+#ifdef OVGPU_SHIM_RESIDENT_TRACKS
+  mirror.attach(ctx.get(), snap.cam_index); // (first update: creates the store, replays the frames recorded so far)
+  mirror.sync();
+  const int F = (int)ids.size();
+  ctx.check(ovgpu_tracks_to_features(ctx.get(), F, ids.data(), snap.fs.clone_times.data()), "ovgpu_tracks_to_features");
+  { // the mirror must have followed the database: the device-assembled batch has the host's track lengths, or the integration is missing a call
+    std::vector<int32_t> dev_offs((size_t)F + 1);
+    int32_t Fd = 0, Md = 0;
+    ctx.check(ovgpu_get_features(ctx.get(), &Fd, &Md, dev_offs.data(), nullptr, nullptr, nullptr, nullptr), "ovgpu_get_features");
+    if (Fd != F || dev_offs != offs)
+      throw std::runtime_error("ovgpu: the resident track store is out of step with the FeatureDatabase (a TrackMirror call is missing: ovgpu_track_mirror.h)");
+  }
+#else
+  const ovgpu_features_view fv = ff.view();
   ctx.check(ovgpu_set_features(ctx.get(), &fv), "ovgpu_set_features");
   const int F = fv.F;
+#endif
   std::vector<int32_t> status(F), anchor(F);
   std::vector<double> pA(3 * (size_t)F), pG(3 * (size_t)F);
   int32_t rows = 0;
@@ -78,11 +118,18 @@ void UpdaterMSCKF::update(std::shared_ptr<State> state, std::vector<std::shared_
   // ---- side effects on the features: triangulation results, erase the rejected, flag the used
   size_t f = 0;
   for (auto it = feature_vec.begin(); it != feature_vec.end(); f++) {
+#ifdef OVGPU_SHIM_RESIDENT_TRACKS
+    ovgpu_shim::write_triangulation_nth(**it, anchor[f] < 0 ? -1 : anchor[f] - offs[f], &pA[3 * f], &pG[3 * f]);
+#else
     ovgpu_shim::write_triangulation(**it, snap, ff, anchor[f], &pA[3 * f], &pG[3 * f]);
+#endif
     (*it)->to_delete = true; // :137, :226, :262 — every feature that reached this point is flagged
     if (status[f] != OVGPU_FEAT_USED) it = feature_vec.erase(it);
     else ++it;
   }
+#ifdef OVGPU_SHIM_RESIDENT_TRACKS
+  mirror.erase(seen_ids); // every track of this update is flagged to_delete: FeatureDatabase::cleanup() drops them (VioManager.cpp:579)
+#endif
   if (rows < 1) return; // :266-268 / :276-278
 #ifdef OVGPU_SHIM_MODE_B
   ovgpu_shim::StateAccess::apply_update(*state, P_dev.data(), dx_dev.data(), sv.N); // StateHelper.cpp:166-196

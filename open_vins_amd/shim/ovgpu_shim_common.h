@@ -91,12 +91,13 @@ struct StateSnapshot {
 };
 
 // Feature::clean_old_measurements + flattening of one track; returns its number of measurements inside the window
-inline int flatten_track(ov_core::Feature &f, const StateSnapshot &snap, const CloneIndex &clones, FlatFeatures &ff) {
+inline int clean_track(ov_core::Feature &f, const StateSnapshot &snap) {
   f.clean_old_measurements(snap.fs.clone_times);
   int total = 0;
   for (const auto &pair : f.timestamps) total += (int)pair.second.size();
   return total;
 }
+inline int flatten_track(ov_core::Feature &f, const StateSnapshot &snap, const CloneIndex &clones, FlatFeatures &ff) { return clean_track(f, snap); }
 inline void append_track(const ov_core::Feature &f, const StateSnapshot &snap, const CloneIndex &clones, FlatFeatures &ff) {
   for (const auto &pair : f.timestamps) { // iteration order of Feature::timestamps: the anchor rule depends on it
     const auto &uvs = f.uvs.at(pair.first), &uvn = f.uvs_norm.at(pair.first);
@@ -113,6 +114,23 @@ inline void write_triangulation(ov_core::Feature &feat, const StateSnapshot &sna
   feat.anchor_clone_timestamp = ff.meas_time[anchor_meas];
   feat.p_FinA = Eigen::Map<const Eigen::Vector3d>(pA);
   feat.p_FinG = Eigen::Map<const Eigen::Vector3d>(pG);
+}
+
+// the same from the k-th observation of the (cleaned) feature in the order its tracks are flattened — the iteration order of
+// Feature::timestamps, time order inside a camera: what the resident-track mode has instead of a host-side flat batch
+inline void write_triangulation_nth(ov_core::Feature &feat, int k, const double *pA, const double *pG) {
+  if (k < 0) return;
+  for (const auto &pair : feat.timestamps) {
+    if (k < (int)pair.second.size()) {
+      feat.anchor_cam_id = (int)pair.first;
+      feat.anchor_clone_timestamp = pair.second[(size_t)k];
+      feat.p_FinA = Eigen::Map<const Eigen::Vector3d>(pA);
+      feat.p_FinG = Eigen::Map<const Eigen::Vector3d>(pG);
+      return;
+    }
+    k -= (int)pair.second.size();
+  }
+  throw std::runtime_error("ovgpu: anchor measurement outside the track");
 }
 
 // mode A: the compressed (H, r) in the canonical column order -> the stock StateHelper::EKFUpdate (UpdaterMSCKF.cpp:280-285)

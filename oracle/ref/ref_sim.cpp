@@ -39,6 +39,9 @@
 #include "types/IMU.h"
 #include "types/PoseJPL.h"
 #include "update/UpdaterMSCKF.h"
+#ifdef OVGPU_SHIM_RESIDENT_TRACKS
+#include "ovgpu_track_mirror.h"
+#endif
 #include "utils/print.h"
 #include "utils/quat_ops.h"
 #include "utils/sensor_data.h"
@@ -159,6 +162,9 @@ void front_end(RefSim &s, double timestamp, const std::vector<int> &camids,
       cv::Point2f pt(feat.second(0), feat.second(1));
       cv::Point2f npt_l = s.state->_cam_intrinsics_cameras.at(cam_id)->undistort_cv(pt);
       s.db->update_feature(id, timestamp, cam_id, pt.x, pt.y, npt_l.x, npt_l.y);
+#ifdef OVGPU_SHIM_RESIDENT_TRACKS // the drop-in's opt-in resident-track mode: the mirror follows the database call for call (shim/ovgpu_track_mirror.h)
+      ovgpu_shim::TrackMirror::instance().update_feature(id, timestamp, cam_id, pt.x, pt.y, npt_l.x, npt_l.y);
+#endif
     }
   }
 }
@@ -330,6 +336,10 @@ void *ref_sim_create(const ref_sim_config *c) {
   s->state->_timestamp = imustate(0, 0);
   s->startup_time = imustate(0, 0);
   s->db->cleanup_measurements(s->state->_timestamp);
+#ifdef OVGPU_SHIM_RESIDENT_TRACKS
+  ovgpu_shim::TrackMirror::instance().reset(); // a new filter: the mirror starts with it
+  ovgpu_shim::TrackMirror::instance().cleanup_measurements(s->state->_timestamp);
+#endif
   return s;
 }
 
@@ -485,7 +495,12 @@ void ref_sim_finish(void *h) {
   auto &state = s.state;
   for (auto const &feat : s.featsup) feat->to_delete = true;
   s.db->cleanup();
-  if ((int)state->_clones_IMU.size() > state->_options.max_clone_size) s.db->cleanup_measurements(state->margtimestep());
+  if ((int)state->_clones_IMU.size() > state->_options.max_clone_size) {
+    s.db->cleanup_measurements(state->margtimestep());
+#ifdef OVGPU_SHIM_RESIDENT_TRACKS
+    ovgpu_shim::TrackMirror::instance().cleanup_measurements(state->margtimestep());
+#endif
+  }
   StateHelper::marginalize_old_clone(state);
   s.featsup.clear(), s.cleaned.clear();
   s.pending = false;

@@ -131,6 +131,8 @@ if __name__ == "__main__":
     seconds = float(sys.argv[2]) if len(sys.argv) > 2 else 60.0
     pyref.load()
     for kind, arg in CASES:
+        if mode.startswith("r") and kind != "loop":
+            continue  # the resident-track build updates from the mirrored track store: only a LOOP feeds it (the per-call driver builds bare Features)
         globals()[kind](mode, seconds if kind == "loop" else arg)
     emit("done")
     sys.stdout.flush()

@@ -7,7 +7,7 @@
 // the oracle's, whose agreement with the reference (tests/test_ref_build.py) and with the HIP library (tests/test_gpu_parity.py) is
 // established elsewhere.
 //
-// Only the entry points the shims call exist, with the semantics include/ovgpu.h documents (resident state updated by mode-B calls,
+// Only the entry points the shims call exist (the track store of the resident-track mode included), with the semantics include/ovgpu.h documents (resident state updated by mode-B calls,
 // untouched by mode-A calls; landmarks resident across calls; per-feature options until the next batch).  Not modelled: per-feature
 // sigma scaling of the rows ovgpu_slam_compress returns (no ArUco case runs through it), device errors, capacities.
 #include <algorithm>
@@ -15,6 +15,7 @@
 #include <cstdint>
 #include <cstring>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/ovgpu.h"
@@ -44,6 +45,18 @@ struct ovgpu_ctx {
   std::vector<double> fsig, fmul;
   std::vector<double> pA, pG;
   std::vector<int32_t> anchor;
+  // the track store (ovgpu_tracks_*): per track the observations in append order and the cameras in order of first insertion
+  struct Obs {
+    double t;
+    int32_t cam;
+    float u, v, un, vn;
+  };
+  struct Track {
+    std::vector<Obs> obs;
+    std::vector<int32_t> cams;
+  };
+  int trk_max = 0, trk_obs = 0;
+  std::unordered_map<int64_t, Track> tracks;
 
   ovgpu_state_view sv() const {
     ovgpu_state_view v;
@@ -411,6 +424,99 @@ int ovgpu_refine(ovgpu_ctx *c, const double *p_FinA_in, const int32_t *anchor_me
   if (p_FinA) std::copy(a.begin(), a.begin() + 3 * (size_t)c->F, p_FinA);
   if (p_FinG) std::copy(g.begin(), g.begin() + 3 * (size_t)c->F, p_FinG);
   if (status) std::copy(st.begin(), st.begin() + c->F, status);
+  return OVGPU_OK;
+}
+
+// ---- the device FeatureDatabase (include/ovgpu.h: ovgpu_tracks_*), as a host container with the store's semantics
+int ovgpu_tracks_create(ovgpu_ctx *c, int32_t max_tracks, int32_t max_obs) {
+  if (!c || max_tracks <= 0 || max_obs <= 0) return fail(OVGPU_ERR_INVALID, "bad track store size");
+  c->trk_max = max_tracks, c->trk_obs = max_obs, c->tracks.clear();
+  return OVGPU_OK;
+}
+int ovgpu_tracks_append(ovgpu_ctx *c, double timestamp, int32_t n, const int64_t *featid, const int32_t *cam_id, const float *uv, const float *uvn) {
+  if (!c || c->trk_max <= 0) return fail(OVGPU_ERR_NO_STATE, "ovgpu_tracks_create was never called");
+  std::unordered_map<int64_t, int> add;
+  size_t fresh = 0;
+  for (int i = 0; i < n; i++) add[featid[i]]++;
+  for (const auto &kv : add) {
+    const auto it = c->tracks.find(kv.first);
+    if (it == c->tracks.end()) fresh++;
+    if ((it == c->tracks.end() ? 0 : (int)it->second.obs.size()) + kv.second > c->trk_obs) return fail(OVGPU_ERR_CAPACITY, "a track is full");
+  }
+  if (c->tracks.size() + fresh > (size_t)c->trk_max) return fail(OVGPU_ERR_CAPACITY, "the track store is full");
+  for (int i = 0; i < n; i++) {
+    ovgpu_ctx::Track &t = c->tracks[featid[i]];
+    if (std::find(t.cams.begin(), t.cams.end(), cam_id[i]) == t.cams.end()) t.cams.push_back(cam_id[i]);
+    t.obs.push_back({timestamp, cam_id[i], uv[2 * i], uv[2 * i + 1], uvn[2 * i], uvn[2 * i + 1]});
+  }
+  return OVGPU_OK;
+}
+int ovgpu_tracks_erase(ovgpu_ctx *c, int32_t n, const int64_t *featid) {
+  if (!c || c->trk_max <= 0) return fail(OVGPU_ERR_NO_STATE, "ovgpu_tracks_create was never called");
+  for (int i = 0; i < n; i++) c->tracks.erase(featid[i]);
+  return OVGPU_OK;
+}
+static int tracks_clean(ovgpu_ctx *c, double timestamp, bool exact, int32_t *n_erased) {
+  if (!c || c->trk_max <= 0) return fail(OVGPU_ERR_NO_STATE, "ovgpu_tracks_create was never called");
+  int erased = 0;
+  for (auto it = c->tracks.begin(); it != c->tracks.end();) {
+    auto &o = it->second.obs;
+    o.erase(std::remove_if(o.begin(), o.end(), [&](const ovgpu_ctx::Obs &x) { return exact ? x.t == timestamp : x.t <= timestamp; }), o.end());
+    if (o.empty()) it = c->tracks.erase(it), erased++;
+    else ++it;
+  }
+  if (n_erased) *n_erased = erased;
+  return OVGPU_OK;
+}
+int ovgpu_tracks_cleanup_measurements(ovgpu_ctx *c, double timestamp, int32_t *n_erased) { return tracks_clean(c, timestamp, false, n_erased); }
+int ovgpu_tracks_cleanup_measurements_exact(ovgpu_ctx *c, double timestamp, int32_t *n_erased) { return tracks_clean(c, timestamp, true, n_erased); }
+int ovgpu_tracks_count(ovgpu_ctx *c, int32_t *n_tracks) {
+  if (!c || !n_tracks) return fail(OVGPU_ERR_INVALID, "null argument");
+  *n_tracks = (int32_t)c->tracks.size();
+  return OVGPU_OK;
+}
+// the resident batch out of F stored tracks: observations at a clone time (exact ==), camera groups in REVERSE order of first insertion
+// (OVGPU_GROUPS_REFERENCE: how libstdc++ iterates Feature::timestamps), storage order inside a group
+int ovgpu_tracks_to_features(ovgpu_ctx *c, int32_t F, const int64_t *featid, const double *clone_times) {
+  if (!c || !c->have_state || c->poses_only) return fail(OVGPU_ERR_NO_STATE, "ovgpu_set_state must precede ovgpu_tracks_to_features");
+  if (c->trk_max <= 0) return fail(OVGPU_ERR_NO_STATE, "ovgpu_tracks_create was never called");
+  c->F = F, c->offs.assign(1, 0), c->uv.clear(), c->uvn.clear(), c->clone_idx.clear(), c->cam_idx.clear();
+  for (int f = 0; f < F; f++) {
+    const auto it = c->tracks.find(featid[f]);
+    if (it != c->tracks.end()) {
+      const ovgpu_ctx::Track &t = it->second;
+      for (int e = (int)t.cams.size() - 1; e >= 0; e--) {
+        if (t.cams[e] < 0 || t.cams[e] >= c->K) continue;
+        for (const ovgpu_ctx::Obs &o : t.obs) {
+          if (o.cam != t.cams[e]) continue;
+          int ci = -1;
+          for (int i = 0; i < c->C; i++)
+            if (clone_times[i] == o.t) {
+              ci = i;
+              break;
+            }
+          if (ci < 0) continue;
+          c->uv.push_back(o.u), c->uv.push_back(o.v), c->uvn.push_back(o.un), c->uvn.push_back(o.vn);
+          c->clone_idx.push_back(ci), c->cam_idx.push_back(o.cam);
+        }
+      }
+    }
+    c->offs.push_back((int32_t)c->clone_idx.size());
+  }
+  c->M = (int)c->clone_idx.size();
+  c->fsig.clear(), c->fmul.clear();
+  c->have_feats = true;
+  return OVGPU_OK;
+}
+int ovgpu_get_features(ovgpu_ctx *c, int32_t *F_out, int32_t *M_out, int32_t *meas_offsets, float *uv, float *uvn, int32_t *clone_idx, int32_t *cam_idx) {
+  if (!c || !c->have_feats) return fail(OVGPU_ERR_NO_STATE, "no feature batch");
+  if (F_out) *F_out = c->F;
+  if (M_out) *M_out = c->M;
+  if (meas_offsets) std::copy(c->offs.begin(), c->offs.end(), meas_offsets);
+  if (uv) std::copy(c->uv.begin(), c->uv.end(), uv);
+  if (uvn) std::copy(c->uvn.begin(), c->uvn.end(), uvn);
+  if (clone_idx) std::copy(c->clone_idx.begin(), c->clone_idx.end(), clone_idx);
+  if (cam_idx) std::copy(c->cam_idx.begin(), c->cam_idx.end(), cam_idx);
   return OVGPU_OK;
 }
 

@@ -54,6 +54,17 @@ def test_helper_headers_compile_in_a_caller():
     assert r.returncode == 0, r.stderr[-3000:]
 
 
+@pytest.mark.parametrize("mode", ["A", "B"])
+def test_resident_track_mode_of_the_msckf_unit_compiles(mode):
+    """-DOVGPU_SHIM_RESIDENT_TRACKS (ovgpu_track_mirror.h): the opt-in mode that names tracks of the library's store instead of flattening them."""
+    cmd = ["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Werror", "-DOVGPU_SHIM_RESIDENT_TRACKS", f"-I{MOCK}", f"-I{MOCK}/update", f"-I{MOCK}/feat",
+           f"-I{ROOT}/include", f"-I{SHIM}", os.path.join(SHIM, "UpdaterMSCKF.cpp")]
+    if mode == "B":
+        cmd.insert(1, "-DOVGPU_SHIM_MODE_B")
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+
+
 def test_every_shim_source_is_covered():
     assert sorted(f for f in os.listdir(SHIM) if f.endswith(".cpp") and f != "selftest.cpp") == sorted(UNITS)
 
@@ -82,7 +93,7 @@ def test_dropin_units_keep_the_reference_signatures():
 
 
 def test_no_shim_source_touches_the_oracle_or_the_environment():
-    for name in list(UNITS) + ["ovgpu_shim_common.h", "ovgpu_flatten.h", "ovgpu_state_access.h", "ovgpu_zupt.h", "ovgpu_retri.h"]:
+    for name in list(UNITS) + ["ovgpu_shim_common.h", "ovgpu_flatten.h", "ovgpu_state_access.h", "ovgpu_zupt.h", "ovgpu_retri.h", "ovgpu_track_mirror.h"]:
         s = _src(name)
         assert "oracle" not in s and "getenv" not in s, name
 
