@@ -39,6 +39,7 @@
 #include "types/IMU.h"
 #include "types/PoseJPL.h"
 #include "update/UpdaterMSCKF.h"
+#include <cstdlib>
 #ifdef OVGPU_SHIM_RESIDENT_TRACKS
 #include "ovgpu_track_mirror.h"
 #endif
@@ -163,7 +164,10 @@ void front_end(RefSim &s, double timestamp, const std::vector<int> &camids,
       cv::Point2f npt_l = s.state->_cam_intrinsics_cameras.at(cam_id)->undistort_cv(pt);
       s.db->update_feature(id, timestamp, cam_id, pt.x, pt.y, npt_l.x, npt_l.y);
 #ifdef OVGPU_SHIM_RESIDENT_TRACKS // the drop-in's opt-in resident-track mode: the mirror follows the database call for call (shim/ovgpu_track_mirror.h)
-      ovgpu_shim::TrackMirror::instance().update_feature(id, timestamp, cam_id, pt.x, pt.y, npt_l.x, npt_l.y);
+      // (test hook: OVGPU_TEST_DROP_MIRROR_FRAME=n forgets the mirror call of every n-th frame — the integration mistake the shim must catch)
+      static const int drop_every = std::getenv("OVGPU_TEST_DROP_MIRROR_FRAME") ? std::atoi(std::getenv("OVGPU_TEST_DROP_MIRROR_FRAME")) : 0;
+      if (!(drop_every > 0 && s.frames % drop_every == drop_every - 1))
+        ovgpu_shim::TrackMirror::instance().update_feature(id, timestamp, cam_id, pt.x, pt.y, npt_l.x, npt_l.y);
 #endif
     }
   }

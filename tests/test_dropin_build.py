@@ -200,6 +200,19 @@ def test_resident_track_mode_of_the_dropin_runs_the_closed_loop_with_the_oracle_
     _judge(_run_probe("r_cpu", 30.0), LIMITS_CPU, 290, loop_only=True)
 
 
+def test_resident_track_mode_refuses_to_update_from_a_store_that_missed_a_frame(dropin_libs):
+    """The integration mistake the mode invites: a front-end path that feeds the FeatureDatabase but not the mirror.  The test hook of
+    oracle/ref/ref_sim.cpp forgets the mirror call of every 9th frame; the shim compares the device-assembled batch's track lengths with the
+    host's on every update and throws (the reference's update path has no error channel: the process ends) instead of updating from stale tracks."""
+    if pyref.can_build():
+        pyref.build_dropin("dropin_cpu")
+    if not os.path.exists(pyref.dropin_path("r_cpu")):
+        pytest.skip("oracle/_ref/libov_dropin_r_cpu.so is not here and cannot be built (no /root/reference)")
+    env = dict(os.environ, OVGPU_TEST_DROP_MIRROR_FRAME="9")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "dropin_probe.py"), "r_cpu", "10"], capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode != 0 and "out of step with the FeatureDatabase" in p.stderr and '"done"' not in p.stdout, (p.returncode, p.stdout[-500:], p.stderr[-800:])
+
+
 @pytest.mark.gpu
 @pytest.mark.xfail(strict=False, reason="written after the round's GPU budget was spent: its first run on hardware is the driver's round-end suite "
                                         "(a failure here is a finding about the shims in the real tree, not about the library)")
