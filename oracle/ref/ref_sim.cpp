@@ -39,6 +39,7 @@
 #include "types/IMU.h"
 #include "types/PoseJPL.h"
 #include "update/UpdaterMSCKF.h"
+#include "update/UpdaterSLAM.h"
 #include <cstdlib>
 #ifdef OVGPU_SHIM_RESIDENT_TRACKS
 #include "ovgpu_track_mirror.h"
@@ -61,6 +62,9 @@ typedef struct {
   int32_t seed_state_init, seed_perturb, seed_measurements;
   double sigma_px, chi2_multipler;
   double freq_cam, freq_imu, distance_threshold, min_feature_gen_dist, max_feature_gen_dist;
+  /* SLAM landmarks in the loop (config/rpng_sim/estimator_config.yaml:17-20 ships max_slam: 50, dt_slam_delay: 2): 0 = an MSCKF-only filter */
+  int32_t max_slam_features, feat_rep_slam;
+  double dt_slam_delay;
 } ref_sim_config;
 }
 
@@ -88,6 +92,8 @@ struct RefSim {
   std::shared_ptr<Propagator> propagator;
   std::shared_ptr<FeatureDatabase> db;
   std::shared_ptr<UpdaterMSCKF> updater;
+  std::shared_ptr<UpdaterSLAM> updater_slam; // only with max_slam_features > 0
+  std::vector<std::shared_ptr<Feature>> feats_slam_update, feats_slam_delayed; // VioManager's feats_slam_UPDATE / _DELAYED of the pending frame
   size_t currid = 0;
   double startup_time = 0;
   // run_simulation.cpp's one-frame buffer
@@ -149,6 +155,7 @@ void build_filter(RefSim &s) {
   }
   s.propagator = std::make_shared<Propagator>(params.imu_noises, params.gravity_mag);
   s.updater = std::make_shared<UpdaterMSCKF>(params.msckf_options, params.featinit_options);
+  if (params.state_options.max_slam_features > 0) s.updater_slam = std::make_shared<UpdaterSLAM>(params.slam_options, params.aruco_options, params.featinit_options); // VioManager.cpp:156
   s.db = std::make_shared<FeatureDatabase>();
   s.currid = 4 * (size_t)state->_options.max_aruco_features + 1; // TrackBase.cpp:34
 }
@@ -224,7 +231,35 @@ bool propagate_and_select(RefSim &s, double timestamp, const std::vector<int> &s
       it2++;
     }
   }
-  // :497-520 (max_slam_features = 0: nothing is taken out of feats_maxtracks)
+  // :430-491 SLAM landmarks (only with max_slam_features > 0; no ArUco tracker here: curr_aruco_tags = 0)
+  s.feats_slam_update.clear(), s.feats_slam_delayed.clear();
+  if (state->_options.max_slam_features > 0) {
+    std::vector<std::shared_ptr<Feature>> feats_slam;
+    // :441-452 new landmarks out of the tracks that reached the window length, once the delay has passed and while there is room
+    if (timestamp - s.startup_time >= s.params.dt_slam_delay && (int)state->_features_SLAM.size() < state->_options.max_slam_features) {
+      const int amount_to_add = state->_options.max_slam_features - (int)state->_features_SLAM.size();
+      const int valid_amount = (amount_to_add > (int)feats_maxtracks.size()) ? (int)feats_maxtracks.size() : amount_to_add;
+      if (valid_amount > 0) {
+        feats_slam.insert(feats_slam.end(), feats_maxtracks.end() - valid_amount, feats_maxtracks.end());
+        feats_maxtracks.erase(feats_maxtracks.end() - valid_amount, feats_maxtracks.end());
+      }
+    }
+    // :459-476 the tracks of the landmarks in the state; a landmark that lost its track in its own camera, or failed twice, is marginalised
+    for (std::pair<const size_t, std::shared_ptr<Landmark>> &landmark : state->_features_SLAM) {
+      std::shared_ptr<Feature> feat2 = s.db->get_feature(landmark.second->_featid);
+      if (feat2 != nullptr) feats_slam.push_back(feat2);
+      assert(landmark.second->_unique_camera_id != -1);
+      const bool current_unique_cam = std::find(sensor_ids.begin(), sensor_ids.end(), landmark.second->_unique_camera_id) != sensor_ids.end();
+      if (feat2 == nullptr && current_unique_cam) landmark.second->should_marg = true;
+      if (landmark.second->update_fail_count > 1) landmark.second->should_marg = true;
+    }
+    StateHelper::marginalize_slam(state); // :481
+    for (size_t i = 0; i < feats_slam.size(); i++) { // :484-494
+      if (state->_features_SLAM.find(feats_slam.at(i)->featid) != state->_features_SLAM.end()) s.feats_slam_update.push_back(feats_slam.at(i));
+      else s.feats_slam_delayed.push_back(feats_slam.at(i));
+    }
+  }
+  // :497-520
   std::vector<std::shared_ptr<Feature>> featsup_MSCKF = feats_lost;
   featsup_MSCKF.insert(featsup_MSCKF.end(), feats_marg.begin(), feats_marg.end());
   featsup_MSCKF.insert(featsup_MSCKF.end(), feats_maxtracks.begin(), feats_maxtracks.end());
@@ -289,8 +324,12 @@ void *ref_sim_create(const ref_sim_config *c) {
   p.state_options.do_calib_imu_g_sensitivity = c->calib_imu_g_sensitivity != 0;
   p.state_options.imu_model = StateOptions::KALIBR;
   p.state_options.max_clone_size = c->max_clones;
-  p.state_options.max_slam_features = 0;
+  p.state_options.max_slam_features = c->max_slam_features;
   p.state_options.max_slam_in_update = 25;
+  p.state_options.feat_rep_slam = (LandmarkRepresentation::Representation)c->feat_rep_slam;
+  p.dt_slam_delay = c->dt_slam_delay;
+  p.slam_options.sigma_pix = c->sigma_px, p.slam_options.sigma_pix_sq = c->sigma_px * c->sigma_px, p.slam_options.chi2_multipler = c->chi2_multipler;
+  p.aruco_options = p.slam_options;
   p.state_options.max_msckf_in_update = c->max_msckf_in_update;
   p.state_options.max_aruco_features = 1024;
   p.state_options.num_cameras = c->num_cameras;
@@ -452,6 +491,19 @@ int ref_sim_update_reference(void *h, int32_t *feat_used) {
   s.updater->update(s.state, s.featsup);
   s.propagator->invalidate_cache();
   for (size_t f = 0; f < all.size() && feat_used; f++) feat_used[f] = std::find(s.featsup.begin(), s.featsup.end(), all[f]) != s.featsup.end() ? 1 : 0;
+  if (s.updater_slam) { // VioManager.cpp:529-547: the landmarks' update in chunks of max_slam_in_update, then the delayed initialisation
+    std::vector<std::shared_ptr<Feature>> done, todo = s.feats_slam_update;
+    while (!todo.empty()) {
+      const int n = std::min(s.state->_options.max_slam_in_update, (int)todo.size());
+      std::vector<std::shared_ptr<Feature>> chunk(todo.begin(), todo.begin() + n);
+      todo.erase(todo.begin(), todo.begin() + n);
+      s.updater_slam->update(s.state, chunk);
+      done.insert(done.end(), chunk.begin(), chunk.end());
+      s.propagator->invalidate_cache();
+    }
+    s.feats_slam_update = done;
+    s.updater_slam->delayed_init(s.state, s.feats_slam_delayed);
+  }
   s.updates++;
   return 0;
 }
@@ -463,6 +515,7 @@ int ref_sim_update_reference(void *h, int32_t *feat_used) {
 int ref_sim_update_external(void *h, const double *dx, const double *P, const int32_t *feat_status, const double *p_FinG) {
   RefSim &s = *static_cast<RefSim *>(h);
   if (!s.pending) return 1;
+  if (s.updater_slam) return 2; // (an outside updater takes the MSCKF update only: run SLAM loops with the library's own updaters)
   auto &state = s.state;
   const int N = state->max_covariance_size();
   bool any = false;
@@ -498,7 +551,19 @@ void ref_sim_finish(void *h) {
   RefSim &s = *static_cast<RefSim *>(h);
   auto &state = s.state;
   for (auto const &feat : s.featsup) feat->to_delete = true;
+#ifdef OVGPU_SHIM_RESIDENT_TRACKS
+  { // tracks flagged to_delete OUTSIDE the MSCKF update (UpdaterSLAM::update / delayed_init flag what they were handed) leave the mirror as well
+    std::vector<int64_t> gone;
+    for (auto const &v : {s.feats_slam_update, s.feats_slam_delayed})
+      for (auto const &feat : v)
+        if (feat->to_delete) gone.push_back((int64_t)feat->featid);
+    for (auto const &kv : s.db->get_internal_data())
+      if (kv.second->to_delete && std::find(gone.begin(), gone.end(), (int64_t)kv.first) == gone.end() && s.updater_slam) gone.push_back((int64_t)kv.first);
+    ovgpu_shim::TrackMirror::instance().erase(gone);
+  }
+#endif
   s.db->cleanup();
+  if (s.updater_slam) s.updater_slam->change_anchors(state); // VioManager.cpp:585
   if ((int)state->_clones_IMU.size() > state->_options.max_clone_size) {
     s.db->cleanup_measurements(state->margtimestep());
 #ifdef OVGPU_SHIM_RESIDENT_TRACKS
@@ -506,7 +571,7 @@ void ref_sim_finish(void *h) {
 #endif
   }
   StateHelper::marginalize_old_clone(state);
-  s.featsup.clear(), s.cleaned.clear();
+  s.featsup.clear(), s.cleaned.clear(), s.feats_slam_update.clear(), s.feats_slam_delayed.clear();
   s.pending = false;
 }
 

@@ -24,7 +24,8 @@ class Config(C.Structure):
                 ("calib_imu_g_sensitivity", C.c_int32), ("feat_rep_msckf", C.c_int32), ("use_stereo", C.c_int32), ("do_perturbation", C.c_int32),
                 ("seed_state_init", C.c_int32), ("seed_perturb", C.c_int32), ("seed_measurements", C.c_int32), ("sigma_px", C.c_double),
                 ("chi2_multipler", C.c_double), ("freq_cam", C.c_double), ("freq_imu", C.c_double), ("distance_threshold", C.c_double),
-                ("min_feature_gen_dist", C.c_double), ("max_feature_gen_dist", C.c_double)]
+                ("min_feature_gen_dist", C.c_double), ("max_feature_gen_dist", C.c_double),
+                ("max_slam_features", C.c_int32), ("feat_rep_slam", C.c_int32), ("dt_slam_delay", C.c_double)]
 
 
 def rpng_sim_config(traj_path=None, **kw):
@@ -34,7 +35,8 @@ def rpng_sim_config(traj_path=None, **kw):
     c = Config(traj_path=traj.encode(), num_cameras=1, max_clones=11, max_msckf_in_update=50, num_pts=250, use_fej=1, integration=1,
                calib_cam_extrinsics=1, calib_cam_intrinsics=1, calib_cam_timeoffset=1, calib_imu_intrinsics=1, calib_imu_g_sensitivity=1,
                feat_rep_msckf=0, use_stereo=1, do_perturbation=0, seed_state_init=0, seed_perturb=0, seed_measurements=0, sigma_px=1.0,
-               chi2_multipler=1.0, freq_cam=10.0, freq_imu=400.0, distance_threshold=1.1, min_feature_gen_dist=5.0, max_feature_gen_dist=7.0)
+               chi2_multipler=1.0, freq_cam=10.0, freq_imu=400.0, distance_threshold=1.1, min_feature_gen_dist=5.0, max_feature_gen_dist=7.0,
+               max_slam_features=0, feat_rep_slam=0, dt_slam_delay=2.0)  # (the shipped file has max_slam: 50; BASELINE configs[0] is the MSCKF-only filter)
     for k, v in kw.items():
         if not hasattr(c, k):
             raise AttributeError(k)

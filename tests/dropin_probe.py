@@ -104,36 +104,43 @@ def anchors(mode, rep):
          P=rel(got["P"], ref["P"]), value=float(np.abs(got["value"] - ref["value"]).max()), fej=float(np.abs(got["fej"] - ref["fej"]).max()))
 
 
-def loop(mode, seconds):
+def loop_slam(mode, seconds):
+    """The same loop with SLAM landmarks in the filter (config/rpng_sim/estimator_config.yaml ships max_slam: 50; here 25, delay 2 s): VioManager's
+    landmark handling (VioManager.cpp:430-491, :529-547, :585) around UpdaterSLAM::update / delayed_init / change_anchors — the shim's, against the
+    reference's."""
+    loop(mode, seconds, name="loop_slam", max_slam_features=25, dt_slam_delay=2.0)
+
+
+def loop(mode, seconds, name="loop", **cfg):
     """The rpng_sim closed loop (BASELINE configs[0]; tests/test_rpng_sim_loop.py) with the DROP-IN as the filter's updater: the reference's
     Simulator, Propagator, FeatureDatabase and State around open_vins_amd/shim/UpdaterMSCKF.cpp, against the same loop around the reference's
     UpdaterMSCKF.cpp; the control = two runs of the reference 1e-13 m apart at the start."""
     from test_rpng_sim_loop import _ate, run_filter, separation
-    ref = run_filter("reference", seconds=seconds)
-    ctl = run_filter("reference", seconds=seconds, perturb=1e-13)
+    ref = run_filter("reference", seconds=seconds, **cfg)
+    ctl = run_filter("reference", seconds=seconds, perturb=1e-13, **cfg)
     with pyref.using(pyref.dropin_path(mode)):
-        got = run_filter("reference", seconds=seconds)  # ("reference" = the library's own UpdaterMSCKF::update: here the shim's)
+        got = run_filter("reference", seconds=seconds, **cfg)  # ("reference" = the library's own updaters: here the shim's)
     n = min(len(got["used"]), len(ref["used"]))
     same_first = all(np.array_equal(got["used"][k], ref["used"][k]) for k in range(min(n, 100)))
     n_dec = sum(len(u) for u in ref["used"][:n])
     n_diff = sum(int((u != v).sum()) if len(u) == len(v) else len(v) for u, v in zip(got["used"][:n], ref["used"][:n]))
     d = separation(got, ref)
     a, b = _ate(got), _ate(ref)
-    emit(f"loop:{seconds}", updates=len(got["used"]), updates_reference=len(ref["used"]), status_equal=bool(same_first and len(got["used"]) == len(ref["used"])),
+    emit(f"{name}:{seconds}", updates=len(got["used"]), state_dim_max=int(got["N"].max()), state_dim_max_reference=int(ref["N"].max()), updates_reference=len(ref["used"]), status_equal=bool(same_first and len(got["used"]) == len(ref["used"])),
          decisions=int(n_dec), differing=int(n_diff), sep_first_ten=float(d[:10].max()), sep=float(d.max()), control=float(separation(ctl, ref).max()),
          ate_deg=a[0], ate_m=a[1], ate_deg_reference=b[0], ate_m_reference=b[1])
 
 
-CASES = [("msckf", 0), ("msckf", 3), ("msckf", 7), ("msckf", 11), ("msckf", 19), ("slam", 0), ("slam", 4), ("slam_aruco", 0), ("slam_aruco", 5), ("delayed", 0), ("delayed", 4), ("delayed", 5), ("delayed_aruco", 0), ("anchors", 2), ("anchors", 4), ("loop", 60.0)]
+CASES = [("msckf", 0), ("msckf", 3), ("msckf", 7), ("msckf", 11), ("msckf", 19), ("slam", 0), ("slam", 4), ("slam_aruco", 0), ("slam_aruco", 5), ("delayed", 0), ("delayed", 4), ("delayed", 5), ("delayed_aruco", 0), ("anchors", 2), ("anchors", 4), ("loop", 60.0), ("loop_slam", 60.0)]
 
 if __name__ == "__main__":
     mode = sys.argv[1]  # a | b (libovgpu: needs the GPU) or a_cpu | b_cpu (tests/fake_ovgpu, the oracle-backed double of the C ABI: runs anywhere)
     seconds = float(sys.argv[2]) if len(sys.argv) > 2 else 60.0
     pyref.load()
     for kind, arg in CASES:
-        if mode.startswith("r") and kind != "loop":
+        if mode.startswith("r") and not kind.startswith("loop"):
             continue  # the resident-track build updates from the mirrored track store: only a LOOP feeds it (the per-call driver builds bare Features)
-        globals()[kind](mode, seconds if kind == "loop" else arg)
+        globals()[kind](mode, seconds if kind.startswith("loop") else arg)
     emit("done")
     sys.stdout.flush()
     os._exit(0)  # (the shims keep their contexts in a function-local static: nothing to learn from the order of static destructors at exit)

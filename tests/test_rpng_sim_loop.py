@@ -64,7 +64,7 @@ def run_filter(update, seconds=SECONDS, perturb=0.0, **cfg_kw):
     sim = refsim.RefSim(refsim.rpng_sim_config(**cfg_kw))
     if perturb:
         sim.perturb(perturb)
-    est, gt, used, nfeat = [], [], [], []
+    est, gt, used, nfeat, dims = [], [], [], [], []
     t0 = None
     while sim.advance():
         prob = sim.pending()
@@ -75,14 +75,14 @@ def run_filter(update, seconds=SECONDS, perturb=0.0, **cfg_kw):
             sim.update_external(out["dx"], out["P"], out["feat_status"], out.get("p_FinG"))
             u = out["feat_status"] == capi.FEAT_USED
         sim.finish()
-        e, g, _, ok = sim.state()
+        e, g, extra, ok = sim.state()
         assert ok
         t0 = e[0] if t0 is None else t0
-        est.append(e), gt.append(g), used.append(u), nfeat.append(prob.F)
+        est.append(e), gt.append(g), used.append(u), nfeat.append(prob.F), dims.append(int(extra[1]))
         if e[0] - t0 >= seconds:
             break
     sim.close()
-    return dict(est=np.array(est), gt=np.array(gt), used=used, nfeat=np.array(nfeat))
+    return dict(est=np.array(est), gt=np.array(gt), used=used, nfeat=np.array(nfeat), N=np.array(dims))
 
 
 def separation(a, b):
