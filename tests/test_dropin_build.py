@@ -141,6 +141,31 @@ def _run_probe(mode, seconds):
     return lines[:-1]
 
 
+@pytest.fixture(scope="module")
+def cpu_probes(dropin_libs):
+    """The three oracle-backed builds run side by side (they share nothing): module-scoped, so the CPU suite pays the longest of them once."""
+    if pyref.can_build():
+        pyref.build_dropin("dropin_cpu")
+    modes = [m for m in ("a_cpu", "b_cpu", "r_cpu") if os.path.exists(pyref.dropin_path(m))]
+    procs = {m: subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dropin_probe.py"), m, "20"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for m in modes}
+    out = {}
+    for m, pr in procs.items():
+        so, se = pr.communicate(timeout=900)
+        lines = [json.loads(l) for l in so.splitlines() if l.startswith("{")]
+        out[m] = (pr.returncode, lines, se)
+    return out
+
+
+def _cpu_lines(cpu_probes, mode):
+    if mode not in cpu_probes:
+        pytest.skip(f"oracle/_ref/libov_dropin_{mode}.so is not here and cannot be built (no /root/reference)")
+    rc, lines, err = cpu_probes[mode]
+    seen = [l["case"] for l in lines]
+    assert rc == 0 and seen and seen[-1] == "done", (rc, seen, err[-2000:])
+    return lines[:-1]
+
+
 def _judge(lines, limits, min_updates, loop_only=False):
     bad = []
     for l in lines:
@@ -175,31 +200,23 @@ LIMITS_CPU = {"msckf": dict(pos=1e-10, dx=1e-10, P=1e-11, state=1e-10), "slam": 
 
 
 @pytest.mark.parametrize("mode", ["a_cpu", "b_cpu"])
-def test_dropin_library_equals_the_reference_updaters_with_the_oracle_behind_the_abi(dropin_libs, mode):
+def test_dropin_library_equals_the_reference_updaters_with_the_oracle_behind_the_abi(cpu_probes, mode):
     """The shim's C++ END TO END on this machine: the drop-in library linked against tests/fake_ovgpu (include/ovgpu.h's entry points served by
     the CPU oracle) instead of libovgpu.  UpdaterMSCKF::update on five seeded batches (six representations, calibration / FEJ flags, outliers),
     UpdaterSLAM::update, delayed_init chains, change_anchors, and 20 s of the rpng_sim closed loop with the shim as the reference filter's
     updater (MSCKF-only as BASELINE configs[0], and with SLAM landmarks in the state: VioManager's landmark handling around the shim's UpdaterSLAM) — each against the reference's own updaters on identical reference `State`s: identical accept / reject sets with the rejecting
     stage (which also runs the FeatureInitializer shim against the reference's), dx / P' / landmarks at the oracle's agreement with the
     reference, the closed loop inside the reference's own control run."""
-    if pyref.can_build():
-        pyref.build_dropin("dropin_cpu")
-    if not os.path.exists(pyref.dropin_path(mode)):
-        pytest.skip("oracle/_ref/libov_dropin_*_cpu.so is not here and cannot be built (no /root/reference)")
-    _judge(_run_probe(mode, 20.0), LIMITS_CPU, 190)
+    _judge(_cpu_lines(cpu_probes, mode), LIMITS_CPU, 190)
 
 
-def test_resident_track_mode_of_the_dropin_runs_the_closed_loop_with_the_oracle_behind_the_abi(dropin_libs):
+def test_resident_track_mode_of_the_dropin_runs_the_closed_loop_with_the_oracle_behind_the_abi(cpu_probes):
     """-DOVGPU_SHIM_RESIDENT_TRACKS (shim/ovgpu_track_mirror.h): the observations are mirrored into the library's track
     store as the front end makes them — the three TrackMirror calls a maintainer adds next to FeatureDatabase::update_feature /
     cleanup_measurements sit in oracle/ref/ref_sim.cpp, the restatement of VioManager's loop — and UpdaterMSCKF::update names its tracks
     instead of flattening and uploading them (ovgpu_tracks_to_features; the device-assembled batch is checked against the host's track
     lengths on every update, a missing mirror call throws).  20 s of the rpng_sim closed loops, mode B, against the reference's own updater."""
-    if pyref.can_build():
-        pyref.build_dropin("dropin_cpu")
-    if not os.path.exists(pyref.dropin_path("r_cpu")):
-        pytest.skip("oracle/_ref/libov_dropin_r_cpu.so is not here and cannot be built (no /root/reference)")
-    _judge(_run_probe("r_cpu", 20.0), LIMITS_CPU, 190, loop_only=True)
+    _judge(_cpu_lines(cpu_probes, "r_cpu"), LIMITS_CPU, 190, loop_only=True)
 
 
 def test_resident_track_mode_refuses_to_update_from_a_store_that_missed_a_frame(dropin_libs):
