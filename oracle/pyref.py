@@ -280,3 +280,22 @@ def ekf_update(opts, views, H, res, col_cov_id, sigma2):
     rc = load().ref_ekf_update(C.byref(opts), C.byref(views.state), _p(H), _p(res), C.c_int(H.shape[0]), C.c_int(H.shape[1]), _pi(cols),
                                C.c_double(float(sigma2)), _p(dx), _p(P))
     return rc, P, dx
+
+
+def zupt_try_update(opts, views, imu_value, imu_t, imu_wm, imu_am, t_state, t_update, max_velocity=0.5, noise_multiplier=10.0, max_disparity=1.0):
+    """UpdaterZeroVelocity::try_update on the view's state with the IMU at imu_value [16] (oracle/ref/ref_driver.cpp: ref_zupt_try_update)."""
+    N = views.state.N
+    iv = np.ascontiguousarray(imu_value, dtype=np.float64)
+    t = np.ascontiguousarray(imu_t, dtype=np.float64)
+    wm = np.ascontiguousarray(imu_wm, dtype=np.float64)
+    am = np.ascontiguousarray(imu_am, dtype=np.float64)
+    out = dict(dx=np.zeros(N), P=np.zeros((N, N)), imu=np.zeros(16))
+    acc, ts = C.c_int32(0), C.c_double(0.0)
+    lib = load()
+    lib.ref_zupt_try_update.restype = C.c_int
+    rc = lib.ref_zupt_try_update(C.byref(opts), C.byref(views.state), _p(iv), C.c_int(len(t)), _p(t), _p(wm), _p(am), C.c_double(t_state), C.c_double(t_update),
+                                 C.c_double(max_velocity), C.c_double(noise_multiplier), C.c_double(max_disparity), C.byref(acc), _p(out["dx"]), _p(out["P"]),
+                                 _p(out["imu"]), C.byref(ts))
+    assert rc == 0
+    out["accepted"], out["timestamp"] = bool(acc.value), ts.value
+    return out

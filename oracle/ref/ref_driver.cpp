@@ -38,6 +38,10 @@
 #include "types/PoseJPL.h"
 #include "update/UpdaterHelper.h"
 #include "update/UpdaterMSCKF.h"
+#include "feat/FeatureDatabase.h"
+#include "state/Propagator.h"
+#include "update/UpdaterZeroVelocity.h"
+#include "utils/sensor_data.h"
 #include "update/UpdaterSLAM.h"
 #include "utils/print.h"
 #include "utils/quat_ops.h"
@@ -821,6 +825,40 @@ int ref_ekf_update(const ovgpu_options *o, const ovgpu_state_view *st, const dou
   StateHelper::EKFUpdate(rs.state, order, Hm, r, R);
   export_dx(rs, before, dx, st->N);
   export_cov(rs, P_out);
+  return OVGPU_OK;
+}
+
+// UpdaterZeroVelocity::try_update (UpdaterZeroVelocity.cpp:64-332) on a state built from the view with the IMU variable at imu_value [16]
+// (q, p, v, bg, ba) and State::_timestamp = t_state: n_imu readings (time, gyroscope, accelerometer) are fed, then try_update(state, t_update)
+// runs with an empty feature database (the disparity test cannot pass: the decision is the chi2 / velocity one, :241).  In the drop-in builds
+// the covariance work of the function is the shim's (oracle/ref/patch_zupt.py applies INTEGRATION.md's patch to the reference's own file).
+int ref_zupt_try_update(const ovgpu_options *o, const ovgpu_state_view *st, const double *imu_value, int n_imu, const double *imu_t, const double *imu_wm,
+                        const double *imu_am, double t_state, double t_update, double max_velocity, double noise_multiplier, double max_disparity,
+                        int32_t *accepted, double *dx, double *P_out, double *imu_value_out, double *state_time_out) {
+  RefState rs;
+  if (!build_state(o, st, nullptr, imu_value, 0, 0, 0, rs)) return OVGPU_ERR_INVALID;
+  NoiseManager noises;
+  UpdaterOptions uo;
+  uo.chi2_multipler = o->chi2_multipler, uo.sigma_pix = o->sigma_pix, uo.sigma_pix_sq = o->sigma_pix * o->sigma_pix;
+  auto db = std::make_shared<FeatureDatabase>();
+  auto prop = std::make_shared<Propagator>(noises, 9.81);
+  UpdaterZeroVelocity zv(uo, noises, db, prop, 9.81, max_velocity, noise_multiplier, max_disparity);
+  for (int i = 0; i < n_imu; i++) {
+    ImuData m;
+    m.timestamp = imu_t[i];
+    m.wm << imu_wm[3 * i], imu_wm[3 * i + 1], imu_wm[3 * i + 2];
+    m.am << imu_am[3 * i], imu_am[3 * i + 1], imu_am[3 * i + 2];
+    zv.feed_imu(m, -1);
+  }
+  rs.state->_timestamp = t_state;
+  Snapshot before = snapshot(rs);
+  const bool ok = zv.try_update(rs.state, t_update);
+  if (accepted) *accepted = ok ? 1 : 0;
+  export_dx(rs, before, dx, st->N);
+  export_cov(rs, P_out);
+  if (imu_value_out)
+    for (int i = 0; i < 16; i++) imu_value_out[i] = rs.state->_imu->value()(i, 0);
+  if (state_time_out) *state_time_out = rs.state->_timestamp;
   return OVGPU_OK;
 }
 

@@ -94,6 +94,30 @@ def delayed_aruco(mode, rep):
     delayed(mode, rep, aruco=True)
 
 
+def zupt(mode, moving):
+    """UpdaterZeroVelocity::try_update (UpdaterZeroVelocity.cpp:64-332) with INTEGRATION.md's patch applied to the reference's own file at build time
+    (oracle/ref/patch_zupt.py: the chi2 on the marginal covariance, the bias random walk and the update through shim/ovgpu_zupt.h; mode B builds)
+    against the unpatched function: an IMU at rest (accepted: bias propagation + EKF update, the state time moves) and one that moves (rejected)."""
+    prob = synth.make_problem(2, F=1, C=8)
+    opts = capi.default_options(chi2_multipler=1.0)
+    rng = np.random.default_rng(3)
+    t_state = 10.0 + 0.1 * (prob.C - 1)  # the driver's clone times are 10.0, 10.1, ...; the state sits at the newest clone
+    t_update = t_state + 0.1
+    t = np.arange(t_state - 0.02, t_update + 0.02, 1.0 / 400.0)
+    bg, ba = np.array([0.002, -0.001, 0.0015]), np.array([0.02, -0.01, 0.015])
+    imu = np.concatenate([[0, 0, 0, 1], [0.3, -0.2, 1.1], [0.4, 0, 0] if moving else [0.001, -0.002, 0.0005], bg, ba])
+    wm = bg + 1.6968e-04 * np.sqrt(400.0) * rng.standard_normal((len(t), 3)) + ([0.2, 0, 0] if moving else 0)
+    am = np.array([0, 0, 9.81]) + ba + 2.0e-3 * np.sqrt(400.0) * rng.standard_normal((len(t), 3))
+    args = (opts, None, imu, t, wm, am, t_state, t_update)
+    ref = pyref.zupt_try_update(args[0], capi.Views(prob), *args[2:])
+    with pyref.using(pyref.dropin_path(mode)):
+        got = pyref.zupt_try_update(args[0], capi.Views(prob), *args[2:])
+    m = np.isfinite(ref["dx"])
+    emit(f"zupt:{'moving' if moving else 'rest'}", accepted=bool(ref["accepted"]), status_equal=bool(got["accepted"] == ref["accepted"] and got["timestamp"] == ref["timestamp"]),
+         dx=rel(got["dx"][m], ref["dx"][m]) if ref["accepted"] else float(np.abs(got["dx"][m] - ref["dx"][m]).max()), P=rel(got["P"], ref["P"]),
+         state=float(np.abs(got["imu"] - ref["imu"]).max()))
+
+
 def anchors(mode, rep):
     prob = synth.make_slam_problem(2, L=10, lm_rep=rep)
     opts = capi.default_options(chi2_multipler=1.0)
@@ -131,7 +155,7 @@ def loop(mode, seconds, name="loop", **cfg):
          ate_deg=a[0], ate_m=a[1], ate_deg_reference=b[0], ate_m_reference=b[1])
 
 
-CASES = [("msckf", 0), ("msckf", 3), ("msckf", 7), ("msckf", 11), ("msckf", 19), ("slam", 0), ("slam", 4), ("slam_aruco", 0), ("slam_aruco", 5), ("delayed", 0), ("delayed", 4), ("delayed", 5), ("delayed_aruco", 0), ("anchors", 2), ("anchors", 4), ("loop", 60.0), ("loop_slam", 60.0)]
+CASES = [("msckf", 0), ("msckf", 3), ("msckf", 7), ("msckf", 11), ("msckf", 19), ("slam", 0), ("slam", 4), ("slam_aruco", 0), ("slam_aruco", 5), ("delayed", 0), ("delayed", 4), ("delayed", 5), ("delayed_aruco", 0), ("anchors", 2), ("anchors", 4), ("zupt", 0), ("zupt", 1), ("loop", 60.0), ("loop_slam", 60.0)]
 
 if __name__ == "__main__":
     mode = sys.argv[1]  # a | b (libovgpu: needs the GPU) or a_cpu | b_cpu (tests/fake_ovgpu, the oracle-backed double of the C ABI: runs anywhere)

@@ -520,4 +520,30 @@ int ovgpu_get_features(ovgpu_ctx *c, int32_t *F_out, int32_t *M_out, int32_t *me
   return OVGPU_OK;
 }
 
+// ---- window bookkeeping / standalone update on the resident covariance (shim/ovgpu_zupt.h)
+int ovgpu_state_marginal_covariance(ovgpu_ctx *c, int32_t n, const int32_t *cov_idx, double *out) {
+  if (!c || !c->have_state || !cov_idx || !out) return fail(OVGPU_ERR_NO_STATE, "no state");
+  for (int i = 0; i < n; i++)
+    for (int j = 0; j < n; j++) out[(size_t)i * n + j] = c->P[(size_t)cov_idx[i] * c->N + cov_idx[j]];
+  return OVGPU_OK;
+}
+int ovgpu_state_propagate(ovgpu_ctx *c, int32_t new_cov_id, int32_t n_new, int32_t n_old, const int32_t *old_cov_ids, const double *Phi, const double *Q) {
+  if (!c || !c->have_state) return fail(OVGPU_ERR_NO_STATE, "no state");
+  const int rc = oracle_propagate(c->P.data(), c->N, new_cov_id, n_new, n_old, old_cov_ids, Phi, Q);
+  return rc == OVGPU_OK ? OVGPU_OK : fail(rc, "oracle_propagate failed");
+}
+int ovgpu_ekf_update(ovgpu_ctx *c, int rows, int cols, const int32_t *col_cov_id, const double *H, const double *res, double sigma2, double *dx, double *P_out) {
+  if (!c || !c->have_state) return fail(OVGPU_ERR_NO_STATE, "no state");
+  std::vector<double> dxv(c->N, 0.0);
+  const ovgpu_state_view s = c->sv();
+  const int rc = oracle_ekf_update(c->P.data(), c->N, H, res, rows, cols, col_cov_id, sigma2, dxv.data());
+  if (rc != OVGPU_OK) return fail(rc, "oracle_ekf_update failed");
+  std::vector<double> cq(7 * (size_t)c->C), kq(7 * (size_t)c->K), iq(8 * (size_t)c->K);
+  oracle_apply_dx(&c->o, &s, dxv.data(), cq.data(), kq.data(), iq.data());
+  c->clone_q_p = cq, c->calib_q_p = kq, c->intr = iq;
+  if (dx) std::copy(dxv.begin(), dxv.end(), dx);
+  if (P_out) std::copy(c->P.begin(), c->P.end(), P_out);
+  return OVGPU_OK;
+}
+
 } // extern "C"

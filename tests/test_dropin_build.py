@@ -94,6 +94,10 @@ def test_dropin_libraries_link_the_shim_into_the_reference_objects(dropin_libs):
             assert f"U {s}\n" in und, (mode, s)
         for s in other:
             assert f"U {s}\n" not in und, (mode, s)
+        # UpdaterZeroVelocity::try_update: mode B carries the reference's own file with INTEGRATION.md's patch applied at build time
+        # (oracle/ref/patch_zupt.py: its covariance work goes through shim/ovgpu_zupt.h), mode A the unpatched object
+        for s in ("ovgpu_state_marginal_covariance", "ovgpu_state_propagate", "ovgpu_ekf_update"):
+            assert (f"U {s}\n" in und) == (mode == "b"), (mode, s)
         syms = _nm(path)
         # the replaced member functions are the SHIM's (its persistent flattening buffer is a function-local static of update()) ...
         assert "guard variable for ov_msckf::UpdaterMSCKF::update(" in syms or "ov_msckf::UpdaterMSCKF::update(std::shared_ptr<ov_msckf::State>, std::vector<std::shared_ptr<ov_core::Feature>" in syms
@@ -130,7 +134,7 @@ def test_dropin_library_runs_the_reference_driver_up_to_the_shims_early_return(d
 # what the drop-in library has to reproduce of the reference's own updaters (tests/dropin_probe.py's keys): the tolerances of the
 # GPU-against-reference fixtures (tests/test_ref_fixtures.py)
 LIMITS = {"msckf": dict(pos=1e-8, dx=1e-7, P=1e-8, state=1e-9), "slam": dict(dx=1e-7, P=1e-8, landmarks=1e-9, state=1e-9),
-          "delayed": dict(value=1e-8, P=1e-7, state=1e-9), "anchors": dict(P=1e-11, value=1e-11, fej=1e-11)}
+          "delayed": dict(value=1e-8, P=1e-7, state=1e-9), "anchors": dict(P=1e-11, value=1e-11, fej=1e-11), "zupt": dict(dx=1e-7, P=1e-8, state=1e-9)}
 
 
 def _run_probe(mode, seconds):
@@ -196,7 +200,7 @@ def _judge(lines, limits, min_updates, loop_only=False):
 
 # the C ABI served by the CPU oracle: what differs from the reference is the oracle's arithmetic (tests/test_ref_build.py: 1e-12)
 LIMITS_CPU = {"msckf": dict(pos=1e-10, dx=1e-10, P=1e-11, state=1e-10), "slam": dict(dx=1e-10, P=1e-11, landmarks=1e-10, state=1e-10),
-              "delayed": dict(value=1e-10, P=1e-10, state=1e-10), "anchors": dict(P=1e-13, value=1e-13, fej=1e-13), "loop_first_ten": 1e-10}
+              "delayed": dict(value=1e-10, P=1e-10, state=1e-10), "anchors": dict(P=1e-13, value=1e-13, fej=1e-13), "zupt": dict(dx=1e-10, P=1e-11, state=1e-11), "loop_first_ten": 1e-10}
 
 
 @pytest.mark.parametrize("mode", ["a_cpu", "b_cpu"])
