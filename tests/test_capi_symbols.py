@@ -110,3 +110,9 @@ def test_product_package_does_not_touch_the_oracle():
             if fn.endswith((".py", ".h", ".hip", ".cpp", ".hpp")):
                 txt = open(os.path.join(dirpath, fn), errors="ignore").read()
                 assert "pyoracle" not in txt and "ov_oracle" not in txt and "libov_oracle" not in txt, f"{fn} references the oracle"
+                # ... nor the oracle-backed test double of the C ABI (tests/fake_ovgpu) or the reference builds of oracle/_ref
+                assert "fake_ovgpu" not in txt and "ovgpu_fake" not in txt and "libov_ref" not in txt and "libov_dropin" not in txt, f"{fn} references test infrastructure"
+    # and bench.py / __graft_entry__.smoke() load the product library only (the drop-in and fake builds are made by build(), never loaded there)
+    for fn in ("bench.py",):
+        txt = open(os.path.join(ROOT, fn)).read()
+        assert "fake_ovgpu" not in txt and "ovgpu_fake" not in txt and "libov_dropin" not in txt, fn
