@@ -88,6 +88,20 @@ void UpdaterMSCKF::update(std::shared_ptr<State> state, std::vector<std::shared_
     ctx.check(ovgpu_get_features(ctx.get(), &Fd, &Md, dev_offs.data(), nullptr, nullptr, nullptr, nullptr), "ovgpu_get_features");
     if (Fd != F || dev_offs != offs)
       throw std::runtime_error("ovgpu: the resident track store is out of step with the FeatureDatabase (a TrackMirror call is missing: ovgpu_track_mirror.h)");
+#ifdef OVGPU_SHIM_RESIDENT_VERIFY
+    // test builds: the WHOLE device-assembled batch against the host's flattening, observation by observation (camera, clone, pixels) — the
+    // lengths above cannot see an order mistake inside a track
+    ovgpu_shim::FlatFeatures host;
+    for (auto &ft : feature_vec) ovgpu_shim::append_track(*ft, snap, clones, host);
+    std::vector<int32_t> dci((size_t)Md + 1), dcam((size_t)Md + 1);
+    std::vector<float> duv(2 * (size_t)Md + 2), duvn(2 * (size_t)Md + 2);
+    ctx.check(ovgpu_get_features(ctx.get(), &Fd, &Md, nullptr, duv.data(), duvn.data(), dci.data(), dcam.data()), "ovgpu_get_features");
+    bool same = Md == host.M();
+    for (int i = 0; same && i < Md; i++)
+      same = dci[i] == host.clone_idx[i] && dcam[i] == host.cam_idx[i] && duv[2 * i] == host.uv[2 * i] && duv[2 * i + 1] == host.uv[2 * i + 1] &&
+             duvn[2 * i] == host.uvn[2 * i] && duvn[2 * i + 1] == host.uvn[2 * i + 1];
+    if (!same) throw std::runtime_error("ovgpu: the device-assembled batch differs from the host's flattening (OVGPU_SHIM_RESIDENT_VERIFY)");
+#endif
   }
 #else
   const ovgpu_features_view fv = ff.view();

@@ -77,8 +77,9 @@ public:
   void sync() {
     if (!ctx_) throw std::runtime_error("ovgpu TrackMirror: sync before attach");
     close_frame();
-    for (const Op &op : log_) apply(op);
-    log_.clear();
+    std::vector<Op> todo;
+    todo.swap(log_); // (apply() never records)
+    for (const Op &op : todo) apply(op);
   }
   bool attached() const { return ctx_ != nullptr; }
 
@@ -109,13 +110,16 @@ private:
     have_frame_ = false;
     Op op{Op::APPEND, frame_.t, std::move(frame_), {}};
     frame_ = Frame();
-    if (ctx_) apply(op);
-    else log_.push_back(std::move(op));
+    submit(std::move(op));
   }
   void other(Op::Kind k, double t, const std::vector<int64_t> &ids) {
     close_frame(); // operations keep their order
-    Op op{k, t, Frame(), ids};
-    if (ctx_) apply(op);
+    submit(Op{k, t, Frame(), ids});
+  }
+  // straight to the device once the store exists AND nothing recorded is still waiting: an operation never overtakes the log (the frame that
+  // is open when the first update attaches the store comes AFTER the frames recorded before it)
+  void submit(Op op) {
+    if (ctx_ && log_.empty()) apply(op);
     else log_.push_back(std::move(op));
   }
   void apply(const Op &op) {

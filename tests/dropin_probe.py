@@ -135,6 +135,12 @@ def loop_slam(mode, seconds):
     loop(mode, seconds, name="loop_slam", max_slam_features=25, dt_slam_delay=2.0)
 
 
+def loop_stereo(mode, seconds):
+    """Two cameras, anchored representations (MSCKF features and SLAM landmarks as ANCHORED_MSCKF_INVERSE_DEPTH): camera groups inside a track, the
+    anchor rule on tied counts, and UpdaterSLAM::change_anchors moving live landmarks every time their anchor clone is about to be marginalised."""
+    loop(mode, seconds, name="loop_stereo", num_cameras=2, max_slam_features=15, dt_slam_delay=2.0, feat_rep_slam=4, feat_rep_msckf=4)
+
+
 def loop(mode, seconds, name="loop", **cfg):
     """The rpng_sim closed loop (BASELINE configs[0]; tests/test_rpng_sim_loop.py) with the DROP-IN as the filter's updater: the reference's
     Simulator, Propagator, FeatureDatabase and State around open_vins_amd/shim/UpdaterMSCKF.cpp, against the same loop around the reference's
@@ -155,7 +161,7 @@ def loop(mode, seconds, name="loop", **cfg):
          ate_deg=a[0], ate_m=a[1], ate_deg_reference=b[0], ate_m_reference=b[1])
 
 
-CASES = [("msckf", 0), ("msckf", 3), ("msckf", 7), ("msckf", 11), ("msckf", 19), ("slam", 0), ("slam", 4), ("slam_aruco", 0), ("slam_aruco", 5), ("delayed", 0), ("delayed", 4), ("delayed", 5), ("delayed_aruco", 0), ("anchors", 2), ("anchors", 4), ("zupt", 0), ("zupt", 1), ("loop", 60.0), ("loop_slam", 60.0)]
+CASES = [("msckf", 0), ("msckf", 3), ("msckf", 7), ("msckf", 11), ("msckf", 19), ("slam", 0), ("slam", 4), ("slam_aruco", 0), ("slam_aruco", 5), ("delayed", 0), ("delayed", 4), ("delayed", 5), ("delayed_aruco", 0), ("anchors", 2), ("anchors", 4), ("zupt", 0), ("zupt", 1), ("loop", 60.0), ("loop_slam", 60.0), ("loop_stereo", 60.0)]
 
 if __name__ == "__main__":
     mode = sys.argv[1]  # a | b (libovgpu: needs the GPU) or a_cpu | b_cpu (tests/fake_ovgpu, the oracle-backed double of the C ABI: runs anywhere)

@@ -181,7 +181,7 @@ def _judge(lines, limits, min_updates, loop_only=False):
             # estimates close over the first ten updates and within 5 x the reference's own control run (two reference runs 1e-13 m apart at
             # the start), the same ATE
             print("drop-in closed loop:", l)
-            if kind == "loop_slam" and not (l["state_dim_max"] == l["state_dim_max_reference"] >= 126 + 3 * 10):
+            if kind in ("loop_slam", "loop_stereo") and not (l["state_dim_max"] == l["state_dim_max_reference"] >= 126 + 3 * 10):
                 bad.append((l["case"], "landmarks in the state", l["state_dim_max"], l["state_dim_max_reference"]))
             ok = (l["updates"] >= min_updates and l["updates"] == l["updates_reference"] and l["differing"] <= 0.01 * l["decisions"]
                   and l["sep_first_ten"] < limits["loop_first_ten"] and l["sep"] < 5 * l["control"]
@@ -193,7 +193,8 @@ def _judge(lines, limits, min_updates, loop_only=False):
             if not (0.0 <= l[k] < lim):
                 bad.append((l["case"], k, l[k], lim))
     assert not bad, bad
-    assert any(l["case"].startswith("loop:") for l in lines) and any(l["case"].startswith("loop_slam:") for l in lines)
+    for kind in ("loop:", "loop_slam:", "loop_stereo:"):
+        assert any(l["case"].startswith(kind) for l in lines), kind
     if not loop_only:
         assert sum(l.get("used", 0) for l in lines) > 50 and any(l["case"].startswith("delayed") and l["accepted"] >= 4 for l in lines)
 
