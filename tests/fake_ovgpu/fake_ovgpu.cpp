@@ -31,7 +31,7 @@ int fail(int code, const std::string &m) {
 
 struct ovgpu_ctx {
   ovgpu_options o;
-  bool have_state = false, have_feats = false, poses_only = false;
+  bool have_state = false, have_feats = false, poses_only = false, tri_readable = false;
   int N = 0, C = 0, K = 0;
   std::vector<double> P, clone_q_p, clone_fej, calib_q_p, intr;
   std::vector<int32_t> clone_cov, calib_cov, intr_cov;
@@ -151,7 +151,7 @@ int ovgpu_set_state(ovgpu_ctx *c, const ovgpu_state_view *st) {
   put(c->clone_q_p, st->clone_q_p, 7 * (size_t)st->C), put(c->clone_fej, st->clone_q_p_fej, 7 * (size_t)st->C), put(c->clone_cov, st->clone_cov_id, st->C);
   put(c->calib_q_p, st->calib_q_p, 7 * (size_t)st->K), put(c->intr, st->intrinsics, 8 * (size_t)st->K), put(c->fisheye, st->cam_is_fisheye, st->K);
   put(c->calib_cov, st->calib_cov_id, st->K), put(c->intr_cov, st->intr_cov_id, st->K);
-  c->have_state = true, c->poses_only = false, c->have_feats = false;
+  c->have_state = true, c->poses_only = false, c->have_feats = false, c->tri_readable = false;
   c->L = 0, c->lm_rep = 0, c->lm_value.clear(), c->lm_fej.clear(), c->lm_cov.clear(), c->lm_acam.clear(), c->lm_aclone.clear();
   return OVGPU_OK;
 }
@@ -162,7 +162,7 @@ int ovgpu_set_features(ovgpu_ctx *c, const ovgpu_features_view *fv) {
   put(c->offs, fv->meas_offsets, (size_t)fv->F + 1);
   put(c->uv, fv->uv, 2 * (size_t)fv->M), put(c->uvn, fv->uvn, 2 * (size_t)fv->M), put(c->clone_idx, fv->clone_idx, fv->M), put(c->cam_idx, fv->cam_idx, fv->M);
   c->fsig.clear(), c->fmul.clear();
-  c->have_feats = true;
+  c->have_feats = true, c->tri_readable = false;
   return OVGPU_OK;
 }
 
@@ -172,6 +172,7 @@ int ovgpu_set_landmarks(ovgpu_ctx *c, const ovgpu_landmarks_view *lm) {
   c->L = lm->L, c->lm_rep = lm->feat_rep;
   put(c->lm_value, lm->p_value, 3 * (size_t)lm->L), put(c->lm_fej, lm->p_fej, 3 * (size_t)lm->L), put(c->lm_cov, lm->cov_id, lm->L);
   put(c->lm_acam, lm->anchor_cam, lm->L), put(c->lm_aclone, lm->anchor_clone, lm->L);
+  c->have_feats = false, c->tri_readable = false; // as the library: the column map changed, ovgpu_set_features must follow
   return OVGPU_OK;
 }
 
@@ -219,7 +220,8 @@ int ovgpu_msckf_compress(ovgpu_ctx *c, int32_t *feat_status, double *chi2, doubl
 }
 
 int ovgpu_get_triangulation(ovgpu_ctx *c, double *p_FinA, double *p_FinG, int32_t *anchor_meas) {
-  if (!c || (int)c->anchor.size() < c->F) return fail(OVGPU_ERR_NO_STATE, "no pipeline call on this batch yet");
+  if (!c || !c->have_state || !(c->have_feats || c->tri_readable)) return fail(OVGPU_ERR_NO_STATE, "state / features not set");
+  if ((int)c->anchor.size() < c->F) return fail(OVGPU_ERR_NO_STATE, "no pipeline call on this batch yet");
   if (p_FinA) std::copy(c->pA.begin(), c->pA.begin() + 3 * (size_t)c->F, p_FinA);
   if (p_FinG) std::copy(c->pG.begin(), c->pG.begin() + 3 * (size_t)c->F, p_FinG);
   if (anchor_meas) std::copy(c->anchor.begin(), c->anchor.begin() + c->F, anchor_meas);
@@ -321,8 +323,7 @@ int ovgpu_slam_delayed_init(ovgpu_ctx *c, int32_t feat_rep, int32_t *feat_status
     c->lm_cov.push_back(cov[i]), c->lm_acam.push_back(relative ? ac[i] : -1), c->lm_aclone.push_back(relative ? acl[i] : -1);
     c->L++;
   }
-  c->have_feats = false;
-  c->have_feats = true; // (ovgpu_get_triangulation still reads this batch)
+  c->have_feats = false, c->tri_readable = true; // as the library: the column map changed (no further update from this batch), its triangulation stays readable
   return OVGPU_OK;
 }
 
@@ -541,6 +542,7 @@ int ovgpu_ekf_update(ovgpu_ctx *c, int rows, int cols, const int32_t *col_cov_id
   std::vector<double> cq(7 * (size_t)c->C), kq(7 * (size_t)c->K), iq(8 * (size_t)c->K);
   oracle_apply_dx(&c->o, &s, dxv.data(), cq.data(), kq.data(), iq.data());
   c->clone_q_p = cq, c->calib_q_p = kq, c->intr = iq;
+  c->have_feats = false, c->tri_readable = false; // as the library: the compression buffers are shared, upload the batch again
   if (dx) std::copy(dxv.begin(), dxv.end(), dx);
   if (P_out) std::copy(c->P.begin(), c->P.end(), P_out);
   return OVGPU_OK;

@@ -880,6 +880,27 @@ def test_delayed_init_parity(Updater, oracle, rep):
     up.close()
 
 
+@pytest.mark.xfail(strict=False, reason="written with the round's GPU minutes spent (the last 12 s of them found the defect through the in-tree drop-in build): "
+                                        "first run on hardware is the driver's round-end suite")
+def test_triangulation_stays_readable_after_delayed_init(Updater, oracle):
+    """include/ovgpu.h: ovgpu_get_triangulation reads what the triangulation stage of the LAST pipeline call left — ovgpu_slam_delayed_init included
+    (the drop-in's UpdaterSLAM::delayed_init writes the Feature side effects from it).  The delayed initialisation rebuilds the column map, which
+    marks the feature batch stale for further updates; until late round 4 that also made the triangulation unreadable (OVGPU_ERR_NO_STATE)."""
+    prob = synth.make_problem(2, F=16, outlier_frac=0.2)
+    opts = capi.default_options(chi2_multipler=1.0)
+    tri = oracle.triangulate(opts, capi.Views(prob))
+    up = Updater(opts)
+    up.set_problem(prob)
+    out = up.delayed_init(0)
+    got = up.get_triangulation()
+    ok = tri["status"] == capi.FEAT_USED
+    assert ok.sum() >= 8 and (out["lm_cov_id"] >= 0).sum() >= 4
+    assert np.abs(got["p_FinG"][ok] - tri["p_FinG"][ok]).max() < 1e-9 and np.array_equal(got["anchor_meas"][ok], tri["anchor_meas"][ok])
+    with pytest.raises(capi.OvgpuError):  # ... while another update from the stale batch is still refused
+        up.update()
+    up.close()
+
+
 def _aruco_options(F, seed):
     """Mixed per-feature options as UpdaterSLAM applies them: tag corners (landmark id < 4 * max_aruco) use sigma_pix_aruco
     and aruco_chi2_multipler, the others the SLAM values."""
