@@ -9,7 +9,8 @@
 //
 // Only the entry points the shims call exist (the track store of the resident-track mode included), with the semantics include/ovgpu.h documents (resident state updated by mode-B calls,
 // untouched by mode-A calls; landmarks resident across calls; per-feature options until the next batch).  Not modelled: per-feature
-// sigma scaling of the rows ovgpu_slam_compress returns (no ArUco case runs through it), device errors, capacities.
+// sigma scaling of the rows ovgpu_slam_compress returns (no ArUco case runs through it), device errors, capacities.  The rules of WHEN a call
+// is allowed follow csrc/api_*.inc (which call invalidates the resident batch, which needs one): a shim that calls out of order fails here as on the device.
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
@@ -158,6 +159,10 @@ int ovgpu_set_state(ovgpu_ctx *c, const ovgpu_state_view *st) {
 
 int ovgpu_set_features(ovgpu_ctx *c, const ovgpu_features_view *fv) {
   if (!c || !fv) return fail(OVGPU_ERR_INVALID, "null argument");
+  if (!c->have_state) return fail(OVGPU_ERR_NO_STATE, "ovgpu_set_state must precede ovgpu_set_features");
+  if (fv->F > 0 && (fv->meas_offsets[0] != 0 || fv->meas_offsets[fv->F] != fv->M)) return fail(OVGPU_ERR_INVALID, "meas_offsets must span [0, M]");
+  for (int i = 0; i < fv->M; i++)
+    if (fv->clone_idx[i] < 0 || fv->clone_idx[i] >= c->C || fv->cam_idx[i] < 0 || fv->cam_idx[i] >= c->K) return fail(OVGPU_ERR_INVALID, "measurement refers to an unknown clone / camera");
   c->F = fv->F, c->M = fv->M;
   put(c->offs, fv->meas_offsets, (size_t)fv->F + 1);
   put(c->uv, fv->uv, 2 * (size_t)fv->M), put(c->uvn, fv->uvn, 2 * (size_t)fv->M), put(c->clone_idx, fv->clone_idx, fv->M), put(c->cam_idx, fv->cam_idx, fv->M);
@@ -229,7 +234,7 @@ int ovgpu_get_triangulation(ovgpu_ctx *c, double *p_FinA, double *p_FinG, int32_
 }
 
 int ovgpu_get_state(ovgpu_ctx *c, double *P, double *clone_q_p, double *calib_q_p, double *intrinsics) {
-  if (!c || !c->have_state) return fail(OVGPU_ERR_NO_STATE, "no state");
+  if (!c || !c->have_state || c->poses_only) return fail(OVGPU_ERR_NO_STATE, "ovgpu_set_state was never called");
   if (P) std::copy(c->P.begin(), c->P.end(), P);
   if (clone_q_p) std::copy(c->clone_q_p.begin(), c->clone_q_p.end(), clone_q_p);
   if (calib_q_p) std::copy(c->calib_q_p.begin(), c->calib_q_p.end(), calib_q_p);
@@ -523,18 +528,18 @@ int ovgpu_get_features(ovgpu_ctx *c, int32_t *F_out, int32_t *M_out, int32_t *me
 
 // ---- window bookkeeping / standalone update on the resident covariance (shim/ovgpu_zupt.h)
 int ovgpu_state_marginal_covariance(ovgpu_ctx *c, int32_t n, const int32_t *cov_idx, double *out) {
-  if (!c || !c->have_state || !cov_idx || !out) return fail(OVGPU_ERR_NO_STATE, "no state");
+  if (!c || !c->have_state || c->poses_only || !cov_idx || !out) return fail(OVGPU_ERR_NO_STATE, "no state");
   for (int i = 0; i < n; i++)
     for (int j = 0; j < n; j++) out[(size_t)i * n + j] = c->P[(size_t)cov_idx[i] * c->N + cov_idx[j]];
   return OVGPU_OK;
 }
 int ovgpu_state_propagate(ovgpu_ctx *c, int32_t new_cov_id, int32_t n_new, int32_t n_old, const int32_t *old_cov_ids, const double *Phi, const double *Q) {
-  if (!c || !c->have_state) return fail(OVGPU_ERR_NO_STATE, "no state");
+  if (!c || !c->have_state || c->poses_only) return fail(OVGPU_ERR_NO_STATE, "no state");
   const int rc = oracle_propagate(c->P.data(), c->N, new_cov_id, n_new, n_old, old_cov_ids, Phi, Q);
   return rc == OVGPU_OK ? OVGPU_OK : fail(rc, "oracle_propagate failed");
 }
 int ovgpu_ekf_update(ovgpu_ctx *c, int rows, int cols, const int32_t *col_cov_id, const double *H, const double *res, double sigma2, double *dx, double *P_out) {
-  if (!c || !c->have_state) return fail(OVGPU_ERR_NO_STATE, "no state");
+  if (!c || !c->have_state || c->poses_only) return fail(OVGPU_ERR_NO_STATE, "no state");
   std::vector<double> dxv(c->N, 0.0);
   const ovgpu_state_view s = c->sv();
   const int rc = oracle_ekf_update(c->P.data(), c->N, H, res, rows, cols, col_cov_id, sigma2, dxv.data());
