@@ -244,4 +244,4 @@ def test_resident_track_mode_refuses_to_update_from_a_store_that_missed_a_frame(
 def test_dropin_library_equals_the_reference_updaters_on_the_gpu(dropin_libs, mode):
     if not os.path.exists(pyref.dropin_path(mode)):
         pytest.skip("drop-in library of this mode is not here")
-    _judge(_run_probe(mode, 30.0), dict(LIMITS, loop_first_ten=1e-8), 290, loop_only=(mode == "r"))
+    _judge(_run_probe(mode, 15.0), dict(LIMITS, loop_first_ten=1e-8), 140, loop_only=(mode == "r"))
