@@ -161,12 +161,75 @@ def loop(mode, seconds, name="loop", **cfg):
          ate_deg=a[0], ate_m=a[1], ate_deg_reference=b[0], ate_m_reference=b[1])
 
 
+def sweep(mode):
+    """Every seeded shape of the GPU parity suite through the drop-in: the 40 MSCKF updates (3-40 clones, 1-4 cameras, 1-89 features, ragged / full
+    tracks, both lens models, six representations, FEJ / calibration flags, outliers), the 12 random SLAM updates and the 12 random delayed-init chains of
+    tests/test_ref_build.py.  One line: the worst deviations and the cases whose accept / reject sets (or new landmark ids / anchors) differ."""
+    from test_ref_build import _msckf_case
+    bad, w = [], dict(msckf_dx=0.0, msckf_P=0.0, msckf_pos=0.0, slam_dx=0.0, slam_P=0.0, slam_lm=0.0, delayed_P=0.0, delayed_value=0.0)
+    path = pyref.dropin_path(mode)
+    for seed in range(40):
+        prob, opts = _msckf_case(seed)
+        ref = pyref.msckf_update(opts, capi.Views(prob))
+        with pyref.using(path):
+            got = pyref.msckf_update(opts, capi.Views(prob))
+        if not np.array_equal(got["feat_status"], ref["feat_status"]):
+            bad.append(f"msckf:{seed}")
+        tri = (ref["feat_status"] == capi.FEAT_USED) | (ref["feat_status"] == capi.FEAT_CHI2_REJECTED)
+        if (ref["feat_status"] == capi.FEAT_USED).any():
+            w["msckf_dx"] = max(w["msckf_dx"], rel(got["dx"], ref["dx"]))
+        w["msckf_P"] = max(w["msckf_P"], rel(got["P"], ref["P"]))
+        if tri.any():
+            w["msckf_pos"] = max(w["msckf_pos"], float(np.abs(got["p_FinG"] - ref["p_FinG"])[tri].max()))
+    for seed in range(12):
+        rng = np.random.default_rng(2000 + seed)
+        kw = dict(C=int(rng.integers(6, 31)), K=int(rng.integers(1, 4)), track=("full", "ragged")[int(rng.integers(2))], fisheye=bool(rng.integers(2)),
+                  seed=int(rng.integers(1 << 20)))
+        prob = synth.make_slam_problem(2, L=int(rng.integers(1, 13)), lm_rep=int(rng.integers(0, 6)), **kw)
+        opts = capi.default_options(chi2_multipler=float(rng.choice([1.0, 5.0])), do_fej=int(rng.integers(2)), do_calib_camera_pose=int(rng.integers(2)),
+                                    do_calib_camera_intrinsics=int(rng.integers(2)))
+        ref = pyref.slam_update(opts, capi.Views(prob))
+        with pyref.using(path):
+            got = pyref.slam_update(opts, capi.Views(prob))
+        if not np.array_equal(got["feat_status"], ref["feat_status"]):
+            bad.append(f"slam:{seed}")
+        if (ref["feat_status"] == capi.FEAT_USED).any():
+            w["slam_dx"], w["slam_P"] = max(w["slam_dx"], rel(got["dx"], ref["dx"])), max(w["slam_P"], rel(got["P"], ref["P"]))
+        w["slam_lm"] = max(w["slam_lm"], float(np.abs(got["landmarks"] - ref["landmarks"]).max()))
+    for seed in range(12):
+        rng = np.random.default_rng(3000 + seed)
+        kw = dict(C=int(rng.integers(6, 31)), K=int(rng.integers(1, 4)), F=int(rng.integers(1, 21)), track=("full", "ragged")[int(rng.integers(2))],
+                  fisheye=bool(rng.integers(2)), seed=int(rng.integers(1 << 20)), outlier_frac=float(rng.choice([0.0, 0.3])))
+        rep = int(rng.integers(0, 6))
+        prob = synth.make_problem(2, **kw)
+        opts = capi.default_options(chi2_multipler=float(rng.choice([1.0, 5.0])), do_fej=int(rng.integers(2)), do_calib_camera_pose=int(rng.integers(2)),
+                                    do_calib_camera_intrinsics=int(rng.integers(2)))
+        ref = pyref.slam_delayed_init(opts, capi.Views(prob), feat_rep=rep)
+        with pyref.using(path):
+            got = pyref.slam_delayed_init(opts, capi.Views(prob), feat_rep=rep)
+        acc = ref["lm_cov_id"] >= 0
+        anch = acc & (ref["anchor_cam"] >= 0)
+        if not (np.array_equal(got["feat_status"], ref["feat_status"]) and got["N"] == ref["N"] and np.array_equal(got["lm_cov_id"], ref["lm_cov_id"])
+                and np.array_equal(got["anchor_cam"][anch], ref["anchor_cam"][anch]) and np.array_equal(got["anchor_clone"][anch], ref["anchor_clone"][anch])):
+            bad.append(f"delayed:{seed}")
+            continue
+        w["delayed_P"] = max(w["delayed_P"], rel(got["P"], ref["P"]))
+        if acc.any():
+            w["delayed_value"] = max(w["delayed_value"], float(np.abs(got["lm_value"][acc] - ref["lm_value"][acc]).max()))
+    emit("sweep", differing=bad, **w)
+
+
 CASES = [("msckf", 0), ("msckf", 3), ("msckf", 7), ("msckf", 11), ("msckf", 19), ("slam", 0), ("slam", 4), ("slam_aruco", 0), ("slam_aruco", 5), ("delayed", 0), ("delayed", 4), ("delayed", 5), ("delayed_aruco", 0), ("anchors", 2), ("anchors", 4), ("zupt", 0), ("zupt", 1), ("loop", 60.0), ("loop_slam", 60.0), ("loop_stereo", 60.0)]
 
 if __name__ == "__main__":
     mode = sys.argv[1]  # a | b (libovgpu: needs the GPU) or a_cpu | b_cpu (tests/fake_ovgpu, the oracle-backed double of the C ABI: runs anywhere)
-    seconds = float(sys.argv[2]) if len(sys.argv) > 2 else 60.0
+    seconds = float(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2] != "sweep" else 60.0
     pyref.load()
+    if len(sys.argv) > 2 and sys.argv[2] == "sweep":
+        sweep(mode)
+        emit("done")
+        sys.stdout.flush()
+        os._exit(0)
     for kind, arg in CASES:
         if mode.startswith("r") and not kind.startswith("loop"):
             continue  # the resident-track build updates from the mirrored track store: only a LOOP feeds it (the per-call driver builds bare Features)

@@ -153,6 +153,10 @@ def cpu_probes(dropin_libs):
     modes = [m for m in ("a_cpu", "b_cpu", "r_cpu") if os.path.exists(pyref.dropin_path(m))]
     procs = {m: subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dropin_probe.py"), m, "20"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
              for m in modes}
+    for m in modes:  # ... and, beside them, the sweep over every seeded shape of the parity suite (modes A and B)
+        if not m.startswith("r"):
+            procs["sweep_" + m] = subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dropin_probe.py"), m, "sweep"], stdout=subprocess.PIPE,
+                                                   stderr=subprocess.PIPE, text=True)
     out = {}
     for m, pr in procs.items():
         so, se = pr.communicate(timeout=900)
@@ -213,6 +217,17 @@ def test_dropin_library_equals_the_reference_updaters_with_the_oracle_behind_the
     stage (which also runs the FeatureInitializer shim against the reference's), dx / P' / landmarks at the oracle's agreement with the
     reference, the closed loop inside the reference's own control run."""
     _judge(_cpu_lines(cpu_probes, mode), LIMITS_CPU, 190)
+
+
+@pytest.mark.parametrize("mode", ["a_cpu", "b_cpu"])
+def test_dropin_library_on_every_seeded_shape_of_the_parity_suite(cpu_probes, mode):
+    """The 40 MSCKF updates, 12 SLAM updates and 12 delayed-initialisation chains of tests/test_ref_build.py (3-40 clones, 1-4 cameras, both lens
+    models, six representations, every flag combination, outliers) through the shim: the same accept / reject sets, landmark ids and anchors as the
+    reference's updaters on every one, the numbers at the oracle's agreement with the reference."""
+    (l,) = _cpu_lines(cpu_probes, "sweep_" + mode)
+    assert l["case"] == "sweep" and l["differing"] == [], l
+    assert l["msckf_dx"] < 1e-10 and l["msckf_P"] < 1e-11 and l["msckf_pos"] < 1e-9 and l["slam_dx"] < 1e-10 and l["slam_P"] < 1e-11 and l["slam_lm"] < 1e-10
+    assert l["delayed_P"] < 1e-10 and l["delayed_value"] < 1e-9
 
 
 def test_resident_track_mode_of_the_dropin_runs_the_closed_loop_with_the_oracle_behind_the_abi(cpu_probes):
