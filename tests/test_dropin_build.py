@@ -260,3 +260,19 @@ def test_dropin_library_equals_the_reference_updaters_on_the_gpu(dropin_libs, mo
     if not os.path.exists(pyref.dropin_path(mode)):
         pytest.skip("drop-in library of this mode is not here")
     _judge(_run_probe(mode, 15.0), dict(LIMITS, loop_first_ten=1e-8), 140, loop_only=(mode == "r"))
+
+
+@pytest.mark.gpu
+@pytest.mark.xfail(strict=False, reason="written after the round's GPU budget was spent: its first run on hardware is the driver's round-end suite")
+@pytest.mark.parametrize("mode", ["a", "b"])
+def test_dropin_library_on_every_seeded_shape_of_the_parity_suite_on_the_gpu(dropin_libs, mode):
+    """The same sweep (40 MSCKF updates, 12 SLAM updates, 12 delayed-initialisation chains) through the drop-in library linked against libovgpu."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "dropin_probe.py"), mode, "sweep"], capture_output=True, text=True, timeout=900)
+    lines = [json.loads(l) for l in p.stdout.splitlines() if l.startswith("{")]
+    assert p.returncode == 0 and len(lines) == 2 and lines[-1]["case"] == "done", (p.returncode, p.stdout[-500:], p.stderr[-2000:])
+    l = lines[0]
+    print("drop-in sweep on the GPU:", l)
+    # a gate decision within round-off of its threshold may differ between two float64 implementations (tests/parity_util.py): at most one such case
+    assert len(l["differing"]) <= 1, l
+    assert l["msckf_dx"] < 1e-7 and l["msckf_P"] < 1e-8 and l["msckf_pos"] < 1e-8 and l["slam_dx"] < 1e-7 and l["slam_P"] < 1e-8 and l["slam_lm"] < 1e-9
+    assert l["delayed_P"] < 1e-7 and l["delayed_value"] < 1e-8
