@@ -175,6 +175,7 @@ def sweep(mode):
             got = pyref.msckf_update(opts, capi.Views(prob))
         if not np.array_equal(got["feat_status"], ref["feat_status"]):
             bad.append(f"msckf:{seed}")
+            continue  # (another accept set is another update: its numbers say nothing)
         tri = (ref["feat_status"] == capi.FEAT_USED) | (ref["feat_status"] == capi.FEAT_CHI2_REJECTED)
         if (ref["feat_status"] == capi.FEAT_USED).any():
             w["msckf_dx"] = max(w["msckf_dx"], rel(got["dx"], ref["dx"]))
@@ -193,6 +194,7 @@ def sweep(mode):
             got = pyref.slam_update(opts, capi.Views(prob))
         if not np.array_equal(got["feat_status"], ref["feat_status"]):
             bad.append(f"slam:{seed}")
+            continue
         if (ref["feat_status"] == capi.FEAT_USED).any():
             w["slam_dx"], w["slam_P"] = max(w["slam_dx"], rel(got["dx"], ref["dx"])), max(w["slam_P"], rel(got["P"], ref["P"]))
         w["slam_lm"] = max(w["slam_lm"], float(np.abs(got["landmarks"] - ref["landmarks"]).max()))
