@@ -54,6 +54,8 @@ def parse_args(argv=None):
     ap.add_argument("--stage-events-every", type=int, default=4, help="the library's per-stage HIP events (roofline durations) on every n-th update of the timed region")
     ap.add_argument("--gate-always-factor", action="store_true", help="ovgpu_options::gate_always_factor = 1: form and factor every feature's gate matrix "
                     "(default: features whose residual bound is under the chi2 threshold are accepted without it)")
+    ap.add_argument("--debug-option", action="append", default=[], metavar="NAME=VALUE",
+                    help="ovgpu_debug_option(NAME, VALUE) on every context before the batch is uploaded (developer A/Bs, e.g. featy_shape=1)")
     ap.add_argument("--gram-fp32", action="store_true", help="BASELINE configs[4]'s fp32 compression: Gram matrix accumulated on v_mfma_f32_16x16x4_f32")
     return ap.parse_args(argv)
 
@@ -159,6 +161,9 @@ def main(argv=None):
         # update (measured: 0.982 -> 0.961 ms at every 4th update, 0.948 with none).  They are recorded on every n-th update of the timed
         # region; the reported durations are averages over those updates.
         up.debug_option("stage_timing_period", args.stage_events_every)
+        for kv in args.debug_option:
+            name, _, val = kv.partition("=")
+            up.debug_option(name, int(val))
         up.set_problem(shard)  # H2D once; everything below runs on resident data
         native = True
         if world > 1 and not local_only:

@@ -51,15 +51,15 @@ namespace feat {
 #ifndef FY_SYRK_UNROLL
 #define FY_SYRK_UNROLL 2
 #endif
-constexpr int FY_CB = 64; // columns per block = lanes of a wavefront
-constexpr int FY_LS = 66; // row stride of the LDS block in doubles: 16-byte aligned rows, conflict-free 16-byte operand reads
+constexpr int FY_CB = 64; // columns per block of the 64-column shapes = lanes of a wavefront (a template parameter of k_feat_y since round 5: 64 or 32)
+constexpr int FY_LS = 66; // row stride of the LDS block in doubles = CB + 2: 16-byte aligned rows, conflict-free 16-byte operand reads
                           // (rows r and r + 1 of a tile are 4 banks apart: 16 lanes x 4 banks = all 64)
 
 struct FeatYLds {
   size_t yb, vl, wpart, misc, total;
 };
-// nt_max = tile rows of the longest track; nw = wavefronts per workgroup
-__host__ __device__ inline FeatYLds featy_lds_layout(int nt_max, int nw) {
+// nt_max = tile rows of the longest track; nta_max = tile rows of its gate matrix (2 m + 4 rows, round 5); nw = wavefronts per workgroup; cb = columns per block
+__host__ __device__ inline FeatYLds featy_lds_layout(int nt_max, int nta_max, int nw, int cb) {
   FeatYLds L;
   size_t o = 0;
   auto take = [&](size_t bytes) {
@@ -67,10 +67,13 @@ __host__ __device__ inline FeatYLds featy_lds_layout(int nt_max, int nw) {
     o += (bytes + 15) & ~(size_t)15;
     return at;
   };
-  // the block; afterwards the Cholesky's row panel ((nt_max + 1) tiles) and, behind it, the solved right-hand sides (16 nt_max x 4)
-  L.yb = take((size_t)16 * nt_max * FY_LS * sizeof(double));
+  // the block; afterwards the Cholesky's row panel (nta_max tiles) and, behind it, the solved right-hand sides (16 nt_max x 4)
+  {
+    const size_t blk = (size_t)16 * nt_max * (cb + 2) * sizeof(double), pan = ((size_t)nta_max * 256 + (size_t)16 * nt_max * 4) * sizeof(double);
+    L.yb = take(blk > pan ? blk : pan);
+  }
   L.vl = take((((size_t)16 * nt_max * 3 * sizeof(double)) + 1023) & ~(size_t)1023); // whole 1 KiB chunks: filled by the LDS DMA path
-  const size_t wp = (size_t)nw * 3 * 64 * sizeof(double), stage = 2 * 256 * sizeof(double);
+  const size_t wp = (size_t)nw * 3 * cb * sizeof(double), stage = 2 * 256 * sizeof(double);
   L.wpart = take(wp > stage ? wp : stage); // V^T Y partial sums per wavefront; afterwards the Cholesky's diagonal-tile stage
   L.misc = take(32 * sizeof(double) + (size_t)(nt_max + 16) * sizeof(int)); // V^T r partials per wavefront, then rowlim / sched
   L.total = o;
@@ -149,11 +152,16 @@ __global__ void __launch_bounds__(256) k_feat_vt(SysParams p, FeatStore st, doub
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   };
+  double rsq = 0.0; // |[r | H_f]|_F^2: the diagonal of the gate matrix's four augmented rows (k_feat_y) must dominate it / s^2
   for (int r = lane; r < n; r += 64) {
     const double *rd = rows + (size_t)(r >> 1) * RS + RO_HF + 3 * (r & 1);
-    hf[3 * r] = rd[0], hf[3 * r + 1] = rd[1], hf[3 * r + 2] = rd[2];
-    res[r] = rows[(size_t)(r >> 1) * RS + RO_RES + (r & 1)];
+    const double h0 = rd[0], h1 = rd[1], h2 = rd[2], rr = rows[(size_t)(r >> 1) * RS + RO_RES + (r & 1)];
+    hf[3 * r] = h0, hf[3 * r + 1] = h1, hf[3 * r + 2] = h2;
+    res[r] = rr;
+    rsq = fma(h0, h0, fma(h1, h1, fma(h2, h2, fma(rr, rr, rsq))));
   }
+  rsq = wave_sum(rsq);
+  if (lane == 0) tq[(size_t)8 * f + 7] = 1.0 + rsq / p.opt.sigma_pix_sq;
   wsync();
   sys_hf_householder(hf - RO_HF, 6, V, hq, n, 3, lane);
   wsync();
@@ -179,7 +187,8 @@ __global__ void __launch_bounds__(256) k_feat_vt(SysParams p, FeatStore st, doub
     if (lane == 0) tq[(size_t)8 * f + 6] = sumsq / p.opt.sigma_pix_sq;
   }
   // The distinct column blocks ("instances": first column, width) of every tile row of 16 rows, ascending — what the sweep of k_feat_y
-  // loops over.  il[0] = count, il[1] = last non-zero column of the tile row, il[FY_IOFF ..] = (width << 16) | first column.
+  // loops over.  il[0] = count, il[1] = last non-zero column of the tile row, il[FY_IOFF ..] = (type << 24) | (width << 16) | first column
+  // (type 0 clone block, 1 camera extrinsics, 2 camera intrinsics: k_featw.h selects the lane's operand by it).
   // (built in LDS: the column triples of the measurements are staged by all lanes, the lists grow in the wavefront's scratch)
   const int NT = (n + 15) >> 4;
   int *cols3 = reinterpret_cast<int *>(hf);                 // [m][3]: hf is dead (6 m doubles = 12 m ints)
@@ -205,13 +214,13 @@ __global__ void __launch_bounds__(256) k_feat_vt(SysParams p, FeatStore st, doub
 #pragma unroll
         for (int e = 0; e < 8; e++)
           if (e == np_) seen_p[e] = c1;
-        np_++, il[FY_IOFF + cnt++] = c1 | (6 << 16), lim = max(lim, c1 + 5);
+        np_++, il[FY_IOFF + cnt++] = c1 | (6 << 16) | (1 << 24), lim = max(lim, c1 + 5);
       }
       if (!si) {
 #pragma unroll
         for (int e = 0; e < 8; e++)
           if (e == ni_) seen_i[e] = c2;
-        ni_++, il[FY_IOFF + cnt++] = c2 | (8 << 16), lim = max(lim, c2 + 7);
+        ni_++, il[FY_IOFF + cnt++] = c2 | (8 << 16) | (2 << 24), lim = max(lim, c2 + 7);
       }
     }
     for (int a = 1; a < cnt; a++) { // ascending first column: a column block's dead instances (left of it) are a prefix of the list
@@ -227,9 +236,9 @@ __global__ void __launch_bounds__(256) k_feat_vt(SysParams p, FeatStore st, doub
     for (int kb = 0; kb < nblk && kb < 12; kb++) {
       const int c_lo = cb * kb;
       int e0 = 0;
-      while (e0 < cnt && (il[FY_IOFF + e0] & 0xffff) + (il[FY_IOFF + e0] >> 16) - 1 < c_lo) e0++;
+      while (e0 < cnt && (il[FY_IOFF + e0] & 0xffff) + ((il[FY_IOFF + e0] >> 16) & 0xff) - 1 < c_lo) e0++;
       int e1 = e0;
-      while (e1 < cnt && (il[FY_IOFF + e1] & 0xffff) + (il[FY_IOFF + e1] >> 16) - 1 < c_lo + cb / 2) e1++;
+      while (e1 < cnt && (il[FY_IOFF + e1] & 0xffff) + ((il[FY_IOFF + e1] >> 16) & 0xff) - 1 < c_lo + cb / 2) e1++;
 #pragma unroll
       for (int w = 0; w < 4; w++)
         if (w == kb / 3) packed[w] |= (e0 | (e1 << 5)) << (10 * (kb % 3));
@@ -248,9 +257,21 @@ __global__ void __launch_bounds__(256) k_feat_vt(SysParams p, FeatStore st, doub
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // ---------------------------------------------------------------------------------------------------
-// Blocked Cholesky S0 = U^T U of the gate matrix held as tiles in registers (right-hand sides carried) + the chi2 statistic.
-// Same scheme as k_feat.h (e), (f).  acc / tij: this wavefront's tiles; panel: (NT + 1) tiles of LDS; st0 / st1: 2 x 256 doubles.
-// Returns chi2 in lane 0 of wavefront 0 (other lanes: undefined); ends with the workgroup synchronised.
+// Blocked Cholesky of the AUGMENTED gate matrix held as tiles in registers + the chi2 statistic.
+//
+// Round 5: the right-hand sides [r | H_f] are four extra ROWS / COLUMNS of the matrix instead of a tile column of their own,
+//
+//        M = [ S0    R ]      S0 = Y Y^T + s^2 I (n x n),  R = [r | H_f] (n x 4),  beta = 1 + |R|_F^2 / s^2 (k_feat_vt: tq[8 f + 7])
+//            [ R^T   beta I ]
+//
+// M = U^T U has U_12 = U_11^-T R — the solved right-hand sides y_r, Y_f the statistic needs — in columns n .. n+3 of the rows < n,
+// whatever stands below (beta only has to keep the pivots n .. n+3 that share the last diagonal tile positive: R^T S0^-1 R <= R^T R / s^2).
+// A track of m observations takes ceil((2 m + 4) / 16) tile rows and the upper triangle alone: 28 tiles at m = 50 (35 with the
+// right-hand-side column), 36 at m = 60 (44) — 9 accumulator tiles per wavefront in the 4-wavefront shape instead of 11, a quarter
+// fewer matrix instructions in the factorisation, and no tile that is three quarters padding.
+//
+// acc / tij: this wavefront's tiles; panel: NTA tiles of LDS; st0 / st1: 2 x 256 doubles.  NT = tile rows that hold rows of S0
+// (only those are factored).  Returns chi2 in lane 0 of wavefront 0 (other lanes: undefined); ends with the workgroup synchronised.
 // ---------------------------------------------------------------------------------------------------
 template <int NW, int TPW>
 __device__ __forceinline__ double gate_cholesky_chi2(d4 (&acc)[TPW], const int (&tij)[TPW], int NT, int n, double *panel, double *st0, double *st1, double *rhs,
@@ -268,14 +289,19 @@ __device__ __forceinline__ double gate_cholesky_chi2(d4 (&acc)[TPW], const int (
         for (int s = 0; s < TPW; s++)
           if (s == slot_t) av = acc[s];
         d4 ev;
-        // the step's critical path: three wavefronts of this workgroup wait at the barrier below, the wavefront of the CU's OTHER workgroup
-        // on this SIMD does not — the chain goes first whenever it has an instruction ready
+        // the step's critical path: three wavefronts of this workgroup wait at the barrier below, the wavefronts of the CU's OTHER workgroups
+        // on this SIMD do not — the chain goes first whenever it has an instruction ready
         // (measured, same box: 4-wavefront shape, two workgroups per CU: stage 0.4189 -> 0.4141 ms at configs[2]; the 8-wavefront shapes
         // have the CU to themselves and do not move, 6.480 / 6.493 ms at configs[3]: not applied there)
         if (NW == 4) __builtin_amdgcn_s_setprio(3);
         (void)diag_tile_factor_blk(av, ev, st0, lane, nullptr, 0.0, 16);
 #pragma unroll
         for (int q = 0; q < 4; q++) st1[cl * 16 + g + 4 * q] = ev[q]; // U^-T in accumulator layout -> U^-1 row-major
+        if (k == NT - 1) { // the last tile of S0 holds augmented columns: its U is read below
+#pragma unroll
+          for (int s = 0; s < TPW; s++)
+            if (s == slot_t) acc[s] = av;
+        }
         if (NW == 4) __builtin_amdgcn_s_setprio(0);
       }
     }
@@ -298,10 +324,10 @@ __device__ __forceinline__ double gate_cholesky_chi2(d4 (&acc)[TPW], const int (
       }
     }
     lds_barrier();
-    // (3) trailing update S_ij -= W_ki^T W_kj, k < i <= j (j = NT: the right-hand sides)
+    // (3) trailing update S_ij -= W_ki^T W_kj, k < i <= j (the tile row behind S0's last, if any, is never factored: not updated)
 #pragma unroll
     for (int s = 0; s < TPW; s++) {
-      if (tij[s] >= 0 && TI(s) > k) {
+      if (tij[s] >= 0 && TI(s) > k && TI(s) < NT) {
         const double *pi = panel + (size_t)TI(s) * 256, *pj = panel + (size_t)TJ(s) * 256;
         double a[4], b[4];
 #pragma unroll
@@ -312,12 +338,18 @@ __device__ __forceinline__ double gate_cholesky_chi2(d4 (&acc)[TPW], const int (
     }
     // no barrier here: the next step's factorisation touches st0 / st1 only, and its panel writes come after its first barrier
   }
-  // chi2 = |y_r|^2 - g^T G^-1 g,  y_r = U^-T r, Y_f = U^-T H_f
+  // chi2 = |y_r|^2 - g^T G^-1 g,  y_r = U^-T r, Y_f = U^-T H_f: columns n .. n+3 of U, rows < n
 #pragma unroll
   for (int s = 0; s < TPW; s++) {
-    if (tij[s] >= 0 && TJ(s) == NT && cl < 4) {
+    if (tij[s] >= 0 && TI(s) < NT) {
+      const int c = 16 * TJ(s) + cl - n;
+      if (c >= 0 && c < 4) {
 #pragma unroll
-      for (int q = 0; q < 4; q++) rhs[(size_t)(16 * TI(s) + g + 4 * q) * 4 + cl] = acc[s][q];
+        for (int q = 0; q < 4; q++) {
+          const int a = 16 * TI(s) + g + 4 * q;
+          if (a < n) rhs[(size_t)a * 4 + c] = acc[s][q];
+        }
+      }
     }
   }
   lds_barrier();
@@ -346,7 +378,8 @@ __device__ __forceinline__ double gate_cholesky_chi2(d4 (&acc)[TPW], const int (
 
 // ---------------------------------------------------------------------------------------------------
 // k_feat_y: one feature per workgroup (see the head of this file).  NW wavefronts, TPW gate tiles per wavefront:
-// NT (NT + 1) / 2 + NT <= NW * TPW for every feature of the batch.  tq: the factors T of k_feat_vt.
+// NTA (NTA + 1) / 2 <= NW * TPW for every feature of the batch, NTA = ceil((2 m + 4) / 16).  CB = columns per block (64 or 32):
+// the LDS block is 16 nt_max x (CB + 2) doubles.  tq: the factors T of k_feat_vt.
 //
 // The sweep Y = H L runs on the matrix cores as well.  A tile row (16 rows = 8 measurements) touches a handful of column blocks
 // of H — the clone blocks of its clones, the extrinsic / intrinsic blocks of its cameras ("instances", listed per tile row in the
@@ -357,28 +390,32 @@ __device__ __forceinline__ double gate_cholesky_chi2(d4 (&acc)[TPW], const int (
 // goes through the scalar cache, and the thread-per-column form this replaces (Jacobian values as scalar operands, 100+ scalar
 // registers per measurement, 229 of them spilled) spent 44 % of the kernel in its sweep.
 // ---------------------------------------------------------------------------------------------------
-template <int NW, int TPW, int OCC, bool F32OUT = false>
+template <int NW, int TPW, int OCC, bool F32OUT = false, int CB = FY_CB>
 __global__ void __launch_bounds__(64 * NW, OCC)
-    k_feat_y(SysParams p, int nt_max, const double *__restrict__ rowsG, const int32_t *__restrict__ minfoG, const double *__restrict__ VG,
+    k_feat_y(SysParams p, int nt_max, int nta_max, const double *__restrict__ rowsG, const int32_t *__restrict__ minfoG, const double *__restrict__ VG,
              const double *__restrict__ tqG, const int32_t *__restrict__ instG, const int32_t *__restrict__ slotsG) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int NTH = 64 * NW;
+  constexpr int LS = CB + 2;      // row stride of the LDS block (FY_LS at 64 columns)
+  constexpr int NCTB = CB / 16;   // column tiles per block
+  constexpr int HP = 64 / CB;     // rows a wavefront handles at once in the per-column phases (lane = (row parity hp, column))
+  static_assert(CB == 64 || CB == 32, "column blocks of 64 or 32");
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, cl = lane & 15;
+  const int colb = lane & (CB - 1), hp = lane / CB;
   const int D = p.D, LD = p.LD, RS = p.row_stride;
-  const FeatYLds lo = featy_lds_layout(nt_max, NW);
+  const FeatYLds lo = featy_lds_layout(nt_max, nta_max, NW, CB);
   double *Yb = reinterpret_cast<double *>(smem + lo.yb);
   double *panel = Yb;                                   // the Cholesky's row panel takes the block's place once the gate matrix is complete
-  double *rhs = Yb + (size_t)(nt_max + 1) * 256;        // ... and the solved right-hand sides sit behind it
+  double *rhs = Yb + (size_t)nta_max * 256;             // ... and the solved right-hand sides sit behind it
   double *Vl = reinterpret_cast<double *>(smem + lo.vl); // [16 nt_max][3] reflectors
   double *wpart = reinterpret_cast<double *>(smem + lo.wpart);
   double *st0 = wpart, *st1 = wpart + 256;
-  double *zres = reinterpret_cast<double *>(smem + lo.misc);                     // [3 NW] V^T r of the residual column, per wavefront
   int *rowlim = reinterpret_cast<int *>(smem + lo.misc + 32 * sizeof(double));   // [nt_max] last non-zero column of each tile row
   int *sched = rowlim + nt_max;                                                  // [4]
   const double sig2 = p.opt.sigma_pix_sq;
-  const int nblk = (D + FY_CB - 1) / FY_CB;
+  const int nblk = (D + CB - 1) / CB;
 
   // phase counters of workgroup 0 (tools/dev_featy_phases.py): a developer build only (-DOVG_FEAT_PROF) — the six read-modify-writes per
   // feature cost that workgroup a third of its time, and the bookkeeping costs every wavefront registers
@@ -412,8 +449,9 @@ __global__ void __launch_bounds__(64 * NW, OCC)
       for (int64_t e = tid; e < (int64_t)n_out * out.ld; e += NTH) out.zero(e);
       continue;
     }
-    const int n = 2 * m, NT = (n + 15) >> 4, NTT = NT * (NT + 1) / 2, ntiles = NTT + NT;
-    // this wavefront's tiles: linear index t = s NW + wv over the upper triangle column by column, then the right-hand-side column NT
+    // NT: tile rows that hold rows of Y (swept, factored); NTA: tile rows of the gate matrix with its four augmented rows
+    const int n = 2 * m, NT = (n + 15) >> 4, NTA = (n + 4 + 15) >> 4, NTT = NTA * (NTA + 1) / 2;
+    // this wavefront's tiles: linear index t = s NW + wv over the upper triangle column by column
     int tij[TPW]; // (j << 8) | i, or -1 for an unused slot
     d4 acc[TPW];
 #pragma unroll
@@ -425,8 +463,6 @@ __global__ void __launch_bounds__(64 * NW, OCC)
         j += ((j + 1) * (j + 2) / 2 <= t) ? 1 : 0;
         j -= (j * (j + 1) / 2 > t) ? 1 : 0;
         i = t - j * (j + 1) / 2;
-      } else if (t < ntiles) {
-        j = NT, i = t - NTT;
       }
       tij[s] = i < 0 ? -1 : ((j << 8) | i);
       acc[s] = d4{0.0, 0.0, 0.0, 0.0};
@@ -463,8 +499,8 @@ __global__ void __launch_bounds__(64 * NW, OCC)
 
     // ------------------------------------------------------------------ the column blocks
     for (int kb = 0; kb < nblk; kb++) {
-      const int c_lo = FY_CB * kb;
-      // ---- sweep on the matrix cores: this wavefront's tile rows of Y = H L, columns c_lo .. c_lo + 63 -> LDS
+      const int c_lo = CB * kb;
+      // ---- sweep on the matrix cores: this wavefront's tile rows of Y = H L, columns c_lo .. c_lo + CB - 1 -> LDS
       for (int i = wv; i < NT && !(FY_SKIP(p) & 1); i += NW) {
         const int r = 16 * i + cl;
         const bool rv = r < n;
@@ -476,20 +512,22 @@ __global__ void __launch_bounds__(64 * NW, OCC)
         const double hC0 = rd[RO_CLONE + 6 * par + g], hC1 = rd[RO_CLONE + 6 * par + g1];
         const double hP0 = rd[RO_CPOSE + 6 * par + g], hP1 = rd[RO_CPOSE + 6 * par + g1];
         const double hI0 = rd[RO_CINTR + 8 * par + g], hI1 = rd[RO_CINTR + 8 * par + 4 + g];
-        d4 ay[4];
+        d4 ay[NCTB];
 #pragma unroll
-        for (int ct = 0; ct < 4; ct++) ay[ct] = d4{0.0, 0.0, 0.0, 0.0};
+        for (int ct = 0; ct < NCTB; ct++) ay[ct] = d4{0.0, 0.0, 0.0, 0.0};
         const int32_t *il = finst + (size_t)i * FY_ISTR; // wave-uniform: scalar loads
         const int cnt = il[0];
         auto code_at = [&](int e) { return il[FY_IOFF + e]; };
-        // first instance that reaches this column block, and the first that reaches past its first two column tiles (k_feat_vt)
+        // first instance that reaches this column block, and the first that reaches past its first half (k_feat_vt)
         const int pk = il[2 + kb / 3] >> (10 * (kb % 3));
         const int e0 = pk & 31, e1 = (pk >> 5) & 31;
-        // The rows of L an instance selects, for the four column tiles of the block.  Straight-line code: every load is issued
+        // The rows of L an instance selects, for the column tiles of the block.  Straight-line code: every load is issued
         // unconditionally at a clamped address and masked afterwards (right of an instance L holds explicit zeros, so a column tile
         // beyond it costs two idle products, not a branch): the loads of the NEXT instance stay in flight behind this one's products.
-        const int colc = min(c_lo + cl, D - 1) - c_lo; // this lane's column of tile 0 (clamped), tiles 1..3: + 16 ct, clamped below
-        const bool okc[4] = {c_lo + cl < D, c_lo + 16 + cl < D, c_lo + 32 + cl < D, c_lo + 48 + cl < D};
+        const int colc = min(c_lo + cl, D - 1) - c_lo; // this lane's column of tile 0 (clamped), the other tiles: + 16 ct, clamped below
+        bool okc[NCTB];
+#pragma unroll
+        for (int ct = 0; ct < NCTB; ct++) okc[ct] = c_lo + 16 * ct + cl < D;
         // instances e_a .. e_b - 1 into the first NCT column tiles of the block
         auto run = [&](auto nct_tag, int e_a, int e_b) {
           constexpr int NCT = decltype(nct_tag)::value;
@@ -510,7 +548,7 @@ __global__ void __launch_bounds__(64 * NW, OCC)
           for (int e = e_a; e < e_b; e++) {
             load_b(code_n, bn); // in flight while this instance's products run (TWO instances ahead, a third operand set: 0.439 -> 0.454 ms of stage time)
             const int code_nn = code_at(min(e + 2, e_b - 1));
-            const int fc = code & 0xffff, w = code >> 16;
+            const int fc = code & 0xffff, w = (code >> 16) & 0xff;
             const double a0 = myc == fc ? hC0 : (myp == fc ? hP0 : (myi == fc ? hI0 : 0.0));
             const double a1 = (4 + g < w) ? (myc == fc ? hC1 : (myp == fc ? hP1 : (myi == fc ? hI1 : 0.0))) : 0.0; // k >= w: the next block's rows of L
 #pragma unroll
@@ -523,39 +561,40 @@ __global__ void __launch_bounds__(64 * NW, OCC)
             code = code_n, code_n = code_nn;
           }
         };
-        // instances that end inside the first two column tiles of the block (in block 0: the calibration blocks) skip the other two
-        run(std::integral_constant<int, 2>{}, e0, e1);
-        run(std::integral_constant<int, 4>{}, e1, cnt);
+        // instances that end inside the first half of the block (in block 0: the calibration blocks) skip the other half
+        run(std::integral_constant<int, NCTB / 2>{}, e0, e1);
+        run(std::integral_constant<int, NCTB>{}, e1, cnt);
 #pragma unroll
-        for (int ct = 0; ct < 4; ct++)
+        for (int ct = 0; ct < NCTB; ct++)
 #pragma unroll
-          for (int q = 0; q < 4; q++) Yb[(size_t)(16 * i + g + 4 * q) * FY_LS + 16 * ct + cl] = ay[ct][q];
+          for (int q = 0; q < 4; q++) Yb[(size_t)(16 * i + g + 4 * q) * LS + 16 * ct + cl] = ay[ct][q];
       }
       if (kb == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the reflectors' DMA (issued in the prologue) has landed
       lds_barrier();
       FEAT_T(1)
-      // ---- V^T Y per column (lane = column, the rows dealt to the wavefronts)
+      // ---- V^T Y per column (lane = (row parity, column), the rows dealt to the wavefronts)
       if (!(FY_SKIP(p) & 2)) {
         double w0 = 0.0, w1 = 0.0, w2 = 0.0;
 #pragma unroll 8
-        for (int a = wv; a < n; a += NW) {
-          const double y = Yb[(size_t)a * FY_LS + lane];
+        for (int a = HP * wv + hp; a < n; a += HP * NW) {
+          const double y = Yb[(size_t)a * LS + colb];
           w0 = fma(Vl[3 * a], y, w0), w1 = fma(Vl[3 * a + 1], y, w1), w2 = fma(Vl[3 * a + 2], y, w2);
         }
-        wpart[(wv * 3 + 0) * 64 + lane] = w0, wpart[(wv * 3 + 1) * 64 + lane] = w1, wpart[(wv * 3 + 2) * 64 + lane] = w2;
+        if (HP == 2) w0 += __shfl_xor(w0, 32, 64), w1 += __shfl_xor(w1, 32, 64), w2 += __shfl_xor(w2, 32, 64);
+        if (hp == 0) wpart[(wv * 3 + 0) * CB + colb] = w0, wpart[(wv * 3 + 1) * CB + colb] = w1, wpart[(wv * 3 + 2) * CB + colb] = w2;
       }
       lds_barrier();
       // ---- rows 3.. of Q^T Y = Y - V z -> the stack
       if (!(FY_SKIP(p) & 2)) {
-        const int c = c_lo + lane;
+        const int c = c_lo + colb;
         double s0 = 0.0, s1 = 0.0, s2 = 0.0;
 #pragma unroll
-        for (int w = 0; w < NW; w++) s0 += wpart[(w * 3 + 0) * 64 + lane], s1 += wpart[(w * 3 + 1) * 64 + lane], s2 += wpart[(w * 3 + 2) * 64 + lane];
+        for (int w = 0; w < NW; w++) s0 += wpart[(w * 3 + 0) * CB + colb], s1 += wpart[(w * 3 + 1) * CB + colb], s2 += wpart[(w * 3 + 2) * CB + colb];
         const double z0 = T00 * s0, z1 = T01 * s0 + T11 * s1, z2 = T02 * s0 + T12 * s1 + T22 * s2;
         if (c < D) {
 #pragma unroll 8
-          for (int a = 3 + wv; a < n; a += NW)
-            out.put(a - 3, c, Yb[(size_t)a * FY_LS + lane] - (Vl[3 * a] * z0 + Vl[3 * a + 1] * z1 + Vl[3 * a + 2] * z2));
+          for (int a = 3 + HP * wv + hp; a < n; a += HP * NW)
+            out.put(a - 3, c, Yb[(size_t)a * LS + colb] - (Vl[3 * a] * z0 + Vl[3 * a + 1] * z1 + Vl[3 * a + 2] * z2));
         }
       }
       FEAT_T(2)
@@ -565,8 +604,8 @@ __global__ void __launch_bounds__(64 * NW, OCC)
         if (tij[s] >= 0 && TJ(s) < NT && !skip_gate && !(FY_SKIP(p) & 4)) {
           const int lim = min(min(rowlim[TI(s)], rowlim[TJ(s)]), D - 1);
           if (lim >= c_lo) {
-            const int nsl = min(FY_CB / 8, (lim - c_lo) / 8 + 1);
-            const double *ya = Yb + (size_t)(16 * TI(s) + cl) * FY_LS + 2 * g, *yb = Yb + (size_t)(16 * TJ(s) + cl) * FY_LS + 2 * g;
+            const int nsl = min(CB / 8, (lim - c_lo) / 8 + 1);
+            const double *ya = Yb + (size_t)(16 * TI(s) + cl) * LS + 2 * g, *yb = Yb + (size_t)(16 * TJ(s) + cl) * LS + 2 * g;
 #pragma unroll FY_SYRK_UNROLL
             for (int sl = 0; sl < nsl; sl++) {
               const double2 a = *reinterpret_cast<const double2 *>(ya + 8 * sl), b = *reinterpret_cast<const double2 *>(yb + 8 * sl);
@@ -580,32 +619,32 @@ __global__ void __launch_bounds__(64 * NW, OCC)
       FEAT_T(3)
     }
 
-    // ------------------------------------------------------------------ S0 = Y Y^T + s^2 I (identity on the padding), right-hand sides [r | H_f]
+    // ------------------------------------------------------------------ M = [Y Y^T + s^2 I, R; R^T, beta I] (identity on the padding), R = [r | H_f]
+    const double beta = tqG[(size_t)8 * f + 7];
 #pragma unroll
     for (int s = 0; s < TPW; s++) {
       if (tij[s] < 0 || skip_gate) continue;
-      if (TJ(s) == NT) {
+      if (16 * TJ(s) + 15 >= n) { // a tile that reaches the augmented columns / the padding
         // (the lane's part of the address is recomputed behind an opaque value: hoisted out of the feature loop it was spilled in the
         // 8 x 17 shape, and reloaded from scratch 2 x 68 times per feature, each reload a wait on memory)
         int lane_o; // the lane id from the hardware, inside the asm: `lane` itself — and a hoisted mbcnt — were spilled and reloaded here
         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_o));
-        const int go = lane_o >> 4, clo = lane_o & 15;
+        const int go = lane_o >> 4, b = 16 * TJ(s) + (lane_o & 15);
 #pragma unroll
         for (int q = 0; q < 4; q++) {
           const int a = 16 * TI(s) + go + 4 * q;
-          double v = 0.0;
-          if (clo < 4 && a < n) {
+          double v = acc[s][q];
+          if (a == b) v = a < n ? v + sig2 : (a < n + 4 ? beta : 1.0);
+          else if (a < n && b >= n && b < n + 4) {
             const double *rd = frow + (size_t)(a >> 1) * RS;
-            v = clo == 0 ? rd[RO_RES + (a & 1)] : rd[RO_HF + 3 * (a & 1) + clo - 1];
+            v = b == n ? rd[RO_RES + (a & 1)] : rd[RO_HF + 3 * (a & 1) + b - n - 1];
           }
           acc[s][q] = v;
         }
       } else if (TI(s) == TJ(s)) {
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-          const int a = 16 * TI(s) + g + 4 * q;
-          if (g + 4 * q == cl) acc[s][q] = a < n ? acc[s][q] + sig2 : 1.0;
-        }
+        for (int q = 0; q < 4; q++)
+          if (g + 4 * q == cl) acc[s][q] += sig2;
       }
     }
     FEAT_T(4)
@@ -631,6 +670,18 @@ __global__ void __launch_bounds__(64 * NW, OCC)
 #undef TI
 #undef TJ
 }
+
+// The instantiations the library carries: (wavefronts, tiles per wavefront, wavefronts per SIMD the registers allow, float stack, columns per block).
+// ovgpu_featy_tu.hip instantiates them, ovgpu_api.hip declares them extern.
+//   <4, 9, 2, *, 64>   tracks of up to 62 observations (36 tiles), two workgroups per CU — the headline shape
+//   <8, 17, 1, *, 64>  up to 126 observations (136 tiles), one workgroup per CU
+//   <4, 9, 3, *, 32>, <8, 5, 4, *, 32>  round 5's occupancy experiments: 32-column blocks (half the LDS), 168 / 128 registers
+// (OCC is __launch_bounds__' second argument: wavefronts per SIMD)
+#define OVG_FEATY_SHAPES(X)                                                                                                     \
+  X(4, 9, 2, false, 64) X(4, 9, 2, true, 64) X(8, 17, 1, false, 64) X(8, 17, 1, true, 64) X(4, 9, 3, false, 32) X(8, 5, 4, false, 32)
+#define OVG_FEATY_ARGS                                                                                                                           \
+  SysParams, int, int, const double *__restrict__, const int32_t *__restrict__, const double *__restrict__, const double *__restrict__, \
+      const int32_t *__restrict__, const int32_t *__restrict__
 
 } // namespace feat
 } // namespace ovg

@@ -186,7 +186,7 @@ __global__ void __launch_bounds__(64 * NW, 1)
             for (int e = e_a; e < e_b; e++) {
               load_b(code_n, bn);
               const int code_nn = code_at(min(e + 2, e_b - 1));
-              const int fc = code & 0xffff, w = code >> 16;
+              const int fc = code & 0xffff, w = (code >> 16) & 0xff;
               const double a0 = myc == fc ? hC0 : (myp == fc ? hP0 : (myi == fc ? hI0 : 0.0));
               const double a1 = (4 + g < w) ? (myc == fc ? hC1 : (myp == fc ? hP1 : (myi == fc ? hI1 : 0.0))) : 0.0;
 #pragma unroll

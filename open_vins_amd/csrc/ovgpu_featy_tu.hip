@@ -25,14 +25,9 @@
 
 namespace ovg {
 namespace feat {
-template __global__ void k_feat_y<4, 11, 2, false>(SysParams, int, const double *__restrict__, const int32_t *__restrict__, const double *__restrict__,
-                                                   const double *__restrict__, const int32_t *__restrict__, const int32_t *__restrict__);
-template __global__ void k_feat_y<4, 11, 2, true>(SysParams, int, const double *__restrict__, const int32_t *__restrict__, const double *__restrict__,
-                                                  const double *__restrict__, const int32_t *__restrict__, const int32_t *__restrict__);
-template __global__ void k_feat_y<8, 17, 1, false>(SysParams, int, const double *__restrict__, const int32_t *__restrict__, const double *__restrict__,
-    const double *__restrict__, const int32_t *__restrict__, const int32_t *__restrict__);
-template __global__ void k_feat_y<8, 17, 1, true>(SysParams, int, const double *__restrict__, const int32_t *__restrict__, const double *__restrict__,
-    const double *__restrict__, const int32_t *__restrict__, const int32_t *__restrict__);
+#define X(NW, TPW, OCC, F32, CB) template __global__ void k_feat_y<NW, TPW, OCC, F32, CB>(OVG_FEATY_ARGS);
+OVG_FEATY_SHAPES(X)
+#undef X
 template __global__ void k_feat_y_big<8, 17, false>(SysParams, int, const double *__restrict__, const int32_t *__restrict__, const double *__restrict__,
     const double *__restrict__, const int32_t *__restrict__, const int32_t *__restrict__, double *);
 template __global__ void k_feat_y_big<8, 17, true>(SysParams, int, const double *__restrict__, const int32_t *__restrict__, const double *__restrict__,

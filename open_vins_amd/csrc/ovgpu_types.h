@@ -103,6 +103,8 @@ template <> struct StackRows<false> {
   int ld;
   __device__ __forceinline__ StackRows(const SysParams &p, int64_t row0) : d(p.Hbig + row0 * p.LD), ld(p.LD) {}
   __device__ __forceinline__ void put(int64_t r, int c, double v) const { d[r * ld + c] = v; }
+  // element `off` behind column c0 of the feature's first row: c0 wave-uniform, off the lane's (k_featw.h: scalar base + 32-bit offset addressing)
+  __device__ __forceinline__ void put_at(int c0, int off, double v) const { (d + c0)[off] = v; }
   __device__ __forceinline__ void zero(int64_t e) const { d[e] = 0.0; }
   __device__ __forceinline__ void pad(int, int, int, int) const {}
 };
@@ -111,6 +113,7 @@ template <> struct StackRows<true> {
   int ld;
   __device__ __forceinline__ StackRows(const SysParams &p, int64_t row0) : f(p.Hbig32 + row0 * p.LDF), ld(p.LDF) {}
   __device__ __forceinline__ void put(int64_t r, int c, double v) const { f[r * ld + c] = (float)v; }
+  __device__ __forceinline__ void put_at(int c0, int off, double v) const { (f + c0)[off] = (float)v; }
   __device__ __forceinline__ void zero(int64_t e) const { f[e] = 0.f; }
   // columns LD .. LDF-1 of the feature's n rows: k_gram_f32 copies whole rows into LDS and multiplies what it finds there
   __device__ __forceinline__ void pad(int tid, int nth, int n, int LD) const {

@@ -42,12 +42,15 @@ def _rel(a, b):
     return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
 
 
-def _check_given(Updater, oracle, prob, opts, tol_dx=TOL_DX, tol_p=TOL_P, require_gate=True):
-    """Injects the oracle's triangulation on both sides and compares everything downstream."""
+def _check_given(Updater, oracle, prob, opts, tol_dx=TOL_DX, tol_p=TOL_P, require_gate=True, debug=None):
+    """Injects the oracle's triangulation on both sides and compares everything downstream.
+    debug: ovgpu_debug_option settings of the contexts (e.g. the per-feature kernel's shape)."""
     v = capi.Views(prob)
     tri = oracle.triangulate(opts, v)
     ref = oracle.msckf_update(opts, v, want_compressed=True, given=tri)
     up = Updater(opts)
+    for name, val in (debug or {}).items():
+        up.debug_option(name, val)
     up.set_problem(prob)
     up.set_triangulation(tri["p_FinG"], tri["p_FinA"], tri["anchor_meas"], tri["status"])
     out = up.update()
@@ -80,6 +83,8 @@ def _check_given(Updater, oracle, prob, opts, tol_dx=TOL_DX, tol_p=TOL_P, requir
         full = capi.default_options(**{k: getattr(opts, k) for k, _ in opts._fields_ if not k.startswith("_")})
         full.gate_always_factor = 1
         up = Updater(full)
+        for name, val in (debug or {}).items():
+            up.debug_option(name, val)
         up.set_problem(prob)
         up.set_triangulation(tri["p_FinG"], tri["p_FinA"], tri["anchor_meas"], tri["status"])
         out1 = up.update()
@@ -185,7 +190,9 @@ def test_update_parity_long_tracks(Updater, oracle, general):
 def test_block_row_gate_equals_the_one_pass_gate(Updater, kw):
     """k_feat_y_big (k_featy_big.h) on batches the one-pass kernel holds: with the same tile budget (one pass) and with 5 tiles per
     wavefront (2 .. 5 passes over 8 .. 15 tile rows).  A tile of the gate matrix receives the same updates in the same order
-    whatever the pass structure, so chi2 is BIT-identical; the stacked rows differ in the summation order of V^T Y only."""
+    whatever the pass structure, so chi2 is BIT-identical between the two block-row shapes; the stacked rows differ in the
+    summation order of V^T Y only.  Against the one-pass kernel the statistic agrees to rounding (round 5: that kernel carries the
+    right-hand sides [r | H_f] as four augmented ROWS of the gate matrix, the block-row kernel as a tile column of their own)."""
     kw = dict(kw)
     prob = synth.make_problem(kw.pop("cfg", 2), **kw)
     opts = capi.default_options(chi2_multipler=1.0, gate_always_factor=1)  # the test is about the gate's pass structure
@@ -199,12 +206,24 @@ def test_block_row_gate_equals_the_one_pass_gate(Updater, kw):
     ref = outs[0]
     gate = np.isfinite(ref["chi2"])
     assert gate.sum() > 0.5 * prob.F
+    assert np.array_equal(outs[1]["chi2"][gate], outs[2]["chi2"][gate])
     for out in outs[1:]:
         assert np.array_equal(out["feat_status"], ref["feat_status"])
-        assert np.array_equal(out["chi2"][gate], ref["chi2"][gate])
+        np.testing.assert_allclose(out["chi2"][gate], ref["chi2"][gate], rtol=1e-11)
         assert out["stats"]["n_rows"] == ref["stats"]["n_rows"]
         assert _rel(out["dx"], ref["dx"]) < 1e-10
         assert _rel(out["P"], ref["P"]) < 1e-11
+
+
+@pytest.mark.parametrize("shape", [1, 2, 3])
+@pytest.mark.parametrize("kw", [dict(F=300), dict(F=200, track="ragged", outlier_frac=0.3), dict(F=150, C=11, K=1), dict(cfg=3, F=260)])
+def test_feature_kernel_shapes(Updater, oracle, kw, shape):
+    """The one-pass per-feature kernel in its other shapes (ovgpu_debug_option "featy_shape"; round 5's measured alternatives to the
+    default <4 wavefronts, 9 tiles, 64-column blocks>): 1 = <4, 9> and 2 = <8, 5> with 32-column blocks (three / four wavefronts
+    per SIMD), 3 = one feature per WAVEFRONT (k_featw.h: whitened rows and gate matrix in registers, no workgroup barrier)."""
+    kw = dict(kw)
+    prob = synth.make_problem(kw.pop("cfg", 2), **kw)
+    _check_given(Updater, oracle, prob, capi.default_options(chi2_multipler=1.0), debug=dict(featy_shape=shape))
 
 
 def test_short_and_empty_tracks(Updater, oracle):
