@@ -35,10 +35,12 @@ static constexpr int SYS_NT = 256;  // threads per workgroup
 static constexpr int SYS_RCM = 8;   // measurements per T-chunk (16 rows)
 
 // LDS carve sizes in bytes for a batch whose longest track is m_max (host + device agree on this)
-__host__ __device__ inline size_t sys_lds_fixed_bytes(int m_max, int row_stride, int D) {
+// rows_in_lds = false: the Jacobian records of the feature live in a per-workgroup global workspace (SysParams::rows_ws, k_system_t<true>):
+// tracks whose records do not fit LDS next to the T chunk (~250 observations at 440 columns)
+__host__ __device__ inline size_t sys_lds_fixed_bytes(int m_max, int row_stride, int D, bool rows_in_lds = true) {
   size_t b = 0;
-  b += (size_t)m_max * 8 * sizeof(int);            // minfo
-  b += (size_t)m_max * row_stride * sizeof(double); // rows
+  b += ((size_t)m_max * 8 * sizeof(int) + 15) & ~(size_t)15; // minfo
+  if (rows_in_lds) b += (size_t)m_max * row_stride * sizeof(double); // rows
   b += (size_t)2 * m_max * 3 * sizeof(double);      // V
   b += 64 * sizeof(double);                         // tau, T, representation scratch
   b += (size_t)2 * SYS_RCM * D * sizeof(double);    // T chunk
@@ -119,8 +121,12 @@ __device__ __forceinline__ double lane_bcast_d(double v, int lane) { // lane is 
 // One 8-column panel of the gate Cholesky, factored by a single wavefront in registers: row r of the panel
 // (rows kb .. n+3) lives in lane r & 63, slot r >> 6; pivots and multipliers are broadcast with v_readlane, so
 // there is no LDS round trip and no workgroup barrier inside the panel.  CS = row slots per lane.
-template <int CS>
-__device__ __forceinline__ void gate_chol_panel(double *S, int n, int kb, int nb, int lane) {
+// LONG: the trapezoid has more rows than CS x 64 (a track of more than 254 observations): the pivots' reciprocals and the
+// multipliers L[kb + jj][kb + k] of the panel are kept (wave-uniform) and the rows behind the first CS x 64 take the same column
+// operations, 512 at a time (gate_chol_panel_rest) — the statistic of a track of ANY length the row store holds, UpdaterMSCKF.cpp:216-222
+// (dof >= 500: the quantile computed on the fly there, the extended table here).
+template <int CS, bool LONG = false>
+__device__ __forceinline__ void gate_chol_panel(double *S, int n, int kb, int nb, int lane, double *pinv = nullptr, double *pmul = nullptr) {
   constexpr int CB = 8;
   double a[CS][CB];
   size_t base[CS];
@@ -144,12 +150,14 @@ __device__ __forceinline__ void gate_chol_panel(double *S, int n, int kb, int nb
       double d = dkk * inv;
       d = fma(0.5 * inv, fma(-d, d, dkk), d);
       if (!(dkk > 0.0)) d = sqrt(dkk), inv = 1.0 / d; // keep the NaN / inf behaviour of a broken-down factorisation
+      if (LONG) pinv[k] = inv;
 #pragma unroll
       for (int sl = 0; sl < CS; sl++) a[sl][k] = (lane + 64 * sl == k) ? d : a[sl][k] * inv;
 #pragma unroll
       for (int jj = k + 1; jj < CB; jj++) {
         if (jj < nb) {
           const double ljk = lane_bcast_d(a[0][k], jj); // L[kb + jj][kb + k]
+          if (LONG) pmul[k * CB + jj] = ljk;
 #pragma unroll
           for (int sl = 0; sl < CS; sl++) a[sl][jj] = fma(-a[sl][k], ljk, a[sl][jj]);
         }
@@ -162,6 +170,34 @@ __device__ __forceinline__ void gate_chol_panel(double *S, int n, int kb, int nb
 #pragma unroll
     for (int jj = 0; jj < CB; jj++)
       if (okr[sl] && jj < nb && (row >= n || kb + jj <= row)) S[base[sl] + jj] = a[sl][jj];
+  }
+}
+
+// the rows row0 .. row0 + 64 CS - 1 of the panel at kb (all of them below the pivot rows): the column operations of gate_chol_panel
+// with its recorded reciprocals pinv[k] and multipliers pmul[k * 8 + jj]
+template <int CS>
+__device__ __forceinline__ void gate_chol_panel_rest(double *S, int n, int kb, int nb, int lane, int row0, const double *pinv, const double *pmul) {
+  constexpr int CB = 8;
+#pragma unroll 1
+  for (int sl = 0; sl < CS; sl++) {
+    const int row = row0 + lane + 64 * sl;
+    if (row >= n + 4) continue;
+    const size_t base = (row < n ? (size_t)row * (row + 1) / 2 : (size_t)n * (n + 1) / 2 + (size_t)(row - n) * n) + kb; // &S[row][kb]
+    double a[CB];
+#pragma unroll
+    for (int jj = 0; jj < CB; jj++) a[jj] = jj < nb ? S[base + jj] : 0.0; // (row > kb + 7: the whole panel is left of the diagonal)
+#pragma unroll
+    for (int k = 0; k < CB; k++) {
+      if (k < nb) {
+        a[k] *= pinv[k];
+#pragma unroll
+        for (int jj = k + 1; jj < CB; jj++)
+          if (jj < nb) a[jj] = fma(-a[k], pmul[k * CB + jj], a[jj]);
+      }
+    }
+#pragma unroll
+    for (int jj = 0; jj < CB; jj++)
+      if (jj < nb) S[base + jj] = a[jj];
   }
 }
 
@@ -323,14 +359,16 @@ __device__ __forceinline__ void sys_hf_householder(double *rows, int RS, double 
 }
 
 #ifndef OVG_TU_FEATY // (a non-template kernel: defined in the library's main translation unit only, see ovgpu_featy_tu.hip)
-__global__ void __launch_bounds__(SYS_NT) k_system(SysParams p) {
+// RG: the feature's Jacobian records in the global workspace SysParams::rows_ws instead of LDS (long tracks at many columns; round 5)
+template <bool RG> __global__ void __launch_bounds__(SYS_NT) k_system_t(SysParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
   const int D = p.D, LD = p.LD, N = p.N, RS = p.row_stride;
   // ---- LDS carve
   int *minfo = reinterpret_cast<int *>(smem);
-  double *rows = reinterpret_cast<double *>(smem + (((size_t)p.m_max * 8 * sizeof(int) + 15) & ~(size_t)15));
-  double *V = rows + (size_t)p.m_max * RS;
+  double *rows_lds = reinterpret_cast<double *>(smem + (((size_t)p.m_max * 8 * sizeof(int) + 15) & ~(size_t)15));
+  double *rows = RG ? p.rows_ws + (size_t)blockIdx.x * p.m_max * RS : rows_lds;
+  double *V = RG ? rows_lds : rows_lds + (size_t)p.m_max * RS;
   double *hq = V + (size_t)2 * p.m_max * 3; // [0..2] tau, [3..11] T, [12..20] dpfg_dlambda, [21..38] H_anc, [39..56] H_calib, [57..] flags
   double *Tch = hq + 64;
   double *S_lds = Tch + (size_t)2 * SYS_RCM * D;
@@ -583,7 +621,12 @@ __global__ void __launch_bounds__(SYS_NT) k_system(SysParams p) {
         const int nb = min(CB, n - kb);
         if (wv == 0) {
           if (n + 4 - kb <= 128) gate_chol_panel<2>(S, n, kb, nb, lane);
-          else gate_chol_panel<8>(S, n, kb, nb, lane);
+          else if (n + 4 - kb <= 512) gate_chol_panel<8>(S, n, kb, nb, lane);
+          else { // a track of more than 254 observations: the first 512 rows of the trapezoid, then the rest with the recorded pivots
+            double pinv[8], pmul[64];
+            gate_chol_panel<8, true>(S, n, kb, nb, lane, pinv, pmul);
+            for (int row0 = kb + 512; row0 < n + 4; row0 += 512) gate_chol_panel_rest<8>(S, n, kb, nb, lane, row0, pinv, pmul);
+          }
         }
         __syncthreads();
         SYS_T(0)

@@ -64,6 +64,7 @@ struct SysParams {
   int LDF;                  // its row stride, 32 ceil(LD / 32)
   double *ws;               // global workspace for the gate matrix when it does not fit LDS
   int64_t ws_stride;        // doubles per workgroup
+  double *rows_ws;          // k_system_t<true>: the workgroups' Jacobian records, m_max * row_stride doubles each (records that do not fit LDS)
   int m_lds_max;            // largest track length whose gate matrix is LDS-resident
   int m_max;                // largest track length in the batch
   int row_stride;           // doubles per measurement in the LDS row store (48, or 72 with anchored reps)

@@ -61,6 +61,54 @@ def _parity(Updater, oracle, prob, opts, tol_dx=1e-8, tol_p=1e-9, key=None, **fi
     return out, ref
 
 
+def _parity_device_triangulation(Updater, oracle, prob, opts, tol_dx=1e-8, tol_p=1e-9, key=None):
+    """END TO END at full size with the DEVICE's triangulation (no set_triangulation): triangulate -> per-feature systems -> gate ->
+    compression -> update in one ovgpu_msckf_update.  Two comparisons against the oracle:
+      1. the triangulation itself (verdicts identical, positions to 1e-6 m: FeatureInitializer's float32 cost path decides the
+         Levenberg-Marquardt steps, so a feature near a step boundary may end one iteration apart; tests/test_gpu_parity.py holds the
+         tight bound on batches without such features);
+      2. everything downstream against the oracle run ON THE DEVICE'S positions (accept sets, chi2, dx, P') at the full-size tolerances."""
+    v = capi.Views(prob)
+    if key is not None and key in _ORACLE_RUNS:
+        tri, _ = _ORACLE_RUNS[key]
+    else:
+        tri = oracle.triangulate(opts, v)
+    up = Updater(opts)
+    up.set_problem(prob)
+    out = up.update()
+    got = up.get_triangulation()
+    up.close()
+    tri_failed = (out["feat_status"] != capi.FEAT_USED) & (out["feat_status"] != capi.FEAT_CHI2_REJECTED)
+    assert np.array_equal(tri_failed, tri["status"] != capi.FEAT_USED), "the triangulation verdicts differ"
+    assert np.array_equal(out["feat_status"][tri_failed], tri["status"][tri_failed])
+    ok = ~tri_failed
+    assert ok.sum() > 0.9 * prob.F
+    assert np.abs(got["p_FinG"][ok] - tri["p_FinG"][ok]).max() < 1e-6
+    status = np.where(tri_failed, out["feat_status"], capi.FEAT_USED).astype(np.int32)
+    given = dict(p_FinG=got["p_FinG"], p_FinA=got["p_FinA"], anchor_meas=got["anchor_meas"], status=status)
+    ref = oracle.msckf_update(opts, v, given=given)
+    ref = oracle_with_the_same_gate_verdicts(oracle, opts, v, given, ref, out)
+    assert_chi2(out, ref, 1e-8, strict=bool(opts.gate_always_factor))
+    assert np.array_equal(out["feat_status"], ref["feat_status"])
+    assert ref["stats"]["n_used"] > 0.8 * prob.F
+    assert _rel(out["dx"], ref["dx"]) < tol_dx, _rel(out["dx"], ref["dx"])
+    assert _rel(out["P"], ref["P"]) < tol_p, _rel(out["P"], ref["P"])
+    assert np.abs(out["clone_q_p"] - ref["clone_q_p"]).max() < 1e-9
+    return out, ref
+
+
+def test_cfg3_full_size_end_to_end_with_the_device_triangulation(Updater, oracle):
+    """BASELINE configs[2] (2000 features, 100 k measurements) with nothing injected: the batch bench.py times."""
+    prob = synth.make_problem(3)
+    _parity_device_triangulation(Updater, oracle, prob, capi.default_options(chi2_multipler=1.0), key=("cfg3", 2000))
+
+
+def test_cfg4_shard_end_to_end_with_the_device_triangulation(Updater, oracle):
+    """One of 8 ranks' share of BASELINE configs[3] (4 cameras, 1250 features of ~100 observations: k_feat_y<8, 17>) with nothing injected."""
+    prob = synth.make_problem(4, F=1250)
+    _parity_device_triangulation(Updater, oracle, prob, capi.default_options(chi2_multipler=1.0), key=("cfg4", 1250))
+
+
 @pytest.mark.parametrize("full_gate", [0, 1])
 def test_cfg3_full_size_against_oracle(Updater, oracle, full_gate):
     """BASELINE configs[2]: 30 clones + online calibration, 2000 features (93 k measurements).  full_gate = 0: the library's
@@ -86,7 +134,7 @@ def test_cfg4_shard_against_oracle(Updater, oracle):
     """One of 8 ranks' share of BASELINE configs[3]: 4 cameras, N = 252, D = 236, 1250 features of ~100 observations."""
     prob = synth.make_problem(4, F=1250)
     assert prob.K == 4 and prob.N == 252
-    _parity(Updater, oracle, prob, capi.default_options(chi2_multipler=1.0))
+    _parity(Updater, oracle, prob, capi.default_options(chi2_multipler=1.0), key=("cfg4", 1250))
 
 
 def test_10k_features_against_oracle(Updater, oracle):

@@ -1598,21 +1598,38 @@ def test_refinement_alone_from_a_given_estimate(Updater, oracle):
     up.close()
 
 
-def test_tracks_beyond_the_gate_capacity_are_refused(Updater):
-    """A track of 300 observations (2m + 4 > 512 gate rows) fits neither per-feature kernel: OVGPU_ERR_CAPACITY at
-    ovgpu_set_features, not a silently mis-scaled chi2 (k_system.h: gate_chol_panel<8> holds 512 rows)."""
+def _with_a_long_first_track(prob, length):
+    """prob with its first track's observations repeated up to `length` (a track longer than any camera rig produces in one window)."""
     import copy
-    prob = synth.make_problem(5, F=3)
     a, b = int(prob.meas_offsets[0]), int(prob.meas_offsets[1])
     m = b - a
-    assert 100 <= m <= 254
-    reps = -(-300 // m)
-    sel = np.concatenate([np.tile(np.arange(a, b), reps)[:300], np.arange(b, prob.M)])
+    reps = -(-length // m)
+    sel = np.concatenate([np.tile(np.arange(a, b), reps)[:length], np.arange(b, prob.M)])
     q = copy.copy(prob)
     q.uv = np.ascontiguousarray(prob.uv.reshape(-1, 2)[sel].reshape(-1))
     q.uvn = np.ascontiguousarray(prob.uvn.reshape(-1, 2)[sel].reshape(-1))
     q.clone_idx, q.cam_idx = np.ascontiguousarray(prob.clone_idx[sel]), np.ascontiguousarray(prob.cam_idx[sel])
-    q.meas_offsets = np.concatenate([[0], prob.meas_offsets[1:] + (300 - m)]).astype(np.int32)
+    q.meas_offsets = np.concatenate([[0], prob.meas_offsets[1:] + (length - m)]).astype(np.int32)
+    return q
+
+
+def test_tracks_beyond_254_observations_are_gated(Updater, oracle):
+    """A track of 280 observations: 2m + 4 = 564 gate rows, dof = 557 >= 500 (the reference computes that quantile on the fly,
+    UpdaterMSCKF.cpp:216-222).  Beyond the fused kernels (232 observations) and, until round 5, beyond the library (the general kernel's
+    panel routine held 512 rows: OVGPU_ERR_CAPACITY): now the panel takes the trapezoid 512 rows at a time (k_system.h) and the
+    statistic, the threshold and the update are the oracle's."""
+    prob = synth.make_problem(2, F=3)
+    q = _with_a_long_first_track(prob, 280)  # (the row store of the general kernel: 160 KB of LDS hold ~290 records next to a 208-column chunk)
+    out, ref = _check_given(Updater, oracle, q, capi.default_options(chi2_multipler=1.0, gate_always_factor=1), tol_dx=1e-7, tol_p=1e-8)
+    assert np.isfinite(out["chi2"][0]) and out["chi2_thresh"][0] > 600.0  # chi2_95(557) = 613.0: beyond the reference's table of 500
+
+
+def test_tracks_beyond_the_general_kernel_tables_are_refused(Updater):
+    """A track of 2500 observations: its block ids and reflectors (80 bytes per observation) do not fit LDS next to the general kernel's
+    T chunk — OVGPU_ERR_CAPACITY at ovgpu_set_features, never a silently mis-gated feature.  (The Jacobian records themselves move to a
+    global workspace when they do not fit, k_system_t<true>: the fixture ref_msckf_dof_beyond_table, 256 observations at 440 columns.)"""
+    prob = synth.make_problem(5, F=3)
+    q = _with_a_long_first_track(prob, 2500)
     up = Updater(capi.default_options())
     with pytest.raises(capi.OvgpuError) as ei:
         up.set_problem(q)
