@@ -54,6 +54,12 @@ def parse_args(argv=None):
     ap.add_argument("--stage-events-every", type=int, default=4, help="the library's per-stage HIP events (roofline durations) on every n-th update of the timed region")
     ap.add_argument("--gate-always-factor", action="store_true", help="ovgpu_options::gate_always_factor = 1: form and factor every feature's gate matrix "
                     "(default: features whose residual bound is under the chi2 threshold are accepted without it)")
+    ap.add_argument("--no-imu-intrinsics", action="store_true",
+                    help="headline batch on the N = 224 state of SURVEY 8(d) (camera calibration only) instead of BASELINE configs[2] as written "
+                         "(\"online cam/IMU calib\": N = 248, the default at one GPU)")
+    ap.add_argument("--min-timed-seconds", type=float, default=1.0,
+                    help="timed loops of exactly --steps updates are repeated (at least 3) until this much time has been timed: a utilisation sampler "
+                         "sees the run whatever --steps is")
     ap.add_argument("--debug-option", action="append", default=[], metavar="NAME=VALUE",
                     help="ovgpu_debug_option(NAME, VALUE) on every context before the batch is uploaded (developer A/Bs, e.g. featy_shape=1)")
     ap.add_argument("--gram-fp32", action="store_true", help="BASELINE configs[4]'s fp32 compression: Gram matrix accumulated on v_mfma_f32_16x16x4_f32")
@@ -152,7 +158,7 @@ def main(argv=None):
     timed_loops = []  # seconds of every timed loop of the last run()
     rank_loops = []   # the last timed loop of the last run(): every rank's own seconds (before the max over ranks)
 
-    def run(prob_full, feats_of_rank, steps, warmup, local_only=False, repeats=1, opts=opts):
+    def run(prob_full, feats_of_rank, steps, warmup, local_only=False, repeats=1, opts=opts, min_seconds=0.0):
         """Times `steps` updates of prob_full sharded as feats_of_rank(rank); returns (seconds max over ranks, updater, shard).
         local_only: every rank updates with ITS shard alone (no exchange) — the compute side of the scaling model."""
         shard = prob_full if world == 1 else prob_full.subset(feats_of_rank)
@@ -195,7 +201,8 @@ def main(argv=None):
         fence()
         up.kernel_times(reset=True)
         dts = []
-        for _ in range(repeats):  # every repeat times EXACTLY `steps` updates between two fences, max over ranks
+        timed = 0.0
+        while len(dts) < repeats or (timed < min_seconds and len(dts) < 200):  # every repeat times EXACTLY `steps` updates between two fences, max over ranks
             t0 = time.perf_counter()
             for _ in range(steps):
                 step()
@@ -211,14 +218,55 @@ def main(argv=None):
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 dt = float(t.item())
             dts.append(dt)
+            timed += dt  # (the max over ranks: every rank takes the same decision)
         timed_loops.clear()
         timed_loops.extend(dts)
         return sorted(dts)[len(dts) // 2], up, shard
 
     # ---- headline workload
-    prob = synth.make_problem(cfg, F=args.features)
+    # BASELINE configs[2] reads "30 clones + online cam/IMU calib": with StateOptions::do_calib_imu_intrinsics the state carries 24 more rows
+    # of P behind the IMU block (State.cpp:65-88: N = 248) that never get Jacobian columns -- the headline at one GPU since
+    # round 5; --no-imu-intrinsics gives SURVEY 8(d)'s N = 224 state (rounds 1-4's headline, now the extra `survey_8d_state`)
+    imu_intr = cfg == CFG_SINGLE and not args.no_imu_intrinsics
+    prob = synth.make_problem(cfg, F=args.features, imu_intrinsics=imu_intr)
     mine = parallel.shard_features(prob.meas_offsets, rank, world)
-    dt, up, shard = run(prob, mine, args.steps, args.warmup, repeats=3)  # the MEDIAN of three timed loops of K steps is the line's value
+    preflight = None
+    if world > 1:
+        # PREFLIGHT of a multi-rank run, on stderr before anything is timed (the first line a failed SCALE run leaves behind): every rank's
+        # device, shard and the time of its shard as a stand-alone update, and the scaling model's prediction from them
+        pre = {"rank": rank, "device": (torch.cuda.get_device_name(local_rank) if hook is None else "cpu (test hook)"), "features_this_rank": int(len(mine))}
+        try:
+            pdt, pup, _ = run(prob, mine, 3, 1, local_only=True)
+            pup.close()
+            pre["local_ms_per_step"] = 1e3 * pdt / 3
+        except Exception as e:  # noqa: BLE001
+            pre["error"] = repr(e)
+        every = [None] * world
+        dist.all_gather_object(every, pre)
+        gram_bytes = 8.0 * (16 * ((prob.Dmax + 1 + 15) // 16)) ** 2
+        t_ar = 2 * (world - 1) * 8e-3 + 2.0 * (world - 1) / world * gram_bytes / 40e9 * 1e3
+        locals_ms = [e.get("local_ms_per_step") for e in every]
+        preflight = {"ranks": every, "exchange_bytes": gram_bytes, "modelled_all_reduce_ms": t_ar,
+                     "predicted_ms": (max(locals_ms) + t_ar) if all(x is not None for x in locals_ms) else None}
+        if rank == 0:
+            print("[bench preflight] " + json.dumps(preflight), file=sys.stderr, flush=True)
+    # the MEDIAN of the timed loops of K steps is the line's value (three loops, more until --min-timed-seconds have been timed)
+    err = None
+    try:
+        dt, up, shard = run(prob, mine, args.steps, args.warmup, repeats=3, min_seconds=args.min_timed_seconds if hook is None else 0.0)
+    except Exception as e:  # noqa: BLE001
+        if world == 1:
+            raise
+        err = e
+    if world > 1:
+        # a failure on ANY rank ends the run on every rank, with what is known so far on stderr (exchange kind, preflight, the error)
+        try:
+            parallel.agree_on_status(dist, "timed headline run", err)
+        except parallel.ShardedUpdateError as e:
+            if rank == 0:
+                print("[bench failed] " + json.dumps({"error": str(e), "exchange": exchange, "preflight": preflight, "n_gpus": world,
+                                                      "steps": args.steps, "warmup": args.warmup}), file=sys.stderr, flush=True)
+            sys.exit(3)
     headline_loops = [1e3 * x / args.steps for x in timed_loops]
     headline_rank_ms = [1e3 * x / args.steps for x in rank_loops]
     kt = up.kernel_times(reset=True)
@@ -271,13 +319,11 @@ def main(argv=None):
                         "uncertainty: the regime of the rpng_sim closed loop), where the gate's residual bound decides most features; NOT the headline",
                 "ms_per_step": 1e3 * tdt / tsteps, "ms_per_step_with_every_gate_factored": 1e3 * fdt / tsteps,
                 "features_used": int(tres["stats"]["n_used"]), "features_passed_by_the_bound": int(tres["stats"]["n_gate_bound"])}
-        if world == 1 and args.cfg is None and args.features is None:
-            # BASELINE configs[2] reads "online cam/IMU calib": with StateOptions::do_calib_imu_intrinsics the state carries 24 more
-            # rows of P behind the IMU block (State.cpp:65-88: N = 248) that never get Jacobian columns -- the per-feature
-            # stage and the compression are the headline's, the update's N x N products grow.  The same batch on that state, beside the
-            # headline (whose N = 224 is SURVEY 8(d)'s cfg-3 figure); an extra must never take the line down with it.
+        if world == 1 and args.cfg is None and args.features is None and imu_intr:
+            # the same batch on SURVEY 8(d)'s cfg-3 state (camera calibration only, N = 224: the headline of rounds 1-4) beside the headline;
+            # an extra must never take the line down with it.
             try:
-                iprob = synth.make_problem(cfg, imu_intrinsics=True)
+                iprob = synth.make_problem(cfg, imu_intrinsics=False)
                 isteps = max(5, args.steps // 4)
                 keep_loops = list(timed_loops)
                 idt, iup, _ = run(iprob, None, isteps, 5)
@@ -285,11 +331,11 @@ def main(argv=None):
                 ires = iup.update()
                 iup.close()
                 timed_loops[:] = keep_loops
-                extras["imu_intrinsics_state"] = {"workload": f"the headline batch on a state that also calibrates the IMU intrinsics: N={iprob.N}, D={iprob.Dmax}",
-                                                  "ms_per_step": 1e3 * idt / isteps, "value": iprob.F / (idt / isteps), "unit": "features/s",
-                                                  "features_used": int(ires["stats"]["n_used"])}
+                extras["survey_8d_state"] = {"workload": f"the headline batch on the state without IMU intrinsics (SURVEY 8(d); rounds 1-4's headline): N={iprob.N}, D={iprob.Dmax}",
+                                             "ms_per_step": 1e3 * idt / isteps, "value": iprob.F / (idt / isteps), "unit": "features/s",
+                                             "features_used": int(ires["stats"]["n_used"])}
             except Exception as e:  # noqa: BLE001
-                extras["imu_intrinsics_state"] = {"error": repr(e)}
+                extras["survey_8d_state"] = {"error": repr(e)}
         if world > 1:
             pass
         elif cfg != CFG_MULTI:  # the strong-scaling job of N > 1 on this one GPU: the reference point of the scaling curve
@@ -343,7 +389,7 @@ def main(argv=None):
             "data": "synthetic",
             "config": {
                 "workload": (f"BASELINE.json configs[{cfg - 1}]: {prob.K}-camera radtan rig, {prob.C}-clone window, {prob.F} MSCKF features/update"
-                             f"{' dealt over ' + str(world) + ' GPUs' if world > 1 else ''}, N={prob.N}, D={prob.Dmax}, online cam extrinsic+intrinsic calib, FEJ"),
+                             f"{' dealt over ' + str(world) + ' GPUs' if world > 1 else ''}, N={prob.N}, D={prob.Dmax}, online cam extrinsic+intrinsic calib{' + IMU intrinsics in the state' if imu_intr else ''}, FEJ"),
                 "features_total": prob.F, "features_this_rank": shard.F, "clones": prob.C, "cameras": prob.K, "state_dim": prob.N,
                 "measurements_total": prob.M, "features_used_rank0": int(res["stats"]["n_used"]),
                 "parallelism": f"feature-shard x{world}, one all-reduce of the Gram matrix: {exchange['kind']}" if world > 1 else "single GPU",
@@ -407,6 +453,7 @@ def main(argv=None):
             # what the first real multi-GPU line is read against (no N > 1 run has been measured: DESIGN.md section 5)
             out["exchange"] = dict(exchange)
             out["per_rank_ms_per_step"] = headline_rank_ms  # last timed loop, every rank's own clock
+            out["preflight"] = preflight
         if hook is not None:
             out["test_hook"] = os.environ["OVGPU_BENCH_TEST_HOOK"] + ": host stand-in for the updater over gloo -- control flow only, NOT a measurement"
         out.update(extras)
@@ -524,11 +571,11 @@ def pmc_traffic_bytes(cfg):
 
 def _oracle_chunk(job):
     """Loops A and B (triangulation, Jacobians, nullspace projection, gate) of a feature subset in a worker process."""
-    cfg, F, lo, hi = job
+    cfg, F, lo, hi, imu_intr = job
     from open_vins_amd import capi, synth
     from oracle import pyoracle
     import numpy as np
-    prob = synth.make_problem(cfg, F=F).subset(np.arange(lo, hi))
+    prob = synth.make_problem(cfg, F=F, imu_intrinsics=imu_intr).subset(np.arange(lo, hi))
     opts = capi.default_options(chi2_multipler=1.0)
     v = capi.Views(prob)
     pyoracle.msckf_update(opts, v)
@@ -571,7 +618,7 @@ def cpu_baseline(prob, opts, sample_features=500, reps=5):
         cores = os.cpu_count() or 1
         if cores > 1:
             bounds = np.linspace(0, Fs, cores + 1).astype(int)
-            jobs = [(prob.cfg, prob.F, int(bounds[i]), int(bounds[i + 1])) for i in range(cores) if bounds[i + 1] > bounds[i]]
+            jobs = [(prob.cfg, prob.F, int(bounds[i]), int(bounds[i + 1]), bool(prob.meta.get("imu_intrinsics", False))) for i in range(cores) if bounds[i + 1] > bounds[i]]
             best = []
             with mp.get_context("spawn").Pool(len(jobs)) as pool:
                 for _ in range(3):
@@ -583,6 +630,22 @@ def cpu_baseline(prob, opts, sample_features=500, reps=5):
                                           f"compression and EKF update of the 1-thread run ({serial:.3f} s)"}
     except Exception as e:  # the all-cores variant is a courtesy figure; never fail the bench line for it
         out["all_cores"] = {"error": repr(e)}
+    # The reference's OWN update-path sources (oracle/_ref/libov_ref.so: UpdaterMSCKF.cpp, UpdaterHelper.cpp, StateHelper.cpp, FeatureInitializer.cpp ...
+    # compiled where they lie) on the same sample, ONE update: kind "reference" in the letter — but against stand-in Eigen / Boost headers
+    # (oracle/ref/standin: an eager, untuned restatement), so its time says nothing about Eigen's and it is NOT the baseline; listed because it
+    # runs.  Never fails the line.
+    try:
+        from oracle import pyref
+        if pyref.available():
+            pyref.msckf_update(opts, capi.Views(sample.subset(np.arange(min(20, Fs)))))  # (loads the library)
+            t = time.perf_counter()
+            pyref.msckf_update(opts, v)
+            sec = time.perf_counter() - t
+            out["reference_sources_standin_eigen"] = {
+                "value": Fs / sec, "unit": "features/s", "cores": 1, "kind": "reference sources, stand-in Eigen (NOT a measurement of Eigen)",
+                "sample": f"the same {Fs} features, one update: {sec:.2f} s", "seconds_per_update": sec}
+    except Exception as e:  # noqa: BLE001
+        out["reference_sources_standin_eigen"] = {"error": repr(e)}
     return out
 
 

@@ -22,6 +22,12 @@ struct TrackStore {
 };
 
 // FeatureDatabase::update_feature for n observations of one frame: observation i goes to the end of track slot[i]
+// ovgpu_tracks_erase: the observation counts of the erased tracks' slots
+__global__ void __launch_bounds__(256) k_tracks_clear(int n, const int32_t *__restrict__ slots, int32_t *__restrict__ count) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) count[slots[i]] = 0;
+}
+
 __global__ void k_tracks_append(int n, double timestamp, const int32_t *__restrict__ slot, const int32_t *__restrict__ cam, const float *__restrict__ uv,
                                 const float *__restrict__ uvn, TrackStore ts, int32_t *overflow) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -29,6 +29,7 @@
 #include "k_gram.h"
 #include "k_gram32.h"
 #include <unordered_map>
+#include <unordered_set>
 #include <dlfcn.h>
 #include "k_system.h"
 #include "k_feat.h"

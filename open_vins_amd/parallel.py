@@ -56,27 +56,80 @@ class GpuShardBackend:
         return self.up.gram_update(tensor.data_ptr(), want_outputs=want_outputs)
 
 
+class ShardedUpdateError(RuntimeError):
+    """A stage of a sharded update failed on at least one rank.  Raised on EVERY rank with the same content (`codes[r]` = rank r's
+    ovgpu_status, 0 where the stage succeeded; -1 for an exception without a status): a failure that is local to one rank — a
+    follower workgroup of the single-launch Cholesky that was not co-scheduled (OVGPU_ERR_HIP: the library does not repeat locally
+    inside a collective update), an allocation, a track beyond a kernel's capacity — must not leave the ranks disagreeing about
+    whether the update happened, nor one of them waiting in a collective the others never enter."""
+
+    def __init__(self, stage, codes, messages):
+        self.stage, self.codes, self.messages = stage, list(codes), list(messages)
+        bad = ", ".join(f"rank {r}: status {c} ({m})" for r, (c, m) in enumerate(zip(self.codes, self.messages)) if c)
+        super().__init__(f"sharded update failed in its {stage} stage on {sum(1 for c in self.codes if c)} of {len(self.codes)} ranks — {bad}")
+
+
+def agree_on_status(dist, stage: str, error: BaseException | None):
+    """Collective: every rank reports the outcome of `stage` (error = the exception it caught, or None); returns normally when all
+    succeeded, raises the SAME ShardedUpdateError on every rank otherwise.  One all_gather_object of a (code, message) pair."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    mine = (0, "") if error is None else (int(getattr(error, "code", -1)) or -1, str(error)[:200])
+    if world == 1:
+        every = [mine]
+    else:
+        every = [None] * world
+        dist.all_gather_object(every, mine)
+    if any(c for c, _ in every):
+        raise ShardedUpdateError(stage, [c for c, _ in every], [m for _, m in every])
+
+
 def distributed_update(backend, dist, device, want_outputs=True):
     """One sharded update step.  `dist` is torch.distributed (already initialised; backend "nccl" = RCCL on
-    ROCm, "gloo" in the CPU tests); `device` the torch device of this rank's tensors."""
+    ROCm, "gloo" in the CPU tests); `device` the torch device of this rank's tensors.
+    A rank whose local stage fails still enters the exchange (with zeros) and every rank then raises the same ShardedUpdateError;
+    likewise after the update stage (agree_on_status)."""
     import torch
     world = dist.get_world_size()
     n = backend.triangle_len()
     ng = backend.gram_len() if hasattr(backend, "gram_len") else 0
+
+    def attempt(fn):
+        try:
+            return fn(), None
+        except Exception as e:  # noqa: BLE001
+            return None, e
+
     if ng > 0:
         gram = torch.empty(ng, dtype=torch.float64, device=device)
-        backend.local_gram_into(gram)  # synchronises the context's stream before returning
+        _, err = attempt(lambda: backend.local_gram_into(gram))  # synchronises the context's stream before returning
+        if err is not None:
+            gram.zero_()
         if world > 1:
             dist.all_reduce(gram, op=dist.ReduceOp.SUM)
             if gram.is_cuda:
                 torch.cuda.current_stream(device).synchronize()
-        return backend.gram_update_from(gram, want_outputs)
+            agree_on_status(dist, "local (per-feature + Gram)", err)
+        elif err is not None:
+            raise err
+        out, err = attempt(lambda: backend.gram_update_from(gram, want_outputs))
+        if world > 1:
+            agree_on_status(dist, "update", err)
+        elif err is not None:
+            raise err
+        return out
     mine = torch.empty(n, dtype=torch.float64, device=device)
-    backend.local_into(mine)  # synchronises the context's stream before returning
+    _, err = attempt(lambda: backend.local_into(mine))  # synchronises the context's stream before returning
     if world == 1:
+        if err is not None:
+            raise err
         return backend.merge_update_from(mine, 1, want_outputs)
+    if err is not None:
+        mine.zero_()
     gathered = torch.empty(n * world, dtype=torch.float64, device=device)
     dist.all_gather_into_tensor(gathered, mine)
     if gathered.is_cuda:
         torch.cuda.current_stream(device).synchronize()  # RCCL ran on torch's stream, the merge runs on ours
-    return backend.merge_update_from(gathered, world, want_outputs)
+    agree_on_status(dist, "local (per-feature + compression)", err)
+    out, err = attempt(lambda: backend.merge_update_from(gathered, world, want_outputs))
+    agree_on_status(dist, "merge + update", err)
+    return out

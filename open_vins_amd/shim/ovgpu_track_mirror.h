@@ -26,6 +26,7 @@
 #include <stdexcept>
 #include <string>
 #include <unordered_map>
+#include <iterator>
 #include <vector>
 
 #include "ovgpu.h"
@@ -79,7 +80,14 @@ public:
     close_frame();
     std::vector<Op> todo;
     todo.swap(log_); // (apply() never records)
-    for (const Op &op : todo) apply(op);
+    for (size_t i = 0; i < todo.size(); i++) {
+      try {
+        apply(todo[i]);
+      } catch (...) { // what the device has not taken stays recorded, in order: the mirror is replayed from here by the next sync()
+        log_.insert(log_.begin(), std::make_move_iterator(todo.begin() + (std::ptrdiff_t)i), std::make_move_iterator(todo.end()));
+        throw;
+      }
+    }
   }
   bool attached() const { return ctx_ != nullptr; }
 

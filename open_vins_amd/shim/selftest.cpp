@@ -216,7 +216,7 @@ static int time_dropin(int F, int reps, bool gpu = true, bool resident = false) 
     }
     std::vector<int32_t> status(F);
     std::vector<double> pG(3 * (size_t)F), dx(fs.N), P1((size_t)fs.N * fs.N);
-    std::vector<double> t_app, t_gat, t_upd;
+    std::vector<double> t_app, t_gat, t_upd, t_era;
     int used = 0;
     size_t n_last = 0;
     for (int it = 0; it < reps + 1; it++) {
@@ -241,15 +241,23 @@ static int time_dropin(int F, int reps, bool gpu = true, bool resident = false) 
       ovgpu_update_stats st;
       ctx.check(ovgpu_msckf_update(ctx.get(), status.data(), nullptr, nullptr, pG.data(), dx.data(), P1.data(), &st), "ovgpu_msckf_update");
       const double t3 = now_ms();
-      if (it >= 1) t_app.push_back(t1 - t0), t_gat.push_back(t2 - t1), t_upd.push_back(t3 - t2);
+      // what shim/UpdaterMSCKF.cpp (-DOVGPU_SHIM_RESIDENT_TRACKS) does around the call as well: the batch's offsets read back for its length
+      // check, and the tracks it was handed erased from the store (FeatureDatabase semantics: an update consumes its features)
+      int32_t Fd = 0, Md = 0;
+      std::vector<int32_t> offs((size_t)F + 1);
+      ctx.check(ovgpu_get_features(ctx.get(), &Fd, &Md, offs.data(), nullptr, nullptr, nullptr, nullptr), "ovgpu_get_features");
+      ctx.check(ovgpu_tracks_erase(ctx.get(), F, ids.data()), "ovgpu_tracks_erase");
+      const double t4 = now_ms();
+      if (it >= 1) t_app.push_back(t1 - t0), t_gat.push_back(t2 - t1), t_upd.push_back(t3 - t2), t_era.push_back(t4 - t3);
       used = 0;
       for (int f = 0; f < F; f++) used += status[f] == OVGPU_FEAT_USED;
     }
-    const double a = median(t_app), g = median(t_gat), u = median(t_upd);
-    std::printf("{\"what\": \"resident path from C++: tracks and state on the device, per update the newest frame's observations in, dx / P' out\", "
+    const double a = median(t_app), g = median(t_gat), u = median(t_upd), e = median(t_era);
+    std::printf("{\"what\": \"resident path from C++: tracks and state on the device, per update the newest frame's observations in, dx / P' out, "
+                "the batch's length check and the erasure of its tracks included\", "
                 "\"features\": %d, \"observations_newest_frame\": %zu, \"features_used\": %d, \"reps\": %d, \"append_ms\": %.4f, "
-                "\"tracks_to_features_ms\": %.4f, \"mode_b_call_ms\": %.4f, \"resident_mode_b_ms\": %.4f}\n",
-                F, n_last, used, reps, a, g, u, a + g + u);
+                "\"tracks_to_features_ms\": %.4f, \"mode_b_call_ms\": %.4f, \"length_check_and_erase_ms\": %.4f, \"resident_mode_b_ms\": %.4f}\n",
+                F, n_last, used, reps, a, g, u, e, a + g + u + e);
     return used > F / 2 ? 0 : 1;
   }
   if (!gpu) { // `--time-host`: the flattening alone (no device needed)

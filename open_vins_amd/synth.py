@@ -445,7 +445,7 @@ def make_problem(cfg=2, rep=0, *, C=None, K=None, F=None, track="full", fisheye=
         uv=np.asarray(uv_l, dtype=np.float32).reshape(-1), uvn=np.asarray(uvn_l, dtype=np.float32).reshape(-1),
         clone_idx=np.asarray(cl_l, dtype=np.int32), cam_idx=np.asarray(cam_l, dtype=np.int32),
         p_FinG_true=np.asarray(pf_l, dtype=np.float64).reshape(-1, 3),
-        meta=dict(track=track, fisheye=bool(fisheye), min_obs=min_obs),
+        meta=dict(track=track, fisheye=bool(fisheye), min_obs=min_obs, imu_intrinsics=bool(imu_intrinsics)),
     )
 
 

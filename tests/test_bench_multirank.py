@@ -29,6 +29,12 @@ def test_two_rank_bench_runs_end_to_end_over_gloo():
     assert len(d["per_rank_ms_per_step"]) == 2 and all(t > 0 for t in d["per_rank_ms_per_step"])
     assert max(d["per_rank_ms_per_step"]) <= d["ms_per_step_timed_loops"][-1] * 1.0001  # the line's time is the max over ranks
     assert d["predicted_ms"] > 0 and "weak" in d and d["weak"]["features_total"] == 12
+    # the preflight: on stderr before anything is timed, and in the line
+    pre = [l for l in p.stderr.splitlines() if l.startswith("[bench preflight] ")]
+    assert len(pre) == 1
+    pf = json.loads(pre[0][len("[bench preflight] "):])
+    assert [r["rank"] for r in pf["ranks"]] == [0, 1] and all(r["local_ms_per_step"] > 0 and r["features_this_rank"] == 7 for r in pf["ranks"])
+    assert pf["predicted_ms"] > 0 and d["preflight"]["predicted_ms"] == pf["predicted_ms"]
     assert d["config"]["features_total"] == 14 and d["config"]["features_this_rank"] == 7
     assert "feature-shard x2" in d["config"]["parallelism"]
     assert d["vs_baseline"] is None and d["metric"].startswith("MSCKF features/sec")

@@ -253,8 +253,6 @@ def test_resident_track_mode_refuses_to_update_from_a_store_that_missed_a_frame(
 
 
 @pytest.mark.gpu
-@pytest.mark.xfail(strict=False, reason="written after the round's GPU budget was spent: its first run on hardware is the driver's round-end suite "
-                                        "(a failure here is a finding about the shims in the real tree, not about the library)")
 @pytest.mark.parametrize("mode", ["a", "b", "r"])
 def test_dropin_library_equals_the_reference_updaters_on_the_gpu(dropin_libs, mode):
     if not os.path.exists(pyref.dropin_path(mode)):
@@ -263,7 +261,6 @@ def test_dropin_library_equals_the_reference_updaters_on_the_gpu(dropin_libs, mo
 
 
 @pytest.mark.gpu
-@pytest.mark.xfail(strict=False, reason="written after the round's GPU budget was spent: its first run on hardware is the driver's round-end suite")
 @pytest.mark.parametrize("mode", ["a", "b"])
 def test_dropin_library_on_every_seeded_shape_of_the_parity_suite_on_the_gpu(dropin_libs, mode):
     """The same sweep (40 MSCKF updates, 12 SLAM updates, 12 delayed-initialisation chains) through the drop-in library linked against libovgpu."""

@@ -899,8 +899,6 @@ def test_delayed_init_parity(Updater, oracle, rep):
     up.close()
 
 
-@pytest.mark.xfail(strict=False, reason="written with the round's GPU minutes spent (the last 12 s of them found the defect through the in-tree drop-in build): "
-                                        "first run on hardware is the driver's round-end suite")
 def test_triangulation_stays_readable_after_delayed_init(Updater, oracle):
     """include/ovgpu.h: ovgpu_get_triangulation reads what the triangulation stage of the LAST pipeline call left — ovgpu_slam_delayed_init included
     (the drop-in's UpdaterSLAM::delayed_init writes the Feature side effects from it).  The delayed initialisation rebuilds the column map, which

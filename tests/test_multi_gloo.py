@@ -139,3 +139,68 @@ def test_two_rank_sharded_update_matches_single_process(oracle, gram):
     ref = oracle.msckf_update(capi.default_options(chi2_multipler=1.0), capi.Views(prob))
     assert np.linalg.norm(res[0][1] - ref["P"]) / np.linalg.norm(ref["P"]) < 1e-10
     assert np.linalg.norm(res[0][2] - ref["dx"]) / np.linalg.norm(ref["dx"]) < 1e-9
+
+
+def _failing_worker(rank, world, port, q, stage, gram):
+    """Rank 1's backend fails in `stage` the way a rank of a real run does (capi.OvgpuError with a status); rank 0 succeeds."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    from open_vins_amd import capi, parallel, synth
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    prob = synth.make_problem(2, F=24, C=10)
+    opts = capi.default_options(chi2_multipler=1.0)
+    ids = parallel.shard_features(prob.meas_offsets, rank, world)
+    base = OracleGramBackend if gram else OracleShardBackend
+
+    class Failing(base):
+        def _maybe_fail(self, what):
+            if rank == 1 and what == stage:
+                raise capi.OvgpuError(capi.ERR_HIP, "single-launch Cholesky: a follower workgroup timed out (injected)")
+
+        def local_gram_into(self, tensor):
+            self._maybe_fail("local")
+            return super().local_gram_into(tensor)
+
+        def local_into(self, tensor):
+            self._maybe_fail("local")
+            return super().local_into(tensor)
+
+        def gram_update_from(self, tensor, want_outputs=True):
+            self._maybe_fail("update")
+            return super().gram_update_from(tensor, want_outputs)
+
+        def merge_update_from(self, tensor, G, want_outputs=True):
+            self._maybe_fail("update")
+            return super().merge_update_from(tensor, G, want_outputs)
+
+    try:
+        parallel.distributed_update(Failing(prob, opts, ids), dist, torch.device("cpu"))
+        q.put((rank, "no error", None, None))
+    except parallel.ShardedUpdateError as e:
+        q.put((rank, "ShardedUpdateError", e.codes, str(e)))
+    dist.barrier()  # both ranks are still in step: nobody is left behind in a collective
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("stage", ["local", "update"])
+@pytest.mark.parametrize("gram", [False, True])
+def test_a_failure_on_one_rank_is_raised_identically_on_every_rank(stage, gram):
+    """parallel.agree_on_status: a rank-local failure (the sharded path's follower time-out is returned, never repeated locally) reaches every
+    rank as the same ShardedUpdateError — same codes, same text — and no rank hangs in a collective the other never enters."""
+    from open_vins_amd import capi
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_failing_worker, args=(r, world, port, q, stage, gram)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [r[1] for r in res] == ["ShardedUpdateError", "ShardedUpdateError"]
+    assert res[0][2] == res[1][2] == [0, capi.ERR_HIP]
+    assert res[0][3] == res[1][3] and "rank 1" in res[0][3] and "timed out" in res[0][3]
