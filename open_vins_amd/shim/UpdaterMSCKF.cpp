@@ -18,10 +18,40 @@
 #ifdef OVGPU_SHIM_RESIDENT_TRACKS
 #include "ovgpu_track_mirror.h" // opt-in: the observations live in the library's track store, an update names its tracks
 #endif
+#ifdef OVGPU_SHIM_RESIDENT_COV
+#ifndef OVGPU_SHIM_MODE_B
+#error "OVGPU_SHIM_RESIDENT_COV needs OVGPU_SHIM_MODE_B: the device applies the update to the covariance it holds"
+#endif
+#include "ovgpu_resident_cov.h" // opt-in: the covariance lives in the library's context between frames (with shim/StateHelper_resident.cpp)
+#endif
 
 using namespace ov_core;
 using namespace ov_type;
 using namespace ov_msckf;
+
+#ifdef OVGPU_SHIM_TIMING
+// test builds: where one update's host time goes (tests/dropin_probe.py `time` reads the sums through ovgpu_shim_update_laps)
+#include <chrono>
+static double g_laps[9];
+extern "C" void ovgpu_shim_update_laps(double *out9, int reset) {
+  for (int i = 0; i < 9; i++) out9[i] = g_laps[i], g_laps[i] = reset ? 0.0 : g_laps[i];
+}
+struct Lap {
+  std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+  void operator()(int i) {
+    const auto n = std::chrono::steady_clock::now();
+    g_laps[i] += std::chrono::duration<double, std::milli>(n - t).count(), t = n;
+  }
+};
+#define OVGPU_LAP(i) lap(i)
+#else
+#define OVGPU_LAP(i) (void)0
+#endif
+
+#ifdef OVGPU_SHIM_RESIDENT_VERIFY
+static int g_resident_verify = 1;
+extern "C" void ovgpu_shim_resident_verify(int on) { g_resident_verify = on; } // (test builds only: tests/dropin_probe.py `time` measures without the check)
+#endif
 
 UpdaterMSCKF::UpdaterMSCKF(UpdaterOptions &options, FeatureInitializerOptions &feat_init_options) : _options(options) {
   _options.sigma_pix_sq = std::pow(_options.sigma_pix, 2);
@@ -31,8 +61,17 @@ UpdaterMSCKF::UpdaterMSCKF(UpdaterOptions &options, FeatureInitializerOptions &f
 
 void UpdaterMSCKF::update(std::shared_ptr<State> state, std::vector<std::shared_ptr<Feature>> &feature_vec) {
   if (feature_vec.empty()) return; // UpdaterMSCKF.cpp:61-62
+#ifdef OVGPU_SHIM_TIMING
+  Lap lap;
+  g_laps[8] += 1.0;
+#endif
+#ifdef OVGPU_SHIM_RESIDENT_COV
+  const ovgpu_shim::StateSnapshot snap(state, /*with_cov=*/false); // values, ids, order: the covariance is (or will be, below) on the device
+#else
   const ovgpu_shim::StateSnapshot snap(state);
+#endif
   const ovgpu_shim::CloneIndex clones(snap.fs.clone_times);
+  OVGPU_LAP(0); // snapshot
 
   // ---- 1. clean + flatten the tracks (UpdaterMSCKF.cpp:71-93)
 #ifdef OVGPU_SHIM_RESIDENT_TRACKS
@@ -58,25 +97,27 @@ void UpdaterMSCKF::update(std::shared_ptr<State> state, std::vector<std::shared_
   }
 #else
   static thread_local ovgpu_shim::FlatFeatures ff; // reused from update to update: a fresh 3.5 MB of buffers per call costs more in page faults than the flattening itself
-  ff.clear();
-  for (auto it = feature_vec.begin(); it != feature_vec.end();) {
-    if (ovgpu_shim::flatten_track(**it, snap, clones, ff) < 2) {
-      (*it)->to_delete = true;
-      it = feature_vec.erase(it);
-      continue;
-    }
-    ovgpu_shim::append_track(**it, snap, clones, ff);
-    ++it;
-  }
+  ovgpu_shim::clean_flatten_batch(feature_vec, snap, clones, ff, 2); // :84-92: a track with fewer than two observations in the window is flagged and dropped
   if (feature_vec.empty()) return;
 #endif
 
+  OVGPU_LAP(1); // clean + flatten
   // ---- 2..5 on the GPU: triangulate, Jacobians, nullspace, chi2 gate, stack, compress (options re-read on every call)
   LandmarkRepresentation::Representation rep = state->_options.feat_rep_msckf; // :180-183: the single depth maps to the MSCKF inverse depth
   if (rep == LandmarkRepresentation::Representation::ANCHORED_INVERSE_DEPTH_SINGLE) rep = LandmarkRepresentation::Representation::ANCHORED_MSCKF_INVERSE_DEPTH;
   ovgpu_shim::Context &ctx = ovgpu_shim::context_for(ovgpu_shim::make_options(_options, initializer_feat->config(), state->_options, (int)rep));
   const ovgpu_state_view sv = snap.fs.view();
+#ifdef OVGPU_SHIM_RESIDENT_COV
+  // the state is resident: uploaded once (and again after anything on the host wrote the covariance: another updater's host path,
+  // an initialisation), kept current by StateHelper's device-side wrappers in between
+  ovgpu_shim::ResidentCov &rcov = ovgpu_shim::ResidentCov::instance();
+  rcov.bind(state.get());
+  rcov.attach(ctx);
+  rcov.ensure_device(state);
+#else
   ctx.check(ovgpu_set_state(ctx.get(), &sv), "ovgpu_set_state");
+#endif
+  OVGPU_LAP(2); // state hand-over
 #ifdef OVGPU_SHIM_RESIDENT_TRACKS
   mirror.attach(ctx.get(), snap.cam_index); // (first update: creates the store, replays the frames recorded so far)
   mirror.sync();
@@ -90,7 +131,8 @@ void UpdaterMSCKF::update(std::shared_ptr<State> state, std::vector<std::shared_
       throw std::runtime_error("ovgpu: the resident track store is out of step with the FeatureDatabase (a TrackMirror call is missing: ovgpu_track_mirror.h)");
 #ifdef OVGPU_SHIM_RESIDENT_VERIFY
     // test builds: the WHOLE device-assembled batch against the host's flattening, observation by observation (camera, clone, pixels) — the
-    // lengths above cannot see an order mistake inside a track
+    // lengths above cannot see an order mistake inside a track (switched off by the timing probe: ovgpu_shim_resident_verify)
+    if (g_resident_verify) {
     ovgpu_shim::FlatFeatures host;
     for (auto &ft : feature_vec) ovgpu_shim::append_track(*ft, snap, clones, host);
     std::vector<int32_t> dci((size_t)Md + 1), dcam((size_t)Md + 1);
@@ -101,6 +143,7 @@ void UpdaterMSCKF::update(std::shared_ptr<State> state, std::vector<std::shared_
       same = dci[i] == host.clone_idx[i] && dcam[i] == host.cam_idx[i] && duv[2 * i] == host.uv[2 * i] && duv[2 * i + 1] == host.uv[2 * i + 1] &&
              duvn[2 * i] == host.uvn[2 * i] && duvn[2 * i + 1] == host.uvn[2 * i + 1];
     if (!same) throw std::runtime_error("ovgpu: the device-assembled batch differs from the host's flattening (OVGPU_SHIM_RESIDENT_VERIFY)");
+    }
 #endif
   }
 #else
@@ -108,6 +151,7 @@ void UpdaterMSCKF::update(std::shared_ptr<State> state, std::vector<std::shared_
   ctx.check(ovgpu_set_features(ctx.get(), &fv), "ovgpu_set_features");
   const int F = fv.F;
 #endif
+  OVGPU_LAP(3); // track hand-over
   std::vector<int32_t> status(F), anchor(F);
   std::vector<double> pA(3 * (size_t)F), pG(3 * (size_t)F);
   int32_t rows = 0;
@@ -115,8 +159,14 @@ void UpdaterMSCKF::update(std::shared_ptr<State> state, std::vector<std::shared_
 #ifdef OVGPU_SHIM_MODE_B
   // the device applies the update itself (Gram matrix of the prior-whitened stack on the matrix cores); p_FinA / the anchors
   // are read back from the same triangulation afterwards
+#ifdef OVGPU_SHIM_RESIDENT_COV
+  std::vector<double> dx_dev((size_t)sv.N);
+  ctx.check(ovgpu_msckf_update(ctx.get(), status.data(), nullptr, nullptr, pG.data(), dx_dev.data(), nullptr, &stats), "ovgpu_msckf_update"); // P' stays where it is
+#else
   std::vector<double> dx_dev((size_t)sv.N), P_dev((size_t)sv.N * sv.N);
   ctx.check(ovgpu_msckf_update(ctx.get(), status.data(), nullptr, nullptr, pG.data(), dx_dev.data(), P_dev.data(), &stats), "ovgpu_msckf_update");
+#endif
+  OVGPU_LAP(4); // the call
   ctx.check(ovgpu_get_triangulation(ctx.get(), pA.data(), nullptr, anchor.data()), "ovgpu_get_triangulation");
   rows = stats.n_rows;
 #else
@@ -129,25 +179,35 @@ void UpdaterMSCKF::update(std::shared_ptr<State> state, std::vector<std::shared_
   ctx.check(ovgpu_get_triangulation(ctx.get(), pA.data(), nullptr, anchor.data()), "ovgpu_get_triangulation"); // ONE triangulation serves both
 #endif
 
+  OVGPU_LAP(5); // triangulation read-back
   // ---- side effects on the features: triangulation results, erase the rejected, flag the used
-  size_t f = 0;
-  for (auto it = feature_vec.begin(); it != feature_vec.end(); f++) {
+  size_t used = 0; // (one pass: the accepted tracks move up, in order — erasing the rejected one by one is quadratic in the batch)
+  for (size_t f = 0; f < feature_vec.size(); f++) {
+    std::shared_ptr<Feature> &ft = feature_vec[f];
+    if (f + 4 < feature_vec.size()) __builtin_prefetch(feature_vec[f + 4].get(), 1);
 #ifdef OVGPU_SHIM_RESIDENT_TRACKS
-    ovgpu_shim::write_triangulation_nth(**it, anchor[f] < 0 ? -1 : anchor[f] - offs[f], &pA[3 * f], &pG[3 * f]);
+    ovgpu_shim::write_triangulation_nth(*ft, anchor[f] < 0 ? -1 : anchor[f] - offs[f], &pA[3 * f], &pG[3 * f]);
 #else
-    ovgpu_shim::write_triangulation(**it, snap, ff, anchor[f], &pA[3 * f], &pG[3 * f]);
+    ovgpu_shim::write_triangulation(*ft, snap, ff, anchor[f], &pA[3 * f], &pG[3 * f]);
 #endif
-    (*it)->to_delete = true; // :137, :226, :262 — every feature that reached this point is flagged
-    if (status[f] != OVGPU_FEAT_USED) it = feature_vec.erase(it);
-    else ++it;
+    ft->to_delete = true; // :137, :226, :262 — every feature that reached this point is flagged
+    if (status[f] != OVGPU_FEAT_USED) continue;
+    if (used != f) feature_vec[used] = std::move(ft);
+    used++;
   }
+  feature_vec.resize(used);
 #ifdef OVGPU_SHIM_RESIDENT_TRACKS
   mirror.erase(seen_ids); // every track of this update is flagged to_delete: FeatureDatabase::cleanup() drops them (VioManager.cpp:579)
 #endif
+  OVGPU_LAP(6); // side effects on the tracks
   if (rows < 1) return; // :266-268 / :276-278
-#ifdef OVGPU_SHIM_MODE_B
+#if defined(OVGPU_SHIM_RESIDENT_COV)
+  ovgpu_shim::StateAccess::apply_dx(*state, dx_dev.data(), sv.N); // StateHelper.cpp:185-196: the values follow on the host, the covariance was updated in place
+  rcov.device_written();
+#elif defined(OVGPU_SHIM_MODE_B)
   ovgpu_shim::StateAccess::apply_update(*state, P_dev.data(), dx_dev.data(), sv.N); // StateHelper.cpp:166-196
 #else
   ovgpu_shim::ekf_update_with(state, snap.var_of_cov, col_cov.data(), D, rows, H.data(), r.data(), _options.sigma_pix_sq); // :280-285
 #endif
+  OVGPU_LAP(7); // state write-back
 }

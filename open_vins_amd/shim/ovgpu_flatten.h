@@ -11,13 +11,19 @@
 #pragma once
 #include <algorithm>
 #include <climits>
+#include <condition_variable>
 #include <cstddef>
 #include <cstdint>
 #include <cstdlib>
+#include <exception>
+#include <cstring>
+#include <functional>
 #include <initializer_list>
+#include <mutex>
 #include <new>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -81,6 +87,10 @@ public:
   void commit(size_t k) { n_ += k; }
   void clear() { n_ = 0; } // keeps the allocation: a buffer reused from update to update touches no fresh pages
   void push_back(const T &v) { *room(1) = v, n_++; }
+  void truncate(size_t n) { n_ = std::min(n_, n); }
+  void append(const T *src, size_t k) {
+    if (k) std::memcpy(room(k), src, k * sizeof(T)), n_ += k;
+  }
   size_t size() const { return n_; }
   const T *data() const { return p_; }
   const T &operator[](size_t i) const { return p_[i]; }
@@ -121,6 +131,50 @@ struct FlatFeatures {
     uv.commit(2 * kept), uvn.commit(2 * kept), clone_idx.commit(kept), cam_idx.commit(kept), meas_time.commit(kept);
     return (int)kept;
   }
+  // The same with Feature::clean_old_measurements (Feature.cpp:26-53) folded in: `drop(i, w)` is called for the observations the
+  // reference would erase — once per camera with the first dropped index i == w to start, then `keep(i, w)` for every later kept
+  // observation i that moves to position w, and `cut(w)` with the final length — so the containers end as the reference leaves them
+  // while every timestamp is looked at once (the reference: a std::find over the clone times and three hash look-ups per observation).
+  // `ahead(i)` is called a few observations early: the reference keeps every observation's two floats in a heap block of their own, the
+  // walk is a chain of cache misses unless they are requested before they are needed.
+  template <class GetUV, class GetUVN, class Keep, class Cut, class Ahead>
+  int add_camera_cleaning(int cam, std::vector<double> &times, GetUV get_uv, GetUVN get_uvn, Keep keep, Cut cut, Ahead ahead, const CloneIndex &clones) {
+    const size_t n = times.size();
+    for (size_t i = 0; i < std::min<size_t>(n, 8); i++) ahead(i);
+    float *puv = uv.room(2 * n), *pun = uvn.room(2 * n);
+    int32_t *pc = clone_idx.room(n), *pk = cam_idx.room(n);
+    double *pt = meas_time.room(n);
+    size_t kept = 0, cursor = 0;
+    for (size_t i = 0; i < n; i++) {
+      const double t = times[i];
+      if (i + 8 < n) ahead(i + 8);
+      const int32_t ci = clones.find_next(t, cursor);
+      if (ci < 0) continue;
+      get_uv(i, puv[2 * kept], puv[2 * kept + 1]);
+      get_uvn(i, pun[2 * kept], pun[2 * kept + 1]);
+      pc[kept] = ci, pk[kept] = cam, pt[kept] = t;
+      if (kept != i) times[kept] = t, keep(i, kept);
+      kept++;
+    }
+    if (kept != n) times.resize(kept), cut(kept);
+    uv.commit(2 * kept), uvn.commit(2 * kept), clone_idx.commit(kept), cam_idx.commit(kept), meas_time.commit(kept);
+    return (int)kept;
+  }
+  // forget the observations added since the last end_feature() (a track that turned out too short)
+  void drop_open_feature() {
+    const size_t m = (size_t)meas_offsets[meas_offsets.size() - 1];
+    uv.truncate(2 * m), uvn.truncate(2 * m), clone_idx.truncate(m), cam_idx.truncate(m), meas_time.truncate(m);
+  }
+  // the features of `o` behind this batch's (the parts of a batch flattened by several threads)
+  void append_batch(const FlatFeatures &o) {
+    const int32_t base = M();
+    int32_t *po = meas_offsets.room((size_t)o.F());
+    for (int32_t f = 0; f < o.F(); f++) po[f] = base + o.meas_offsets[(size_t)f + 1];
+    meas_offsets.commit((size_t)o.F());
+    uv.append(o.uv.data(), o.uv.size()), uvn.append(o.uvn.data(), o.uvn.size());
+    clone_idx.append(o.clone_idx.data(), o.clone_idx.size()), cam_idx.append(o.cam_idx.data(), o.cam_idx.size());
+    meas_time.append(o.meas_time.data(), o.meas_time.size());
+  }
   // capacity for F features and M observations up front (the buffers double on demand without it)
   void reserve(size_t F, size_t M) {
     meas_offsets.reserve(F + 1);
@@ -140,6 +194,77 @@ struct FlatFeatures {
     v.clone_idx = clone_idx.data(), v.cam_idx = cam_idx.data();
     return v;
   }
+};
+
+// A few persistent helper threads for the one loop of the drop-in that walks the reference's per-observation heap objects (at 2 000
+// tracks of a running filter that walk is most of the update's host time, and it is cache misses, not arithmetic).  run(n, fn) calls
+// fn(part) for part = 0..n-1, part 0 on the calling thread, and returns when all are done; an exception of any part is rethrown.
+class ForkJoin {
+public:
+  explicit ForkJoin(int helpers) {
+    for (int i = 0; i < helpers; i++) threads_.emplace_back([this, i] { loop(i + 1); });
+  }
+  ~ForkJoin() {
+    {
+      std::lock_guard<std::mutex> g(m_);
+      stop_ = true, epoch_++;
+    }
+    wake_.notify_all();
+    for (auto &t : threads_) t.join();
+  }
+  int parts() const { return (int)threads_.size() + 1; }
+  void run(int n, const std::function<void(int)> &fn) {
+    n = std::min(n, parts());
+    {
+      std::lock_guard<std::mutex> g(m_);
+      fn_ = &fn, n_ = n, pending_ = n - 1, error_ = nullptr, epoch_++;
+    }
+    if (n > 1) wake_.notify_all();
+    std::exception_ptr mine;
+    try {
+      fn(0);
+    } catch (...) {
+      mine = std::current_exception();
+    }
+    std::unique_lock<std::mutex> g(m_);
+    done_.wait(g, [this] { return pending_ == 0; });
+    fn_ = nullptr;
+    if (mine) std::rethrow_exception(mine);
+    if (error_) std::rethrow_exception(error_);
+  }
+
+private:
+  void loop(int part) {
+    unsigned long seen = 0;
+    for (;;) {
+      const std::function<void(int)> *fn = nullptr;
+      {
+        std::unique_lock<std::mutex> g(m_);
+        wake_.wait(g, [&] { return epoch_ != seen; });
+        seen = epoch_;
+        if (stop_) return;
+        if (part < n_) fn = fn_;
+      }
+      if (!fn) continue;
+      std::exception_ptr err;
+      try {
+        (*fn)(part);
+      } catch (...) {
+        err = std::current_exception();
+      }
+      std::lock_guard<std::mutex> g(m_);
+      if (err && !error_) error_ = err;
+      if (--pending_ == 0) done_.notify_one();
+    }
+  }
+  std::vector<std::thread> threads_;
+  std::mutex m_;
+  std::condition_variable wake_, done_;
+  const std::function<void(int)> *fn_ = nullptr;
+  int n_ = 0, pending_ = 0;
+  unsigned long epoch_ = 0;
+  bool stop_ = false;
+  std::exception_ptr error_;
 };
 
 struct FlatState {

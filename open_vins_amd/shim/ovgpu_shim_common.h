@@ -63,7 +63,9 @@ struct StateSnapshot {
   std::vector<std::shared_ptr<ov_type::PoseJPL>> clone_vars; // clone index -> variable
   std::vector<std::shared_ptr<ov_type::Type>> var_of_cov;    // every variable that can own Jacobian columns
 
-  explicit StateSnapshot(const std::shared_ptr<ov_msckf::State> &state) {
+  // with_cov = false: values, ids and order only (the resident-covariance mode: P is on the device already);
+  // through_helper = false: State::_Cov read directly (from inside StateHelper's own wrappers, ovgpu_resident_cov.h)
+  explicit StateSnapshot(const std::shared_ptr<ov_msckf::State> &state, bool with_cov = true, bool through_helper = true) {
     for (const auto &c : state->_clones_IMU) {
       const Eigen::Vector4d q = c.second->quat(), qf = c.second->quat_fej();
       const Eigen::Vector3d p = c.second->pos(), pf = c.second->pos_fej();
@@ -84,27 +86,93 @@ struct StateSnapshot {
                     state->_options.do_calib_camera_intrinsics ? state->_cam_intrinsics.at(id)->id() : -1);
       var_of_cov.push_back(pose), var_of_cov.push_back(state->_cam_intrinsics.at(id));
     }
-    const Eigen::MatrixXd P = ov_msckf::StateHelper::get_full_covariance(state); // symmetric: column-major == row-major
-    fs.N = (int32_t)P.rows();
-    fs.P.assign(P.data(), P.data() + P.size());
+    fs.N = (int32_t)state->max_covariance_size();
+    if (with_cov) {
+      const Eigen::MatrixXd P = through_helper ? ov_msckf::StateHelper::get_full_covariance(state) : snapshot_cov_direct(*state); // symmetric: column-major == row-major
+      fs.N = (int32_t)P.rows();
+      fs.P.assign(P.data(), P.data() + P.size());
+    }
   }
+  static Eigen::MatrixXd snapshot_cov_direct(ov_msckf::State &s);
 };
 
-// Feature::clean_old_measurements + flattening of one track; returns its number of measurements inside the window
+// Feature::clean_old_measurements (the containers end exactly as Feature.cpp:26-53 leaves them: observations outside the window erased,
+// order kept, emptied cameras still present) and the flattening of what is left, in ONE walk over the track; returns the number of
+// observations inside the window.  The track is appended to `ff` when it has at least `min_meas` of them, otherwise `ff` is unchanged.
+inline int clean_append_track(ov_core::Feature &f, const StateSnapshot &snap, const CloneIndex &clones, FlatFeatures &ff, int min_meas = 0) {
+  int total = 0;
+  for (auto &pair : f.timestamps) { // iteration order of Feature::timestamps: the anchor rule depends on it
+    auto &uvs = f.uvs.at(pair.first);
+    auto &uvn = f.uvs_norm.at(pair.first);
+    total += ff.add_camera_cleaning(
+        snap.cam_index.at(pair.first), pair.second, [&](size_t i, float &a, float &b) { a = uvs[i](0), b = uvs[i](1); },
+        [&](size_t i, float &a, float &b) { a = uvn[i](0), b = uvn[i](1); }, [&](size_t i, size_t w) { uvs[w] = std::move(uvs[i]), uvn[w] = std::move(uvn[i]); },
+        [&](size_t w) { uvs.resize(w), uvn.resize(w); }, [&](size_t i) { __builtin_prefetch(&uvs[i](0)), __builtin_prefetch(&uvn[i](0)); }, clones);
+  }
+  if (total < min_meas) ff.drop_open_feature();
+  else ff.end_feature();
+  return total;
+}
+// the cleaning alone (the resident-track mode copies nothing out of the Feature objects)
 inline int clean_track(ov_core::Feature &f, const StateSnapshot &snap) {
   f.clean_old_measurements(snap.fs.clone_times);
   int total = 0;
   for (const auto &pair : f.timestamps) total += (int)pair.second.size();
   return total;
 }
-inline int flatten_track(ov_core::Feature &f, const StateSnapshot &snap, const CloneIndex &clones, FlatFeatures &ff) { return clean_track(f, snap); }
+inline int flatten_track(ov_core::Feature &f, const StateSnapshot &snap, const CloneIndex &, FlatFeatures &) { return clean_track(f, snap); } // (the SLAM units: clean, decide, then append_track)
+// the flattening alone, of a track that is clean already
 inline void append_track(const ov_core::Feature &f, const StateSnapshot &snap, const CloneIndex &clones, FlatFeatures &ff) {
-  for (const auto &pair : f.timestamps) { // iteration order of Feature::timestamps: the anchor rule depends on it
+  for (const auto &pair : f.timestamps) {
     const auto &uvs = f.uvs.at(pair.first), &uvn = f.uvs_norm.at(pair.first);
     ff.add_camera(snap.cam_index.at(pair.first), pair.second, [&](size_t i, float &a, float &b) { a = uvs[i](0), b = uvs[i](1); },
                   [&](size_t i, float &a, float &b) { a = uvn[i](0), b = uvn[i](1); }, clones);
   }
   ff.end_feature();
+}
+
+// A whole batch: clean + flatten every track of `feature_vec` into `ff` (cleared first); tracks with fewer than `min_meas` observations
+// inside the window are flagged to_delete and leave the vector (UpdaterMSCKF.cpp:84-92), the others keep their order.  Above a few hundred
+// tracks the walk is split over OVGPU_SHIM_FLATTEN_THREADS threads (contiguous ranges of the vector, each into its own buffers, joined in
+// order: the batch is the same whatever the count); -DOVGPU_SHIM_FLATTEN_THREADS=1 keeps it on the caller's thread.
+#ifndef OVGPU_SHIM_FLATTEN_THREADS
+#define OVGPU_SHIM_FLATTEN_THREADS 4
+#endif
+inline void clean_flatten_batch(std::vector<std::shared_ptr<ov_core::Feature>> &feature_vec, const StateSnapshot &snap, const CloneIndex &clones, FlatFeatures &ff,
+                                int min_meas) {
+  ff.clear();
+  const size_t n = feature_vec.size();
+  std::vector<uint8_t> keep(n);
+  const int parts = (OVGPU_SHIM_FLATTEN_THREADS > 1 && n >= 256) ? OVGPU_SHIM_FLATTEN_THREADS : 1;
+  if (parts == 1) {
+    for (size_t i = 0; i < n; i++) {
+      if (i + 2 < n) __builtin_prefetch(feature_vec[i + 2].get());
+      keep[i] = clean_append_track(*feature_vec[i], snap, clones, ff, min_meas) >= min_meas;
+    }
+  } else {
+    static ForkJoin pool(OVGPU_SHIM_FLATTEN_THREADS - 1);
+    static std::vector<FlatFeatures> part_ff(OVGPU_SHIM_FLATTEN_THREADS); // reused from update to update, like `ff`
+    const std::function<void(int)> work = [&](int p) {
+      FlatFeatures &mine = part_ff[(size_t)p];
+      mine.clear();
+      for (size_t i = n * (size_t)p / (size_t)parts, e = n * ((size_t)p + 1) / (size_t)parts; i < e; i++) {
+        if (i + 2 < e) __builtin_prefetch(feature_vec[i + 2].get());
+        keep[i] = clean_append_track(*feature_vec[i], snap, clones, mine, min_meas) >= min_meas;
+      }
+    };
+    pool.run(parts, work);
+    for (int p = 0; p < parts; p++) ff.append_batch(part_ff[(size_t)p]);
+  }
+  size_t w = 0;
+  for (size_t i = 0; i < n; i++) {
+    if (!keep[i]) {
+      feature_vec[i]->to_delete = true;
+      continue;
+    }
+    if (w != i) feature_vec[w] = std::move(feature_vec[i]);
+    w++;
+  }
+  feature_vec.resize(w);
 }
 
 // FeatureInitializer's side effects on a Feature (FeatureInitializer.cpp:45-46, :109-110, :333-335, :373) from the device's outputs
@@ -181,5 +249,10 @@ struct FlatLandmarks {
     return lv;
   }
 };
+
+#ifndef OVGPU_SHIM_RESIDENT_COV
+// (only the resident-covariance build reads State::_Cov without going through StateHelper: ovgpu_resident_cov.h)
+inline Eigen::MatrixXd StateSnapshot::snapshot_cov_direct(ov_msckf::State &) { throw std::logic_error("ovgpu: StateSnapshot(through_helper = false) outside the resident-covariance build"); }
+#endif
 
 } // namespace ovgpu_shim

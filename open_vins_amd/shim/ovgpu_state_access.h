@@ -17,15 +17,30 @@
 
 namespace ovgpu_shim {
 struct StateAccess {
-  static Eigen::MatrixXd &cov(ov_msckf::State &s) { return s._Cov; }
+  // State::_Cov for an updater's write-back (the resident-covariance build is told: the device's copy is stale from here on) ...
+  static Eigen::MatrixXd &cov(ov_msckf::State &s) {
+    host_wrote_covariance();
+    return s._Cov;
+  }
+  // ... and for the residency code itself (sizes, downloads: ovgpu_resident_cov.h, StateHelper_resident.cpp)
+  static Eigen::MatrixXd &cov_raw(ov_msckf::State &s) { return s._Cov; }
   static std::vector<std::shared_ptr<ov_type::Type>> &variables(ov_msckf::State &s) { return s._variables; }
 
   // StateHelper::EKFUpdate's tail (StateHelper.cpp:166-196) with the numbers computed on the device: P' row-major N x N, dx N.
   // The negative-diagonal check of :171-182 has already happened on the device (OVGPU_ERR_NEGATIVE_DIAGONAL).
   static void apply_update(ov_msckf::State &s, const double *P_rowmajor, const double *dx, int N) {
+    host_wrote_covariance();
     s._Cov = Eigen::Map<const Eigen::Matrix<double, Eigen::Dynamic, Eigen::Dynamic, Eigen::RowMajor>>(P_rowmajor, N, N);
     const Eigen::Map<const Eigen::VectorXd> d(dx, N);
     for (auto &var : s._variables) var->update(d.segment(var->id(), var->size())); // :185-187
+    refresh_cameras(s);
+  }
+  // an updater's write-back into State::_Cov: in the resident-covariance build (ovgpu_resident_cov.h defines the hook) the device's copy is stale from here on
+  static void host_wrote_covariance();
+  // the same with the covariance left where it is (the resident-covariance mode: P' stays on the device)
+  static void apply_dx(ov_msckf::State &s, const double *dx, int N) {
+    const Eigen::Map<const Eigen::VectorXd> d(dx, N);
+    for (auto &var : s._variables) var->update(d.segment(var->id(), var->size()));
     refresh_cameras(s);
   }
   // the camera objects carry the intrinsics as well and the trackers undistort through them (StateHelper.cpp:191-196)
@@ -34,4 +49,11 @@ struct StateAccess {
     for (auto const &calib : s._cam_intrinsics) s._cam_intrinsics_cameras.at(calib.first)->set_value(calib.second->value());
   }
 };
+// (ovgpu_shim_common.h: StateSnapshot reads State::_Cov directly when it is called from inside StateHelper's wrappers)
 } // namespace ovgpu_shim
+
+#ifdef OVGPU_SHIM_RESIDENT_COV
+#include "ovgpu_resident_cov.h" // (defines StateAccess::host_wrote_covariance)
+#else
+inline void ovgpu_shim::StateAccess::host_wrote_covariance() {}
+#endif

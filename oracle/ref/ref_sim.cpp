@@ -21,6 +21,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <ctime>
 #include <map>
 #include <memory>
 #include <vector>
@@ -85,7 +86,15 @@ const double CAM_INTR[4][8] = {{458.654, 457.296, 367.215, 248.375, -0.28340811,
                                {458.654, 457.296, 367.215, 248.375, -0.28340811, 0.07395907, 0.00019359, 1.76187114e-05},
                                {457.587, 456.134, 379.999, 255.238, -0.28368365, 0.07451284, -0.00010473, -3.55590700e-05}};
 
+static double now_s() {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
 struct RefSim {
+  double t_prop = 0.0, t_update = 0.0, t_marg = 0.0; // wall seconds inside Propagator::propagate_and_clone, UpdaterMSCKF::update, StateHelper::marginalize_old_clone
+  long n_obs = 0, n_feats = 0;                       // observations / features handed to UpdaterMSCKF::update
   VioManagerOptions params;
   std::shared_ptr<Simulator> sim;
   std::shared_ptr<State> state;
@@ -185,7 +194,11 @@ void front_end(RefSim &s, double timestamp, const std::vector<int> &camids,
 bool propagate_and_select(RefSim &s, double timestamp, const std::vector<int> &sensor_ids) {
   auto &state = s.state;
   if (state->_timestamp > timestamp) return false; // VioManager.cpp:333-337
-  if (state->_timestamp != timestamp) s.propagator->propagate_and_clone(state, timestamp); // :341-343
+  if (state->_timestamp != timestamp) {
+    const double t0 = now_s();
+    s.propagator->propagate_and_clone(state, timestamp); // :341-343
+    s.t_prop += now_s() - t0;
+  }
   if ((int)state->_clones_IMU.size() < std::min(state->_options.max_clone_size, 5)) return false; // :348-352
   if (state->_timestamp != timestamp) return false; // :355-359
   // :372-381
@@ -450,9 +463,11 @@ void ref_sim_export(void *h, double *P, double *clone_q_p, double *clone_q_p_fej
   RefSim &s = *static_cast<RefSim *>(h);
   auto &state = s.state;
   const int N = state->max_covariance_size();
-  Eigen::MatrixXd Cov = StateHelper::get_full_covariance(state);
-  for (int i = 0; i < N; i++)
-    for (int j = 0; j < N; j++) P[(size_t)i * N + j] = Cov(i, j);
+  if (P) { // (null: the caller only wants the batch — the library's own updaters do the update, and a resident covariance stays where it is)
+    Eigen::MatrixXd Cov = StateHelper::get_full_covariance(state);
+    for (int i = 0; i < N; i++)
+      for (int j = 0; j < N; j++) P[(size_t)i * N + j] = Cov(i, j);
+  }
   int ci = 0;
   std::map<double, int> index_of_time;
   for (const auto &clone : state->_clones_IMU) {
@@ -488,7 +503,13 @@ int ref_sim_update_reference(void *h, int32_t *feat_used) {
   RefSim &s = *static_cast<RefSim *>(h);
   if (!s.pending) return 1;
   std::vector<std::shared_ptr<Feature>> all = s.featsup;
+  for (const auto &f : all) {
+    s.n_feats++;
+    for (const auto &pair : f->timestamps) s.n_obs += (long)pair.second.size();
+  }
+  const double t0u = now_s();
   s.updater->update(s.state, s.featsup);
+  s.t_update += now_s() - t0u;
   s.propagator->invalidate_cache();
   for (size_t f = 0; f < all.size() && feat_used; f++) feat_used[f] = std::find(s.featsup.begin(), s.featsup.end(), all[f]) != s.featsup.end() ? 1 : 0;
   if (s.updater_slam) { // VioManager.cpp:529-547: the landmarks' update in chunks of max_slam_in_update, then the delayed initialisation
@@ -570,9 +591,20 @@ void ref_sim_finish(void *h) {
     ovgpu_shim::TrackMirror::instance().cleanup_measurements(state->margtimestep());
 #endif
   }
-  StateHelper::marginalize_old_clone(state);
+  {
+    const double t0 = now_s();
+    StateHelper::marginalize_old_clone(state);
+    s.t_marg += now_s() - t0;
+  }
   s.featsup.clear(), s.cleaned.clear(), s.feats_slam_update.clear(), s.feats_slam_delayed.clear();
   s.pending = false;
+}
+
+// wall seconds spent so far inside propagate_and_clone / UpdaterMSCKF::update / marginalize_old_clone, and the features / observations the
+// updater was handed (the drop-in's cost in a running filter: tests/dropin_probe.py `time`)
+void ref_sim_times(void *h, double *out5) {
+  RefSim &s = *static_cast<RefSim *>(h);
+  out5[0] = s.t_prop, out5[1] = s.t_update, out5[2] = s.t_marg, out5[3] = (double)s.n_feats, out5[4] = (double)s.n_obs;
 }
 
 // estimate (timestamp, q, p, v, bg, ba = 17) and ground truth at the same instant; returns 0 when the truth is unavailable there

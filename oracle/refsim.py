@@ -68,8 +68,9 @@ class RefSim:
         """Runs the simulation until an MSCKF update is ready; False when the trajectory ended."""
         return self.lib.ref_sim_advance(self.h) == 1
 
-    def pending(self):
-        """The waiting update as a synth.Problem-like snapshot (+ featid)."""
+    def pending(self, with_cov=True):
+        """The waiting update as a synth.Problem-like snapshot (+ featid).  with_cov = False: P stays zero (the filter's own updaters
+        will do the update: nothing reads it, and a covariance resident on a device is not brought back for it)."""
         N, Cn, K, F, M = (C.c_int32() for _ in range(5))
         self.lib.ref_sim_dims(self.h, C.byref(N), C.byref(Cn), C.byref(K), C.byref(F), C.byref(M))
         N, Cn, K, F, M = N.value, Cn.value, K.value, F.value, M.value
@@ -81,7 +82,7 @@ class RefSim:
                             lm_value=None)
         dp, ip, fp = C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_float)
         a = lambda x, t: x.ctypes.data_as(t)
-        self.lib.ref_sim_export(self.h, a(p.P, dp), a(p.clone_q_p, dp), a(p.clone_q_p_fej, dp), a(p.clone_cov_id, ip), a(p.calib_q_p, dp),
+        self.lib.ref_sim_export(self.h, a(p.P, dp) if with_cov else None, a(p.clone_q_p, dp), a(p.clone_q_p_fej, dp), a(p.clone_cov_id, ip), a(p.calib_q_p, dp),
                                 a(p.intrinsics, dp), a(p.calib_cov_id, ip), a(p.intr_cov_id, ip), a(p.meas_offsets, ip), a(p.uv, fp), a(p.uvn, fp),
                                 a(p.clone_idx, ip), a(p.cam_idx, ip), p.featid.ctypes.data_as(C.POINTER(C.c_uint64)))
         p.uv, p.uvn, p.clone_idx, p.cam_idx = p.uv[: 2 * M], p.uvn[: 2 * M], p.clone_idx[:M], p.cam_idx[:M]
@@ -101,6 +102,12 @@ class RefSim:
         dp = C.POINTER(C.c_double)
         self.lib.ref_sim_update_external(self.h, dx.ctypes.data_as(dp), P.ctypes.data_as(dp), st.ctypes.data_as(C.POINTER(C.c_int32)),
                                          pg.ctypes.data_as(dp) if pg is not None else None)
+
+    def times(self):
+        """Wall seconds inside propagate_and_clone / UpdaterMSCKF::update / marginalize_old_clone so far, features and observations handed to the updater."""
+        out = np.zeros(5)
+        self.lib.ref_sim_times(self.h, out.ctypes.data_as(C.POINTER(C.c_double)))
+        return dict(propagate_s=out[0], update_s=out[1], marginalize_s=out[2], features=int(out[3]), observations=int(out[4]))
 
     def finish(self):
         self.lib.ref_sim_finish(self.h)

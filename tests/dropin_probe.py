@@ -141,6 +141,13 @@ def loop_stereo(mode, seconds):
     loop(mode, seconds, name="loop_stereo", num_cameras=2, max_slam_features=15, dt_slam_delay=2.0, feat_rep_slam=4, feat_rep_msckf=4)
 
 
+def loop_wide(mode, seconds):
+    """Two seconds of the loop with a stereo rig and 3 000 points in view: > 256 tracks per update, where the shim splits its clean + flatten walk
+    over threads (shim/ovgpu_shim_common.h: clean_flatten_batch) and compacts the accepted tracks in one pass — the same decisions, in the same
+    order, as the reference's erase-as-you-go loops."""
+    loop(mode, 2.0, name="loop_wide", num_cameras=2, num_pts=3000, max_msckf_in_update=4000)
+
+
 def loop(mode, seconds, name="loop", **cfg):
     """The rpng_sim closed loop (BASELINE configs[0]; tests/test_rpng_sim_loop.py) with the DROP-IN as the filter's updater: the reference's
     Simulator, Propagator, FeatureDatabase and State around open_vins_amd/shim/UpdaterMSCKF.cpp, against the same loop around the reference's
@@ -148,8 +155,17 @@ def loop(mode, seconds, name="loop", **cfg):
     from test_rpng_sim_loop import _ate, run_filter, separation
     ref = run_filter("reference", seconds=seconds, **cfg)
     ctl = run_filter("reference", seconds=seconds, perturb=1e-13, **cfg)
-    with pyref.using(pyref.dropin_path(mode)):
+    traffic = None
+    with pyref.using(pyref.dropin_path(mode)) as lib:
+        if mode.startswith("rc") or mode.startswith("c"):  # the resident-covariance builds count the N x N copies they make
+            import ctypes
+            before = (ctypes.c_long(0), ctypes.c_long(0))
+            lib.ovgpu_shim_resident_cov_traffic(ctypes.byref(before[0]), ctypes.byref(before[1]))
         got = run_filter("reference", seconds=seconds, **cfg)  # ("reference" = the library's own updaters: here the shim's)
+        if mode.startswith("rc") or mode.startswith("c"):
+            after = (ctypes.c_long(0), ctypes.c_long(0))
+            lib.ovgpu_shim_resident_cov_traffic(ctypes.byref(after[0]), ctypes.byref(after[1]))
+            traffic = dict(cov_uploads=after[0].value - before[0].value, cov_downloads=after[1].value - before[1].value)
     n = min(len(got["used"]), len(ref["used"]))
     same_first = all(np.array_equal(got["used"][k], ref["used"][k]) for k in range(min(n, 100)))
     n_dec = sum(len(u) for u in ref["used"][:n])
@@ -158,7 +174,65 @@ def loop(mode, seconds, name="loop", **cfg):
     a, b = _ate(got), _ate(ref)
     emit(f"{name}:{seconds}", updates=len(got["used"]), state_dim_max=int(got["N"].max()), state_dim_max_reference=int(ref["N"].max()), updates_reference=len(ref["used"]), status_equal=bool(same_first and len(got["used"]) == len(ref["used"])),
          decisions=int(n_dec), differing=int(n_diff), sep_first_ten=float(d[:10].max()), sep=float(d.max()), control=float(separation(ctl, ref).max()),
-         ate_deg=a[0], ate_m=a[1], ate_deg_reference=b[0], ate_m_reference=b[1])
+         ate_deg=a[0], ate_m=a[1], ate_deg_reference=b[0], ate_m_reference=b[1], **(traffic or {}))
+
+
+_LAPS = ("snapshot", "clean_flatten", "state_handover", "track_handover", "call", "triangulation_readback", "track_side_effects", "state_writeback")
+
+
+def _laps(lib, reset=False):
+    """UpdaterMSCKF::update's own stopwatch (test builds: -DOVGPU_SHIM_TIMING), ms per update since the last reset."""
+    import ctypes
+    try:
+        fn = lib.ovgpu_shim_update_laps
+    except AttributeError:
+        return None
+    out = (ctypes.c_double * 9)()
+    fn(out, 1 if reset else 0)
+    n = max(out[8], 1.0)
+    return {k: round(out[i] / n, 4) for i, k in enumerate(_LAPS)}
+
+
+def time_loop(mode, seconds=6.0, **cfg):
+    """The drop-in's cost INSIDE a running filter at a large shape: the reference's simulator / propagator / database around the shim with a stereo
+    rig, a 30-clone window and as many tracks per frame as the simulator is asked for — wall time per frame inside Propagator::propagate_and_clone
+    (StateHelper::EKFPropagation + augment_clone), UpdaterMSCKF::update and StateHelper::marginalize_old_clone, second half of the run."""
+    from oracle import refsim
+    kw = dict(num_cameras=2, max_clones=30, num_pts=1100, max_msckf_in_update=4000)
+    kw.update(cfg)
+    with pyref.using(pyref.dropin_path(mode)) as lib:
+        if mode.startswith("r"):
+            lib.ovgpu_shim_resident_verify(0)  # (the test builds of the resident modes compare every device-assembled batch with the host's flattening: not part of the mode)
+        sim = refsim.RefSim(refsim.rpng_sim_config(**kw))
+        t0 = None
+        half = None
+        frames = 0
+        while sim.advance():
+            prob = sim.pending(with_cov=False)
+            sim.update_reference(prob.F)
+            sim.finish()
+            e, g, extra, ok = sim.state()
+            t0 = e[0] if t0 is None else t0
+            frames += 1
+            if half is None and e[0] - t0 >= seconds / 2:
+                half = (frames, sim.times())
+                _laps(lib, reset=True)
+            if e[0] - t0 >= seconds:
+                break
+        end = sim.times()
+        laps = _laps(lib)
+        sim.close()
+        traffic = {}
+        if mode.startswith("rc") or mode.startswith("c"):
+            import ctypes
+            u, d = ctypes.c_long(0), ctypes.c_long(0)
+            lib.ovgpu_shim_resident_cov_traffic(ctypes.byref(u), ctypes.byref(d))
+            traffic = dict(cov_uploads=u.value, cov_downloads=d.value)
+    n = frames - half[0]
+    h = half[1]
+    emit(f"time:{mode}", frames=n, features_per_update=(end["features"] - h["features"]) / n, observations_per_update=(end["observations"] - h["observations"]) / n,
+         state_dim=int(extra[1]), update_ms=1e3 * (end["update_s"] - h["update_s"]) / n, propagate_and_clone_ms=1e3 * (end["propagate_s"] - h["propagate_s"]) / n,
+         marginalize_ms=1e3 * (end["marginalize_s"] - h["marginalize_s"]) / n, **traffic, **({"update_laps_ms": laps} if laps else {}))
 
 
 def sweep(mode):
@@ -221,19 +295,24 @@ def sweep(mode):
     emit("sweep", differing=bad, **w)
 
 
-CASES = [("msckf", 0), ("msckf", 3), ("msckf", 7), ("msckf", 11), ("msckf", 19), ("slam", 0), ("slam", 4), ("slam_aruco", 0), ("slam_aruco", 5), ("delayed", 0), ("delayed", 4), ("delayed", 5), ("delayed_aruco", 0), ("anchors", 2), ("anchors", 4), ("zupt", 0), ("zupt", 1), ("loop", 60.0), ("loop_slam", 60.0), ("loop_stereo", 60.0)]
+CASES = [("msckf", 0), ("msckf", 3), ("msckf", 7), ("msckf", 11), ("msckf", 19), ("slam", 0), ("slam", 4), ("slam_aruco", 0), ("slam_aruco", 5), ("delayed", 0), ("delayed", 4), ("delayed", 5), ("delayed_aruco", 0), ("anchors", 2), ("anchors", 4), ("zupt", 0), ("zupt", 1), ("loop", 60.0), ("loop_slam", 60.0), ("loop_stereo", 60.0), ("loop_wide", 2.0)]
 
 if __name__ == "__main__":
     mode = sys.argv[1]  # a | b (libovgpu: needs the GPU) or a_cpu | b_cpu (tests/fake_ovgpu, the oracle-backed double of the C ABI: runs anywhere)
-    seconds = float(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2] != "sweep" else 60.0
+    seconds = float(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2] not in ("sweep", "time") else 60.0
     pyref.load()
+    if len(sys.argv) > 2 and sys.argv[2] == "time":
+        time_loop(mode, float(sys.argv[3]) if len(sys.argv) > 3 else 6.0, **({"num_pts": int(sys.argv[4])} if len(sys.argv) > 4 else {}))
+        emit("done")
+        sys.stdout.flush()
+        os._exit(0)
     if len(sys.argv) > 2 and sys.argv[2] == "sweep":
         sweep(mode)
         emit("done")
         sys.stdout.flush()
         os._exit(0)
     for kind, arg in CASES:
-        if mode.startswith("r") and not kind.startswith("loop"):
+        if mode.startswith("r") and (not kind.startswith("loop") or kind == "loop_wide"):
             continue  # the resident-track build updates from the mirrored track store: only a LOOP feeds it (the per-call driver builds bare Features)
         globals()[kind](mode, seconds if kind.startswith("loop") else arg)
     emit("done")

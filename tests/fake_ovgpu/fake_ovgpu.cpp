@@ -533,6 +533,65 @@ int ovgpu_state_marginal_covariance(ovgpu_ctx *c, int32_t n, const int32_t *cov_
     for (int j = 0; j < n; j++) out[(size_t)i * n + j] = c->P[(size_t)cov_idx[i] * c->N + cov_idx[j]];
   return OVGPU_OK;
 }
+int ovgpu_state_dims(ovgpu_ctx *c, int32_t *N_out, int32_t *C_out) {
+  if (!c || !c->have_state || c->poses_only) return fail(OVGPU_ERR_NO_STATE, "no state");
+  if (N_out) *N_out = c->N;
+  if (C_out) *C_out = c->C;
+  return OVGPU_OK;
+}
+// csrc/api_window.inc: a block that starts inside a resident variable must be exactly that variable; ids behind the block move forward;
+// a dropped clone leaves the clone tables (landmarks: not modelled here — the resident-covariance shim keeps none in this context)
+int ovgpu_state_marginalize(ovgpu_ctx *c, int32_t cov_id, int32_t size) {
+  if (!c || !c->have_state || c->poses_only) return fail(OVGPU_ERR_NO_STATE, "no state");
+  if (cov_id < 0 || size <= 0 || cov_id + size > c->N) return fail(OVGPU_ERR_INVALID, "marginalised block outside the covariance");
+  if (c->L > 0) return fail(OVGPU_ERR_INVALID, "fake_ovgpu: marginalisation with resident landmarks is not modelled");
+  auto hit = [&](int id, int sz) { return id >= 0 && id < cov_id + size && id + sz > cov_id; };
+  int drop_clone = -1;
+  for (int i = 0; i < c->C; i++)
+    if (hit(c->clone_cov[i], 6)) {
+      if (c->clone_cov[i] != cov_id || size != 6 || c->C <= 1) return fail(OVGPU_ERR_INVALID, "block cuts through a clone (or it is the last one)");
+      drop_clone = i;
+    }
+  for (int k = 0; k < c->K; k++) {
+    if (hit(c->calib_cov[k], 6)) {
+      if (c->calib_cov[k] != cov_id || size != 6) return fail(OVGPU_ERR_INVALID, "block cuts through a camera pose");
+      c->calib_cov[k] = -1;
+    }
+    if (hit(c->intr_cov[k], 8)) {
+      if (c->intr_cov[k] != cov_id || size != 8) return fail(OVGPU_ERR_INVALID, "block cuts through camera intrinsics");
+      c->intr_cov[k] = -1;
+    }
+  }
+  std::vector<double> Pn((size_t)(c->N - size) * (c->N - size));
+  oracle_marginalize(c->P.data(), c->N, cov_id, size, Pn.data());
+  c->P.swap(Pn), c->N -= size;
+  if (drop_clone >= 0) {
+    c->clone_q_p.erase(c->clone_q_p.begin() + 7 * drop_clone, c->clone_q_p.begin() + 7 * drop_clone + 7);
+    c->clone_fej.erase(c->clone_fej.begin() + 7 * drop_clone, c->clone_fej.begin() + 7 * drop_clone + 7);
+    c->clone_cov.erase(c->clone_cov.begin() + drop_clone);
+    c->C -= 1;
+  }
+  auto shift = [&](int32_t &id) { if (id > cov_id) id -= size; };
+  for (auto &id : c->clone_cov) shift(id);
+  for (auto &id : c->calib_cov) shift(id);
+  for (auto &id : c->intr_cov) shift(id);
+  c->have_feats = false, c->tri_readable = false; // the column map changed: the batch is uploaded again
+  return OVGPU_OK;
+}
+int ovgpu_state_augment_clone(ovgpu_ctx *c, int32_t src_cov_id, const double *q_p, const double *q_p_fej, int32_t dt_cov_id, const double *dnc_dt, int32_t *new_cov_id) {
+  if (!c || !q_p || !q_p_fej) return fail(OVGPU_ERR_INVALID, "null argument");
+  if (!c->have_state || c->poses_only) return fail(OVGPU_ERR_NO_STATE, "no state");
+  if (src_cov_id < 0 || src_cov_id + 6 > c->N || dt_cov_id >= c->N || (dt_cov_id >= 0 && !dnc_dt)) return fail(OVGPU_ERR_INVALID, "bad clone arguments");
+  std::vector<double> Pn((size_t)(c->N + 6) * (c->N + 6));
+  oracle_augment_clone(c->P.data(), c->N, src_cov_id, 6, dt_cov_id, dnc_dt, Pn.data());
+  if (new_cov_id) *new_cov_id = c->N;
+  c->clone_cov.push_back(c->N);
+  c->P.swap(Pn), c->N += 6;
+  c->clone_q_p.insert(c->clone_q_p.end(), q_p, q_p + 7), c->clone_fej.insert(c->clone_fej.end(), q_p_fej, q_p_fej + 7);
+  c->C += 1;
+  c->have_feats = false, c->tri_readable = false;
+  return OVGPU_OK;
+}
 int ovgpu_state_propagate(ovgpu_ctx *c, int32_t new_cov_id, int32_t n_new, int32_t n_old, const int32_t *old_cov_ids, const double *Phi, const double *Q) {
   if (!c || !c->have_state || c->poses_only) return fail(OVGPU_ERR_NO_STATE, "no state");
   const int rc = oracle_propagate(c->P.data(), c->N, new_cov_id, n_new, n_old, old_cov_ids, Phi, Q);

@@ -67,7 +67,7 @@ def run_filter(update, seconds=SECONDS, perturb=0.0, **cfg_kw):
     est, gt, used, nfeat, dims = [], [], [], [], []
     t0 = None
     while sim.advance():
-        prob = sim.pending()
+        prob = sim.pending(with_cov=update != "reference")
         if update == "reference":
             u = sim.update_reference(prob.F).astype(bool)
         else:
