@@ -50,6 +50,8 @@ def parse_args(argv=None):
     ap.add_argument("--features", type=int, default=None, help="override the TOTAL number of features of the update")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the PCIe-inclusive and the secondary (weak / single-GPU reference) measurements")
+    ap.add_argument("--shim-in-filter", action="store_true", help="also time the drop-in libraries (the shim compiled into the reference's own tree, when "
+                    "they were built: __graft_entry__.build) inside the reference's running filter: UpdaterMSCKF::update per frame, modes B and resident covariance")
     ap.add_argument("--route", choices=["gram", "tsqr"], default="gram")
     ap.add_argument("--stage-events-every", type=int, default=4, help="the library's per-stage HIP events (roofline durations) on every n-th update of the timed region")
     ap.add_argument("--gate-always-factor", action="store_true", help="ovgpu_options::gate_always_factor = 1: form and factor every feature's gate matrix "
@@ -461,6 +463,12 @@ def main(argv=None):
             out["pcie_inclusive_ms"] = pcie_inclusive_ms(prob, opts, local_rank)
             out["mode_a"] = mode_a_ms(prob, opts, local_rank, capi)
             out["shim"] = shim_dropin_ms(prob.F)
+            # host to host with the covariance RESIDENT (the shim's -DOVGPU_SHIM_RESIDENT_COV: tracks flattened and uploaded, dx back, P' stays):
+            # flatten + upload + call from the C++ selftest on fresh containers.  Inside the reference's running filter (fragmented heap, its own
+            # Feature objects) the walk over the tracks costs more: --shim-in-filter, profiles/r05_d_dropin_in_filter_times.txt
+            out["shim_resident_ms"] = (out["shim"] or {}).get("shim_resident_cov_ms")
+            if args.shim_in_filter:
+                out["shim_in_filter"] = shim_in_filter_ms()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(prob, opts)
         print(json.dumps(out), flush=True)
@@ -522,6 +530,21 @@ def shim_dropin_ms(F):
         return res
     except Exception as e:  # noqa: BLE001
         return {"error": str(e)}
+
+
+def shim_in_filter_ms():
+    """The SHIPPED shim units inside the reference's own filter loop (its simulator, propagator, feature database and State around
+    shim/UpdaterMSCKF.cpp; stereo, 30 clones, ~2 300 tracks per update): wall time of UpdaterMSCKF::update per frame with its per-stage laps,
+    mode B and mode B with the covariance resident.  Opt-in: the libraries hold the reference's objects and exist only where it was built."""
+    out = {}
+    for mode in ("b", "c"):
+        try:
+            p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "dropin_probe.py"), mode, "time", "8", "20000"], capture_output=True, text=True, timeout=600)
+            line = [json.loads(l) for l in p.stdout.splitlines() if l.startswith('{"case": "time')]
+            out[mode] = line[-1] if line else {"error": (p.stdout + p.stderr)[-300:]}
+        except Exception as e:  # noqa: BLE001
+            out[mode] = {"error": str(e)}
+    return out
 
 
 def mode_a_ms(prob, opts, device, capi):

@@ -282,7 +282,7 @@ static int time_dropin(int F, int reps, bool gpu = true, bool resident = false) 
   const int Dmax = 6 * C + 14 * K;
   std::vector<int32_t> status(F), anchor(F), col_cov(Dmax);
   std::vector<double> pA(3 * (size_t)F), pG(3 * (size_t)F), H((size_t)Dmax * Dmax), r(Dmax), dx(fs.N), P1((size_t)fs.N * fs.N);
-  std::vector<double> t_flat, t_up, t_a, t_b, t_dev;
+  std::vector<double> t_flat, t_up, t_a, t_b, t_dev, t_c;
   int used = 0, rows = 0, M = 0;
   for (int it = 0; it < reps + 2; it++) {
     const double t0 = now_ms();
@@ -304,7 +304,16 @@ static int time_dropin(int F, int reps, bool gpu = true, bool resident = false) 
     // mode B on the same upload (the state is untouched by mode A)
     ctx.check(ovgpu_msckf_update(ctx.get(), status.data(), nullptr, nullptr, pG.data(), dx.data(), P1.data(), &st), "ovgpu_msckf_update");
     const double t4 = now_ms();
-    if (it >= 2) t_flat.push_back(t1 - t0), t_up.push_back(t2 - t1), t_a.push_back(t3 - t2), t_b.push_back(t4 - t3), t_dev.push_back(st.ms_total);
+    // the covariance RESIDENT (shim -DOVGPU_SHIM_RESIDENT_COV: no ovgpu_set_state, no P' read-back — the state the update left on the device is the
+    // next frame's; here it is put back first, outside the clock, so that every repetition updates the same prior): tracks in, dx out
+    ctx.check(ovgpu_reset_state(ctx.get()), "ovgpu_reset_state");
+    ctx.check(ovgpu_synchronize(ctx.get()), "ovgpu_synchronize");
+    const double t5 = now_ms();
+    ctx.check(ovgpu_set_features(ctx.get(), &fv), "ovgpu_set_features");
+    ctx.check(ovgpu_msckf_update(ctx.get(), status.data(), nullptr, nullptr, pG.data(), dx.data(), nullptr, &st), "ovgpu_msckf_update");
+    ctx.check(ovgpu_get_triangulation(ctx.get(), pA.data(), nullptr, anchor.data()), "ovgpu_get_triangulation");
+    const double t6 = now_ms();
+    if (it >= 2) t_flat.push_back(t1 - t0), t_up.push_back(t2 - t1), t_a.push_back(t3 - t2), t_b.push_back(t4 - t3), t_dev.push_back(st.ms_total), t_c.push_back(t6 - t5);
     rows = rr, used = 0;
     for (int f = 0; f < F; f++) used += status[f] == OVGPU_FEAT_USED;
   }
@@ -312,8 +321,8 @@ static int time_dropin(int F, int reps, bool gpu = true, bool resident = false) 
   std::printf("{\"what\": \"drop-in path from C++, host to host, reference-shaped Feature containers\", \"features\": %d, \"measurements\": %d, "
               "\"observations_incl_stale\": %zu, \"clones\": %d, \"cameras\": %d, \"features_used\": %d, \"rows_mode_a\": %d, \"reps\": %d, "
               "\"flatten_ms\": %.4f, \"upload_ms\": %.4f, \"mode_a_call_ms\": %.4f, \"mode_b_call_ms\": %.4f, \"device_update_ms\": %.4f, "
-              "\"shim_mode_a_ms\": %.4f, \"shim_mode_b_ms\": %.4f}\n",
-              F, M, n_obs + (size_t)F * K, C, K, used, rows, reps, fl, up, a, b, median(t_dev), fl + up + a, fl + up + b);
+              "\"shim_mode_a_ms\": %.4f, \"shim_mode_b_ms\": %.4f, \"resident_cov_tracks_in_dx_out_ms\": %.4f, \"shim_resident_cov_ms\": %.4f}\n",
+              F, M, n_obs + (size_t)F * K, C, K, used, rows, reps, fl, up, a, b, median(t_dev), fl + up + a, fl + up + b, median(t_c), fl + median(t_c));
   return used > F / 2 ? 0 : 1;
 }
 
