@@ -6,8 +6,8 @@
 //   chi2 gate                                           UpdaterMSCKF.cpp:209-234, StateHelper.cpp:226-254
 //   stacking into Hx_big / res_big                      UpdaterMSCKF.cpp:237-255
 //
-// What changed against k_feat.h (whose kernels stay: the legacy form, ovgpu_debug_option "legacy_feature_kernel").  There the gate
-// matrix was S0 = (H P) H^T + s^2 I: a thread-per-column sweep T = H P over the sparse rows (650 KB of P through the vector cache
+// What changed against round 2's three-sweep kernels of k_feat.h (k_feat_rows / k_feat_qr / k_feat_z / k_feat / k_feat_out; deleted in
+// round 4, their measurements stay in DESIGN.md section 4).  There the gate matrix was S0 = (H P) H^T + s^2 I: a thread-per-column sweep T = H P over the sparse rows (650 KB of P through the vector cache
 // per feature, two multiply-adds per loaded double), S0's tiles as per-lane gathers from the T chunk in LDS, and — in a second
 // kernel, k_feat_out — the sweep Y = H L AGAIN for the rows that go to the stack.  Both sweeps and the gathers were latency
 // bound (54 - 72 % of wave-cycles in s_waitcnt, round-2 PMC passes).  With P_DD = L L^T (the prior block's factor, which the
