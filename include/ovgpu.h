@@ -58,8 +58,15 @@ extern "C" {
 /*      ovgpu_tracks_not_containing_newer reads the stored observations (per   */
 /*      camera the LAST one, as the reference does) instead of the host's      */
 /*      record of the last append: same answer for times appended in order.    */
+/*   7  (round 5) ovgpu_landmarks_view grew a last member, feat_rep_each: the   */
+/*      representation PER LANDMARK (NULL = feat_rep for all, the behaviour     */
+/*      before), so that one ovgpu_slam_update stacks SLAM landmarks and ArUco   */
+/*      corners kept in different representations as UpdaterSLAM.cpp:427-447     */
+/*      does; ovgpu_slam_delayed_init may initialise in a representation other   */
+/*      than the resident landmarks'; ovgpu_get_landmark_reps reads them back.   */
+/*      A caller compiled against ABI 6 passes a shorter struct: rebuild.        */
 /* ------------------------------------------------------------------------- */
-#define OVGPU_ABI_VERSION 6
+#define OVGPU_ABI_VERSION 7
 int ovgpu_abi_version(void);
 
 /* ------------------------------------------------------------------------- */
@@ -399,7 +406,10 @@ int ovgpu_get_state(ovgpu_ctx *ctx, double *P, double *clone_q_p,
 
 /* SLAM landmarks that live in the state (State::_features_SLAM, ov_type::Landmark,
  * ov_core/src/types/Landmark.h), all in one representation `feat_rep` (StateOptions
- * feat_rep_slam; 0 = GLOBAL_3D, the reference default, StateOptions.h:89).
+ * feat_rep_slam; 0 = GLOBAL_3D, the reference default, StateOptions.h:89) or — feat_rep_each —
+ * each in its own (Landmark::_feat_representation: ArUco corners are initialised in
+ * StateOptions::feat_rep_aruco, the others in feat_rep_slam, and UpdaterSLAM::update reads the
+ * representation from the landmark, UpdaterSLAM.cpp:336-341).
  *   p_value [3*L]  Landmark::value()  — REPRESENTATION coordinates (xyz, (theta, phi, rho) or
  *                  (alpha, beta, rho), Landmark.cpp:66-141); the library applies
  *                  Landmark::get_xyz (Landmark.cpp:25-62) where the reference does
@@ -420,6 +430,9 @@ typedef struct {
   const int32_t *cov_id;
   const int32_t *anchor_cam;
   const int32_t *anchor_clone;
+  const int32_t *feat_rep_each; /* optional [L]: ovgpu_feat_rep per landmark; NULL = feat_rep for all (ABI 7).
+                                 * A 3-dof landmark takes 3 covariance ids / columns, a single-depth one 1; the
+                                 * anchors of the global ones are not read                                     */
 } ovgpu_landmarks_view;
 
 /* Uploads the landmarks the next ovgpu_slam_update works on; their 3 columns each join the
@@ -464,8 +477,10 @@ int ovgpu_slam_compress(ovgpu_ctx *ctx, const int32_t *lm_index, int32_t *feat_s
  * against chi2_multipler * chi2_0.95(2m) (:459-470), and for an accepted feature the covariance
  * augmentation (:541-565), the landmark's first correction (:569) and StateHelper::EKFUpdate
  * with the 2m-3 rows (:476-478).  The context's options are the UpdaterSLAM's (sigma_pix,
- * chi2_multipler of `slam`).  `feat_rep` = StateOptions::feat_rep_slam (must equal the
- * representation of the resident landmarks when there are any).  ANCHORED_INVERSE_DEPTH_SINGLE:
+ * chi2_multipler of `slam`).  `feat_rep` = the representation the NEW landmarks get
+ * (StateOptions::feat_rep_slam, or feat_rep_aruco for a batch of ArUco corners, UpdaterSLAM.cpp:
+ * 206-213); the resident landmarks keep theirs (ABI 7; one representation for all before).
+ * ANCHORED_INVERSE_DEPTH_SINGLE:
  * the bearing is projected out first (UpdaterSLAM.cpp:181-196), the third of the three rows
  * initialises the 1-dof landmark and the gate uses the quantile of 2m-2 dof.
  *
@@ -498,6 +513,9 @@ int ovgpu_slam_delayed_init(ovgpu_ctx *ctx, int32_t feat_rep, int32_t *feat_stat
 int ovgpu_get_landmarks(ovgpu_ctx *ctx, int32_t *L_out, double *value, double *fej,
                         int32_t *cov_id, int32_t *anchor_cam, int32_t *anchor_clone);
 
+/* ... and their representations, feat_rep [L] (ovgpu_feat_rep; ABI 7).                      */
+int ovgpu_get_landmark_reps(ovgpu_ctx *ctx, int32_t *L_out, int32_t *feat_rep);
+
 /* UpdaterSLAM::perform_anchor_change (UpdaterSLAM.cpp:506-647) for the resident anchored landmark
  * lm_index: its position is re-expressed in the camera `new_anchor_cam` of clone `new_anchor_clone`
  * (value and first estimate, :536-571), and the covariance is propagated with
@@ -512,6 +530,13 @@ int ovgpu_slam_change_anchor(ovgpu_ctx *ctx, int32_t lm_index, int32_t new_ancho
  * reference passes state->_timestamp), same camera.  n_changed (optional) = how many moved.  */
 int ovgpu_slam_change_anchors(ovgpu_ctx *ctx, int32_t marg_clone, int32_t new_clone,
                               int32_t *n_changed);
+
+/* Per-feature landmark representation for ovgpu_slam_delayed_init on the uploaded batch: UpdaterSLAM::delayed_init
+ * initialises an ArUco corner in StateOptions::feat_rep_aruco and every other feature in feat_rep_slam
+ * (UpdaterSLAM.cpp:160-166).  feat_rep [F] (ovgpu_feat_rep); NULL = the call's feat_rep argument for every feature.
+ * The covariance then grows by 3 or 1 per accepted feature as each one's representation says.  Until the next batch is
+ * uploaded (ABI 7).                                                                                         */
+int ovgpu_set_feature_reps(ovgpu_ctx *ctx, const int32_t *feat_rep);
 
 /* Per-feature measurement noise and gate multiplier for the uploaded batch — UpdaterSLAM keeps two
  * UpdaterOptions, `slam` and `aruco`, and picks per feature by its id (UpdaterSLAM.cpp:227-232,

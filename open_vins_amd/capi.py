@@ -84,7 +84,7 @@ class FeaturesView(C.Structure):
 class LandmarksView(C.Structure):
     """ovgpu_landmarks_view"""
     _fields_ = [("L", C.c_int32), ("feat_rep", C.c_int32), ("p_value", c_double_p), ("p_fej", c_double_p), ("cov_id", c_int32_p),
-                ("anchor_cam", c_int32_p), ("anchor_clone", c_int32_p)]
+                ("anchor_cam", c_int32_p), ("anchor_clone", c_int32_p), ("feat_rep_each", c_int32_p)]
 
 
 class UpdateStats(C.Structure):
@@ -160,6 +160,9 @@ class Views:
             lv.p_fej = _ptr(self.lm_fej, C.c_double)
             lv.cov_id = _ptr(self.lm_cov_id, C.c_int32)
             lv.feat_rep = int(getattr(prob, "lm_rep", 0) or 0)
+            # one representation per landmark (ABI 7; UpdaterSLAM.cpp:336-341), or lm_rep for all
+            self.lm_rep_each = i32(prob.lm_rep_each) if getattr(prob, "lm_rep_each", None) is not None else None
+            lv.feat_rep_each = _ptr(self.lm_rep_each, C.c_int32)
             self.lm_anchor_cam = i32(prob.lm_anchor_cam) if getattr(prob, "lm_anchor_cam", None) is not None else None
             self.lm_anchor_clone = i32(prob.lm_anchor_clone) if getattr(prob, "lm_anchor_clone", None) is not None else None
             lv.anchor_cam = _ptr(self.lm_anchor_cam, C.c_int32)
@@ -214,6 +217,8 @@ def declare(lib):
         "ovgpu_tracks_to_features": (C.c_int, [ctxp, C.c_int32, C.POINTER(C.c_int64), c_double_p]),
         "ovgpu_tracks_group_order": (C.c_int, [ctxp, C.c_int32]),
         "ovgpu_set_feature_options": (C.c_int, [ctxp, c_double_p, c_double_p]),
+        "ovgpu_set_feature_reps": (C.c_int, [ctxp, c_int32_p]),
+        "ovgpu_get_landmark_reps": (C.c_int, [ctxp, c_int32_p, c_int32_p]),
         "ovgpu_get_features": (C.c_int, [ctxp, c_int32_p, c_int32_p, c_int32_p, c_float_p, c_float_p, c_int32_p, c_int32_p]),
         "ovgpu_slam_change_anchor": (C.c_int, [ctxp, C.c_int32, C.c_int32, C.c_int32]),
         "ovgpu_slam_change_anchors": (C.c_int, [ctxp, C.c_int32, C.c_int32, c_int32_p]),

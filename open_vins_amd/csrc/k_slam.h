@@ -47,32 +47,39 @@ struct LandmarkStore {
   double *value, *fej;    // [3 * cap] representation coordinates
   int32_t *cov, *col;     // [cap] covariance id, first Jacobian column (-1: not in the column map yet)
   int32_t *anchor;        // [cap] packed (camera << 10 | clone) or -1
+  int32_t *rep;           // [cap] ovgpu_feat_rep of the landmark (Landmark::_feat_representation; round 5: per landmark)
 };
+__host__ __device__ inline int lm_rep_dof(int rep) { return rep == OVGPU_REP_ANCHORED_INVERSE_DEPTH_SINGLE ? 1 : 3; }
 
 // per-feature inputs of the SLAM update from the landmark each feature observes (UpdaterSLAM.cpp:333-353)
-__global__ void k_slam_gather(int F, int rep, int min_meas, const int32_t *__restrict__ lm_index, const int32_t *__restrict__ meas_offsets, LandmarkStore lm,
+// (the representation is the LANDMARK's, UpdaterSLAM.cpp:336-341: landmarks of several representations share one batch)
+__global__ void k_slam_gather(int F, const int32_t *__restrict__ lm_index, const int32_t *__restrict__ meas_offsets, LandmarkStore lm,
                               double *p_FinG, double *p_FinA, double *p_fej, int32_t *feat_lm, int32_t *feat_lmcol, int32_t *feat_lmcov,
                               int32_t *feat_anchor, int32_t *status) {
   const int f = blockIdx.x * blockDim.x + threadIdx.x;
   if (f >= F) return;
   const int l = lm_index[f];
+  const int rep = lm.rep[l];
   const V3 x = lm_to_xyz(rep, lm.value + 3 * l), xf = lm_to_xyz(rep, lm.fej + 3 * l);
   double *dst = rep >= OVGPU_REP_ANCHORED_3D ? p_FinA : p_FinG; // position in the anchor camera / in the global frame
   dst[3 * f] = x.x, dst[3 * f + 1] = x.y, dst[3 * f + 2] = x.z;
   p_fej[3 * f] = xf.x, p_fej[3 * f + 1] = xf.y, p_fej[3 * f + 2] = xf.z;
   feat_lm[f] = l, feat_lmcol[f] = lm.col[l], feat_lmcov[f] = lm.cov[l], feat_anchor[f] = lm.anchor[l];
   // UpdaterSLAM.cpp:289-291; a single-depth landmark needs two measurements: one leaves no row after its bearing is projected out
+  const int min_meas = lm_rep_dof(rep) == 1 ? 2 : 1;
   status[f] = (meas_offsets[f + 1] - meas_offsets[f] >= min_meas) ? OVGPU_FEAT_USED : OVGPU_FEAT_TOO_FEW_MEAS;
 }
 
 // Landmark::update: value += dx[id .. id+2]     (L from a device counter when the count changes inside a stream of launches)
-// sz = state dof of a landmark: 3, or 1 for a single-depth landmark whose state variable is the LAST of its three stored values
-__global__ void k_landmark_update(int L, const int32_t *__restrict__ L_dev, int sz, const double *__restrict__ dx, const int32_t *__restrict__ lm_cov,
-                                  double *lm_value, const int32_t *pred) {
+// state dof of a landmark: 3, or 1 for a single-depth landmark whose state variable is the LAST of its three stored values
+__global__ void k_landmark_update(int L, const int32_t *__restrict__ L_dev, const int32_t *__restrict__ lm_rep, const double *__restrict__ dx,
+                                  const int32_t *__restrict__ lm_cov, double *lm_value, const int32_t *pred) {
   if (pred && *pred == 0) return;
   const int n = L_dev ? *L_dev : L;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t < sz * n) lm_value[3 * (t / sz) + (3 - sz) + t % sz] += dx[lm_cov[t / sz] + t % sz];
+  if (t >= 3 * n) return;
+  const int l = t / 3, k = t % 3, j0 = 3 - lm_rep_dof(lm_rep[l]);
+  if (k >= j0) lm_value[3 * l + k] += dx[lm_cov[l] + k - j0];
 }
 
 // dst (n x n, leading dimension ldd) <- src (leading dimension lds); the rest of dst's rows / columns up to nd is zeroed
@@ -345,7 +352,7 @@ __global__ void __launch_bounds__(256) k_init_invertible(InitParams p) {
       p.lm.fej[3 * slot + j] = v[j];
       p.lm.value[3 * slot + j] = v[j] + (j >= j0 ? G[(size_t)j * LD + D] : 0.0); // new_variable->update(H_Linv * res), :569
     }
-    p.lm.cov[slot] = id, p.lm.col[slot] = -1;
+    p.lm.cov[slot] = id, p.lm.col[slot] = -1, p.lm.rep[slot] = p.rep;
     p.lm.anchor[slot] = relative ? (int32_t)p.meas_cc[p.anchor_meas[p.f]] : -1;
     p.feat_slot[p.f] = slot;
   }

@@ -373,8 +373,6 @@ template <bool RG> __global__ void __launch_bounds__(SYS_NT) k_system_t(SysParam
   double *Tch = hq + 64;
   double *S_lds = Tch + (size_t)2 * SYS_RCM * D;
 
-  const bool relative = rep_is_relative(p.opt.feat_rep);
-
 #ifdef SYS_PROFILE
   long long sys_tacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, sys_tlast = clock64();
 #define SYS_T(i) { __syncthreads(); const long long tn = clock64(); sys_tacc[i] += tn - sys_tlast; sys_tlast = tn; }
@@ -410,14 +408,19 @@ template <bool RG> __global__ void __launch_bounds__(SYS_NT) k_system_t(SysParam
     //   MSCKF feature, delayed init          nproj 3, no landmark column
     //   3-dof SLAM landmark                  nproj 0, columns 0..2                                  (UpdaterSLAM.cpp:381-383)
     //   ANCHORED_INVERSE_DEPTH_SINGLE        nproj 2 (the bearing is marginalised), column 2 = depth (UpdaterSLAM.cpp:371-379)
-    const int lm_size = slam ? p.lm_size : 0, lm_off = 3 - lm_size, nproj = 3 - lm_size;
+    // SLAM: the representation is the LANDMARK's (UpdaterSLAM.cpp:336-341: SLAM landmarks and ArUco corners of different representations
+    // are stacked in one update, :427-447); the single depth takes the Jacobians of the MSCKF inverse depth (:338-341)
+    const int lm_id = slam ? p.feat_lm[f] : -1, lm_col = slam ? p.feat_lmcol[f] : -1, lm_cov = slam ? p.feat_lmcov[f] : -1;
+    const int lrep = (slam && p.lm_rep) ? p.lm_rep[lm_id] : -1;
+    const int rep_f = lrep < 0 ? p.opt.feat_rep : (lrep == OVGPU_REP_ANCHORED_INVERSE_DEPTH_SINGLE ? OVGPU_REP_ANCHORED_MSCKF_INVERSE_DEPTH : lrep);
+    const bool relative = rep_is_relative(rep_f);
+    const int lm_size = slam ? (lrep < 0 ? p.lm_size : (lrep == OVGPU_REP_ANCHORED_INVERSE_DEPTH_SINGLE ? 1 : 3)) : 0, lm_off = 3 - lm_size, nproj = 3 - lm_size;
     // per-feature measurement noise and gate multiplier (UpdaterSLAM's ArUco options, UpdaterSLAM.cpp:227-232, :392-409): the
     // rows leave the kernel scaled by sigma / sigma_f, so that the stacked system keeps ONE isotropic noise level (a QR of the
     // stack only preserves R = sigma^2 I)
     const double sig2_f = p.feat_sigma ? p.feat_sigma[f] * p.feat_sigma[f] : p.opt.sigma_pix_sq;
     const double mult_f = p.feat_chi2mult ? p.feat_chi2mult[f] : p.opt.chi2_multipler;
     const double oscale = p.feat_sigma ? sqrt(p.opt.sigma_pix_sq) / p.feat_sigma[f] : 1.0;
-    const int lm_id = slam ? p.feat_lm[f] : -1, lm_col = slam ? p.feat_lmcol[f] : -1, lm_cov = slam ? p.feat_lmcov[f] : -1;
     V3 p_FinG_fej = slam ? load_v3(p.p_fej + 3 * f) : p_FinG; // fej == value for MSCKF features (UpdaterMSCKF.cpp:186-194)
     int anchor_cam = -1, anchor_clone = -1;
     if (relative) {
@@ -434,13 +437,13 @@ template <bool RG> __global__ void __launch_bounds__(SYS_NT) k_system_t(SysParam
     }
     if (tid == 0) {
       double *dl = hq + 12;
-      if (p.opt.feat_rep == OVGPU_REP_GLOBAL_3D) {
+      if (rep_f == OVGPU_REP_GLOBAL_3D) {
         dl[0] = 1, dl[1] = 0, dl[2] = 0, dl[3] = 0, dl[4] = 1, dl[5] = 0, dl[6] = 0, dl[7] = 0, dl[8] = 1;
-      } else if (p.opt.feat_rep == OVGPU_REP_GLOBAL_FULL_INVERSE_DEPTH) {
+      } else if (rep_f == OVGPU_REP_GLOBAL_FULL_INVERSE_DEPTH) {
         inv_depth_jac(p.opt.do_fej ? p_FinG_fej : p_FinG, dl); // UpdaterHelper.cpp:46 (fej == value for MSCKF features)
       } else {
         // anchored (UpdaterHelper.cpp:84-189)
-        anchored_rep_jacobian(p.opt.feat_rep, p.opt.do_fej, p.tab_cam + 12 * anchor_cam, p.tab_clone + 24 * anchor_clone, load_v3(p.p_FinA + 3 * f), dl,
+        anchored_rep_jacobian(rep_f, p.opt.do_fej, p.tab_cam + 12 * anchor_cam, p.tab_clone + 24 * anchor_clone, load_v3(p.p_FinA + 3 * f), dl,
                               hq + 21, hq + 39);
       }
     }

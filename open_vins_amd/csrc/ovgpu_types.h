@@ -72,6 +72,7 @@ struct SysParams {
   // UpdaterSLAM::update mode (landmarks live in the state): no nullspace projection, gate on all 2m rows
   int slam;
   int lm_size;              // 3, or 1 for ANCHORED_INVERSE_DEPTH_SINGLE landmarks (the bearing columns of H_f are projected out)
+  const int32_t *lm_rep;    // SLAM mode: [L] the landmarks' own representations (UpdaterSLAM.cpp:336-341); opt.feat_rep / lm_size are then per feature
   const double *feat_sigma;    // [F] per-feature sigma_pix, or nullptr (the context's)
   const double *feat_chi2mult; // [F] per-feature chi2 multiplier, or nullptr
   int init_dof_less;        // init mode: 0, or 2 for a single-depth landmark (StateHelper::initialize sees 2m - 2 residual rows)

@@ -5,9 +5,9 @@
 // Unlike the mode-A shims this one has to WRITE State::_Cov and State::_variables, which are private with `friend class
 // StateHelper` (State.h:182-192): it needs the one line of ovgpu_state_access.h added to the reference.  Without that patch keep
 // the reference's delayed_init: it keeps working on the GPU triangulation through the FeatureInitializer shim, with the
-// StateHelper::initialize chain on the CPU.  This file initialises every feature in StateOptions::feat_rep_slam, ArUco corners
-// included (their sigma and chi2 multiplier come from _options_aruco); a build with feat_rep_aruco != feat_rep_slam keeps the
-// reference's delayed_init for the tags.
+// StateHelper::initialize chain on the CPU.  Every feature is initialised in the representation the reference gives it —
+// StateOptions::feat_rep_aruco for an ArUco corner, feat_rep_slam otherwise (:160-166; ovgpu_set_feature_reps, ABI 7) — with the
+// ArUco corners' sigma and chi2 multiplier from _options_aruco, next to resident landmarks of any representation.
 #include "UpdaterSLAM.h"
 
 #include "ovgpu_shim_common.h"
@@ -20,22 +20,21 @@ using namespace ov_msckf;
 void UpdaterSLAM::delayed_init(std::shared_ptr<State> state, std::vector<std::shared_ptr<Feature>> &feature_vec) {
   if (feature_vec.empty()) return; // :64-65
   const auto rep = state->_options.feat_rep_slam;
-  const bool single = rep == LandmarkRepresentation::Representation::ANCHORED_INVERSE_DEPTH_SINGLE;
-  const bool relative = LandmarkRepresentation::is_relative_representation(rep);
-  const int lsz = single ? 1 : 3; // landmark size, :199
+  auto is_single = [](LandmarkRepresentation::Representation r) { return r == LandmarkRepresentation::Representation::ANCHORED_INVERSE_DEPTH_SINGLE; };
   const ovgpu_shim::StateSnapshot snap(state);
   const ovgpu_shim::CloneIndex clones(snap.fs.clone_times);
   const int N0 = snap.fs.N;
 
   // ---- landmarks already in the state: resident so that every update of the chain corrects them
   ovgpu_shim::FlatLandmarks old;
-  for (const auto &kv : state->_features_SLAM)
-    if (kv.second->_feat_representation == rep) old.add(kv.second, snap, clones); // the others are corrected below through dx_seq
+  for (const auto &kv : state->_features_SLAM) old.add(kv.second, snap, clones);
 
   // ---- 1. clean the tracks (:75-96) and flatten them
   static thread_local ovgpu_shim::FlatFeatures ff; // reused from update to update: a fresh 3.5 MB of buffers per call costs more in page faults than the flattening itself
   ff.clear();
   std::vector<double> f_sigma, f_mult; // ArUco corners use _options_aruco (:226-232)
+  std::vector<int32_t> f_rep;          // ... and StateOptions::feat_rep_aruco (:160-166)
+  int Nmax = N0;
   bool any_aruco = false;
   for (auto it = feature_vec.begin(); it != feature_vec.end();) {
     if (ovgpu_shim::flatten_track(**it, snap, clones, ff) < 2) { // :91-93
@@ -48,6 +47,9 @@ void UpdaterSLAM::delayed_init(std::shared_ptr<State> state, std::vector<std::sh
     any_aruco |= is_aruco;
     f_sigma.push_back(is_aruco ? _options_aruco.sigma_pix : _options_slam.sigma_pix);
     f_mult.push_back(is_aruco ? _options_aruco.chi2_multipler : _options_slam.chi2_multipler);
+    const auto frep = is_aruco ? state->_options.feat_rep_aruco : rep;
+    f_rep.push_back((int32_t)frep);
+    Nmax += is_single(frep) ? 1 : 3; // landmark size, :199
     ++it;
   }
   if (feature_vec.empty()) return;
@@ -57,12 +59,13 @@ void UpdaterSLAM::delayed_init(std::shared_ptr<State> state, std::vector<std::sh
   ovgpu_ctx *ctx = cx.get();
   const ovgpu_state_view sv = snap.fs.view();
   const ovgpu_features_view fv = ff.view();
-  const ovgpu_landmarks_view lv = old.view((int)rep);
+  const ovgpu_landmarks_view lv = old.view();
   cx.check(ovgpu_set_state(ctx, &sv), "ovgpu_set_state");
   cx.check(ovgpu_set_landmarks(ctx, &lv), "ovgpu_set_landmarks");
   cx.check(ovgpu_set_features(ctx, &fv), "ovgpu_set_features");
   if (any_aruco) cx.check(ovgpu_set_feature_options(ctx, f_sigma.data(), f_mult.data()), "ovgpu_set_feature_options");
-  const int F = fv.F, Nmax = N0 + lsz * F;
+  if (any_aruco && state->_options.feat_rep_aruco != rep) cx.check(ovgpu_set_feature_reps(ctx, f_rep.data()), "ovgpu_set_feature_reps");
+  const int F = fv.F;
   std::vector<int32_t> status(F), new_cov(F), acam(F), aclone(F), tri_anchor(F);
   std::vector<double> new_val(3 * (size_t)F), new_fej(3 * (size_t)F), dx_seq((size_t)F * Nmax), Pout((size_t)Nmax * Nmax), pA(3 * (size_t)F), pG(3 * (size_t)F);
   int32_t N1 = 0;
@@ -72,8 +75,8 @@ void UpdaterSLAM::delayed_init(std::shared_ptr<State> state, std::vector<std::sh
   cx.check(ovgpu_get_triangulation(ctx, pA.data(), pG.data(), tri_anchor.data()), "ovgpu_get_triangulation");
 
   // ---- write the posterior back
-  // (a) variables the library does not hold (IMU, time offset, IMU intrinsics, landmarks of another representation): the
-  //     corrections of the chain, in order (StateHelper.cpp:185-187)
+  // (a) variables the library does not hold (IMU, time offset, IMU intrinsics): the corrections of the chain, in order
+  //     (StateHelper.cpp:185-187)
   std::vector<char> held(N0, 0);
   auto mark = [&](const std::shared_ptr<Type> &v) {
     for (int i = 0; i < v->size(); i++) held[v->id() + i] = 1;
@@ -108,7 +111,7 @@ void UpdaterSLAM::delayed_init(std::shared_ptr<State> state, std::vector<std::sh
     std::vector<double> lv1(3 * (old.lm.size() + (size_t)F));
     cx.check(ovgpu_get_landmarks(ctx, &L1, lv1.data(), nullptr, nullptr, nullptr, nullptr), "ovgpu_get_landmarks");
     for (size_t l = 0; l < old.lm.size(); l++) {
-      if (single) old.lm[l]->set_value(Eigen::Matrix<double, 1, 1>(lv1[3 * l + 2]));
+      if (is_single(old.lm[l]->_feat_representation)) old.lm[l]->set_value(Eigen::Matrix<double, 1, 1>(lv1[3 * l + 2]));
       else old.lm[l]->set_value(Eigen::Map<const Eigen::Vector3d>(lv1.data() + 3 * l));
     }
   }
@@ -124,9 +127,11 @@ void UpdaterSLAM::delayed_init(std::shared_ptr<State> state, std::vector<std::sh
       it = feature_vec.erase(it);
       continue;
     }
-    auto landmark = std::make_shared<Landmark>(lsz);
+    const auto frep = (LandmarkRepresentation::Representation)f_rep[f];
+    const bool single = is_single(frep), relative = LandmarkRepresentation::is_relative_representation(frep);
+    auto landmark = std::make_shared<Landmark>(single ? 1 : 3);
     landmark->_featid = (*it)->featid;
-    landmark->_feat_representation = rep;
+    landmark->_feat_representation = frep;
     landmark->_unique_camera_id = (*it)->anchor_cam_id; // :214 (VioManager.cpp:469-471 asserts it and decides should_marg with it)
     if (relative) {
       landmark->_anchor_cam_id = (int)snap.cam_ids[acam[f]];

@@ -1,9 +1,9 @@
 // Drop-in replacement for the body of ov_msckf::UpdaterSLAM::update (ov_msckf/src/update/UpdaterSLAM.cpp:253-479,
 // rpng/open_vins v2.7).  Delete that definition from UpdaterSLAM.cpp and compile this file next to it (the class declaration,
 // the constructor and perform_anchor_change stay the reference's).  Mode A by default, -DOVGPU_SHIM_MODE_B as in UpdaterMSCKF.cpp.
-// Landmark representations: all six (LandmarkRepresentation.h:38-46).  Landmarks whose representation differs from
-// StateOptions::feat_rep_slam (ArUco tags with feat_rep_aruco != feat_rep_slam) are updated in a second pass of the same code:
-// one call of the library holds one representation.
+// Landmark representations: all six (LandmarkRepresentation.h:38-46), in any mix: every landmark is handed over with its own
+// _feat_representation (ovgpu_landmarks_view::feat_rep_each, ABI 7), so SLAM landmarks in feat_rep_slam and ArUco corners in a
+// different feat_rep_aruco share ONE stacked system and one EKF update, as :427-447 builds them (two passes before round 5).
 #include "UpdaterSLAM.h"
 
 #include "ovgpu_shim_common.h"
@@ -16,9 +16,7 @@ using namespace ov_type;
 using namespace ov_msckf;
 
 namespace {
-// one pass: the tracks of feature_vec whose landmark uses representation `rep`; the others stay in `later`
-void update_pass(UpdaterOptions &opt_slam, UpdaterOptions &opt_aruco, std::shared_ptr<State> state, std::vector<std::shared_ptr<Feature>> &feature_vec,
-                 LandmarkRepresentation::Representation rep, std::vector<std::shared_ptr<Feature>> &later) {
+void update_all(UpdaterOptions &opt_slam, UpdaterOptions &opt_aruco, std::shared_ptr<State> state, std::vector<std::shared_ptr<Feature>> &feature_vec) {
   const ovgpu_shim::StateSnapshot snap(state);
   const ovgpu_shim::CloneIndex clones(snap.fs.clone_times);
   static thread_local ovgpu_shim::FlatFeatures ff; // reused from update to update: a fresh 3.5 MB of buffers per call costs more in page faults than the flattening itself
@@ -30,11 +28,6 @@ void update_pass(UpdaterOptions &opt_slam, UpdaterOptions &opt_aruco, std::share
   std::vector<std::shared_ptr<Type>> var_of_cov = snap.var_of_cov;
   for (auto it = feature_vec.begin(); it != feature_vec.end();) {
     std::shared_ptr<Landmark> landmark = state->_features_SLAM.at((*it)->featid);
-    if (landmark->_feat_representation != rep) { // another representation: next pass
-      later.push_back(*it);
-      it = feature_vec.erase(it);
-      continue;
-    }
     // :283-295.  The single-depth representation needs two measurements (its bearing is projected out); a landmark with exactly one
     // is dropped from THIS update without to_delete, so that FeatureDatabase::cleanup keeps the measurement for the next frame.
     const int ct_meas = ovgpu_shim::flatten_track(**it, snap, clones, ff);
@@ -64,7 +57,7 @@ void update_pass(UpdaterOptions &opt_slam, UpdaterOptions &opt_aruco, std::share
   ovgpu_shim::Context &ctx = ovgpu_shim::context_for(ovgpu_shim::make_options(opt_slam, fo, state->_options, OVGPU_REP_GLOBAL_3D));
   const ovgpu_state_view sv = snap.fs.view();
   const ovgpu_features_view fv = ff.view();
-  const ovgpu_landmarks_view lv = fl.view((int)rep);
+  const ovgpu_landmarks_view lv = fl.view();
   ctx.check(ovgpu_set_state(ctx.get(), &sv), "ovgpu_set_state");
   ctx.check(ovgpu_set_landmarks(ctx.get(), &lv), "ovgpu_set_landmarks");
   ctx.check(ovgpu_set_features(ctx.get(), &fv), "ovgpu_set_features");
@@ -109,11 +102,5 @@ void update_pass(UpdaterOptions &opt_slam, UpdaterOptions &opt_aruco, std::share
 
 void UpdaterSLAM::update(std::shared_ptr<State> state, std::vector<std::shared_ptr<Feature>> &feature_vec) {
   if (feature_vec.empty()) return; // :256-257
-  std::vector<std::shared_ptr<Feature>> later, none;
-  update_pass(_options_slam, _options_aruco, state, feature_vec, state->_options.feat_rep_slam, later);
-  if (!later.empty()) { // ArUco tags in feat_rep_aruco: the same code on the state the first pass left
-    update_pass(_options_slam, _options_aruco, state, later, state->_options.feat_rep_aruco, none);
-    feature_vec.insert(feature_vec.end(), later.begin(), later.end()); // the survivors of both passes, as the reference leaves them
-    for (auto &x : none) x->to_delete = true; // a third representation does not exist in the reference
-  }
+  update_all(_options_slam, _options_aruco, state, feature_vec);
 }

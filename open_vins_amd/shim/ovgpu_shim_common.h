@@ -223,7 +223,7 @@ inline void ekf_update_with(const std::shared_ptr<ov_msckf::State> &state, const
 // Landmark.cpp:57-60, :124-140), its anchor as (camera index, clone index)
 struct FlatLandmarks {
   std::vector<double> value, fej;
-  std::vector<int32_t> cov, anchor_cam, anchor_clone;
+  std::vector<int32_t> cov, anchor_cam, anchor_clone, rep; // rep: Landmark::_feat_representation of each (ABI 7: one view, any mix)
   std::vector<std::shared_ptr<ov_type::Landmark>> lm;
   void add(const std::shared_ptr<ov_type::Landmark> &l, const StateSnapshot &snap, const CloneIndex &clones) {
     const auto rep = l->_feat_representation;
@@ -238,13 +238,14 @@ struct FlatLandmarks {
     }
     value.insert(value.end(), v.data(), v.data() + 3), fej.insert(fej.end(), vf.data(), vf.data() + 3);
     cov.push_back(l->id());
+    this->rep.push_back((int32_t)rep); // ovgpu_feat_rep follows the enum order of LandmarkRepresentation.h:38-46
     anchor_cam.push_back(relative ? snap.cam_index.at(l->_anchor_cam_id) : -1);
     anchor_clone.push_back(relative ? clones.find(l->_anchor_clone_timestamp) : -1);
     lm.push_back(l);
   }
-  ovgpu_landmarks_view view(int rep) const {
+  ovgpu_landmarks_view view() const {
     ovgpu_landmarks_view lv;
-    lv.L = (int32_t)cov.size(), lv.feat_rep = rep; // ovgpu_feat_rep follows the enum order of LandmarkRepresentation.h:38-46
+    lv.L = (int32_t)cov.size(), lv.feat_rep = rep.empty() ? 0 : rep[0], lv.feat_rep_each = rep.data();
     lv.p_value = value.data(), lv.p_fej = fej.data(), lv.cov_id = cov.data(), lv.anchor_cam = anchor_cam.data(), lv.anchor_clone = anchor_clone.data();
     return lv;
   }

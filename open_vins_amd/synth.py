@@ -527,35 +527,49 @@ def make_slam_problem(cfg=2, L=20, *, lm_rep=0, lm_noise=0.05, seed=None, **kw) 
     prob = make_problem(cfg, F=L, seed=seed, **kw)
     rng = np.random.default_rng([prob.seed, 7])
     N0 = prob.N
-    sz = 1 if lm_rep == 5 else 3  # state dof of a landmark
-    N = N0 + sz * L
+    # lm_rep: one representation for all, or one per landmark (ArUco corners in StateOptions::feat_rep_aruco next to landmarks in
+    # feat_rep_slam: UpdaterSLAM::update reads the representation from each landmark, UpdaterSLAM.cpp:336-341)
+    reps = np.full(L, int(lm_rep), np.int32) if np.isscalar(lm_rep) else np.ascontiguousarray(lm_rep, dtype=np.int32)
+    assert reps.shape == (L,)
+    mixed = not np.isscalar(lm_rep)
+    szs = np.where(reps == 5, 1, 3)  # state dof of each landmark
+    N = N0 + int(szs.sum())
     xyz = prob.p_FinG_true + rng.normal(0, lm_noise, (L, 3))
     xyz_fej = xyz + rng.normal(0, lm_noise / 5, (L, 3))
-    prob.lm_rep = int(lm_rep)
-    if lm_rep >= 2:
+    prob.lm_rep = int(reps[0]) if L else 0
+    prob.lm_rep_each = reps if mixed else None
+    if (reps >= 2).any():
         first = prob.meas_offsets[:-1]
-        prob.lm_anchor_cam = prob.cam_idx[first].astype(np.int32)
-        prob.lm_anchor_clone = prob.clone_idx[first].astype(np.int32)
+        prob.lm_anchor_cam = np.where(reps >= 2, prob.cam_idx[first], -1).astype(np.int32)
+        prob.lm_anchor_clone = np.where(reps >= 2, prob.clone_idx[first], -1).astype(np.int32)
 
         def to_anchor(p):
-            out = np.zeros_like(p)
+            out = p.copy()
             for l in range(L):
+                if reps[l] < 2:
+                    continue
                 qc, qk = prob.clone_q_p[prob.lm_anchor_clone[l]], prob.calib_q_p[prob.lm_anchor_cam[l]]
                 R_GtoI, R_ItoC = quat_2_rot(qc[:4]), quat_2_rot(qk[:4])
                 out[l] = R_ItoC @ (R_GtoI @ (p[l] - qc[4:7])) + qk[4:7]
             return out
 
         xyz, xyz_fej = to_anchor(xyz), to_anchor(xyz_fej)
-    prob.lm_value = np.ascontiguousarray(landmark_from_xyz(lm_rep, xyz))
-    prob.lm_fej = np.ascontiguousarray(landmark_from_xyz(lm_rep, xyz_fej))
-    prob.lm_cov_id = (N0 + sz * np.arange(L)).astype(np.int32)
+    val, fej = np.zeros((L, 3)), np.zeros((L, 3))
+    for r in np.unique(reps):
+        sel = reps == r
+        val[sel], fej[sel] = landmark_from_xyz(int(r), xyz[sel]), landmark_from_xyz(int(r), xyz_fej[sel])
+    prob.lm_value = np.ascontiguousarray(val)
+    prob.lm_fej = np.ascontiguousarray(fej)
+    prob.lm_cov_id = (N0 + np.concatenate([[0], np.cumsum(szs)[:-1]])).astype(np.int32) if L else np.zeros(0, np.int32)
     prob.lm_index = np.arange(L, dtype=np.int32)
-    lm_sig = np.full((L, 3), 2 * lm_noise)
-    if lm_rep in (1, 3, 4, 5):  # angles / normalised coordinates and an inverse depth: scale the sigma to the coordinates
-        depth = np.linalg.norm(xyz, axis=1)
-        lm_sig = np.stack([2 * lm_noise / depth, 2 * lm_noise / depth, 2 * lm_noise / depth ** 2], axis=1)
-    if sz == 1:
-        lm_sig = lm_sig[:, 2:3]  # only the inverse depth is a state variable
+    depth = np.linalg.norm(xyz, axis=1)
+    lm_sig_parts = []
+    for l in range(L):
+        sg = np.full(3, 2 * lm_noise)
+        if reps[l] in (1, 3, 4, 5):  # angles / normalised coordinates and an inverse depth: scale the sigma to the coordinates
+            sg = np.array([2 * lm_noise / depth[l], 2 * lm_noise / depth[l], 2 * lm_noise / depth[l] ** 2])
+        lm_sig_parts.append(sg[2:3] if szs[l] == 1 else sg)  # single depth: only the inverse depth is a state variable
+    lm_sig = np.concatenate(lm_sig_parts) if L else np.zeros(0)
     sig = np.concatenate([state_sigmas(prob.C, prob.K), lm_sig.reshape(-1)])
     G = np.tril(rng.normal(0, 1.0 / np.sqrt(N), (N, N)), -1)
     Lc = sig[:, None] * (np.eye(N) + 0.1 * G)

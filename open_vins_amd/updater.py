@@ -227,11 +227,16 @@ class UpdaterMSCKF:
         return out
 
     # ---- UpdaterSLAM::delayed_init (UpdaterSLAM.cpp:61-251) -------------
-    def delayed_init(self, feat_rep=0):
+    def delayed_init(self, feat_rep=0, feat_rep_each=None):
         """Runs the delayed initialisation on the resident state and tracks (set_problem / set_slam_problem first;
-        set_triangulation optionally replaces the triangulation stage).  The state grows by 3 per accepted feature."""
+        set_triangulation optionally replaces the triangulation stage).  The state grows by 3 (1: single depth) per accepted
+        feature.  feat_rep_each [F]: the representation per feature (UpdaterSLAM.cpp:160-166: feat_rep_aruco for ArUco corners)."""
         F, N = self.F, self.N
-        Nmax = N + (1 if int(feat_rep) == capi.REP_ANCHORED_INVERSE_DEPTH_SINGLE else 3) * F
+        reps = np.full(F, int(feat_rep), np.int32)
+        if feat_rep_each is not None:
+            reps = np.ascontiguousarray(feat_rep_each, dtype=np.int32)
+            capi.check(self.lib.ovgpu_set_feature_reps(self._ctx, _ip(reps)), "ovgpu_set_feature_reps")
+        Nmax = N + int(np.where(reps == capi.REP_ANCHORED_INVERSE_DEPTH_SINGLE, 1, 3).sum())
         out = dict(feat_status=np.zeros(F, np.int32), chi2=np.zeros(F), chi2_thresh=np.zeros(F), lm_cov_id=np.zeros(F, np.int32),
                    lm_value=np.zeros((F, 3)), lm_fej=np.zeros((F, 3)), anchor_cam=np.zeros(F, np.int32), anchor_clone=np.zeros(F, np.int32),
                    dx_seq=np.zeros((F, Nmax)))
@@ -255,8 +260,9 @@ class UpdaterMSCKF:
         capi.check(self.lib.ovgpu_get_landmarks(self._ctx, C.byref(L), None, None, None, None, None), "ovgpu_get_landmarks")
         n = L.value
         out = dict(value=np.zeros((n, 3)), fej=np.zeros((n, 3)), cov_id=np.zeros(n, np.int32), anchor_cam=np.zeros(n, np.int32),
-                   anchor_clone=np.zeros(n, np.int32))
+                   anchor_clone=np.zeros(n, np.int32), feat_rep=np.zeros(n, np.int32))
         if n:
+            capi.check(self.lib.ovgpu_get_landmark_reps(self._ctx, C.byref(L), _ip(out["feat_rep"])), "ovgpu_get_landmark_reps")
             capi.check(self.lib.ovgpu_get_landmarks(self._ctx, C.byref(L), _dp(out["value"]), _dp(out["fej"]), _ip(out["cov_id"]),
                                                     _ip(out["anchor_cam"]), _ip(out["anchor_clone"])), "ovgpu_get_landmarks")
         return out

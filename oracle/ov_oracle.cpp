@@ -1541,7 +1541,8 @@ int oracle_msckf_update_given(const ovgpu_options *opts, const ovgpu_state_view 
 }
 
 // ---------------------------------------------------------------------------
-// UpdaterSLAM::update — UpdaterSLAM.cpp:253-479, landmarks in any 3-dof representation (lm->feat_rep).
+// UpdaterSLAM::update — UpdaterSLAM.cpp:253-479, every landmark in its own representation (lm->feat_rep_each, or lm->feat_rep for
+// all: the reference reads landmark->_feat_representation per feature, :336-341).
 // Column order: the canonical map of the MSCKF path with the landmarks merged in
 // by covariance id (the reference's is "first seen"; any order gives the same
 // update).  Unused variables keep zero columns.
@@ -1552,6 +1553,7 @@ int oracle_slam_update(const ovgpu_options *opts, const ovgpu_state_view *st, co
                        ovgpu_update_stats *stats, const double *feat_sigma, const double *feat_chi2mult) {
   const ovgpu_options &o = *opts;
   const int F = fv->F, N = st->N, L = lm->L;
+  auto lm_rep_of = [&](int l) { return lm->feat_rep_each ? (int)lm->feat_rep_each[l] : (int)lm->feat_rep; };
   std::vector<double> noise_rows; // R_big's diagonal when the features do not share one sigma (:444)
   StateTables T = build_tables(st);
   ColumnMap cm = build_column_map(o, st);
@@ -1562,7 +1564,7 @@ int oracle_slam_update(const ovgpu_options *opts, const ovgpu_state_view *st, co
   {
     int col = 0;
     for (const VarRef &v : cm.vars) ents.push_back({v.cov_id, v.size, (int)(&v - &cm.vars[0]), -1}), col += v.size;
-    for (int l = 0; l < L; l++) ents.push_back({lm->cov_id[l], lm->feat_rep == OVGPU_REP_ANCHORED_INVERSE_DEPTH_SINGLE ? 1 : 3, -1, l});
+    for (int l = 0; l < L; l++) ents.push_back({lm->cov_id[l], lm_rep_of(l) == OVGPU_REP_ANCHORED_INVERSE_DEPTH_SINGLE ? 1 : 3, -1, l});
     std::stable_sort(ents.begin(), ents.end(), [](const Ent &a, const Ent &b) { return a.cov < b.cov; });
   }
   std::vector<int> base_col(cm.vars.size(), -1), lm_col(L, -1);
@@ -1604,12 +1606,12 @@ int oracle_slam_update(const ovgpu_options *opts, const ovgpu_state_view *st, co
       continue;
     }
     const int l = lm_index[f];
-    const bool single = lm->feat_rep == OVGPU_REP_ANCHORED_INVERSE_DEPTH_SINGLE;
+    const bool single = lm_rep_of(l) == OVGPU_REP_ANCHORED_INVERSE_DEPTH_SINGLE;
     if (single && m < 2) { // one measurement leaves no row once the bearing is projected out
       status[f] = OVGPU_FEAT_TOO_FEW_MEAS;
       continue;
     }
-    const int lrep = single ? OVGPU_REP_ANCHORED_MSCKF_INVERSE_DEPTH : lm->feat_rep; // :338-341
+    const int lrep = single ? OVGPU_REP_ANCHORED_MSCKF_INVERSE_DEPTH : lm_rep_of(l); // :338-341
     // :345-353: get_xyz of the landmark, in the anchor frame for an anchored representation
     V3 pG = landmark_get_xyz(lrep, lm->p_value + 3 * l);
     V3 pF = landmark_get_xyz(lrep, lm->p_fej + 3 * l);
@@ -1690,7 +1692,7 @@ int oracle_slam_update(const ovgpu_options *opts, const ovgpu_state_view *st, co
   if (lm_out)
     for (int l = 0; l < L; l++)
       for (int i = 0; i < 3; i++) { // Landmark::update, Landmark.h:80-89 (single depth: only rho is a state variable)
-        const bool sgl = lm->feat_rep == OVGPU_REP_ANCHORED_INVERSE_DEPTH_SINGLE;
+        const bool sgl = lm_rep_of(l) == OVGPU_REP_ANCHORED_INVERSE_DEPTH_SINGLE;
         lm_out[3 * l + i] = lm->p_value[3 * l + i] + (sgl ? (i == 2 ? dx[lm->cov_id[l]] : 0.0) : dx[lm->cov_id[l] + i]);
       }
   if (D_out) *D_out = Dt;
@@ -1719,10 +1721,17 @@ int oracle_slam_delayed_init(const ovgpu_options *opts, const ovgpu_state_view *
                              double *chi2_thresh_out, int32_t *lm_cov_id, double *lm_value, double *lm_fej, int32_t *anchor_cam_out,
                              int32_t *anchor_clone_out, double *dx_seq, int32_t *N_out, double *P_out, double *clone_q_p_out,
                              double *calib_q_p_out, double *intrinsics_out, double *lm_existing_out, const double *feat_sigma,
-                             const double *feat_chi2mult) {
+                             const double *feat_chi2mult, const int32_t *feat_rep_each) {
   const ovgpu_options &o = *opts;
-  const int F = fv->F, N0 = st_in->N, C = st_in->C, K = st_in->K, Nmax = N0 + (feat_rep == OVGPU_REP_ANCHORED_INVERSE_DEPTH_SINGLE ? 1 : 3) * F;
+  // :160-166: the representation is chosen per feature (feat_rep_aruco for an ArUco corner, feat_rep_slam otherwise)
+  const int feat_rep_all = feat_rep;
+  auto rep_of = [&](int f) { return feat_rep_each ? (int)feat_rep_each[f] : feat_rep_all; };
+  auto dof_of = [](int rep) { return rep == OVGPU_REP_ANCHORED_INVERSE_DEPTH_SINGLE ? 1 : 3; };
+  const int F = fv->F, N0 = st_in->N, C = st_in->C, K = st_in->K;
+  int Nmax = N0;
+  for (int f = 0; f < F; f++) Nmax += dof_of(rep_of(f));
   const int L0 = lm ? lm->L : 0;
+  auto lm_rep_of = [&](int l) { return lm->feat_rep_each ? (int)lm->feat_rep_each[l] : (int)lm->feat_rep; };
   const double sigma2 = std::pow(o.sigma_pix, 2);
   // mutable copy of the state
   std::vector<double> clone_qp(st_in->clone_q_p, st_in->clone_q_p + 7 * C), calib_qp(st_in->calib_q_p, st_in->calib_q_p + 7 * K),
@@ -1775,6 +1784,7 @@ int oracle_slam_delayed_init(const ovgpu_options *opts, const ovgpu_state_view *
     const int m = fm.m1 - fm.m0;
     int n = 2 * m;
     StateTables T = build_tables(&st); // the CURRENT state estimate (FEJ values never change)
+    const int feat_rep = rep_of(f);
     const bool single = feat_rep == OVGPU_REP_ANCHORED_INVERSE_DEPTH_SINGLE;
     const int jrep = single ? OVGPU_REP_ANCHORED_MSCKF_INVERSE_DEPTH : feat_rep; // :151-155
     const int nL = single ? 1 : 3;                                                // landmark_size :199
@@ -1924,11 +1934,15 @@ int oracle_slam_delayed_init(const ovgpu_options *opts, const ovgpu_state_view *
       oracle_apply_dx(opts, &st, dx.data(), cq.data(), kq.data(), iq.data());
       clone_qp = cq, calib_qp = kq, intr = iq;
       st.clone_q_p = clone_qp.data(), st.calib_q_p = calib_qp.data(), st.intrinsics = intr.data();
-      for (int l = 0; l < L0; l++)
-        for (int i = 0; i < nL; i++) lm_old[3 * l + (3 - nL) + i] += dx[lm->cov_id[l] + i];
+      for (int l = 0; l < L0; l++) {
+        const int nl = dof_of(lm_rep_of(l));
+        for (int i = 0; i < nl; i++) lm_old[3 * l + (3 - nl) + i] += dx[lm->cov_id[l] + i];
+      }
       for (int g = 0; g <= f; g++)
-        if (new_cov[g] >= 0)
-          for (int i = 0; i < nL; i++) new_val[3 * g + (3 - nL) + i] += dx[new_cov[g] + i];
+        if (new_cov[g] >= 0) {
+          const int ng = dof_of(rep_of(g));
+          for (int i = 0; i < ng; i++) new_val[3 * g + (3 - ng) + i] += dx[new_cov[g] + i];
+        }
     }
   }
   for (int f = 0; f < F; f++) {
@@ -1940,7 +1954,7 @@ int oracle_slam_delayed_init(const ovgpu_options *opts, const ovgpu_state_view *
       if (lm_value) lm_value[3 * f + i] = new_val[3 * f + i];
       if (lm_fej) lm_fej[3 * f + i] = new_fej[3 * f + i];
     }
-    const bool rel = is_relative(feat_rep) && new_cov[f] >= 0;
+    const bool rel = is_relative(rep_of(f)) && new_cov[f] >= 0;
     if (anchor_cam_out) anchor_cam_out[f] = rel ? fv->cam_idx[anchor[f]] : -1;
     if (anchor_clone_out) anchor_clone_out[f] = rel ? fv->clone_idx[anchor[f]] : -1;
   }
@@ -2026,7 +2040,7 @@ int oracle_propagate(double *P, int N, int start_id, int n_new, int n_old, const
 int oracle_anchor_change(const ovgpu_options *opts, const ovgpu_state_view *st, const ovgpu_landmarks_view *lm, int l, int new_cam, int new_clone,
                          double *P_out, double *value_out, double *fej_out) {
   const ovgpu_options &o = *opts;
-  const int rep = lm->feat_rep, N = st->N;
+  const int rep = lm->feat_rep_each ? lm->feat_rep_each[l] : lm->feat_rep, N = st->N;
   if (!is_relative(rep)) return OVGPU_ERR_INVALID;
   StateTables T = build_tables(st);
   const bool single = rep == OVGPU_REP_ANCHORED_INVERSE_DEPTH_SINGLE;

@@ -133,7 +133,7 @@ int oracle_slam_delayed_init(const ovgpu_options *opts, const ovgpu_state_view *
                              double *chi2_thresh_out, int32_t *lm_cov_id, double *lm_value, double *lm_fej, int32_t *anchor_cam_out,
                              int32_t *anchor_clone_out, double *dx_seq, int32_t *N_out, double *P_out, double *clone_q_p_out,
                              double *calib_q_p_out, double *intrinsics_out, double *lm_existing_out, const double *feat_sigma,
-                             const double *feat_chi2mult);
+                             const double *feat_chi2mult, const int32_t *feat_rep_each /* optional [F]: per feature, UpdaterSLAM.cpp:160-166 */);
 
 /* Window bookkeeping: StateHelper::marginalize (StateHelper.cpp:271-339), clone + augment_clone's time-offset
  * part (:341-391, :601-611), EKFPropagation (:36-114) on dense row-major covariances. */

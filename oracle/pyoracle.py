@@ -229,12 +229,13 @@ def slam_update(opts, views, want_stack=False, feat_sigma=None, feat_chi2mult=No
     return out
 
 
-def slam_delayed_init(opts, views, feat_rep=0, tri=None, feat_sigma=None, feat_chi2mult=None):
+def slam_delayed_init(opts, views, feat_rep=0, tri=None, feat_sigma=None, feat_chi2mult=None, feat_rep_each=None):
     """UpdaterSLAM::delayed_init + StateHelper::initialize (oracle_slam_delayed_init).  `tri` (the dict of
     triangulate()) replaces the triangulation stage.  views may carry landmarks already in the state."""
     lib = load()
     F, N, Cn, K = views.features.F, views.state.N, views.state.C, views.state.K
-    Nmax = N + (1 if int(feat_rep) == capi.REP_ANCHORED_INVERSE_DEPTH_SINGLE else 3) * F
+    reps = np.full(F, int(feat_rep), np.int32) if feat_rep_each is None else np.ascontiguousarray(feat_rep_each, dtype=np.int32)
+    Nmax = N + int(np.where(reps == capi.REP_ANCHORED_INVERSE_DEPTH_SINGLE, 1, 3).sum())
     L0 = views.landmarks.L if views.landmarks is not None else 0
     out = dict(feat_status=np.zeros(F, dtype=np.int32), chi2=np.zeros(F), chi2_thresh=np.zeros(F), lm_cov_id=np.zeros(F, dtype=np.int32),
                lm_value=np.zeros((F, 3)), lm_fej=np.zeros((F, 3)), anchor_cam=np.zeros(F, dtype=np.int32), anchor_clone=np.zeros(F, dtype=np.int32),
@@ -254,7 +255,8 @@ def slam_delayed_init(opts, views, feat_rep=0, tri=None, feat_sigma=None, feat_c
                                       _pi(g["an"]) if g else None, _pi(g["st"]) if g else None, _pi(out["feat_status"]), _p(out["chi2"]),
                                       _p(out["chi2_thresh"]), _pi(out["lm_cov_id"]), _p(out["lm_value"]), _p(out["lm_fej"]), _pi(out["anchor_cam"]),
                                       _pi(out["anchor_clone"]), _p(out["dx_seq"]), C.byref(N_out), _p(Pbuf), _p(out["clone_q_p"]),
-                                      _p(out["calib_q_p"]), _p(out["intrinsics"]), _p(out["landmarks_existing"]) if L0 else None, fs_p, fm_p)
+                                      _p(out["calib_q_p"]), _p(out["intrinsics"]), _p(out["landmarks_existing"]) if L0 else None, fs_p, fm_p,
+                                      _pi(reps) if feat_rep_each is not None else None)
     out["rc"] = rc
     n = N_out.value
     out["N"] = n

@@ -203,7 +203,9 @@ def slam_update(opts, views, feat_sigma=None, feat_chi2mult=None):
     return out
 
 
-def slam_delayed_init(opts, views, feat_rep=0, feat_sigma=None, feat_chi2mult=None):
+def slam_delayed_init(opts, views, feat_rep=0, feat_sigma=None, feat_chi2mult=None, feat_rep_aruco=-1, feat_is_aruco=None):
+    """feat_rep_aruco >= 0: StateOptions::feat_rep_aruco — the features that carry their own sigma / multiplier (the ArUco corners) are
+    initialised in it, the others in feat_rep (UpdaterSLAM.cpp:160-166)."""
     F, N, Cn, K = views.features.F, views.state.N, views.state.C, views.state.K
     L0 = views.landmarks.L if views.landmarks is not None else 0
     Nmax = N + 3 * F
@@ -213,11 +215,18 @@ def slam_delayed_init(opts, views, feat_rep=0, feat_sigma=None, feat_chi2mult=No
     Pbuf = np.zeros(Nmax * Nmax)
     N_out = C.c_int32(0)
     is_aruco, sa, ma = _aruco(F, feat_sigma, feat_chi2mult, opts)
+    if feat_is_aruco is not None:  # the ArUco corners named explicitly (they may share the SLAM options and differ in representation only)
+        given = np.ascontiguousarray(feat_is_aruco, dtype=np.int32)
+        if is_aruco is None or not is_aruco.any():
+            sa, ma = float(opts.sigma_pix), float(opts.chi2_multipler)
+        else:
+            assert np.array_equal(given, is_aruco), "features with their own sigma / multiplier are the ArUco corners"
+        is_aruco = given
     rc = load().ref_slam_delayed_init(C.byref(opts), C.byref(views.state), C.byref(views.landmarks) if L0 else None, C.byref(views.features),
                                       C.c_int(int(feat_rep)), _pi(is_aruco), C.c_double(sa), C.c_double(ma), _pi(out["feat_status"]),
                                       _pi(out["lm_cov_id"]), _p(out["lm_value"]), _p(out["lm_fej"]), _pi(out["anchor_cam"]), _pi(out["anchor_clone"]),
                                       C.byref(N_out), _p(Pbuf), _p(out["clone_q_p"]), _p(out["calib_q_p"]), _p(out["intrinsics"]),
-                                      _p(out["landmarks_existing"]) if L0 else None)
+                                      _p(out["landmarks_existing"]) if L0 else None, C.c_int(int(feat_rep_aruco)))
     assert rc == 0
     n = N_out.value
     out["N"] = n

@@ -101,6 +101,8 @@ std::vector<std::shared_ptr<Type>> variables_by_id(const RefState &rs) {
 }
 
 int landmark_dim(int rep) { return rep == OVGPU_REP_ANCHORED_INVERSE_DEPTH_SINGLE ? 1 : 3; }
+// the representation of landmark l of a view: its own (feat_rep_each, ABI 7) or the view's
+int lm_rep_of(const ovgpu_landmarks_view *lm, int l) { return lm->feat_rep_each ? lm->feat_rep_each[l] : lm->feat_rep; }
 
 // Builds the reference State of a view.  imu_value (optional): 16 doubles q, p, v, bg, ba.
 bool build_state(const ovgpu_options *o, const ovgpu_state_view *st, const ovgpu_landmarks_view *lm, const double *imu_value,
@@ -117,7 +119,7 @@ bool build_state(const ovgpu_options *o, const ovgpu_state_view *st, const ovgpu
   so.feat_rep_slam = (Rep)feat_rep_slam;
   so.feat_rep_aruco = (Rep)feat_rep_aruco;
   int ldim = 0;
-  for (int l = 0; l < L; l++) ldim += landmark_dim(lm->feat_rep);
+  for (int l = 0; l < L; l++) ldim += landmark_dim(lm_rep_of(lm, l));
   // rows of the view that the reference state does not model: calibration blocks that carry a covariance id while their flag is off
   // (the synthetic states keep one layout for every flag combination).  The reference then runs on the MARGINAL of the rest,
   // which is exact: H has no columns for those variables, and the sub-block of an EKF update is the update of the sub-block.
@@ -173,7 +175,7 @@ bool build_state(const ovgpu_options *o, const ovgpu_state_view *st, const ovgpu
   // (that call only grows the covariance and registers the variable; the covariance is overwritten below)
   rs.landmarks.resize(L);
   for (int l = 0; l < L; l++) {
-    const int rep = lm->feat_rep, dim = landmark_dim(rep);
+    const int rep = lm_rep_of(lm, l), dim = landmark_dim(rep);
     auto land = std::make_shared<Landmark>(dim);
     land->_featid = (size_t)(max_aruco_features + 1000 + l);
     land->_feat_representation = (Rep)rep;
@@ -642,7 +644,7 @@ int ref_slam_update(const ovgpu_options *o, const ovgpu_state_view *st, const ov
   for (int f = 0; f < fv->F; f++) {
     // erased without to_delete: too few measurements for the representation (UpdaterSLAM.cpp:289-296)
     const int m = fv->meas_offsets[f + 1] - fv->meas_offsets[f];
-    if (feat_status[f] != OVGPU_FEAT_USED && (m < 1 || (lm->feat_rep == OVGPU_REP_ANCHORED_INVERSE_DEPTH_SINGLE && m < 2)))
+    if (feat_status[f] != OVGPU_FEAT_USED && (m < 1 || (lm_rep_of(lm, lm_index[f]) == OVGPU_REP_ANCHORED_INVERSE_DEPTH_SINGLE && m < 2)))
       feat_status[f] = OVGPU_FEAT_TOO_FEW_MEAS;
   }
   export_dx(rs, before, dx, st->N);
@@ -658,10 +660,11 @@ int ref_slam_update(const ovgpu_options *o, const ovgpu_state_view *st, const ov
 int ref_slam_delayed_init(const ovgpu_options *o, const ovgpu_state_view *st, const ovgpu_landmarks_view *lm, const ovgpu_features_view *fv,
                           int feat_rep, const int32_t *feat_is_aruco, double aruco_sigma, double aruco_mult, int32_t *feat_status,
                           int32_t *lm_cov_id, double *lm_value, double *lm_fej, int32_t *anchor_cam, int32_t *anchor_clone, int32_t *N_out,
-                          double *P_out, double *clone_q_p_out, double *calib_q_p_out, double *intrinsics_out, double *lm_existing_out) {
+                          double *P_out, double *clone_q_p_out, double *calib_q_p_out, double *intrinsics_out, double *lm_existing_out,
+                          int feat_rep_aruco /* StateOptions::feat_rep_aruco: the features flagged feat_is_aruco (UpdaterSLAM.cpp:160-166); < 0: feat_rep */) {
   RefState rs;
   const int max_aruco = 1000;
-  if (!build_state(o, st, (lm && lm->L) ? lm : nullptr, nullptr, max_aruco, feat_rep, feat_rep, rs)) return OVGPU_ERR_INVALID;
+  if (!build_state(o, st, (lm && lm->L) ? lm : nullptr, nullptr, max_aruco, feat_rep, feat_rep_aruco < 0 ? feat_rep : feat_rep_aruco, rs)) return OVGPU_ERR_INVALID;
   std::vector<std::shared_ptr<Feature>> probe;
   std::vector<int> stt;
   triangulate_all(o, rs, fv, probe, stt);
@@ -731,7 +734,7 @@ int ref_change_anchors(const ovgpu_options *o, const ovgpu_state_view *st, const
   export_cov(rs, P_out);
   for (int l = 0; l < lm->L; l++) {
     export_landmark(rs.landmarks[l], lm_value + 3 * l, lm_fej + 3 * l);
-    anchor_clone_out[l] = LandmarkRepresentation::is_relative_representation((Rep)lm->feat_rep) ? clone_index_of(rs.landmarks[l]->_anchor_clone_timestamp) : -1;
+    anchor_clone_out[l] = LandmarkRepresentation::is_relative_representation((Rep)lm_rep_of(lm, l)) ? clone_index_of(rs.landmarks[l]->_anchor_clone_timestamp) : -1;
   }
   return OVGPU_OK;
 }

@@ -40,10 +40,11 @@ struct ovgpu_ctx {
   int F = 0, M = 0;
   std::vector<int32_t> offs, clone_idx, cam_idx;
   std::vector<float> uv, uvn;
-  int L = 0, lm_rep = 0;
+  int L = 0;
   std::vector<double> lm_value, lm_fej;
-  std::vector<int32_t> lm_cov, lm_acam, lm_aclone;
+  std::vector<int32_t> lm_cov, lm_acam, lm_aclone, lm_reps; // lm_reps: the representation of every resident landmark (ABI 7)
   std::vector<double> fsig, fmul;
+  std::vector<int32_t> freps; // ovgpu_set_feature_reps
   std::vector<double> pA, pG;
   std::vector<int32_t> anchor;
   // the track store (ovgpu_tracks_*): per track the observations in append order and the cameras in order of first insertion
@@ -77,7 +78,7 @@ struct ovgpu_ctx {
   ovgpu_landmarks_view lv() const {
     ovgpu_landmarks_view v;
     std::memset(&v, 0, sizeof(v));
-    v.L = L, v.feat_rep = lm_rep, v.p_value = lm_value.data(), v.p_fej = lm_fej.data(), v.cov_id = lm_cov.data();
+    v.L = L, v.feat_rep = L > 0 ? lm_reps[0] : 0, v.feat_rep_each = lm_reps.data(), v.p_value = lm_value.data(), v.p_fej = lm_fej.data(), v.cov_id = lm_cov.data();
     v.anchor_cam = lm_acam.data(), v.anchor_clone = lm_aclone.data();
     return v;
   }
@@ -153,7 +154,7 @@ int ovgpu_set_state(ovgpu_ctx *c, const ovgpu_state_view *st) {
   put(c->calib_q_p, st->calib_q_p, 7 * (size_t)st->K), put(c->intr, st->intrinsics, 8 * (size_t)st->K), put(c->fisheye, st->cam_is_fisheye, st->K);
   put(c->calib_cov, st->calib_cov_id, st->K), put(c->intr_cov, st->intr_cov_id, st->K);
   c->have_state = true, c->poses_only = false, c->have_feats = false, c->tri_readable = false;
-  c->L = 0, c->lm_rep = 0, c->lm_value.clear(), c->lm_fej.clear(), c->lm_cov.clear(), c->lm_acam.clear(), c->lm_aclone.clear();
+  c->L = 0, c->lm_reps.clear(), c->lm_value.clear(), c->lm_fej.clear(), c->lm_cov.clear(), c->lm_acam.clear(), c->lm_aclone.clear();
   return OVGPU_OK;
 }
 
@@ -166,7 +167,7 @@ int ovgpu_set_features(ovgpu_ctx *c, const ovgpu_features_view *fv) {
   c->F = fv->F, c->M = fv->M;
   put(c->offs, fv->meas_offsets, (size_t)fv->F + 1);
   put(c->uv, fv->uv, 2 * (size_t)fv->M), put(c->uvn, fv->uvn, 2 * (size_t)fv->M), put(c->clone_idx, fv->clone_idx, fv->M), put(c->cam_idx, fv->cam_idx, fv->M);
-  c->fsig.clear(), c->fmul.clear();
+  c->fsig.clear(), c->fmul.clear(), c->freps.clear();
   c->have_feats = true, c->tri_readable = false;
   return OVGPU_OK;
 }
@@ -174,10 +175,26 @@ int ovgpu_set_features(ovgpu_ctx *c, const ovgpu_features_view *fv) {
 int ovgpu_set_landmarks(ovgpu_ctx *c, const ovgpu_landmarks_view *lm) {
   if (!c || !lm) return fail(OVGPU_ERR_INVALID, "null argument");
   if (!c->have_state) return fail(OVGPU_ERR_NO_STATE, "ovgpu_set_state first");
-  c->L = lm->L, c->lm_rep = lm->feat_rep;
+  c->L = lm->L;
+  if (lm->feat_rep_each) c->lm_reps.assign(lm->feat_rep_each, lm->feat_rep_each + lm->L);
+  else c->lm_reps.assign(lm->L, lm->feat_rep);
   put(c->lm_value, lm->p_value, 3 * (size_t)lm->L), put(c->lm_fej, lm->p_fej, 3 * (size_t)lm->L), put(c->lm_cov, lm->cov_id, lm->L);
   put(c->lm_acam, lm->anchor_cam, lm->L), put(c->lm_aclone, lm->anchor_clone, lm->L);
   c->have_feats = false, c->tri_readable = false; // as the library: the column map changed, ovgpu_set_features must follow
+  return OVGPU_OK;
+}
+
+int ovgpu_set_feature_reps(ovgpu_ctx *c, const int32_t *feat_rep) {
+  if (!c || !c->have_feats) return fail(OVGPU_ERR_NO_STATE, "no feature batch");
+  c->freps.clear();
+  if (feat_rep) c->freps.assign(feat_rep, feat_rep + c->F);
+  return OVGPU_OK;
+}
+
+int ovgpu_get_landmark_reps(ovgpu_ctx *c, int32_t *L_out, int32_t *feat_rep) {
+  if (!c) return fail(OVGPU_ERR_INVALID, "null ctx");
+  if (L_out) *L_out = c->L;
+  if (feat_rep) std::copy(c->lm_reps.begin(), c->lm_reps.end(), feat_rep);
   return OVGPU_OK;
 }
 
@@ -293,19 +310,22 @@ int ovgpu_slam_compress(ovgpu_ctx *c, const int32_t *lm_index, int32_t *feat_sta
 int ovgpu_slam_delayed_init(ovgpu_ctx *c, int32_t feat_rep, int32_t *feat_status, double *chi2, double *chi2_thresh, int32_t *lm_cov_id, double *lm_value, double *lm_fej,
                             int32_t *anchor_cam, int32_t *anchor_clone, double *dx_seq, int32_t *N_out, double *P_out, ovgpu_update_stats *stats) {
   if (!c || !c->have_state || !c->have_feats) return fail(OVGPU_ERR_NO_STATE, "state / features missing");
-  if (c->L > 0 && c->lm_rep != feat_rep) return fail(OVGPU_ERR_INVALID, "the resident landmarks use another representation");
   const ovgpu_state_view s = c->sv();
   const ovgpu_features_view f = c->fv();
   const ovgpu_landmarks_view l = c->lv();
   c->triangulate_now();
-  const int F = c->F, lsz = feat_rep == OVGPU_REP_ANCHORED_INVERSE_DEPTH_SINGLE ? 1 : 3, Nmax = c->N + lsz * F;
+  const int F = c->F;
+  const int32_t *freps = (int)c->freps.size() == F && F > 0 ? c->freps.data() : nullptr;
+  auto rep_of = [&](int i) { return freps ? (int)freps[i] : (int)feat_rep; };
+  int Nmax = c->N;
+  for (int i = 0; i < F; i++) Nmax += rep_of(i) == OVGPU_REP_ANCHORED_INVERSE_DEPTH_SINGLE ? 1 : 3;
   std::vector<int32_t> st(std::max(F, 1)), cov(std::max(F, 1)), ac(std::max(F, 1)), acl(std::max(F, 1));
   std::vector<double> val(3 * (size_t)std::max(F, 1)), fej(3 * (size_t)std::max(F, 1)), dxs((size_t)std::max(F, 1) * Nmax), Pv((size_t)Nmax * Nmax), cq(7 * (size_t)c->C),
       kq(7 * (size_t)c->K), iq(8 * (size_t)c->K), lex(3 * (size_t)std::max(c->L, 1));
   int32_t N1 = 0;
   const int rcode = oracle_slam_delayed_init(&c->o, &s, c->L > 0 ? &l : nullptr, &f, feat_rep, nullptr, nullptr, nullptr, nullptr, st.data(), chi2, chi2_thresh, cov.data(),
                                              val.data(), fej.data(), ac.data(), acl.data(), dxs.data(), &N1, Pv.data(), cq.data(), kq.data(), iq.data(),
-                                             c->L > 0 ? lex.data() : nullptr, c->sig(), c->mul());
+                                             c->L > 0 ? lex.data() : nullptr, c->sig(), c->mul(), freps);
   if (rcode != OVGPU_OK) return fail(rcode, "oracle_slam_delayed_init failed");
   if (feat_status) std::copy(st.begin(), st.begin() + F, feat_status);
   if (lm_cov_id) std::copy(cov.begin(), cov.begin() + F, lm_cov_id);
@@ -320,10 +340,10 @@ int ovgpu_slam_delayed_init(ovgpu_ctx *c, int32_t feat_rep, int32_t *feat_status
   // the resident state afterwards: dimension N1, the accepted landmarks appended to the resident ones
   c->N = N1, c->P.assign(Pv.begin(), Pv.begin() + (size_t)N1 * N1), c->clone_q_p = cq, c->calib_q_p = kq, c->intr = iq;
   if (c->L > 0) c->lm_value.assign(lex.begin(), lex.begin() + 3 * (size_t)c->L);
-  c->lm_rep = feat_rep;
-  const bool relative = feat_rep >= OVGPU_REP_ANCHORED_3D;
   for (int i = 0; i < F; i++) {
     if (cov[i] < 0) continue;
+    const bool relative = rep_of(i) >= OVGPU_REP_ANCHORED_3D;
+    c->lm_reps.push_back(rep_of(i));
     c->lm_value.insert(c->lm_value.end(), val.begin() + 3 * i, val.begin() + 3 * i + 3), c->lm_fej.insert(c->lm_fej.end(), fej.begin() + 3 * i, fej.begin() + 3 * i + 3);
     c->lm_cov.push_back(cov[i]), c->lm_acam.push_back(relative ? ac[i] : -1), c->lm_aclone.push_back(relative ? acl[i] : -1);
     c->L++;
@@ -347,9 +367,8 @@ int ovgpu_get_landmarks(ovgpu_ctx *c, int32_t *L_out, double *value, double *fej
 int ovgpu_slam_change_anchors(ovgpu_ctx *c, int32_t marg_clone, int32_t new_clone, int32_t *n_changed) {
   if (!c || !c->have_state) return fail(OVGPU_ERR_NO_STATE, "no state");
   if (n_changed) *n_changed = 0;
-  if (c->L <= 0 || c->lm_rep < OVGPU_REP_ANCHORED_3D) return OVGPU_OK; // :493-496
   for (int l = 0; l < c->L; l++) {
-    if (c->lm_aclone[l] != marg_clone) continue;
+    if (c->lm_reps[l] < OVGPU_REP_ANCHORED_3D || c->lm_aclone[l] != marg_clone) continue; // :493-496: global landmarks are skipped
     const ovgpu_state_view s = c->sv();
     const ovgpu_landmarks_view lv = c->lv();
     std::vector<double> Pv((size_t)c->N * c->N);

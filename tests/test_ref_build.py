@@ -265,6 +265,87 @@ def test_slam_update_with_aruco_options_against_the_reference(rep):
     assert _rel(pyref.slam_update(opts, v)["dx"], a["dx"]) > 1e-3  # the options matter
 
 
+MIXED_REPS = [  # feat_rep_slam next to feat_rep_aruco (StateOptions.h:89-95), and every representation at once
+    [capi.REP_ANCHORED_MSCKF_INVERSE_DEPTH, capi.REP_GLOBAL_3D],
+    [capi.REP_GLOBAL_3D, capi.REP_ANCHORED_FULL_INVERSE_DEPTH],
+    [capi.REP_ANCHORED_INVERSE_DEPTH_SINGLE, capi.REP_GLOBAL_3D],
+    [capi.REP_ANCHORED_3D, capi.REP_ANCHORED_INVERSE_DEPTH_SINGLE],
+    [0, 1, 2, 3, 4, 5],
+]
+
+
+@pytest.mark.parametrize("reps", MIXED_REPS, ids=lambda r: "-".join(map(str, r)))
+def test_slam_update_mixed_representations_against_the_reference(reps):
+    """UpdaterSLAM.cpp:336-341, :427-447: the representation is read from each landmark, and SLAM landmarks and ArUco corners kept in
+    different representations (feat_rep_slam != feat_rep_aruco) share ONE Hx_big / R_big and one EKFUpdate."""
+    L = 12
+    each = np.array([reps[l % len(reps)] for l in range(L)], np.int32)
+    prob = synth.make_slam_problem(2, L=L, lm_rep=each)
+    opts = capi.default_options(chi2_multipler=1.0)
+    v = capi.Views(prob)
+    tag = each == reps[-1]  # the corners carry the ArUco option set as well
+    sig, mult = np.where(tag, 2.5, 1.0), np.where(tag, 3.0, 1.0)
+    for kw in ({}, dict(feat_sigma=sig, feat_chi2mult=mult)):
+        a, b = pyoracle.slam_update(opts, v, **kw), pyref.slam_update(opts, v, **kw)
+        assert np.array_equal(a["feat_status"], b["feat_status"]) and (a["feat_status"] == capi.FEAT_USED).sum() >= 6
+        assert _rel(b["dx"], a["dx"]) < TOL_DX and _rel(b["P"], a["P"]) < TOL_P
+        assert np.abs(a["landmarks"] - b["landmarks"]).max() < TOL_VAL
+    # ... and it is not what two passes give: the second pass is linearised at the state the first one left
+    first = pyoracle.slam_update(opts, v)
+    assert first["stats"]["n_rows"] == sum(2 * int(prob.meas_offsets[f + 1] - prob.meas_offsets[f]) - (2 if each[f] == 5 else 0)
+                                           for f in range(L) if first["feat_status"][f] == capi.FEAT_USED)
+
+
+@pytest.mark.parametrize("rep_slam,rep_aruco", [(capi.REP_ANCHORED_MSCKF_INVERSE_DEPTH, capi.REP_GLOBAL_3D), (capi.REP_GLOBAL_3D, capi.REP_ANCHORED_INVERSE_DEPTH_SINGLE),
+                                                (capi.REP_ANCHORED_INVERSE_DEPTH_SINGLE, capi.REP_ANCHORED_3D)])
+def test_delayed_init_mixed_representations_against_the_reference(rep_slam, rep_aruco):
+    """UpdaterSLAM.cpp:160-166: an ArUco corner is initialised in feat_rep_aruco, every other feature in feat_rep_slam, one chain."""
+    prob = synth.make_problem(2, F=16, outlier_frac=0.2)
+    opts = capi.default_options(chi2_multipler=1.0)
+    v = capi.Views(prob)
+    tag = np.random.default_rng(5).random(16) < 0.4
+    each = np.where(tag, rep_aruco, rep_slam).astype(np.int32)
+    a = pyoracle.slam_delayed_init(opts, v, feat_rep=rep_slam, feat_rep_each=each)
+    b = pyref.slam_delayed_init(opts, v, feat_rep=rep_slam, feat_rep_aruco=rep_aruco, feat_is_aruco=tag)
+    assert 4 <= (a["lm_cov_id"] >= 0).sum() < 16
+    _check_delayed_init(a, b)
+    sig, mult = np.where(tag, 2.5, 1.0), np.where(tag, 3.0, 1.0)
+    _check_delayed_init(pyoracle.slam_delayed_init(opts, v, feat_rep=rep_slam, feat_rep_each=each, feat_sigma=sig, feat_chi2mult=mult),
+                        pyref.slam_delayed_init(opts, v, feat_rep=rep_slam, feat_rep_aruco=rep_aruco, feat_sigma=sig, feat_chi2mult=mult))
+
+
+def test_delayed_init_beside_landmarks_of_other_representations():
+    """New landmarks in one representation next to resident ones in others (an ArUco batch initialised after SLAM landmarks exist)."""
+    each = np.array([0, 4, 5, 2, 4, 5], np.int32)
+    prob = synth.make_slam_problem(2, L=6, lm_rep=each, C=14)
+    opts = capi.default_options(chi2_multipler=1.0)
+    v = capi.Views(prob)
+    for rep in (capi.REP_GLOBAL_3D, capi.REP_ANCHORED_INVERSE_DEPTH_SINGLE):
+        a = pyoracle.slam_delayed_init(opts, v, feat_rep=rep)
+        b = pyref.slam_delayed_init(opts, v, feat_rep=rep)
+        assert (a["lm_cov_id"] >= 0).sum() >= 3
+        _check_delayed_init(a, b)
+        np.testing.assert_allclose(a["landmarks_existing"], b["landmarks_existing"], rtol=TOL_VAL, atol=TOL_VAL)
+
+
+def test_change_anchors_mixed_representations_against_the_reference():
+    """UpdaterSLAM::change_anchors skips the global landmarks and moves each anchored one in ITS representation (:493-500)."""
+    each = np.array([4, 0, 5, 2, 1, 3, 4, 0, 5, 2], np.int32)
+    prob = synth.make_slam_problem(2, L=10, lm_rep=each)
+    opts = capi.default_options(chi2_multipler=1.0)
+    b = pyref.change_anchors(opts, capi.Views(prob))
+    ref = synth.make_slam_problem(2, L=10, lm_rep=each)
+    moved = np.flatnonzero((prob.lm_anchor_clone == 0) & (each >= 2))
+    assert len(moved) >= 2
+    for l in moved:
+        o = pyoracle.anchor_change(opts, capi.Views(ref), int(l), int(ref.lm_anchor_cam[l]), ref.C - 1)
+        ref.P, ref.lm_value[l], ref.lm_fej[l], ref.lm_anchor_clone[l] = o["P"], o["value"], o["fej"], ref.C - 1
+    assert np.array_equal(b["anchor_clone"], ref.lm_anchor_clone)
+    assert _rel(b["P"], ref.P) < 1e-13
+    np.testing.assert_allclose(b["value"], ref.lm_value, rtol=1e-13, atol=1e-15)
+    np.testing.assert_allclose(b["fej"], ref.lm_fej, rtol=1e-13, atol=1e-15)
+
+
 def _check_delayed_init(a, b):
     assert np.array_equal(a["feat_status"], b["feat_status"])
     assert a["N"] == b["N"] and np.array_equal(a["lm_cov_id"], b["lm_cov_id"])
