@@ -76,6 +76,56 @@ def slam_aruco(mode, rep):
          dx=rel(got["dx"], ref["dx"]), P=rel(got["P"], ref["P"]), landmarks=float(np.abs(got["landmarks"] - ref["landmarks"]).max()), state=state_dev(got, ref))
 
 
+_MIXES = [[4, 0], [0, 3], [5, 0], [2, 5], [0, 1, 2, 3, 4, 5]]  # feat_rep_slam next to feat_rep_aruco; all six at once
+
+
+def slam_mixed(mode, k):
+    """Round 5 (ABI 7): SLAM landmarks and ArUco corners kept in DIFFERENT representations in one UpdaterSLAM::update — the reference stacks them
+    into one Hx_big (UpdaterSLAM.cpp:427-447); the shim hands every landmark over with its own representation and makes ONE library call."""
+    each = np.array([_MIXES[k][l % len(_MIXES[k])] for l in range(12)], np.int32)
+    prob = synth.make_slam_problem(2, L=12, lm_rep=each)
+    opts = capi.default_options(chi2_multipler=1.0)
+    tag = each == _MIXES[k][-1]
+    for name, kw in (("", {}), ("aruco", dict(feat_sigma=np.where(tag, 2.5, 1.0), feat_chi2mult=np.where(tag, 3.0, 1.0)))):
+        if name and mode == "a_cpu":  # (tests/fake_ovgpu does not model the row scaling of ovgpu_slam_compress under per-feature sigma)
+            continue
+        ref = pyref.slam_update(opts, capi.Views(prob), **kw)
+        with pyref.using(pyref.dropin_path(mode)):
+            got = pyref.slam_update(opts, capi.Views(prob), **kw)
+        emit(f"slam:mixed{name}{k}", used=int((ref["feat_status"] == capi.FEAT_USED).sum()), status_equal=bool(np.array_equal(got["feat_status"], ref["feat_status"])),
+             dx=rel(got["dx"], ref["dx"]), P=rel(got["P"], ref["P"]), landmarks=float(np.abs(got["landmarks"] - ref["landmarks"]).max()), state=state_dev(got, ref))
+
+
+def delayed_mixed(mode, k):
+    """UpdaterSLAM::delayed_init with feat_rep_aruco != feat_rep_slam (UpdaterSLAM.cpp:160-166): the corners of the batch are initialised in one
+    representation, the other features in another, in one chain; next to resident landmarks of a third (k = 1)."""
+    rep_slam, rep_aruco = ((4, 0), (0, 5), (5, 2))[k]
+    tag = np.random.default_rng(5).random(16) < 0.4
+    prob = synth.make_problem(2, F=16, outlier_frac=0.2) if k != 1 else synth.make_slam_problem(2, L=16, lm_rep=np.array([4, 2] * 8, np.int32), outlier_frac=0.2)
+    opts = capi.default_options(chi2_multipler=1.0)
+    for name, kw in (("", dict(feat_is_aruco=tag)), ("aruco", dict(feat_sigma=np.where(tag, 2.5, 1.0), feat_chi2mult=np.where(tag, 3.0, 1.0)))):
+        ref = pyref.slam_delayed_init(opts, capi.Views(prob), feat_rep=rep_slam, feat_rep_aruco=rep_aruco, **kw)
+        with pyref.using(pyref.dropin_path(mode)):
+            got = pyref.slam_delayed_init(opts, capi.Views(prob), feat_rep=rep_slam, feat_rep_aruco=rep_aruco, **kw)
+        acc = ref["lm_cov_id"] >= 0
+        same = bool(np.array_equal(got["feat_status"], ref["feat_status"]) and got["N"] == ref["N"] and np.array_equal(got["lm_cov_id"], ref["lm_cov_id"]))
+        old = float(np.abs(got["landmarks_existing"] - ref["landmarks_existing"]).max()) if ref["landmarks_existing"].size else 0.0
+        emit(f"delayed:mixed{name}{k}", accepted=int(acc.sum()), status_equal=same,
+             value=max(float(np.abs(got["lm_value"][acc] - ref["lm_value"][acc]).max()), old) if same and acc.any() else -1.0,
+             P=rel(got["P"], ref["P"]) if same else -1.0, state=state_dev(got, ref))
+
+
+def anchors_mixed(mode, _):
+    each = np.array([4, 0, 5, 2, 1, 3, 4, 0, 5, 2], np.int32)
+    prob = synth.make_slam_problem(2, L=10, lm_rep=each)
+    opts = capi.default_options(chi2_multipler=1.0)
+    ref = pyref.change_anchors(opts, capi.Views(prob))
+    with pyref.using(pyref.dropin_path(mode)):
+        got = pyref.change_anchors(opts, capi.Views(prob))
+    emit("anchors:mixed", moved=int(((prob.lm_anchor_clone == 0) & (each >= 2)).sum()), status_equal=bool(np.array_equal(got["anchor_clone"], ref["anchor_clone"])),
+         P=rel(got["P"], ref["P"]), value=float(np.abs(got["value"] - ref["value"]).max()), fej=float(np.abs(got["fej"] - ref["fej"]).max()))
+
+
 def delayed(mode, rep, aruco=False):
     prob = synth.make_problem(2, F=16, outlier_frac=0.2)
     opts = capi.default_options(chi2_multipler=1.0)
@@ -295,7 +345,8 @@ def sweep(mode):
     emit("sweep", differing=bad, **w)
 
 
-CASES = [("msckf", 0), ("msckf", 3), ("msckf", 7), ("msckf", 11), ("msckf", 19), ("slam", 0), ("slam", 4), ("slam_aruco", 0), ("slam_aruco", 5), ("delayed", 0), ("delayed", 4), ("delayed", 5), ("delayed_aruco", 0), ("anchors", 2), ("anchors", 4), ("zupt", 0), ("zupt", 1), ("loop", 60.0), ("loop_slam", 60.0), ("loop_stereo", 60.0), ("loop_wide", 2.0)]
+CASES = [("msckf", 0), ("msckf", 3), ("msckf", 7), ("msckf", 11), ("msckf", 19), ("slam", 0), ("slam", 4), ("slam_aruco", 0), ("slam_aruco", 5), ("delayed", 0), ("delayed", 4), ("delayed", 5), ("delayed_aruco", 0), ("anchors", 2), ("anchors", 4), ("slam_mixed", 0), ("slam_mixed", 2), ("slam_mixed", 3), ("slam_mixed", 4), ("delayed_mixed", 0), ("delayed_mixed", 1),
+         ("delayed_mixed", 2), ("anchors_mixed", 0), ("zupt", 0), ("zupt", 1), ("loop", 60.0), ("loop_slam", 60.0), ("loop_stereo", 60.0), ("loop_wide", 2.0)]
 
 if __name__ == "__main__":
     mode = sys.argv[1]  # a | b (libovgpu: needs the GPU) or a_cpu | b_cpu (tests/fake_ovgpu, the oracle-backed double of the C ABI: runs anywhere)

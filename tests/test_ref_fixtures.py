@@ -8,7 +8,9 @@ MSCKF inverse depth, no FEJ, equidistant lens; ANCHORED_INVERSE_DEPTH_SINGLE map
 with rows <= cols (Q9: no compression); a 256-observation track, r = 509 >= 500 (Q8: beyond the chi2 table); calibration off; the
 IMU-intrinsics block in the state (N + 24); 1-d triangulation.  SLAM updates with ArUco options in four representations; delayed
 initialisation chains (three representations, ArUco options, gate rejects); anchor changes (three representations, other camera);
-propagate -> clone with the time-offset Jacobian -> marginalise.
+propagate -> clone with the time-offset Jacobian -> marginalise.  Round 5: SLAM updates over landmarks of SEVERAL representations at once
+(feat_rep_slam next to a different feat_rep_aruco; 3-dof next to the 1-dof single depth; all six) and delayed initialisations that give the
+ArUco corners their own representation.
 """
 import glob
 import os
@@ -31,7 +33,7 @@ def _rel(a, b):
 
 def _load(path):
     z = np.load(path)
-    prob = SimpleNamespace(lm_value=None, lm_rep=0, lm_anchor_cam=None, lm_anchor_clone=None)
+    prob = SimpleNamespace(lm_value=None, lm_rep=0, lm_anchor_cam=None, lm_anchor_clone=None, lm_rep_each=None)
     for k in z.files:
         if k.startswith("in_"):
             v = z[k]
@@ -65,7 +67,9 @@ def test_fixture_set_is_complete():
             "msckf_rows_le_cols", "msckf_dof_beyond_table", "msckf_no_calibration", "msckf_imu_intrinsics_state", "msckf_1d_triangulation",
             "slam_update_global3d_aruco", "slam_update_anchored_msckf_aruco", "slam_update_single_depth_aruco", "slam_update_anchored_full_aruco",
             "delayed_init_global3d", "delayed_init_anchored_msckf", "delayed_init_single_depth", "anchor_change_anchored3d",
-            "anchor_change_anchored_msckf", "anchor_change_single_depth", "window_propagate_clone_marginalize"}
+            "anchor_change_anchored_msckf", "anchor_change_single_depth", "window_propagate_clone_marginalize",
+            "slam_update_mixed_msckf_and_global3d", "slam_update_mixed_single_depth_and_anchored3d", "slam_update_mixed_all_six",
+            "delayed_init_mixed_msckf_and_global3d", "delayed_init_mixed_global3d_and_single_depth"}
     assert need <= have, need - have
 
 
@@ -122,7 +126,7 @@ def test_oracle_delayed_init_matches_the_reference(name):
     from oracle import pyoracle
     _, prob, opts, ref, extra = _load(_path(name))
     got = pyoracle.slam_delayed_init(opts, capi.Views(prob), feat_rep=int(extra["feat_rep"]), feat_sigma=extra["feat_sigma"],
-                                     feat_chi2mult=extra["feat_chi2mult"])
+                                     feat_chi2mult=extra["feat_chi2mult"], feat_rep_each=extra.get("feat_rep_each"))
     _check_delayed_init(got, ref, 1e-10, 1e-11, 1e-11)  # a chain of up to six initialisations, each an update of the whole state
 
 
@@ -197,7 +201,7 @@ def test_gpu_delayed_init_matches_the_reference(Updater, name):
     up = Updater(opts)
     up.set_problem(prob)
     up.set_feature_options(extra["feat_sigma"], extra["feat_chi2mult"])
-    got = up.delayed_init(int(extra["feat_rep"]))
+    got = up.delayed_init(int(extra["feat_rep"]), feat_rep_each=extra.get("feat_rep_each"))
     got.update(up.get_state(P=False))
     up.close()
     _check_delayed_init(got, ref, 1e-8, 1e-7, 1e-9)

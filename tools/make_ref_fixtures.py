@@ -2,7 +2,7 @@
 small seeded snapshots, written to tests/golden/ref_*.npz.  tests/test_ref_fixtures.py holds the oracle (CPU) and the HIP library
 (-m gpu) to these files; they need neither /root/reference nor oracle/_ref at test time.
 
-Run here (the container that has /root/reference):   python tools/make_ref_fixtures.py
+Run here (the container that has /root/reference):   python tools/make_ref_fixtures.py [name-substring ...]   (no argument: every fixture)
 Inputs are stored in full (Problem fields as `in_*`, option fields as `opt_*`), so a change of synth.py cannot silently shift them.
 """
 import os
@@ -18,7 +18,7 @@ from oracle import pyref  # noqa: E402
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 PROB_FIELDS = ["N", "C", "K", "P", "clone_q_p", "clone_q_p_fej", "clone_cov_id", "calib_q_p", "intrinsics", "cam_is_fisheye", "calib_cov_id",
                "intr_cov_id", "meas_offsets", "uv", "uvn", "clone_idx", "cam_idx", "lm_value", "lm_fej", "lm_cov_id", "lm_index", "lm_rep",
-               "lm_anchor_cam", "lm_anchor_clone"]
+               "lm_anchor_cam", "lm_anchor_clone", "lm_rep_each"]
 OPT_FIELDS = ["chi2_multipler", "sigma_pix", "triangulate_1d", "refine_features", "max_runs", "init_lamda", "max_lamda", "min_dx", "min_dcost",
               "lam_mult", "min_dist", "max_dist", "max_baseline", "max_cond_number", "do_fej", "do_calib_camera_pose",
               "do_calib_camera_intrinsics", "feat_rep_msckf"]
@@ -41,6 +41,8 @@ def pack(kind, prob, opts, out, **extra):
 
 
 def save(name, d):
+    if len(sys.argv) > 1 and not any(s in name for s in sys.argv[1:]):
+        return
     path = os.path.join(GOLDEN, f"ref_{name}.npz")
     np.savez_compressed(path, **d)
     print(f"{name:34s} {os.path.getsize(path) / 1024:8.1f} KiB  kind={d['kind']}")
@@ -94,7 +96,34 @@ def main():
         assert (out["feat_status"] == capi.FEAT_USED).sum() >= 3
         save(f"slam_update_{nm}_aruco", pack("slam_update", prob, opts, out, feat_sigma=sig, feat_chi2mult=mult))
 
+    # ... SLAM landmarks (feat_rep_slam) and ArUco corners (feat_rep_aruco != feat_rep_slam) in ONE update (UpdaterSLAM.cpp:336-341, :427-447):
+    # the anchored MSCKF inverse depth next to global xyz; the 1-dof single depth next to anchored xyz; all six at once
+    for each, nm in (([4, 0, 4, 0, 4, 4], "msckf_and_global3d"), ([5, 2, 5, 2, 5, 5], "single_depth_and_anchored3d"), ([0, 1, 2, 3, 4, 5], "all_six")):
+        each = np.array(each, np.int32)
+        prob = synth.make_slam_problem(2, L=6, lm_rep=each, C=9, K=2, seed=60 + int(each[1]))
+        opts = capi.default_options(chi2_multipler=1.0)
+        v = capi.Views(prob)
+        tag = each == each[1]  # the corners: the second representation, with the ArUco option set
+        sig, mult = np.where(tag, 2.5, 1.0), np.where(tag, 3.0, 1.0)
+        out = pyref.slam_update(opts, v, feat_sigma=sig, feat_chi2mult=mult)
+        assert (out["feat_status"] == capi.FEAT_USED).sum() >= 4
+        save(f"slam_update_mixed_{nm}", pack("slam_update", prob, opts, out, feat_sigma=sig, feat_chi2mult=mult))
+
     # ---- UpdaterSLAM::delayed_init (chain of StateHelper::initialize) --------------------------------------------------------
+    # ... with the ArUco corners initialised in feat_rep_aruco, the other features in feat_rep_slam (:160-166)
+    for rep_slam, rep_aruco, nm in ((R.REP_ANCHORED_MSCKF_INVERSE_DEPTH, R.REP_GLOBAL_3D, "msckf_and_global3d"),
+                                    (R.REP_GLOBAL_3D, R.REP_ANCHORED_INVERSE_DEPTH_SINGLE, "global3d_and_single_depth")):
+        prob = synth.make_problem(2, F=6, C=12, K=2, outlier_frac=0.3, seed=70 + rep_slam)
+        opts = capi.default_options(chi2_multipler=1.0)
+        v = capi.Views(prob)
+        sig, mult = aruco(6, 5)
+        each = np.where(sig != 1.0, rep_aruco, rep_slam).astype(np.int32)
+        assert 1 <= (each == rep_aruco).sum() < 6
+        out = pyref.slam_delayed_init(opts, v, feat_rep=rep_slam, feat_sigma=sig, feat_chi2mult=mult, feat_rep_aruco=rep_aruco)
+        acc = out["lm_cov_id"] >= 0
+        assert 2 <= acc.sum() and len(set(each[acc].tolist())) == 2, (acc, each)
+        save(f"delayed_init_mixed_{nm}", pack("delayed_init", prob, opts, out, feat_rep=rep_slam, feat_sigma=sig, feat_chi2mult=mult, feat_rep_each=each))
+
     for rep, nm in ((R.REP_GLOBAL_3D, "global3d"), (R.REP_ANCHORED_MSCKF_INVERSE_DEPTH, "anchored_msckf"),
                     (R.REP_ANCHORED_INVERSE_DEPTH_SINGLE, "single_depth")):
         prob = synth.make_problem(2, F=6, C=12, K=2, outlier_frac=0.3, seed=30 + rep)
