@@ -23,6 +23,8 @@
 // Padding: rows / columns D .. 16 ceil(D / 16) - 1 of A behave as an identity block and the carried columns are tiled from
 // column D on, so no tile mixes matrix and carried columns; nothing outside [D x LA] is read or written.
 #pragma once
+#include <type_traits>
+
 #include "k_feat.h"
 
 // Cycle counters of the factor / follower wavefronts (p.dbg, tools/dev_tail_ab.py): a developer build only (-DOVG_CHOL_PROF).  clock64() is
@@ -77,17 +79,36 @@ enum { CH_SRC_MATRIX = 0, CH_SRC_PRIOR = 1, CH_SRC_WHITENED = 2 };
 constexpr int CH_TMAX = 16;  // tile rows: D <= 256
 constexpr int CH_NW = 8;     // wavefronts per workgroup
 
-__device__ __forceinline__ double ld_a(const CholParams &p, int r, int c) { // element (r, c) of the padded matrix part
-  if (!(r < p.D && c < p.D)) return r == c ? 1.0 : 0.0;
-  if (p.src == CH_SRC_PRIOR) return p.P[(size_t)p.col_cov[r] * p.N + p.col_cov[c]];
-  if (p.src == CH_SRC_WHITENED) return p.G[(size_t)r * p.LG + c] * p.inv_sigma2 + (r == c ? 1.0 : 0.0);
-  return p.A[(size_t)r * p.LA + c];
+// Element (r, c) of the padded matrix part / carried column col (D <= col < LA) of row r, in two halves: *_idx gives the (clamped) position
+// of the ONE global load the element needs, as a 32-bit index into its source array (every source is far smaller than 2^31 doubles) — the
+// indices of the prior's gather come from `cov`, col_cov staged in LDS by the caller — and *_val turns the loaded double into the element (the
+// whitened system's scaling, the identity padding).  SRC is a template parameter: the callers dispatch ONCE on p.src around their whole load
+// block.  Round 5: the callers issue every load of a wavefront's forty (sixty-four) elements first and finish them afterwards, in
+// straight-line code of ~6 instructions per element.  Before, every element tested the padding, branched on p.src, fetched col_cov[r] and
+// col_cov[c] from memory and formed a 64-bit address with a quarter-rate multiply, ~60 instructions and two dependent round trips per
+// element: with four wavefronts per SIMD doing that at once the first tile reached the chain wavefront 35 - 54 kcycles (17 - 25 us) after the
+// kernel started, a fifth of its run time (tools/dev_chol_phases.py: "start-up").
+template <int SRC> __device__ __forceinline__ const double *ld_src(const CholParams &p) { return SRC == CH_SRC_PRIOR ? p.P : (SRC == CH_SRC_WHITENED ? p.G : p.A); }
+template <int SRC> __device__ __forceinline__ int ld_a_idx(const CholParams &p, const int *cov, int r, int c) {
+  const int rr = min(r, p.D - 1), cq = min(c, p.D - 1);
+  if (SRC == CH_SRC_PRIOR) return cov[rr] * p.N + cov[cq];
+  return rr * (SRC == CH_SRC_WHITENED ? p.LG : p.LA) + cq;
 }
-__device__ __forceinline__ double ld_c(const CholParams &p, int r, int col) { // carried column col (D <= col < LA) of row r < D
+template <int SRC> __device__ __forceinline__ double ld_a_val(const CholParams &p, double raw, int r, int c) {
+  const double v = SRC == CH_SRC_WHITENED ? raw * p.inv_sigma2 + (r == c ? 1.0 : 0.0) : raw;
+  return (r < p.D && c < p.D) ? v : (r == c ? 1.0 : 0.0);
+}
+template <int SRC> __device__ __forceinline__ const double *ld_c_ptr(const CholParams &p, const int *cov, int r, int col) {
+  const int rr = min(r, p.D - 1), cc = min(col, p.LA - 1) - p.D, ccn = min(cc, p.N - 1);
+  if (SRC == CH_SRC_PRIOR) return p.P + (cov[rr] * p.N + ccn);
+  if (SRC == CH_SRC_WHITENED) return cc < p.N ? p.Y1 + (rr * p.LA + p.D + ccn) : p.G + (rr * p.LG + p.D);
+  return p.A + (rr * p.LA + p.D + cc);
+}
+template <int SRC> __device__ __forceinline__ double ld_c_val(const CholParams &p, double raw, int col, bool valid) {
   const int cc = col - p.D;
-  if (p.src == CH_SRC_PRIOR) return cc < p.N ? p.P[(size_t)p.col_cov[r] * p.N + cc] : 0.0;
-  if (p.src == CH_SRC_WHITENED) return cc < p.N ? p.Y1[(size_t)r * p.LA + col] : p.G[(size_t)r * p.LG + p.D] * p.inv_sigma2;
-  return p.A[(size_t)r * p.LA + col];
+  double v = raw;
+  if (SRC == CH_SRC_WHITENED && cc >= p.N) v = raw * p.inv_sigma2;
+  return (valid && (SRC != CH_SRC_PRIOR || cc < p.N)) ? v : 0.0;
 }
 __device__ __forceinline__ bool chol_skipped(const CholParams &p) { return (p.pred && *p.pred == 0) || (p.pred_not && *p.pred_not != 0); }
 
@@ -100,19 +121,23 @@ constexpr int CH_FW = 15;  // tile wavefronts of the factor workgroup (wavefront
 // In k_chol_factor every step cost the chain wavefront ~16 kcycles for a 6-kcycle tile factorisation: it takes part in the
 // three s_barriers of the step, so it waits for the SLOWEST tile wavefront's panel solve (and that wavefront's stores) before it
 // may even look for the next diagonal tile.  Here the wavefronts synchronise through LDS words only:
-//   uinv_ready   chain -> tile wavefronts: U_kk^-1 of step k is in st1[k & 1]
-//   diag_ready   owner -> chain: diagonal tile k + 1 is in st0
-//   panel_cnt[k] tile wavefronts among themselves: row panel k is complete in panel[k & 1] (a counting barrier of the 15)
-// and the tiles are dealt so that ONE wavefront owns (k, k+1) and (k+1, k+1) (wavefront k: slots 0 and 1).  Right after
-// U_kk^-1 appears, that wavefront solves W_k,k+1, applies it to its diagonal tile straight from registers (the accumulator layout
-// of W IS the operand layout of W^T W), and hands the tile over: the chain wavefront factors tile k + 1 while the other fourteen are
-// still solving / storing / updating step k.  Double buffers (st1, panel) keep a fast wavefront's step k + 1 off a slow
-// wavefront's step k: a wavefront enters the panel solve of step k + 2 only after every wavefront has counted itself into
-// panel_cnt[k + 1], i.e. has finished reading panel[k & 1] and st1[k & 1].
+//   pair_ready   owner -> chain: the tiles (k, k+1) and (k+1, k+1), updated through step k - 1, are in hb[k & 1]
+//   uinv_ready   chain -> tile wavefronts: U_kk^-1 of step k is in st1[k % 3]
+//   panel_cnt[k] row panel k is complete in panel[k & 1] (a counting barrier of the tiles' writers)
+// Round 5: THE CHAIN WAVEFRONT RUNS THE WHOLE CRITICAL PATH ITSELF.  Until round 4 the wavefront that owned (k, k+1) and (k+1, k+1)
+// waited for U_kk^-1, solved W_k,k+1, updated the next diagonal tile and handed it back — two LDS hand-overs between two wavefronts
+// that each poll, per step: measured (tools/dev_chol_phases.py, N = 248: 13 steps) 7.0 kcycles of factoring and 5.4 kcycles of
+// WAITING for the next tile per step, 181 kcycles = 85 us per factorisation.  Now the owner of the pair deposits both tiles one
+// step AHEAD (right after their last trailing update, while the chain is still factoring tile k), and the chain goes from
+// U_kk^-1 to W_k,k+1 = U_kk^-T S_k,k+1 to S_k+1,k+1 -= W^T W to the next factorisation without asking anybody: eight dependent
+// matrix instructions and no poll on its path.  The arithmetic of every tile is what it was (same instructions, same order):
+// the outputs are bit-identical to round 4's.
+// Double buffers (hb, panel; st1 / su in three) keep a fast wavefront's step k + 1 off a slow wavefront's step k: a wavefront
+// writes into the row panel of step k + 2 only after every tile wavefront has counted itself out of step k (done_cnt[k]).
 // Every wait is bounded (a wavefront that runs into the bound raises err / flags[0] like a follower does and leaves).
 // ---------------------------------------------------------------------------------------------------
 constexpr int CH_F2_SLOTS = 10; // 0: (w, w+1); 1: (w+1, w+1); 2 .. 8: the far tiles (j - i >= 2) dealt round-robin; 9: (0, 0) on wavefront 0
-inline size_t chol_factor2_lds_bytes() { return (size_t)(2 * CH_TMAX * 256 + 7 * 256 + 16 * CH_TMAX + 64) * sizeof(double); }
+inline size_t chol_factor2_lds_bytes() { return (size_t)(2 * CH_TMAX * 256 + 7 * 256 + 4 * 256 + 16 * CH_TMAX + 64 + 128) * sizeof(double); }
 
 __global__ void __launch_bounds__(64 * (CH_FW + 1), 4) k_chol_factor2(CholParams p) {
   extern __shared__ __attribute__((aligned(16))) double f2_lds[];
@@ -120,16 +145,23 @@ __global__ void __launch_bounds__(64 * (CH_FW + 1), 4) k_chol_factor2(CholParams
   double *st0 = panel + 2 * CH_TMAX * 256;      // [256] diagonal tile hand-over / the factorisation's scratch
   double *st1 = st0 + 256;                      // [3][256] U_kk^-1, row-major
   double *su = st1 + 3 * 256;                   // [3][256] U_kk, row-major (for the wavefront that writes it to memory)
-  double *d0s = su + 3 * 256;                   // [16 CH_TMAX] CH_SRC_PRIOR: the diagonal before the factorisation
-  int *sync = reinterpret_cast<int *>(d0s + 16 * CH_TMAX); // [0] diag_ready, [1] uinv_ready, [2] abort, [16 + k] tiles of row panel k in LDS,
-                                                           // [32 + k] tile wavefronts that are done with step k (its buffers may be reused)
+  double *hb = su + 3 * 256;                    // [2][2][256] the pair of step k on its way to the chain: (k, k+1), (k+1, k+1), accumulator layout as stored
+  double *d0s = hb + 4 * 256;                   // [16 CH_TMAX] CH_SRC_PRIOR: the diagonal before the factorisation
+  int *sync = reinterpret_cast<int *>(d0s + 16 * CH_TMAX); // [0] pair_ready (pairs deposited; tile (0, 0) with the first), [1] uinv_ready, [2] abort,
+                                                           // [16 + k] tiles of row panel k in LDS, [32 + k] tile wavefronts that are done with step k (its buffers may be reused)
+  const long long k_begin = OVG_CHOL_CLOCK();
   if (chol_skipped(p)) return;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, cl = lane & 15;
   const int D = p.D, LA = p.LA, TM = (D + 15) >> 4;
+  int *cov = sync + 128; // [16 CH_TMAX] CH_SRC_PRIOR: col_cov (the gathers below take their indices from here)
   if (tid < 64) sync[tid] = 0;
-  if (p.src == CH_SRC_PRIOR && tid < 16 * CH_TMAX) d0s[tid] = tid < D ? p.P[(size_t)p.col_cov[tid] * p.N + p.col_cov[tid]] : 1.0;
+  if (p.src == CH_SRC_PRIOR && tid < 16 * CH_TMAX) {
+    const int cv = tid < D ? p.col_cov[tid] : 0;
+    cov[tid] = cv;
+    d0s[tid] = tid < D ? p.P[(size_t)cv * p.N + cv] : 1.0;
+  }
   const double *diag0 = p.src == CH_SRC_PRIOR ? d0s : p.diag0;
   __syncthreads();
   auto st_dev = [](double *ptr, double v) { __hip_atomic_store(ptr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
@@ -162,22 +194,26 @@ __global__ void __launch_bounds__(64 * (CH_FW + 1), 4) k_chol_factor2(CholParams
     if (lane == 0) __hip_atomic_store(sync + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   };
 
+#ifdef OVG_CHOL_PROF
+  if (OVG_CHOL_DBG(p) && lane == 0) p.dbg[350 + wv] = (__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4)); // HW_ID[5:4]: the SIMD this wavefront runs on
+#endif
+  if (OVG_CHOL_DBG(p) && tid == 0) p.dbg[373] += OVG_CHOL_CLOCK() - k_begin; // kernel entry -> every wavefront past the first barrier
   if (wv == CH_FW) {
-    // ------------------------------------------------------------------ the diagonal chain: LDS in, LDS out, nothing else
+    // ------------------------------------------------------------------ the chain: diagonal tile, pair, diagonal tile ... — LDS in, LDS out, nothing else
     __builtin_amdgcn_s_setprio(3); // ahead of the three tile wavefronts on this SIMD whenever it has an instruction ready
-    long long c_wait = 0, c_fact = 0;
+    long long c_wait = 0, c_fact = 0, c_pair = 0;
     const long long c_begin = OVG_CHOL_CLOCK();
-    for (int k = 0; k < TM; k++) {
-      const long long c0 = OVG_CHOL_CLOCK();
-      if (!wait_for(0, k + 1)) return;
-      const long long c1 = OVG_CHOL_CLOCK();
-      c_wait += c1 - c0;
-      d4 sv, ev;
+    if (!wait_for(0, 1)) return; // tile (0, 0) in st0, the first pair in hb[0]
+    d4 sv, ev;
 #pragma unroll
-      for (int q = 0; q < 4; q++) sv[q] = st0[(g + 4 * q) * 16 + cl];
-      __builtin_amdgcn_wave_barrier(); // st0 becomes the factorisation's scratch
+    for (int q = 0; q < 4; q++) sv[q] = st0[(g + 4 * q) * 16 + cl];
+    __builtin_amdgcn_wave_barrier(); // st0 becomes the factorisation's scratch
+    c_wait += OVG_CHOL_CLOCK() - c_begin;
+    for (int k = 0; k < TM; k++) {
+      const long long c1 = OVG_CHOL_CLOCK();
       const bool bad = feat::diag_tile_factor_blk(sv, ev, st0, lane, diag0 ? diag0 + 16 * k : nullptr, p.pivot_tol, D - 16 * k);
-      c_fact += OVG_CHOL_CLOCK() - c1;
+      const long long c2 = OVG_CHOL_CLOCK();
+      c_fact += c2 - c1;
       if (bad && lane == 0) __hip_atomic_store(p.flags, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (k >= 3 && !wait_for(32 + k - 3, CH_FW)) return; // (long satisfied: the buffers of step k - 3 are free)
       double *s1 = st1 + (k % 3) * 256, *sk = su + (k % 3) * 256;
@@ -185,12 +221,37 @@ __global__ void __launch_bounds__(64 * (CH_FW + 1), 4) k_chol_factor2(CholParams
       for (int q = 0; q < 4; q++) s1[cl * 16 + g + 4 * q] = ev[q], sk[(g + 4 * q) * 16 + cl] = sv[q]; // U^-T in accumulator layout -> U^-1 row-major; U_kk
       publish(1, k + 1);
       // (a store instruction holds its wavefront for ~600 cycles, and this is the chain: tile wavefronts write U_kk and U_kk^-1 out)
+      if (k + 1 < TM) {
+        // the pair: W_k,k+1 = U_kk^-T S_k,k+1 (into the row panel for everybody's trailing update), S_k+1,k+1 -= W^T W, straight into the next
+        // factorisation.  Both tiles were deposited a step ago (the wait is long satisfied), so nothing on this path polls.
+        if (!wait_for(0, k + 2)) return;
+        const double *hp = hb + (size_t)(k & 1) * 512;
+        d4 sp;
+        double ua[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) sp[q] = hp[(g + 4 * q) * 16 + cl], sv[q] = hp[256 + (g + 4 * q) * 16 + cl];
+#pragma unroll
+        for (int u = 0; u < 4; u++) ua[u] = s1[(4 * u + g) * 16 + cl];
+        d4 w = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int u = 0; u < 4; u++) FEAT_MFMA(ua[u], sp[u], w);
+#pragma unroll
+        for (int u = 0; u < 4; u++) FEAT_MFMA(-w[u], w[u], sv); // S_k+1,k+1 -= W^T W: lane (g, cl) holds W[4u + g][cl] in w[u]
+        if (k >= 2 && !wait_for(32 + k - 2, CH_FW)) return; // every wavefront is done with row panel k - 2 (long satisfied): its buffer is free
+        double *pt = panel + ((size_t)(k & 1) * CH_TMAX + (k + 1)) * 256;
+#pragma unroll
+        for (int q = 0; q < 4; q++) pt[(g + 4 * q) * 16 + cl] = w[q];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) (void)__hip_atomic_fetch_add(sync + 16 + k, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        c_pair += OVG_CHOL_CLOCK() - c2;
+      }
     }
-    if (OVG_CHOL_DBG(p) && lane == 0) p.dbg[310] += OVG_CHOL_CLOCK() - c_begin, p.dbg[311] += c_wait, p.dbg[312] += c_fact, p.dbg[313] += 1;
+    if (OVG_CHOL_DBG(p) && lane == 0) p.dbg[310] += OVG_CHOL_CLOCK() - c_begin, p.dbg[311] += c_wait, p.dbg[312] += c_fact, p.dbg[313] += 1, p.dbg[314] += c_pair;
     return;
   }
 
   // -------------------------------------------------------------------- tile wavefronts
+  const long long s_begin = OVG_CHOL_CLOCK();
   int tij[CH_F2_SLOTS]; // (j << 8) | i, or -1
   d4 acc[CH_F2_SLOTS];
 #pragma unroll
@@ -209,19 +270,48 @@ __global__ void __launch_bounds__(64 * (CH_FW + 1), 4) k_chol_factor2(CholParams
       if (j < TM) i = f;
     }
     tij[s] = i < 0 ? -1 : ((j << 8) | i);
-    d4 v = {0.0, 0.0, 0.0, 0.0};
-    if (i >= 0) {
-#pragma unroll
-      for (int q = 0; q < 4; q++) v[q] = ld_a(p, 16 * i + g + 4 * q, 16 * j + cl);
-    }
-    acc[s] = v;
   }
+  const long long s_tij = OVG_CHOL_CLOCK();
+  // the loads: tile (0, 0) and the pair first (what the chain wavefront starts with); every load issued before any is waited for (an unused slot
+  // reads tile (0, 0) and drops it: no branch around a load)
+  auto load_tiles = [&](auto src_tag) {
+    constexpr int SRC = decltype(src_tag)::value;
+    const double *base = ld_src<SRC>(p);
+    double raw[CH_F2_SLOTS][4];
+#pragma unroll
+    for (int o = 0; o < CH_F2_SLOTS; o++) {
+      const int s = o == 0 ? 9 : o - 1; // order 9, 0, 1, 2 .. 8
+      const int ti = tij[s] >= 0 ? (tij[s] & 255) : 0, tj = tij[s] >= 0 ? (tij[s] >> 8) : 0;
+#pragma unroll
+      for (int q = 0; q < 4; q++) raw[s][q] = base[ld_a_idx<SRC>(p, cov, 16 * ti + g + 4 * q, 16 * tj + cl)];
+    }
+#pragma unroll
+    for (int s = 0; s < CH_F2_SLOTS; s++) {
+      const int ti = tij[s] >= 0 ? (tij[s] & 255) : 0, tj = tij[s] >= 0 ? (tij[s] >> 8) : 0;
+#pragma unroll
+      for (int q = 0; q < 4; q++) acc[s][q] = tij[s] >= 0 ? ld_a_val<SRC>(p, raw[s][q], 16 * ti + g + 4 * q, 16 * tj + cl) : 0.0;
+    }
+  };
+  if (p.src == CH_SRC_PRIOR) load_tiles(std::integral_constant<int, CH_SRC_PRIOR>{});
+  else if (p.src == CH_SRC_WHITENED) load_tiles(std::integral_constant<int, CH_SRC_WHITENED>{});
+  else load_tiles(std::integral_constant<int, CH_SRC_MATRIX>{});
 #define CTI(s) (tij[s] & 255)
 #define CTJ(s) (tij[s] >> 8)
-  if (wv == 0) { // tile (0, 0) to the chain wavefront
+  // the pair of step k — tiles (k, k+1) and (k+1, k+1), slots 0 and 1 of wavefront k — goes to the chain wavefront as soon as it has its last
+  // trailing update (step k - 1); the first one, with tile (0, 0), right away
+  auto deposit_pair = [&](int k) {
+    double *hp = hb + (size_t)(k & 1) * 512;
+#pragma unroll
+    for (int q = 0; q < 4; q++) hp[(g + 4 * q) * 16 + cl] = acc[0][q], hp[256 + (g + 4 * q) * 16 + cl] = acc[1][q];
+    publish(0, k + 2);
+  };
+  if (wv == 0) {
+    const long long s_issued = OVG_CHOL_CLOCK();
 #pragma unroll
     for (int q = 0; q < 4; q++) st0[(g + 4 * q) * 16 + cl] = acc[9][q];
-    publish(0, 1);
+    if (TM > 1) deposit_pair(0);
+    else publish(0, 1);
+    if (OVG_CHOL_DBG(p) && lane == 0) p.dbg[370] += s_tij - s_begin, p.dbg[371] += s_issued - s_tij, p.dbg[372] += OVG_CHOL_CLOCK() - s_issued;
   }
   // Tile (k, j) of U, row-major in LDS at `tile` -> memory: Y (write-through for the followers when to_followers) and, transposed,
   // L = U^T: four consecutive doubles of a column per lane (the per-lane transposed stores of the accumulator layout touch 64
@@ -301,7 +391,7 @@ __global__ void __launch_bounds__(64 * (CH_FW + 1), 4) k_chol_factor2(CholParams
   const long long t_begin = OVG_CHOL_CLOCK();
   for (int k = 0; k < TM; k++) {
     const long long t0 = OVG_CHOL_CLOCK();
-    if (!wait_for(1, k + 1, wv != k)) return; // (wavefront k is the one the chain waits for)
+    if (!wait_for(1, k + 1)) return;
     const long long t1 = OVG_CHOL_CLOCK();
     t_uinv += t1 - t0;
     double *pan = panel + (size_t)(k & 1) * CH_TMAX * 256;
@@ -312,29 +402,8 @@ __global__ void __launch_bounds__(64 * (CH_FW + 1), 4) k_chol_factor2(CholParams
 #pragma unroll
       for (int u = 0; u < 4; u++) ua[u] = s1[(4 * u + g) * 16 + cl];
     }
-    // (a) the pair first: W_k,k+1, the next diagonal tile, hand-over
-    if (wv == k && k + 1 < TM) {
-      __builtin_amdgcn_s_setprio(2); // the chain waits for this
-      d4 w = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int u = 0; u < 4; u++) FEAT_MFMA(ua[u], acc[0][u], w);
-      d4 av = acc[1];
-#pragma unroll
-      for (int u = 0; u < 4; u++) FEAT_MFMA(-w[u], w[u], av); // S_k+1,k+1 -= W^T W: lane (g, cl) holds W[4u + g][cl] in w[u]
-#pragma unroll
-      for (int q = 0; q < 4; q++) st0[(g + 4 * q) * 16 + cl] = av[q];
-      publish(0, k + 2);
-      __builtin_amdgcn_s_setprio(0);
-      if (OVG_CHOL_DBG(p) && lane == 0) p.dbg[340] += OVG_CHOL_CLOCK() - t1, p.dbg[341] += t1 - t0, p.dbg[342] += 1;
-      acc[1] = av;
-      if (k >= 2 && !wait_for(32 + k - 2, CH_FW)) return; // every wavefront is done with row panel k - 2 (long satisfied): its buffer is free
-      double *pt = pan + (size_t)(k + 1) * 256;
-#pragma unroll
-      for (int q = 0; q < 4; q++) pt[(g + 4 * q) * 16 + cl] = w[q];
-      wrote++;
-    }
-    // (b) the other tiles of row k
-    if (!(wv == k && k + 1 < TM) && k >= 2 && !wait_for(32 + k - 2, CH_FW)) return;
+    // (b) this wavefront's tiles of row k right of the pair's (k, k+1), which the chain wavefront solves
+    if (k >= 2 && !wait_for(32 + k - 2, CH_FW)) return; // every wavefront is done with row panel k - 2 (long satisfied): its buffer is free
 #pragma unroll
     for (int s = 2; s < 9; s++) {
       if (tij[s] >= 0 && CTI(s) == k) {
@@ -356,7 +425,9 @@ __global__ void __launch_bounds__(64 * (CH_FW + 1), 4) k_chol_factor2(CholParams
     if (!wait_for(16 + k, TM - 1 - k)) return;
     const long long t4 = OVG_CHOL_CLOCK();
     t_cnt += t4 - t3;
-    // (c) trailing update S_ij -= W_ki^T W_kj of this wavefront's tiles below row k (its next diagonal tile is done)
+    // (c) trailing update S_ij -= W_ki^T W_kj of this wavefront's tiles below row k.  Its pair comes first (slots 0, 1: the tiles (wv, wv+1) and
+    //     (wv+1, wv+1) take their updates of the steps k < wv here; step wv's update of (wv+1, wv+1) is the chain wavefront's, from registers) and
+    //     leaves for the chain wavefront with its last one, a whole step before it is needed
 #pragma unroll
     for (int s = 0; s < 9; s++) {
       if (tij[s] >= 0 && CTI(s) > k && !(s == 1 && wv == k)) {
@@ -367,6 +438,7 @@ __global__ void __launch_bounds__(64 * (CH_FW + 1), 4) k_chol_factor2(CholParams
 #pragma unroll
         for (int u = 0; u < 4; u++) FEAT_MFMA(a[u], b[u], acc[s]);
       }
+      if (s == 1 && wv == k + 1 && tij[0] >= 0) deposit_pair(k + 1);
     }
     const long long t5 = OVG_CHOL_CLOCK();
     t_trail += t5 - t4;
@@ -387,29 +459,37 @@ __global__ void __launch_bounds__(64 * (CH_FW + 1), 4) k_chol_factor2(CholParams
 
 // followers: one wavefront per 16 carried columns (launched on a second stream next to k_chol_factor2)
 __global__ void __launch_bounds__(64 * CH_NW, 2) k_chol_follow(CholParams p) {
+  __shared__ int cov[16 * CH_TMAX]; // CH_SRC_PRIOR: col_cov (see ld_a)
   if (chol_skipped(p)) return;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, cl = lane & 15;
   const int D = p.D, LA = p.LA, TM = (D + 15) >> 4;
+  if (p.src == CH_SRC_PRIOR) {
+    if (tid < 16 * CH_TMAX) cov[tid] = tid < D ? p.col_cov[tid] : 0;
+    __syncthreads();
+  }
   const int jc = blockIdx.x * CH_NW + wv; // carried tile
   const int c0 = D + 16 * jc;
   if (c0 >= LA) return;
   const int col = c0 + cl;
   const bool colok = col < LA;
   d4 acc[CH_TMAX];
+  auto load_columns = [&](auto src_tag) { // all 64 loads of the lane first (rows beyond the matrix read a clamped address and are dropped), then the elements
+    constexpr int SRC = decltype(src_tag)::value;
+    double raw[CH_TMAX][4];
 #pragma unroll
-  for (int i = 0; i < CH_TMAX; i++) {
-    d4 v = {0.0, 0.0, 0.0, 0.0};
-    if (i < TM) {
+    for (int i = 0; i < CH_TMAX; i++)
 #pragma unroll
-      for (int q = 0; q < 4; q++) {
-        const int r = 16 * i + g + 4 * q;
-        v[q] = (r < D && colok) ? ld_c(p, r, col) : 0.0;
-      }
-    }
-    acc[i] = v;
-  }
+      for (int q = 0; q < 4; q++) raw[i][q] = *ld_c_ptr<SRC>(p, cov, 16 * i + g + 4 * q, col);
+#pragma unroll
+    for (int i = 0; i < CH_TMAX; i++)
+#pragma unroll
+      for (int q = 0; q < 4; q++) acc[i][q] = ld_c_val<SRC>(p, raw[i][q], col, 16 * i + g + 4 * q < D && colok);
+  };
+  if (p.src == CH_SRC_PRIOR) load_columns(std::integral_constant<int, CH_SRC_PRIOR>{});
+  else if (p.src == CH_SRC_WHITENED) load_columns(std::integral_constant<int, CH_SRC_WHITENED>{});
+  else load_columns(std::integral_constant<int, CH_SRC_MATRIX>{});
   const long long f_begin = OVG_CHOL_CLOCK();
   long long f_wait = 0;
   for (int k = 0; k < TM; k++) {
