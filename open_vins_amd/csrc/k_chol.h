@@ -150,18 +150,16 @@ __global__ void __launch_bounds__(64 * (CH_FW + 1), 4) k_chol_factor2(CholParams
   int *sync = reinterpret_cast<int *>(d0s + 16 * CH_TMAX); // [0] pair_ready (pairs deposited; tile (0, 0) with the first), [1] uinv_ready, [2] abort,
                                                            // [16 + k] tiles of row panel k in LDS, [32 + k] tile wavefronts that are done with step k (its buffers may be reused)
   const long long k_begin = OVG_CHOL_CLOCK();
-  if (chol_skipped(p)) return;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, cl = lane & 15;
   const int D = p.D, LA = p.LA, TM = (D + 15) >> 4;
   int *cov = sync + 128; // [16 CH_TMAX] CH_SRC_PRIOR: col_cov (the gathers below take their indices from here)
+  int cv = 0;
+  if (p.src == CH_SRC_PRIOR && tid < D) cv = p.col_cov[tid]; // in flight next to the predicate words
+  if (chol_skipped(p)) return;
   if (tid < 64) sync[tid] = 0;
-  if (p.src == CH_SRC_PRIOR && tid < 16 * CH_TMAX) {
-    const int cv = tid < D ? p.col_cov[tid] : 0;
-    cov[tid] = cv;
-    d0s[tid] = tid < D ? p.P[(size_t)cv * p.N + cv] : 1.0;
-  }
+  if (tid < 16 * CH_TMAX) cov[tid] = cv;
   const double *diag0 = p.src == CH_SRC_PRIOR ? d0s : p.diag0;
   __syncthreads();
   auto st_dev = [](double *ptr, double v) { __hip_atomic_store(ptr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
@@ -203,6 +201,13 @@ __global__ void __launch_bounds__(64 * (CH_FW + 1), 4) k_chol_factor2(CholParams
     __builtin_amdgcn_s_setprio(3); // ahead of the three tile wavefronts on this SIMD whenever it has an instruction ready
     long long c_wait = 0, c_fact = 0, c_pair = 0;
     const long long c_begin = OVG_CHOL_CLOCK();
+    if (p.src == CH_SRC_PRIOR) { // the prior's diagonal before the factorisation (the pivot test's yardstick): read by this wavefront only, fetched while tile (0, 0) is on its way
+      double dv[4];
+#pragma unroll
+      for (int t = 0; t < 4; t++) dv[t] = p.P[cov[min(lane + 64 * t, D - 1)] * (p.N + 1)];
+#pragma unroll
+      for (int t = 0; t < 4; t++) d0s[lane + 64 * t] = lane + 64 * t < D ? dv[t] : 1.0;
+    }
     if (!wait_for(0, 1)) return; // tile (0, 0) in st0, the first pair in hb[0]
     d4 sv, ev;
 #pragma unroll
@@ -211,40 +216,45 @@ __global__ void __launch_bounds__(64 * (CH_FW + 1), 4) k_chol_factor2(CholParams
     c_wait += OVG_CHOL_CLOCK() - c_begin;
     for (int k = 0; k < TM; k++) {
       const long long c1 = OVG_CHOL_CLOCK();
+      // the three words this step's hand-overs depend on — read NOW, checked behind the factorisation: all three are long satisfied in a
+      // running pipeline, and a poll is an LDS round trip on the one path nothing hides
+      const int f_bufs = k >= 3 ? lds_ld(32 + k - 3) : CH_FW, f_pair = lds_ld(0), f_panel = k >= 2 ? lds_ld(32 + k - 2) : CH_FW;
       const bool bad = feat::diag_tile_factor_blk(sv, ev, st0, lane, diag0 ? diag0 + 16 * k : nullptr, p.pivot_tol, D - 16 * k);
       const long long c2 = OVG_CHOL_CLOCK();
       c_fact += c2 - c1;
       if (bad && lane == 0) __hip_atomic_store(p.flags, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (k >= 3 && !wait_for(32 + k - 3, CH_FW)) return; // (long satisfied: the buffers of step k - 3 are free)
+      if (f_bufs < CH_FW && !wait_for(32 + k - 3, CH_FW)) return; // the buffers of step k - 3 are free
       double *s1 = st1 + (k % 3) * 256, *sk = su + (k % 3) * 256;
 #pragma unroll
       for (int q = 0; q < 4; q++) s1[cl * 16 + g + 4 * q] = ev[q], sk[(g + 4 * q) * 16 + cl] = sv[q]; // U^-T in accumulator layout -> U^-1 row-major; U_kk
-      publish(1, k + 1);
       // (a store instruction holds its wavefront for ~600 cycles, and this is the chain: tile wavefronts write U_kk and U_kk^-1 out)
-      if (k + 1 < TM) {
-        // the pair: W_k,k+1 = U_kk^-T S_k,k+1 (into the row panel for everybody's trailing update), S_k+1,k+1 -= W^T W, straight into the next
-        // factorisation.  Both tiles were deposited a step ago (the wait is long satisfied), so nothing on this path polls.
-        if (!wait_for(0, k + 2)) return;
-        const double *hp = hb + (size_t)(k & 1) * 512;
-        d4 sp;
-        double ua[4];
-#pragma unroll
-        for (int q = 0; q < 4; q++) sp[q] = hp[(g + 4 * q) * 16 + cl], sv[q] = hp[256 + (g + 4 * q) * 16 + cl];
-#pragma unroll
-        for (int u = 0; u < 4; u++) ua[u] = s1[(4 * u + g) * 16 + cl];
-        d4 w = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int u = 0; u < 4; u++) FEAT_MFMA(ua[u], sp[u], w);
-#pragma unroll
-        for (int u = 0; u < 4; u++) FEAT_MFMA(-w[u], w[u], sv); // S_k+1,k+1 -= W^T W: lane (g, cl) holds W[4u + g][cl] in w[u]
-        if (k >= 2 && !wait_for(32 + k - 2, CH_FW)) return; // every wavefront is done with row panel k - 2 (long satisfied): its buffer is free
-        double *pt = panel + ((size_t)(k & 1) * CH_TMAX + (k + 1)) * 256;
-#pragma unroll
-        for (int q = 0; q < 4; q++) pt[(g + 4 * q) * 16 + cl] = w[q];
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (lane == 0) (void)__hip_atomic_fetch_add(sync + 16 + k, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        c_pair += OVG_CHOL_CLOCK() - c2;
+      if (k + 1 == TM) {
+        publish(1, k + 1);
+        break;
       }
+      // the pair: W_k,k+1 = U_kk^-T S_k,k+1 (into the row panel for everybody's trailing update), S_k+1,k+1 -= W^T W, straight into the next
+      // factorisation.  Both tiles were deposited a step ago: their reads queue up behind the writes above, ONE wait covers both.
+      if (f_pair < k + 2 && !wait_for(0, k + 2)) return;
+      const double *hp = hb + (size_t)(k & 1) * 512;
+      d4 sp;
+      double ua[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) sp[q] = hp[(g + 4 * q) * 16 + cl], sv[q] = hp[256 + (g + 4 * q) * 16 + cl];
+#pragma unroll
+      for (int u = 0; u < 4; u++) ua[u] = s1[(4 * u + g) * 16 + cl];
+      publish(1, k + 1);
+      d4 w = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int u = 0; u < 4; u++) FEAT_MFMA(ua[u], sp[u], w);
+#pragma unroll
+      for (int u = 0; u < 4; u++) FEAT_MFMA(-w[u], w[u], sv); // S_k+1,k+1 -= W^T W: lane (g, cl) holds W[4u + g][cl] in w[u]
+      if (f_panel < CH_FW && !wait_for(32 + k - 2, CH_FW)) return; // every wavefront is done with row panel k - 2: its buffer is free
+      double *pt = panel + ((size_t)(k & 1) * CH_TMAX + (k + 1)) * 256;
+#pragma unroll
+      for (int q = 0; q < 4; q++) pt[(g + 4 * q) * 16 + cl] = w[q];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (lane == 0) (void)__hip_atomic_fetch_add(sync + 16 + k, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      c_pair += OVG_CHOL_CLOCK() - c2;
     }
     if (OVG_CHOL_DBG(p) && lane == 0) p.dbg[310] += OVG_CHOL_CLOCK() - c_begin, p.dbg[311] += c_wait, p.dbg[312] += c_fact, p.dbg[313] += 1, p.dbg[314] += c_pair;
     return;
@@ -263,11 +273,13 @@ __global__ void __launch_bounds__(64 * (CH_FW + 1), 4) k_chol_factor2(CholParams
       if (wv + 1 < TM) i = wv + 1, j = wv + 1;
     } else if (s == 9) {
       if (wv == 0) i = 0, j = 0;
-    } else { // far tile number f = (s - 2) CH_FW + wv, column by column: column j >= 2 holds rows 0 .. j-2
-      int f = (s - 2) * CH_FW + wv;
-      j = 2;
-      while (j < TM && f >= j - 1) f -= j - 1, j++;
-      if (j < TM) i = f;
+    } else { // far tile number f = (s - 2) CH_FW + wv, column by column: column j >= 2 holds rows 0 .. j-2, i.e. columns 2 .. j-1 hold (j-1)(j-2)/2 tiles
+      const int f = (s - 2) * CH_FW + wv;
+      int m = (int)((1.f + sqrtf(1.f + 8.f * (float)f)) * 0.5f); // the largest m with m (m - 1) / 2 <= f (closed form: seven search loops cost every wavefront 4 kcycles at start-up)
+      m += ((m + 1) * m / 2 <= f) ? 1 : 0;
+      m -= (m * (m - 1) / 2 > f) ? 1 : 0;
+      j = m + 1;
+      if (j < TM) i = f - m * (m - 1) / 2;
     }
     tij[s] = i < 0 ? -1 : ((j << 8) | i);
   }
