@@ -4,21 +4,19 @@
 // [B | h]) used to be 13 launches of k_ekf_chol_step each — a chain of 16-row steps in which every launch boundary, and every
 // wavefront refactoring the diagonal block for itself, sat on the critical path (26 launches = 0.29 ms of a 1.15 ms update).
 //
-//   k_chol_factor2           ONE workgroup (round 2's k_chol_factor described here; round 3's barrier-free form of it is what remains, see below): 15 wavefronts hold the upper triangle of A as 16 x 16 tiles in REGISTERS (accumulator
-//                            layout of v_mfma_f64_16x16x4_f64; tiles dealt round-robin, 10 per wavefront), a 16th runs the
-//                            chain of diagonal tiles and holds nothing else (the factorisation of a tile needs ~90 registers: in
-//                            a wavefront that also holds tiles they end up in scratch, and scratch latency on the chain).  Step k:
-//                              the owner of tile (k, k) hands it over through LDS, the chain wavefront factors it (k_feat.h:
-//                              diag_tile_factor, U_kk^-1 falls out of the same instruction stream)     -> LDS, barrier
-//                              every wavefront: W_kj = U_kk^-T S_kj on the matrix cores, W_kj -> LDS row panel, Y and (transposed) L
-//                                                                                                     -> barrier, publish step k
-//                              every wavefront: S_ij -= W_ki^T W_kj, operands from the LDS row panel
-//                            The hand-offs of the chain are LDS + s_barrier; nothing leaves the compute unit on the critical path.
-//   k_chol_follow            (second stream) one wavefront per 16 carried columns (all 16-row tiles of those columns in registers).  They follow
-//                            the factor workgroup through a per-step counter in memory (bounded spin): the factor workgroup's
-//                            wavefronts write U_kk^-1 and the row panel through to memory (sc1 stores) and count
-//                            themselves in one step later, the followers read past the caches.  No fence, no vmcnt wait and
-//                            no store sits on the factor workgroup's chain.
+//   k_chol_fused, block 0    the FACTOR workgroup: 15 wavefronts hold the upper triangle of A as 16 x 16 tiles in REGISTERS (accumulator
+//                            layout of v_mfma_f64_16x16x4_f64; tiles dealt round-robin, 10 per wavefront), a 16th runs the chain of
+//                            diagonal tiles — and, since round 5, the whole critical path: after factoring tile k (k_feat.h:
+//                            diag_tile_factor_blk, U_kk^-1 falls out of the same instruction stream) it solves W_k,k+1, updates tile
+//                            (k+1, k+1) and factors it, from tiles their owner deposited a step ahead.  Every other wavefront, step k:
+//                              W_kj = U_kk^-T S_kj on the matrix cores -> LDS row panel (counting barrier), S_ij -= W_ki^T W_kj from
+//                              the panel, then row k of U -> memory (Y and, transposed, L), written through for the other blocks.
+//                            All hand-overs are LDS words; no s_barrier in the step loop.
+//   k_chol_fused, blocks 1.. the CARRIED columns: two wavefronts per 16 columns (eight tile rows each, in registers).  They follow block 0
+//                            through a per-step counter in memory (bounded spin): block 0's wavefronts write U_kk^-1 and the row panel
+//                            through (sc1 stores) and count themselves in one step later, the followers read past the caches.  No fence,
+//                            no vmcnt wait and no store sits on the factor workgroup's chain.  (Until round 4 a kernel of its own on a
+//                            helper stream: the event hand-overs in front of it and behind it cost the update ~25 us.)
 //
 // Padding: rows / columns D .. 16 ceil(D / 16) - 1 of A behave as an identity block and the carried columns are tiled from
 // column D on, so no tile mixes matrix and carried columns; nothing outside [D x LA] is read or written.
@@ -72,7 +70,7 @@ struct CholParams {
   double inv_sigma2 = 0.0;
   const double *Y1 = nullptr;         // CH_SRC_WHITENED: [D x LA], the first factorisation's result
   const int32_t *pred_not = nullptr;  // optional: nothing happens when *pred_not != 0 (the not-SPD / time-out flag of an earlier factorisation)
-  int n_arrive = 0;                   // wavefronts of the factor workgroup that count themselves into prog[k] (set by the host: k_chol_factor 16, k_chol_factor2 15)
+  int n_arrive = 0;                   // wavefronts of the factor workgroup that count themselves into prog[k] (set by the host: CH_FW = 15)
 };
 enum { CH_SRC_MATRIX = 0, CH_SRC_PRIOR = 1, CH_SRC_WHITENED = 2 };
 
@@ -115,7 +113,7 @@ __device__ __forceinline__ bool chol_skipped(const CholParams &p) { return (p.pr
 constexpr int CH_FW = 15;  // tile wavefronts of the factor workgroup (wavefront 15 runs the diagonal chain and holds no tiles)
 
 // ---------------------------------------------------------------------------------------------------
-// k_chol_factor2: the factorisation WITHOUT workgroup barriers in the step loop.  (k_chol_factor, its round-2 form with three
+// chol_factor_block (block 0 of k_chol_fused): the factorisation WITHOUT workgroup barriers in the step loop.  (k_chol_factor, its round-2 form with three
 // s_barriers per step, was deleted in round 4: nothing but a debug switch reached it.)
 //
 // In k_chol_factor every step cost the chain wavefront ~16 kcycles for a 6-kcycle tile factorisation: it takes part in the
@@ -137,10 +135,9 @@ constexpr int CH_FW = 15;  // tile wavefronts of the factor workgroup (wavefront
 // Every wait is bounded (a wavefront that runs into the bound raises err / flags[0] like a follower does and leaves).
 // ---------------------------------------------------------------------------------------------------
 constexpr int CH_F2_SLOTS = 10; // 0: (w, w+1); 1: (w+1, w+1); 2 .. 8: the far tiles (j - i >= 2) dealt round-robin; 9: (0, 0) on wavefront 0
-inline size_t chol_factor2_lds_bytes() { return (size_t)(2 * CH_TMAX * 256 + 7 * 256 + 4 * 256 + 16 * CH_TMAX + 64 + 128) * sizeof(double); }
+inline size_t chol_lds_bytes() { return (size_t)(2 * CH_TMAX * 256 + 7 * 256 + 4 * 256 + 16 * CH_TMAX + 64 + 128) * sizeof(double); }
 
-__global__ void __launch_bounds__(64 * (CH_FW + 1), 4) k_chol_factor2(CholParams p) {
-  extern __shared__ __attribute__((aligned(16))) double f2_lds[];
+__device__ __forceinline__ void chol_factor_block(const CholParams &p, double *f2_lds) {
   double *panel = f2_lds;                       // [2][CH_TMAX][256]
   double *st0 = panel + 2 * CH_TMAX * 256;      // [256] diagonal tile hand-over / the factorisation's scratch
   double *st1 = st0 + 256;                      // [3][256] U_kk^-1, row-major
@@ -469,105 +466,155 @@ __global__ void __launch_bounds__(64 * (CH_FW + 1), 4) k_chol_factor2(CholParams
 #undef CTJ
 }
 
-// followers: one wavefront per 16 carried columns (launched on a second stream next to k_chol_factor2)
-__global__ void __launch_bounds__(64 * CH_NW, 2) k_chol_follow(CholParams p) {
-  __shared__ int cov[16 * CH_TMAX]; // CH_SRC_PRIOR: col_cov (see ld_a)
-  if (chol_skipped(p)) return;
+// ---------------------------------------------------------------------------------------------------
+// The carried columns: blocks 1 .. of the SAME launch (round 5; until round 4 a kernel of its own on a helper stream, behind an event).
+// Two wavefronts per 16 carried columns: half h holds the tile rows 8h .. 8h+7 of those columns in registers (a whole column of 16 tiles
+// is 128 registers, the budget of a 16-wavefront workgroup's lane).  They follow the factor workgroup (block 0) through its per-step
+// counter in memory: step k's U_kk^-1 and row panel are written through by block 0 (sc1 stores) and read here past the caches.
+// Step k < 8: the lower half solves W = U_kk^-T S_k (its own tile row), stores it, and hands it to the upper half through LDS (double
+// buffer, acknowledged); both halves update their rows below k.  From step 8 on the lower half is finished and the upper half does both.
+// Blocks of one launch are placed in order, block 0 first: the factor workgroup is resident before anybody waits for it.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void chol_follow_block(const CholParams &p, double *lds, int fb) {
+  double *pairbuf = lds;                                            // [8][2][256] W of step k on its way from the lower to the upper half, accumulator layout (slot q * 64 + lane)
+  int *fl = reinterpret_cast<int *>(pairbuf + 8 * 2 * 256);         // [cs] W of step fl - 1 is in pairbuf, [8 + cs] the upper half has read step fl - 1, [16] a wavefront gave up
+  int *cov = fl + 32;                                               // [16 CH_TMAX] CH_SRC_PRIOR: col_cov (see ld_a_idx)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, cl = lane & 15;
   const int D = p.D, LA = p.LA, TM = (D + 15) >> 4;
-  if (p.src == CH_SRC_PRIOR) {
-    if (tid < 16 * CH_TMAX) cov[tid] = tid < D ? p.col_cov[tid] : 0;
-    __syncthreads();
-  }
-  const int jc = blockIdx.x * CH_NW + wv; // carried tile
-  const int c0 = D + 16 * jc;
-  if (c0 >= LA) return;
+  int cv = 0;
+  if (p.src == CH_SRC_PRIOR && tid < D) cv = p.col_cov[tid];
+  if (chol_skipped(p)) return;
+  if (tid < 32) fl[tid] = 0;
+  if (tid < 16 * CH_TMAX) cov[tid] = cv;
+  __syncthreads();
+  const int cs = wv >> 1, h = wv & 1;
+  const int c0 = D + 16 * (fb * 8 + cs); // first of this pair's carried columns
+  const int i0 = 8 * h;                  // first tile row of this half
+  if (c0 >= LA || i0 >= TM) return;
   const int col = c0 + cl;
   const bool colok = col < LA;
-  d4 acc[CH_TMAX];
-  auto load_columns = [&](auto src_tag) { // all 64 loads of the lane first (rows beyond the matrix read a clamped address and are dropped), then the elements
+  d4 acc[8];
+  auto load_columns = [&](auto src_tag) { // all 32 loads of the lane first (rows beyond the matrix read a clamped address and are dropped), then the elements
     constexpr int SRC = decltype(src_tag)::value;
-    double raw[CH_TMAX][4];
+    double raw[8][4];
 #pragma unroll
-    for (int i = 0; i < CH_TMAX; i++)
+    for (int ii = 0; ii < 8; ii++)
 #pragma unroll
-      for (int q = 0; q < 4; q++) raw[i][q] = *ld_c_ptr<SRC>(p, cov, 16 * i + g + 4 * q, col);
+      for (int q = 0; q < 4; q++) raw[ii][q] = *ld_c_ptr<SRC>(p, cov, 16 * (i0 + ii) + g + 4 * q, col);
 #pragma unroll
-    for (int i = 0; i < CH_TMAX; i++)
+    for (int ii = 0; ii < 8; ii++)
 #pragma unroll
-      for (int q = 0; q < 4; q++) acc[i][q] = ld_c_val<SRC>(p, raw[i][q], col, 16 * i + g + 4 * q < D && colok);
+      for (int q = 0; q < 4; q++) acc[ii][q] = ld_c_val<SRC>(p, raw[ii][q], col, 16 * (i0 + ii) + g + 4 * q < D && colok);
   };
   if (p.src == CH_SRC_PRIOR) load_columns(std::integral_constant<int, CH_SRC_PRIOR>{});
   else if (p.src == CH_SRC_WHITENED) load_columns(std::integral_constant<int, CH_SRC_WHITENED>{});
   else load_columns(std::integral_constant<int, CH_SRC_MATRIX>{});
+  auto give_up = [&]() {
+    // Block 0 never published the step (it is placed first, so this means it left early or the device is wedged).  The carried columns stay
+    // unwritten, so NOTHING behind this factorisation may run: err is raised for the host, and the update is switched off through the very
+    // words the following kernels are predicated on.  The resident state is then untouched and the host repeats the update with the
+    // step-wise kernels (finish_update / update_with_fallbacks).
+    if (lane == 0) {
+      __hip_atomic_store(fl + 16, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      p.err[0] = 1;
+      p.flags[0] = 1;
+      if (p.pred) *const_cast<int32_t *>(p.pred) = 0;
+    }
+  };
+  auto lds_wait = [&](int i, int want) { // a word of this block's LDS; false: the partner gave up (or the bound was hit)
+    int spins = 0;
+    while (__hip_atomic_load(fl + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < want) {
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > (1 << 22) || __hip_atomic_load(fl + 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) return false;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    return true;
+  };
+  auto ld_sys = [](const double *ptr) { return __hip_atomic_load(ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }; // block 0's data was written through (sc1 stores): read past this CU's L1
+  const bool feeds = h == 0 && TM > 8; // the upper half exists and needs W of the steps 0 .. 7
   const long long f_begin = OVG_CHOL_CLOCK();
   long long f_wait = 0;
   for (int k = 0; k < TM; k++) {
-    // wait for step k of the factor workgroup
+    if ((k >> 3) > h) break; // the rows of this half are final
     const long long f_w0 = OVG_CHOL_CLOCK();
-    int spins = 0;
-    while (__hip_atomic_load(p.prog + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < p.n_arrive) {
-      __builtin_amdgcn_s_sleep(2);
-      if (++spins > p.spin_limit) {
-        // The factor workgroup never got scheduled next to us (a shared GPU, a full chip).  The carried columns stay unwritten, so
-        // NOTHING behind this factorisation may run: err is raised for the host, and the update is switched off through the very
-        // words the following kernels are predicated on — the not-SPD flag of a first factorisation (k_tf_abh derives `go` from
-        // it), the `go` word itself for a second one.  The resident state is then untouched and the host repeats the update with
-        // the step-wise kernels (finish_update / update_with_fallbacks).
-        if (lane == 0) {
-          p.err[0] = 1;
-          p.flags[0] = 1;
-          if (p.pred) *const_cast<int32_t *>(p.pred) = 0;
+    { // step k of the factor workgroup
+      int spins = 0;
+      while (__hip_atomic_load(p.prog + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < p.n_arrive) {
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > p.spin_limit) {
+          give_up();
+          return;
         }
-        return;
       }
     }
     f_wait += OVG_CHOL_CLOCK() - f_w0;
-    // the factor workgroup's data was written through (sc1 stores): sc1 loads read it past this CU's L1
-    auto ld_sys = [](const double *ptr) { return __hip_atomic_load(ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
-    double ua[4];
-#pragma unroll
-    for (int u = 0; u < 4; u++) ua[u] = ld_sys(p.uinv + (size_t)k * 256 + (4 * u + g) * 16 + cl);
     d4 w = {0.0, 0.0, 0.0, 0.0};
+    double *pb = pairbuf + ((size_t)cs * 2 + (k & 1)) * 256;
+    if ((k >> 3) == h) { // this half holds tile row k: W = U_kk^-T S_k
+      double ua[4];
 #pragma unroll
-    for (int i = 0; i < CH_TMAX; i++) {
-      if (i == k) {
-#pragma unroll
-        for (int u = 0; u < 4; u++) FEAT_MFMA(ua[u], acc[i][u], w);
-      }
-    }
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-      const int r = 16 * k + g + 4 * q;
-      if (r < D && colok) p.Y[(size_t)r * LA + col] = w[q];
-    }
-    // the row panel's tiles (k, i), i > k, as A operands: element (4u + g, cl) of tile i = Y[16 k + 4u + g][16 i + cl]; 8 tiles in flight
-#pragma unroll
-    for (int h = 0; h < CH_TMAX; h += 8) {
-      if (h + 7 <= k || h >= TM) continue;
-      double wa[8][4];
+      for (int u = 0; u < 4; u++) ua[u] = ld_sys(p.uinv + (size_t)k * 256 + (4 * u + g) * 16 + cl);
 #pragma unroll
       for (int ii = 0; ii < 8; ii++) {
-        const int i = h + ii;
+        if (ii == (k & 7)) {
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-          const int r = 16 * k + 4 * u + g, c = 16 * i + cl;
-          wa[ii][u] = (i > k && i < TM && r < D && c < D) ? ld_sys(p.Y + (size_t)r * LA + c) : 0.0;
+          for (int u = 0; u < 4; u++) FEAT_MFMA(ua[u], acc[ii][u], w);
         }
       }
 #pragma unroll
-      for (int ii = 0; ii < 8; ii++) {
-        const int i = h + ii;
-        if (i > k && i < TM) {
+      for (int q = 0; q < 4; q++) {
+        const int r = 16 * k + g + 4 * q;
+        if (r < D && colok) p.Y[(size_t)r * LA + col] = w[q];
+      }
+      if (feeds) {
+        if (k >= 2 && !lds_wait(8 + cs, k - 1)) return; // the upper half has read step k - 2 (long satisfied): its buffer is free
 #pragma unroll
-          for (int u = 0; u < 4; u++) FEAT_MFMA(-wa[ii][u], w[u], acc[i]);
+        for (int q = 0; q < 4; q++) pb[q * 64 + lane] = w[q];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_store(fl + cs, k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+    } else { // the upper half below step 8: W comes from the lower half
+      if (!lds_wait(cs, k + 1)) return;
+#pragma unroll
+      for (int q = 0; q < 4; q++) w[q] = pb[q * 64 + lane];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (lane == 0) __hip_atomic_store(fl + 8 + cs, k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    // the row panel's tiles (k, i), i > k, as A operands: element (4u + g, cl) of tile i = Y[16 k + 4u + g][16 i + cl]; four tiles in flight.
+    // (rows of a tile row below the last are all inside the matrix; the columns of a partial last tile are masked: right of column D - 1 the
+    // row holds carried columns)
+    const double *yk = p.Y + (size_t)(16 * k + g) * LA + cl;
+#pragma unroll
+    for (int b = 0; b < 8; b += 4) {
+      if (i0 + b + 3 <= k || i0 + b >= TM) continue;
+      double wa[4][4];
+#pragma unroll
+      for (int ii = 0; ii < 4; ii++) {
+        const int i = min(i0 + b + ii, TM - 1);
+#pragma unroll
+        for (int u = 0; u < 4; u++) wa[ii][u] = ld_sys(yk + (size_t)(4 * u) * LA + 16 * i);
+      }
+#pragma unroll
+      for (int ii = 0; ii < 4; ii++) {
+        const int i = i0 + b + ii;
+        if (i > k && i < TM) {
+          const bool cok = 16 * i + cl < D;
+#pragma unroll
+          for (int u = 0; u < 4; u++) FEAT_MFMA(-(cok ? wa[ii][u] : 0.0), w[u], acc[b + ii]);
         }
       }
     }
   }
-  if (OVG_CHOL_DBG(p) && blockIdx.x == 0 && tid == 0) p.dbg[303] += OVG_CHOL_CLOCK() - f_begin, p.dbg[304] += f_wait;
+  if (OVG_CHOL_DBG(p) && fb == 0 && tid == 64) p.dbg[303] += OVG_CHOL_CLOCK() - f_begin, p.dbg[304] += f_wait; // (wavefront 1: the upper half of the first pair runs to the end)
+}
+
+// ONE launch: block 0 factors, blocks 1 .. carry the columns.  Grid = 1 + ceil(carried tiles / 8), 1024 threads, chol_lds_bytes() of dynamic LDS.
+__global__ void __launch_bounds__(64 * (CH_FW + 1), 4) k_chol_fused(CholParams p) {
+  extern __shared__ __attribute__((aligned(16))) double chol_lds[];
+  if (blockIdx.x == 0) chol_factor_block(p, chol_lds);
+  else chol_follow_block(p, chol_lds, blockIdx.x - 1);
 }
 
 } // namespace chol
