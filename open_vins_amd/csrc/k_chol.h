@@ -374,7 +374,6 @@ __device__ __forceinline__ void chol_factor_block(const CholParams &p, double *f
   // row kk of U, U_kk and U_kk^-1 -> memory, by their LDS copies; then this wavefront is done with step kk's buffers
   auto row_to_memory = [&](int kk) {
     const double *pn = panel + (size_t)(kk & 1) * CH_TMAX * 256;
-    if (kk > 0) arrive(kk - 1); // the stores of row kk - 1 were issued a step ago
     if (wv == kk && kk + 1 < TM) store_row_tile(kk, kk + 1, pn + (size_t)(kk + 1) * 256, true);
     // this wavefront's far tiles of row kk, found by arithmetic instead of by walking its (unrolled) slots: ONE copy of the store code
     // and no hoisted address per slot (unrolled seven times the addresses of all copies were computed up front and spilled — 244 bytes
@@ -399,6 +398,9 @@ __device__ __forceinline__ void chol_factor_block(const CholParams &p, double *f
   long long t_uinv = 0, t_st = 0, t_panel = 0, t_cnt = 0, t_trail = 0;
   const long long t_begin = OVG_CHOL_CLOCK();
   for (int k = 0; k < TM; k++) {
+    // the stores of row k - 1 were issued at the end of the last iteration: their completion is waited for HERE, in front of a wait this wavefront has
+    // anyway, and counted for the carried columns' blocks (until round 5 one iteration later, in row_to_memory: they ran two steps behind)
+    if (k > 0) arrive(k - 1);
     const long long t0 = OVG_CHOL_CLOCK();
     if (!wait_for(1, k + 1)) return;
     const long long t1 = OVG_CHOL_CLOCK();
