@@ -12,7 +12,7 @@
 //                              W_kj = U_kk^-T S_kj on the matrix cores -> LDS row panel (counting barrier), S_ij -= W_ki^T W_kj from
 //                              the panel, then row k of U -> memory (Y and, transposed, L), written through for the other blocks.
 //                            All hand-overs are LDS words; no s_barrier in the step loop.
-//   k_chol_fused, blocks 1.. the CARRIED columns: two wavefronts per 16 columns (eight tile rows each, in registers).  They follow block 0
+//   k_chol_fused, blocks 1.. the CARRIED columns: four wavefronts per 16 columns (four tile rows each, in registers).  They follow block 0
 //                            through a per-step counter in memory (bounded spin): block 0's wavefronts write U_kk^-1 and the row panel
 //                            through (sc1 stores) and count themselves in one step later, the followers read past the caches.  No fence,
 //                            no vmcnt wait and no store sits on the factor workgroup's chain.  (Until round 4 a kernel of its own on a
@@ -470,17 +470,22 @@ __device__ __forceinline__ void chol_factor_block(const CholParams &p, double *f
 
 // ---------------------------------------------------------------------------------------------------
 // The carried columns: blocks 1 .. of the SAME launch (round 5; until round 4 a kernel of its own on a helper stream, behind an event).
-// Two wavefronts per 16 carried columns: half h holds the tile rows 8h .. 8h+7 of those columns in registers (a whole column of 16 tiles
-// is 128 registers, the budget of a 16-wavefront workgroup's lane).  They follow the factor workgroup (block 0) through its per-step
-// counter in memory: step k's U_kk^-1 and row panel are written through by block 0 (sc1 stores) and read here past the caches.
-// Step k < 8: the lower half solves W = U_kk^-T S_k (its own tile row), stores it, and hands it to the upper half through LDS (double
-// buffer, acknowledged); both halves update their rows below k.  From step 8 on the lower half is finished and the upper half does both.
+// FOUR wavefronts per 16 carried columns: quarter qt holds the tile rows 4 qt .. 4 qt + 3 of those columns in registers.  They follow the
+// factor workgroup (block 0) through its per-step counter in memory: step k's U_kk^-1 and row panel are written through by block 0 (sc1
+// stores) and read here past the caches.  Step k: the quarter that holds tile row k solves W = U_kk^-T S_k, stores it, and hands it to the
+// quarters below it through LDS (double buffer, acknowledged); every quarter with rows below k updates them.  A quarter's whole step —
+// U_kk^-1 (or nothing) and its four panel tiles — is ONE batch of loads: with two wavefronts per column (eight tile rows, the panel in two
+// batches behind the solve) a step was three memory round trips, more than the chain's step, and the carried columns finished 25 kcycles
+// behind the factorisation (measured).
 // Blocks of one launch are placed in order, block 0 first: the factor workgroup is resident before anybody waits for it.
 // ---------------------------------------------------------------------------------------------------
+constexpr int CH_FQ = 4;              // wavefronts per carried tile column
+constexpr int CH_FT = CH_TMAX / CH_FQ; // tile rows per wavefront
+constexpr int CH_FC = (CH_FW + 1) / CH_FQ; // carried tile columns per block
 __device__ __forceinline__ void chol_follow_block(const CholParams &p, double *lds, int fb) {
-  double *pairbuf = lds;                                            // [8][2][256] W of step k on its way from the lower to the upper half, accumulator layout (slot q * 64 + lane)
-  int *fl = reinterpret_cast<int *>(pairbuf + 8 * 2 * 256);         // [cs] W of step fl - 1 is in pairbuf, [8 + cs] the upper half has read step fl - 1, [16] a wavefront gave up
-  int *cov = fl + 32;                                               // [16 CH_TMAX] CH_SRC_PRIOR: col_cov (see ld_a_idx)
+  double *wbuf = lds;                                                // [CH_FC][2][256] W of step k on its way to the quarters below, accumulator layout (slot q * 64 + lane)
+  int *fl = reinterpret_cast<int *>(wbuf + CH_FC * 2 * 256);         // [cs] W of step fl - 1 is in wbuf; [8 + 4 cs + qt] quarter qt has read step fl - 1; [31] a wavefront gave up
+  int *cov = fl + 32;                                                // [16 CH_TMAX] CH_SRC_PRIOR: col_cov (see ld_a_idx)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, cl = lane & 15;
@@ -491,22 +496,22 @@ __device__ __forceinline__ void chol_follow_block(const CholParams &p, double *l
   if (tid < 32) fl[tid] = 0;
   if (tid < 16 * CH_TMAX) cov[tid] = cv;
   __syncthreads();
-  const int cs = wv >> 1, h = wv & 1;
-  const int c0 = D + 16 * (fb * 8 + cs); // first of this pair's carried columns
-  const int i0 = 8 * h;                  // first tile row of this half
+  const int cs = wv / CH_FQ, qt = wv % CH_FQ;
+  const int c0 = D + 16 * (fb * CH_FC + cs); // first of this group's carried columns
+  const int i0 = CH_FT * qt;                 // first tile row of this quarter
   if (c0 >= LA || i0 >= TM) return;
   const int col = c0 + cl;
   const bool colok = col < LA;
-  d4 acc[8];
-  auto load_columns = [&](auto src_tag) { // all 32 loads of the lane first (rows beyond the matrix read a clamped address and are dropped), then the elements
+  d4 acc[CH_FT];
+  auto load_columns = [&](auto src_tag) { // all loads of the lane first (rows beyond the matrix read a clamped address and are dropped), then the elements
     constexpr int SRC = decltype(src_tag)::value;
-    double raw[8][4];
+    double raw[CH_FT][4];
 #pragma unroll
-    for (int ii = 0; ii < 8; ii++)
+    for (int ii = 0; ii < CH_FT; ii++)
 #pragma unroll
       for (int q = 0; q < 4; q++) raw[ii][q] = *ld_c_ptr<SRC>(p, cov, 16 * (i0 + ii) + g + 4 * q, col);
 #pragma unroll
-    for (int ii = 0; ii < 8; ii++)
+    for (int ii = 0; ii < CH_FT; ii++)
 #pragma unroll
       for (int q = 0; q < 4; q++) acc[ii][q] = ld_c_val<SRC>(p, raw[ii][q], col, 16 * (i0 + ii) + g + 4 * q < D && colok);
   };
@@ -519,27 +524,28 @@ __device__ __forceinline__ void chol_follow_block(const CholParams &p, double *l
     // words the following kernels are predicated on.  The resident state is then untouched and the host repeats the update with the
     // step-wise kernels (finish_update / update_with_fallbacks).
     if (lane == 0) {
-      __hip_atomic_store(fl + 16, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_store(fl + 31, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       p.err[0] = 1;
       p.flags[0] = 1;
       if (p.pred) *const_cast<int32_t *>(p.pred) = 0;
     }
   };
-  auto lds_wait = [&](int i, int want) { // a word of this block's LDS; false: the partner gave up (or the bound was hit)
+  auto lds_wait = [&](int i, int want) { // a word of this block's LDS; false: another wavefront gave up (or the bound was hit)
     int spins = 0;
     while (__hip_atomic_load(fl + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < want) {
       __builtin_amdgcn_s_sleep(1);
-      if (++spins > (1 << 22) || __hip_atomic_load(fl + 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) return false;
+      if (++spins > (1 << 22) || __hip_atomic_load(fl + 31, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) return false;
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     return true;
   };
   auto ld_sys = [](const double *ptr) { return __hip_atomic_load(ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }; // block 0's data was written through (sc1 stores): read past this CU's L1
-  const bool feeds = h == 0 && TM > 8; // the upper half exists and needs W of the steps 0 .. 7
+  const int q_last = (TM - 1) / CH_FT; // the last quarter that holds rows
   const long long f_begin = OVG_CHOL_CLOCK();
   long long f_wait = 0;
   for (int k = 0; k < TM; k++) {
-    if ((k >> 3) > h) break; // the rows of this half are final
+    const int qo = k / CH_FT; // the quarter that holds tile row k
+    if (qo > qt) break;       // the rows of this quarter are final
     const long long f_w0 = OVG_CHOL_CLOCK();
     { // step k of the factor workgroup
       int spins = 0;
@@ -552,15 +558,26 @@ __device__ __forceinline__ void chol_follow_block(const CholParams &p, double *l
       }
     }
     f_wait += OVG_CHOL_CLOCK() - f_w0;
+    // ONE batch of loads: U_kk^-1 (the solving quarter) and the row panel's tiles (k, i) of this quarter's rows i > k, as A operands: element
+    // (4u + g, cl) of tile i = Y[16 k + 4u + g][16 i + cl].  (Rows of a tile row below the last are all inside the matrix; the columns of a
+    // partial last tile are masked: right of column D - 1 the row holds carried columns.)
+    const bool solves = qo == qt;
+    double ua[4], wa[CH_FT][4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) ua[u] = solves ? ld_sys(p.uinv + (size_t)k * 256 + (4 * u + g) * 16 + cl) : 0.0;
+    const double *yk = p.Y + (size_t)(16 * k + g) * LA + cl;
+#pragma unroll
+    for (int ii = 0; ii < CH_FT; ii++) {
+      const int i = min(i0 + ii, TM - 1);
+#pragma unroll
+      for (int u = 0; u < 4; u++) wa[ii][u] = ld_sys(yk + (size_t)(4 * u) * LA + 16 * i);
+    }
     d4 w = {0.0, 0.0, 0.0, 0.0};
-    double *pb = pairbuf + ((size_t)cs * 2 + (k & 1)) * 256;
-    if ((k >> 3) == h) { // this half holds tile row k: W = U_kk^-T S_k
-      double ua[4];
+    double *pb = wbuf + ((size_t)cs * 2 + (k & 1)) * 256;
+    if (solves) { // W = U_kk^-T S_k
 #pragma unroll
-      for (int u = 0; u < 4; u++) ua[u] = ld_sys(p.uinv + (size_t)k * 256 + (4 * u + g) * 16 + cl);
-#pragma unroll
-      for (int ii = 0; ii < 8; ii++) {
-        if (ii == (k & 7)) {
+      for (int ii = 0; ii < CH_FT; ii++) {
+        if (ii == k % CH_FT) {
 #pragma unroll
           for (int u = 0; u < 4; u++) FEAT_MFMA(ua[u], acc[ii][u], w);
         }
@@ -570,49 +587,37 @@ __device__ __forceinline__ void chol_follow_block(const CholParams &p, double *l
         const int r = 16 * k + g + 4 * q;
         if (r < D && colok) p.Y[(size_t)r * LA + col] = w[q];
       }
-      if (feeds) {
-        if (k >= 2 && !lds_wait(8 + cs, k - 1)) return; // the upper half has read step k - 2 (long satisfied): its buffer is free
+      if (qt < q_last) { // quarters below need W
+        if (k >= 2) { // they have read step k - 2 (long satisfied): its buffer is free
+          for (int o = qt + 1; o <= q_last; o++)
+            if (!lds_wait(8 + CH_FQ * cs + o, k - 1)) return;
+        }
 #pragma unroll
         for (int q = 0; q < 4; q++) pb[q * 64 + lane] = w[q];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (lane == 0) __hip_atomic_store(fl + cs, k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
-    } else { // the upper half below step 8: W comes from the lower half
+    } else { // a quarter below the solving one: W comes through LDS
       if (!lds_wait(cs, k + 1)) return;
 #pragma unroll
       for (int q = 0; q < 4; q++) w[q] = pb[q * 64 + lane];
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if (lane == 0) __hip_atomic_store(fl + 8 + cs, k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (lane == 0) __hip_atomic_store(fl + 8 + CH_FQ * cs + qt, k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
-    // the row panel's tiles (k, i), i > k, as A operands: element (4u + g, cl) of tile i = Y[16 k + 4u + g][16 i + cl]; four tiles in flight.
-    // (rows of a tile row below the last are all inside the matrix; the columns of a partial last tile are masked: right of column D - 1 the
-    // row holds carried columns)
-    const double *yk = p.Y + (size_t)(16 * k + g) * LA + cl;
 #pragma unroll
-    for (int b = 0; b < 8; b += 4) {
-      if (i0 + b + 3 <= k || i0 + b >= TM) continue;
-      double wa[4][4];
+    for (int ii = 0; ii < CH_FT; ii++) {
+      const int i = i0 + ii;
+      if (i > k && i < TM) {
+        const bool cok = 16 * i + cl < D;
 #pragma unroll
-      for (int ii = 0; ii < 4; ii++) {
-        const int i = min(i0 + b + ii, TM - 1);
-#pragma unroll
-        for (int u = 0; u < 4; u++) wa[ii][u] = ld_sys(yk + (size_t)(4 * u) * LA + 16 * i);
-      }
-#pragma unroll
-      for (int ii = 0; ii < 4; ii++) {
-        const int i = i0 + b + ii;
-        if (i > k && i < TM) {
-          const bool cok = 16 * i + cl < D;
-#pragma unroll
-          for (int u = 0; u < 4; u++) FEAT_MFMA(-(cok ? wa[ii][u] : 0.0), w[u], acc[b + ii]);
-        }
+        for (int u = 0; u < 4; u++) FEAT_MFMA(-(cok ? wa[ii][u] : 0.0), w[u], acc[ii]);
       }
     }
   }
-  if (OVG_CHOL_DBG(p) && fb == 0 && tid == 64) p.dbg[303] += OVG_CHOL_CLOCK() - f_begin, p.dbg[304] += f_wait; // (wavefront 1: the upper half of the first pair runs to the end)
+  if (OVG_CHOL_DBG(p) && fb == 0 && wv == min(q_last, CH_FQ - 1) && lane == 0) p.dbg[303] += OVG_CHOL_CLOCK() - f_begin, p.dbg[304] += f_wait; // (the last quarter of the first group runs to the end)
 }
 
-// ONE launch: block 0 factors, blocks 1 .. carry the columns.  Grid = 1 + ceil(carried tiles / 8), 1024 threads, chol_lds_bytes() of dynamic LDS.
+// ONE launch: block 0 factors, blocks 1 .. carry the columns.  Grid = 1 + ceil(carried tiles / CH_FC), 1024 threads, chol_lds_bytes() of dynamic LDS.
 __global__ void __launch_bounds__(64 * (CH_FW + 1), 4) k_chol_fused(CholParams p) {
   extern __shared__ __attribute__((aligned(16))) double chol_lds[];
   if (blockIdx.x == 0) chol_factor_block(p, chol_lds);
