@@ -820,7 +820,8 @@ int ovgpu_comm_destroy(ovgpu_ctx *ctx);
  * update are enqueued back to back on the context's stream, no host synchronisation in between.  Per-feature outputs are the
  * shard's; dx / P_out are identical on every rank.  _async returns after enqueueing (status through ovgpu_synchronize).
  * Errors: OVGPU_ERR_NOT_SPD conditions of the (replicated) prior are repeated through the Householder route on every rank alike.
- * A follower time-out of the single-launch Cholesky (a scheduling event of ONE rank, possible only when the device is shared) is NOT
+ * A follower time-out of the single-launch Cholesky (a scheduling event of ONE rank; since round 5 the carried columns' workgroups are
+ * blocks of the factor workgroup's own launch, placed behind it, so it takes a wedged device or the test knob to see one) is NOT
  * repeated in a world of more than one rank -- a local repeat would issue a collective the peers never match: OVGPU_ERR_HIP is
  * returned, this rank's state is untouched while the peers have applied the update, and the caller uploads the state again on every
  * rank (ovgpu_multi_msckf_update: the same, detected for the whole set).  options.no_single_launch_cholesky = 1 rules it out. */

@@ -561,16 +561,18 @@ __device__ __forceinline__ void chol_follow_block(const CholParams &p, double *l
     // ONE batch of loads: U_kk^-1 (the solving quarter) and the row panel's tiles (k, i) of this quarter's rows i > k, as A operands: element
     // (4u + g, cl) of tile i = Y[16 k + 4u + g][16 i + cl].  (Rows of a tile row below the last are all inside the matrix; the columns of a
     // partial last tile are masked: right of column D - 1 the row holds carried columns.)
-    const bool solves = qo == qt;
+    const bool solves = qo == qt, updates = i0 + CH_FT - 1 > k && k + 1 < TM; // (wave-uniform) rows of this quarter below row k exist
     double ua[4], wa[CH_FT][4];
 #pragma unroll
     for (int u = 0; u < 4; u++) ua[u] = solves ? ld_sys(p.uinv + (size_t)k * 256 + (4 * u + g) * 16 + cl) : 0.0;
-    const double *yk = p.Y + (size_t)(16 * k + g) * LA + cl;
+    if (updates) { // (k < TM - 1 here: the panel's rows 16 k .. 16 k + 15 are rows of the matrix)
+      const double *yk = p.Y + (size_t)(16 * k + g) * LA + cl;
 #pragma unroll
-    for (int ii = 0; ii < CH_FT; ii++) {
-      const int i = min(i0 + ii, TM - 1);
+      for (int ii = 0; ii < CH_FT; ii++) {
+        const int i = min(i0 + ii, TM - 1);
 #pragma unroll
-      for (int u = 0; u < 4; u++) wa[ii][u] = ld_sys(yk + (size_t)(4 * u) * LA + 16 * i);
+        for (int u = 0; u < 4; u++) wa[ii][u] = ld_sys(yk + (size_t)(4 * u) * LA + 16 * i);
+      }
     }
     d4 w = {0.0, 0.0, 0.0, 0.0};
     double *pb = wbuf + ((size_t)cs * 2 + (k & 1)) * 256;
@@ -604,13 +606,15 @@ __device__ __forceinline__ void chol_follow_block(const CholParams &p, double *l
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       if (lane == 0) __hip_atomic_store(fl + 8 + CH_FQ * cs + qt, k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
+    if (updates) {
 #pragma unroll
-    for (int ii = 0; ii < CH_FT; ii++) {
-      const int i = i0 + ii;
-      if (i > k && i < TM) {
-        const bool cok = 16 * i + cl < D;
+      for (int ii = 0; ii < CH_FT; ii++) {
+        const int i = i0 + ii;
+        if (i > k && i < TM) {
+          const bool cok = 16 * i + cl < D;
 #pragma unroll
-        for (int u = 0; u < 4; u++) FEAT_MFMA(-(cok ? wa[ii][u] : 0.0), w[u], acc[ii]);
+          for (int u = 0; u < 4; u++) FEAT_MFMA(-(cok ? wa[ii][u] : 0.0), w[u], acc[ii]);
+        }
       }
     }
   }

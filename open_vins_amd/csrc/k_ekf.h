@@ -265,6 +265,19 @@ __device__ __forceinline__ void ekf_dx_item(const EkfParams &p, int i) {
       s3 = fma(a[j + 3], b[j + 3], s3);
     }
   }
+  if (r + 16 <= p.D) { // (D = 208 = 6 x 32 + 16)
+    double a[16], b[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) a[j] = Y[(size_t)(r + j) * p.LA + i], b[j] = y[(size_t)(r + j) * p.LA];
+#pragma unroll
+    for (int j = 0; j < 16; j += 4) {
+      s0 = fma(a[j], b[j], s0);
+      s1 = fma(a[j + 1], b[j + 1], s1);
+      s2 = fma(a[j + 2], b[j + 2], s2);
+      s3 = fma(a[j + 3], b[j + 3], s3);
+    }
+    r += 16;
+  }
   for (; r + 4 <= p.D; r += 4) { // 8 independent loads per trip
     s0 = fma(Y[(size_t)r * p.LA + i], y[(size_t)r * p.LA], s0);
     s1 = fma(Y[(size_t)(r + 1) * p.LA + i], y[(size_t)(r + 1) * p.LA], s1);
@@ -549,7 +562,7 @@ __device__ __forceinline__ void tf_pupdate_tile(const EkfParams &p, const double
   const bool rok = r0 + li < p.N;
   const int rr = rok ? r0 + li : p.N - 1, cc = c0 + li < p.N ? c0 + li : p.N - 1;
   double4_t bb = {0.0, 0.0, 0.0, 0.0}, yy = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll 2
+#pragma unroll 4
   for (int k0 = 0; k0 < p.D; k0 += 16) {
     double a1[4], b1[4], a2[4], b2[4];
 #pragma unroll
