@@ -234,3 +234,33 @@ def test_change_anchors_and_marginalize_in_a_mixed_state(Updater, oracle):
     assert np.array_equal(out["feat_status"], ref_u["feat_status"]) and (ref_u["feat_status"] == capi.FEAT_USED).sum() >= 4
     assert _rel(out["dx"], ref_u["dx"]) < 1e-7 and _rel(out["P"], ref_u["P"]) < 1e-8
     up.close()
+
+
+def test_mixed_representation_edge_cases(Updater, oracle):
+    """Bad inputs of the ABI 7 entry points: an unknown representation in feat_rep_each / ovgpu_set_feature_reps, per-feature representations
+    without a batch, anchors missing for an anchored landmark; and the empty cases (no landmarks, per-feature reps cleared with NULL)."""
+    import ctypes as C
+    opts = capi.default_options(chi2_multipler=1.0)
+    each = np.array([0, 4, 5, 2], np.int32)
+    prob = synth.make_slam_problem(2, L=4, lm_rep=each)
+    up = Updater(opts)
+    v = capi.Views(prob)
+    capi.check(up.lib.ovgpu_set_state(up._ctx, C.byref(v.state)), "ovgpu_set_state")
+    bad = np.array([0, 4, 9, 2], np.int32)
+    lv = capi.LandmarksView.from_buffer_copy(v.landmarks)
+    lv.feat_rep_each = bad.ctypes.data_as(capi.c_int32_p)
+    assert up.lib.ovgpu_set_landmarks(up._ctx, C.byref(lv)) == capi.ERR_INVALID
+    lv = capi.LandmarksView.from_buffer_copy(v.landmarks)
+    lv.anchor_cam = None  # landmarks 1 .. 3 are anchored
+    assert up.lib.ovgpu_set_landmarks(up._ctx, C.byref(lv)) == capi.ERR_INVALID
+    assert up.lib.ovgpu_set_feature_reps(up._ctx, each.ctypes.data_as(capi.c_int32_p)) == capi.ERR_NO_STATE  # no batch is resident
+    up.set_slam_problem(prob)
+    assert up.lib.ovgpu_set_feature_reps(up._ctx, bad.ctypes.data_as(capi.c_int32_p)) == capi.ERR_INVALID
+    capi.check(up.lib.ovgpu_set_feature_reps(up._ctx, each.ctypes.data_as(capi.c_int32_p)), "ovgpu_set_feature_reps")
+    capi.check(up.lib.ovgpu_set_feature_reps(up._ctx, None), "ovgpu_set_feature_reps")  # cleared: the call's feat_rep for every feature again
+    lm = up.get_landmarks()
+    assert np.array_equal(lm["feat_rep"], each) and np.array_equal(lm["anchor_cam"] >= 0, each >= 2)
+    out = up.slam_update()
+    ref = oracle.slam_update(opts, v)
+    assert np.array_equal(out["feat_status"], ref["feat_status"]) and _rel(out["dx"], ref["dx"]) < 1e-7
+    up.close()
