@@ -852,6 +852,8 @@ int ovgpu_last_update_route(ovgpu_ctx *ctx);
  *                             are switched off on the device, the state stays untouched and the synchronous update calls repeat
  *                             the update with the step-wise kernels
  *   "chol_timeouts"           (read only) number of updates repeated that way
+ *   "tri_waves"               features per workgroup of the triangulation kernel, 1 .. 16; 0 (default) = chosen by the batch so that,
+ *                             where possible, a few compute units stay free for the prior block's factorisation launched beside it
  *   "stage_timing_period"     n >= 1: the six stage events (ovgpu_update_stats::ms_*, ovgpu_kernel_times) go into every n-th update
  *                             only (each is a marker packet the next kernel waits for, ~5 us); updates without events report 0
  *   "stack_is_f32"            (read only) the last pipeline stored the stack as floats and ran k_gram_f32 (options.gram_fp32)

@@ -91,13 +91,13 @@ __device__ __forceinline__ double gn_cost(const double *lds_cc, const uint16_t *
 }
 
 // grid: ceil(F / 4) blocks of 256 threads (4 wavefronts = 4 features per workgroup)
-__global__ void __launch_bounds__(256) k_triangulate(TriParams p) {
+__global__ void __launch_bounds__(1024) k_triangulate(TriParams p) {
   extern __shared__ __attribute__((aligned(16))) double lds_cc[]; // [K*C*12]
   for (int i = threadIdx.x; i < p.K * p.C * 12; i += blockDim.x) lds_cc[i] = p.tab_cc[i];
   __syncthreads();
 
   const int lane = threadIdx.x & 63;
-  const int f = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int f = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (f >= p.F) return; // whole wavefront leaves together
   const int m0 = p.meas_offsets[f], m1 = p.meas_offsets[f + 1];
   const int m = m1 - m0;
