@@ -169,6 +169,7 @@ struct FeatStore {
   double *z;      // [F][3][LD]  T^T V^T [H L | r]
   const int32_t *meas_feat; // [M] feature of each measurement
   double *w;                // [F][3][LD] T^T V^T [H | r] of every feature (k_feat_qr), the left operand of k_feat_z
+  const int32_t *pos;       // [M] where each measurement's record goes: clone-major order inside its feature (computed with the batch's layout, api_state.inc)
 };
 
 

@@ -89,19 +89,7 @@ __global__ void __launch_bounds__(256) k_feat_rows_sorted(SysParams p, FeatStore
   if (gm >= M) return;
   const int f = st.meas_feat[gm];
   if (p.status[f] != OVGPU_FEAT_USED) return;
-  const int m0 = p.meas_offsets[f], m1 = p.meas_offsets[f + 1];
-  // rank of this measurement inside its feature: (clone column, camera, index)
-  auto key = [&](int i) {
-    const int code = p.meas_cc[i];
-    return (p.clone_col[code & 1023] << 8) | (code >> 10);
-  };
-  const int mykey = key(gm);
-  int rank = 0;
-  for (int i = m0; i < m1; i++) {
-    const int k = key(i);
-    rank += (k < mykey) || (k == mykey && i < gm);
-  }
-  const int pos = m0 + rank;
+  const int pos = st.pos[gm]; // its rank inside the feature by (clone column, camera, index), from the batch's layout (k_feat_sort_pos)
   const V3 p_FinG = load_v3(p.p_FinG + 3 * f); // fej == value for MSCKF features (UpdaterMSCKF.cpp:186-194)
   double hq[21];
   double *dl = hq + 12;
