@@ -3,6 +3,8 @@
 # bench lines.  Usage: gpu_bitcompare.sh TAG [control] [cfg3] [cfg2] [cfg4] [cfg5]
 #   control   also the base build against itself (the determinism control)
 #   cfgN      bench lines to alternate: cfg3 = configs[2] (the headline), cfg2 = configs[1], cfg4 = configs[3] on one GPU, cfg5 = one rank's share of configs[4]
+# (Since k_feat_anchor, round 5, k_triangulate compiles to differently paired multiply-adds: against a base older than that commit p_FinG and what follows
+# from it differ at 1e-13; take a base from that commit or later for a bit-for-bit answer.)
 # ab_old/problems.pkl: the problems, generated here on the CPU (`python tools/dev_bitcompare.py prepare ab_old/problems.pkl`).
 # Late round 4 this was run as: `bitcmp control cfg3 cfg2` (the 4-wavefront kernel in its own translation unit), `bitcmp2 cfg4 cfg5` (the 8-wavefront and
 # block-row kernels), `prio cfg4 cfg3` (the gate chain's wave priority): profiles/r04_late_*.
