@@ -106,9 +106,8 @@ constexpr int FY_INST = 24;           // instances per tile row: <= 8 clones + 8
 constexpr int FY_ISTR = 32;           // ints per tile row in the instance table: [0] count, [1] last non-zero column, [8 ..] instances
 constexpr int FY_IOFF = 8;
 // Round 4: the wavefront also finishes what needs nothing but the reflectors — the RESIDUAL column of the feature's stacked rows
-// (rows 3.. of Q^T r; never whitened) and the residual bound of the gate, |Q2^T r|^2 / s^2 (tq[8 f + 6]) — and leaves, per tile row
-// and column block of `cb` columns, the first instance that reaches the block and the first that reaches past its first half
-// (il[2 ..], three blocks of 10 bits per int): k_feat_y's prologue and its sweep were chains of dependent look-ups for these.
+// (rows 3.. of Q^T r; never whitened) and the residual bound of the gate, |Q2^T r|^2 / s^2 (tq[8 f + 6]).  (The instance lists of the
+// feature's tile rows, built behind that until round 5, depend on the batch alone: k_feat_inst below, once per batch.)
 template <bool F32OUT>
 __device__ __forceinline__ void vt_residual_column(const SysParams &p, int64_t orow0, const double *V, const double *res, int n, int lane, double z0, double z1,
                                                     double z2, double &sumsq) {
@@ -122,7 +121,7 @@ __device__ __forceinline__ void vt_residual_column(const SysParams &p, int64_t o
   sumsq = wave_sum(sq);
 }
 #ifndef OVG_TU_FEATY
-__global__ void __launch_bounds__(256) k_feat_vt(SysParams p, FeatStore st, double *__restrict__ tq, int32_t *__restrict__ inst, int nt_max, int cb) {
+__global__ void __launch_bounds__(256) k_feat_vt(SysParams p, FeatStore st, double *__restrict__ tq) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int f = blockIdx.x * 4 + wv;
@@ -174,21 +173,36 @@ __global__ void __launch_bounds__(256) k_feat_vt(SysParams p, FeatStore st, doub
     // reference's test (UpdaterMSCKF.cpp:216-225) whatever its gate matrix holds
     if (lane == 0) tq[(size_t)8 * f + 6] = sumsq / p.opt.sigma_pix_sq;
   }
-  // The distinct column blocks ("instances": first column, width) of every tile row of 16 rows, ascending — what the sweep of k_feat_y
-  // loops over.  il[0] = count, il[1] = last non-zero column of the tile row, il[FY_IOFF ..] = (type << 24) | (width << 16) | first column
-  // (type 0 clone block, 1 camera extrinsics, 2 camera intrinsics: k_featw.h selects the lane's operand by it).
-  // (built in LDS: the column triples of the measurements are staged by all lanes, the lists grow in the wavefront's scratch)
+}
+
+// k_feat_inst: one wavefront per feature -> the distinct column blocks ("instances": first column, width) of every tile row of 16 rows,
+// ascending — what the sweep of k_feat_y loops over.  il[0] = count, il[1] = last non-zero column of the tile row, il[2 .. 5] = per column block
+// of `cb` columns the first instance that reaches the block and the first that reaches past its first half (three blocks of 10 bits per int),
+// il[FY_IOFF ..] = (type << 24) | (width << 16) | first column (type 0 clone block, 1 camera extrinsics, 2 camera intrinsics: k_featw.h selects
+// the lane's operand by it).  A function of the batch and of the column map alone: run once per batch (round 5; the tail of k_feat_vt on every
+// update before, ~8 us on the critical chain of the update's head).  The column triples of the measurements are staged clone-major (pos,
+// k_feat_sort_pos) in LDS by all lanes, one lane per tile row builds its list there.
+__global__ void __launch_bounds__(256) k_feat_inst(int F, int m_max, int D, const int32_t *__restrict__ meas_offsets, const uint16_t *__restrict__ meas_cc,
+                                                   const int32_t *__restrict__ pos, const int32_t *__restrict__ clone_col, const int32_t *__restrict__ calib_col,
+                                                   const int32_t *__restrict__ intr_col, int32_t *__restrict__ inst, int nt_max, int cb) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int f = blockIdx.x * 4 + wv;
+  if (f >= F) return;
+  int *cols3 = reinterpret_cast<int *>(smem) + (size_t)wv * (3 * m_max + ((2 * m_max + 15) >> 4) * FY_ISTR); // [m][3]
+  int *lists = cols3 + 3 * m_max;                                                                            // [NT][FY_ISTR]
+  const int m0 = meas_offsets[f], m = meas_offsets[f + 1] - m0, n = 2 * m;
   const int NT = (n + 15) >> 4;
-  int *cols3 = reinterpret_cast<int *>(hf);                 // [m][3]: hf is dead (6 m doubles = 12 m ints)
-  int *lists = reinterpret_cast<int *>(V);                  // [NT][FY_ISTR]: V is in HBM by now (6 m doubles >= NT FY_ISTR ints for m >= 3 ... checked below)
-  const bool lds_lists = (size_t)NT * FY_ISTR <= (size_t)12 * m;
-  const int32_t *finfo = st.minfo + (size_t)8 * m0;
-  wsync();
-  for (int i = lane; i < m; i += 64) cols3[3 * i] = finfo[8 * i + 2], cols3[3 * i + 1] = finfo[8 * i + 3], cols3[3 * i + 2] = finfo[8 * i + 4];
-  wsync();
+  for (int i = lane; i < m; i += 64) {
+    const int code = meas_cc[m0 + i], j = pos[m0 + i] - m0;
+    cols3[3 * j] = clone_col[code & 1023], cols3[3 * j + 1] = calib_col[code >> 10], cols3[3 * j + 2] = intr_col[code >> 10];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   if (lane < NT) {
     int *gl = inst + ((size_t)f * nt_max + lane) * FY_ISTR;
-    int *il = lds_lists ? lists + lane * FY_ISTR : gl;
+    int *il = lists + lane * FY_ISTR;
     int cnt = 0, lim = -1, prev = -1;
     int seen_p[8], seen_i[8], np_ = 0, ni_ = 0; // the calibration blocks met so far in this tile row (at most one pair per measurement)
     const int i1 = min(8 * lane + 8, m);
@@ -219,7 +233,7 @@ __global__ void __launch_bounds__(256) k_feat_vt(SysParams p, FeatStore st, doub
     }
     il[0] = cnt, il[1] = lim;
     // per column block of cb columns: e0 = the first instance that reaches the block, e1 = the first that reaches past its first half
-    const int nblk = (p.D + cb - 1) / cb;
+    const int nblk = (D + cb - 1) / cb;
     int packed[4] = {0, 0, 0, 0};
     for (int kb = 0; kb < nblk && kb < 12; kb++) {
       const int c_lo = cb * kb;
@@ -232,10 +246,8 @@ __global__ void __launch_bounds__(256) k_feat_vt(SysParams p, FeatStore st, doub
         if (w == kb / 3) packed[w] |= (e0 | (e1 << 5)) << (10 * (kb % 3));
     }
     gl[2] = packed[0], gl[3] = packed[1], gl[4] = packed[2], gl[5] = packed[3];
-    if (lds_lists) {
-      gl[0] = cnt, gl[1] = lim;
-      for (int e = 0; e < cnt; e++) gl[FY_IOFF + e] = il[FY_IOFF + e];
-    }
+    gl[0] = cnt, gl[1] = lim;
+    for (int e = 0; e < cnt; e++) gl[FY_IOFF + e] = il[FY_IOFF + e];
   }
 }
 #endif // OVG_TU_FEATY
