@@ -290,7 +290,12 @@ double ovgpu_chi2_quantile_95(int dof);
  * The data stay resident in HBM until the next ovgpu_set_state.              */
 int ovgpu_set_state(ovgpu_ctx *ctx, const ovgpu_state_view *st);
 
-/* Uploads a batch of feature tracks (host pointers) and keeps it resident.   */
+/* Uploads a batch of feature tracks (host pointers) and keeps it resident.
+ * What depends on the batch and on the state's column map alone is derived
+ * here, once, behind the copies on the context's stream (the anchor
+ * measurement of every track by FeatureInitializer.cpp:36-46's rule, the
+ * clone-major order of a track's measurements, the column blocks each tile of
+ * 16 Jacobian rows touches): updates on the resident batch do not repeat it.  */
 int ovgpu_set_features(ovgpu_ctx *ctx, const ovgpu_features_view *fv);
 
 /* ------------------------------------------------------------------------- */
