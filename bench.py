@@ -160,7 +160,7 @@ def main(argv=None):
     timed_loops = []  # seconds of every timed loop of the last run()
     rank_loops = []   # the last timed loop of the last run(): every rank's own seconds (before the max over ranks)
 
-    def run(prob_full, feats_of_rank, steps, warmup, local_only=False, repeats=1, opts=opts, min_seconds=0.0):
+    def run(prob_full, feats_of_rank, steps, warmup, local_only=False, repeats=1, opts=opts, min_seconds=0.0, debug=None):
         """Times `steps` updates of prob_full sharded as feats_of_rank(rank); returns (seconds max over ranks, updater, shard).
         local_only: every rank updates with ITS shard alone (no exchange) — the compute side of the scaling model."""
         shard = prob_full if world == 1 else prob_full.subset(feats_of_rank)
@@ -171,6 +171,8 @@ def main(argv=None):
         up.debug_option("stage_timing_period", args.stage_events_every)
         for kv in args.debug_option:
             name, _, val = kv.partition("=")
+            up.debug_option(name, int(val))
+        for name, val in (debug or {}).items():
             up.debug_option(name, int(val))
         up.set_problem(shard)  # H2D once; everything below runs on resident data
         native = True
@@ -300,6 +302,20 @@ def main(argv=None):
             gup.close()
             timed_loops[:] = keep_loops
             extras["gate_always_factor_ms_per_step"] = 1e3 * gdt / gsteps
+        if world == 1:
+            # The integer tables ovgpu_set_features derives ONCE per batch (anchor measurements, clone-major positions, column-block lists:
+            # ~40 us of small kernels) are outside the timed region above, like the upload they belong to.  A filter hands over a new batch
+            # every frame: this is the same loop with those tables rebuilt at the head of EVERY update (ovgpu_debug_option
+            # "layout_every_update"), i.e. resident inputs, nothing derived from them reused.
+            try:
+                lsteps = max(5, args.steps // 4)
+                keep_loops = list(timed_loops)
+                ldt, lup, _ = run(prob, mine, lsteps, 5, debug={"layout_every_update": 1})
+                lup.close()
+                timed_loops[:] = keep_loops
+                extras["ms_per_step_with_batch_layout"] = 1e3 * ldt / lsteps
+            except Exception as e:  # noqa: BLE001  (a library without the switch)
+                print(f"[bench] ms_per_step_with_batch_layout not measured: {e}", file=sys.stderr, flush=True)
         if world == 1 and not args.gate_always_factor and args.route == "gram":
             # The same batch on a window as tight as a RUNNING filter's.  SURVEY 8(d)'s snapshot gives every clone an independent 0.57 deg /
             # 5 cm of prior uncertainty (10 - 50 px of predicted-pixel uncertainty: no residual bound can decide such a gate); in the

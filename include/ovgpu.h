@@ -857,6 +857,9 @@ int ovgpu_last_update_route(ovgpu_ctx *ctx);
  *                             are switched off on the device, the state stays untouched and the synchronous update calls repeat
  *                             the update with the step-wise kernels
  *   "chol_timeouts"           (read only) number of updates repeated that way
+ *   "layout_every_update"     1: the integer tables ovgpu_set_features derives once per batch (anchor measurements, clone-major
+ *                             positions, column-block lists) are built again at the head of every update — what a timing loop over
+ *                             a resident batch has to add to stand for a filter that hands over a new batch per frame
  *   "tri_waves"               features per workgroup of the triangulation kernel, 1 .. 16; 0 (default) = chosen by the batch so that,
  *                             where possible, a few compute units stay free for the prior block's factorisation launched beside it
  *   "stage_timing_period"     n >= 1: the six stage events (ovgpu_update_stats::ms_*, ovgpu_kernel_times) go into every n-th update
