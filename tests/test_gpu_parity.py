@@ -226,6 +226,30 @@ def test_feature_kernel_shapes(Updater, oracle, kw, shape):
     _check_given(Updater, oracle, prob, capi.default_options(chi2_multipler=1.0), debug=dict(featy_shape=shape))
 
 
+@pytest.mark.parametrize("kw", [dict(F=300), dict(F=200, track="ragged", outlier_frac=0.3), dict(cfg=3, F=260)])
+def test_batch_tables_rebuilt_on_every_update(Updater, kw):
+    """ovgpu_debug_option "layout_every_update": the integer tables ovgpu_set_features derives once per batch (anchor measurements,
+    clone-major positions, column-block lists of the tile rows) rebuilt at the head of every update -- the loop bench.py reports as
+    ms_per_step_with_batch_layout.  The same kernels on the same batch: the update must not change."""
+    kw = dict(kw)
+    prob = synth.make_problem(kw.pop("cfg", 2), **kw)
+    opts = capi.default_options(chi2_multipler=1.0)
+    outs = []
+    for flag in (0, 1):
+        up = Updater(opts)
+        assert up.debug_option("layout_every_update", flag) == 0
+        up.set_problem(prob)
+        outs.append(up.update())
+        assert up.debug_option("layout_every_update") == flag
+        up.close()
+    ref, out = outs
+    assert (ref["feat_status"] == capi.FEAT_USED).sum() > 0.3 * prob.F
+    assert np.array_equal(out["feat_status"], ref["feat_status"])
+    assert out["stats"]["n_rows"] == ref["stats"]["n_rows"]
+    assert _rel(out["dx"], ref["dx"]) < 1e-12
+    assert _rel(out["P"], ref["P"]) < 1e-12
+
+
 def test_short_and_empty_tracks(Updater, oracle):
     prob = synth.make_problem(2, F=12)
     keep, offs = [], [0]
