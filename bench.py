@@ -307,15 +307,16 @@ def main(argv=None):
             # ~40 us of small kernels) are outside the timed region above, like the upload they belong to.  A filter hands over a new batch
             # every frame: this is the same loop with those tables rebuilt at the head of EVERY update (ovgpu_debug_option
             # "layout_every_update"), i.e. resident inputs, nothing derived from them reused.
+            keep_loops = list(timed_loops)
             try:
                 lsteps = max(5, args.steps // 4)
-                keep_loops = list(timed_loops)
                 ldt, lup, _ = run(prob, mine, lsteps, 5, debug={"layout_every_update": 1})
                 lup.close()
-                timed_loops[:] = keep_loops
                 extras["ms_per_step_with_batch_layout"] = 1e3 * ldt / lsteps
             except Exception as e:  # noqa: BLE001  (a library without the switch)
                 print(f"[bench] ms_per_step_with_batch_layout not measured: {e}", file=sys.stderr, flush=True)
+            finally:
+                timed_loops[:] = keep_loops
         if world == 1 and not args.gate_always_factor and args.route == "gram":
             # The same batch on a window as tight as a RUNNING filter's.  SURVEY 8(d)'s snapshot gives every clone an independent 0.57 deg /
             # 5 cm of prior uncertainty (10 - 50 px of predicted-pixel uncertainty: no residual bound can decide such a gate); in the
