@@ -419,7 +419,7 @@ def test_slam_update_in_other_representations(rep):
     reproduce the posterior in information form, and the landmark columns must be the GLOBAL_3D ones chained with
     d xyz / d lambda — checked through finite differences of get_xyz on the residual."""
     from oracle import pyoracle
-    prob = synth.make_slam_problem(2, L=8, lm_rep=rep)
+    prob = synth.make_slam_problem(2, L=8, lm_rep=rep, C=16)
     opts = capi.default_options(chi2_multipler=5.0)
     v = capi.Views(prob)
     o = pyoracle.slam_update(opts, v, want_stack=True)
@@ -441,7 +441,7 @@ def test_slam_update_in_other_representations(rep):
         eps = 1e-3 * max(abs(prob.lm_value[f, i]), 0.05)
         rr = []
         for sgn in (+1, -1):
-            p2 = synth.make_slam_problem(2, L=8, lm_rep=rep)
+            p2 = synth.make_slam_problem(2, L=8, lm_rep=rep, C=16)
             p2.lm_value[f, i] += sgn * eps
             rr.append(pyoracle.slam_update(opts0, capi.Views(p2), want_stack=True)["r"][rows])
         fd = -(rr[0] - rr[1]) / (2 * eps)

@@ -253,7 +253,7 @@ def test_slam_update_against_the_reference_random_shapes(seed):
 def test_slam_update_with_aruco_options_against_the_reference(rep):
     """UpdaterSLAM.cpp:392-409, :444: tag corners (feature id < max_aruco_features) carry their own sigma and chi2 multiplier; R_big is
     diagonal but not isotropic."""
-    prob = synth.make_slam_problem(2, L=12, lm_rep=rep)
+    prob = synth.make_slam_problem(2, L=12, lm_rep=rep, C=16)  # (a 16-clone window: the reference's EKFUpdate through the stand-in Eigen is cubic in the state)
     opts = capi.default_options(chi2_multipler=1.0)
     v = capi.Views(prob)
     tag = np.random.default_rng(3).random(v.features.F) < 0.4
@@ -268,8 +268,10 @@ def test_slam_update_with_aruco_options_against_the_reference(rep):
 MIXED_REPS = [  # feat_rep_slam next to feat_rep_aruco (StateOptions.h:89-95), and every representation at once
     [capi.REP_ANCHORED_MSCKF_INVERSE_DEPTH, capi.REP_GLOBAL_3D],
     [capi.REP_ANCHORED_3D, capi.REP_ANCHORED_INVERSE_DEPTH_SINGLE],
+    [capi.REP_GLOBAL_FULL_INVERSE_DEPTH, capi.REP_ANCHORED_FULL_INVERSE_DEPTH],
+    [capi.REP_ANCHORED_INVERSE_DEPTH_SINGLE, capi.REP_GLOBAL_FULL_INVERSE_DEPTH],
     [0, 1, 2, 3, 4, 5],
-]  # (the reference's EKFUpdate through the stand-in Eigen takes ~20 s per call at this state size: three mixes; the GPU suite and the fixtures hold two more)
+]  # (on a 16-clone window: the reference's EKFUpdate through the stand-in Eigen is cubic in the state, ~20 s per call at 30 clones)
 
 
 @pytest.mark.parametrize("reps", MIXED_REPS, ids=lambda r: "-".join(map(str, r)))
@@ -278,7 +280,7 @@ def test_slam_update_mixed_representations_against_the_reference(reps):
     different representations (feat_rep_slam != feat_rep_aruco) share ONE Hx_big / R_big and one EKFUpdate."""
     L = 12
     each = np.array([reps[l % len(reps)] for l in range(L)], np.int32)
-    prob = synth.make_slam_problem(2, L=L, lm_rep=each)
+    prob = synth.make_slam_problem(2, L=L, lm_rep=each, C=16)
     opts = capi.default_options(chi2_multipler=1.0)
     v = capi.Views(prob)
     tag = each == reps[-1]  # the corners carry the ArUco option set as well
