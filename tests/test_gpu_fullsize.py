@@ -98,9 +98,33 @@ def _parity_device_triangulation(Updater, oracle, prob, opts, tol_dx=1e-8, tol_p
 
 
 def test_cfg3_full_size_end_to_end_with_the_device_triangulation(Updater, oracle):
-    """BASELINE configs[2] (2000 features, 100 k measurements) with nothing injected: the batch bench.py times."""
+    """BASELINE configs[2] (2000 features, 100 k measurements) on SURVEY 8(d)'s N = 224 state with nothing injected (bench.py's
+    `survey_8d_state` extra; the batch bench.py's HEADLINE times is the next test's)."""
     prob = synth.make_problem(3)
+    assert prob.N == 224
     _parity_device_triangulation(Updater, oracle, prob, capi.default_options(chi2_multipler=1.0), key=("cfg3", 2000))
+
+
+def test_headline_config_end_to_end_with_the_device_triangulation(Updater, oracle):
+    """THE configuration bench.py times (bench.py: synth.make_problem(3, imu_intrinsics=True)): BASELINE configs[2] as written — 2000 features,
+    30 clones, stereo, online camera AND IMU calibration: the 24 IMU-intrinsic variables of State.cpp:65-88 are in the state (N = 248) and
+    get no Jacobian columns (UpdaterHelper.cpp:201-261), their coupling enters through P (UpdaterMSCKF.cpp:209-234, StateHelper.cpp:116-197).
+    Nothing injected: device triangulation -> gate -> compression -> update against the oracle."""
+    prob = synth.make_problem(3, imu_intrinsics=True)
+    assert prob.F == 2000 and prob.N == 248
+    _parity_device_triangulation(Updater, oracle, prob, capi.default_options(chi2_multipler=1.0), key=("cfg3_imu", 2000))
+
+
+@pytest.mark.parametrize("full_gate", [0, 1])
+def test_headline_config_against_oracle(Updater, oracle, full_gate):
+    """The same N = 248 batch with the oracle's triangulation injected on both sides (positions then agree exactly: every number downstream is
+    held to the full-size tolerances), with the default gate and with every gate matrix factored."""
+    prob = synth.make_problem(3, imu_intrinsics=True)
+    assert prob.F == 2000 and prob.N == 248
+    out, ref = _parity(Updater, oracle, prob, capi.default_options(chi2_multipler=1.0, gate_always_factor=full_gate), key=("cfg3_imu", 2000))
+    # the IMU-intrinsic block moves through its cross-covariance only: its correction is non-zero and its posterior block the oracle's
+    imu_i = slice(15, 39)
+    assert np.abs(ref["dx"][imu_i]).max() > 0 and _rel(out["P"][imu_i, imu_i], ref["P"][imu_i, imu_i]) < 1e-9
 
 
 def test_cfg4_shard_end_to_end_with_the_device_triangulation(Updater, oracle):
