@@ -65,8 +65,12 @@ extern "C" {
 /*      does; ovgpu_slam_delayed_init may initialise in a representation other   */
 /*      than the resident landmarks'; ovgpu_get_landmark_reps reads them back.   */
 /*      A caller compiled against ABI 6 passes a shorter struct: rebuild.        */
+/*   8  (round 6) OVGPU_COMPRESS_CHOLQR (= 2, the unpivoted Cholesky factor of  */
+/*      the Gram matrix as a compressed system: a documented negative result)   */
+/*      is gone: ovgpu_create returns OVGPU_ERR_INVALID for it.  Nothing else   */
+/*      changed shape.                                                          */
 /* ------------------------------------------------------------------------- */
-#define OVGPU_ABI_VERSION 7
+#define OVGPU_ABI_VERSION 8
 int ovgpu_abi_version(void);
 
 /* ------------------------------------------------------------------------- */
@@ -191,8 +195,9 @@ typedef enum {
                              /* stacks and when the prior block's factorisation fails)                          */
   OVGPU_COMPRESS_TSQR = 1,   /* Householder TSQR: the reference's upper-triangular factor (mode A) + the        */
                              /* reference-shaped update (mode B); always used by ovgpu_measurement_compress     */
-  OVGPU_COMPRESS_CHOLQR = 2, /* R = chol(Gram), UNPIVOTED: kept as the measured negative result of DESIGN.md    */
-                             /* section 4 (closed-loop drift 6e-6)                                              */
+                             /* (2 was OVGPU_COMPRESS_CHOLQR, the UNPIVOTED factor of the Gram matrix: a        */
+                             /* measured negative result — closed-loop drift 6e-6 — retired with ABI 8;         */
+                             /* ovgpu_create refuses the value)                                                 */
   OVGPU_COMPRESS_PCHOLQR = 3 /* what ovgpu_last_update_route reports after a mode A call that took the pivoted  */
                              /* factor; as an option it is an alias of OVGPU_COMPRESS_GRAM                      */
 } ovgpu_compress_route;

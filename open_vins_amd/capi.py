@@ -20,7 +20,7 @@ ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_NEGATIVE_DIAGONAL, ERR_NOT_SPD, ERR_CAP
 FEAT_USED, FEAT_TOO_FEW_MEAS, FEAT_TRI_FAILED, FEAT_GN_FAILED, FEAT_CHI2_REJECTED = 0, 1, 2, 3, 4
 REP_GLOBAL_3D, REP_GLOBAL_FULL_INVERSE_DEPTH, REP_ANCHORED_3D = 0, 1, 2
 REP_ANCHORED_FULL_INVERSE_DEPTH, REP_ANCHORED_MSCKF_INVERSE_DEPTH, REP_ANCHORED_INVERSE_DEPTH_SINGLE = 3, 4, 5
-COMPRESS_GRAM, COMPRESS_TSQR, COMPRESS_CHOLQR, COMPRESS_PCHOLQR = 0, 1, 2, 3
+COMPRESS_GRAM, COMPRESS_TSQR, COMPRESS_PCHOLQR = 0, 1, 3  # (2: the unpivoted Gram factor, retired with ABI 8)
 GROUPS_REFERENCE, GROUPS_DESCENDING, GROUPS_ASCENDING = 0, 1, 2
 
 c_double_p = C.POINTER(C.c_double)

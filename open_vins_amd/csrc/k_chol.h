@@ -548,6 +548,10 @@ __device__ __forceinline__ void chol_follow_block(const CholParams &p, double *l
     if (qo > qt) break;       // the rows of this quarter are final
     const long long f_w0 = OVG_CHOL_CLOCK();
     { // step k of the factor workgroup
+      if (p.spin_limit <= 0) { // the test knob (ovgpu_debug_option "chol_follow_spin_limit" = 0): give up whether or not the step is there —
+        give_up();             // with one poll allowed the outcome was a race against the factor workgroup (it flipped under a loaded GPU)
+        return;
+      }
       int spins = 0;
       while (__hip_atomic_load(p.prog + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < p.n_arrive) {
         __builtin_amdgcn_s_sleep(2);

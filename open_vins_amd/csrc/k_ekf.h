@@ -289,135 +289,6 @@ __device__ __forceinline__ void ekf_dx_item(const EkfParams &p, int i) {
 }
 __global__ void k_ekf_dx(EkfParams p) { ekf_dx_item(p, blockIdx.x * blockDim.x + threadIdx.x); }
 
-// One step of iterative refinement of dx against the Gram matrix of the stack (k_gram.h).  A Cholesky factor of the
-// rank-deficient G = H^T H reproduces G to rounding error, but the component of g = H^T r along the numerically dependent
-// columns is lost with the dropped pivots (measured: |ddx| / |dx| = 1e-7 on a 3-feature update).  The update satisfies
-//     (I + P G / sigma^2) dx = P g / sigma^2          (P the PRIOR covariance, G and g scattered to state coordinates)
-// and (I + P G / sigma^2)^-1 = I - K H = I - Y^T U^-T R is at hand from the factorisation, so
-//     rho = P g' / sigma^2 - dx,   g' = g - G dx      and      dx += rho - Y^T U^-T R rho
-// costs a few matrix-vector products and brings dx to the accuracy of G itself.  Runs BEFORE k_ekf_pupdate (needs the prior).
-// One workgroup of 16 wavefronts; G [LG x LG] symmetric, column D = g.
-__device__ __forceinline__ double wave_sum_f64(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
-
-// (loads are issued unconditionally on clamped indices and masked when their values are USED: a load behind a branch, or a
-// select right behind a load, makes the compiler wait for every outstanding load first, and the kernel is all load latency)
-__global__ void __launch_bounds__(1024) k_ekf_dx_refine(EkfParams p, const double *__restrict__ G, int LG, double *rho) {
-  if (p.pred && *p.pred == 0) return;
-  __shared__ double vD[256], w[256], ss[256], part[4][256];
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, D = p.D, N = p.N, LA = p.LA;
-  if (tid < D) vD[tid] = p.dx[p.col_cov[tid]];
-  __syncthreads();
-  // the matrix-vector products: one wavefront per row, eight rows in flight
-  for (int c0 = wv; c0 < D; c0 += 128) { // g' = g - G dx_D
-    double a[8];
-    const double *row[8];
-#pragma unroll
-    for (int u = 0; u < 8; u++) a[u] = 0.0, row[u] = G + (size_t)min(c0 + 16 * u, D - 1) * LG;
-    for (int j = lane; j < D; j += 64) {
-      const double x = vD[j];
-#pragma unroll
-      for (int u = 0; u < 8; u++) a[u] = fma(row[u][j], x, a[u]);
-    }
-#pragma unroll
-    for (int u = 0; u < 8; u++) {
-      const double r = wave_sum_f64(a[u]);
-      if (lane == 0 && c0 + 16 * u < D) w[c0 + 16 * u] = row[u][D] - r;
-    }
-  }
-  __syncthreads();
-  for (int i0 = wv; i0 < N; i0 += 128) { // rho = P(:, cols) g' / sigma^2 - dx
-    double a[8];
-    const double *row[8];
-#pragma unroll
-    for (int u = 0; u < 8; u++) a[u] = 0.0, row[u] = p.P + (size_t)min(i0 + 16 * u, N - 1) * N;
-    for (int c = lane; c < D; c += 64) {
-      const double x = w[c];
-      const int cc = p.col_cov[c];
-#pragma unroll
-      for (int u = 0; u < 8; u++) a[u] = fma(row[u][cc], x, a[u]);
-    }
-#pragma unroll
-    for (int u = 0; u < 8; u++) {
-      const double r = wave_sum_f64(a[u]);
-      const int i = i0 + 16 * u;
-      if (lane == 0 && i < N) rho[i] = r / p.sigma2 - p.dx[i];
-    }
-  }
-  __syncthreads();
-  if (tid < D) vD[tid] = rho[p.col_cov[tid]];
-  __syncthreads();
-  for (int k0 = wv; k0 < D; k0 += 128) { // t = R rho_D (w is free again; R has explicit zeros left of its diagonal)
-    double a[8];
-    const double *row[8];
-#pragma unroll
-    for (int u = 0; u < 8; u++) a[u] = 0.0, row[u] = p.R + (size_t)min(k0 + 16 * u, D - 1) * p.LD;
-    for (int c = lane; c < D; c += 64) {
-      const double x = vD[c];
-#pragma unroll
-      for (int u = 0; u < 8; u++) a[u] = fma(row[u][c], x, a[u]);
-    }
-#pragma unroll
-    for (int u = 0; u < 8; u++) {
-      const double r = wave_sum_f64(a[u]);
-      if (lane == 0 && k0 + 16 * u < D) w[k0 + 16 * u] = r;
-    }
-  }
-  __syncthreads();
-  // s = U^-T t by forward substitution: thread k carries t_k; the 16 x 16 diagonal block is solved inside its wavefront
-  // with lane shuffles, the rows below take the 16 new entries of s from LDS after one barrier per block
-  const int k = tid, kc = min(k, D - 1);
-  double t = k < D ? w[k] : 0.0;
-  const double rd = 1.0 / p.Y[(size_t)kc * LA + kc];
-  double u[16];
-#pragma unroll
-  for (int a = 0; a < 16; a++) u[a] = p.Y[(size_t)min(a, D - 1) * LA + kc];
-  for (int ib = 0; ib < D; ib += 16) {
-    double un[16];
-#pragma unroll
-    for (int a = 0; a < 16; a++) un[a] = p.Y[(size_t)min(ib + 16 + a, D - 1) * LA + kc]; // next block, in flight during the solve
-    const bool solver = wv == (ib >> 6);
-    if (solver) {
-#pragma unroll
-      for (int a = 0; a < 16; a++) {
-        const int i = ib + a;
-        const double s = __shfl(t * rd, i & 63, 64);
-        if (k == i) ss[i] = s;
-        if (k > i && k < D && i < D) t = fma(-u[a], s, t);
-      }
-    }
-    __syncthreads();
-    if (!solver) {
-#pragma unroll
-      for (int a = 0; a < 16; a++)
-        if (ib + a < D && k > ib + a && k < D) t = fma(-u[a], ss[ib + a], t);
-    }
-#pragma unroll
-    for (int a = 0; a < 16; a++) u[a] = un[a];
-  }
-  __syncthreads();
-  const int q = tid >> 8, il = tid & 255; // dx += rho - Y^T s, the sum over k in four parts
-  for (int i0 = 0; i0 < N; i0 += 256) {
-    const int i = i0 + il;
-    const double *Y = p.Y + D + min(i, N - 1);
-    double b0 = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0;
-    int kk = q;
-    for (; kk + 12 < D; kk += 16) {
-      b0 = fma(Y[(size_t)kk * LA], ss[kk], b0);
-      b1 = fma(Y[(size_t)(kk + 4) * LA], ss[kk + 4], b1);
-      b2 = fma(Y[(size_t)(kk + 8) * LA], ss[kk + 8], b2);
-      b3 = fma(Y[(size_t)(kk + 12) * LA], ss[kk + 12], b3);
-    }
-    for (; kk < D; kk += 4) b0 = fma(Y[(size_t)kk * LA], ss[kk], b0);
-    part[q][il] = (b0 + b1) + (b2 + b3);
-    __syncthreads();
-    if (q == 0 && i < N) p.dx[i] += rho[i] - ((part[0][il] + part[1][il]) + (part[2][il] + part[3][il]));
-    __syncthreads();
-  }
-}
 
 // ---------------------------------------------------------------------------------------------------
 // EKF update from the Gram matrix of the stack (k_gram.h), in coordinates whitened by the PRIOR.

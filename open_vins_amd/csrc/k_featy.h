@@ -89,7 +89,7 @@ __global__ void __launch_bounds__(256) k_feat_rows_sorted(SysParams p, FeatStore
   if (gm >= M) return;
   const int f = st.meas_feat[gm];
   if (p.status[f] != OVGPU_FEAT_USED) return;
-  const int pos = st.pos[gm]; // its rank inside the feature by (clone column, camera, index), from the batch's layout (k_feat_sort_pos)
+  const int pos = st.pos[gm]; // its rank inside the feature by (clone column, camera, index), from the batch's layout (k_batch_layout)
   const V3 p_FinG = load_v3(p.p_FinG + 3 * f); // fej == value for MSCKF features (UpdaterMSCKF.cpp:186-194)
   double hq[21];
   double *dl = hq + 12;
@@ -107,7 +107,7 @@ constexpr int FY_ISTR = 32;           // ints per tile row in the instance table
 constexpr int FY_IOFF = 8;
 // Round 4: the wavefront also finishes what needs nothing but the reflectors — the RESIDUAL column of the feature's stacked rows
 // (rows 3.. of Q^T r; never whitened) and the residual bound of the gate, |Q2^T r|^2 / s^2 (tq[8 f + 6]).  (The instance lists of the
-// feature's tile rows, built behind that until round 5, depend on the batch alone: k_feat_inst below, once per batch.)
+// feature's tile rows, built behind that until round 5, depend on the batch alone: k_batch_layout below, once per batch.)
 template <bool F32OUT>
 __device__ __forceinline__ void vt_residual_column(const SysParams &p, int64_t orow0, const double *V, const double *res, int n, int lane, double z0, double z1,
                                                     double z2, double &sumsq) {
@@ -175,79 +175,171 @@ __global__ void __launch_bounds__(256) k_feat_vt(SysParams p, FeatStore st, doub
   }
 }
 
-// k_feat_inst: one wavefront per feature -> the distinct column blocks ("instances": first column, width) of every tile row of 16 rows,
-// ascending — what the sweep of k_feat_y loops over.  il[0] = count, il[1] = last non-zero column of the tile row, il[2 .. 5] = per column block
-// of `cb` columns the first instance that reaches the block and the first that reaches past its first half (three blocks of 10 bits per int),
-// il[FY_IOFF ..] = (type << 24) | (width << 16) | first column (type 0 clone block, 1 camera extrinsics, 2 camera intrinsics: k_featw.h selects
-// the lane's operand by it).  A function of the batch and of the column map alone: run once per batch (round 5; the tail of k_feat_vt on every
-// update before, ~8 us on the critical chain of the update's head).  The column triples of the measurements are staged clone-major (pos,
-// k_feat_sort_pos) in LDS by all lanes, one lane per tile row builds its list there.
-__global__ void __launch_bounds__(256) k_feat_inst(int F, int m_max, int D, const int32_t *__restrict__ meas_offsets, const uint16_t *__restrict__ meas_cc,
-                                                   const int32_t *__restrict__ pos, const int32_t *__restrict__ clone_col, const int32_t *__restrict__ calib_col,
-                                                   const int32_t *__restrict__ intr_col, int32_t *__restrict__ inst, int nt_max, int cb) {
+// k_batch_layout: every integer table of a feature batch that depends on the batch and on the column map alone, ONE launch, one workgroup
+// of two wavefronts per feature (round 6; round 5: four launches, k_feat_anchor / k_fill_meas_feat / k_feat_sort_pos / k_feat_inst, the last
+// with one LANE per tile row walking a serial chain of ~500 dependent LDS round trips):
+//   anchor_pre[f]  FeatureInitializer.cpp:36-46's anchor measurement: first camera group with strictly most measurements, its last
+//                  measurement (measurements are grouped by camera).  One wavefront: runs of equal camera ids by ballots over 64 measurements at
+//                  a time — a run's end lane finds its start as the highest start bit at or below it (or the run carried in from the chunk
+//                  before) —, the longest run, the earliest of equals, wins a wavefront arg-max.  Every path (k_triangulate reads it);
+//   meas_feat[i]   the feature of measurement i (k_feat_rows_sorted is a thread per measurement);
+//   pos[i]         where measurement i's Jacobian record goes inside its feature: clone-major order (clone column, then camera, then index),
+//                  what k_feat_y's sweep relies on.  The packed keys of the feature sit in LDS, every thread ranks its own;
+//   inst           the distinct column blocks ("instances": first column, width) of every tile row of 16 rows = 8 measurements, ascending — what
+//                  the sweep of k_feat_y loops over.  il[0] = count, il[1] = last non-zero column of the tile row, il[2 .. 5] = per column block
+//                  of `cb` columns the first instance that reaches the block and the first that reaches past its first half (three blocks of 10
+//                  bits per int), il[FY_IOFF ..] = (type << 24) | (width << 16) | first column (type 0 clone block, 1 camera extrinsics, 2
+//                  camera intrinsics).  One THREAD per candidate (tile row, measurement, kind): 24 per tile row, five tile rows per pass.  A
+//                  candidate is kept when no earlier one of its tile row names the same block (blocks are disjoint column ranges: the first
+//                  column identifies one), its place in the list is the number of kept first columns below its own, and the block starts are
+//                  counts as well (ends ascend with the first columns).
+// anchor_pre / pos / inst may each be null (the general per-feature kernel needs the anchors only: no LDS then).  LDS: batch_layout_lds_ints.
+__host__ __device__ inline int batch_layout_m_pad(int m_max) { return (m_max + 15) & ~15; } // (the kernel's m_max argument: keys padded to whole 16-int reads)
+__host__ __device__ inline size_t batch_layout_lds_ints(int m_pad) { return (size_t)4 * m_pad + (size_t)((2 * m_pad + 15) >> 4) * 48; }
+constexpr int BL_NTH = 128, BL_TR = BL_NTH / 24; // threads per feature; tile rows per pass of the candidate phase
+__global__ void __launch_bounds__(BL_NTH) k_batch_layout(int F, int m_max, int D, const int32_t *__restrict__ meas_offsets, const uint16_t *__restrict__ meas_cc,
+                                                      const int32_t *__restrict__ clone_col, const int32_t *__restrict__ calib_col, const int32_t *__restrict__ intr_col,
+                                                      int32_t *__restrict__ anchor_pre, int32_t *__restrict__ meas_feat, int32_t *__restrict__ pos, int32_t *__restrict__ inst,
+                                                      int nt_max, int cb, int C, int K) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int f = blockIdx.x * 4 + wv;
-  if (f >= F) return;
-  int *cols3 = reinterpret_cast<int *>(smem) + (size_t)wv * (3 * m_max + ((2 * m_max + 15) >> 4) * FY_ISTR); // [m][3]
-  int *lists = cols3 + 3 * m_max;                                                                            // [NT][FY_ISTR]
-  const int m0 = meas_offsets[f], m = meas_offsets[f + 1] - m0, n = 2 * m;
-  const int NT = (n + 15) >> 4;
-  for (int i = lane; i < m; i += 64) {
-    const int code = meas_cc[m0 + i], j = pos[m0 + i] - m0;
-    cols3[3 * j] = clone_col[code & 1023], cols3[3 * j + 1] = calib_col[code >> 10], cols3[3 * j + 2] = intr_col[code >> 10];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int f = blockIdx.x;
+  // the column tables (a few dozen ints) go to LDS while the feature's offsets are on their way: the keys below then cost ONE global round trip
+  // (the packed codes), not two — this kernel is a chain of memory latencies, nothing else
+  __shared__ int tab_clone[1024], tab_calib[64], tab_intr[64];
+  if (pos) {
+    for (int i = tid; i < C; i += BL_NTH) tab_clone[i] = clone_col[i];
+    if (tid < K) tab_calib[tid] = calib_col[tid], tab_intr[tid] = intr_col[tid];
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  if (lane < NT) {
-    int *gl = inst + ((size_t)f * nt_max + lane) * FY_ISTR;
-    int *il = lists + lane * FY_ISTR;
-    int cnt = 0, lim = -1, prev = -1;
-    int seen_p[8], seen_i[8], np_ = 0, ni_ = 0; // the calibration blocks met so far in this tile row (at most one pair per measurement)
-    const int i1 = min(8 * lane + 8, m);
-    for (int i = 8 * lane; i < i1; i++) {
-      const int c0 = cols3[3 * i], c1 = cols3[3 * i + 1], c2 = cols3[3 * i + 2];
-      if (c0 != prev) il[FY_IOFF + cnt++] = c0 | (6 << 16), prev = c0, lim = max(lim, c0 + 5); // records are clone-major: equal clone columns are neighbours
-      bool sp = c1 < 0, si = c2 < 0;
-#pragma unroll
-      for (int e = 0; e < 8; e++) sp = sp || (e < np_ && seen_p[e] == c1), si = si || (e < ni_ && seen_i[e] == c2);
-      if (!sp) {
-#pragma unroll
-        for (int e = 0; e < 8; e++)
-          if (e == np_) seen_p[e] = c1;
-        np_++, il[FY_IOFF + cnt++] = c1 | (6 << 16) | (1 << 24), lim = max(lim, c1 + 5);
+  const int m0 = meas_offsets[f], m = meas_offsets[f + 1] - m0;
+  if (anchor_pre && wv == (blockDim.x >> 6) - 1) { // the LAST wavefront: the keys of a track of up to 64 observations are the first one's work
+    long long best = -1; // (run length << 32) | (2^31 - 1 - run start): the longest run, the earliest of equals
+    int best_end = -1, carry_start = 0;
+    for (int base = 0; base < m; base += 64) {
+      const int i = base + lane;
+      const bool valid = i < m;
+      const int cam = valid ? (int)(meas_cc[m0 + i] >> 10) : -1;
+      const int prev = (valid && i > 0) ? (int)(meas_cc[m0 + i - 1] >> 10) : -2;
+      const int next = (valid && i + 1 < m) ? (int)(meas_cc[m0 + i + 1] >> 10) : -3;
+      const unsigned long long starts = __ballot(valid && cam != prev);
+      if (valid && cam != next) { // the last measurement of a run
+        const unsigned long long below = starts & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
+        const int start = below ? base + 63 - __clzll((long long)below) : carry_start;
+        const long long key = ((long long)(i - start + 1) << 32) | (long long)(0x7fffffff - start);
+        if (key > best) best = key, best_end = i;
       }
-      if (!si) {
+      if (starts) carry_start = base + 63 - __clzll((long long)starts);
+    }
 #pragma unroll
-        for (int e = 0; e < 8; e++)
-          if (e == ni_) seen_i[e] = c2;
-        ni_++, il[FY_IOFF + cnt++] = c2 | (8 << 16) | (2 << 24), lim = max(lim, c2 + 7);
+    for (int off = 32; off >= 1; off >>= 1) {
+      const long long ob = __shfl_xor(best, off);
+      const int oe = __shfl_xor(best_end, off);
+      if (ob > best) best = ob, best_end = oe;
+    }
+    if (lane == 0) anchor_pre[f] = best_end >= 0 ? m0 + best_end : -1;
+  }
+  if (!pos) return;
+  // (every loop over LDS below has its reads issued as 16-byte vectors ahead of their use: a serial chain of dependent 4-byte LDS round trips —
+  //  ~130 cycles apiece — was this kernel's whole time in its first form, 21 us)
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
+  int *keys = reinterpret_cast<int *>(smem); // [m], padded with INT_MAX to a multiple of 16
+  int *cols3 = keys + m_max;                 // [m][3]
+  int *cand = cols3 + 3 * m_max;             // [NT][24] first columns of the candidates, -1 = none
+  const int NT = (2 * m + 15) >> 4;
+  int *kept = cand + 24 * ((2 * m_max + 15) >> 4); // [NT][24] list codes of the kept candidates, -1 = dropped
+  __syncthreads(); // the column tables are in LDS
+  for (int i = tid; i < ((m + 15) & ~15); i += BL_NTH) {
+    int key = 0x7fffffff;
+    if (i < m) {
+      const int code = meas_cc[m0 + i], cam = code >> 10;
+      key = (tab_clone[code & 1023] << 8) | cam;
+      meas_feat[m0 + i] = f;
+      if (inst) cand[i] = tab_calib[cam], kept[i] = tab_intr[cam]; // (parked in the candidate tables, free until the barrier below)
+    }
+    keys[i] = key;
+  }
+  __syncthreads();
+  for (int i = tid; i < m; i += BL_NTH) {
+    const int mykey = keys[i];
+    int rank = 0;
+    const i32x4 *k4 = reinterpret_cast<const i32x4 *>(keys);
+    for (int j = 0; j < m; j += 16) {
+      const i32x4 a = k4[(j >> 2)], b = k4[(j >> 2) + 1], c = k4[(j >> 2) + 2], d = k4[(j >> 2) + 3];
+#define OVG_RK(v, o) rank += (v.x < mykey) || (v.x == mykey && j + o < i), rank += (v.y < mykey) || (v.y == mykey && j + o + 1 < i), \
+                     rank += (v.z < mykey) || (v.z == mykey && j + o + 2 < i), rank += (v.w < mykey) || (v.w == mykey && j + o + 3 < i)
+      OVG_RK(a, 0), OVG_RK(b, 4), OVG_RK(c, 8), OVG_RK(d, 12);
+#undef OVG_RK
+    }
+    pos[m0 + i] = m0 + rank;
+    if (inst) {
+      const int c1 = cand[i], c2 = kept[i];
+      cols3[3 * rank] = mykey >> 8, cols3[3 * rank + 1] = c1, cols3[3 * rank + 2] = c2;
+    }
+  }
+  if (!inst) return;
+  __syncthreads();
+  const int nblk = (D + cb - 1) / cb;
+  for (int t0 = 0; t0 < NT; t0 += BL_TR) { // (uniform trip count: the barriers below are met by every thread)
+    const int g = tid / 24, jk = tid - 24 * g, tr = t0 + g;       // candidate jk = 3 * (measurement of the tile row) + kind
+    const bool live = g < BL_TR && tr < NT;
+    const int i = 8 * tr + jk / 3, kind = jk - 3 * (jk / 3);
+    int v = -1;
+    if (live && i < m) v = cols3[3 * i + kind];
+    if (live) cand[24 * tr + jk] = v;
+    __syncthreads();
+    bool keep = v >= 0;
+    if (live) {
+      const i32x4 *c4 = reinterpret_cast<const i32x4 *>(cand + 24 * tr);
+      int u[24];
+#pragma unroll
+      for (int q = 0; q < 6; q++) {
+        const i32x4 w = c4[q];
+        u[4 * q] = w.x, u[4 * q + 1] = w.y, u[4 * q + 2] = w.z, u[4 * q + 3] = w.w;
+      }
+#pragma unroll
+      for (int e = 0; e < 24; e++) keep = keep && (e >= jk || u[e] != v);
+    }
+    const int width = kind == 2 ? 8 : 6, code = v | (width << 16) | (kind << 24);
+    if (live) kept[24 * tr + jk] = keep ? code : -1;
+    __syncthreads();
+    if (live) {
+      const i32x4 *k4 = reinterpret_cast<const i32x4 *>(kept + 24 * tr);
+      int u[24];
+#pragma unroll
+      for (int q = 0; q < 6; q++) {
+        const i32x4 w = k4[q];
+        u[4 * q] = w.x, u[4 * q + 1] = w.y, u[4 * q + 2] = w.z, u[4 * q + 3] = w.w;
+      }
+      int *gl = inst + ((size_t)f * nt_max + tr) * FY_ISTR;
+      int below = 0, cnt = 0, lim = -1;
+#pragma unroll
+      for (int e = 0; e < 24; e++) {
+        const bool on = u[e] >= 0;
+        cnt += on;
+        below += on && (u[e] & 0xffff) < v;
+        lim = on ? max(lim, (u[e] & 0xffff) + ((u[e] >> 16) & 0xff) - 1) : lim;
+      }
+      if (keep) gl[FY_IOFF + below] = code; // ascending first column: a column block's dead instances (left of it) are a prefix of the list
+      if (jk == 0) gl[0] = cnt, gl[1] = lim;
+      if (jk >= 1 && jk <= 4) { // per column block of cb columns: e0 = the first instance that reaches the block, e1 = the first that reaches past its first half
+        int packed = 0;
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+          const int kb = 3 * (jk - 1) + q;
+          if (kb < nblk) {
+            const int c_lo = cb * kb;
+            int e0 = 0, e1 = 0;
+#pragma unroll
+            for (int e = 0; e < 24; e++) {
+              const int end = (u[e] & 0xffff) + ((u[e] >> 16) & 0xff) - 1;
+              e0 += u[e] >= 0 && end < c_lo, e1 += u[e] >= 0 && end < c_lo + cb / 2;
+            }
+            packed |= (e0 | (e1 << 5)) << (10 * q);
+          }
+        }
+        gl[1 + jk] = packed;
       }
     }
-    for (int a = 1; a < cnt; a++) { // ascending first column: a column block's dead instances (left of it) are a prefix of the list
-      const int v = il[FY_IOFF + a];
-      int b = a - 1;
-      while (b >= 0 && (il[FY_IOFF + b] & 0xffff) > (v & 0xffff)) il[FY_IOFF + b + 1] = il[FY_IOFF + b], b--;
-      il[FY_IOFF + b + 1] = v;
-    }
-    il[0] = cnt, il[1] = lim;
-    // per column block of cb columns: e0 = the first instance that reaches the block, e1 = the first that reaches past its first half
-    const int nblk = (D + cb - 1) / cb;
-    int packed[4] = {0, 0, 0, 0};
-    for (int kb = 0; kb < nblk && kb < 12; kb++) {
-      const int c_lo = cb * kb;
-      int e0 = 0;
-      while (e0 < cnt && (il[FY_IOFF + e0] & 0xffff) + ((il[FY_IOFF + e0] >> 16) & 0xff) - 1 < c_lo) e0++;
-      int e1 = e0;
-      while (e1 < cnt && (il[FY_IOFF + e1] & 0xffff) + ((il[FY_IOFF + e1] >> 16) & 0xff) - 1 < c_lo + cb / 2) e1++;
-#pragma unroll
-      for (int w = 0; w < 4; w++)
-        if (w == kb / 3) packed[w] |= (e0 | (e1 << 5)) << (10 * (kb % 3));
-    }
-    gl[2] = packed[0], gl[3] = packed[1], gl[4] = packed[2], gl[5] = packed[3];
-    gl[0] = cnt, gl[1] = lim;
-    for (int e = 0; e < cnt; e++) gl[FY_IOFF + e] = il[FY_IOFF + e];
   }
 }
 #endif // OVG_TU_FEATY
@@ -675,10 +767,12 @@ __global__ void __launch_bounds__(64 * NW, OCC)
 // ovgpu_featy_tu.hip instantiates them, ovgpu_api.hip declares them extern.
 //   <4, 9, 2, *, 64>   tracks of up to 62 observations (36 tiles), two workgroups per CU — the headline shape
 //   <8, 17, 1, *, 64>  up to 126 observations (136 tiles), one workgroup per CU
-//   <4, 9, 3, *, 32>, <8, 5, 4, *, 32>  round 5's occupancy experiments: 32-column blocks (half the LDS), 168 / 128 registers
-// (OCC is __launch_bounds__' second argument: wavefronts per SIMD)
+// (OCC is __launch_bounds__' second argument: wavefronts per SIMD.  Round 5's occupancy experiments <4, 9, 3, *, 32>, <8, 5, 4, *, 32> and the
+// wavefront-per-feature kernel were measured slower — profiles/r05_b_feature_kernel_shapes_ab.txt — and left the tree in round 6, as did
+// round 6's own <8, 17, 1, *, 32>: 32-column blocks remove the 8-wavefront shape's spills and cost more in barriers than the spills did,
+// 7.26 against 6.61 ms of stage time at configs[3] on one GPU, profiles/r06_a_featy_8wave_32_column_blocks_ab.txt.)
 #define OVG_FEATY_SHAPES(X)                                                                                                     \
-  X(4, 9, 2, false, 64) X(4, 9, 2, true, 64) X(8, 17, 1, false, 64) X(8, 17, 1, true, 64) X(4, 9, 3, false, 32) X(8, 5, 4, false, 32)
+  X(4, 9, 2, false, 64) X(4, 9, 2, true, 64) X(8, 17, 1, false, 64) X(8, 17, 1, true, 64)
 #define OVG_FEATY_ARGS                                                                                                                           \
   SysParams, int, int, const double *__restrict__, const int32_t *__restrict__, const double *__restrict__, const double *__restrict__, \
       const int32_t *__restrict__, const int32_t *__restrict__

@@ -26,14 +26,10 @@
 // The default route feeds G straight into the EKF update written in coordinates whitened by the prior (k_ekf.h,
 // "EKF update from the Gram matrix"): no factor of G is ever formed.  Across GPUs Gram matrices simply add (one all-reduce).
 //
-//   k_gram_chol    (compress_route = OVGPU_COMPRESS_CHOLQR only) right-looking Cholesky of the (LD x LD) sum inside ONE workgroup, the
-//                  matrix held in registers (block-cyclic over 32 x 32 threads), one barrier per row; non-positive pivots —
-//                  the stack of an MSCKF update is rank deficient along the unobservable directions — leave a zero row.
-//                  This is the measured NEGATIVE result of DESIGN.md section 4: forming and factoring G squares the
-//                  condition number, the factor carries errors of order eps |G| in the directions the measurements do not
-//                  constrain, and a filter's covariance is large exactly there.  Snapshot parity holds on tall stacks
-//                  (|dP| / |P| = 2e-11 on the 77178 x 209 cfg-2 stack, tools/dev_gram_accuracy.py), the 52-frame closed loop
-//                  drifts 6e-6 (tools/dev_closed_loop_dev.py; Householder TSQR and the prior-whitened update: 1e-13).
+//   (k_gram_chol, the UNPIVOTED Cholesky factor of the Gram matrix as a compressed system — compress_route = OVGPU_COMPRESS_CHOLQR of rounds
+//   1-5, the measured negative result: forming and factoring G squares the condition number, a 52-frame closed loop drifted 6e-6 where the
+//   Householder TSQR and the prior-whitened update stay at 1e-13 — left the tree in round 6; tests/test_mode_a_numerics.py keeps the numpy
+//   demonstration, docs/history/ the numbers.  Mode A's factor is the diagonally PIVOTED one, k_gram_pchol below.)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -728,8 +724,7 @@ __global__ void __launch_bounds__(1024) k_gram_reduce(int NT, int nparts, const 
 // below k.  The publish buffers alternate, so step k + 1 never overwrites what a slow wavefront still reads.  Finished rows
 // collect in LDS and leave in bursts of 16 rows written by all 16 wavefronts: a global store costs the issuing wavefront
 // ~600 cycles, which on the owner's critical path was most of the step (measured: 2.0 us per row, 0.4 ms per factorisation).
-constexpr int CH_NB = 8; // blocks per dimension of k_gram_chol: LD <= 256; the kernels are instantiated per block count (a run-time count puts every
-                         // multiply-add behind its own scalar branch)
+constexpr int CH_NB = 8;
 constexpr int CH_FLUSH = 16;
 constexpr int PCH_NB = 12; // k_gram_pchol: LD <= 384 (beyond 9 blocks the register blocks of a thread no longer fit 128 registers and spill: slower per step, correct)
 __device__ __forceinline__ double rsqrt_f64(double d) {
@@ -741,88 +736,6 @@ __device__ __forceinline__ double rsqrt_f64(double d) {
 }
 inline size_t chol_lds_bytes(int LD) { return (size_t)2 * CH_FLUSH * LD * sizeof(double); }
 
-template <int NB>
-__global__ void __launch_bounds__(1024) k_gram_chol(int D, int LD, int LG, const double *G, double *out, int32_t *n_dropped) {
-  extern __shared__ double rstore[]; // [2][CH_FLUSH][LD] finished rows on their way to memory
-  __shared__ __attribute__((aligned(16))) double rowbuf[2][32 * CH_NB];
-  __shared__ double diag0[256];
-  __shared__ int okflag[2];
-  __shared__ int drops;
-  const int tid = threadIdx.x, ti = tid >> 5, tj = tid & 31;
-  double a[NB][NB];
-#pragma unroll
-  for (int bi = 0; bi < NB; bi++)
-#pragma unroll
-    for (int bj = 0; bj < NB; bj++) {
-      a[bi][bj] = 0.0;
-      if (bj >= bi) {
-        const int i = ti + 32 * bi, j = tj + 32 * bj;
-        if (i < LD && j < LD) a[bi][bj] = G[(size_t)i * LG + j];
-      }
-    }
-  if (tid < 256) diag0[tid] = tid < LD ? G[(size_t)tid * LG + tid] : 0.0;
-  if (tid == 0) drops = 0;
-  __syncthreads();
-  for (int k = 0; k < D; k++) {
-    double *rb = rowbuf[k & 1];
-    const int bk = k >> 5;
-    if ((tid >> 6) == ((k & 31) >> 1)) { // the wavefront that holds row k (both halves run the shuffle)
-      double dv = 0.0;
-#pragma unroll
-      for (int b = 0; b < NB; b++)
-        if (b == bk) dv = a[b][b];
-      const double d = __shfl(dv, 32 * ((k & 31) & 1) + (k & 31), 64); // element (k, k): thread ti = tj = k & 31
-      const bool ok = d > 1e-15 * diag0[k] && d > 0.0;
-      const double inv = ok ? rsqrt_f64(d) : 0.0;
-      if (ti == (k & 31)) {
-        double *o = rstore + ((size_t)((k / CH_FLUSH) & 1) * CH_FLUSH + (k % CH_FLUSH)) * LD;
-#pragma unroll
-        for (int bi = 0; bi < NB; bi++)
-          if (bi == bk) {
-#pragma unroll
-            for (int bj = 0; bj < NB; bj++) {
-                const double r = bj >= bi ? a[bi][bj] * inv : 0.0;
-                rb[((bj >> 1) * 32 + tj) * 2 + (bj & 1)] = r;
-                const int j = tj + 32 * bj;
-                if (j < LD) o[j] = j >= k ? r : 0.0;
-              }
-          }
-        if (tj == 0) {
-          okflag[k & 1] = ok ? 1 : 0;
-          if (!ok) drops++;
-        }
-      }
-    }
-    __syncthreads();
-    if (okflag[k & 1]) {
-      constexpr int NP = (NB + 1) / 2;
-      double ri[2 * NP], rj[2 * NP];
-#pragma unroll
-      for (int m = 0; m < NP; m++) {
-        ri[2 * m] = ri[2 * m + 1] = rj[2 * m] = rj[2 * m + 1] = 0.0;
-        if (2 * m + 1 >= bk) { // blocks left of the pivot's block are dead
-          const double2 vi = *reinterpret_cast<const double2 *>(rb + (m * 32 + ti) * 2), vj = *reinterpret_cast<const double2 *>(rb + (m * 32 + tj) * 2);
-          ri[2 * m] = vi.x, ri[2 * m + 1] = vi.y, rj[2 * m] = vj.x, rj[2 * m + 1] = vj.y;
-        }
-      }
-#pragma unroll
-      for (int bi = 0; bi < NB; bi++) {
-        if (32 * bi + 31 > k) { // the block row still has rows below k
-#pragma unroll
-          for (int bj = bi; bj < NB; bj++) a[bi][bj] = fma(-ri[bi], rj[bj], a[bi][bj]);
-        }
-      }
-    }
-    if ((k % CH_FLUSH) == CH_FLUSH - 1 || k == D - 1) { // rows k0 .. k are complete (published before the barrier above)
-      const int k0 = (k / CH_FLUSH) * CH_FLUSH, n = (k - k0 + 1) * LD;
-      const double *src = rstore + (size_t)((k / CH_FLUSH) & 1) * CH_FLUSH * LD;
-      double *dst = out + (size_t)k0 * LD;
-      for (int e = tid; e < n; e += 1024) dst[e] = src[e];
-    }
-  }
-  __syncthreads();
-  if (tid == 0 && n_dropped) *n_dropped = drops;
-}
 
 
 // ---------------------------------------------------------------------------------------------------

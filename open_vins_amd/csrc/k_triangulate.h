@@ -90,27 +90,6 @@ __device__ __forceinline__ double gn_cost(const double *lds_cc, const uint16_t *
   return wave_sum(err);
 }
 
-// The anchor rule (FeatureInitializer.cpp:36-46): first camera group with strictly most measurements, last measurement of that group.
-// Measurements are grouped by camera.  One thread per feature, once per batch.
-__global__ void __launch_bounds__(256) k_feat_anchor(int F, const int32_t *__restrict__ meas_offsets, const uint16_t *__restrict__ meas_cc,
-                                                     int32_t *__restrict__ anchor_pre) {
-  const int f = blockIdx.x * 256 + threadIdx.x;
-  if (f >= F) return;
-  const int m0 = meas_offsets[f], m1 = meas_offsets[f + 1];
-  int best_count = 0, best_last = -1, i = m0;
-  while (i < m1) {
-    const int cam = meas_cc[i] >> 10;
-    int j = i + 1;
-    while (j < m1 && (meas_cc[j] >> 10) == cam) j++;
-    if (j - i > best_count) {
-      best_count = j - i;
-      best_last = j - 1;
-    }
-    i = j;
-  }
-  anchor_pre[f] = best_last;
-}
-
 // grid: ceil(F / w) blocks of w wavefronts = w features per workgroup (enqueue_triangulate)
 __global__ void __launch_bounds__(1024) k_triangulate(TriParams p) {
   extern __shared__ __attribute__((aligned(16))) double lds_cc[]; // [K*C*12]
@@ -139,7 +118,7 @@ __global__ void __launch_bounds__(1024) k_triangulate(TriParams p) {
     return;
   }
 
-  // ---- anchor rule (FeatureInitializer.cpp:36-46): a property of the batch, found when it was laid out (k_feat_anchor below; until round 5
+  // ---- anchor rule (FeatureInitializer.cpp:36-46): a property of the batch, found when it was laid out (feat::k_batch_layout, k_featy.h; until round 5
   //      every wavefront scanned its feature's packed codes here, ~50 dependent loads in front of its first floating-point instruction)
   const bool seeded = p.seed_pA != nullptr; // single_gaussnewton on a caller's estimate: its anchor and position stand
   const int anchor = __builtin_amdgcn_readfirstlane(seeded ? p.seed_anchor[f] : p.anchor_pre[f]);

@@ -25,7 +25,6 @@
 #include "k_tracks.h"
 #include "k_featy.h"
 #include "k_featy_big.h"
-#include "k_featw.h"
 #include "k_gram.h"
 #include "k_gram32.h"
 #include <unordered_map>
@@ -45,9 +44,6 @@ namespace ovg {
 namespace feat {
 #define X(NW, TPW, OCC, F32, CB) extern template __global__ void k_feat_y<NW, TPW, OCC, F32, CB>(OVG_FEATY_ARGS);
 OVG_FEATY_SHAPES(X)
-#undef X
-#define X(NTM, F32) extern template __global__ void k_feat_w<NTM, F32>(OVG_FEATW_ARGS);
-OVG_FEATW_SHAPES(X)
 #undef X
 extern template __global__ void k_feat_y_big<8, 17, false>(SysParams, int, const double *__restrict__, const int32_t *__restrict__, const double *__restrict__,
     const double *__restrict__, const int32_t *__restrict__, const int32_t *__restrict__, double *);

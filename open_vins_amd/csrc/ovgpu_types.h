@@ -32,7 +32,7 @@ struct TriParams {
   DevOptions opt;
   const double *seed_pA;       // ovgpu_refine: start the refinement from these positions (anchor frame) ...
   const int32_t *seed_anchor;  // ... in these anchors, instead of triangulating (FeatureInitializer::single_gaussnewton alone)
-  const int32_t *anchor_pre;   // [F] the anchor measurement of every feature by FeatureInitializer.cpp:36-46's rule, found when the batch was laid out (k_feat_anchor)
+  const int32_t *anchor_pre;   // [F] the anchor measurement of every feature by FeatureInitializer.cpp:36-46's rule, found when the batch was laid out (feat::k_batch_layout)
 };
 
 // column kinds of the canonical stacked-Jacobian column order

@@ -60,7 +60,7 @@ def test_struct_layouts_match_header(tmp_path):
 def test_enum_values_match_header(tmp_path):
     """The route / status / representation codes of the ctypes mirror are the header's enumerators as gcc evaluates them."""
     import subprocess
-    names = {"OVGPU_COMPRESS_GRAM": capi.COMPRESS_GRAM, "OVGPU_COMPRESS_TSQR": capi.COMPRESS_TSQR, "OVGPU_COMPRESS_CHOLQR": capi.COMPRESS_CHOLQR,
+    names = {"OVGPU_COMPRESS_GRAM": capi.COMPRESS_GRAM, "OVGPU_COMPRESS_TSQR": capi.COMPRESS_TSQR,
              "OVGPU_COMPRESS_PCHOLQR": capi.COMPRESS_PCHOLQR, "OVGPU_FEAT_USED": capi.FEAT_USED, "OVGPU_FEAT_CHI2_REJECTED": capi.FEAT_CHI2_REJECTED}
     lines = ['#include <stdio.h>', '#include "ovgpu.h"', 'int main(void) {'] + [f'  printf("{n} %d\\n", (int){n});' for n in names] + ['  return 0;', '}']
     src = tmp_path / "enums.c"

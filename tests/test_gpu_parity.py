@@ -215,22 +215,11 @@ def test_block_row_gate_equals_the_one_pass_gate(Updater, kw):
         assert _rel(out["P"], ref["P"]) < 1e-11
 
 
-@pytest.mark.parametrize("shape", [1, 2, 3])
-@pytest.mark.parametrize("kw", [dict(F=300), dict(F=200, track="ragged", outlier_frac=0.3), dict(F=150, C=11, K=1), dict(cfg=3, F=260)])
-def test_feature_kernel_shapes(Updater, oracle, kw, shape):
-    """The one-pass per-feature kernel in its other shapes (ovgpu_debug_option "featy_shape"; round 5's measured alternatives to the
-    default <4 wavefronts, 9 tiles, 64-column blocks>): 1 = <4, 9> and 2 = <8, 5> with 32-column blocks (three / four wavefronts
-    per SIMD), 3 = one feature per WAVEFRONT (k_featw.h: whitened rows and gate matrix in registers, no workgroup barrier)."""
-    kw = dict(kw)
-    prob = synth.make_problem(kw.pop("cfg", 2), **kw)
-    _check_given(Updater, oracle, prob, capi.default_options(chi2_multipler=1.0), debug=dict(featy_shape=shape))
-
-
 @pytest.mark.parametrize("kw", [dict(F=300), dict(F=200, track="ragged", outlier_frac=0.3), dict(cfg=3, F=260)])
 def test_batch_tables_rebuilt_on_every_update(Updater, kw):
     """ovgpu_debug_option "layout_every_update": the integer tables ovgpu_set_features derives once per batch (anchor measurements,
-    clone-major positions, column-block lists of the tile rows) rebuilt at the head of every update -- the loop bench.py reports as
-    ms_per_step_with_batch_layout.  The same kernels on the same batch: the update must not change."""
+    clone-major positions, column-block lists of the tile rows) rebuilt at the head of every update (one launch, k_batch_layout) -- bench.py's
+    headline loop since round 6.  The same kernel on the same batch: the update must not change."""
     kw = dict(kw)
     prob = synth.make_problem(kw.pop("cfg", 2), **kw)
     opts = capi.default_options(chi2_multipler=1.0)
@@ -338,16 +327,17 @@ def test_mode_a_default_under_the_library_switches(Updater, oracle, kw):
     assert st == 0 and _rel(P1, ref["P"]) < TOL_P and _rel(dx1, ref["dx"]) < TOL_DX
 
 
-@pytest.mark.parametrize("route", ["default", "tsqr", "cholqr"])
+@pytest.mark.parametrize("route", ["default", "tsqr"])
 def test_mode_a_compressed_system(Updater, oracle, route):
     """ovgpu_msckf_compress hands back (H, r) for the stock StateHelper::EKFUpdate: H^T H and H^T r equal the reference's compressed
     system's, and feeding it to the oracle's EKFUpdate reproduces the oracle's posterior.
     default: the diagonally PIVOTED Cholesky factor of the whitened stack's Gram matrix, un-whitened (k_gram_pchol) — dense, rows =
              its numerical rank, at the Gram route's cost; the closed loop holds it to the Householder level (test_closed_loop.py);
-    tsqr:    the triangle of the Householder TSQR, the reference's own form (R is unique up to row signs, SURVEY section 7);
-    cholqr:  (opt-in, round 3's negative result) the UNPIVOTED factor: good on a snapshot like this one, drifts in the closed loop."""
+    tsqr:    the triangle of the Householder TSQR, the reference's own form (R is unique up to row signs).
+    (The UNPIVOTED factor, rounds 3-5's OVGPU_COMPRESS_CHOLQR — good on a snapshot like this one, drifting in the closed loop — left the
+    library in round 6: ovgpu_create refuses the value, test_retired_compress_route_is_refused.)"""
     prob = synth.make_problem(2, F=100)
-    code = dict(default=capi.COMPRESS_GRAM, cholqr=capi.COMPRESS_CHOLQR, tsqr=capi.COMPRESS_TSQR)[route]
+    code = dict(default=capi.COMPRESS_GRAM, tsqr=capi.COMPRESS_TSQR)[route]
     opts = capi.default_options(chi2_multipler=1.0, compress_route=code)
     v = capi.Views(prob)
     tri = oracle.triangulate(opts, v)
@@ -366,10 +356,7 @@ def test_mode_a_compressed_system(Updater, oracle, route):
     print(f"mode A, {route}: |H^T H - G| / |G| = {eG:.1e}, |H^T r - g| / |g| = {eg:.1e}")
     if route == "tsqr":
         assert np.abs(np.tril(H, -1)).max() == 0.0
-    if route != "cholqr":
-        assert eG < 1e-11 and eg < 1e-10
-    else:
-        assert eG < 1e-9 and eg < 1e-9
+    assert eG < 1e-11 and eg < 1e-10
     st, P1, dx1 = oracle.ekf_update(prob.P, H, r, cmp["col_cov_id"], 1.0)
     assert st == 0
     assert _rel(P1, ref["P"]) < TOL_P and _rel(dx1, ref["dx"]) < TOL_DX
@@ -615,6 +602,13 @@ def _compress_with(Updater, prob, opts, tri, **fields):
     return cmp
 
 
+def test_retired_compress_route_is_refused(Updater):
+    """ABI 8: compress_route = 2 (the unpivoted Cholesky factor of the Gram matrix, rounds 3-5's documented negative result) no longer exists."""
+    with pytest.raises(capi.OvgpuError) as ei:
+        Updater(capi.default_options(compress_route=2))
+    assert ei.value.code == capi.ERR_INVALID
+
+
 def _update_with(Updater, prob, opts, tri, **fields):
     up = Updater(_opts_with(opts, **fields))
     up.set_problem(prob)
@@ -631,8 +625,7 @@ def test_gram_route_gives_the_householder_posterior(Updater, oracle, kw):
     whitened by the prior (k_ekf.h) unless options.compress_route = OVGPU_COMPRESS_TSQR selects the Householder TSQR + the reference-shaped update:
     same dx and P, far inside the parity tolerance against the oracle (which compresses with Givens rotations like the
     reference).  LD = 209 / 237 / 87 / 51 columns: 14, 15, 6 and 4 column tiles; F = 3 has hardly more rows than columns.
-    OVGPU_COMPRESS_CHOLQR (R = chol(Gram) + dx refinement, tall stacks only) is the documented negative result: it holds
-    the parity tolerance on these snapshots but not in the closed loop (tests/test_closed_loop.py runs the default)."""
+    (tests/test_closed_loop.py runs the default through 52 frames.)"""
     kw = dict(kw)
     prob = synth.make_problem(kw.pop("cfg", 2), **kw)
     opts = capi.default_options(chi2_multipler=1.0)
@@ -642,13 +635,11 @@ def test_gram_route_gives_the_householder_posterior(Updater, oracle, kw):
     a = _update_with(Updater, prob, opts, tri, compress_route=capi.COMPRESS_TSQR)
     b = _update_with(Updater, prob, opts, tri, compress_route=capi.COMPRESS_GRAM)
     b2 = _update_with(Updater, prob, opts, tri, compress_route=capi.COMPRESS_GRAM)
-    c = _update_with(Updater, prob, opts, tri, compress_route=capi.COMPRESS_CHOLQR)
-    for o in (a, b, c):
+    for o in (a, b):
         assert np.array_equal(o["feat_status"], ref["feat_status"]) and o["stats"]["status"] == 0 and np.array_equal(o["P"], o["P"].T)
     assert np.array_equal(b["dx"], b2["dx"]) and np.array_equal(b["P"], b2["P"])  # ordered sums: reproducible bit for bit
     assert _rel(b["dx"], a["dx"]) < 1e-9 and _rel(b["P"], a["P"]) < 1e-10
     assert _rel(b["dx"], ref["dx"]) < 1e-8 and _rel(b["P"], ref["P"]) < 1e-9
-    assert _rel(c["dx"], ref["dx"]) < 1e-7 and _rel(c["P"], ref["P"]) < 1e-8
 
 
 def test_semi_definite_prior_takes_the_householder_route(Updater, oracle):

@@ -10,7 +10,7 @@ cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 F = int(sys.argv[2]) if len(sys.argv) > 2 else None
 prob = synth.make_problem(cfg, F=F) if F else synth.make_problem(cfg)
 res = {}
-for name, code in (("tsqr (Householder)", capi.COMPRESS_TSQR), ("cholqr (unpivoted)", capi.COMPRESS_CHOLQR), ("pcholqr (pivoted)", capi.COMPRESS_PCHOLQR),
+for name, code in (("tsqr (Householder)", capi.COMPRESS_TSQR), ("pcholqr (pivoted)", capi.COMPRESS_PCHOLQR),
                    ("default", capi.COMPRESS_GRAM)):
     up = UpdaterMSCKF(capi.default_options(chi2_multipler=1.0, compress_route=code))
     up.set_problem(prob)

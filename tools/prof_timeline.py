@@ -4,7 +4,8 @@ latest end of the kernels that started before it."""
 import sqlite3, sys
 db = sqlite3.connect(sys.argv[1])
 rows = db.execute("select name, start, end from kernels order by start").fetchall()
-marks = [i for i, r in enumerate(rows) if "k_restore_state" in r[0]]
+marker = sys.argv[3] if len(sys.argv) > 3 else "k_restore_state"  # (a frame of tools/dev_frame.py: "k_build_tables", ovgpu_set_state's last launch)
+marks = [i for i, r in enumerate(rows) if marker in r[0]]
 which = int(sys.argv[2]) if len(sys.argv) > 2 else len(marks) // 2
 a, b = marks[which], marks[which + 1]
 t0 = rows[a][1]
