@@ -209,7 +209,7 @@ template <int W, int NTC> __device__ __forceinline__ void gram_il_loop(const Gra
   const int LD = p.LD;
   const int g = lane >> 4, cl = lane & 15;
   constexpr int JLO = WR::R0 < NTC ? WR::R0 : NTC;
-  constexpr int SL = NTC / 2; // staging slots per k-step
+  constexpr int SL = (NTC + 1) / 2; // staging slots per k-step (an odd NTC — 15 tile columns, round 6 — has 4 SL = NQ + 2 of them: the last two are empty)
   constexpr int NQ = 2 * NTC;
   constexpr int SCRATCH = GR_LS - 1;
   double v[NQ];
@@ -272,16 +272,20 @@ template <int W, int NTC> __device__ __forceinline__ void gram_il_loop(const Gra
         if (j - JLO < SL) {
           __builtin_amdgcn_sched_barrier(0);
           const int q = (ks & 3) * SL + (j - JLO);
-          if (ks < 4) put(nxt, q); // k-steps 0-3: stage s + 1 from the registers into the other buffer
-          else fetch1(q);          // k-steps 4-7: stage s + 2 into the registers just freed
+          if (q < NQ) {
+            if (ks < 4) put(nxt, q); // k-steps 0-3: stage s + 1 from the registers into the other buffer
+            else fetch1(q);          // k-steps 4-7: stage s + 2 into the registers just freed
+          }
           __builtin_amdgcn_sched_barrier(0);
         }
       }
 #pragma unroll
       for (int sl = NTC - JLO; sl < SL; sl++) { // wavefronts with fewer tile columns than slots
         const int q = (ks & 3) * SL + sl;
-        if (ks < 4) put(nxt, q);
-        else fetch1(q);
+        if (q < NQ) {
+          if (ks < 4) put(nxt, q);
+          else fetch1(q);
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
     }

@@ -57,8 +57,8 @@ using ovgpu_shim::StateAccess;
 namespace {
 // host-side function of the reference on a covariance that may live on the device: bring it, run, and the host side is the current one
 template <class Fn> auto on_host(const std::shared_ptr<State> &state, bool writes, Fn fn, bool overwrites = false) -> decltype(fn()) {
-  ResidentCov &rc = ResidentCov::instance();
-  rc.bind(state.get());
+  ResidentCov &rc = ResidentCov::of(state);
+  const ResidentCov::Guard guard = rc.lock(); // (recursive: on_host below takes it again)
   if (overwrites) rc.host_written(); // (the whole covariance is replaced: nothing to bring back first)
   if (rc.attached()) rc.ensure_host(*state);
   struct Mark { // (also when fn throws / returns a value)
@@ -74,8 +74,8 @@ template <class Fn> auto on_host(const std::shared_ptr<State> &state, bool write
 
 void StateHelper::EKFPropagation(std::shared_ptr<State> state, const std::vector<std::shared_ptr<Type>> &order_NEW, const std::vector<std::shared_ptr<Type>> &order_OLD,
                                  const Eigen::MatrixXd &Phi, const Eigen::MatrixXd &Q) {
-  ResidentCov &rc = ResidentCov::instance();
-  rc.bind(state.get());
+  ResidentCov &rc = ResidentCov::of(state);
+  const ResidentCov::Guard guard = rc.lock(); // (recursive: on_host below takes it again)
   if (!rc.on_device()) return on_host(state, true, [&] { StateHelperHost::EKFPropagation(state, order_NEW, order_OLD, Phi, Q); });
   // StateHelper.cpp:41-58: something to propagate, and the new variables contiguous in the covariance (the device call checks the block too)
   if (order_NEW.empty() || order_OLD.empty()) {
@@ -111,8 +111,8 @@ void StateHelper::set_initial_covariance(std::shared_ptr<State> state, const Eig
 }
 
 Eigen::MatrixXd StateHelper::get_marginal_covariance(std::shared_ptr<State> state, const std::vector<std::shared_ptr<Type>> &small_variables) {
-  ResidentCov &rc = ResidentCov::instance();
-  rc.bind(state.get());
+  ResidentCov &rc = ResidentCov::of(state);
+  const ResidentCov::Guard guard = rc.lock(); // (recursive: on_host below takes it again)
   if (!rc.on_device() || rc.host_valid()) return on_host(state, false, [&] { return StateHelperHost::get_marginal_covariance(state, small_variables); });
   const std::vector<int32_t> ids = ovgpu_shim::flat_ids(small_variables); // the block alone comes back: no N x N download for a chi2 test
   const int n = (int)ids.size();
@@ -126,8 +126,8 @@ Eigen::MatrixXd StateHelper::get_full_covariance(std::shared_ptr<State> state) {
 }
 
 void StateHelper::marginalize(std::shared_ptr<State> state, std::shared_ptr<Type> marg) {
-  ResidentCov &rc = ResidentCov::instance();
-  rc.bind(state.get());
+  ResidentCov &rc = ResidentCov::of(state);
+  const ResidentCov::Guard guard = rc.lock(); // (recursive: on_host below takes it again)
   if (!rc.on_device()) return on_host(state, true, [&] { StateHelperHost::marginalize(state, marg); });
   std::vector<std::shared_ptr<Type>> &vars = StateAccess::variables(*state);
   if (std::find(vars.begin(), vars.end(), marg) == vars.end()) { // StateHelper.cpp:274-278
@@ -166,8 +166,8 @@ void StateHelper::initialize_invertible(std::shared_ptr<State> state, std::share
 }
 
 void StateHelper::augment_clone(std::shared_ptr<State> state, Eigen::Matrix<double, 3, 1> last_w) {
-  ResidentCov &rc = ResidentCov::instance();
-  rc.bind(state.get());
+  ResidentCov &rc = ResidentCov::of(state);
+  const ResidentCov::Guard guard = rc.lock(); // (recursive: on_host below takes it again)
   if (!rc.on_device()) return on_host(state, true, [&] { StateHelperHost::augment_clone(state, last_w); });
   if (state->_clones_IMU.find(state->_timestamp) != state->_clones_IMU.end()) { // StateHelper.cpp:582-585
     PRINT_ERROR(RED "TRIED TO INSERT A CLONE AT THE SAME TIME AS AN EXISTING CLONE, EXITING!#!@#!@#\n" RESET);
@@ -230,6 +230,6 @@ void StateHelper::marginalize_slam(std::shared_ptr<State> state) {
 
 // how often the covariance crossed PCIe as a whole since the process started (tests, INTEGRATION.md's residency check)
 extern "C" void ovgpu_shim_resident_cov_traffic(long *uploads, long *downloads) {
-  if (uploads) *uploads = ResidentCov::instance().uploads();
-  if (downloads) *downloads = ResidentCov::instance().downloads();
+  if (uploads) *uploads = ResidentCov::uploads().load();
+  if (downloads) *downloads = ResidentCov::downloads().load();
 }

@@ -15,9 +15,6 @@
 #ifdef OVGPU_SHIM_MODE_B
 #include "ovgpu_state_access.h"
 #endif
-#ifdef OVGPU_SHIM_RESIDENT_TRACKS
-#include "ovgpu_track_mirror.h" // opt-in: the observations live in the library's track store, an update names its tracks
-#endif
 #ifdef OVGPU_SHIM_RESIDENT_COV
 #ifndef OVGPU_SHIM_MODE_B
 #error "OVGPU_SHIM_RESIDENT_COV needs OVGPU_SHIM_MODE_B: the device applies the update to the covariance it holds"
@@ -48,10 +45,6 @@ struct Lap {
 #define OVGPU_LAP(i) (void)0
 #endif
 
-#ifdef OVGPU_SHIM_RESIDENT_VERIFY
-static int g_resident_verify = 1;
-extern "C" void ovgpu_shim_resident_verify(int on) { g_resident_verify = on; } // (test builds only: tests/dropin_probe.py `time` measures without the check)
-#endif
 
 UpdaterMSCKF::UpdaterMSCKF(UpdaterOptions &options, FeatureInitializerOptions &feat_init_options) : _options(options) {
   _options.sigma_pix_sq = std::pow(_options.sigma_pix, 2);
@@ -74,32 +67,9 @@ void UpdaterMSCKF::update(std::shared_ptr<State> state, std::vector<std::shared_
   OVGPU_LAP(0); // snapshot
 
   // ---- 1. clean + flatten the tracks (UpdaterMSCKF.cpp:71-93)
-#ifdef OVGPU_SHIM_RESIDENT_TRACKS
-  // resident tracks (ovgpu_track_mirror.h): the Feature objects are cleaned as the reference cleans them (the database's own objects,
-  // :74), but nothing is copied out of them — the device holds every observation since the frame it was made
-  ovgpu_shim::TrackMirror &mirror = ovgpu_shim::TrackMirror::instance();
-  std::vector<int64_t> ids, seen_ids; // the batch; every track handed in (all of them leave the database after this update)
-  std::vector<int32_t> offs(1, 0);
-  for (auto it = feature_vec.begin(); it != feature_vec.end();) {
-    seen_ids.push_back((int64_t)(*it)->featid);
-    const int ct = ovgpu_shim::clean_track(**it, snap);
-    if (ct < 2) {
-      (*it)->to_delete = true;
-      it = feature_vec.erase(it);
-      continue;
-    }
-    ids.push_back((int64_t)(*it)->featid), offs.push_back(offs.back() + ct);
-    ++it;
-  }
-  if (feature_vec.empty()) {
-    if (mirror.attached()) mirror.erase(seen_ids);
-    return;
-  }
-#else
   static thread_local ovgpu_shim::FlatFeatures ff; // reused from update to update: a fresh 3.5 MB of buffers per call costs more in page faults than the flattening itself
   ovgpu_shim::clean_flatten_batch(feature_vec, snap, clones, ff, 2); // :84-92: a track with fewer than two observations in the window is flagged and dropped
   if (feature_vec.empty()) return;
-#endif
 
   OVGPU_LAP(1); // clean + flatten
   // ---- 2..5 on the GPU: triangulate, Jacobians, nullspace, chi2 gate, stack, compress (options re-read on every call)
@@ -110,47 +80,19 @@ void UpdaterMSCKF::update(std::shared_ptr<State> state, std::vector<std::shared_
 #ifdef OVGPU_SHIM_RESIDENT_COV
   // the state is resident: uploaded once (and again after anything on the host wrote the covariance: another updater's host path,
   // an initialisation), kept current by StateHelper's device-side wrappers in between
-  ovgpu_shim::ResidentCov &rcov = ovgpu_shim::ResidentCov::instance();
-  rcov.bind(state.get());
-  rcov.attach(ctx);
+  // (the record of THIS State; its lock is held to the end of the update: StateHelper's wrappers on other threads — a marginal covariance
+  //  for the odometry thread, Propagator.cpp:147 — reach the same context and wait)
+  ovgpu_shim::ResidentCov &rcov = ovgpu_shim::ResidentCov::of(state);
+  const ovgpu_shim::ResidentCov::Guard rguard = rcov.lock();
+  rcov.attach(ctx, *state);
   rcov.ensure_device(state);
 #else
   ctx.check(ovgpu_set_state(ctx.get(), &sv), "ovgpu_set_state");
 #endif
   OVGPU_LAP(2); // state hand-over
-#ifdef OVGPU_SHIM_RESIDENT_TRACKS
-  mirror.attach(ctx.get(), snap.cam_index); // (first update: creates the store, replays the frames recorded so far)
-  mirror.sync();
-  const int F = (int)ids.size();
-  ctx.check(ovgpu_tracks_to_features(ctx.get(), F, ids.data(), snap.fs.clone_times.data()), "ovgpu_tracks_to_features");
-  { // the mirror must have followed the database: the device-assembled batch has the host's track lengths, or the integration is missing a call
-    std::vector<int32_t> dev_offs((size_t)F + 1);
-    int32_t Fd = 0, Md = 0;
-    ctx.check(ovgpu_get_features(ctx.get(), &Fd, &Md, dev_offs.data(), nullptr, nullptr, nullptr, nullptr), "ovgpu_get_features");
-    if (Fd != F || dev_offs != offs)
-      throw std::runtime_error("ovgpu: the resident track store is out of step with the FeatureDatabase (a TrackMirror call is missing: ovgpu_track_mirror.h)");
-#ifdef OVGPU_SHIM_RESIDENT_VERIFY
-    // test builds: the WHOLE device-assembled batch against the host's flattening, observation by observation (camera, clone, pixels) — the
-    // lengths above cannot see an order mistake inside a track (switched off by the timing probe: ovgpu_shim_resident_verify)
-    if (g_resident_verify) {
-    ovgpu_shim::FlatFeatures host;
-    for (auto &ft : feature_vec) ovgpu_shim::append_track(*ft, snap, clones, host);
-    std::vector<int32_t> dci((size_t)Md + 1), dcam((size_t)Md + 1);
-    std::vector<float> duv(2 * (size_t)Md + 2), duvn(2 * (size_t)Md + 2);
-    ctx.check(ovgpu_get_features(ctx.get(), &Fd, &Md, nullptr, duv.data(), duvn.data(), dci.data(), dcam.data()), "ovgpu_get_features");
-    bool same = Md == host.M();
-    for (int i = 0; same && i < Md; i++)
-      same = dci[i] == host.clone_idx[i] && dcam[i] == host.cam_idx[i] && duv[2 * i] == host.uv[2 * i] && duv[2 * i + 1] == host.uv[2 * i + 1] &&
-             duvn[2 * i] == host.uvn[2 * i] && duvn[2 * i + 1] == host.uvn[2 * i + 1];
-    if (!same) throw std::runtime_error("ovgpu: the device-assembled batch differs from the host's flattening (OVGPU_SHIM_RESIDENT_VERIFY)");
-    }
-#endif
-  }
-#else
   const ovgpu_features_view fv = ff.view();
   ctx.check(ovgpu_set_features(ctx.get(), &fv), "ovgpu_set_features");
   const int F = fv.F;
-#endif
   OVGPU_LAP(3); // track hand-over
   std::vector<int32_t> status(F), anchor(F);
   std::vector<double> pA(3 * (size_t)F), pG(3 * (size_t)F);
@@ -185,20 +127,13 @@ void UpdaterMSCKF::update(std::shared_ptr<State> state, std::vector<std::shared_
   for (size_t f = 0; f < feature_vec.size(); f++) {
     std::shared_ptr<Feature> &ft = feature_vec[f];
     if (f + 4 < feature_vec.size()) __builtin_prefetch(feature_vec[f + 4].get(), 1);
-#ifdef OVGPU_SHIM_RESIDENT_TRACKS
-    ovgpu_shim::write_triangulation_nth(*ft, anchor[f] < 0 ? -1 : anchor[f] - offs[f], &pA[3 * f], &pG[3 * f]);
-#else
     ovgpu_shim::write_triangulation(*ft, snap, ff, anchor[f], &pA[3 * f], &pG[3 * f]);
-#endif
     ft->to_delete = true; // :137, :226, :262 — every feature that reached this point is flagged
     if (status[f] != OVGPU_FEAT_USED) continue;
     if (used != f) feature_vec[used] = std::move(ft);
     used++;
   }
   feature_vec.resize(used);
-#ifdef OVGPU_SHIM_RESIDENT_TRACKS
-  mirror.erase(seen_ids); // every track of this update is flagged to_delete: FeatureDatabase::cleanup() drops them (VioManager.cpp:579)
-#endif
   OVGPU_LAP(6); // side effects on the tracks
   if (rows < 1) return; // :266-268 / :276-278
 #if defined(OVGPU_SHIM_RESIDENT_COV)

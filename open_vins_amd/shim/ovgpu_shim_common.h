@@ -8,6 +8,7 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <unordered_map>
 #include <vector>
@@ -34,6 +35,8 @@ namespace ovgpu_shim {
 // options are compared on every call, an updater constructed later with other thresholds gets its own context.
 inline Context &context_for(const ovgpu_options &o) {
   static std::vector<std::pair<ovgpu_options, std::unique_ptr<Context>>> cache;
+  static std::mutex cache_mutex; // (updaters of two filters on two threads may construct their contexts at once; a Context itself is one caller's at a time)
+  const std::lock_guard<std::mutex> guard(cache_mutex);
   for (auto &e : cache)
     if (std::memcmp(&e.first, &o, sizeof(o)) == 0) return *e.second;
   cache.emplace_back(o, std::unique_ptr<Context>(new Context(o)));
@@ -113,7 +116,7 @@ inline int clean_append_track(ov_core::Feature &f, const StateSnapshot &snap, co
   else ff.end_feature();
   return total;
 }
-// the cleaning alone (the resident-track mode copies nothing out of the Feature objects)
+// the cleaning alone (the SLAM units clean, decide, then append_track)
 inline int clean_track(ov_core::Feature &f, const StateSnapshot &snap) {
   f.clean_old_measurements(snap.fs.clone_times);
   int total = 0;
@@ -152,6 +155,8 @@ inline void clean_flatten_batch(std::vector<std::shared_ptr<ov_core::Feature>> &
   } else {
     static ForkJoin pool(OVGPU_SHIM_FLATTEN_THREADS - 1);
     static std::vector<FlatFeatures> part_ff(OVGPU_SHIM_FLATTEN_THREADS); // reused from update to update, like `ff`
+    static std::mutex pool_mutex; // the pool and its buffers are one per process: updaters on several threads take turns (ForkJoin::run is not re-entrant)
+    const std::lock_guard<std::mutex> pool_guard(pool_mutex);
     const std::function<void(int)> work = [&](int p) {
       FlatFeatures &mine = part_ff[(size_t)p];
       mine.clear();
@@ -182,23 +187,6 @@ inline void write_triangulation(ov_core::Feature &feat, const StateSnapshot &sna
   feat.anchor_clone_timestamp = ff.meas_time[anchor_meas];
   feat.p_FinA = Eigen::Map<const Eigen::Vector3d>(pA);
   feat.p_FinG = Eigen::Map<const Eigen::Vector3d>(pG);
-}
-
-// the same from the k-th observation of the (cleaned) feature in the order its tracks are flattened — the iteration order of
-// Feature::timestamps, time order inside a camera: what the resident-track mode has instead of a host-side flat batch
-inline void write_triangulation_nth(ov_core::Feature &feat, int k, const double *pA, const double *pG) {
-  if (k < 0) return;
-  for (const auto &pair : feat.timestamps) {
-    if (k < (int)pair.second.size()) {
-      feat.anchor_cam_id = (int)pair.first;
-      feat.anchor_clone_timestamp = pair.second[(size_t)k];
-      feat.p_FinA = Eigen::Map<const Eigen::Vector3d>(pA);
-      feat.p_FinG = Eigen::Map<const Eigen::Vector3d>(pG);
-      return;
-    }
-    k -= (int)pair.second.size();
-  }
-  throw std::runtime_error("ovgpu: anchor measurement outside the track");
 }
 
 // mode A: the compressed (H, r) in the canonical column order -> the stock StateHelper::EKFUpdate (UpdaterMSCKF.cpp:280-285)

@@ -19,7 +19,7 @@ namespace ovgpu_shim {
 struct StateAccess {
   // State::_Cov for an updater's write-back (the resident-covariance build is told: the device's copy is stale from here on) ...
   static Eigen::MatrixXd &cov(ov_msckf::State &s) {
-    host_wrote_covariance();
+    host_wrote_covariance(s);
     return s._Cov;
   }
   // ... and for the residency code itself (sizes, downloads: ovgpu_resident_cov.h, StateHelper_resident.cpp)
@@ -29,14 +29,14 @@ struct StateAccess {
   // StateHelper::EKFUpdate's tail (StateHelper.cpp:166-196) with the numbers computed on the device: P' row-major N x N, dx N.
   // The negative-diagonal check of :171-182 has already happened on the device (OVGPU_ERR_NEGATIVE_DIAGONAL).
   static void apply_update(ov_msckf::State &s, const double *P_rowmajor, const double *dx, int N) {
-    host_wrote_covariance();
+    host_wrote_covariance(s);
     s._Cov = Eigen::Map<const Eigen::Matrix<double, Eigen::Dynamic, Eigen::Dynamic, Eigen::RowMajor>>(P_rowmajor, N, N);
     const Eigen::Map<const Eigen::VectorXd> d(dx, N);
     for (auto &var : s._variables) var->update(d.segment(var->id(), var->size())); // :185-187
     refresh_cameras(s);
   }
   // an updater's write-back into State::_Cov: in the resident-covariance build (ovgpu_resident_cov.h defines the hook) the device's copy is stale from here on
-  static void host_wrote_covariance();
+  static void host_wrote_covariance(ov_msckf::State &s);
   // the same with the covariance left where it is (the resident-covariance mode: P' stays on the device)
   static void apply_dx(ov_msckf::State &s, const double *dx, int N) {
     const Eigen::Map<const Eigen::VectorXd> d(dx, N);
@@ -55,5 +55,5 @@ struct StateAccess {
 #ifdef OVGPU_SHIM_RESIDENT_COV
 #include "ovgpu_resident_cov.h" // (defines StateAccess::host_wrote_covariance)
 #else
-inline void ovgpu_shim::StateAccess::host_wrote_covariance() {}
+inline void ovgpu_shim::StateAccess::host_wrote_covariance(ov_msckf::State &) {}
 #endif

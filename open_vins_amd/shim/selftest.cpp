@@ -241,8 +241,8 @@ static int time_dropin(int F, int reps, bool gpu = true, bool resident = false) 
       ovgpu_update_stats st;
       ctx.check(ovgpu_msckf_update(ctx.get(), status.data(), nullptr, nullptr, pG.data(), dx.data(), P1.data(), &st), "ovgpu_msckf_update");
       const double t3 = now_ms();
-      // what shim/UpdaterMSCKF.cpp (-DOVGPU_SHIM_RESIDENT_TRACKS) does around the call as well: the batch's offsets read back for its length
-      // check, and the tracks it was handed erased from the store (FeatureDatabase semantics: an update consumes its features)
+      // what a host that keeps its tracks in the store does around the call as well: the batch's offsets read back for a length check, and the
+      // tracks it was handed erased from the store (FeatureDatabase semantics: an update consumes its features)
       int32_t Fd = 0, Md = 0;
       std::vector<int32_t> offs((size_t)F + 1);
       ctx.check(ovgpu_get_features(ctx.get(), &Fd, &Md, offs.data(), nullptr, nullptr, nullptr, nullptr), "ovgpu_get_features");

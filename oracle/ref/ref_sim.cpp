@@ -42,9 +42,6 @@
 #include "update/UpdaterMSCKF.h"
 #include "update/UpdaterSLAM.h"
 #include <cstdlib>
-#ifdef OVGPU_SHIM_RESIDENT_TRACKS
-#include "ovgpu_track_mirror.h"
-#endif
 #include "utils/print.h"
 #include "utils/quat_ops.h"
 #include "utils/sensor_data.h"
@@ -179,12 +176,6 @@ void front_end(RefSim &s, double timestamp, const std::vector<int> &camids,
       cv::Point2f pt(feat.second(0), feat.second(1));
       cv::Point2f npt_l = s.state->_cam_intrinsics_cameras.at(cam_id)->undistort_cv(pt);
       s.db->update_feature(id, timestamp, cam_id, pt.x, pt.y, npt_l.x, npt_l.y);
-#ifdef OVGPU_SHIM_RESIDENT_TRACKS // the drop-in's opt-in resident-track mode: the mirror follows the database call for call (shim/ovgpu_track_mirror.h)
-      // (test hook: OVGPU_TEST_DROP_MIRROR_FRAME=n forgets the mirror call of every n-th frame — the integration mistake the shim must catch)
-      static const int drop_every = std::getenv("OVGPU_TEST_DROP_MIRROR_FRAME") ? std::atoi(std::getenv("OVGPU_TEST_DROP_MIRROR_FRAME")) : 0;
-      if (!(drop_every > 0 && s.frames % drop_every == drop_every - 1))
-        ovgpu_shim::TrackMirror::instance().update_feature(id, timestamp, cam_id, pt.x, pt.y, npt_l.x, npt_l.y);
-#endif
     }
   }
 }
@@ -392,10 +383,6 @@ void *ref_sim_create(const ref_sim_config *c) {
   s->state->_timestamp = imustate(0, 0);
   s->startup_time = imustate(0, 0);
   s->db->cleanup_measurements(s->state->_timestamp);
-#ifdef OVGPU_SHIM_RESIDENT_TRACKS
-  ovgpu_shim::TrackMirror::instance().reset(); // a new filter: the mirror starts with it
-  ovgpu_shim::TrackMirror::instance().cleanup_measurements(s->state->_timestamp);
-#endif
   return s;
 }
 
@@ -572,24 +559,10 @@ void ref_sim_finish(void *h) {
   RefSim &s = *static_cast<RefSim *>(h);
   auto &state = s.state;
   for (auto const &feat : s.featsup) feat->to_delete = true;
-#ifdef OVGPU_SHIM_RESIDENT_TRACKS
-  { // tracks flagged to_delete OUTSIDE the MSCKF update (UpdaterSLAM::update / delayed_init flag what they were handed) leave the mirror as well
-    std::vector<int64_t> gone;
-    for (auto const &v : {s.feats_slam_update, s.feats_slam_delayed})
-      for (auto const &feat : v)
-        if (feat->to_delete) gone.push_back((int64_t)feat->featid);
-    for (auto const &kv : s.db->get_internal_data())
-      if (kv.second->to_delete && std::find(gone.begin(), gone.end(), (int64_t)kv.first) == gone.end() && s.updater_slam) gone.push_back((int64_t)kv.first);
-    ovgpu_shim::TrackMirror::instance().erase(gone);
-  }
-#endif
   s.db->cleanup();
   if (s.updater_slam) s.updater_slam->change_anchors(state); // VioManager.cpp:585
   if ((int)state->_clones_IMU.size() > state->_options.max_clone_size) {
     s.db->cleanup_measurements(state->margtimestep());
-#ifdef OVGPU_SHIM_RESIDENT_TRACKS
-    ovgpu_shim::TrackMirror::instance().cleanup_measurements(state->margtimestep());
-#endif
   }
   {
     const double t0 = now_s();

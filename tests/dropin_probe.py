@@ -207,12 +207,12 @@ def loop(mode, seconds, name="loop", **cfg):
     ctl = run_filter("reference", seconds=seconds, perturb=1e-13, **cfg)
     traffic = None
     with pyref.using(pyref.dropin_path(mode)) as lib:
-        if mode.startswith("rc") or mode.startswith("c"):  # the resident-covariance builds count the N x N copies they make
+        if mode.startswith("c"):  # the resident-covariance builds count the N x N copies they make
             import ctypes
             before = (ctypes.c_long(0), ctypes.c_long(0))
             lib.ovgpu_shim_resident_cov_traffic(ctypes.byref(before[0]), ctypes.byref(before[1]))
         got = run_filter("reference", seconds=seconds, **cfg)  # ("reference" = the library's own updaters: here the shim's)
-        if mode.startswith("rc") or mode.startswith("c"):
+        if mode.startswith("c"):
             after = (ctypes.c_long(0), ctypes.c_long(0))
             lib.ovgpu_shim_resident_cov_traffic(ctypes.byref(after[0]), ctypes.byref(after[1]))
             traffic = dict(cov_uploads=after[0].value - before[0].value, cov_downloads=after[1].value - before[1].value)
@@ -251,8 +251,6 @@ def time_loop(mode, seconds=6.0, **cfg):
     kw = dict(num_cameras=2, max_clones=30, num_pts=1100, max_msckf_in_update=4000)
     kw.update(cfg)
     with pyref.using(pyref.dropin_path(mode)) as lib:
-        if mode.startswith("r"):
-            lib.ovgpu_shim_resident_verify(0)  # (the test builds of the resident modes compare every device-assembled batch with the host's flattening: not part of the mode)
         sim = refsim.RefSim(refsim.rpng_sim_config(**kw))
         t0 = None
         half = None
@@ -273,7 +271,7 @@ def time_loop(mode, seconds=6.0, **cfg):
         laps = _laps(lib)
         sim.close()
         traffic = {}
-        if mode.startswith("rc") or mode.startswith("c"):
+        if mode.startswith("c"):
             import ctypes
             u, d = ctypes.c_long(0), ctypes.c_long(0)
             lib.ovgpu_shim_resident_cov_traffic(ctypes.byref(u), ctypes.byref(d))
@@ -363,8 +361,6 @@ if __name__ == "__main__":
         sys.stdout.flush()
         os._exit(0)
     for kind, arg in CASES:
-        if mode.startswith("r") and (not kind.startswith("loop") or kind == "loop_wide"):
-            continue  # the resident-track build updates from the mirrored track store: only a LOOP feeds it (the per-call driver builds bare Features)
         globals()[kind](mode, seconds if kind.startswith("loop") else arg)
     emit("done")
     sys.stdout.flush()

@@ -150,13 +150,12 @@ def cpu_probes(dropin_libs):
     """The oracle-backed builds run side by side (they share nothing): module-scoped, so the CPU suite pays the longest of them once."""
     if pyref.can_build():
         pyref.build_dropin("dropin_cpu")
-    modes = [m for m in ("a_cpu", "b_cpu", "r_cpu", "c_cpu", "rc_cpu") if os.path.exists(pyref.dropin_path(m))]
+    modes = [m for m in ("a_cpu", "b_cpu", "c_cpu") if os.path.exists(pyref.dropin_path(m))]
     procs = {m: subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dropin_probe.py"), m, "20"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
              for m in modes}
     for m in modes:  # ... and, beside them, the sweep over every seeded shape of the parity suite (modes A and B)
-        if not m.startswith("r"):
-            procs["sweep_" + m] = subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dropin_probe.py"), m, "sweep"], stdout=subprocess.PIPE,
-                                                   stderr=subprocess.PIPE, text=True)
+        procs["sweep_" + m] = subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dropin_probe.py"), m, "sweep"], stdout=subprocess.PIPE,
+                                               stderr=subprocess.PIPE, text=True)
     out = {}
     for m, pr in procs.items():
         so, se = pr.communicate(timeout=900)
@@ -235,15 +234,6 @@ def test_dropin_library_on_every_seeded_shape_of_the_parity_suite(cpu_probes, mo
     assert l["delayed_P"] < 1e-10 and l["delayed_value"] < 1e-9
 
 
-def test_resident_track_mode_of_the_dropin_runs_the_closed_loop_with_the_oracle_behind_the_abi(cpu_probes):
-    """-DOVGPU_SHIM_RESIDENT_TRACKS (shim/ovgpu_track_mirror.h): the observations are mirrored into the library's track
-    store as the front end makes them — the three TrackMirror calls a maintainer adds next to FeatureDatabase::update_feature /
-    cleanup_measurements sit in oracle/ref/ref_sim.cpp, the restatement of VioManager's loop — and UpdaterMSCKF::update names its tracks
-    instead of flattening and uploading them (ovgpu_tracks_to_features; the device-assembled batch is checked against the host's track
-    lengths on every update, a missing mirror call throws).  20 s of the rpng_sim closed loops, mode B, against the reference's own updater."""
-    _judge(_cpu_lines(cpu_probes, "r_cpu"), LIMITS_CPU, 190, loop_only=True)
-
-
 def _judge_resident_covariance(lines):
     """What the mode is for: between two MSCKF updates nothing moves the N x N covariance across the bus.  The MSCKF-only loop uploads it once
     (the filter's initial covariance) and never reads it back: propagation, cloning, marginalisation and the update itself all happen on the
@@ -267,32 +257,13 @@ def test_resident_covariance_mode_of_the_dropin_equals_the_reference_with_the_or
     _judge_resident_covariance(lines)
 
 
-def test_both_resident_modes_together_run_the_closed_loops_with_the_oracle_behind_the_abi(cpu_probes):
-    lines = _cpu_lines(cpu_probes, "rc_cpu")
-    _judge(lines, LIMITS_CPU, 190, loop_only=True)
-    _judge_resident_covariance(lines)
-
-
-def test_resident_track_mode_refuses_to_update_from_a_store_that_missed_a_frame(dropin_libs):
-    """The integration mistake the mode invites: a front-end path that feeds the FeatureDatabase but not the mirror.  The test hook of
-    oracle/ref/ref_sim.cpp forgets the mirror call of every 9th frame; the shim compares the device-assembled batch's track lengths with the
-    host's on every update and throws (the reference's update path has no error channel: the process ends) instead of updating from stale tracks."""
-    if pyref.can_build():
-        pyref.build_dropin("dropin_cpu")
-    if not os.path.exists(pyref.dropin_path("r_cpu")):
-        pytest.skip("oracle/_ref/libov_dropin_r_cpu.so is not here and cannot be built (no /root/reference)")
-    env = dict(os.environ, OVGPU_TEST_DROP_MIRROR_FRAME="9")
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "dropin_probe.py"), "r_cpu", "10"], capture_output=True, text=True, timeout=600, env=env)
-    assert p.returncode != 0 and "out of step with the FeatureDatabase" in p.stderr and '"done"' not in p.stdout, (p.returncode, p.stdout[-500:], p.stderr[-800:])
-
-
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["a", "b", "r", "c"])
+@pytest.mark.parametrize("mode", ["a", "b", "c"])
 def test_dropin_library_equals_the_reference_updaters_on_the_gpu(dropin_libs, mode):
     if not os.path.exists(pyref.dropin_path(mode)):
         pytest.skip("drop-in library of this mode is not here")
     lines = _run_probe(mode, 6.0)  # (6 s of each closed loop = 60 updates; the CPU legs run 20 s, the GPU suite has a time budget)
-    _judge(lines, dict(LIMITS, loop_first_ten=1e-8), 50, loop_only=(mode == "r"))
+    _judge(lines, dict(LIMITS, loop_first_ten=1e-8), 50)
     if mode == "c":  # the covariance stays on the device from frame to frame
         _judge_resident_covariance(lines)
 

@@ -54,17 +54,6 @@ def test_helper_headers_compile_in_a_caller():
     assert r.returncode == 0, r.stderr[-3000:]
 
 
-@pytest.mark.parametrize("mode", ["A", "B"])
-def test_resident_track_mode_of_the_msckf_unit_compiles(mode):
-    """-DOVGPU_SHIM_RESIDENT_TRACKS (ovgpu_track_mirror.h): the opt-in mode that names tracks of the library's store instead of flattening them."""
-    cmd = ["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Werror", "-DOVGPU_SHIM_RESIDENT_TRACKS", f"-I{MOCK}", f"-I{MOCK}/update", f"-I{MOCK}/feat",
-           f"-I{ROOT}/include", f"-I{SHIM}", os.path.join(SHIM, "UpdaterMSCKF.cpp")]
-    if mode == "B":
-        cmd.insert(1, "-DOVGPU_SHIM_MODE_B")
-    r = subprocess.run(cmd, capture_output=True, text=True)
-    assert r.returncode == 0, r.stderr[-3000:]
-
-
 def test_resident_covariance_mode_of_the_msckf_unit_compiles():
     """-DOVGPU_SHIM_RESIDENT_COV (ovgpu_resident_cov.h): the covariance stays in the library's context; mode B only."""
     base = ["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Werror", "-DOVGPU_SHIM_RESIDENT_COV", f"-I{MOCK}", f"-I{MOCK}/update", f"-I{MOCK}/feat",
@@ -105,7 +94,7 @@ def test_dropin_units_keep_the_reference_signatures():
 
 
 def test_no_shim_source_touches_the_oracle_or_the_environment():
-    for name in list(UNITS) + ["ovgpu_shim_common.h", "ovgpu_flatten.h", "ovgpu_state_access.h", "ovgpu_zupt.h", "ovgpu_retri.h", "ovgpu_track_mirror.h", "ovgpu_resident_cov.h", "StateHelper_resident.cpp"]:
+    for name in list(UNITS) + ["ovgpu_shim_common.h", "ovgpu_flatten.h", "ovgpu_state_access.h", "ovgpu_zupt.h", "ovgpu_retri.h", "ovgpu_resident_cov.h", "StateHelper_resident.cpp"]:
         s = _src(name)
         assert "oracle" not in s and "getenv" not in s, name
 
