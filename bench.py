@@ -283,6 +283,15 @@ def main(argv=None):
                 print("[bench failed] " + json.dumps({"error": str(e), "exchange": exchange, "preflight": preflight, "n_gpus": world,
                                                       "steps": args.steps, "warmup": args.warmup}), file=sys.stderr, flush=True)
             sys.exit(3)
+    rank_records = None
+    if world > 1:
+        # every rank's own record on EVERY path (native exchange or host-driven fall-back): its shard, and what the RCCL communicator itself says
+        # (ncclCommCount / ncclCommUserRank through ovgpu_comm_info; -1 = no communicator) -- what a first multi-GPU line is checked against
+        info = up.comm_info() if hasattr(up, "comm_info") else dict(rank=rank, world=world, rccl_rank=-1, rccl_ranks=-1)
+        rec = {"rank": rank, "features_this_rank": int(shard.F), "measurements_this_rank": int(shard.M), "world_told": int(info["world"]),
+               "rccl_rank": int(info["rccl_rank"]), "rccl_ranks": int(info["rccl_ranks"])}
+        rank_records = [None] * world
+        dist.all_gather_object(rank_records, rec)
     headline_loops = [1e3 * x / args.steps for x in timed_loops]
     headline_rank_ms = [1e3 * x / args.steps for x in rank_loops]
     kt = up.kernel_times(reset=True)
@@ -485,6 +494,8 @@ def main(argv=None):
         if world > 1:
             # what the first real multi-GPU line is read against (no N > 1 run has been measured: DESIGN.md section 5)
             out["exchange"] = dict(exchange)
+            out["exchange"]["ranks"] = rank_records
+            out["exchange"]["rccl_ranks"] = sorted({r["rccl_ranks"] for r in rank_records})  # [N] when RCCL spans the N ranks; [-1] on the host-driven fall-back
             out["per_rank_ms_per_step"] = headline_rank_ms  # last timed loop, every rank's own clock
             out["preflight"] = preflight
         if hook is not None:

@@ -68,7 +68,7 @@ extern "C" {
 /*   8  (round 6) OVGPU_COMPRESS_CHOLQR (= 2, the unpivoted Cholesky factor of  */
 /*      the Gram matrix as a compressed system: a documented negative result)   */
 /*      is gone: ovgpu_create returns OVGPU_ERR_INVALID for it.  Nothing else   */
-/*      changed shape.                                                          */
+/*      changed shape.  New: ovgpu_comm_info.                                   */
 /* ------------------------------------------------------------------------- */
 #define OVGPU_ABI_VERSION 8
 int ovgpu_abi_version(void);
@@ -825,6 +825,9 @@ typedef struct { char internal[128]; } ovgpu_comm_id; /* = ncclUniqueId */
 int ovgpu_comm_unique_id(ovgpu_comm_id *id);
 int ovgpu_comm_init_rank(ovgpu_ctx *ctx, const ovgpu_comm_id *id, int rank, int world);
 int ovgpu_comm_destroy(ovgpu_ctx *ctx);
+/* rank / world as ovgpu_comm_init_rank was told, and as the RCCL communicator itself reports them (ncclCommUserRank / ncclCommCount;
+ * -1 without a communicator): evidence for a multi-GPU run's log that the collective spans the ranks it is believed to span. */
+int ovgpu_comm_info(ovgpu_ctx *ctx, int32_t *rank_told, int32_t *world_told, int32_t *rccl_rank, int32_t *rccl_ranks);
 
 /* UpdaterMSCKF::update of THIS rank's shard (uploaded with ovgpu_set_features on the replicated state): local stage, exchange and
  * update are enqueued back to back on the context's stream, no host synchronisation in between.  Per-feature outputs are the

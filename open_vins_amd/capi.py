@@ -248,6 +248,7 @@ def declare(lib):
         "ovgpu_comm_unique_id": (C.c_int, [vp]),
         "ovgpu_comm_init_rank": (C.c_int, [ctxp, vp, C.c_int, C.c_int]),
         "ovgpu_comm_destroy": (C.c_int, [ctxp]),
+        "ovgpu_comm_info": (C.c_int, [ctxp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
         "ovgpu_msckf_update_sharded": (C.c_int, [ctxp, c_int32_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, C.POINTER(UpdateStats)]),
         "ovgpu_msckf_update_sharded_async": (C.c_int, [ctxp]),
         "ovgpu_multi_create": (C.c_int, [C.POINTER(Options), C.c_int, c_int32_p, C.POINTER(vp)]),

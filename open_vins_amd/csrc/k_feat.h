@@ -102,6 +102,14 @@ __device__ __forceinline__ bool diag_tile_factor_blk(d4 &s, d4 &e, double *sh, i
 #pragma unroll
   for (int q = 0; q < 4; q++) e[q] = (g + 4 * q == cl) ? 1.0 : 0.0;
   bool bad = false;
+  // The pivot thresholds, ALL sixteen before the chain starts (round 6): as `bad || !(dk > tol * diag0[k])` inside it every pivot had a branch
+  // and — in the prior's factorisation, which has a diag0 — a dependent load with its own s_waitcnt in front of the next v_rsq_f64 (ISA of round
+  // 5's k_chol_fused: sixteen flat_load / s_waitcnt vmcnt(0) pairs per diagonal tile on the one path nothing hides; -5 us per update)
+  double thr[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) thr[k] = diag0 ? diag0[k < nb ? k : 0] : 0.0;
+#pragma unroll
+  for (int k = 0; k < 16; k++) thr[k] = diag0 ? tol * thr[k] : 0.0;
 #pragma unroll
   for (int b = 0; b < 4; b++) {
     const int kb = 4 * b;
@@ -124,7 +132,7 @@ __device__ __forceinline__ bool diag_tile_factor_blk(d4 &s, d4 &e, double *sh, i
       double dk = a[r][r];
 #pragma unroll
       for (int t = 0; t < r; t++) dk = fma(-u[t][r], u[t][r], dk);
-      if (kb + r < nb) bad = bad || !(dk > (diag0 ? tol * diag0[kb + r] : 0.0));
+      bad = bad | ((kb + r < nb) & !(dk > thr[kb + r]));
       double d;
       rsqrt_pair(dk, inv[r], d);
       u[r][r] = d;

@@ -69,14 +69,25 @@ class ShardedUpdateError(RuntimeError):
         super().__init__(f"sharded update failed in its {stage} stage on {sum(1 for c in self.codes if c)} of {len(self.codes)} ranks — {bad}")
 
 
-def agree_on_status(dist, stage: str, error: BaseException | None):
+def agree_on_status(dist, stage: str, error: BaseException | None, device=None, failed_ranks: int | None = None):
     """Collective: every rank reports the outcome of `stage` (error = the exception it caught, or None); returns normally when all
-    succeeded, raises the SAME ShardedUpdateError on every rank otherwise.  One all_gather_object of a (code, message) pair."""
+    succeeded, raises the SAME ShardedUpdateError on every rank otherwise.
+    The common case costs ONE number: `failed_ranks` is the count of failing ranks when the caller already carried it in a tensor it
+    exchanged anyway (distributed_update: one more element of the all-reduced Gram buffer / of the gathered triangle); without it a
+    one-element all-reduce on `device` finds it.  Only when it is non-zero are the (code, message) pairs gathered (a pickled
+    all_gather_object with its own host synchronisation: round 5 paid two of those per update for an error-only signal)."""
     world = dist.get_world_size() if dist.is_initialized() else 1
     mine = (0, "") if error is None else (int(getattr(error, "code", -1)) or -1, str(error)[:200])
     if world == 1:
         every = [mine]
     else:
+        if failed_ranks is None:
+            import torch
+            flag = torch.tensor([1.0 if error is not None else 0.0], dtype=torch.float64, device=device if device is not None else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.SUM)
+            failed_ranks = int(round(float(flag.item())))
+        if failed_ranks == 0:
+            return
         every = [None] * world
         dist.all_gather_object(every, mine)
     if any(c for c, _ in every):
@@ -99,37 +110,44 @@ def distributed_update(backend, dist, device, want_outputs=True):
         except Exception as e:  # noqa: BLE001
             return None, e
 
+    # The exchanged buffer carries ONE more element behind the payload: 1.0 on a rank whose local stage failed.  Summed (Gram protocol) or
+    # gathered (triangles) with the payload, it tells every rank how many ranks failed without a collective of its own.
     if ng > 0:
-        gram = torch.empty(ng, dtype=torch.float64, device=device)
+        buf = torch.empty(ng + 1, dtype=torch.float64, device=device)
+        gram = buf[:ng]
         _, err = attempt(lambda: backend.local_gram_into(gram))  # synchronises the context's stream before returning
         if err is not None:
             gram.zero_()
+        buf[ng] = 1.0 if err is not None else 0.0
         if world > 1:
-            dist.all_reduce(gram, op=dist.ReduceOp.SUM)
-            if gram.is_cuda:
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+            if buf.is_cuda:
                 torch.cuda.current_stream(device).synchronize()
-            agree_on_status(dist, "local (per-feature + Gram)", err)
+            agree_on_status(dist, "local (per-feature + Gram)", err, failed_ranks=int(round(float(buf[ng].item()))))
         elif err is not None:
             raise err
         out, err = attempt(lambda: backend.gram_update_from(gram, want_outputs))
         if world > 1:
-            agree_on_status(dist, "update", err)
+            agree_on_status(dist, "update", err, device=device)
         elif err is not None:
             raise err
         return out
-    mine = torch.empty(n, dtype=torch.float64, device=device)
-    _, err = attempt(lambda: backend.local_into(mine))  # synchronises the context's stream before returning
+    mine = torch.empty(n + 1, dtype=torch.float64, device=device)
+    _, err = attempt(lambda: backend.local_into(mine[:n]))  # synchronises the context's stream before returning
     if world == 1:
         if err is not None:
             raise err
-        return backend.merge_update_from(mine, 1, want_outputs)
+        return backend.merge_update_from(mine[:n], 1, want_outputs)
     if err is not None:
         mine.zero_()
-    gathered = torch.empty(n * world, dtype=torch.float64, device=device)
-    dist.all_gather_into_tensor(gathered, mine)
-    if gathered.is_cuda:
+    mine[n] = 1.0 if err is not None else 0.0
+    both = torch.empty((n + 1) * world, dtype=torch.float64, device=device)
+    dist.all_gather_into_tensor(both, mine)
+    if both.is_cuda:
         torch.cuda.current_stream(device).synchronize()  # RCCL ran on torch's stream, the merge runs on ours
-    agree_on_status(dist, "local (per-feature + compression)", err)
+    both = both.view(world, n + 1)
+    agree_on_status(dist, "local (per-feature + compression)", err, failed_ranks=int(round(float(both[:, n].sum().item()))))
+    gathered = both[:, :n].contiguous().view(-1)
     out, err = attempt(lambda: backend.merge_update_from(gathered, world, want_outputs))
-    agree_on_status(dist, "merge + update", err)
+    agree_on_status(dist, "merge + update", err, device=device)
     return out

@@ -526,6 +526,12 @@ class UpdaterMSCKF:
         idbuf = C.create_string_buffer(bytes(t.cpu().tolist()), 128)
         capi.check(self.lib.ovgpu_comm_init_rank(self._ctx, idbuf, rank, world), "ovgpu_comm_init_rank")
 
+    def comm_info(self):
+        """rank / world as told to ovgpu_comm_init_rank, and as the RCCL communicator reports them (-1: no communicator)."""
+        v = [C.c_int32(0) for _ in range(4)]
+        capi.check(self.lib.ovgpu_comm_info(self._ctx, *[C.byref(x) for x in v]), "ovgpu_comm_info")
+        return dict(rank=v[0].value, world=v[1].value, rccl_rank=v[2].value, rccl_ranks=v[3].value)
+
     def comm_init_single(self):
         """A communicator of one rank (no collective is issued): the native sharded entry points on a single GPU."""
         idbuf = C.create_string_buffer(128)

@@ -25,6 +25,8 @@ def test_two_rank_bench_runs_end_to_end_over_gloo():
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "strong"
     assert "test_hook" in d and "NOT a measurement" in d["test_hook"]
     assert "host-driven fallback" in d["exchange"]["kind"]          # both ranks agreed after the native communicator failed
+    assert [r["rank"] for r in d["exchange"]["ranks"]] == [0, 1] and [r["features_this_rank"] for r in d["exchange"]["ranks"]] == [7, 7]
+    assert d["exchange"]["rccl_ranks"] == [-1]                       # no RCCL communicator on this host: the line says so
     assert "native RCCL exchange unavailable" in p.stderr
     assert len(d["per_rank_ms_per_step"]) == 2 and all(t > 0 for t in d["per_rank_ms_per_step"])
     assert max(d["per_rank_ms_per_step"]) <= d["ms_per_step_timed_loops"][-1] * 1.0001  # the line's time is the max over ranks
