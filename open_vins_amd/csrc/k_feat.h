@@ -168,6 +168,83 @@ __device__ __forceinline__ bool diag_tile_factor_blk(d4 &s, d4 &e, double *sh, i
   return bad;
 }
 
+// Round 6: the diagonal tile WITHOUT square roots and with a chain a third as long — block L D L^T by 4 x 4 blocks,
+//        S = L D L^T,   L unit lower triangular by blocks, D = diag(A_0 .. A_3), A_b the 4 x 4 Schur complements,
+// which is all the gate needs: the trailing update of the blocked elimination is S_ij -= S_ki^T S_kk^-1 S_kj = Y_ki^T X_kj with
+// Y_kj = L^-1 S_kj, X_kj = D^-1 Y_kj, and the statistic r^T S^-1 r is an entry of the Schur complement of the augmented matrix.
+//   s   in: the tile (accumulator layout); out: rows of the blocks >= nblk hold their Schur complement with respect to the eliminated
+//       blocks (columns >= 4 nblk are meaningful), the other rows are scratch
+//   e   out: E = L^-1 (rows of the blocks >= nblk: rows of the identity carried through the elimination)
+//   f   out: F = D^-1 L^-1 (rows of the blocks >= nblk: zero)
+//   sh  128 doubles of LDS scratch private to the wavefront;  nblk (wave-uniform): the leading 4 x 4 blocks to eliminate
+// Block step b: the four rows of [S | E] go through LDS.  Lane (g, c) needs ROW g of A_b^-1 only (its part of the A operand of the
+// rank-4 update, (A_b^-1 Z_b)[g][c]), so it reads the block PERMUTED with its own row last — (g+1, g+2, g+3, g) mod 4, a symmetric
+// permutation of a positive definite block — and evaluates the last row of the inverse of [P Q; Q^T R] (2 x 2 blocks) with every
+// division deferred:  T' = adj(P) Q,  S' = det(P) R - Q^T T',  last row = [ -T' adj(S')[:, 1] ; det(P) adj(S')[1, :] ] / det(S').
+// ONE reciprocal per block step and nothing but its Newton correction behind it on the chain (det P -> S' -> det S' -> 1 / det S' ->
+// one product -> the matrix instruction): ~13 dependent operations per four pivots where the Cholesky form above has ~36 (four
+// reciprocal square roots with two Newton steps each), no lane selects, ~45 instead of ~100 instructions per block step.  The four
+// lane groups invert four differently ordered copies of the block: the rows agree to rounding (pivoting order of a positive definite
+// 4 x 4), which is what the elimination's other roundings are.  Lanes of the columns c < 4 b + 4 compute on finished columns: their
+// products land in rows / columns nothing reads again.  Measured against the Cholesky form: profiles/r06_c_diagonal_tile_ldl.txt.
+__device__ __forceinline__ void diag_tile_ldl_blk(d4 &s, d4 &e, d4 &f, double *sh, int lane, int nblk) {
+  // (the lane id from the hardware, inside an opaque statement: the ten per-lane offsets below depend on nothing else, were hoisted out of the
+  //  feature loop of k_feat_y<8, 17, 1> and spilled — thirteen scratch loads per block step on the one path nothing hides)
+  int lane_o;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_o));
+  (void)lane;
+  const int g = lane_o >> 4, cl = lane_o & 15;
+  const int p0 = (g + 1) & 3, p1 = (g + 2) & 3, p2 = (g + 3) & 3, p3 = g;
+  // (both triangles of a diagonal tile are kept — SYRK, trailing and in-tile updates write whole tiles — so the block is read where the
+  //  permutation points, equal to its mirror image up to rounding)
+  const int o00 = p0 * 16 + p0, o01 = p0 * 16 + p1, o11 = p1 * 16 + p1, o02 = p0 * 16 + p2, o03 = p0 * 16 + p3, o12 = p1 * 16 + p2, o13 = p1 * 16 + p3,
+            o22 = p2 * 16 + p2, o23 = p2 * 16 + p3, o33 = p3 * 16 + p3;
+#pragma unroll
+  for (int q = 0; q < 4; q++) e[q] = (g + 4 * q == cl) ? 1.0 : 0.0, f[q] = 0.0;
+#pragma unroll
+  for (int b = 0; b < 4; b++) {
+    if (b < nblk) {
+      const int kb = 4 * b;
+      sh[g * 16 + cl] = s[b], sh[64 + g * 16 + cl] = e[b];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const double *ab = sh + kb;
+      const double a00 = ab[o00], a01 = ab[o01], a11 = ab[o11];                   // P
+      const double q00 = ab[o02], q01 = ab[o03], q10 = ab[o12], q11 = ab[o13];    // Q
+      const double r00 = ab[o22], r01 = ab[o23], r11 = ab[o33];                   // R
+      const double z0 = sh[p0 * 16 + cl], z1 = sh[p1 * 16 + cl], z2 = sh[p2 * 16 + cl], z3 = sh[p3 * 16 + cl];
+      const double e0 = sh[64 + p0 * 16 + cl], e1 = sh[64 + p1 * 16 + cl], e2 = sh[64 + p2 * 16 + cl], e3 = sh[64 + p3 * 16 + cl];
+      const double detp = fma(a00, a11, -(a01 * a01));
+      const double t00 = fma(a11, q00, -(a01 * q10)), t01 = fma(a11, q01, -(a01 * q11)); // T' = adj(P) Q
+      const double t10 = fma(a00, q10, -(a01 * q00)), t11 = fma(a00, q11, -(a01 * q01));
+      const double s00 = fma(detp, r00, -fma(q00, t00, q10 * t10));                       // S' = det(P) R - Q^T T'
+      const double s01 = fma(detp, r01, -fma(q00, t01, q10 * t11));
+      const double s11 = fma(detp, r11, -fma(q01, t01, q11 * t11));
+      const double dets = fma(s00, s11, -(s01 * s01));
+      // numerators of the last row of the inverse: [ -m0, -m1, -det(P) s01, det(P) s00 ],  m = T' adj(S')[:, 1]
+      const double m0 = fma(t01, s00, -(t00 * s01)), m1 = fma(t11, s00, -(t10 * s01));
+      const double n2 = -(detp * s01), n3 = detp * s00;
+      const double nz = fma(n3, z3, fma(n2, z2, -fma(m0, z0, m1 * z1)));
+      const double ne = fma(n3, e3, fma(n2, e2, -fma(m0, e0, m1 * e1)));
+      double rho = __builtin_amdgcn_rcp(dets); // ~2^-23; (1 + eps + eps^2) behind it leaves eps^3
+      const double eps = fma(-dets, rho, 1.0);
+      rho = fma(rho, fma(eps, eps, eps), rho);
+      const double zi = nz * rho;
+      f[b] = ne * rho;
+      if (b < 3) { // rows below the block: [S | E] -= (A_b^-1 Z_b)^T [Z_b | E_b]  (finished rows of s take the update as well: scratch from here on)
+        FEAT_MFMA(-zi, s[b], s);
+        d4 ue = {0.0, 0.0, 0.0, 0.0};
+        FEAT_MFMA(-zi, e[b], ue);
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+          if (q > b) e[q] += ue[q];
+      }
+      __builtin_amdgcn_wave_barrier(); // sh is rewritten by the next block step
+    }
+  }
+}
+
 // Row store in HBM, written by k_feat_rows: per measurement RS doubles (the sparse Jacobian rows of k_system.h, offsets RO_*) and
 // 8 ints (camera, clone, first column of the clone / extrinsic / intrinsic block, their covariance ids).
 struct FeatStore {

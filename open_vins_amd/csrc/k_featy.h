@@ -67,14 +67,14 @@ __host__ __device__ inline FeatYLds featy_lds_layout(int nt_max, int nta_max, in
     o += (bytes + 15) & ~(size_t)15;
     return at;
   };
-  // the block; afterwards the Cholesky's row panel (nta_max tiles) and, behind it, the solved right-hand sides (16 nt_max x 4)
+  // the block; afterwards the gate's row panel, twice (Y and X = D^-1 Y: 2 nta_max tiles)
   {
-    const size_t blk = (size_t)16 * nt_max * (cb + 2) * sizeof(double), pan = ((size_t)nta_max * 256 + (size_t)16 * nt_max * 4) * sizeof(double);
+    const size_t blk = (size_t)16 * nt_max * (cb + 2) * sizeof(double), pan = (size_t)2 * nta_max * 256 * sizeof(double);
     L.yb = take(blk > pan ? blk : pan);
   }
   L.vl = take((((size_t)16 * nt_max * 3 * sizeof(double)) + 1023) & ~(size_t)1023); // whole 1 KiB chunks: filled by the LDS DMA path
-  const size_t wp = (size_t)nw * 3 * cb * sizeof(double), stage = 2 * 256 * sizeof(double);
-  L.wpart = take(wp > stage ? wp : stage); // V^T Y partial sums per wavefront; afterwards the Cholesky's diagonal-tile stage
+  const size_t wp = (size_t)nw * 3 * cb * sizeof(double), stage = (128 + 2 * 256) * sizeof(double);
+  L.wpart = take(wp > stage ? wp : stage); // V^T Y partial sums per wavefront; afterwards the gate's diagonal-tile stage: scratch, E, F
   L.misc = take(32 * sizeof(double) + (size_t)(nt_max + 16) * sizeof(int)); // V^T r partials per wavefront, then rowlim / sched
   L.total = o;
   return L;
@@ -349,30 +349,51 @@ __global__ void __launch_bounds__(BL_NTH) k_batch_layout(int F, int m_max, int D
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // ---------------------------------------------------------------------------------------------------
-// Blocked Cholesky of the AUGMENTED gate matrix held as tiles in registers + the chi2 statistic.
+// Blocked elimination of the AUGMENTED gate matrix held as tiles in registers + the chi2 statistic.
 //
-// Round 5: the right-hand sides [r | H_f] are four extra ROWS / COLUMNS of the matrix instead of a tile column of their own,
+// Round 5: the right-hand sides [r | H_f] are four extra ROWS / COLUMNS of the matrix instead of a tile column of their own.
+// Round 6: no square roots and no solved right-hand sides — a block L D L^T (diag_tile_ldl_blk, k_feat.h) of
 //
-//        M = [ S0    R ]      S0 = Y Y^T + s^2 I (n x n),  R = [r | H_f] (n x 4),  beta = 1 + |R|_F^2 / s^2 (k_feat_vt: tq[8 f + 7])
-//            [ R^T   beta I ]
+//        M = [ S0    R ]      S0 = Y Y^T + s^2 I (n x n),  R = [r | H_f] (n x 4) in the columns n4 .. n4+3, n4 = n rounded up to a multiple
+//            [ R^T   0 ]      of 4 (the rows n .. n4-1: identity; the 4 x 4 blocks of the elimination never mix rows of S0 with rows of R)
 //
-// M = U^T U has U_12 = U_11^-T R — the solved right-hand sides y_r, Y_f the statistic needs — in columns n .. n+3 of the rows < n,
-// whatever stands below (beta only has to keep the pivots n .. n+3 that share the last diagonal tile positive: R^T S0^-1 R <= R^T R / s^2).
-// A track of m observations takes ceil((2 m + 4) / 16) tile rows and the upper triangle alone: 28 tiles at m = 50 (35 with the
-// right-hand-side column), 36 at m = 60 (44) — 9 accumulator tiles per wavefront in the 4-wavefront shape instead of 11, a quarter
-// fewer matrix instructions in the factorisation, and no tile that is three quarters padding.
+// whose Schur complement with respect to S0 IS the statistic's ingredients:  C = -R^T S0^-1 R  (4 x 4),
+//        chi2 = r^T S0^-1 r - g^T G^-1 g,   r^T S0^-1 r = -C_00,  g = -C_0,1:3 (H_f^T S0^-1 r),  G = -C_1:3,1:3 (H_f^T S0^-1 H_f)
+// (the nullspace projection of UpdaterHelper.cpp:426-454 as a Schur complement, as before).  C starts at zero and only ever takes the
+// products -Y_k^T X_k: nothing is subtracted from a large diagonal.  Per tile row k: the owner of the diagonal tile eliminates it
+// (E = L^-1 and F = D^-1 L^-1 fall out), every panel tile takes Y_kj = E S_kj and X_kj = F S_kj (the row panel is published twice), the
+// trailing tiles S_ij -= Y_ki^T X_kj = S_ki^T S_kk^-1 S_kj.  When the augmented rows share the last tile of S0 (n4 not a multiple of 16),
+// that tile's own elimination — its leading (n4 mod 16) / 4 blocks — completes C in the chain wavefront's registers and the last step has
+// no panel; otherwise C is the corner of the tile (NT, NT).
+// A track of m observations takes ceil((2 m + 4) / 16) tile rows (n4 + 4 and n + 4 round to the same count for every even n) and the
+// upper triangle alone: 28 tiles at m = 50, 36 at m = 60.
 //
-// acc / tij: this wavefront's tiles; panel: NTA tiles of LDS; st0 / st1: 2 x 256 doubles.  NT = tile rows that hold rows of S0
-// (only those are factored).  Returns chi2 in lane 0 of wavefront 0 (other lanes: undefined); ends with the workgroup synchronised.
+// acc / tij: this wavefront's tiles; panel: 2 x nta_max tiles of LDS (Y, then X); st0: 128 doubles, stE / stF: 256 each; slot: one double.
+// NT = tile rows that hold rows of S0, NTA = tile rows of M.  Returns chi2 in every lane; ends with the workgroup synchronised.
 // ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double gate_corner_chi2(const d4 &t, int q, int coff) { // C = rows 4 q .. 4 q + 3, columns coff .. coff + 3 of the tile (q, coff wave-uniform)
+  double v = t[0];
+#pragma unroll
+  for (int u = 1; u < 4; u++) v = q == u ? t[u] : v;
+  const double c00 = bcast_lane(v, coff), c01 = bcast_lane(v, coff + 1), c02 = bcast_lane(v, coff + 2), c03 = bcast_lane(v, coff + 3);
+  const double c11 = bcast_lane(v, 16 + coff + 1), c12 = bcast_lane(v, 16 + coff + 2), c13 = bcast_lane(v, 16 + coff + 3);
+  const double c22 = bcast_lane(v, 32 + coff + 2), c23 = bcast_lane(v, 32 + coff + 3), c33 = bcast_lane(v, 48 + coff + 3);
+  const M3 Gm{-c11, -c12, -c13, -c12, -c22, -c23, -c13, -c23, -c33};
+  const V3 gv{-c01, -c02, -c03};
+  const V3 x = colpiv_qr_solve3(Gm, gv);
+  return -c00 - dot(gv, x);
+}
 template <int NW, int TPW>
-__device__ __forceinline__ double gate_cholesky_chi2(d4 (&acc)[TPW], const int (&tij)[TPW], int NT, int n, double *panel, double *st0, double *st1, double *rhs,
-                                                     int lane, int wv) {
+__device__ __forceinline__ double gate_ldl_chi2(d4 (&acc)[TPW], const int (&tij)[TPW], int NT, int NTA, int n, double *panel, double *panelx, double *st0, double *stE,
+                                                double *stF, double *slot, int lane, int wv) {
   const int g = lane >> 4, cl = lane & 15;
+  const int n4 = (n + 3) & ~3;
+  const bool shared = NTA == NT; // the augmented rows share S0's last tile
 #define TI(s) (tij[s] & 255)
 #define TJ(s) (tij[s] >> 8)
   for (int k = 0; k < NT; k++) {
-    { // (1) the owner of the diagonal tile factors it and publishes U_kk^-1
+    const bool last = shared && k == NT - 1;
+    { // (1) the owner of the diagonal tile eliminates it and publishes E, F
       const int tkk = k * (k + 1) / 2 + k;
       if (tkk % NW == wv) {
         const int slot_t = tkk / NW;
@@ -380,47 +401,48 @@ __device__ __forceinline__ double gate_cholesky_chi2(d4 (&acc)[TPW], const int (
 #pragma unroll
         for (int s = 0; s < TPW; s++)
           if (s == slot_t) av = acc[s];
-        d4 ev;
-        // the step's critical path: three wavefronts of this workgroup wait at the barrier below, the wavefronts of the CU's OTHER workgroups
-        // on this SIMD do not — the chain goes first whenever it has an instruction ready
-        // (measured, same box: 4-wavefront shape, two workgroups per CU: stage 0.4189 -> 0.4141 ms at configs[2]; the 8-wavefront shapes
-        // have the CU to themselves and do not move, 6.480 / 6.493 ms at configs[3]: not applied there)
+        d4 ev, fv;
+        // the step's critical path: the other wavefronts of this workgroup wait at the barrier below, the wavefronts of the CU's OTHER workgroups
+        // on this SIMD do not — the chain goes first whenever it has an instruction ready (round 4: stage 0.4189 -> 0.4141 ms at configs[2];
+        // the 8-wavefront shapes have the CU to themselves and do not move)
         if (NW == 4) __builtin_amdgcn_s_setprio(3);
-        (void)diag_tile_factor_blk(av, ev, st0, lane, nullptr, 0.0, 16);
+        const int nblk = min(4, (n4 - 16 * k) >> 2);
+        diag_tile_ldl_blk(av, ev, fv, st0, lane, nblk);
+        if (last) *slot = gate_corner_chi2(av, nblk, 4 * nblk);
+        else {
 #pragma unroll
-        for (int q = 0; q < 4; q++) st1[cl * 16 + g + 4 * q] = ev[q]; // U^-T in accumulator layout -> U^-1 row-major
-        if (k == NT - 1) { // the last tile of S0 holds augmented columns: its U is read below
-#pragma unroll
-          for (int s = 0; s < TPW; s++)
-            if (s == slot_t) acc[s] = av;
+          for (int q = 0; q < 4; q++) stE[cl * 16 + g + 4 * q] = ev[q], stF[cl * 16 + g + 4 * q] = fv[q]; // accumulator layout -> the A operand's order
         }
         if (NW == 4) __builtin_amdgcn_s_setprio(0);
       }
     }
+    if (last) break;
     lds_barrier();
-    { // (2) row panel: W_kj = U_kk^-T S_kj, published for the trailing update
-      double ua[4];
+    { // (2) row panel: Y_kj = E S_kj, X_kj = F S_kj, published for the trailing update
+      double ea[4], fa[4];
 #pragma unroll
-      for (int u = 0; u < 4; u++) ua[u] = st1[(4 * u + g) * 16 + cl];
+      for (int u = 0; u < 4; u++) ea[u] = stE[(4 * u + g) * 16 + cl], fa[u] = stF[(4 * u + g) * 16 + cl];
 #pragma unroll
       for (int s = 0; s < TPW; s++) {
         if (tij[s] >= 0 && TI(s) == k && TJ(s) > k) {
-          d4 w = {0.0, 0.0, 0.0, 0.0};
+          d4 y = {0.0, 0.0, 0.0, 0.0}, x = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-          for (int u = 0; u < 4; u++) FEAT_MFMA(ua[u], acc[s][u], w);
-          acc[s] = w;
-          double *pt = panel + (size_t)TJ(s) * 256;
+          for (int u = 0; u < 4; u++) {
+            FEAT_MFMA(ea[u], acc[s][u], y);
+            FEAT_MFMA(fa[u], acc[s][u], x);
+          }
+          double *py = panel + (size_t)TJ(s) * 256, *px = panelx + (size_t)TJ(s) * 256;
 #pragma unroll
-          for (int q = 0; q < 4; q++) pt[(g + 4 * q) * 16 + cl] = w[q];
+          for (int q = 0; q < 4; q++) py[(g + 4 * q) * 16 + cl] = y[q], px[(g + 4 * q) * 16 + cl] = x[q];
         }
       }
     }
     lds_barrier();
-    // (3) trailing update S_ij -= W_ki^T W_kj, k < i <= j (the tile row behind S0's last, if any, is never factored: not updated)
+    // (3) trailing update S_ij -= Y_ki^T X_kj, k < i <= j (the corner tile (NT, NT) of the augmented rows included)
 #pragma unroll
     for (int s = 0; s < TPW; s++) {
-      if (tij[s] >= 0 && TI(s) > k && TI(s) < NT) {
-        const double *pi = panel + (size_t)TI(s) * 256, *pj = panel + (size_t)TJ(s) * 256;
+      if (tij[s] >= 0 && TI(s) > k) {
+        const double *pi = panel + (size_t)TI(s) * 256, *pj = panelx + (size_t)TJ(s) * 256;
         double a[4], b[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) a[u] = -pi[(4 * u + g) * 16 + cl], b[u] = pj[(4 * u + g) * 16 + cl];
@@ -428,44 +450,24 @@ __device__ __forceinline__ double gate_cholesky_chi2(d4 (&acc)[TPW], const int (
         for (int u = 0; u < 4; u++) FEAT_MFMA(a[u], b[u], acc[s]);
       }
     }
-    // no barrier here: the next step's factorisation touches st0 / st1 only, and its panel writes come after its first barrier
+    // no barrier here: the next step's elimination touches st0 / stE / stF only (their readers are behind the second barrier), and its
+    // panel writes come after its first barrier
   }
-  // chi2 = |y_r|^2 - g^T G^-1 g,  y_r = U^-T r, Y_f = U^-T H_f: columns n .. n+3 of U, rows < n
+  if (!shared) { // C = the corner of the tile (NT, NT)
+    const int tc = NT * (NT + 1) / 2 + NT;
+    if (tc % NW == wv) {
+      const int slot_t = tc / NW;
+      d4 av = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-  for (int s = 0; s < TPW; s++) {
-    if (tij[s] >= 0 && TI(s) < NT) {
-      const int c = 16 * TJ(s) + cl - n;
-      if (c >= 0 && c < 4) {
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-          const int a = 16 * TI(s) + g + 4 * q;
-          if (a < n) rhs[(size_t)a * 4 + c] = acc[s][q];
-        }
-      }
+      for (int s = 0; s < TPW; s++)
+        if (s == slot_t) av = acc[s];
+      *slot = gate_corner_chi2(av, 0, 0);
     }
   }
   lds_barrier();
-  double chi2 = 0.0;
-  if (wv == 0) {
-    double a = 0, G00 = 0, G01 = 0, G02 = 0, G11 = 0, G12 = 0, G22 = 0, g0 = 0, g1 = 0, g2 = 0;
-    for (int j = lane; j < n; j += 64) {
-      const double yr = rhs[4 * j], y0 = rhs[4 * j + 1], y1 = rhs[4 * j + 2], y2 = rhs[4 * j + 3];
-      a = fma(yr, yr, a);
-      G00 = fma(y0, y0, G00), G01 = fma(y0, y1, G01), G02 = fma(y0, y2, G02);
-      G11 = fma(y1, y1, G11), G12 = fma(y1, y2, G12), G22 = fma(y2, y2, G22);
-      g0 = fma(y0, yr, g0), g1 = fma(y1, yr, g1), g2 = fma(y2, yr, g2);
-    }
-    a = wave_sum(a);
-    G00 = wave_sum(G00), G01 = wave_sum(G01), G02 = wave_sum(G02), G11 = wave_sum(G11), G12 = wave_sum(G12), G22 = wave_sum(G22);
-    g0 = wave_sum(g0), g1 = wave_sum(g1), g2 = wave_sum(g2);
-    const M3 Gm{G00, G01, G02, G01, G11, G12, G02, G12, G22};
-    const V3 gv{g0, g1, g2};
-    const V3 x = colpiv_qr_solve3(Gm, gv);
-    chi2 = a - dot(gv, x);
-  }
 #undef TI
 #undef TJ
-  return chi2;
+  return *slot;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -499,11 +501,12 @@ __global__ void __launch_bounds__(64 * NW, OCC)
   const int D = p.D, LD = p.LD, RS = p.row_stride;
   const FeatYLds lo = featy_lds_layout(nt_max, nta_max, NW, CB);
   double *Yb = reinterpret_cast<double *>(smem + lo.yb);
-  double *panel = Yb;                                   // the Cholesky's row panel takes the block's place once the gate matrix is complete
-  double *rhs = Yb + (size_t)nta_max * 256;             // ... and the solved right-hand sides sit behind it
+  double *panel = Yb;                                   // the gate's row panel takes the block's place once the gate matrix is complete:
+  double *panelx = Yb + (size_t)nta_max * 256;          // Y_kj, and X_kj = D^-1 Y_kj behind it
   double *Vl = reinterpret_cast<double *>(smem + lo.vl); // [16 nt_max][3] reflectors
   double *wpart = reinterpret_cast<double *>(smem + lo.wpart);
-  double *st0 = wpart, *st1 = wpart + 256;
+  double *st0 = wpart, *stE = wpart + 128, *stF = wpart + 384;
+  double *chi2_slot = reinterpret_cast<double *>(smem + lo.misc);
   int *rowlim = reinterpret_cast<int *>(smem + lo.misc + 32 * sizeof(double));   // [nt_max] last non-zero column of each tile row
   int *sched = rowlim + nt_max;                                                  // [4]
   const double sig2 = p.opt.sigma_pix_sq;
@@ -556,7 +559,7 @@ __global__ void __launch_bounds__(64 * NW, OCC)
         j -= (j * (j + 1) / 2 > t) ? 1 : 0;
         i = t - j * (j + 1) / 2;
       }
-      tij[s] = i < 0 ? -1 : ((j << 8) | i);
+      tij[s] = __builtin_amdgcn_readfirstlane(i < 0 ? -1 : ((j << 8) | i)); // (wave-uniform: scalar registers, scalar branches)
       acc[s] = d4{0.0, 0.0, 0.0, 0.0};
     }
 #define TI(s) (tij[s] & 255)
@@ -711,8 +714,8 @@ __global__ void __launch_bounds__(64 * NW, OCC)
       FEAT_T(3)
     }
 
-    // ------------------------------------------------------------------ M = [Y Y^T + s^2 I, R; R^T, beta I] (identity on the padding), R = [r | H_f]
-    const double beta = tqG[(size_t)8 * f + 7];
+    // ------------------------------------------------------------------ M = [Y Y^T + s^2 I, R; R^T, 0], R = [r | H_f] in the columns n4 .. n4 + 3 (identity on the padding)
+    const int n4 = (n + 3) & ~3;
 #pragma unroll
     for (int s = 0; s < TPW; s++) {
       if (tij[s] < 0 || skip_gate) continue;
@@ -726,10 +729,10 @@ __global__ void __launch_bounds__(64 * NW, OCC)
         for (int q = 0; q < 4; q++) {
           const int a = 16 * TI(s) + go + 4 * q;
           double v = acc[s][q];
-          if (a == b) v = a < n ? v + sig2 : (a < n + 4 ? beta : 1.0);
-          else if (a < n && b >= n && b < n + 4) {
+          if (a == b) v = a < n ? v + sig2 : ((a >= n4 && a < n4 + 4) ? 0.0 : 1.0);
+          else if (a < n && b >= n4 && b < n4 + 4) {
             const double *rd = frow + (size_t)(a >> 1) * RS;
-            v = b == n ? rd[RO_RES + (a & 1)] : rd[RO_HF + 3 * (a & 1) + b - n - 1];
+            v = b == n4 ? rd[RO_RES + (a & 1)] : rd[RO_HF + 3 * (a & 1) + b - n4 - 1];
           }
           acc[s][q] = v;
         }
@@ -741,7 +744,7 @@ __global__ void __launch_bounds__(64 * NW, OCC)
     }
     FEAT_T(4)
     // a feature passed by the bound reports the BOUND as its statistic (>= the reference's chi2, <= the threshold; include/ovgpu.h)
-    const double chi2 = skip_gate ? bound : ((FY_SKIP(p) & 8) ? 0.0 : gate_cholesky_chi2<NW, TPW>(acc, tij, NT, n, panel, st0, st1, rhs, lane, wv));
+    const double chi2 = skip_gate ? bound : ((FY_SKIP(p) & 8) ? 0.0 : gate_ldl_chi2<NW, TPW>(acc, tij, NT, NTA, n, panel, panelx, st0, stE, stF, chi2_slot, lane, wv));
     if (wv == 0 && lane == 0) {
       if (skip_gate && p.rows_used) atomicAdd(p.rows_used + 1, 1);
       p.chi2[f] = chi2;
