@@ -111,6 +111,7 @@ template <int SRC> __device__ __forceinline__ double ld_c_val(const CholParams &
 __device__ __forceinline__ bool chol_skipped(const CholParams &p) { return (p.pred && *p.pred == 0) || (p.pred_not && *p.pred_not != 0); }
 
 constexpr int CH_FW = 15;  // tile wavefronts of the factor workgroup (wavefront 15 runs the diagonal chain and holds no tiles)
+__host__ __device__ inline int chol_tile_waves(int tile_rows) { return tile_rows <= 13 ? 12 : CH_FW; } // (see chol_factor_block: 13 tile rows = 12 pairs + 66 far tiles in 7 x 12 slots)
 
 // ---------------------------------------------------------------------------------------------------
 // chol_factor_block (block 0 of k_chol_fused): the factorisation WITHOUT workgroup barriers in the step loop.  (k_chol_factor, its round-2 form with three
@@ -151,6 +152,15 @@ __device__ __forceinline__ void chol_factor_block(const CholParams &p, double *f
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, cl = lane & 15;
   const int D = p.D, LA = p.LA, TM = (D + 15) >> 4;
+  // Round 6: up to 13 tile rows (208 columns: configs[1], configs[2]) TWELVE tile wavefronts hold the triangle and the three that share the chain
+  // wavefront's SIMD leave at once.  Wavefronts go to the SIMDs round-robin (HW_ID of a 16-wavefront workgroup: 2, 1, 3, 0, 2, 1, 3, 0, ..), so the
+  // chain (wavefront 15) sat with the tile wavefronts 3, 7 and 11, and every instruction of its dependent sequence queued behind their 64-cycle
+  // matrix instructions: 7.6 kcycles per diagonal tile against 3.2 alone, 5.5 per pair against ~1 (tools/dev_chol_phases.py,
+  // profiles/r06_b_diagonal_tile_probe.txt).  The tile wavefronts were waiting for the chain half of their time: a quarter more tiles each is free.
+  // fw = chol_tile_waves(TM) tile wavefronts, numbered lw = 0 .. fw - 1; p.n_arrive (what the followers count to) is the same number.
+  const int fw = chol_tile_waves(TM);
+  const bool lean = fw < CH_FW;
+  const int lw = lean ? wv - (wv >> 2) : wv;
   int *cov = sync + 128; // [16 CH_TMAX] CH_SRC_PRIOR: col_cov (the gathers below take their indices from here)
   int cv = 0;
   if (p.src == CH_SRC_PRIOR && tid < D) cv = p.col_cov[tid]; // in flight next to the predicate words
@@ -159,6 +169,7 @@ __device__ __forceinline__ void chol_factor_block(const CholParams &p, double *f
   if (tid < 16 * CH_TMAX) cov[tid] = cv;
   const double *diag0 = p.src == CH_SRC_PRIOR ? d0s : p.diag0;
   __syncthreads();
+  if (lean && wv != CH_FW && (wv & 3) == 3) return; // the chain's SIMD is the chain's
   auto st_dev = [](double *ptr, double v) { __hip_atomic_store(ptr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
   auto arrive = [&](int k) { // this wavefront's stores of row k are complete
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -215,12 +226,12 @@ __device__ __forceinline__ void chol_factor_block(const CholParams &p, double *f
       const long long c1 = OVG_CHOL_CLOCK();
       // the three words this step's hand-overs depend on — read NOW, checked behind the factorisation: all three are long satisfied in a
       // running pipeline, and a poll is an LDS round trip on the one path nothing hides
-      const int f_bufs = k >= 3 ? lds_ld(32 + k - 3) : CH_FW, f_pair = lds_ld(0), f_panel = k >= 2 ? lds_ld(32 + k - 2) : CH_FW;
+      const int f_bufs = k >= 3 ? lds_ld(32 + k - 3) : fw, f_pair = lds_ld(0), f_panel = k >= 2 ? lds_ld(32 + k - 2) : fw;
       const bool bad = feat::diag_tile_factor_blk(sv, ev, st0, lane, diag0 ? diag0 + 16 * k : nullptr, p.pivot_tol, D - 16 * k);
       const long long c2 = OVG_CHOL_CLOCK();
       c_fact += c2 - c1;
       if (bad && lane == 0) __hip_atomic_store(p.flags, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (f_bufs < CH_FW && !wait_for(32 + k - 3, CH_FW)) return; // the buffers of step k - 3 are free
+      if (f_bufs < fw && !wait_for(32 + k - 3, fw)) return; // the buffers of step k - 3 are free
       double *s1 = st1 + (k % 3) * 256, *sk = su + (k % 3) * 256;
 #pragma unroll
       for (int q = 0; q < 4; q++) s1[cl * 16 + g + 4 * q] = ev[q], sk[(g + 4 * q) * 16 + cl] = sv[q]; // U^-T in accumulator layout -> U^-1 row-major; U_kk
@@ -245,7 +256,7 @@ __device__ __forceinline__ void chol_factor_block(const CholParams &p, double *f
       for (int u = 0; u < 4; u++) FEAT_MFMA(ua[u], sp[u], w);
 #pragma unroll
       for (int u = 0; u < 4; u++) FEAT_MFMA(-w[u], w[u], sv); // S_k+1,k+1 -= W^T W: lane (g, cl) holds W[4u + g][cl] in w[u]
-      if (f_panel < CH_FW && !wait_for(32 + k - 2, CH_FW)) return; // every wavefront is done with row panel k - 2: its buffer is free
+      if (f_panel < fw && !wait_for(32 + k - 2, fw)) return; // every wavefront is done with row panel k - 2: its buffer is free
       double *pt = panel + ((size_t)(k & 1) * CH_TMAX + (k + 1)) * 256;
 #pragma unroll
       for (int q = 0; q < 4; q++) pt[(g + 4 * q) * 16 + cl] = w[q];
@@ -265,13 +276,13 @@ __device__ __forceinline__ void chol_factor_block(const CholParams &p, double *f
   for (int s = 0; s < CH_F2_SLOTS; s++) {
     int i = -1, j = 0;
     if (s == 0) {
-      if (wv + 1 < TM) i = wv, j = wv + 1;
+      if (lw + 1 < TM) i = lw, j = lw + 1;
     } else if (s == 1) {
-      if (wv + 1 < TM) i = wv + 1, j = wv + 1;
+      if (lw + 1 < TM) i = lw + 1, j = lw + 1;
     } else if (s == 9) {
-      if (wv == 0) i = 0, j = 0;
-    } else { // far tile number f = (s - 2) CH_FW + wv, column by column: column j >= 2 holds rows 0 .. j-2, i.e. columns 2 .. j-1 hold (j-1)(j-2)/2 tiles
-      const int f = (s - 2) * CH_FW + wv;
+      if (lw == 0) i = 0, j = 0;
+    } else { // far tile number f = (s - 2) fw + lw, column by column: column j >= 2 holds rows 0 .. j-2, i.e. columns 2 .. j-1 hold (j-1)(j-2)/2 tiles
+      const int f = (s - 2) * fw + lw;
       int m = (int)((1.f + sqrtf(1.f + 8.f * (float)f)) * 0.5f); // the largest m with m (m - 1) / 2 <= f (closed form: seven search loops cost every wavefront 4 kcycles at start-up)
       m += ((m + 1) * m / 2 <= f) ? 1 : 0;
       m -= (m * (m - 1) / 2 > f) ? 1 : 0;
@@ -314,7 +325,7 @@ __device__ __forceinline__ void chol_factor_block(const CholParams &p, double *f
     for (int q = 0; q < 4; q++) hp[(g + 4 * q) * 16 + cl] = acc[0][q], hp[256 + (g + 4 * q) * 16 + cl] = acc[1][q];
     publish(0, k + 2);
   };
-  if (wv == 0) {
+  if (lw == 0) {
     const long long s_issued = OVG_CHOL_CLOCK();
 #pragma unroll
     for (int q = 0; q < 4; q++) st0[(g + 4 * q) * 16 + cl] = acc[9][q];
@@ -374,17 +385,17 @@ __device__ __forceinline__ void chol_factor_block(const CholParams &p, double *f
   // row kk of U, U_kk and U_kk^-1 -> memory, by their LDS copies; then this wavefront is done with step kk's buffers
   auto row_to_memory = [&](int kk) {
     const double *pn = panel + (size_t)(kk & 1) * CH_TMAX * 256;
-    if (wv == kk && kk + 1 < TM) store_row_tile(kk, kk + 1, pn + (size_t)(kk + 1) * 256, true);
+    if (lw == kk && kk + 1 < TM) store_row_tile(kk, kk + 1, pn + (size_t)(kk + 1) * 256, true);
     // this wavefront's far tiles of row kk, found by arithmetic instead of by walking its (unrolled) slots: ONE copy of the store code
     // and no hoisted address per slot (unrolled seven times the addresses of all copies were computed up front and spilled — 244 bytes
     // of scratch whose reloads wait on vmcnt(0), i.e. on the very stores this path must never wait for)
 #pragma unroll 1
     for (int j = kk + 2; j < TM; j++) {
       const int f = (j - 1) * (j - 2) / 2 + kk; // far tile number of (kk, j): column j >= 2 holds rows 0 .. j-2
-      if (f % CH_FW == wv) store_row_tile(kk, j, pn + (size_t)j * 256, true);
+      if (f % fw == lw) store_row_tile(kk, j, pn + (size_t)j * 256, true);
     }
-    if (wv == (kk + 5) % CH_FW) store_row_tile(kk, kk, su + (kk % 3) * 256, false); // U_kk -> Y and L
-    if (wv == (kk + 10) % CH_FW) {                                                 // U_kk^-1 -> memory for the followers
+    if (lw == (kk + 5) % fw) store_row_tile(kk, kk, su + (kk % 3) * 256, false); // U_kk -> Y and L
+    if (lw == (kk + 10) % fw) {                                                 // U_kk^-1 -> memory for the followers
       const double *s1 = st1 + (kk % 3) * 256;
       double e4[4];
 #pragma unroll
@@ -414,7 +425,7 @@ __device__ __forceinline__ void chol_factor_block(const CholParams &p, double *f
       for (int u = 0; u < 4; u++) ua[u] = s1[(4 * u + g) * 16 + cl];
     }
     // (b) this wavefront's tiles of row k right of the pair's (k, k+1), which the chain wavefront solves
-    if (k >= 2 && !wait_for(32 + k - 2, CH_FW)) return; // every wavefront is done with row panel k - 2 (long satisfied): its buffer is free
+    if (k >= 2 && !wait_for(32 + k - 2, fw)) return; // every wavefront is done with row panel k - 2 (long satisfied): its buffer is free
 #pragma unroll
     for (int s = 2; s < 9; s++) {
       if (tij[s] >= 0 && CTI(s) == k) {
@@ -436,12 +447,12 @@ __device__ __forceinline__ void chol_factor_block(const CholParams &p, double *f
     if (!wait_for(16 + k, TM - 1 - k)) return;
     const long long t4 = OVG_CHOL_CLOCK();
     t_cnt += t4 - t3;
-    // (c) trailing update S_ij -= W_ki^T W_kj of this wavefront's tiles below row k.  Its pair comes first (slots 0, 1: the tiles (wv, wv+1) and
-    //     (wv+1, wv+1) take their updates of the steps k < wv here; step wv's update of (wv+1, wv+1) is the chain wavefront's, from registers) and
+    // (c) trailing update S_ij -= W_ki^T W_kj of this wavefront's tiles below row k.  Its pair comes first (slots 0, 1: the tiles (lw, lw+1) and
+    //     (lw+1, lw+1) take their updates of the steps k < lw here; step lw's update of (lw+1, lw+1) is the chain wavefront's, from registers) and
     //     leaves for the chain wavefront with its last one, a whole step before it is needed
 #pragma unroll
     for (int s = 0; s < 9; s++) {
-      if (tij[s] >= 0 && CTI(s) > k && !(s == 1 && wv == k)) {
+      if (tij[s] >= 0 && CTI(s) > k && !(s == 1 && lw == k)) {
         const double *pi = pan + (size_t)CTI(s) * 256, *pj = pan + (size_t)CTJ(s) * 256;
         double a[4], b[4];
 #pragma unroll
@@ -449,7 +460,7 @@ __device__ __forceinline__ void chol_factor_block(const CholParams &p, double *f
 #pragma unroll
         for (int u = 0; u < 4; u++) FEAT_MFMA(a[u], b[u], acc[s]);
       }
-      if (s == 1 && wv == k + 1 && tij[0] >= 0) deposit_pair(k + 1);
+      if (s == 1 && lw == k + 1 && tij[0] >= 0) deposit_pair(k + 1);
     }
     const long long t5 = OVG_CHOL_CLOCK();
     t_trail += t5 - t4;
@@ -460,8 +471,8 @@ __device__ __forceinline__ void chol_factor_block(const CholParams &p, double *f
     t_st += OVG_CHOL_CLOCK() - t5;
   }
   arrive(TM - 1);
-  if (OVG_CHOL_DBG(p) && lane == 0 && (wv == 1 || wv == 7)) {
-    long long *d = p.dbg + (wv == 1 ? 320 : 330);
+  if (OVG_CHOL_DBG(p) && lane == 0 && (lw == 1 || lw == 7)) {
+    long long *d = p.dbg + (lw == 1 ? 320 : 330);
     d[0] += OVG_CHOL_CLOCK() - t_begin, d[1] += t_uinv, d[2] += t_st, d[3] += t_panel, d[4] += t_cnt, d[5] += t_trail, d[6] += 1;
   }
 #undef CTI

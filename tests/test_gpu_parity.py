@@ -191,8 +191,10 @@ def test_block_row_gate_equals_the_one_pass_gate(Updater, kw):
     """k_feat_y_big (k_featy_big.h) on batches the one-pass kernel holds: with the same tile budget (one pass) and with 5 tiles per
     wavefront (2 .. 5 passes over 8 .. 15 tile rows).  A tile of the gate matrix receives the same updates in the same order
     whatever the pass structure, so chi2 is BIT-identical between the two block-row shapes; the stacked rows differ in the
-    summation order of V^T Y only.  Against the one-pass kernel the statistic agrees to rounding (round 5: that kernel carries the
-    right-hand sides [r | H_f] as four augmented ROWS of the gate matrix, the block-row kernel as a tile column of their own)."""
+    summation order of V^T Y only.  Against the one-pass kernel the statistic agrees to rounding of a DIFFERENT elimination (round 5: that
+    kernel carries the right-hand sides [r | H_f] as four augmented ROWS of the gate matrix, the block-row kernel as a tile column of their own;
+    round 6: it eliminates by 4 x 4 blocks without square roots — block L D L^T, k_feat.h — where the block-row kernel keeps the Cholesky
+    form): 1e-9 relative, an order below the suite's own chi2 tolerance against the oracle."""
     kw = dict(kw)
     prob = synth.make_problem(kw.pop("cfg", 2), **kw)
     opts = capi.default_options(chi2_multipler=1.0, gate_always_factor=1)  # the test is about the gate's pass structure
@@ -209,7 +211,7 @@ def test_block_row_gate_equals_the_one_pass_gate(Updater, kw):
     assert np.array_equal(outs[1]["chi2"][gate], outs[2]["chi2"][gate])
     for out in outs[1:]:
         assert np.array_equal(out["feat_status"], ref["feat_status"])
-        np.testing.assert_allclose(out["chi2"][gate], ref["chi2"][gate], rtol=1e-11)
+        np.testing.assert_allclose(out["chi2"][gate], ref["chi2"][gate], rtol=1e-9)
         assert out["stats"]["n_rows"] == ref["stats"]["n_rows"]
         assert _rel(out["dx"], ref["dx"]) < 1e-10
         assert _rel(out["P"], ref["P"]) < 1e-11

@@ -11,7 +11,25 @@ template <int VAR> __global__ void __launch_bounds__(1024) k_probe(const double 
   __shared__ double sh[16][128];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, g = lane >> 4, cl = lane & 15;
   if (wv > 0) { // neighbours: matrix instructions until wave 0 is done
-    if (wv <= busy_waves) {
+    if (busy_waves >= 100 && wv <= busy_waves % 100) { // neighbours that poll an LDS word (s_sleep between polls: 100..) or read LDS back to back (200..)
+      __shared__ int word;
+      __shared__ double blk[2048];
+      double sum = 0;
+      while (__hip_atomic_load(cyc + 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+        if (busy_waves < 200) {
+          for (int i = 0; i < 64; i++) {
+            if (__hip_atomic_load(&word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 12345) sum += 1;
+            __builtin_amdgcn_s_sleep(1);
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < 16; i++) sum += blk[(lane * 17 + i * 64) & 2047];
+        }
+      }
+      if (sum == 12345.678) out[1000 + threadIdx.x] = sum;
+      return;
+    }
+    if (busy_waves < 100 && wv <= busy_waves) {
       d4 acc = {0, 0, 0, 0};
       double a = 1.0 + lane * 1e-3;
       while (__hip_atomic_load(cyc + 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
@@ -51,7 +69,7 @@ int main() {
   long long *dc;
   hipMalloc(&dS, 256 * 8), hipMalloc(&dout, 4096 * 8), hipMalloc(&dc, 16 * 8);
   hipMemcpy(dS, S.data(), 256 * 8, hipMemcpyHostToDevice);
-  for (int busy : {0, 3, 15}) {
+  for (int busy : {0, 3, 15, 112, 115, 212, 215}) {
     long long c[16];
     std::vector<double> o(4096);
     for (int var = 0; var < 3; var++) {
