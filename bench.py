@@ -194,7 +194,8 @@ def main(argv=None):
             try:
                 up.comm_init(dist, device)
             except Exception as e:  # noqa: BLE001
-                print(f"[bench rank {rank}] native RCCL exchange unavailable ({e}); host-driven exchange instead", file=sys.stderr, flush=True)
+                sys.stderr.write(f"[bench rank {rank}] native RCCL exchange unavailable ({e}); host-driven exchange instead\n")
+                sys.stderr.flush()
                 native = False
             ok = torch.tensor([1 if native else 0], dtype=torch.int32, device=device)
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
@@ -265,7 +266,8 @@ def main(argv=None):
         preflight = {"ranks": every, "exchange_bytes": gram_bytes, "modelled_all_reduce_ms": t_ar,
                      "predicted_ms": (max(locals_ms) + t_ar) if all(x is not None for x in locals_ms) else None}
         if rank == 0:
-            print("[bench preflight] " + json.dumps(preflight), file=sys.stderr, flush=True)
+            sys.stderr.write("[bench preflight] " + json.dumps(preflight) + "\n")  # (ONE write: the ranks share this pipe, print() writes the newline separately)
+            sys.stderr.flush()
     # the MEDIAN of the timed loops of K steps is the line's value (three loops, more until --min-timed-seconds have been timed)
     err = None
     try:

@@ -56,7 +56,7 @@ constexpr int FY_LS = 66; // row stride of the LDS block in doubles = CB + 2: 16
                           // (rows r and r + 1 of a tile are 4 banks apart: 16 lanes x 4 banks = all 64)
 
 struct FeatYLds {
-  size_t yb, vl, wpart, misc, total;
+  size_t yb, vl, wpart, misc, raw, total;
 };
 // nt_max = tile rows of the longest track; nta_max = tile rows of its gate matrix (2 m + 4 rows, round 5); nw = wavefronts per workgroup; cb = columns per block
 __host__ __device__ inline FeatYLds featy_lds_layout(int nt_max, int nta_max, int nw, int cb) {
@@ -76,6 +76,7 @@ __host__ __device__ inline FeatYLds featy_lds_layout(int nt_max, int nta_max, in
   const size_t wp = (size_t)nw * 3 * cb * sizeof(double), stage = (128 + 2 * 256) * sizeof(double);
   L.wpart = take(wp > stage ? wp : stage); // V^T Y partial sums per wavefront; afterwards the gate's diagonal-tile stage: scratch, E, F
   L.misc = take(32 * sizeof(double) + (size_t)(nt_max + 16) * sizeof(int)); // V^T r partials per wavefront, then rowlim / sched
+  L.raw = take((size_t)(RAW_MAXCLS + 1) * 16 + 64 + (size_t)RAW_MAXCLS * 16 + 16);    // the unprojected stack: region table (first element, stride | residual column), then per region the feature's first measurement there and its first element
   L.total = o;
   return L;
 }
@@ -110,15 +111,29 @@ constexpr int FY_IOFF = 8;
 // feature's tile rows, built behind that until round 5, depend on the batch alone: k_batch_layout below, once per batch.)
 template <bool F32OUT>
 __device__ __forceinline__ void vt_residual_column(const SysParams &p, int64_t orow0, const double *V, const double *res, int n, int lane, double z0, double z1,
-                                                    double z2, double &sumsq) {
+                                                    double z2, double &sumsq, bool store = true) {
   const StackRows<F32OUT> out(p, orow0);
   double sq = 0.0;
   for (int r = 3 + lane; r < n; r += 64) {
     const double rp = res[r] - (V[3 * r] * z0 + V[3 * r + 1] * z1 + V[3 * r + 2] * z2);
-    out.put(r - 3, p.D, rp);
+    if (store) out.put(r - 3, p.D, rp);
     sq = fma(rp, rp, sq);
   }
   sumsq = wave_sum(sq);
+}
+__device__ __forceinline__ int64_t uniform_i64(int64_t v) { // a wave-uniform value into scalar registers (a row's first element: the stores then take a scalar base + the lane's column)
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)(uint64_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)v >> 32));
+  return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+// first element of the rows of the measurement whose region word is d (RawStack), its stride and residual column (kernel-argument tables: compile-time indices only)
+__device__ __forceinline__ void raw_region_of(const RawStack &rw, int d, int64_t &off, int &ld, int &rcol) {
+  const int k = d >> RAW_CLS_SHIFT;
+  int64_t base = rw.base[0];
+  ld = rw.ld[0], rcol = rw.rcol[0];
+#pragma unroll
+  for (int q = 1; q < RAW_MAXCLS; q++)
+    if (k == q) base = rw.base[q], ld = rw.ld[q], rcol = rw.rcol[q];
+  off = base + (int64_t)(d & RAW_ROW_MASK) * ld;
 }
 #ifndef OVG_TU_FEATY
 __global__ void __launch_bounds__(256) k_feat_vt(SysParams p, FeatStore st, double *__restrict__ tq) {
@@ -168,7 +183,19 @@ __global__ void __launch_bounds__(256) k_feat_vt(SysParams p, FeatStore st, doub
     const double z0 = T00 * w0, z1 = T01 * w0 + T11 * w1, z2 = T02 * w0 + T12 * w1 + T22 * w2;
     double sumsq;
     if (p.Hbig32) vt_residual_column<true>(p, p.row_off[f], V, res, n, lane, z0, z1, z2, sumsq);
-    else vt_residual_column<false>(p, p.row_off[f], V, res, n, lane, z0, z1, z2, sumsq);
+    else vt_residual_column<false>(p, p.row_off[f], V, res, n, lane, z0, z1, z2, sumsq, !p.raw.on);
+    if (p.raw.on) { // the unprojected stack: the residuals as they are, and the residual entries of the three rows the projection drops (region RAW_NEG, rows 4 f ..)
+      for (int r = lane; r < n; r += 64) {
+        int64_t off;
+        int ld, rcol;
+        raw_region_of(p.raw, p.raw.dst[m0 + (r >> 1)], off, ld, rcol);
+        p.raw.H[off + (int64_t)(r & 1) * ld + rcol] = res[r];
+      }
+      if (lane < 4) {
+        const double cr = lane < 3 && lane < n ? res[lane] - (V[3 * lane] * z0 + V[3 * lane + 1] * z1 + V[3 * lane + 2] * z2) : 0.0;
+        p.raw.H[p.raw.base[RAW_NEG] + ((int64_t)4 * f + lane) * p.raw.ld[RAW_NEG] + p.raw.rcol[RAW_NEG]] = cr;
+      }
+    }
     // S = Y Y^T + s^2 I >= s^2 I, so chi2 = r'^T S^-1 r' <= |r'|^2 / s^2: a feature whose BOUND is under its threshold passes the
     // reference's test (UpdaterMSCKF.cpp:216-225) whatever its gate matrix holds
     if (lane == 0) tq[(size_t)8 * f + 6] = sumsq / p.opt.sigma_pix_sq;
@@ -200,15 +227,19 @@ constexpr int BL_NTH = 128, BL_TR = BL_NTH / 24; // threads per feature; tile ro
 __global__ void __launch_bounds__(BL_NTH) k_batch_layout(int F, int m_max, int D, const int32_t *__restrict__ meas_offsets, const uint16_t *__restrict__ meas_cc,
                                                       const int32_t *__restrict__ clone_col, const int32_t *__restrict__ calib_col, const int32_t *__restrict__ intr_col,
                                                       int32_t *__restrict__ anchor_pre, int32_t *__restrict__ meas_feat, int32_t *__restrict__ pos, int32_t *__restrict__ inst,
-                                                      int nt_max, int cb, int C, int K) {
+                                                      int nt_max, int cb, int C, int K, const uint8_t *__restrict__ cls_of_clone, const int32_t *__restrict__ featbase,
+                                                      int32_t *__restrict__ raw_dst) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int f = blockIdx.x;
   // the column tables (a few dozen ints) go to LDS while the feature's offsets are on their way: the keys below then cost ONE global round trip
   // (the packed codes), not two — this kernel is a chain of memory latencies, nothing else
   __shared__ int tab_clone[1024], tab_calib[64], tab_intr[64];
+  __shared__ uint8_t tab_cls[1024];
   if (pos) {
     for (int i = tid; i < C; i += BL_NTH) tab_clone[i] = clone_col[i];
+    if (raw_dst)
+      for (int i = tid; i < C; i += BL_NTH) tab_cls[i] = cls_of_clone[i];
     if (tid < K) tab_calib[tid] = calib_col[tid], tab_intr[tid] = intr_col[tid];
   }
   const int m0 = meas_offsets[f], m = meas_offsets[f + 1] - m0;
@@ -271,6 +302,11 @@ __global__ void __launch_bounds__(BL_NTH) k_batch_layout(int F, int m_max, int D
 #undef OVG_RK
     }
     pos[m0 + i] = m0 + rank;
+    if (raw_dst) { // the unprojected stack (ovgpu_types.h: RawStack): region of the measurement's clone, its two rows there (featbase: the feature's first row of
+                   // the region less twice its measurements in the regions below — the ranks are clone-major, the classes ascend with the clones)
+      const int k = tab_cls[meas_cc[m0 + i] & 1023];
+      raw_dst[m0 + rank] = (k << RAW_CLS_SHIFT) | (featbase[f * RAW_MAXCLS + k] + 2 * rank);
+    }
     if (inst) {
       const int c1 = cand[i], c2 = kept[i];
       cols3[3 * rank] = mykey >> 8, cols3[3 * rank + 1] = c1, cols3[3 * rank + 2] = c2;
@@ -507,6 +543,19 @@ __global__ void __launch_bounds__(64 * NW, OCC)
   double *wpart = reinterpret_cast<double *>(smem + lo.wpart);
   double *st0 = wpart, *stE = wpart + 128, *stF = wpart + 384;
   double *chi2_slot = reinterpret_cast<double *>(smem + lo.misc);
+  // the unprojected stack of the Gram route (ovgpu_types.h: RawStack): region table, then per measurement of the feature its first element and stride | residual column << 16
+  int64_t *rawbase = reinterpret_cast<int64_t *>(smem + lo.raw);
+  int *rawld = reinterpret_cast<int *>(smem + lo.raw + (RAW_MAXCLS + 1) * 8);
+  int *clsbeg = reinterpret_cast<int *>(smem + lo.raw + (RAW_MAXCLS + 1) * 16);          // [k] the feature's first measurement (clone-major position) of region k, -1: none; [k + 8]: its row there
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
+  i32x4 *runs = reinterpret_cast<i32x4 *>(smem + lo.raw + (RAW_MAXCLS + 1) * 16 + 64); // the feature's runs of rows, last region first: (first row | one past the last << 16, stride | residual column << 16, first element lo, hi)
+  int *nruns = reinterpret_cast<int *>(smem + lo.raw + (RAW_MAXCLS + 1) * 16 + 64 + RAW_MAXCLS * 16);
+  const bool raw = !F32OUT && p.raw.on != 0;
+  if (raw) {
+#pragma unroll
+    for (int k = 0; k <= RAW_MAXCLS; k++)
+      if (tid == k) rawbase[k] = p.raw.base[k], rawld[k] = p.raw.ld[k] | (p.raw.rcol[k] << 16);
+  }
   int *rowlim = reinterpret_cast<int *>(smem + lo.misc + 32 * sizeof(double));   // [nt_max] last non-zero column of each tile row
   int *sched = rowlim + nt_max;                                                  // [4]
   const double sig2 = p.opt.sigma_pix_sq;
@@ -540,8 +589,59 @@ __global__ void __launch_bounds__(64 * NW, OCC)
     const int n_out = __builtin_amdgcn_readfirstlane(rec[3]); // 2m - 3 (0 when m < 2)
     const int64_t orow0 = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(rec[5]) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane(rec[4]));
     const StackRows<F32OUT> out(p, orow0);
+    if (raw) { // where the feature's measurements sit in the unprojected stack: clone-major positions ascend through the regions, a region's share is one run of rows
+      if (tid < RAW_MAXCLS) clsbeg[tid] = -1;
+      lds_barrier(); // (the table of the feature before is consumed: the barrier at the head of the loop)
+      if (tid < m) {
+        const int d = p.raw.dst[m0 + tid], k = d >> RAW_CLS_SHIFT, kp = tid > 0 ? (p.raw.dst[m0 + tid - 1] >> RAW_CLS_SHIFT) : -1;
+        if (k != kp) clsbeg[k] = tid, clsbeg[k + 8] = d & RAW_ROW_MASK;
+      }
+      lds_barrier();
+      if (tid == 0) { // the run list, once per feature: ONE 16-byte LDS read per run in the column blocks' store loops
+        int hi = m, nr = 0;
+#pragma unroll
+        for (int k = RAW_MAXCLS - 1; k >= 0; k--) {
+          const int lo_m = clsbeg[k];
+          if (lo_m >= 0) {
+            const int ls = rawld[k];
+            const int64_t off = rawbase[k] + (int64_t)clsbeg[k + 8] * (ls & 0xffff);
+            runs[nr++] = i32x4{(2 * lo_m) | ((2 * hi) << 16), ls, (int)(uint32_t)(uint64_t)off, (int)(uint32_t)((uint64_t)off >> 32)};
+            hi = lo_m;
+          }
+        }
+        *nruns = nr;
+      }
+      lds_barrier();
+    }
+    // the feature's runs of rows: fn(first row, one past the last, first element, stride, residual column), all in scalar registers
+    auto raw_runs = [&](auto fn) {
+      const int nr = __builtin_amdgcn_readfirstlane(*nruns);
+#pragma unroll 1
+      for (int j = 0; j < nr; j++) {
+        const i32x4 r = runs[j];
+        const int ab = __builtin_amdgcn_readfirstlane(r.x), ls = __builtin_amdgcn_readfirstlane(r.y);
+        const uint32_t olo = __builtin_amdgcn_readfirstlane((uint32_t)r.z), ohi = __builtin_amdgcn_readfirstlane((uint32_t)r.w);
+        fn(ab & 0xffff, ab >> 16, (int64_t)(((uint64_t)ohi << 32) | olo), ls & 0xffff, ls >> 16);
+      }
+    };
+    // every row of the feature in the unprojected stack, the residual's column included, and its four rows of the dropped-rows region: zero
+    auto raw_zero = [&]() {
+      raw_runs([&](int a_lo, int a_hi, int64_t off, int ld, int) {
+        for (int a = a_lo + wv; a < a_hi; a += NW) {
+          double *row = p.raw.H + off + (int64_t)(a - a_lo) * ld;
+          for (int c = lane; c < ld; c += 64) row[c] = 0.0;
+        }
+      });
+      const int ldn = rawld[RAW_NEG] & 0xffff;
+      for (int t = wv; t < 4; t += NW) {
+        double *row = p.raw.H + rawbase[RAW_NEG] + ((int64_t)4 * f + t) * ldn;
+        for (int c = lane; c < ldn; c += 64) row[c] = 0.0;
+      }
+    };
     if (p.status[f] != OVGPU_FEAT_USED) { // failed before the gate: its rows of the stack are zero
-      for (int64_t e = tid; e < (int64_t)n_out * out.ld; e += NTH) out.zero(e);
+      if (raw) raw_zero();
+      else
+        for (int64_t e = tid; e < (int64_t)n_out * out.ld; e += NTH) out.zero(e);
       continue;
     }
     // NT: tile rows that hold rows of Y (swept, factored); NTA: tile rows of the gate matrix with its four augmented rows
@@ -686,7 +786,58 @@ __global__ void __launch_bounds__(64 * NW, OCC)
 #pragma unroll
         for (int w = 0; w < NW; w++) s0 += wpart[(w * 3 + 0) * CB + colb], s1 += wpart[(w * 3 + 1) * CB + colb], s2 += wpart[(w * 3 + 2) * CB + colb];
         const double z0 = T00 * s0, z1 = T01 * s0 + T11 * s1, z2 = T02 * s0 + T12 * s1 + T22 * s2;
-        if (c < D) {
+        if (raw) {
+          // the unprojected stack: EVERY row of Y, into the region of its clone, up to that region's width (right of the row's own block the
+          // block holds zeros; the residual's column is k_feat_vt's).  Columns c < j0 — every row reaches them, and they carry the prior's common
+          // mode — leave PROJECTED, (I - Q1 Q1^T) Y = Y - Q1 cf: with cf[t] = (Q^T Y)[t] = Y[t] - V[t] z (t < 3) and Q1[a][t] = [a == t] - V[a] (T V[t]^T)
+          // a row is Y[a] + V[a] u - [a < 3] cf[a], u = sum_t cf[t] T V[t]^T.  The three rows the projection drops, cf, go to the region whose Gram
+          // matrix is subtracted (rows 4 f .., the fourth: zero) — zero where the columns are stored projected.
+          const int ldn = rawld[RAW_NEG] & 0xffff;
+          if (c_lo < p.raw.j0) { // (wave-uniform: the first column block, as a rule)
+            const bool pj = c < p.raw.j0;
+            double cf0 = 0.0, cf1 = 0.0, cf2 = 0.0, u0 = 0.0, u1 = 0.0, u2 = 0.0;
+            if (c < D) {
+              cf0 = Yb[colb] - (Vl[0] * z0 + Vl[1] * z1 + Vl[2] * z2);
+              cf1 = n > 1 ? Yb[(size_t)LS + colb] - (Vl[3] * z0 + Vl[4] * z1 + Vl[5] * z2) : 0.0;
+              cf2 = n > 2 ? Yb[(size_t)2 * LS + colb] - (Vl[6] * z0 + Vl[7] * z1 + Vl[8] * z2) : 0.0;
+            }
+            if (pj) { // w = sum_t cf[t] V[t]^T, u = T w (T upper triangular)
+              const double w0 = cf0 * Vl[0] + cf1 * Vl[3] + cf2 * Vl[6], w1 = cf0 * Vl[1] + cf1 * Vl[4] + cf2 * Vl[7], w2 = cf0 * Vl[2] + cf1 * Vl[5] + cf2 * Vl[8];
+              u0 = T00 * w0 + T01 * w1 + T02 * w2, u1 = T11 * w1 + T12 * w2, u2 = T22 * w2;
+            }
+            // (run by run: inside a region's run the rows are consecutive, the stride and the column limits scalar — per-ROW tables in LDS made every row
+            //  two dependent LDS round trips and a predicate of its own: 1.5 x the projected stack's store phase)
+            raw_runs([&](int a_lo, int a_hi, int64_t off, int ld, int rc) {
+              if (c < ld && c != rc) {
+                double *dstp = p.raw.H + off + c;
+#pragma unroll 4
+                for (int a = a_lo + HP * wv + hp; a < a_hi; a += HP * NW) {
+                  double v = c < D ? Yb[(size_t)a * LS + colb] : 0.0;
+                  const double vp = fma(Vl[3 * a], u0, fma(Vl[3 * a + 1], u1, fma(Vl[3 * a + 2], u2, v))) - (a == 0 ? cf0 : (a == 1 ? cf1 : (a == 2 ? cf2 : 0.0)));
+                  dstp[(int64_t)(a - a_lo) * ld] = pj ? vp : v;
+                }
+              }
+            });
+            if (HP * wv + hp < 4 && c < ldn && c != D) {
+              const int t = HP * wv + hp; // (rows 0 .. 3 of the region's share of this feature: the first wavefronts' lanes)
+              const double v = (pj || c >= D) ? 0.0 : (t == 0 ? cf0 : (t == 1 ? cf1 : (t == 2 ? cf2 : 0.0)));
+              p.raw.H[rawbase[RAW_NEG] + ((int64_t)4 * f + t) * ldn + c] = v;
+            }
+          } else { // the other column blocks: the rows as they are
+            raw_runs([&](int a_lo, int a_hi, int64_t off, int ld, int rc) {
+              if (c_lo < ld && c < ld && c != rc) { // (a region narrower than this column block: nothing, not even the reads)
+                double *dstp = p.raw.H + off + c;
+#pragma unroll 8
+                for (int a = a_lo + HP * wv + hp; a < a_hi; a += HP * NW) dstp[(int64_t)(a - a_lo) * ld] = c < D ? Yb[(size_t)a * LS + colb] : 0.0;
+              }
+            });
+            if (HP * wv + hp < 4 && c < ldn && c != D) {
+              const int t = HP * wv + hp;
+              const double v = (t < 3 && t < n && c < D) ? Yb[(size_t)t * LS + colb] - (Vl[3 * t] * z0 + Vl[3 * t + 1] * z1 + Vl[3 * t + 2] * z2) : 0.0;
+              p.raw.H[rawbase[RAW_NEG] + ((int64_t)4 * f + t) * ldn + c] = v;
+            }
+          }
+        } else if (c < D) {
 #pragma unroll 8
           for (int a = 3 + HP * wv + hp; a < n; a += HP * NW)
             out.put(a - 3, c, Yb[(size_t)a * LS + colb] - (Vl[3 * a] * z0 + Vl[3 * a + 1] * z1 + Vl[3 * a + 2] * z2));
@@ -757,7 +908,9 @@ __global__ void __launch_bounds__(64 * NW, OCC)
     lds_barrier();
     if (sched[1]) { // rejected: its rows leave the stack — behind a full barrier: other wavefronts' stores to the same addresses must have landed
       __syncthreads();
-      for (int64_t e = tid; e < (int64_t)n_out * out.ld; e += NTH) out.zero(e);
+      if (raw) raw_zero();
+      else
+        for (int64_t e = tid; e < (int64_t)n_out * out.ld; e += NTH) out.zero(e);
     }
     FEAT_T(5)
   }

@@ -63,6 +63,12 @@ template <int W> struct WaveRows {
   static constexpr int R0 = 2 * W, R1 = 2 * W + 1, R2 = 14 - 2 * W, R3 = 15 - 2 * W;
   static constexpr int O0 = 0, O1 = O0 + GR_NT - R0, O2 = O1 + GR_NT - R1, O3 = O2 + GR_NT - R2; // first accumulator of each row
 };
+// The row sets of k_gram_regions: dealt 0/7/8/15, 1/6/9/14, 2/5/10/13, 3/4/11/12 they are level at EVERY even tile-column count (8: 9 tiles each; 10: 15/14/13/13;
+// 12: 21/20/19/18; 14: 27/26/26/26 like the sets above, which idle two wavefronts at 4 columns and one at 6).  Same products per tile: the sums do not change.
+template <int W> struct WaveRowsBal {
+  static constexpr int R0 = W, R1 = 7 - W, R2 = 8 + W, R3 = 15 - W;
+  static constexpr int O0 = 0, O1 = O0 + GR_NT - R0, O2 = O1 + GR_NT - R1, O3 = O2 + GR_NT - R2;
+};
 constexpr int GR_ACC = 34; // tiles per wavefront: 64 - (R0 + R1 + R2 + R3)
 
 #define GRAM_MFMA(a, b, c) c = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0)
@@ -93,8 +99,8 @@ template <int W, int NTC> __device__ __forceinline__ void gram_stage(const doubl
 // partial tiles -> memory: registers (2 h, 2 h + 1) of a lane side by side, two 16-byte stores per tile (a store instruction
 // holds the issuing wavefront for hundreds of cycles whatever its width); slot h * 128 + 2 * lane + e of a tile is register
 // q = 2 h + e of that lane = element (16 ti + 4 q + (lane >> 4), 16 tj + (lane & 15))
-template <int W> __device__ __forceinline__ void gram_put(double *out, int NT, int lane, const d4 (&acc)[GR_ACC]) {
-  using WR = WaveRows<W>;
+template <int W, bool BAL = false> __device__ __forceinline__ void gram_put(double *out, int NT, int lane, const d4 (&acc)[GR_ACC]) {
+  using WR = typename std::conditional<BAL, WaveRowsBal<W>, WaveRows<W>>::type;
   auto put = [&](int ti, int tj, const d4 &a) {
     if (ti < NT && tj < NT) {
       double2 *o = reinterpret_cast<double2 *>(out + (size_t)pair_index(NT, ti, tj) * 256) + lane;
@@ -203,9 +209,9 @@ template <int NTC> __global__ void __launch_bounds__(256) k_gram(GramParams p) {
 // sinks into the common successor — behind all matrix instructions again.  Inside, __builtin_amdgcn_sched_barrier(0) pins the order
 // [products of a tile column] [one staging slot] [products of the next column] ..; without it the scheduler gathers the slots into
 // runs (ISA of the first attempt: 90 address instructions up front, 7 LDS writes in a row behind every k-step).
-template <int W, int NTC> __device__ __forceinline__ void gram_il_loop(const GramParams &p, double *gram_lds, int tid, int lane, int chunk_begin, int chunk_end,
+template <int W, int NTC, bool BAL = false> __device__ __forceinline__ void gram_il_loop(const GramParams &p, double *gram_lds, int tid, int lane, int chunk_begin, int chunk_end,
                                                                      d4 (&acc)[GR_ACC]) {
-  using WR = WaveRows<W>;
+  using WR = typename std::conditional<BAL, WaveRowsBal<W>, WaveRows<W>>::type;
   const int LD = p.LD;
   const int g = lane >> 4, cl = lane & 15;
   constexpr int JLO = WR::R0 < NTC ? WR::R0 : NTC;
@@ -313,6 +319,110 @@ template <int NTC> __global__ void __launch_bounds__(256) k_gram_il(GramParams p
   case 2: gram_il_loop<2, NTC>(p, gram_lds, tid, lane, chunk_begin, chunk_end, acc), gram_put<2>(out, NT, lane, acc); break;
   default: gram_il_loop<3, NTC>(p, gram_lds, tid, lane, chunk_begin, chunk_end, acc), gram_put<3>(out, NT, lane, acc); break;
   }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// k_gram_regions (round 6): the Gram matrix of the UNPROJECTED stack (ovgpu_types.h: RawStack), region by region in one launch.
+//
+//   G = sum_f [Y_f | r_f]^T [Y_f | r_f] - c_f^T c_f        c_f: the three rows of Q_f^T [Y_f | r_f] that nullspace_project_inplace drops
+//
+// equals the Gram matrix of the projected rows (Q_f orthogonal), and the unprojected rows of Y = H L END at their clone's block: at 30 clones the
+// tiles their products touch are 47 % of the dense triangle's.  Rows are stored by the tile column their block ends in — region k: 16 ntc[k]
+// columns, the residual in the last one — so every region runs the dense, fully unrolled k_gram_il<ntc[k]> on rows that are dense for IT; the
+// workgroups are dealt to the regions by work (host, with the batch).  The c_f rows are a region of their own whose partial tiles are SUBTRACTED.
+// (Skipping zero tiles inside one kernel over feature-major rows was tried first and lost to its own branches: profiles/r06_d_*.)
+// ---------------------------------------------------------------------------------------------------
+struct GramRegionWG {
+  int32_t ntc, ld, rcol, neg;   // the region: tile columns, row stride, the residual's column, 1 = its tiles are subtracted
+  int64_t h_off, rows;          // first element and rows of the region
+  int32_t chunk_begin, chunk_end, part_tile, pad; // this workgroup's stages of GR_ROWS rows; its first partial tile
+};
+template <int NTC> __device__ __forceinline__ void gram_region_body(const GramParams &p, double *gram_lds, int tid, int lane, int wave, int cb, int ce) {
+  d4 acc[GR_ACC];
+#pragma unroll
+  for (int i = 0; i < GR_ACC; i++) acc[i] = d4{0, 0, 0, 0};
+  switch (wave) {
+  case 0: gram_il_loop<0, NTC, true>(p, gram_lds, tid, lane, cb, ce, acc), gram_put<0, true>(p.part, NTC, lane, acc); break;
+  case 1: gram_il_loop<1, NTC, true>(p, gram_lds, tid, lane, cb, ce, acc), gram_put<1, true>(p.part, NTC, lane, acc); break;
+  case 2: gram_il_loop<2, NTC, true>(p, gram_lds, tid, lane, cb, ce, acc), gram_put<2, true>(p.part, NTC, lane, acc); break;
+  default: gram_il_loop<3, NTC, true>(p, gram_lds, tid, lane, cb, ce, acc), gram_put<3, true>(p.part, NTC, lane, acc); break;
+  }
+}
+__global__ void __launch_bounds__(256) k_gram_regions(const double *H, const GramRegionWG *tab, double *part) {
+  extern __shared__ double gram_lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const GramRegionWG r = tab[blockIdx.x];
+  for (int i = tid; i < 2 * GR_ROWS * GR_LS; i += 256) gram_lds[i] = 0.0;
+  __syncthreads();
+  GramParams p;
+  p.LD = r.ld, p.NT = r.ntc, p.rows_total = r.rows, p.H = H + r.h_off, p.part = part + (size_t)r.part_tile * 256;
+  switch (r.ntc) {
+  case 4: gram_region_body<4>(p, gram_lds, tid, lane, wave, r.chunk_begin, r.chunk_end); break;
+  case 6: gram_region_body<6>(p, gram_lds, tid, lane, wave, r.chunk_begin, r.chunk_end); break;
+  case 8: gram_region_body<8>(p, gram_lds, tid, lane, wave, r.chunk_begin, r.chunk_end); break;
+  case 10: gram_region_body<10>(p, gram_lds, tid, lane, wave, r.chunk_begin, r.chunk_end); break;
+  case 12: gram_region_body<12>(p, gram_lds, tid, lane, wave, r.chunk_begin, r.chunk_end); break;
+  case 14: gram_region_body<14>(p, gram_lds, tid, lane, wave, r.chunk_begin, r.chunk_end); break;
+  default: gram_region_body<15>(p, gram_lds, tid, lane, wave, r.chunk_begin, r.chunk_end); break;
+  }
+}
+
+// The regions' partial tiles -> G [LG x LG] (what k_gram_reduce leaves): one workgroup per tile pair of the FULL grid (NT tile columns, the
+// residual in column D), every element summed over the regions that hold it — column j < D is column j of every region wide enough, column D is
+// column rcol of every region — region by region, workgroup by workgroup, four running quarters per region added in a fixed order: reproducible.
+struct GramRegionSum {
+  int32_t n;                                              // regions with workgroups
+  int32_t ntc[9], rcol[9], neg[9], part_tile[9], nwg[9];  // part_tile: the region's first workgroup's
+};
+__global__ void __launch_bounds__(1024) k_gram_regions_reduce(int NT, int D, GramRegionSum rs, const double *part, double *G) {
+  __shared__ double tot[4][256];
+  const int LG = 16 * NT;
+  const int idx = blockIdx.x, t = threadIdx.x & 255, grp = threadIdx.x >> 8;
+  int ti = 0, rem = idx;
+  while (rem >= NT - ti) rem -= NT - ti, ti++;
+  const int tj = ti + rem;
+  const int q = 2 * (t >> 7) + (t & 1), lane = (t >> 1) & 63; // slot t = h * 128 + 2 * lane + e holds register q = 2 h + e (gram_put)
+  const int i = 16 * ti + 4 * q + (lane >> 4), j = 16 * tj + (lane & 15);
+  double s = 0.0;
+  for (int k = 0; k < rs.n; k++) {
+    const int rc = rs.rcol[k], ntc = rs.ntc[k];
+    // column / row of the element in the region, -1 = the region does not hold it
+    int li = i == D ? rc : (i < rc && i < D ? i : -1), lj = j == D ? rc : (j < rc && j < D ? j : -1);
+    if (li < 0 || lj < 0) continue;
+    if ((li >> 4) > (lj >> 4)) { // (the residual's ROW against a column of its own tile row: the stored triangle holds the mirror image)
+      const int x = li;
+      li = lj, lj = x;
+    }
+    const int lq = (li & 15) >> 2, llane = 16 * (li & 3) + (lj & 15);
+    const int slot = (lq >> 1) * 128 + 2 * llane + (lq & 1);
+    const int NP = ntc * (ntc + 1) / 2;
+    const double *src = part + ((size_t)rs.part_tile[k] + pair_index(ntc, li >> 4, lj >> 4)) * 256 + slot;
+    const int nw = rs.nwg[k], w_lo = (nw * grp) / 4, w_hi = (nw * (grp + 1)) / 4;
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    int w = w_lo;
+    for (; w + 16 <= w_hi; w += 16) { // (sixteen loads in flight per trip: the partials of a region are memory round trips, nothing else)
+      double a[16];
+#pragma unroll
+      for (int u = 0; u < 16; u++) a[u] = src[(size_t)(w + u) * NP * 256];
+#pragma unroll
+      for (int u = 0; u < 16; u += 4) s0 += a[u], s1 += a[u + 1], s2 += a[u + 2], s3 += a[u + 3];
+    }
+    for (; w + 4 <= w_hi; w += 4) {
+      double a[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) a[u] = src[(size_t)(w + u) * NP * 256];
+      s0 += a[0], s1 += a[1], s2 += a[2], s3 += a[3];
+    }
+    for (; w < w_hi; w++) s0 += src[(size_t)w * NP * 256];
+    const double sk = (s0 + s1) + (s2 + s3);
+    s += rs.neg[k] ? -sk : sk;
+  }
+  tot[grp][t] = s;
+  __syncthreads();
+  if (grp != 0) return;
+  const double v = (tot[0][t] + tot[1][t]) + (tot[2][t] + tot[3][t]);
+  G[(size_t)i * LG + j] = v;
+  if (ti != tj) G[(size_t)j * LG + i] = v;
 }
 
 // ---------------------------------------------------------------------------------------------------

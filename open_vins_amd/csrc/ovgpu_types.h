@@ -38,6 +38,22 @@ struct TriParams {
 // column kinds of the canonical stacked-Jacobian column order
 enum { COL_CLONE = 0, COL_CALIB_POSE = 1, COL_CALIB_INTR = 2, COL_LANDMARK = 3, COL_RESIDUAL = 4 };
 
+// Round 6: the stack of the Gram route as UNPROJECTED whitened rows, in regions by column reach (k_gram.h: k_gram_regions).
+//   G = sum_f [Y_f | r_f]^T [Y_f | r_f] - c_f^T c_f,   c_f = the three rows of Q_f^T [Y_f | r_f] the nullspace projection drops (UpdaterHelper.cpp:449-450)
+// A row of Y = H L ends at its clone's block (L is lower triangular, the clones ascend with the columns): the rows of the clones whose blocks end left
+// of column 16 n - 1 form region (class) k with n = ntc[k] tile columns, row stride ld[k] = 16 n, the residual in column rcol[k] (the last one; in
+// the top class and in the region of the c_f rows, index RAW_NEG, column D).  A measurement's two rows sit at rows dst & RAW_ROW_MASK, + 1 of region dst >> RAW_CLS_SHIFT.
+constexpr int RAW_MAXCLS = 8, RAW_NEG = RAW_MAXCLS, RAW_CLS_SHIFT = 27, RAW_ROW_MASK = (1 << RAW_CLS_SHIFT) - 1;
+struct RawStack {
+  int on = 0;                    // the per-feature kernels write this stack instead of the projected rows
+  int ncls = 0;
+  double *H = nullptr;           // every region
+  int64_t base[RAW_MAXCLS + 1];  // first element of each region
+  int32_t ld[RAW_MAXCLS + 1], rcol[RAW_MAXCLS + 1];
+  const int32_t *dst = nullptr;  // [M] by clone-major position of the measurement inside its feature (k_batch_layout)
+  int j0 = 0;                    // columns < j0 (the first clone's block and everything left of it: columns EVERY row holds) are stored projected, see k_featy.h
+};
+
 struct SysParams {
   int F, C, K, D, LD, N;
   const int32_t *meas_offsets;
@@ -95,6 +111,7 @@ struct SysParams {
                       // Non-null: the rows leave the kernel whitened by the prior, Q^T [H_x L | res] (the Gram route)
   int32_t *work_counter; // k_feat: next feature slot to hand out (zeroed before the launch)
   int skip;              // developer ablation of k_feat_y's phases (ovgpu_debug_option "featy_skip"; results are garbage when non-zero)
+  RawStack raw;          // k_feat_vt / k_feat_y: the unprojected stack of the Gram route
   DevOptions opt;
 };
 

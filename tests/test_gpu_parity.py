@@ -1388,7 +1388,9 @@ def test_track_store_builds_the_same_batch_as_the_host(Updater, oracle):
 
 def test_track_store_feeds_the_update(Updater, oracle):
     """Real tracks go through the store: the update on the device-assembled batch is bit-identical to the update on the
-    uploaded one (same bytes in, same kernels)."""
+    uploaded one (same bytes in, same kernels).  (Round 6: an uploaded batch stacks UNPROJECTED rows in regions laid out from the host's
+    measurement codes, k_gram_regions; a device-assembled batch has no host codes and keeps the projected stack — the bit comparison runs with
+    ovgpu_debug_option raw_stack = 0, the default against it at rounding.)"""
     prob = synth.make_problem(2, F=50)
     # synth lists the camera groups in descending id (the reference's iteration order when camera 0 is inserted first) and the
     # front end below delivers camera 0 before camera 1 in every frame: the store must reproduce synth's batch as it is
@@ -1398,7 +1400,12 @@ def test_track_store_feeds_the_update(Updater, oracle):
     opts = capi.default_options(chi2_multipler=1.0)
     up = Updater(opts)
     up.set_problem(prob)
+    ref_default = up.update()
+    assert up.debug_option("raw_stack", 0) == 1
+    up.set_problem(prob)
     ref = up.update()
+    assert _rel(ref["dx"], ref_default["dx"]) < 1e-10 and _rel(ref["P"], ref_default["P"]) < 1e-11
+    np.testing.assert_array_equal(ref["feat_status"], ref_default["feat_status"])
     up.reset_state()
     up.tracks_create(128, 66)
     clone_times = 50.0 + 0.1 * np.arange(prob.C)

@@ -7,6 +7,8 @@ from open_vins_amd.updater import UpdaterMSCKF
 cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 prob = synth.make_problem(cfg)
 up = UpdaterMSCKF(capi.default_options(chi2_multipler=1.0))
+if len(sys.argv) > 2:
+    up.debug_option("raw_stack", int(sys.argv[2]))  # 0: projected stack, 2: one region (developer experiments)
 up.set_problem(prob)
 lib = up.lib
 lib.ovgpu_debug_cycles.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
