@@ -412,6 +412,12 @@ def main(argv=None):
         # the Gram route executes r D^2 multiply-adds for what SURVEY.md 8(d) counts as 2 r D^2 (Householder-equivalent):
         # its roofline fraction is quoted on the EXECUTED flops, the algorithmic rate beside it
         exec_c = 0.5 * achieved_c if gram else achieved_c
+        # Round 6: with the unprojected stack (k_gram_regions) the products EXECUTED are the regions' own triangles — 512 flop per row and tile —, well under
+        # r D^2: the fraction is quoted on those, the dense and the Householder-equivalent counts beside it
+        stack_raw = bool(gram and not args.gram_fp32 and up.debug_option("last_stack_raw"))
+        exec_flops_c = 512.0 * up.debug_option("raw_gram_tile_rows") if stack_raw else (0.5 * flops_compress if gram else flops_compress)
+        if stack_raw:
+            exec_c = exec_flops_c / (ms_c * 1e-3) / 1e12 if ms_c > 0 else 0.0
         out = {
             "metric": "MSCKF features/sec per EKF update (30-clone state)",
             "value": value,
@@ -455,12 +461,15 @@ def main(argv=None):
                 "avg_ms_per_launch": ms_s,
                 "compression": {
                     "kernel": (("k_gram_f32 (v_mfma_f32_32x32x2_f32 rank-k update from the FP32 whitened stack, csrc/k_gram32.h) + k_gram_f32_reduce (f64), timed together"
-                                if args.gram_fp32 else "k_gram<NT> (v_mfma_f64_16x16x4_f64 rank-k update of the whitened stack) + k_gram_reduce, timed together") if gram else
+                                if args.gram_fp32 else ("k_gram_regions (csrc/k_gram.h: the UNPROJECTED whitened rows in regions by column reach, one dense k_gram_il<n> per region in one launch, "
+                                                        "v_mfma_f64_16x16x4_f64; the dropped rows' region subtracted) + k_gram_regions_reduce, timed together" if stack_raw else
+                                                        "k_gram<NT> (v_mfma_f64_16x16x4_f64 rank-k update of the whitened stack) + k_gram_reduce, timed together")) if gram else
                                "Householder TSQR leaf + merge tree"),
                     "dtype": "f32" if (gram and args.gram_fp32) else "f64",
                     "peak": PEAK_FP32_TFLOPS if (gram and args.gram_fp32) else PEAK_FP64_TFLOPS,
                     "achieved": exec_c, "frac": exec_c / (PEAK_FP32_TFLOPS if (gram and args.gram_fp32) else PEAK_FP64_TFLOPS), "algorithmic_tflops": achieved_c,
-                    "algorithmic_flops_per_launch": flops_compress, "avg_ms_per_launch": ms_c,
+                    "algorithmic_flops_per_launch": flops_compress, "executed_flops_per_launch": exec_flops_c, "avg_ms_per_launch": ms_c,
+                    "dense_gram_tflops": 0.5 * achieved_c if gram else None,
                     "traffic": traffic.get("compression") if (traffic and gram) else None,
                 },
                 "update_ms_device": kt["ms_update"],
