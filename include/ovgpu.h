@@ -873,6 +873,15 @@ int ovgpu_last_update_route(ovgpu_ctx *ctx);
  *   "stage_timing_period"     n >= 1: the six stage events (ovgpu_update_stats::ms_*, ovgpu_kernel_times) go into every n-th update
  *                             only (each is a marker packet the next kernel waits for, ~5 us); updates without events report 0
  *   "stack_is_f32"            (read only) the last pipeline stored the stack as floats and ran k_gram_f32 (options.gram_fp32)
+ *   "raw_stack"               (round 6, default 1) the Gram route of ovgpu_msckf_update stacks the UNPROJECTED whitened rows in regions by column reach and
+ *                             subtracts the Gram matrix of the rows the nullspace projection drops (k_gram.h: k_gram_regions) — same H^T H, H^T r to rounding;
+ *                             0: the projected rows of rounds 2-5; takes effect with the next ovgpu_set_state / ovgpu_set_features.  Mode A
+ *                             (ovgpu_msckf_compress), the fp32 variant, the Householder route and batches assembled by ovgpu_tracks_to_features
+ *                             always stack projected rows.  ("raw_work_const": the region work model's constant; 2: one region, developer experiments)
+ *   "last_stack_raw"          (read only) the last pipeline's Gram matrix came from the unprojected stack
+ *   "raw_gram_tile_rows"      (read only) rows x tiles summed over the regions of the resident batch: the 16 x 16 products per row k_gram_regions executes
+ *   "speculative_prior"       (round 6, default 1) ovgpu_set_features starts the prior block's factorisation on the second stream, next to its own
+ *                             uploads; the update joins it.  0: the factorisation starts with the update (round 5)
  *   "featy_big"               1 / 2: the block-row form of the per-feature kernel (k_featy_big.h) on batches the one-pass kernel holds
  *   "gram_interleaved"        0: k_gram instead of k_gram_il (staging not interleaved with the matrix instructions)
  *   "gram_blocks_only"        1: always the 8 x 8-tile block form of the Gram kernel (k_gram_blk)

@@ -614,13 +614,14 @@ __global__ void __launch_bounds__(64 * NW, OCC)
       lds_barrier();
     }
     // the feature's runs of rows: fn(first row, one past the last, first element, stride, residual column), all in scalar registers
+    // (lane j fetches run j: ONE LDS round trip per call, the runs then come out of the lanes by v_readlane — a read per run was a round trip per run)
     auto raw_runs = [&](auto fn) {
       const int nr = __builtin_amdgcn_readfirstlane(*nruns);
+      const i32x4 rr = runs[lane & (RAW_MAXCLS - 1)];
 #pragma unroll 1
       for (int j = 0; j < nr; j++) {
-        const i32x4 r = runs[j];
-        const int ab = __builtin_amdgcn_readfirstlane(r.x), ls = __builtin_amdgcn_readfirstlane(r.y);
-        const uint32_t olo = __builtin_amdgcn_readfirstlane((uint32_t)r.z), ohi = __builtin_amdgcn_readfirstlane((uint32_t)r.w);
+        const int ab = __builtin_amdgcn_readlane(rr.x, j), ls = __builtin_amdgcn_readlane(rr.y, j);
+        const uint32_t olo = (uint32_t)__builtin_amdgcn_readlane(rr.z, j), ohi = (uint32_t)__builtin_amdgcn_readlane(rr.w, j);
         fn(ab & 0xffff, ab >> 16, (int64_t)(((uint64_t)ohi << 32) | olo), ls & 0xffff, ls >> 16);
       }
     };
@@ -779,6 +780,7 @@ __global__ void __launch_bounds__(64 * NW, OCC)
         if (hp == 0) wpart[(wv * 3 + 0) * CB + colb] = w0, wpart[(wv * 3 + 1) * CB + colb] = w1, wpart[(wv * 3 + 2) * CB + colb] = w2;
       }
       lds_barrier();
+      FEAT_T(6)
       // ---- rows 3.. of Q^T Y = Y - V z -> the stack
       if (!(FY_SKIP(p) & 2)) {
         const int c = c_lo + colb;
@@ -812,7 +814,7 @@ __global__ void __launch_bounds__(64 * NW, OCC)
                 double *dstp = p.raw.H + off + c;
 #pragma unroll 4
                 for (int a = a_lo + HP * wv + hp; a < a_hi; a += HP * NW) {
-                  double v = c < D ? Yb[(size_t)a * LS + colb] : 0.0;
+                  const double v = Yb[(size_t)a * LS + colb];
                   const double vp = fma(Vl[3 * a], u0, fma(Vl[3 * a + 1], u1, fma(Vl[3 * a + 2], u2, v))) - (a == 0 ? cf0 : (a == 1 ? cf1 : (a == 2 ? cf2 : 0.0)));
                   dstp[(int64_t)(a - a_lo) * ld] = pj ? vp : v;
                 }
@@ -828,7 +830,7 @@ __global__ void __launch_bounds__(64 * NW, OCC)
               if (c_lo < ld && c < ld && c != rc) { // (a region narrower than this column block: nothing, not even the reads)
                 double *dstp = p.raw.H + off + c;
 #pragma unroll 8
-                for (int a = a_lo + HP * wv + hp; a < a_hi; a += HP * NW) dstp[(int64_t)(a - a_lo) * ld] = c < D ? Yb[(size_t)a * LS + colb] : 0.0;
+                for (int a = a_lo + HP * wv + hp; a < a_hi; a += HP * NW) dstp[(int64_t)(a - a_lo) * ld] = Yb[(size_t)a * LS + colb]; // (columns >= D of the block hold zeros: the sweep masks them)
               }
             });
             if (HP * wv + hp < 4 && c < ldn && c != D) {

@@ -22,8 +22,8 @@ for _ in range(reps):
 up.synchronize()
 buf = (C.c_longlong * 512)()
 lib.ovgpu_debug_cycles(up._ctx, 1, buf)
-a = np.array(buf[220:226], dtype=np.float64) / reps
-names = ["prologue", "sweep", "VtY+project+store", "SYRK", "S0 setup", "Cholesky+verdict"]
+a = np.array(buf[220:227], dtype=np.float64) / reps
+names = ["prologue", "sweep", "store (V^T Y is the last line)", "SYRK", "S0 setup", "Cholesky+verdict", "V^T Y partial sums + barrier"]
 tot = a.sum()
 kt = up.kernel_times(reset=True)
 print("workgroup 0 of k_feat_y, cycles per update (100 MHz clock64 ticks?):")
