@@ -24,10 +24,8 @@ template <int NB> static void run_old(int D, int LD, int LG, const double *G, do
   if (!done) (void)hipFuncSetAttribute((const void *)k_gram_pchol<NB>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024), done = true;
   hipLaunchKernelGGL(k_gram_pchol<NB>, dim3(1), dim3(1024), chol_lds_bytes(LD), 0, D, LD, LG, G, out, dr, tol);
 }
-template <int TPW, int NQ> static void run_new(int D, int LD, int LG, const double *G, double *out, int32_t *dr, double tol) {
-  static bool done = false;
-  if (!done) (void)hipFuncSetAttribute((const void *)k_gram_pchol_blk<TPW, NQ>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024), done = true;
-  hipLaunchKernelGGL((k_gram_pchol_blk<TPW, NQ>), dim3(1), dim3(1024), pchol_blk_lds_bytes(LD), 0, D, LD, LG, G, out, dr, tol);
+template <int NW, int SL, int NQ> static void run_new(int D, int LD, int LG, const double *G, double *out, int32_t *dr, double tol) {
+  hipLaunchKernelGGL((k_gram_pchol_blk<NW, SL, NQ>), dim3(1), dim3(64 * (NW + 1)), 0, 0, D, LD, LG, G, out, dr, tol);
 }
 static void launch_old(int D, int LD, int LG, const double *G, double *out, int32_t *dr, double tol) {
   switch ((LD + 31) / 32) {
@@ -45,10 +43,8 @@ static void launch_old(int D, int LD, int LG, const double *G, double *out, int3
 }
 static bool launch_new(int D, int LD, int LG, const double *G, double *out, int32_t *dr, double tol) {
   const int NT = (LD + 15) / 16;
-  if (NT <= 8) run_new<3, 2>(D, LD, LG, G, out, dr, tol);
-  else if (NT <= 14) run_new<7, 4>(D, LD, LG, G, out, dr, tol);
-  else if (NT <= 16) run_new<10, 4>(D, LD, LG, G, out, dr, tol);
-  else if (NT <= 19) run_new<13, 5>(D, LD, LG, G, out, dr, tol);
+  if (NT <= 8) run_new<4, 9, 2>(D, LD, LG, G, out, dr, tol);
+  else if (NT <= 14) run_new<7, 15, 4>(D, LD, LG, G, out, dr, tol);
   else return false;
   return true;
 }
@@ -85,10 +81,22 @@ int main(int argc, char **argv) {
     CK(hipDeviceSynchronize());
     if (!launch_new(D, LD, LG, dG, dN, dd + 1, tol)) {
       printf("D %d: no blocked instantiation\n", D);
+      CK(hipFree(dG));
+      CK(hipFree(dO));
+      CK(hipFree(dN));
+      CK(hipFree(dd));
       continue;
     }
     CK(hipGetLastError());
     CK(hipDeviceSynchronize());
+#ifdef OVG_PCHOL_PROF
+    {
+      long long pr[16];
+      CK(hipMemcpyFromSymbol(pr, HIP_SYMBOL(g_pchol_prof), sizeof(pr)));
+      printf("  cycles per step (x 100 MHz counter ticks -> shader cycles ~ x 24): pivot wavefront: to A %.0f | A -> own work done %.0f | wait B %.0f | B -> end %.0f   tile wavefront 1: wait A %.0f | publish %.0f | wait B %.0f | after B %.0f\n",
+             (double)pr[0] / D, (double)pr[1] / D, (double)pr[2] / D, (double)pr[3] / D, (double)pr[8] / D, (double)pr[9] / D, (double)pr[10] / D, (double)pr[11] / D);
+    }
+#endif
     std::vector<double> Ro((size_t)D * LD), Rn((size_t)D * LD);
     int32_t dr[2];
     CK(hipMemcpy(Ro.data(), dO, sizeof(double) * D * LD, hipMemcpyDeviceToHost));
