@@ -27,6 +27,7 @@
 #include "k_featy_big.h"
 #include "k_gram.h"
 #include "k_pchol.h"
+#include "k_unwhiten.h"
 #include "k_gram32.h"
 #include <unordered_map>
 #include <unordered_set>
