@@ -403,6 +403,42 @@ def test_mode_a_pivoted_factor_shapes(Updater, oracle, cfg, F, track):
     up.close()
 
 
+@pytest.mark.parametrize("cfg,F,track", [(1, 12, "ragged"), (2, 40, "full"), (3, 600, "full"), (4, 300, "full")])
+def test_mode_a_blocked_kernels_equal_the_kernels_they_replace(Updater, cfg, F, track):
+    """Round 6's blocked kernels of mode A — k_gram_pchol_blk (k_pchol.h: the pivoted factor with the matrix as MFMA tiles and the panel's
+    rank-4 update in instalments) and k_unwhiten_blk (k_unwhiten.h: X = R L^-1 right-looking, the diagonal tiles' inverses from the prior's
+    factorisation) — against the rank-one factor and the substitution kernel of rounds 3-5 (ovgpu_debug_option pchol_blocked / unwhiten_blocked
+    = 0): the same pivots, the same rank, the compressed system equal at rounding (the products are summed in a different order)."""
+    prob = synth.make_problem(cfg, F=F, track=track)
+    opts = capi.default_options(chi2_multipler=1.0)
+    got = {}
+    for name, flags in (("blocked", (1, 1)), ("factor rank-one", (0, 1)), ("substitution", (1, 0)), ("rounds 3-5", (0, 0))):
+        up = Updater(opts)
+        assert up.debug_option("pchol_blocked") == 1 and up.debug_option("unwhiten_blocked") == 1  # the defaults
+        up.debug_option("pchol_blocked", flags[0])
+        up.debug_option("unwhiten_blocked", flags[1])
+        up.set_problem(prob)
+        cmp = up.compress()
+        assert up.lib.ovgpu_last_update_route(up._ctx) == capi.COMPRESS_PCHOLQR
+        got[name] = cmp
+        up.close()
+    ref = got["rounds 3-5"]
+    G0, g0 = ref["H"].T @ ref["H"], ref["H"].T @ ref["r"]
+    for name in ("blocked", "factor rank-one", "substitution"):
+        c = got[name]
+        assert np.array_equal(c["feat_status"], ref["feat_status"])
+        # (a pivot at the stop rule's threshold — rounding noise of the Gram sum — may fall on either side: a row of ~1e-8 of the others' size)
+        assert abs(c["rows"] - ref["rows"]) <= 1
+        G, g = c["H"].T @ c["H"], c["H"].T @ c["r"]
+        eG, eg = np.linalg.norm(G - G0) / np.linalg.norm(G0), np.linalg.norm(g - g0) / np.linalg.norm(g0)
+        same = c["rows"] == ref["rows"]
+        eH = np.abs(c["H"] - ref["H"]).max() / np.abs(ref["H"]).max() if same else float("nan")
+        print(f"cfg {cfg} F {F}: {name} vs rounds 3-5: rank {c['rows']} / {ref['rows']}, |dH| / max|H| = {eH:.1e}, |d H^T H| = {eG:.1e}, |d H^T r| = {eg:.1e}")
+        assert eG < 1e-12 and eg < 1e-11
+        if same:
+            assert eH < 1e-7
+
+
 def test_compress_leaves_the_triangulation_readable(Updater, oracle):
     """Mode A of the shim: ONE triangulation — ovgpu_msckf_compress runs it, ovgpu_get_triangulation reads back what the Feature
     objects need (anchor, p_FinA, p_FinG); the values are those of a stand-alone ovgpu_triangulate on the same batch, bit for bit."""
