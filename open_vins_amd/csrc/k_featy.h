@@ -224,26 +224,38 @@ __global__ void __launch_bounds__(256) k_feat_vt(SysParams p, FeatStore st, doub
 __host__ __device__ inline int batch_layout_m_pad(int m_max) { return (m_max + 15) & ~15; } // (the kernel's m_max argument: keys padded to whole 16-int reads)
 __host__ __device__ inline size_t batch_layout_lds_ints(int m_pad) { return (size_t)4 * m_pad + (size_t)((2 * m_pad + 15) >> 4) * 48; }
 constexpr int BL_NTH = 128, BL_TR = BL_NTH / 24; // threads per feature; tile rows per pass of the candidate phase
-__global__ void __launch_bounds__(BL_NTH) k_batch_layout(int F, int m_max, int D, const int32_t *__restrict__ meas_offsets, const uint16_t *__restrict__ meas_cc,
+// Round 6 (late): EIGHT features per workgroup (1024 threads, a group of BL_NTH threads per feature, the column tables loaded once for all of
+// them).  Not for this kernel's sake: 2000 two-wavefront workgroups land on every compute unit at once, and the prior block's factorisation —
+// dispatched on the second stream a few microseconds later, sixteen wavefronts of 128 registers that need a compute unit to THEMSELVES — sat
+// in the queue until this kernel had drained (its kernel 97 us instead of ~80, the per-feature kernel 20 us behind the reflectors).  250
+// workgroups leave six compute units untouched, as k_triangulate's workgroups of eight features do since round 5.
+constexpr int BL_FPW = 8;
+__global__ void __launch_bounds__(BL_NTH * BL_FPW) k_batch_layout(int F, int m_max, int D, const int32_t *__restrict__ meas_offsets, const uint16_t *__restrict__ meas_cc,
                                                       const int32_t *__restrict__ clone_col, const int32_t *__restrict__ calib_col, const int32_t *__restrict__ intr_col,
                                                       int32_t *__restrict__ anchor_pre, int32_t *__restrict__ meas_feat, int32_t *__restrict__ pos, int32_t *__restrict__ inst,
                                                       int nt_max, int cb, int C, int K, const uint8_t *__restrict__ cls_of_clone, const int32_t *__restrict__ featbase,
                                                       int32_t *__restrict__ raw_dst) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int f = blockIdx.x;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
+  // a group of min(blockDim.x, BL_NTH) threads per feature (the anchors-only launch: one wavefront, one feature per workgroup)
+  const int gth = min((int)blockDim.x, BL_NTH), grp = threadIdx.x / gth;
+  const int tid = threadIdx.x - grp * gth, lane = tid & 63, wv = tid >> 6;
+  const int f = blockIdx.x * ((int)blockDim.x / gth) + grp;
+  const bool active = f < F;
+  unsigned char *smem = smem_all + (size_t)grp * batch_layout_lds_ints(m_max) * sizeof(int32_t);
   // the column tables (a few dozen ints) go to LDS while the feature's offsets are on their way: the keys below then cost ONE global round trip
   // (the packed codes), not two — this kernel is a chain of memory latencies, nothing else
   __shared__ int tab_clone[1024], tab_calib[64], tab_intr[64];
   __shared__ uint8_t tab_cls[1024];
+  __shared__ int grp_nt[BL_FPW];
   if (pos) {
-    for (int i = tid; i < C; i += BL_NTH) tab_clone[i] = clone_col[i];
+    for (int i = threadIdx.x; i < C; i += blockDim.x) tab_clone[i] = clone_col[i];
     if (raw_dst)
-      for (int i = tid; i < C; i += BL_NTH) tab_cls[i] = cls_of_clone[i];
-    if (tid < K) tab_calib[tid] = calib_col[tid], tab_intr[tid] = intr_col[tid];
+      for (int i = threadIdx.x; i < C; i += blockDim.x) tab_cls[i] = cls_of_clone[i];
+    if (threadIdx.x < K) tab_calib[threadIdx.x] = calib_col[threadIdx.x], tab_intr[threadIdx.x] = intr_col[threadIdx.x];
   }
-  const int m0 = meas_offsets[f], m = meas_offsets[f + 1] - m0;
-  if (anchor_pre && wv == (blockDim.x >> 6) - 1) { // the LAST wavefront: the keys of a track of up to 64 observations are the first one's work
+  const int m0 = active ? meas_offsets[f] : 0, m = active ? meas_offsets[f + 1] - m0 : 0;
+  if (pos && tid == 0) grp_nt[grp] = (2 * m + 15) >> 4;
+  if (anchor_pre && active && wv == (gth >> 6) - 1) { // the group's LAST wavefront: the keys of a track of up to 64 observations are the first one's work
     long long best = -1; // (run length << 32) | (2^31 - 1 - run start): the longest run, the earliest of equals
     int best_end = -1, carry_start = 0;
     for (int base = 0; base < m; base += 64) {
@@ -315,7 +327,9 @@ __global__ void __launch_bounds__(BL_NTH) k_batch_layout(int F, int m_max, int D
   if (!inst) return;
   __syncthreads();
   const int nblk = (D + cb - 1) / cb;
-  for (int t0 = 0; t0 < NT; t0 += BL_TR) { // (uniform trip count: the barriers below are met by every thread)
+  int nt_wg = 0; // (uniform trip count: the barriers below are met by every thread of every group)
+  for (int q = 0; q < (int)blockDim.x / gth; q++) nt_wg = max(nt_wg, grp_nt[q]);
+  for (int t0 = 0; t0 < nt_wg; t0 += BL_TR) {
     const int g = tid / 24, jk = tid - 24 * g, tr = t0 + g;       // candidate jk = 3 * (measurement of the tile row) + kind
     const bool live = g < BL_TR && tr < NT;
     const int i = 8 * tr + jk / 3, kind = jk - 3 * (jk / 3);
