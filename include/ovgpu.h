@@ -882,6 +882,12 @@ int ovgpu_last_update_route(ovgpu_ctx *ctx);
  *   "raw_gram_tile_rows"      (read only) rows x tiles summed over the regions of the resident batch: the 16 x 16 products per row k_gram_regions executes
  *   "speculative_prior"       (round 6, default 1) ovgpu_set_features starts the prior block's factorisation on the second stream, next to its own
  *                             uploads; the update joins it.  0: the factorisation starts with the update (round 5)
+ *   "pchol_blocked"           (round 6, default 1) mode A's pivoted Gram factor by the blocked kernel (k_pchol.h, up to 223 Jacobian columns); 0: the
+ *                             rank-one kernel of rounds 3-5 everywhere.  Same pivots, same factor at rounding
+ *   "unwhiten_blocked"        (round 6, default 1) mode A's X = R L^-1 right-looking with the diagonal tiles' inverses of the prior's factorisation
+ *                             (k_unwhiten.h); 0: one wavefront per 16 rows, substitution inside the tiles (rounds 3-5)
+ *   "layout_fpw"              (round 6, default 8) features per workgroup of the batch-layout kernel at most (1 .. 8): the launch is kept at 250
+ *                             workgroups or fewer where that allows, so that the prior's factorisation finds free compute units
  *   "featy_big"               1 / 2: the block-row form of the per-feature kernel (k_featy_big.h) on batches the one-pass kernel holds
  *   "gram_interleaved"        0: k_gram instead of k_gram_il (staging not interleaved with the matrix instructions)
  *   "gram_blocks_only"        1: always the 8 x 8-tile block form of the Gram kernel (k_gram_blk)
