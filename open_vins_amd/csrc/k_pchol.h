@@ -8,25 +8,29 @@
 // How: k_gram_pchol applies every pivot's rank-one update to the whole matrix at once — 1024 threads, two workgroup barriers around
 // ~130 KB of LDS reads per column, 1.15 us per column, 239 us at 208 columns.  Here the upper block triangle sits in the registers of
 // NW TILE wavefronts as 16 x 16 tiles in the accumulator layout of v_mfma_f64_16x16x4_f64 — wavefront w holds tile rows a = w - 1 (from
-// slot 0 up) and b = NT - 1 - a (from the last slot down): NT + 1 tiles each — and is touched once per FOUR pivots by one matrix instruction
-// per tile; the pivot-by-pivot work is one wavefront's (the PIVOT wavefront), alone with one other on its SIMD:
+// slot 0 up) and b = NT - 1 - a (from the last slot down): NT + 1 tiles each — and every tile is touched once per FOUR pivots by one matrix
+// instruction; the pivot-by-pivot work is one wavefront's (the PIVOT wavefront), alone with one other on its SIMD:
 //
 //   pivot wavefront, step k                                   tile wavefronts
 //   announce the pivot column p (chosen at the end of k - 1)
 //   ---------------------------------------------- barrier A ----------------------------------------------
 //   c = sum over the rows m of R the tiles do not hold yet    row p of THEIR matrix -> LDS: the owner of tile row p >> 4 its row pieces
-//       of R[m][p] R[m][:]  (at most four), 1 / sqrt(d)       (one store per tile, immediate offsets), every owner of a row above it the
+//       of R[m][p] R[m][:]  (at most seven), 1 / sqrt(d)      (one store per tile, immediate offsets), every owner of a row above it the
 //                                                             one column piece (the matrix is symmetric) — a branch tree to the tile's registers
 //   ---------------------------------------------- barrier B ----------------------------------------------
-//   R[k][:] = (row - c) / sqrt(d) on the live columns,        k % 4 == 0: the four rows of the panel before this one -> memory, and they
-//   diagonal copy -= R[k][:]^2, next pivot = its maximum       leave the registers' debt: tile -= R_panel(:, i)^T R_panel(:, j), 1 MFMA / tile
-//   (DPP network, as k_gram_pchol), row k -> the panel in LDS
+//   R[k][:] = (row - c) / sqrt(d) on the live columns,        instalment k % 4 of the panel BEFORE this one: tile -= R_panel(:, i)^T R_panel(:, j),
+//   diagonal copy -= R[k][:]^2, next pivot = its maximum       one matrix instruction per tile, the tiles at a quarter of the distances from the
+//   (DPP network, as k_gram_pchol), row k -> the panel in LDS  diagonal (pb_db); k % 4 == 0 also: that panel's four finished rows -> memory
 //
-// The tiles run a panel behind only at k % 4 == 0 (four correction terms), otherwise they hold everything but the current panel's rows
-// (k % 4 terms).  Everything the pivot wavefront needs for c is known BEFORE the row arrives, so the correction, the reciprocal square
-// root and the tile wavefronts' answer overlap.  The pivot's value d and every later decision come from the pivot wavefront's own copy
-// of the diagonal (updated with the rows it wrote: the quantity LAPACK's dpstrf keeps in its `dots`); a column is live while its entry
-// there is not DEAD, the carried column (Y^T r) holds a value no update moves.
+// The rank-4 update of a panel is spread over the four pivot steps of the NEXT panel (a quarter of the triangle each, so the products — 64 cycles
+// apiece, the f64 matrix rate is the vector rate — hide behind the pivot wavefront's own work instead of holding up barrier A once per four steps).
+// The correction therefore covers this panel's first k % 4 rows for every column, and the previous panel's four rows for the columns whose tile of
+// row p has not had its instalment yet (distance of the tile from the diagonal >= pb_db(k % 4): one comparison per column).  The pivot wavefront
+// keeps its last eight rows of R in registers (the step loop unrolled by eight), so the correction costs it seven broadcast reads of R[m][p] and no
+// other memory access; everything it needs is known BEFORE the row arrives: correction, reciprocal square root and the tile wavefronts' answer
+// overlap.  The pivot's value d and every later decision come from the pivot wavefront's own copy of the diagonal (updated with the rows it wrote:
+// the quantity LAPACK's dpstrf keeps in its `dots`); a column is live while its entry there is not DEAD, the carried column (Y^T r) holds a value
+// no update moves.
 //
 // Why eight (nine) wavefronts and not sixteen: four wavefronts of a 1024-thread workgroup share one SIMD's issue port, and the first form of this
 // kernel (15 tile wavefronts, tiles dealt round-robin, every wavefront testing each of its tiles against p) spent 1.7 kcycles per pivot
