@@ -403,13 +403,15 @@ def test_mode_a_pivoted_factor_shapes(Updater, oracle, cfg, F, track):
     up.close()
 
 
-@pytest.mark.parametrize("cfg,F,track", [(1, 12, "ragged"), (2, 40, "full"), (3, 600, "full"), (4, 300, "full")])
-def test_mode_a_blocked_kernels_equal_the_kernels_they_replace(Updater, cfg, F, track):
+@pytest.mark.parametrize("cfg,F,track,C", [(1, 12, "ragged", None), (2, 40, "full", None), (3, 600, "full", None), (4, 300, "full", None),
+                                           (2, 60, "full", 12), (2, 60, "ragged", 17), (2, 80, "full", 21), (2, 80, "ragged", 26), (2, 100, "full", 29)])
+def test_mode_a_blocked_kernels_equal_the_kernels_they_replace(Updater, cfg, F, track, C):
     """Round 6's blocked kernels of mode A — k_gram_pchol_blk (k_pchol.h: the pivoted factor with the matrix as MFMA tiles and the panel's
     rank-4 update in instalments) and k_unwhiten_blk (k_unwhiten.h: X = R L^-1 right-looking, the diagonal tiles' inverses from the prior's
     factorisation) — against the rank-one factor and the substitution kernel of rounds 3-5 (ovgpu_debug_option pchol_blocked / unwhiten_blocked
-    = 0): the same pivots, the same rank, the compressed system equal at rounding (the products are summed in a different order)."""
-    prob = synth.make_problem(cfg, F=F, track=track)
+    = 0): the same pivots, the same rank, the compressed system equal at rounding (the products are summed in a different order).
+    C: windows of 12 .. 29 clones, i.e. 100 .. 202 Jacobian columns = 7 .. 13 tile columns, most of them with a partial last tile."""
+    prob = synth.make_problem(cfg, F=F, track=track, C=C)
     opts = capi.default_options(chi2_multipler=1.0)
     got = {}
     for name, flags in (("blocked", (1, 1)), ("factor rank-one", (0, 1)), ("substitution", (1, 0)), ("rounds 3-5", (0, 0))):
@@ -433,7 +435,7 @@ def test_mode_a_blocked_kernels_equal_the_kernels_they_replace(Updater, cfg, F, 
         eG, eg = np.linalg.norm(G - G0) / np.linalg.norm(G0), np.linalg.norm(g - g0) / np.linalg.norm(g0)
         same = c["rows"] == ref["rows"]
         eH = np.abs(c["H"] - ref["H"]).max() / np.abs(ref["H"]).max() if same else float("nan")
-        print(f"cfg {cfg} F {F}: {name} vs rounds 3-5: rank {c['rows']} / {ref['rows']}, |dH| / max|H| = {eH:.1e}, |d H^T H| = {eG:.1e}, |d H^T r| = {eg:.1e}")
+        print(f"cfg {cfg} F {F} C {C} D {c['H'].shape[1]}: {name} vs rounds 3-5: rank {c['rows']} / {ref['rows']}, |dH| / max|H| = {eH:.1e}, |d H^T H| = {eG:.1e}, |d H^T r| = {eg:.1e}")
         assert eG < 1e-12 and eg < 1e-11
         if same:
             assert eH < 1e-7
